@@ -1,0 +1,274 @@
+"""ctypes/numpy loader for the CPU ORACLE (oracle/qrk_oracle.c).
+
+TEST INFRASTRUCTURE ONLY.  Importable from tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg; the product package (qrkit_amd/) never imports it.
+Parity status: floating-point values are "parity unpinned" by the reference (no
+golden numbers there; Eigen absent) -- see oracle/qrk_oracle.h.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from dataclasses import dataclass
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libqrk_oracle.so")
+
+SUCCESS, NUMERICAL_ISSUE, NO_CONVERGENCE, INVALID_INPUT = 0, 1, 2, 3
+FULL_Q, BLOCK_DIAGONAL_Q = 0, 1
+COLPIV, NOPIV = 0, 1
+
+
+def build(force: bool = False) -> str:
+    """Compile the oracle with gcc (no-op when up to date)."""
+    src = os.path.join(_HERE, "qrk_oracle.c")
+    hdr = os.path.join(_HERE, "qrk_oracle.h")
+    stale = (not os.path.exists(_LIB_PATH)) or any(
+        os.path.getmtime(p) > os.path.getmtime(_LIB_PATH) for p in (src, hdr))
+    if force or stale:
+        subprocess.check_call(["make", "-C", _HERE, "-s", "-B"])
+    return _LIB_PATH
+
+
+class _Desc(C.Structure):
+    _fields_ = [("B", C.c_int64), ("rows", C.POINTER(C.c_int32)), ("cols", C.POINTER(C.c_int32)),
+                ("tile_off", C.POINTER(C.c_int64)), ("matRows", C.c_int32), ("matCols", C.c_int32),
+                ("q_format", C.c_int), ("block_solver", C.c_int)]
+
+
+class _BlockInfo(C.Structure):
+    _fields_ = [("idxRow", C.c_int32), ("idxCol", C.c_int32), ("numRows", C.c_int32), ("numCols", C.c_int32)]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_LIB_PATH)
+        dp, ip, lp = C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_int64)
+        _lib.orc_colpiv_qr.restype = C.c_int
+        _lib.orc_colpiv_qr.argtypes = [dp, C.c_int, C.c_int, C.c_int, dp, ip, ip, dp]
+        _lib.orc_householder_qr.restype = None
+        _lib.orc_householder_qr.argtypes = [dp, C.c_int, C.c_int, C.c_int, dp]
+        _lib.orc_form_q.restype = None
+        _lib.orc_form_q.argtypes = [dp, C.c_int, C.c_int, C.c_int, dp, dp, C.c_int]
+        _lib.orc_block_triangular_factor.restype = None
+        _lib.orc_block_triangular_factor.argtypes = [dp, C.c_int, dp, C.c_int, C.c_int, C.c_int, dp]
+        bi = C.POINTER(_BlockInfo)
+        _lib.orc_from_block_diagonal_pattern.restype = C.c_int
+        _lib.orc_from_block_diagonal_pattern.argtypes = [C.c_int32] * 4 + [bi, C.c_int]
+        _lib.orc_merge_blocks.restype = C.c_int
+        _lib.orc_merge_blocks.argtypes = [bi, C.c_int, C.c_int, C.c_int, bi, C.c_int]
+        _lib.orc_from_block_banded_pattern.restype = C.c_int
+        _lib.orc_from_block_banded_pattern.argtypes = [C.c_int32] * 5 + [C.c_int, bi, C.c_int]
+        _lib.orc_block_info_from_csr.restype = C.c_int
+        _lib.orc_block_info_from_csr.argtypes = [C.c_int32, C.c_int32, ip, ip, C.c_int, bi, C.c_int]
+        _lib.orc_as_banded_as_possible.restype = C.c_int
+        _lib.orc_as_banded_as_possible.argtypes = [C.c_int32, C.c_int32, ip, ip, ip]
+        pd = C.POINTER(_Desc)
+        _lib.orc_bd_sizes.restype = None
+        _lib.orc_bd_sizes.argtypes = [pd, lp, lp]
+        _lib.orc_bd_pattern.restype = None
+        _lib.orc_bd_pattern.argtypes = [pd, ip, ip, ip, ip]
+        _lib.orc_bd_factorize.restype = C.c_int
+        _lib.orc_bd_factorize.argtypes = [pd, dp, dp, dp, ip, dp, lp]
+        _lib.orc_bd_factorize_faithful.restype = C.c_int
+        _lib.orc_bd_factorize_faithful.argtypes = [pd, dp, dp, dp, ip, lp]
+        _lib.orc_bd_solve.restype = C.c_int
+        _lib.orc_bd_solve.argtypes = [pd, dp, dp, ip, dp, C.c_int64, dp]
+        _lib.orc_gen_reference_7x2.restype = None
+        _lib.orc_gen_reference_7x2.argtypes = [C.c_int, dp]
+        _lib.orc_gen_uniform.restype = None
+        _lib.orc_gen_uniform.argtypes = [C.c_uint32, C.c_double, C.c_double, C.c_int64, dp]
+    return _lib
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _ip(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int32))
+
+
+def _lp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int64))
+
+
+# ---------------------------------------------------------------- dense kernels
+
+def colpiv_qr(A: np.ndarray):
+    """Eigen ColPivHouseholderQR on one m x n matrix.  Returns (packedQR, hcoeffs, perm, nonzero_pivots)."""
+    m, n = A.shape
+    qr = np.asfortranarray(A, dtype=np.float64).copy(order="F")
+    k = min(m, n)
+    hc = np.zeros(k)
+    tr = np.zeros(max(k, 1), dtype=np.int32)
+    perm = np.zeros(max(n, 1), dtype=np.int32)
+    mp = C.c_double(0.0)
+    nz = lib().orc_colpiv_qr(_dp(qr), m, n, m, _dp(hc), _ip(tr), _ip(perm), C.byref(mp))
+    return qr, hc, perm[:n], nz
+
+
+def householder_qr(A: np.ndarray):
+    m, n = A.shape
+    qr = np.asfortranarray(A, dtype=np.float64).copy(order="F")
+    hc = np.zeros(min(m, n))
+    lib().orc_householder_qr(_dp(qr), m, n, m, _dp(hc))
+    return qr, hc
+
+
+def form_q(qr: np.ndarray, hc: np.ndarray) -> np.ndarray:
+    m = qr.shape[0]
+    qrf = np.asfortranarray(qr)
+    Q = np.zeros((m, m), order="F")
+    lib().orc_form_q(_dp(qrf), m, len(hc), m, _dp(np.ascontiguousarray(hc)), _dp(Q), m)
+    return Q
+
+
+def block_triangular_factor(V: np.ndarray, hc: np.ndarray) -> np.ndarray:
+    m, n = V.shape
+    Vf = np.asfortranarray(V)
+    T = np.zeros((n, n), order="F")
+    lib().orc_block_triangular_factor(_dp(T), n, _dp(Vf), m, n, m, _dp(np.ascontiguousarray(hc)))
+    return T
+
+
+# ------------------------------------------------------------------- block maps
+
+def _bi_to_np(buf, n):
+    return np.array([(b.idxRow, b.idxCol, b.numRows, b.numCols) for b in buf[:n]], dtype=np.int32).reshape(n, 4)
+
+
+def from_block_diagonal_pattern(matRows, matCols, blockRows, blockCols):
+    cap = max(matCols // blockCols, 1)
+    buf = (_BlockInfo * cap)()
+    n = lib().orc_from_block_diagonal_pattern(matRows, matCols, blockRows, blockCols, buf, cap)
+    return _bi_to_np(buf, n)
+
+
+def from_block_banded_pattern(matRows, matCols, blockRows, blockCols, overlap, suggested=2):
+    cap = max(matCols // max(blockCols - overlap, 1), 1) + 1
+    buf = (_BlockInfo * cap)()
+    n = lib().orc_from_block_banded_pattern(matRows, matCols, blockRows, blockCols, overlap, suggested, buf, cap)
+    return None if n < 0 else _bi_to_np(buf, n)
+
+
+def merge_blocks(blocks: np.ndarray, maxColStep: int, suggested: int = 2):
+    nin = len(blocks)
+    inb = (_BlockInfo * max(nin, 1))()
+    for i, (a, b, c, d) in enumerate(blocks):
+        inb[i] = _BlockInfo(int(a), int(b), int(c), int(d))
+    out = (_BlockInfo * max(nin, 1))()
+    n = lib().orc_merge_blocks(inb, nin, maxColStep, suggested, out, max(nin, 1))
+    return None if n < 0 else _bi_to_np(out, n)
+
+
+def block_info_from_csr(rows, cols, rowptr, colidx, suggested=2):
+    rowptr = np.ascontiguousarray(rowptr, dtype=np.int32)
+    colidx = np.ascontiguousarray(colidx, dtype=np.int32)
+    out = (_BlockInfo * max(rows, 1))()
+    n = lib().orc_block_info_from_csr(rows, cols, _ip(rowptr), _ip(colidx), suggested, out, max(rows, 1))
+    return None if n < 0 else _bi_to_np(out, n)
+
+
+def as_banded_as_possible(rows, cols, rowptr, colidx):
+    rowptr = np.ascontiguousarray(rowptr, dtype=np.int32)
+    colidx = np.ascontiguousarray(colidx, dtype=np.int32)
+    perm = np.zeros(max(rows, 1), dtype=np.int32)
+    has = lib().orc_as_banded_as_possible(rows, cols, _ip(rowptr), _ip(colidx), _ip(perm))
+    return bool(has), perm[:rows]
+
+
+# ------------------------------------------------------- BlockDiagonalSparseQR
+
+@dataclass
+class BDResult:
+    info: int
+    rank: int
+    Q_vals: np.ndarray
+    R_vals: np.ndarray
+    perm: np.ndarray
+    hcoeffs: np.ndarray
+
+
+class BDProblem:
+    """A packed batch of column-major tiles = the reference's SparseBlockDiagonal."""
+
+    def __init__(self, rows, cols, tiles, matRows=None, q_format=FULL_Q, block_solver=COLPIV):
+        self.rows = np.ascontiguousarray(rows, dtype=np.int32)
+        self.cols = np.ascontiguousarray(cols, dtype=np.int32)
+        self.B = len(self.rows)
+        sizes = self.rows.astype(np.int64) * self.cols.astype(np.int64)
+        self.tile_off = np.zeros(self.B + 1, dtype=np.int64)
+        np.cumsum(sizes, out=self.tile_off[1:])
+        self.tiles = np.ascontiguousarray(tiles, dtype=np.float64).reshape(-1)
+        assert self.tiles.size == self.tile_off[-1]
+        self.matRows = int(self.rows.sum()) if matRows is None else int(matRows)
+        self.matCols = int(self.cols.sum())
+        self.q_format, self.block_solver = q_format, block_solver
+        self._d = _Desc(self.B, _ip(self.rows), _ip(self.cols), _lp(self.tile_off), self.matRows,
+                        self.matCols, q_format, block_solver)
+
+    @classmethod
+    def uniform(cls, B, r, c, tiles, **kw):
+        return cls(np.full(B, r, np.int32), np.full(B, c, np.int32), tiles, **kw)
+
+    def sizes(self):
+        q, r = C.c_int64(0), C.c_int64(0)
+        lib().orc_bd_sizes(C.byref(self._d), C.byref(q), C.byref(r))
+        return q.value, r.value
+
+    def pattern(self):
+        nq, nr = self.sizes()
+        q_rowptr = np.zeros(self.matRows + 1, np.int32)
+        q_colidx = np.zeros(max(nq, 1), np.int32)
+        r_colptr = np.zeros(self.matCols + 1, np.int32)
+        r_rowidx = np.zeros(max(nr, 1), np.int32)
+        lib().orc_bd_pattern(C.byref(self._d), _ip(q_rowptr), _ip(q_colidx), _ip(r_colptr), _ip(r_rowidx))
+        return q_rowptr, q_colidx[:nq], r_colptr, r_rowidx[:nr]
+
+    def factorize(self, faithful: bool = False) -> BDResult:
+        nq, nr = self.sizes()
+        Q = np.zeros(max(nq, 1))
+        R = np.zeros(max(nr, 1))
+        perm = np.zeros(max(self.matCols, 1), np.int32)
+        hc = np.zeros(max(self.matCols, 1))
+        rank = C.c_int64(0)
+        if faithful:
+            info = lib().orc_bd_factorize_faithful(C.byref(self._d), _dp(self.tiles), _dp(Q), _dp(R), _ip(perm),
+                                                   C.byref(rank))
+        else:
+            info = lib().orc_bd_factorize(C.byref(self._d), _dp(self.tiles), _dp(Q), _dp(R), _ip(perm), _dp(hc),
+                                          C.byref(rank))
+        return BDResult(info, rank.value, Q[:nq], R[:nr], perm[:self.matCols], hc[:self.matCols])
+
+    def solve(self, res: BDResult, b: np.ndarray) -> np.ndarray:
+        b2 = np.asfortranarray(b.reshape(self.matRows, -1), dtype=np.float64)
+        nrhs = b2.shape[1]
+        x = np.zeros((self.matCols, nrhs), order="F")
+        info = lib().orc_bd_solve(C.byref(self._d), _dp(res.Q_vals), _dp(res.R_vals), _ip(res.perm), _dp(b2), nrhs,
+                                  _dp(x))
+        assert info == SUCCESS
+        return x.reshape(b.shape[:0] + (self.matCols,) + b.shape[1:]) if b.ndim > 1 else x[:, 0]
+
+
+# -------------------------------------------------------------------- generators
+
+def gen_reference_7x2(numVars: int) -> np.ndarray:
+    """Tiles of generate_block_diagonal_matrix (test/test-qrkit.cpp:101-117), shape (numVars, 2, 7) = col-major 7x2."""
+    t = np.zeros(numVars * 14)
+    lib().orc_gen_reference_7x2(numVars, _dp(t))
+    return t
+
+
+def gen_uniform(seed: int, lo: float, hi: float, n: int) -> np.ndarray:
+    t = np.zeros(n)
+    lib().orc_gen_uniform(seed, lo, hi, n, _dp(t))
+    return t
