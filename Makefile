@@ -1,0 +1,28 @@
+# Builds the gfx950 shared library behind the C ABI (include/qrkit_amd.h) and the CPU oracle.
+HIPCC     ?= /opt/rocm/bin/hipcc
+ARCH      ?= gfx950
+HIPFLAGS  ?= -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -Wall -Wno-unused-function
+CSRC      := qrkit_amd/csrc
+OBJDIR    := build/obj
+LIB       := qrkit_amd/lib/libqrkit_amd.so
+SRCS      := $(wildcard $(CSRC)/*.hip)
+OBJS      := $(patsubst $(CSRC)/%.hip,$(OBJDIR)/%.o,$(SRCS))
+
+all: $(LIB) oracle
+
+$(OBJDIR)/%.o: $(CSRC)/%.hip $(CSRC)/qrk_device.h include/qrkit_amd.h
+	@mkdir -p $(OBJDIR)
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+$(LIB): $(OBJS)
+	@mkdir -p qrkit_amd/lib
+	$(HIPCC) -shared -fPIC --offload-arch=$(ARCH) $(OBJS) -o $@
+
+oracle:
+	$(MAKE) -C oracle
+
+clean:
+	rm -rf build $(LIB)
+	$(MAKE) -C oracle clean
+
+.PHONY: all oracle clean

@@ -1,0 +1,174 @@
+/*
+ * qrkit_amd.h -- C ABI of the MI355X (gfx950) structured sparse QR engine.
+ *
+ * This is the drop-in boundary for QRKit's block-diagonal hot path.  QRKit has
+ * no FFI of its own (header-only C++ templates); the seam these entry points
+ * replace is the body of
+ *     QRKit::BlockDiagonalSparseQR<BlockQRSolver,QFormat>::analyzePattern
+ *         (src/QRKit/BlockDiagonalSparseQR.h:392-405)
+ *     QRKit::BlockDiagonalSparseQR<...>::factorize   (:415-547)
+ *     QRKit::BlockDiagonalSparseQR<...>::_solve_impl (:257-280)
+ * i.e. everything between "tiles of a SparseBlockDiagonal in" and
+ * "values of m_Q / m_R / m_outputPerm_c out".  The C++ facade in
+ * include/qrkit/ keeps the reference's class and method names on top of it;
+ * INTEGRATION.md shows the binding a QRKit maintainer would add.
+ *
+ * Conventions
+ *  - plain C types only; the caller owns every buffer; the library never frees
+ *    or retains caller memory beyond the call (device work is enqueued on the
+ *    handle's HIP stream and has completed when the stream has);
+ *  - all matrices are double, tiles column-major (Eigen::Matrix default);
+ *  - index arrays are int32 (QRKit's StorageIndex = int);
+ *  - one handle per host thread (no internal locking);
+ *  - every function returns qrk_status; qrk_last_error() gives the text;
+ *  - there is NO CPU fallback: without a HIP device qrk_create() fails with
+ *    QRK_STATUS_NO_DEVICE and nothing else can be called.
+ */
+#ifndef QRKIT_AMD_H
+#define QRKIT_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define QRK_VERSION_MAJOR 0
+#define QRK_VERSION_MINOR 1
+
+typedef enum qrk_status {
+    QRK_STATUS_OK = 0,
+    QRK_STATUS_INVALID_ARGUMENT = 1,
+    QRK_STATUS_NO_DEVICE = 2,
+    QRK_STATUS_HIP_ERROR = 3,
+    QRK_STATUS_ALLOC_FAILED = 4,
+    QRK_STATUS_UNSUPPORTED = 5,
+    QRK_STATUS_NOT_FACTORIZED = 6
+} qrk_status;
+
+/* Eigen::ComputationInfo, as returned by QRKit's info() (BlockDiagonalSparseQR.h:309-313). */
+typedef enum qrk_info {
+    QRK_INFO_SUCCESS = 0,
+    QRK_INFO_NUMERICAL_ISSUE = 1,
+    QRK_INFO_NO_CONVERGENCE = 2,
+    QRK_INFO_INVALID_INPUT = 3
+} qrk_info;
+
+/* BlockDiagonalSparseQR::MatrixQFormat (BlockDiagonalSparseQR.h:59-62). */
+typedef enum qrk_q_format { QRK_FULL_Q = 0, QRK_BLOCK_DIAGONAL_Q = 1 } qrk_q_format;
+
+/* Which Eigen dense solver stands behind the _BlockQRSolver template parameter
+ * (BlockDiagonalSparseQR.h:37): ColPivHouseholderQR (test/test-qrkit.cpp:32-38,
+ * 49-51) or HouseholderQR (examples/ellipse_fitting.cpp:153). */
+typedef enum qrk_block_solver { QRK_COLPIV_HOUSEHOLDER = 0, QRK_HOUSEHOLDER = 1 } qrk_block_solver;
+
+/* Where the caller's buffers live. */
+typedef enum qrk_memspace { QRK_MEM_DEVICE = 0, QRK_MEM_HOST = 1 } qrk_memspace;
+
+typedef struct qrk_context_s* qrk_handle;
+typedef struct qrk_bd_plan_s* qrk_bd_plan;
+
+/* ------------------------------------------------------------------ context */
+
+/* Library version as major*1000+minor. */
+int qrk_version(void);
+
+/* Number of HIP devices visible (0 when there is none; never initialises a context). */
+int qrk_device_count(void);
+
+/* Create a context on HIP device `device`.  `stream` is a hipStream_t (or NULL
+ * for the device's default stream) on which all work of this handle is enqueued. */
+qrk_status qrk_create(qrk_handle* out, int device, void* stream);
+qrk_status qrk_destroy(qrk_handle h);
+qrk_status qrk_set_stream(qrk_handle h, void* stream);
+/* Block until everything enqueued on the handle's stream has finished. */
+qrk_status qrk_synchronize(qrk_handle h);
+/* Text of the last error on this handle (h may be NULL for creation errors). */
+const char* qrk_last_error(qrk_handle h);
+
+/* -------------------------------------------- block-diagonal: analyzePattern */
+
+/* The block structure of a QRKit::SparseBlockDiagonal (SparseBlockDiagonal.h:43-163):
+ * num_blocks dense tiles on the diagonal, tile i being rows[i] x cols[i].  When
+ * rows == cols == NULL every tile is block_rows x block_cols (the
+ * fromBlockDiagonalPattern case, SparseBlockDiagonal.h:71-89).  mat_rows /
+ * mat_cols are SparseBlockDiagonal::rows()/cols(); mat_rows may exceed the sum
+ * of tile rows (trailing identity rows of Q, BlockDiagonalSparseQR.h:530-533);
+ * mat_cols must equal the sum of tile cols.  rows/cols are HOST arrays. */
+typedef struct qrk_bd_layout {
+    int64_t num_blocks;
+    int32_t block_rows;
+    int32_t block_cols;
+    const int32_t* rows;
+    const int32_t* cols;
+    int32_t mat_rows;
+    int32_t mat_cols;
+} qrk_bd_layout;
+
+/* analyzePattern(): validates the layout, computes the prefix sums the hot loop
+ * carries (base_row, base_col, m1; BlockDiagonalSparseQR.h:428-431,524-525),
+ * uploads the per-tile descriptors and bins tiles by size class.  A landscape
+ * tile (rows < cols) is accepted here and reported by factorize() through
+ * info = QRK_INFO_INVALID_INPUT, as the reference does (:509-516). */
+qrk_status qrk_bd_plan_create(qrk_handle h, const qrk_bd_layout* layout, qrk_q_format q_format,
+                              qrk_block_solver solver, qrk_bd_plan* out);
+qrk_status qrk_bd_plan_destroy(qrk_bd_plan plan);
+
+/* Element counts of the caller-owned arrays:
+ *   tiles_len = sum rows_i*cols_i          (input tiles, packed back to back)
+ *   nnz_q     = sum rows_i^2 + (mat_rows - sum rows_i)   (m_Q values / column indices)
+ *   nnz_r     = sum cols_i*(cols_i+1)/2    (m_R values / row indices)
+ * perm and hcoeffs have mat_cols entries. */
+qrk_status qrk_bd_plan_sizes(qrk_bd_plan plan, int64_t* tiles_len, int64_t* nnz_q, int64_t* nnz_r);
+
+/* Sparse patterns exactly as factorize() assembles them: m_Q is RowMajor CSR
+ * (mat_rows+1 row pointers, nnz_q column indices; BlockDiagonalSparseQR.h:455-492,
+ * 530-536), m_R is ColMajor CSC (mat_cols+1 column pointers, nnz_r row indices;
+ * :475-479,496-500,538-541).  Pure functions of the layout and q_format. */
+qrk_status qrk_bd_pattern(qrk_bd_plan plan, int32_t* q_rowptr, int32_t* q_colidx, int32_t* r_colptr,
+                          int32_t* r_rowidx, qrk_memspace space);
+
+/* ------------------------------------------------- block-diagonal: factorize */
+
+/* factorize(): per tile A_i P_i = Q_i R_i (BlockDiagonalSparseQR.h:432-526).
+ *   tiles   [tiles_len]  in : tile i column-major at the running offset
+ *   q_vals  [nnz_q]      out: values of m_Q in CSR order (row j of Q_i = [U_i(j,:), N_i(j,:)])
+ *   r_vals  [nnz_r]      out: values of m_R in CSC order (upper triangle of R_i by columns)
+ *   perm    [mat_cols]   out: m_outputPerm_c.indices() (:519-521)
+ *   hcoeffs [mat_cols]   out, may be NULL: Householder coefficients tau of every tile
+ * Asynchronous on the handle's stream for QRK_MEM_DEVICE; for QRK_MEM_HOST the
+ * call stages through device buffers and returns after the results are on the host. */
+qrk_status qrk_bd_factorize(qrk_bd_plan plan, const double* tiles, double* q_vals, double* r_vals,
+                            int32_t* perm, double* hcoeffs, qrk_memspace space);
+
+/* info() and rank() after factorize() (BlockDiagonalSparseQR.h:161-165,309-313):
+ * rank = sum of tile cols (the solver is not rank revealing, :439-444). */
+qrk_status qrk_bd_info(qrk_bd_plan plan, qrk_info* info, int64_t* rank);
+
+/* ----------------------------------------------------- block-diagonal: solve */
+
+/* y = Q^T b, the product the reference forms at BlockDiagonalSparseQR.h:266 and the
+ * tests at test/test-qrkit.cpp:187.  b, y: mat_rows x nrhs column-major (ld = mat_rows). */
+qrk_status qrk_bd_apply_qt(qrk_bd_plan plan, const double* q_vals, const double* b, int64_t nrhs,
+                           double* y, qrk_memspace space);
+
+/* _solve_impl (BlockDiagonalSparseQR.h:257-280), FullQ only:
+ * x = P * [ R(0:rank,0:rank)^-1 (Q^T b)(0:rank) ];  b: mat_rows x nrhs, x: mat_cols x nrhs. */
+qrk_status qrk_bd_solve(qrk_bd_plan plan, const double* q_vals, const double* r_vals,
+                        const int32_t* perm, const double* b, int64_t nrhs, double* x,
+                        qrk_memspace space);
+
+/* ------------------------------------------------------------- measurement */
+
+/* Launch the factorisation kernel(s) of `plan` `iters` times back to back on the
+ * handle's stream, rotating over `nsets` consecutive copies of the input/output
+ * arrays (set s uses tiles + s*tiles_len, q_vals + s*nnz_q, ...), bracketed by
+ * HIP events on that same stream.  *avg_ms = elapsed / iters.  Device memory only. */
+qrk_status qrk_bd_time_factorize(qrk_bd_plan plan, const double* tiles, double* q_vals,
+                                 double* r_vals, int32_t* perm, int nsets, int iters,
+                                 float* avg_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QRKIT_AMD_H */

@@ -1,0 +1,93 @@
+"""ctypes binding of the C ABI in include/qrkit_amd.h (libqrkit_amd.so, HIP/gfx950).
+
+There is no fallback of any kind here: if the shared library is missing, or no
+MI355X is visible when a context is created, the call raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libqrkit_amd.so")
+
+# enums of include/qrkit_amd.h
+STATUS_OK, STATUS_INVALID_ARGUMENT, STATUS_NO_DEVICE, STATUS_HIP_ERROR = 0, 1, 2, 3
+STATUS_ALLOC_FAILED, STATUS_UNSUPPORTED, STATUS_NOT_FACTORIZED = 4, 5, 6
+INFO_SUCCESS, INFO_NUMERICAL_ISSUE, INFO_NO_CONVERGENCE, INFO_INVALID_INPUT = 0, 1, 2, 3
+FULL_Q, BLOCK_DIAGONAL_Q = 0, 1
+COLPIV_HOUSEHOLDER, HOUSEHOLDER = 0, 1
+MEM_DEVICE, MEM_HOST = 0, 1
+
+# every symbol the header declares, in header order
+EXPORTS = (
+    "qrk_version", "qrk_device_count", "qrk_create", "qrk_destroy", "qrk_set_stream", "qrk_synchronize",
+    "qrk_last_error", "qrk_bd_plan_create", "qrk_bd_plan_destroy", "qrk_bd_plan_sizes", "qrk_bd_pattern",
+    "qrk_bd_factorize", "qrk_bd_info", "qrk_bd_apply_qt", "qrk_bd_solve", "qrk_bd_time_factorize",
+)
+
+
+class QrkError(RuntimeError):
+    def __init__(self, status: int, message: str):
+        super().__init__(f"qrkit_amd status {status}: {message}")
+        self.status = status
+
+
+class BDLayout(C.Structure):
+    _fields_ = [("num_blocks", C.c_int64), ("block_rows", C.c_int32), ("block_cols", C.c_int32),
+                ("rows", C.POINTER(C.c_int32)), ("cols", C.POINTER(C.c_int32)),
+                ("mat_rows", C.c_int32), ("mat_cols", C.c_int32)]
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """Load libqrkit_amd.so (built by `make` / __graft_entry__.build())."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build the HIP library first (make, or __graft_entry__.build()). "
+            "qrkit_amd has no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    vp, dp, ip = C.c_void_p, C.c_void_p, C.c_void_p  # device or host addresses travel as integers
+    L.qrk_version.restype = C.c_int
+    L.qrk_device_count.restype = C.c_int
+    L.qrk_create.restype = C.c_int
+    L.qrk_create.argtypes = [C.POINTER(vp), C.c_int, vp]
+    L.qrk_destroy.restype = C.c_int
+    L.qrk_destroy.argtypes = [vp]
+    L.qrk_set_stream.restype = C.c_int
+    L.qrk_set_stream.argtypes = [vp, vp]
+    L.qrk_synchronize.restype = C.c_int
+    L.qrk_synchronize.argtypes = [vp]
+    L.qrk_last_error.restype = C.c_char_p
+    L.qrk_last_error.argtypes = [vp]
+    L.qrk_bd_plan_create.restype = C.c_int
+    L.qrk_bd_plan_create.argtypes = [vp, C.POINTER(BDLayout), C.c_int, C.c_int, C.POINTER(vp)]
+    L.qrk_bd_plan_destroy.restype = C.c_int
+    L.qrk_bd_plan_destroy.argtypes = [vp]
+    L.qrk_bd_plan_sizes.restype = C.c_int
+    L.qrk_bd_plan_sizes.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    L.qrk_bd_pattern.restype = C.c_int
+    L.qrk_bd_pattern.argtypes = [vp, ip, ip, ip, ip, C.c_int]
+    L.qrk_bd_factorize.restype = C.c_int
+    L.qrk_bd_factorize.argtypes = [vp, dp, dp, dp, ip, dp, C.c_int]
+    L.qrk_bd_info.restype = C.c_int
+    L.qrk_bd_info.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int64)]
+    L.qrk_bd_apply_qt.restype = C.c_int
+    L.qrk_bd_apply_qt.argtypes = [vp, dp, dp, C.c_int64, dp, C.c_int]
+    L.qrk_bd_solve.restype = C.c_int
+    L.qrk_bd_solve.argtypes = [vp, dp, dp, ip, dp, C.c_int64, dp, C.c_int]
+    L.qrk_bd_time_factorize.restype = C.c_int
+    L.qrk_bd_time_factorize.argtypes = [vp, dp, dp, dp, ip, C.c_int, C.c_int, C.POINTER(C.c_float)]
+    _lib = L
+    return L
+
+
+def check(status: int, handle=None):
+    if status != STATUS_OK:
+        msg = lib().qrk_last_error(handle)
+        raise QrkError(status, msg.decode() if msg else "")

@@ -1,0 +1,190 @@
+// bd_aux.hip -- pattern generation and the block-local solve path of the block-diagonal solver.
+//
+//  * bd_pattern_*: CSR pattern of m_Q and CSC pattern of m_R exactly as
+//    BlockDiagonalSparseQR::factorize inserts them (BlockDiagonalSparseQR.h:455-500,530-541);
+//    pure functions of the tile sizes, so they are generated on the device with coalesced stores
+//    instead of one insertBack() per entry.
+//  * bd_apply_qt / bd_solve: y = Q^T b and x = P R^-1 (Q^T b)_top of _solve_impl (:257-280);
+//    both are block-local, one wavefront per tile and right-hand side.
+#include "qrk_device.h"
+
+namespace qrk {
+
+__device__ __forceinline__ void tile_geom(const TileGeom& g, int64_t t, int& r, int& c, int64_t& qoff,
+                                          int64_t& roff, int& base_row, int& base_col)
+{
+    if (g.t_rows) {
+        r = g.t_rows[t]; c = g.t_cols[t]; qoff = g.q_off[t]; roff = g.r_off[t];
+        base_row = g.row_off[t]; base_col = g.c_off[t];
+    } else {
+        r = g.rows; c = g.cols;
+        qoff = t * (int64_t)r * r; roff = t * (int64_t)(c * (c + 1) / 2);
+        base_row = (int)(t * r); base_col = (int)(t * c);
+    }
+}
+
+// One workgroup per tile.  m1 (the running sum of rows-cols, BlockDiagonalSparseQR.h:428,471)
+// equals base_row - base_col.
+__global__ void __launch_bounds__(256)
+bd_pattern_kernel(TileGeom g, int32_t* __restrict__ q_rowptr, int32_t* __restrict__ q_colidx,
+                  int32_t* __restrict__ r_colptr, int32_t* __restrict__ r_rowidx)
+{
+    for (int64_t t = blockIdx.x; t < g.num_tiles; t += gridDim.x) {
+        int r, c, base_row, base_col;
+        int64_t qoff, roff;
+        tile_geom(g, t, r, c, qoff, roff, base_row, base_col);
+        const int m1 = base_row - base_col;
+        const int n_start = g.mat_cols;
+        for (int j = threadIdx.x; j < r; j += blockDim.x) q_rowptr[base_row + j] = (int32_t)(qoff + (int64_t)j * r);
+        for (int e = threadIdx.x; e < r * r; e += blockDim.x) {
+            const int j = e / r, k = e - j * r;
+            (void)j;
+            int32_t colidx;
+            if (g.q_format == 0) colidx = k < c ? base_col + k : n_start + m1 + (k - c);
+            else colidx = base_row + k;
+            q_colidx[qoff + e] = colidx;
+        }
+        for (int k = threadIdx.x; k < c; k += blockDim.x) r_colptr[base_col + k] = (int32_t)(roff + (int64_t)k * (k + 1) / 2);
+        const int rbase = g.q_format == 0 ? base_col : base_row;
+        for (int k = 0; k < c; ++k)
+            for (int j = threadIdx.x; j <= k; j += blockDim.x) r_rowidx[roff + (int64_t)k * (k + 1) / 2 + j] = rbase + j;
+    }
+}
+
+// Trailing identity rows of Q and the closing pointers.
+__global__ void __launch_bounds__(256)
+bd_pattern_tail_kernel(TileGeom g, int64_t nnz_r, int32_t* __restrict__ q_rowptr,
+                       int32_t* __restrict__ q_colidx, int32_t* __restrict__ r_colptr)
+{
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    const int64_t ntail = (int64_t)g.mat_rows - g.sum_rows;
+    if (i < ntail) {
+        q_rowptr[g.sum_rows + i] = (int32_t)(g.nnz_q_tiles + i);
+        q_colidx[g.nnz_q_tiles + i] = (int32_t)(g.sum_rows + i);
+    }
+    if (i == 0) {
+        q_rowptr[g.mat_rows] = (int32_t)(g.nnz_q_tiles + ntail);
+        r_colptr[g.mat_cols] = (int32_t)nnz_r;
+    }
+}
+
+// Fill the trailing identity VALUES of Q (BlockDiagonalSparseQR.h:530-533).
+__global__ void __launch_bounds__(256)
+bd_q_tail_ones_kernel(double* __restrict__ q_vals, int64_t start, int64_t count)
+{
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i < count) q_vals[start + i] = 1.0;
+}
+
+// y = Q^T b for one tile and one right-hand side per wavefront (tiles with rows <= 64 use the
+// lanes as output index; larger tiles loop).  FullQ: y[base_col+k] for k < c, y[N + m1 + k - c]
+// for the N part; BlockDiagonalQ: y[base_row + k].
+__global__ void __launch_bounds__(64)
+bd_apply_qt_kernel(TileGeom g, const double* __restrict__ q_vals, const double* __restrict__ b,
+                   int64_t nrhs, double* __restrict__ y)
+{
+    const int lane = threadIdx.x;
+    const int64_t total = g.num_tiles * nrhs;
+    for (int64_t w = blockIdx.x; w < total; w += gridDim.x) {
+        const int64_t t = w % g.num_tiles, rhs = w / g.num_tiles;
+        int r, c, base_row, base_col;
+        int64_t qoff, roff;
+        tile_geom(g, t, r, c, qoff, roff, base_row, base_col);
+        const double* bb = b + rhs * (int64_t)g.mat_rows + base_row;
+        double* yy = y + rhs * (int64_t)g.mat_rows;
+        const int m1 = base_row - base_col;
+        for (int k = lane; k < r; k += 64) {
+            double s = 0.0;
+            for (int j = 0; j < r; ++j) s = fma(q_vals[qoff + (int64_t)j * r + k], bb[j], s);
+            int idx;
+            if (g.q_format == 0) idx = k < c ? base_col + k : g.mat_cols + m1 + (k - c);
+            else idx = base_row + k;
+            yy[idx] = s;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256)
+bd_copy_tail_kernel(TileGeom g, const double* __restrict__ b, int64_t nrhs, double* __restrict__ y)
+{
+    const int64_t ntail = (int64_t)g.mat_rows - g.sum_rows;
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i < ntail * nrhs) {
+        const int64_t rhs = i / ntail, k = i - rhs * ntail;
+        y[rhs * (int64_t)g.mat_rows + g.sum_rows + k] = b[rhs * (int64_t)g.mat_rows + g.sum_rows + k];
+    }
+}
+
+// _solve_impl for FullQ, tiles with cols <= 64: per wavefront, y = (Q_i^T b_i)(0:c), column-oriented
+// back substitution with the packed upper-triangular R_i, x[perm[base_col+k]] = y[k].
+__global__ void __launch_bounds__(64)
+bd_solve_kernel(TileGeom g, const double* __restrict__ q_vals, const double* __restrict__ r_vals,
+                const int32_t* __restrict__ perm, const double* __restrict__ b, int64_t nrhs,
+                double* __restrict__ x)
+{
+    const int lane = threadIdx.x;
+    const int64_t total = g.num_tiles * nrhs;
+    for (int64_t w = blockIdx.x; w < total; w += gridDim.x) {
+        const int64_t t = w % g.num_tiles, rhs = w / g.num_tiles;
+        int r, c, base_row, base_col;
+        int64_t qoff, roff;
+        tile_geom(g, t, r, c, qoff, roff, base_row, base_col);
+        const double* bb = b + rhs * (int64_t)g.mat_rows + base_row;
+        double yk = 0.0;
+        if (lane < c)
+            for (int j = 0; j < r; ++j) yk = fma(q_vals[qoff + (int64_t)j * r + lane], bb[j], yk);
+        for (int kk = c - 1; kk >= 0; --kk) {
+            const double* colk = r_vals + roff + (int64_t)kk * (kk + 1) / 2;
+            const double piv = readlane_f64(yk, kk) / colk[kk];
+            if (lane == kk) yk = piv;
+            else if (lane < kk) yk = fma(-colk[lane], piv, yk);
+        }
+        if (lane < c) x[rhs * (int64_t)g.mat_cols + perm[base_col + lane]] = yk;
+    }
+}
+
+void launch_bd_pattern(const TileGeom& g, int64_t nnz_r, int32_t* q_rowptr, int32_t* q_colidx,
+                       int32_t* r_colptr, int32_t* r_rowidx, hipStream_t stream)
+{
+    if (g.num_tiles > 0) {
+        const unsigned grid = (unsigned)(g.num_tiles < 65536 ? g.num_tiles : 65536);
+        hipLaunchKernelGGL(bd_pattern_kernel, dim3(grid), dim3(256), 0, stream, g, q_rowptr, q_colidx,
+                           r_colptr, r_rowidx);
+    }
+    const int64_t ntail = (int64_t)g.mat_rows - g.sum_rows;
+    const unsigned tgrid = (unsigned)((ntail > 0 ? ntail : 1) + 255) / 256;
+    hipLaunchKernelGGL(bd_pattern_tail_kernel, dim3(tgrid), dim3(256), 0, stream, g, nnz_r, q_rowptr,
+                       q_colidx, r_colptr);
+}
+
+void launch_bd_q_tail_ones(double* q_vals, int64_t start, int64_t count, hipStream_t stream)
+{
+    if (count <= 0) return;
+    hipLaunchKernelGGL(bd_q_tail_ones_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, stream,
+                       q_vals, start, count);
+}
+
+void launch_bd_apply_qt(const TileGeom& g, const double* q_vals, const double* b, int64_t nrhs, double* y,
+                        hipStream_t stream)
+{
+    const int64_t total = g.num_tiles * nrhs;
+    if (total > 0) {
+        const unsigned grid = (unsigned)(total < 262144 ? total : 262144);
+        hipLaunchKernelGGL(bd_apply_qt_kernel, dim3(grid), dim3(64), 0, stream, g, q_vals, b, nrhs, y);
+    }
+    const int64_t ntail = ((int64_t)g.mat_rows - g.sum_rows) * nrhs;
+    if (ntail > 0)
+        hipLaunchKernelGGL(bd_copy_tail_kernel, dim3((unsigned)((ntail + 255) / 256)), dim3(256), 0, stream, g,
+                           b, nrhs, y);
+}
+
+void launch_bd_solve(const TileGeom& g, const double* q_vals, const double* r_vals, const int32_t* perm,
+                     const double* b, int64_t nrhs, double* x, hipStream_t stream)
+{
+    const int64_t total = g.num_tiles * nrhs;
+    if (total <= 0) return;
+    const unsigned grid = (unsigned)(total < 262144 ? total : 262144);
+    hipLaunchKernelGGL(bd_solve_kernel, dim3(grid), dim3(64), 0, stream, g, q_vals, r_vals, perm, b, nrhs, x);
+}
+
+}  // namespace qrk

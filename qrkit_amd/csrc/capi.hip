@@ -1,0 +1,466 @@
+// capi.hip -- implementation of the C ABI declared in include/qrkit_amd.h.
+//
+// Host-side counterpart of QRKit::BlockDiagonalSparseQR (src/QRKit/BlockDiagonalSparseQR.h):
+// qrk_bd_plan_create = analyzePattern (:392-405) plus the running offsets of the hot loop
+// (:428-431,524-525) as prefix sums; qrk_bd_factorize = factorize (:415-547);
+// qrk_bd_solve = _solve_impl (:257-280).  There is no CPU fallback anywhere in this file.
+#include "../../include/qrkit_amd.h"
+#include "qrk_device.h"
+
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_create_error;
+
+}  // namespace
+
+struct qrk_context_s {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int num_cus = 256;
+    std::string error;
+};
+
+struct qrk_bd_plan_s {
+    qrk_handle h = nullptr;
+    int64_t B = 0;
+    bool uniform = true;
+    int32_t r = 0, c = 0;
+    int32_t mat_rows = 0, mat_cols = 0, sum_rows = 0;
+    int q_format = 0, solver = 0;
+    int64_t tiles_len = 0, nnz_q_tiles = 0, nnz_q = 0, nnz_r = 0;
+    bool landscape = false;       // some tile has rows < cols -> InvalidInput
+    int32_t max_dim = 0;          // largest tile dimension
+    bool factorized = false;
+    // device-resident per-tile descriptors (mixed batches only)
+    int32_t *d_rows = nullptr, *d_cols = nullptr, *d_coff = nullptr, *d_rowoff = nullptr;
+    int64_t *d_toff = nullptr, *d_qoff = nullptr, *d_roff = nullptr;
+    int32_t* d_wave_ids = nullptr;   // tiles handled by the one-wave kernel
+    int64_t n_wave = 0;
+};
+
+namespace {
+
+qrk_status fail(qrk_handle h, qrk_status st, const std::string& msg)
+{
+    if (h) h->error = msg; else g_create_error = msg;
+    return st;
+}
+
+#define QRK_HIP(h, expr)                                                                       \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess)                                                                  \
+            return fail((h), QRK_STATUS_HIP_ERROR,                                             \
+                        std::string(#expr) + ": " + hipGetErrorString(e_));                    \
+    } while (0)
+
+template <typename T>
+qrk_status upload(qrk_handle h, const std::vector<T>& v, T** out)
+{
+    *out = nullptr;
+    if (v.empty()) return QRK_STATUS_OK;
+    QRK_HIP(h, hipMalloc((void**)out, v.size() * sizeof(T)));
+    QRK_HIP(h, hipMemcpyAsync(*out, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, h->stream));
+    QRK_HIP(h, hipStreamSynchronize(h->stream));
+    return QRK_STATUS_OK;
+}
+
+qrk::TileGeom make_geom(const qrk_bd_plan_s* p)
+{
+    qrk::TileGeom g{};
+    g.num_tiles = p->B;
+    g.rows = p->r; g.cols = p->c;
+    g.t_rows = p->uniform ? nullptr : p->d_rows;
+    g.t_cols = p->d_cols; g.q_off = p->d_qoff; g.r_off = p->d_roff;
+    g.c_off = p->d_coff; g.row_off = p->d_rowoff;
+    g.mat_rows = p->mat_rows; g.mat_cols = p->mat_cols; g.sum_rows = p->sum_rows;
+    g.nnz_q_tiles = p->nnz_q_tiles; g.q_format = p->q_format;
+    return g;
+}
+
+// Scoped device staging of host buffers for the QRK_MEM_HOST entry points.
+struct Staging {
+    qrk_handle h;
+    std::vector<void*> bufs;
+    explicit Staging(qrk_handle hh) : h(hh) {}
+    ~Staging() { for (void* b : bufs) (void)hipFree(b); }
+    template <typename T>
+    qrk_status in(const T* host, int64_t n, T** dev)
+    {
+        *dev = nullptr;
+        if (n <= 0 || !host) return QRK_STATUS_OK;
+        QRK_HIP(h, hipMalloc((void**)dev, (size_t)n * sizeof(T)));
+        bufs.push_back(*dev);
+        QRK_HIP(h, hipMemcpyAsync(*dev, host, (size_t)n * sizeof(T), hipMemcpyHostToDevice, h->stream));
+        return QRK_STATUS_OK;
+    }
+    template <typename T>
+    qrk_status out(int64_t n, T** dev)
+    {
+        *dev = nullptr;
+        if (n <= 0) return QRK_STATUS_OK;
+        QRK_HIP(h, hipMalloc((void**)dev, (size_t)n * sizeof(T)));
+        bufs.push_back(*dev);
+        return QRK_STATUS_OK;
+    }
+    template <typename T>
+    qrk_status back(T* host, const T* dev, int64_t n)
+    {
+        if (n <= 0 || !host || !dev) return QRK_STATUS_OK;
+        QRK_HIP(h, hipMemcpyAsync(host, dev, (size_t)n * sizeof(T), hipMemcpyDeviceToHost, h->stream));
+        return QRK_STATUS_OK;
+    }
+};
+
+qrk_status enqueue_factorize(qrk_bd_plan_s* p, const double* tiles, double* q, double* r, int32_t* perm,
+                             double* hc)
+{
+    qrk_handle h = p->h;
+    qrk::WaveBatch nb{};
+    nb.pivoting = p->solver == QRK_COLPIV_HOUSEHOLDER ? 1 : 0;
+    const int max_blocks = h->num_cus * 16 * 8;   // several tiles per resident wave slot at most
+    if (p->uniform) {
+        nb.num_tiles = p->B; nb.rows = p->r; nb.cols = p->c;
+        const bool full32 = p->r == 32 && p->c == 32 &&
+                            ((reinterpret_cast<uintptr_t>(tiles) | reinterpret_cast<uintptr_t>(q) |
+                              reinterpret_cast<uintptr_t>(r)) & 15u) == 0;
+        qrk::launch_bdqr_wave(nb, full32, tiles, q, r, perm, hc, max_blocks, h->stream);
+    } else {
+        nb.num_tiles = p->n_wave; nb.tile_ids = p->d_wave_ids;
+        nb.t_rows = p->d_rows; nb.t_cols = p->d_cols; nb.t_off = p->d_toff;
+        nb.q_off = p->d_qoff; nb.r_off = p->d_roff; nb.c_off = p->d_coff;
+        qrk::launch_bdqr_wave(nb, false, tiles, q, r, perm, hc, max_blocks, h->stream);
+    }
+    qrk::launch_bd_q_tail_ones(q, p->nnz_q_tiles, p->nnz_q - p->nnz_q_tiles, h->stream);
+    QRK_HIP(h, hipGetLastError());
+    return QRK_STATUS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int qrk_version(void) { return QRK_VERSION_MAJOR * 1000 + QRK_VERSION_MINOR; }
+
+int qrk_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+qrk_status qrk_create(qrk_handle* out, int device, void* stream)
+{
+    if (!out) return fail(nullptr, QRK_STATUS_INVALID_ARGUMENT, "qrk_create: out is NULL");
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+        return fail(nullptr, QRK_STATUS_NO_DEVICE,
+                    "qrk_create: no HIP device visible; this library has no CPU fallback");
+    if (device < 0 || device >= n)
+        return fail(nullptr, QRK_STATUS_INVALID_ARGUMENT, "qrk_create: device index out of range");
+    qrk_context_s* h = new (std::nothrow) qrk_context_s();
+    if (!h) return fail(nullptr, QRK_STATUS_ALLOC_FAILED, "qrk_create: out of host memory");
+    h->device = device;
+    h->stream = static_cast<hipStream_t>(stream);
+    if (hipSetDevice(device) != hipSuccess) {
+        delete h;
+        return fail(nullptr, QRK_STATUS_HIP_ERROR, "qrk_create: hipSetDevice failed");
+    }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) {
+        h->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+            std::string msg = std::string("qrk_create: device is ") + prop.gcnArchName +
+                              ", this library is built for gfx950 (MI355X) only";
+            delete h;
+            return fail(nullptr, QRK_STATUS_UNSUPPORTED, msg);
+        }
+    }
+    *out = h;
+    return QRK_STATUS_OK;
+}
+
+qrk_status qrk_destroy(qrk_handle h)
+{
+    delete h;
+    return QRK_STATUS_OK;
+}
+
+qrk_status qrk_set_stream(qrk_handle h, void* stream)
+{
+    if (!h) return QRK_STATUS_INVALID_ARGUMENT;
+    h->stream = static_cast<hipStream_t>(stream);
+    return QRK_STATUS_OK;
+}
+
+qrk_status qrk_synchronize(qrk_handle h)
+{
+    if (!h) return QRK_STATUS_INVALID_ARGUMENT;
+    QRK_HIP(h, hipStreamSynchronize(h->stream));
+    return QRK_STATUS_OK;
+}
+
+const char* qrk_last_error(qrk_handle h) { return h ? h->error.c_str() : g_create_error.c_str(); }
+
+qrk_status qrk_bd_plan_create(qrk_handle h, const qrk_bd_layout* L, qrk_q_format q_format,
+                              qrk_block_solver solver, qrk_bd_plan* out)
+{
+    if (!h || !L || !out) return fail(h, QRK_STATUS_INVALID_ARGUMENT, "qrk_bd_plan_create: NULL argument");
+    *out = nullptr;
+    if (L->num_blocks < 0 || (L->rows == nullptr) != (L->cols == nullptr))
+        return fail(h, QRK_STATUS_INVALID_ARGUMENT, "qrk_bd_plan_create: bad layout");
+    if (q_format != QRK_FULL_Q && q_format != QRK_BLOCK_DIAGONAL_Q)
+        return fail(h, QRK_STATUS_INVALID_ARGUMENT, "qrk_bd_plan_create: unknown Q format");
+    if (solver != QRK_COLPIV_HOUSEHOLDER && solver != QRK_HOUSEHOLDER)
+        return fail(h, QRK_STATUS_INVALID_ARGUMENT, "qrk_bd_plan_create: unknown block solver");
+    QRK_HIP(h, hipSetDevice(h->device));
+
+    qrk_bd_plan_s* p = new (std::nothrow) qrk_bd_plan_s();
+    if (!p) return fail(h, QRK_STATUS_ALLOC_FAILED, "qrk_bd_plan_create: out of host memory");
+    p->h = h; p->B = L->num_blocks; p->uniform = L->rows == nullptr;
+    p->q_format = q_format; p->solver = solver;
+    p->mat_rows = L->mat_rows; p->mat_cols = L->mat_cols;
+
+    const int64_t B = p->B;
+    int64_t sum_rows = 0, sum_cols = 0;
+    std::vector<int32_t> coff, rowoff, wave_ids;
+    std::vector<int64_t> toff, qoff, roff;
+    if (p->uniform) {
+        p->r = L->block_rows; p->c = L->block_cols;
+        if (p->r <= 0 || p->c <= 0) { delete p; return fail(h, QRK_STATUS_INVALID_ARGUMENT, "qrk_bd_plan_create: non-positive tile size"); }
+        sum_rows = B * p->r; sum_cols = B * p->c;
+        p->tiles_len = B * (int64_t)p->r * p->c;
+        p->nnz_q_tiles = B * (int64_t)p->r * p->r;
+        p->nnz_r = B * (int64_t)(p->c * (p->c + 1) / 2);
+        p->landscape = p->r < p->c;
+        p->max_dim = p->r > p->c ? p->r : p->c;
+    } else {
+        coff.resize(B); rowoff.resize(B); toff.resize(B); qoff.resize(B); roff.resize(B);
+        for (int64_t i = 0; i < B; ++i) {
+            const int32_t r = L->rows[i], c = L->cols[i];
+            if (r <= 0 || c <= 0) { delete p; return fail(h, QRK_STATUS_INVALID_ARGUMENT, "qrk_bd_plan_create: non-positive tile size"); }
+            toff[i] = p->tiles_len; qoff[i] = p->nnz_q_tiles; roff[i] = p->nnz_r;
+            coff[i] = (int32_t)sum_cols; rowoff[i] = (int32_t)sum_rows;
+            p->tiles_len += (int64_t)r * c;
+            p->nnz_q_tiles += (int64_t)r * r;
+            p->nnz_r += (int64_t)c * (c + 1) / 2;
+            sum_rows += r; sum_cols += c;
+            if (r < c) p->landscape = true;
+            const int32_t md = r > c ? r : c;
+            if (md > p->max_dim) p->max_dim = md;
+            if (md <= 32) wave_ids.push_back((int32_t)i);
+        }
+    }
+    if (sum_cols != p->mat_cols || sum_rows > p->mat_rows || sum_rows > INT32_MAX || sum_cols > INT32_MAX) {
+        delete p;
+        return fail(h, QRK_STATUS_INVALID_ARGUMENT,
+                    "qrk_bd_plan_create: mat_cols must equal the sum of tile cols and mat_rows must cover the tile rows");
+    }
+    p->sum_rows = (int32_t)sum_rows;
+    p->nnz_q = p->nnz_q_tiles + (p->mat_rows - sum_rows);
+    if (p->max_dim > 32 && !p->landscape) {
+        delete p;
+        return fail(h, QRK_STATUS_UNSUPPORTED, "qrk_bd_plan_create: tiles larger than 32x32 are not supported yet");
+    }
+    if (!p->uniform) {
+        std::vector<int32_t> rows(L->rows, L->rows + B), cols(L->cols, L->cols + B);
+        qrk_status st;
+        if ((st = upload(h, rows, &p->d_rows)) || (st = upload(h, cols, &p->d_cols)) ||
+            (st = upload(h, coff, &p->d_coff)) || (st = upload(h, rowoff, &p->d_rowoff)) ||
+            (st = upload(h, toff, &p->d_toff)) || (st = upload(h, qoff, &p->d_qoff)) ||
+            (st = upload(h, roff, &p->d_roff)) || (st = upload(h, wave_ids, &p->d_wave_ids))) {
+            qrk_bd_plan_destroy(p);
+            return st;
+        }
+        p->n_wave = (int64_t)wave_ids.size();
+    }
+    *out = p;
+    return QRK_STATUS_OK;
+}
+
+qrk_status qrk_bd_plan_destroy(qrk_bd_plan p)
+{
+    if (!p) return QRK_STATUS_OK;
+    (void)hipFree(p->d_rows); (void)hipFree(p->d_cols); (void)hipFree(p->d_coff); (void)hipFree(p->d_rowoff);
+    (void)hipFree(p->d_toff); (void)hipFree(p->d_qoff); (void)hipFree(p->d_roff); (void)hipFree(p->d_wave_ids);
+    delete p;
+    return QRK_STATUS_OK;
+}
+
+qrk_status qrk_bd_plan_sizes(qrk_bd_plan p, int64_t* tiles_len, int64_t* nnz_q, int64_t* nnz_r)
+{
+    if (!p) return QRK_STATUS_INVALID_ARGUMENT;
+    if (tiles_len) *tiles_len = p->tiles_len;
+    if (nnz_q) *nnz_q = p->nnz_q;
+    if (nnz_r) *nnz_r = p->nnz_r;
+    return QRK_STATUS_OK;
+}
+
+qrk_status qrk_bd_pattern(qrk_bd_plan p, int32_t* q_rowptr, int32_t* q_colidx, int32_t* r_colptr,
+                          int32_t* r_rowidx, qrk_memspace space)
+{
+    if (!p || !q_rowptr || !q_colidx || !r_colptr || !r_rowidx)
+        return fail(p ? p->h : nullptr, QRK_STATUS_INVALID_ARGUMENT, "qrk_bd_pattern: NULL argument");
+    qrk_handle h = p->h;
+    if (p->nnz_q > INT32_MAX || p->nnz_r > INT32_MAX)
+        return fail(h, QRK_STATUS_UNSUPPORTED, "qrk_bd_pattern: nnz exceeds the int32 StorageIndex of the reference");
+    QRK_HIP(h, hipSetDevice(h->device));
+    const qrk::TileGeom g = make_geom(p);
+    if (space == QRK_MEM_DEVICE) {
+        qrk::launch_bd_pattern(g, p->nnz_r, q_rowptr, q_colidx, r_colptr, r_rowidx, h->stream);
+        QRK_HIP(h, hipGetLastError());
+        return QRK_STATUS_OK;
+    }
+    Staging s(h);
+    int32_t *d_qp, *d_qi, *d_rp, *d_ri;
+    qrk_status st;
+    if ((st = s.out(p->mat_rows + 1, &d_qp)) || (st = s.out(p->nnz_q, &d_qi)) ||
+        (st = s.out(p->mat_cols + 1, &d_rp)) || (st = s.out(p->nnz_r, &d_ri)))
+        return st;
+    qrk::launch_bd_pattern(g, p->nnz_r, d_qp, d_qi, d_rp, d_ri, h->stream);
+    QRK_HIP(h, hipGetLastError());
+    if ((st = s.back(q_rowptr, d_qp, p->mat_rows + 1)) || (st = s.back(q_colidx, d_qi, p->nnz_q)) ||
+        (st = s.back(r_colptr, d_rp, p->mat_cols + 1)) || (st = s.back(r_rowidx, d_ri, p->nnz_r)))
+        return st;
+    QRK_HIP(h, hipStreamSynchronize(h->stream));
+    return QRK_STATUS_OK;
+}
+
+qrk_status qrk_bd_factorize(qrk_bd_plan p, const double* tiles, double* q_vals, double* r_vals,
+                            int32_t* perm, double* hcoeffs, qrk_memspace space)
+{
+    if (!p) return QRK_STATUS_INVALID_ARGUMENT;
+    qrk_handle h = p->h;
+    p->factorized = false;
+    if (p->landscape) {   // BlockDiagonalSparseQR.h:509-516: m_info = InvalidInput; return
+        p->factorized = true;
+        return QRK_STATUS_OK;
+    }
+    if (p->B > 0 && (!tiles || !q_vals || !r_vals || !perm))
+        return fail(h, QRK_STATUS_INVALID_ARGUMENT, "qrk_bd_factorize: NULL buffer");
+    QRK_HIP(h, hipSetDevice(h->device));
+    qrk_status st;
+    if (space == QRK_MEM_DEVICE) {
+        if ((st = enqueue_factorize(p, tiles, q_vals, r_vals, perm, hcoeffs))) return st;
+    } else {
+        Staging s(h);
+        double *d_t, *d_q, *d_r, *d_hc = nullptr;
+        int32_t* d_p;
+        if ((st = s.in(tiles, p->tiles_len, &d_t)) || (st = s.out(p->nnz_q, &d_q)) ||
+            (st = s.out(p->nnz_r, &d_r)) || (st = s.out((int64_t)p->mat_cols, &d_p)))
+            return st;
+        if (hcoeffs && (st = s.out((int64_t)p->mat_cols, &d_hc))) return st;
+        if ((st = enqueue_factorize(p, d_t, d_q, d_r, d_p, d_hc))) return st;
+        if ((st = s.back(q_vals, d_q, p->nnz_q)) || (st = s.back(r_vals, d_r, p->nnz_r)) ||
+            (st = s.back(perm, d_p, (int64_t)p->mat_cols)) || (st = s.back(hcoeffs, d_hc, (int64_t)p->mat_cols)))
+            return st;
+        QRK_HIP(h, hipStreamSynchronize(h->stream));
+    }
+    p->factorized = true;
+    return QRK_STATUS_OK;
+}
+
+qrk_status qrk_bd_info(qrk_bd_plan p, qrk_info* info, int64_t* rank)
+{
+    if (!p) return QRK_STATUS_INVALID_ARGUMENT;
+    if (!p->factorized) return fail(p->h, QRK_STATUS_NOT_FACTORIZED, "qrk_bd_info: factorize() has not been called");
+    if (info) *info = p->landscape ? QRK_INFO_INVALID_INPUT : QRK_INFO_SUCCESS;
+    if (rank) *rank = p->mat_cols;   // rank += blockSolver.cols(), BlockDiagonalSparseQR.h:440
+    return QRK_STATUS_OK;
+}
+
+qrk_status qrk_bd_apply_qt(qrk_bd_plan p, const double* q_vals, const double* b, int64_t nrhs, double* y,
+                           qrk_memspace space)
+{
+    if (!p || !q_vals || !b || !y || nrhs < 0)
+        return fail(p ? p->h : nullptr, QRK_STATUS_INVALID_ARGUMENT, "qrk_bd_apply_qt: bad argument");
+    qrk_handle h = p->h;
+    QRK_HIP(h, hipSetDevice(h->device));
+    const qrk::TileGeom g = make_geom(p);
+    if (space == QRK_MEM_DEVICE) {
+        qrk::launch_bd_apply_qt(g, q_vals, b, nrhs, y, h->stream);
+        QRK_HIP(h, hipGetLastError());
+        return QRK_STATUS_OK;
+    }
+    Staging s(h);
+    double *d_q, *d_b, *d_y;
+    qrk_status st;
+    if ((st = s.in(q_vals, p->nnz_q, &d_q)) || (st = s.in(b, nrhs * p->mat_rows, &d_b)) ||
+        (st = s.out(nrhs * p->mat_rows, &d_y)))
+        return st;
+    qrk::launch_bd_apply_qt(g, d_q, d_b, nrhs, d_y, h->stream);
+    QRK_HIP(h, hipGetLastError());
+    if ((st = s.back(y, d_y, nrhs * p->mat_rows))) return st;
+    QRK_HIP(h, hipStreamSynchronize(h->stream));
+    return QRK_STATUS_OK;
+}
+
+qrk_status qrk_bd_solve(qrk_bd_plan p, const double* q_vals, const double* r_vals, const int32_t* perm,
+                        const double* b, int64_t nrhs, double* x, qrk_memspace space)
+{
+    if (!p || !q_vals || !r_vals || !perm || !b || !x || nrhs < 0)
+        return fail(p ? p->h : nullptr, QRK_STATUS_INVALID_ARGUMENT, "qrk_bd_solve: bad argument");
+    qrk_handle h = p->h;
+    if (p->q_format != QRK_FULL_Q)
+        return fail(h, QRK_STATUS_UNSUPPORTED,
+                    "qrk_bd_solve: R is upper triangular only in the FullQ format (BlockDiagonalSparseQR.h:134-154)");
+    if (p->max_dim > 64) return fail(h, QRK_STATUS_UNSUPPORTED, "qrk_bd_solve: tiles wider than 64 columns not supported yet");
+    QRK_HIP(h, hipSetDevice(h->device));
+    const qrk::TileGeom g = make_geom(p);
+    if (space == QRK_MEM_DEVICE) {
+        qrk::launch_bd_solve(g, q_vals, r_vals, perm, b, nrhs, x, h->stream);
+        QRK_HIP(h, hipGetLastError());
+        return QRK_STATUS_OK;
+    }
+    Staging s(h);
+    double *d_q, *d_r, *d_b, *d_x;
+    int32_t* d_p;
+    qrk_status st;
+    if ((st = s.in(q_vals, p->nnz_q, &d_q)) || (st = s.in(r_vals, p->nnz_r, &d_r)) ||
+        (st = s.in(perm, (int64_t)p->mat_cols, &d_p)) || (st = s.in(b, nrhs * p->mat_rows, &d_b)) ||
+        (st = s.out(nrhs * p->mat_cols, &d_x)))
+        return st;
+    qrk::launch_bd_solve(g, d_q, d_r, d_p, d_b, nrhs, d_x, h->stream);
+    QRK_HIP(h, hipGetLastError());
+    if ((st = s.back(x, d_x, nrhs * p->mat_cols))) return st;
+    QRK_HIP(h, hipStreamSynchronize(h->stream));
+    return QRK_STATUS_OK;
+}
+
+qrk_status qrk_bd_time_factorize(qrk_bd_plan p, const double* tiles, double* q_vals, double* r_vals,
+                                 int32_t* perm, int nsets, int iters, float* avg_ms)
+{
+    if (!p || !avg_ms || nsets <= 0 || iters <= 0)
+        return fail(p ? p->h : nullptr, QRK_STATUS_INVALID_ARGUMENT, "qrk_bd_time_factorize: bad argument");
+    qrk_handle h = p->h;
+    if (p->landscape) return fail(h, QRK_STATUS_INVALID_ARGUMENT, "qrk_bd_time_factorize: landscape tile");
+    QRK_HIP(h, hipSetDevice(h->device));
+    hipEvent_t e0, e1;
+    QRK_HIP(h, hipEventCreate(&e0));
+    QRK_HIP(h, hipEventCreate(&e1));
+    QRK_HIP(h, hipEventRecord(e0, h->stream));
+    qrk_status st = QRK_STATUS_OK;
+    for (int it = 0; it < iters && st == QRK_STATUS_OK; ++it) {
+        const int64_t s = it % nsets;
+        st = enqueue_factorize(p, tiles + s * p->tiles_len, q_vals + s * p->nnz_q, r_vals + s * p->nnz_r,
+                               perm + s * (int64_t)p->mat_cols, nullptr);
+    }
+    QRK_HIP(h, hipEventRecord(e1, h->stream));
+    QRK_HIP(h, hipEventSynchronize(e1));
+    float ms = 0.f;
+    QRK_HIP(h, hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *avg_ms = ms / (float)iters;
+    p->factorized = st == QRK_STATUS_OK;
+    return st;
+}
+
+}  // extern "C"

@@ -1,0 +1,102 @@
+// qrk_device.h -- shared device-side declarations for the gfx950 kernels.
+#ifndef QRK_DEVICE_H
+#define QRK_DEVICE_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace qrk {
+
+// Per-launch description of a batch of tiles that all fit one wave (rows, cols <= 32).
+// Uniform batches leave the array pointers null and the kernel derives every
+// offset from the tile index; mixed batches carry explicit per-tile arrays
+// (prefix sums built on the host in qrk_bd_plan_create = the running offsets
+// base_row/base_col of BlockDiagonalSparseQR.h:428-431,524-525).
+struct WaveBatch {
+    int64_t num_tiles;        // tiles in this launch
+    int32_t rows, cols;       // uniform size (used when tile_ids == nullptr)
+    const int32_t* tile_ids;  // [num_tiles] global tile index of each tile of this bin, or null
+    const int32_t* t_rows;    // per global tile (mixed only)
+    const int32_t* t_cols;
+    const int64_t* t_off;     // offset of the tile in `tiles`
+    const int64_t* q_off;     // offset of row 0 of Q_i in q_vals
+    const int64_t* r_off;     // offset of R_i in r_vals
+    const int32_t* c_off;     // base_col of the tile
+    int32_t pivoting;         // 1 = ColPivHouseholderQR, 0 = HouseholderQR
+};
+
+// Per-tile geometry for the auxiliary kernels (uniform batches compute it from the index).
+struct TileGeom {
+    int64_t num_tiles;
+    int32_t rows, cols;          // uniform size when t_rows == nullptr
+    const int32_t* t_rows;
+    const int32_t* t_cols;
+    const int64_t* q_off;        // sum r^2 before the tile
+    const int64_t* r_off;        // sum c(c+1)/2 before the tile
+    const int32_t* c_off;        // base_col
+    const int32_t* row_off;      // base_row
+    int32_t mat_rows, mat_cols;
+    int32_t sum_rows;            // rows covered by tiles; rows beyond get Q(i,i) = 1
+    int64_t nnz_q_tiles;         // sum r^2
+    int32_t q_format;            // 0 FullQ, 1 BlockDiagonalQ
+};
+
+// ---- host-side launchers (defined next to their kernels)
+void launch_bdqr_wave(const WaveBatch& nb, bool full32, const double* tiles, double* q_vals,
+                      double* r_vals, int32_t* perm, double* hcoeffs, int max_blocks,
+                      hipStream_t stream);
+void launch_bd_pattern(const TileGeom& g, int64_t nnz_r, int32_t* q_rowptr, int32_t* q_colidx,
+                       int32_t* r_colptr, int32_t* r_rowidx, hipStream_t stream);
+void launch_bd_q_tail_ones(double* q_vals, int64_t start, int64_t count, hipStream_t stream);
+void launch_bd_apply_qt(const TileGeom& g, const double* q_vals, const double* b, int64_t nrhs,
+                        double* y, hipStream_t stream);
+void launch_bd_solve(const TileGeom& g, const double* q_vals, const double* r_vals,
+                     const int32_t* perm, const double* b, int64_t nrhs, double* x,
+                     hipStream_t stream);
+
+// ---- cross-lane helpers (wave64) ---------------------------------------------------------
+
+__device__ __forceinline__ double readlane_f64(double v, int lane)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_readlane(lo, lane);
+    hi = __builtin_amdgcn_readlane(hi, lane);
+    return __hiloint2double(hi, lo);
+}
+
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+
+// All-reduce max inside every row of 16 lanes: quad xor1, quad xor2, half mirror, row mirror.
+__device__ __forceinline__ double row16_max(double v)
+{
+    v = fmax(v, dpp_f64<0xB1>(v));   // quad_perm [1,0,3,2]
+    v = fmax(v, dpp_f64<0x4E>(v));   // quad_perm [2,3,0,1]
+    v = fmax(v, dpp_f64<0x141>(v));  // row_half_mirror
+    v = fmax(v, dpp_f64<0x140>(v));  // row_mirror
+    return v;
+}
+
+template <int CTRL>
+__device__ __forceinline__ int dpp_i32(int v)
+{
+    return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xF, 0xF, false);
+}
+
+__device__ __forceinline__ int row16_min_i32(int v)
+{
+    v = min(v, dpp_i32<0xB1>(v));
+    v = min(v, dpp_i32<0x4E>(v));
+    v = min(v, dpp_i32<0x141>(v));
+    v = min(v, dpp_i32<0x140>(v));
+    return v;
+}
+
+}  // namespace qrk
+#endif
