@@ -1,0 +1,75 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ (run in the build container, NOT on the GPU box).
+
+The reference (jasvob/QRKit) cannot be built or imported here: it is header-only C++ over Eigen >= 3.3,
+which is absent from this image and from /root/reference, and its own tests hold no golden numbers
+(only invariants, test/test-qrkit.cpp:201-203).  So the fixtures pin VALUES as follows:
+  inputs   : the reference's deterministic generator (libstdc++ default_random_engine +
+             uniform_real_distribution, test/test-qrkit.cpp:64-65,101-117) restated in oracle/qrk_oracle.c,
+             plus seeded U(-1,1) tiles from the same engine;
+  outputs  : the CPU oracle (restatement of Eigen's ColPivHouseholderQR / HouseholderQR /
+             HouseholderSequence and of BlockDiagonalSparseQR::factorize);
+  confirmed: against LAPACK dgeqp3 / dgeqrf via SciPy at generation time (pivots identical, R/Q within
+             1e-13) -- LAPACK uses the same reflector convention and LAWN-176 pivot rule.
+The fixtures are data (inputs + expected outputs) only.
+"""
+import os
+import sys
+
+import numpy as np
+import scipy.linalg as sl
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+from oracle import oracle as orc  # noqa: E402
+
+
+def lapack_confirm(r, c, tiles, res, solver):
+    B = len(tiles) // (r * c)
+    qoff = roff = 0
+    for i in range(B):
+        A = tiles[i * r * c:(i + 1) * r * c].reshape(c, r).T
+        Q = res.Q_vals[qoff:qoff + r * r].reshape(r, r)
+        li = np.tril_indices(c)
+        R = np.zeros((c, c)); R[li[1], li[0]] = res.R_vals[roff:roff + c * (c + 1) // 2]
+        P = res.perm[i * c:(i + 1) * c] - i * c
+        if solver == orc.COLPIV:
+            Qs, Rs, Ps = sl.qr(A, pivoting=True)
+            assert np.array_equal(Ps, P), f"tile {i}: pivots differ from LAPACK dgeqp3"
+        else:
+            Qs, Rs = sl.qr(A)
+            assert np.array_equal(P, np.arange(c))
+        scale = max(np.abs(Rs).max(), 1e-300)
+        assert np.abs(Rs[:c] - R).max() <= 1e-13 * scale, f"tile {i}: R differs from LAPACK"
+        assert np.abs(Qs - Q).max() <= 1e-12, f"tile {i}: Q differs from LAPACK"
+        qoff += r * r; roff += c * (c + 1) // 2
+
+
+def make_case(name, B, r, c, tiles, solver=orc.COLPIV, q_format=orc.FULL_Q, extra_rows=0):
+    rows, cols = np.full(B, r, np.int32), np.full(B, c, np.int32)
+    prob = orc.BDProblem(rows, cols, tiles, matRows=B * r + extra_rows, q_format=q_format, block_solver=solver)
+    res = prob.factorize()
+    assert res.info == 0
+    lapack_confirm(r, c, tiles, res, solver)
+    qp, qi, rp, ri = prob.pattern()
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), rows=rows, cols=cols, tiles=tiles, mat_rows=B * r + extra_rows,
+                        solver=solver, q_format=q_format, Q_vals=res.Q_vals, R_vals=res.R_vals, perm=res.perm,
+                        hcoeffs=res.hcoeffs, rank=res.rank, q_rowptr=qp, q_colidx=qi, r_colptr=rp, r_rowidx=ri)
+    print(f"{name}: {B} tiles {r}x{c} ok")
+
+
+def main():
+    # the reference's own test input: generate_block_diagonal_matrix, first 32 of the 256 7x2 blocks
+    make_case("ref_7x2_colpiv", 32, 7, 2, orc.gen_reference_7x2(32))
+    make_case("ref_7x2_colpiv_bdq", 32, 7, 2, orc.gen_reference_7x2(32), q_format=orc.BLOCK_DIAGONAL_Q, extra_rows=3)
+    make_case("u05_32x32_colpiv", 6, 32, 32, orc.gen_uniform(1, 0.5, 5.0, 6 * 1024))
+    make_case("u11_32x32_colpiv", 6, 32, 32, orc.gen_uniform(2, -1.0, 1.0, 6 * 1024))
+    make_case("u11_32x32_nopiv", 4, 32, 32, orc.gen_uniform(3, -1.0, 1.0, 4 * 1024), solver=orc.NOPIV)
+    make_case("u11_8x6_colpiv", 16, 8, 6, orc.gen_uniform(4, -1.0, 1.0, 16 * 48))
+    make_case("u11_6x6_colpiv", 16, 6, 6, orc.gen_uniform(5, -1.0, 1.0, 16 * 36))
+    make_case("u05_2x1_colpiv", 32, 2, 1, orc.gen_uniform(6, 0.5, 5.0, 32 * 2))
+    make_case("u11_30x20_colpiv", 4, 30, 20, orc.gen_uniform(7, -1.0, 1.0, 4 * 600))
+
+
+if __name__ == "__main__":
+    main()

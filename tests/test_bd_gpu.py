@@ -150,3 +150,47 @@ def test_landscape_tile_is_invalid_input(qa, ctx):
     qr.compute(mat)
     assert qr.info() == qa.INFO_INVALID_INPUT
     assert not qr.m_isInitialized
+
+
+def _dense_from_device(qr, B, r, c):
+    import torch
+    Q = qr.qValues().view(B, r, r)                       # row-major rows of Q_i
+    Rv = qr.rValues().view(B, c * (c + 1) // 2)
+    li = torch.tril_indices(c, c, device=Rv.device)
+    R = torch.zeros(B, c, c, dtype=torch.float64, device=Rv.device)
+    R[:, li[1], li[0]] = Rv                              # packed upper triangle by columns
+    return Q, R
+
+
+@pytest.mark.parametrize("B,r,c", [(10000, 32, 32), (20000, 8, 6), (20000, 6, 6)])
+def test_full_size_properties(qa, ctx, B, r, c):
+    """BASELINE configs[1] (10000 x 32x32) and the left stage of configs[3] at full size: size-independent
+    properties checked on the device for every tile: A P = Q R, Q^T Q = I, valid permutations, plus a sampled
+    comparison with the oracle."""
+    import torch
+    g = torch.Generator(device="cuda"); g.manual_seed(5)
+    tiles = torch.rand(B * r * c, generator=g, device="cuda", dtype=torch.float64) * 2 - 1
+    rows, cols = np.full(B, r, np.int32), np.full(B, c, np.int32)
+    mat = qa.SparseBlockDiagonal.fromTiles(rows, cols, tiles)
+    qr = qa.BlockDiagonalSparseQR(context=ctx)
+    qr.compute(mat)
+    assert qr.info() == 0 and qr.rank() == B * c
+    Q, R = _dense_from_device(qr, B, r, c)
+    A = tiles.view(B, c, r).transpose(1, 2)             # column-major tiles
+    P = torch.as_tensor(qr.colsPermutation(), device="cuda").view(B, c).long() - (torch.arange(B, device="cuda") * c)[:, None]
+    assert bool((P.sort(dim=1).values == torch.arange(c, device="cuda")[None, :]).all())
+    AP = torch.gather(A, 2, P[:, None, :].expand(B, r, c))
+    Rfull = torch.zeros(B, r, c, dtype=torch.float64, device="cuda"); Rfull[:, :c, :] = R
+    err = (torch.bmm(Q, Rfull) - AP).flatten(1).norm(dim=1) / AP.flatten(1).norm(dim=1)
+    assert float(err.max()) <= 1e-13
+    orth = (torch.bmm(Q.transpose(1, 2), Q) - torch.eye(r, dtype=torch.float64, device="cuda")).flatten(1).norm(dim=1)
+    assert float(orth.max()) <= 1e-13
+    # |R_kk| non-increasing (column pivoting)
+    d = R.diagonal(dim1=1, dim2=2).abs()
+    assert bool((d[:, 1:] <= d[:, :-1] * (1 + 1e-12)).all())
+    # sampled tiles against the oracle
+    ns = 300
+    _, ref = oracle_factorize(rows[:ns], cols[:ns], tiles[:ns * r * c].cpu().numpy())
+    np.testing.assert_array_equal(qr.colsPermutation()[:ns * c], ref.perm)
+    assert rel_fro(qr.qValues()[:ns * r * r].cpu().numpy(), ref.Q_vals) <= RTOL
+    assert rel_fro(qr.rValues()[:ns * (c * (c + 1) // 2)].cpu().numpy(), ref.R_vals) <= RTOL
