@@ -8,7 +8,7 @@ LIB       := qrkit_amd/lib/libqrkit_amd.so
 SRCS      := $(wildcard $(CSRC)/*.hip)
 OBJS      := $(patsubst $(CSRC)/%.hip,$(OBJDIR)/%.o,$(SRCS))
 
-all: $(LIB) oracle
+all: $(LIB) oracle cpptest
 
 $(OBJDIR)/%.o: $(CSRC)/%.hip $(CSRC)/qrk_device.h include/qrkit_amd.h
 	@mkdir -p $(OBJDIR)
@@ -21,8 +21,14 @@ $(LIB): $(OBJS)
 oracle:
 	$(MAKE) -C oracle
 
+# C++ facade test (the reference's test_block_diagonal through include/qrkit/QRKit.hpp); needs a GPU to run
+cpptest: $(LIB)
+	@mkdir -p build
+	g++ -O2 -std=c++14 -Wall -Iinclude tests/cpp/test_block_diagonal.cpp -Lqrkit_amd/lib -lqrkit_amd \
+	    -Wl,-rpath,'$$ORIGIN/../qrkit_amd/lib' -o build/test_block_diagonal
+
 clean:
 	rm -rf build $(LIB)
 	$(MAKE) -C oracle clean
 
-.PHONY: all oracle clean
+.PHONY: all oracle clean cpptest

@@ -1,0 +1,104 @@
+// C++ parity test through the facade: the reference's test_block_diagonal
+// (test/test-qrkit.cpp:167-206) on the reference's own input (generate_block_diagonal_matrix,
+// :101-117: default_random_engine + uniform_real_distribution(0.5, 5.0), 7x2 blocks), with the
+// reference's three invariants at 1e-12 (its own bar is 1e-6, test/test.h:31).
+// Also a 32x32 case (BASELINE configs[0] shape) and the landscape -> InvalidInput rule.
+#include <cmath>
+#include <cstdio>
+#include <random>
+
+#include "qrkit/QRKit.hpp"
+
+using namespace qrkit;
+
+static double frob(const Matrix& a) { double s = 0; for (Index i = 0; i < a.rows() * a.cols(); ++i) s += a.data()[i] * a.data()[i]; return std::sqrt(s); }
+
+// Eigen isApprox: ||a-b|| <= prec * min(||a||,||b||)
+static bool approx(const Matrix& a, const Matrix& b, double prec) {
+    Matrix d(a.rows(), a.cols());
+    for (Index i = 0; i < a.rows() * a.cols(); ++i) d.data()[i] = a.data()[i] - b.data()[i];
+    return frob(d) <= prec * std::min(frob(a), frob(b));
+}
+static Matrix matmul(const Matrix& a, const Matrix& b, bool transA) {
+    const Index m = transA ? a.cols() : a.rows(), k = transA ? a.rows() : a.cols(), n = b.cols();
+    Matrix c(m, n);
+    for (Index j = 0; j < n; ++j) for (Index p = 0; p < k; ++p) { const double bv = b(p, j); if (bv == 0) continue;
+        for (Index i = 0; i < m; ++i) c(i, j) += (transA ? a(p, i) : a(i, p)) * bv; }
+    return c;
+}
+
+static void generate_block_diagonal_matrix(Index numParams, Index numResiduals, int blockRows, int blockCols, SparseMatrixColMajor& spJ) {
+    std::default_random_engine gen;
+    std::uniform_real_distribution<double> dist(0.5, 5.0);
+    std::vector<Triplet> jvals;
+    for (int i = 0; i < numParams; i++)
+        for (int j = i * blockCols; j < (i * blockCols) + blockCols && j < numParams; j++)
+            for (int r = 0; r < blockRows; ++r) jvals.emplace_back(i * blockRows + r, j, dist(gen));
+    spJ.resize(numResiduals, numParams);
+    spJ.setFromTriplets(jvals);
+}
+
+static int test_block_diagonal(int numVars, int br, int bc) {
+    const Index numParams = (Index)numVars * bc, numResiduals = (Index)numVars * br;
+    SparseMatrixColMajor spJ;
+    generate_block_diagonal_matrix(numParams, numResiduals, br, bc, spJ);
+    SparseBlockDiagonal blkDiag;
+    blkDiag.fromBlockDiagonalPattern(spJ, br, bc);
+    BlockDiagonalSparseQR<ColPivHouseholderQR> bdqr;
+    bdqr.compute(blkDiag);
+    if (bdqr.info() != Success || bdqr.rank() != numParams) { std::printf("info/rank wrong\n"); return 1; }
+
+    std::mt19937_64 rng(1);
+    std::uniform_real_distribution<double> ud(-1.0, 1.0);
+    Vector x((size_t)numParams);
+    for (double& v : x) v = ud(rng);
+    Vector b = spJ * x;
+    Vector y = bdqr.matrixQ().transposeTimes(b);                       // matrixQ().transpose() * vec   (:187)
+    // R.topLeftCorner(cols, cols).triangularView<Upper>().solve(y.head(cols))        (:191)
+    const SparseMatrixColMajor& R = bdqr.matrixR();
+    Vector solved(y.begin(), y.begin() + numParams);
+    for (Index k = numParams - 1; k >= 0; --k) {
+        const int p0 = R.outerIndex()[(size_t)k], p1 = R.outerIndex()[(size_t)k + 1];
+        solved[(size_t)k] /= R.values()[(size_t)p1 - 1];                 // diagonal is the last entry of the column
+        for (int p = p0; p < p1 - 1; ++p) solved[(size_t)R.innerIndex()[(size_t)p]] -= R.values()[(size_t)p] * solved[(size_t)k];
+    }
+    Vector backperm((size_t)numParams, 0.0);
+    for (Index i = 0; i < numParams; ++i) backperm[(size_t)bdqr.colsPermutation().indices()[(size_t)i]] = solved[(size_t)i];   // (:194-196)
+
+    Matrix J = spJ.toDense(), JP(numResiduals, numParams);
+    for (Index j = 0; j < numParams; ++j) for (Index i = 0; i < numResiduals; ++i) JP(i, j) = J(i, bdqr.colsPermutation().indices()[(size_t)j]);
+    Matrix Qd = bdqr.matrixQ().toDense(), Rd = R.toDense();
+    int fails = 0;
+    if (!approx(matmul(Qd, Rd, false), JP, 1e-12)) { std::printf("Q*R != J*P\n"); ++fails; }            // (:201)
+    if (!approx(matmul(Qd, JP, true), Rd, 1e-12)) { std::printf("Q^T*J*P != R\n"); ++fails; }           // (:202)
+    Matrix xm(numParams, 1), bm(numParams, 1), sm(numParams, 1);
+    Vector viaSolve = bdqr.solve(b);
+    for (Index i = 0; i < numParams; ++i) { xm(i, 0) = x[(size_t)i]; bm(i, 0) = backperm[(size_t)i]; sm(i, 0) = viaSolve[(size_t)i]; }
+    if (!approx(xm, bm, 1e-10)) { std::printf("LS recovery failed\n"); ++fails; }                        // (:203)
+    if (!approx(xm, sm, 1e-10)) { std::printf("solve() recovery failed\n"); ++fails; }
+    Vector yd = bdqr.applyQt(b);
+    for (size_t i = 0; i < y.size(); ++i) if (std::fabs(yd[i] - y[i]) > 1e-12 * (1.0 + std::fabs(y[i]))) { std::printf("applyQt mismatch\n"); ++fails; break; }
+    std::printf("test_block_diagonal %dx%d x %d blocks: %s\n", br, bc, numVars, fails ? "Failed." : "Passed.");
+    return fails;
+}
+
+static int test_landscape() {
+    SparseBlockDiagonal m;
+    Matrix a(2, 3);
+    for (int i = 0; i < 6; ++i) a.data()[i] = i + 1;
+    m.insertBack(a);
+    m.setDims(2, 3);
+    BlockDiagonalSparseQR<> qr;
+    qr.compute(m);
+    const int fails = qr.info() == InvalidInput ? 0 : 1;
+    std::printf("landscape tile -> InvalidInput: %s\n", fails ? "Failed." : "Passed.");
+    return fails;
+}
+
+int main() {
+    int fails = 0;
+    fails += test_block_diagonal(256, 7, 2);     // the reference's main(): numVars = 256 (test-qrkit.cpp:369-377)
+    fails += test_block_diagonal(40, 32, 32);
+    fails += test_landscape();
+    return fails ? 1 : 0;
+}

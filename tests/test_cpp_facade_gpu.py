@@ -1,0 +1,22 @@
+"""GPU: the C++ facade (include/qrkit/QRKit.hpp) runs the reference's test_block_diagonal through the C ABI."""
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.gpu
+def test_cpp_facade_block_diagonal():
+    subprocess.check_call(["make", "-C", ROOT, "-s", "cpptest"])
+    out = subprocess.run([os.path.join(ROOT, "build", "test_block_diagonal")], capture_output=True, text=True, timeout=300)
+    print(out.stdout, out.stderr)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "Failed." not in out.stdout and out.stdout.count("Passed.") == 3
+
+
+def test_cpp_facade_compiles():
+    """CPU: the facade and its test compile and link against the library (no GPU needed)."""
+    subprocess.check_call(["make", "-C", ROOT, "-s", "cpptest"])
+    assert os.path.exists(os.path.join(ROOT, "build", "test_block_diagonal"))
