@@ -38,6 +38,37 @@ constexpr int LDP = WR + 2;   // LDS column stride in doubles: 272 B, conflict-f
 // Row loops of reflector K over the row registers K+1..31.  K is a template parameter so that
 // every register index is static; the k loop stays rolled and dispatches through a uniform
 // switch, which keeps one copy of the per-step scalar code in the instruction cache.
+// sqrt(x) and 1/sqrt(x) for a positive normal x: v_rsq_f64 seed, one Goldschmidt iteration and two
+// residual corrections (the same scheme hipcc uses for sqrt(); here it also yields the reciprocal
+// without an FP64 division).
+__device__ __forceinline__ void sqrt_rsqrt(double x, double& s, double& rs)
+{
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = 0.5 * y;
+    double e = fma(-h, g, 0.5);
+    g = fma(g, e, g);
+    h = fma(h, e, h);
+    double d = fma(-g, g, x);
+    g = fma(d, h, g);
+    d = fma(-g, g, x);
+    g = fma(d, h, g);
+    e = fma(-h, g, 0.5);
+    h = fma(h, e, h);
+    s = g;
+    rs = h + h;
+}
+
+// 1/x by v_rcp_f64 + two Newton steps (<= 1-2 ulp), no v_div_* sequence.
+__device__ __forceinline__ double recip(double x)
+{
+    double y = __builtin_amdgcn_rcp(x);
+    double e = fma(-x, y, 1.0);
+    y = fma(y, e, y);
+    e = fma(-x, y, 1.0);
+    y = fma(y, e, y);
+    return y;
+}
+
 template <int K>
 __device__ __forceinline__ void reflect(double (&a)[WR], int lb, bool upd, bool ispiv,
                                         double& aknew, double& tau_out)
@@ -53,23 +84,25 @@ __device__ __forceinline__ void reflect(double (&a)[WR], int lb, bool upd, bool 
         x[i] = readlane_f64(a[i], lb);
         d = fma(x[i], a[i], d);
     }
-    // makeHouseholder (Eigen/src/Householder/Householder.h)
+    // makeHouseholder (Eigen/src/Householder/Householder.h):
+    //   beta = -sign(x0) sqrt(x0^2 + |tail|^2), tau = (beta - x0)/beta, essential = tail/(x0 - beta)
     const double tailSq = readlane_f64(d, lb);
-    double beta, tau, scale;
-    if (tailSq <= DBL_MIN) {
-        tau = 0.0; beta = xk; scale = 0.0;
-    } else {
-        beta = sqrt(fma(xk, xk, tailSq));
-        if (xk >= 0.0) beta = -beta;
-        scale = 1.0 / (xk - beta);      // essential = tail * scale
-        tau = (beta - xk) / beta;
-    }
+    const bool degen = tailSq <= DBL_MIN;
+    double nrm, inv_nrm;
+    sqrt_rsqrt(fma(xk, xk, tailSq), nrm, inv_nrm);
+    const bool pos0 = xk >= 0.0;
+    double beta = pos0 ? -nrm : nrm;
+    const double inv_beta = pos0 ? -inv_nrm : inv_nrm;
+    const double w = beta - xk;
+    double tau = w * inv_beta;
+    double scale = -recip(w);                    // essential = tail * scale
+    if (degen) { tau = 0.0; beta = xk; scale = 0.0; }
     // applyHouseholderOnTheLeft: tmp = ess^T bottom + row0; row0 -= tau tmp; bottom -= (tau ess) tmp
     const double tmp = fma(scale, d, ak);
-    const double tt = tau * tmp;
-    double an = upd ? ak - tt : ak;
+    const double tt = upd ? tau * tmp : 0.0;
+    double an = ak - tt;
     if (ispiv) an = beta;
-    const double ncoef = upd ? -(tt * scale) : 0.0;
+    const double ncoef = -(tt * scale);
     a[K] = an;
 #pragma unroll
     for (int i = K + 1; i < WR; ++i) a[i] = fma(ncoef, x[i], a[i]);
@@ -98,26 +131,33 @@ __device__ __forceinline__ double tail_sqnorm(const double (&a)[WR])
 
 // One step of ColPivHouseholderQR::computeInPlace (Eigen/src/QR/ColPivHouseholderQR.h) on the
 // wave-resident tile: pivot search, reflector, trailing update (also of Q^T), norm downdate.
+//
+// Column norms are tracked SQUARED (nu2 = m_colNormsUpdated^2, thr_nd2 = sqrt(eps) * m_colNormsDirect^2):
+// Eigen's  temp = (1+t)(1-t), t = |a_kj|/normUpd;  normUpd *= sqrt(temp)  is  nu2 <- max(nu2 - a_kj^2, 0),
+// and its recompute test  temp * (normUpd/normDir)^2 <= sqrt(eps)  is  nu2_new <= sqrt(eps) * normDir^2:
+// the same quantities without two FP64 divisions and a square root per step; the pivot (first maximum)
+// is the same column because squaring is monotone.
 template <int K>
 __device__ __forceinline__ void factor_step_k(double (&a)[WR], double* rrows, int pivoting, int lane,
-                                              bool isA, bool& live, int& pos, double& nupd,
-                                              double& ndir)
+                                              bool isA, bool& live, int& pos, double& nu2,
+                                              double& thr_nd2)
 {
-    // ---- pivot: first maximum of the updated norms over positions K..c-1
+    // ---- pivot: first maximum of the updated norms over positions K..c-1.  Non-negative doubles
+    // order like their bit patterns, so the wave max is an integer max on (hi, lo).
     int lb;
     if (pivoting) {
-        const double key = live ? nupd : -1.0;
-        const double m16 = row16_max(key);
-        const double gm = fmax(readlane_f64(m16, 0), readlane_f64(m16, 16));
-        unsigned long long tie = __ballot(live && key == gm);
-        if (tie == 0ull) tie = __ballot(live && pos == K);   // NaN norms: no swap
-        // first maximum = smallest current position among the tied columns (loop-free)
-        const int pc = ((tie >> lane) & 1ull) ? pos : 64;
-        const int p16 = row16_min_i32(pc);
-        const int p0 = __builtin_amdgcn_readlane(p16, 0), p1 = __builtin_amdgcn_readlane(p16, 16);
-        const int pmin = p0 < p1 ? p0 : p1;
-        lb = __ffsll((long long)__ballot(pc == pmin)) - 1;
-        lb = __builtin_amdgcn_readfirstlane(lb);
+        const int khi = live ? __double2hiint(nu2) : (int)0x80000000;
+        const unsigned klo = (unsigned)__double2loint(nu2);
+        const int mh = half32_max_i32(khi);
+        const unsigned ml = half32_max_u32(khi == mh ? klo : 0u);
+        unsigned long long tie = __ballot(live && khi == mh && klo == ml);
+        if (__popcll(tie) > 1) {
+            // exact tie: Eigen takes the first maximum = smallest CURRENT position
+            const int pc = ((tie >> lane) & 1ull) ? pos : 64;
+            const int pmin = half32_min_i32(pc);
+            tie = __ballot(pc == pmin);
+        }
+        lb = __builtin_amdgcn_readfirstlane(__ffsll((long long)tie) - 1);
         const int bpos = __builtin_amdgcn_readlane(pos, lb);
         if (lane == lb) pos = K;
         else if (live && pos == K) pos = bpos;
@@ -137,32 +177,26 @@ __device__ __forceinline__ void factor_step_k(double (&a)[WR], double* rrows, in
     // register is dead from here on; the epilogue gathers it through the final permutation.
     if (isA && (live || ispiv)) rrows[K * WR + lane] = aknew;
 
-    // ---- LAWN-176 norm downdate for the remaining columns
+    // ---- LAWN-176 norm downdate for the remaining columns (squared form, see above)
     if (pivoting) {
-        bool need = false;
-        if (live && nupd != 0.0) {
-            double tq = fabs(aknew) / nupd;
-            tq = (1.0 + tq) * (1.0 - tq);
-            tq = tq < 0.0 ? 0.0 : tq;
-            const double ratio = nupd / ndir;
-            const double t2 = tq * (ratio * ratio);
-            if (t2 <= 1.4901161193847656e-08) need = true;   // sqrt(DBL_EPSILON)
-            else nupd *= sqrt(tq);
-        }
+        double nn = fma(-aknew, aknew, nu2);
+        nn = nn > 0.0 ? nn : 0.0;
+        const bool need = live && nn <= thr_nd2;
+        nu2 = nn;
         if (__any(need)) {
             const double s = tail_sqnorm<K>(a);
-            if (need) nupd = ndir = sqrt(s);
+            if (need) { nu2 = s; thr_nd2 = s * 1.4901161193847656e-08; }   // sqrt(DBL_EPSILON)
         }
     }
 }
 
 __device__ __forceinline__ void factor_step(int k, double (&a)[WR], double* rrows, int pivoting,
-                                            int lane, bool isA, bool& live, int& pos, double& nupd,
-                                            double& ndir)
+                                            int lane, bool isA, bool& live, int& pos, double& nu2,
+                                            double& thr_nd2)
 {
     // k is a compile-time constant after unrolling; the switch folds to one case.
     switch (k) {
-#define QRK_STEP(K) case K: factor_step_k<K>(a, rrows, pivoting, lane, isA, live, pos, nupd, ndir); break;
+#define QRK_STEP(K) case K: factor_step_k<K>(a, rrows, pivoting, lane, isA, live, pos, nu2, thr_nd2); break;
         QRK_0_31(QRK_STEP)
 #undef QRK_STEP
         default: break;
@@ -233,13 +267,14 @@ bdqr_wave_kernel(WaveBatch nb, const double* __restrict__ tiles, double* __restr
         }
         __syncthreads();   // the LDS image is reused for the outputs
 
-        // ---- column norms (ColPivHouseholderQR: m_colNormsDirect / m_colNormsUpdated)
-        double nupd, ndir;
+        // ---- squared column norms (ColPivHouseholderQR: m_colNormsUpdated^2, sqrt(eps) m_colNormsDirect^2)
+        double nu2, thr_nd2;
         {
             double s = 0.0;
 #pragma unroll
             for (int i = 0; i < WR; ++i) s = fma(a[i], a[i], s);
-            nupd = ndir = sqrt(s);
+            nu2 = s;
+            thr_nd2 = s * 1.4901161193847656e-08;
         }
         bool live = isA && col < c;   // A column not yet chosen as a pivot
         int pos = col;                // current position of this column (Eigen swaps columns)
@@ -250,7 +285,7 @@ bdqr_wave_kernel(WaveBatch nb, const double* __restrict__ tiles, double* __restr
 #pragma unroll
         for (int k = 0; k < WR; ++k) {
             if (FULL32 || k < c)
-                factor_step(k, a, lds, nb.pivoting, lane, isA, live, pos, nupd, ndir);
+                factor_step(k, a, lds, nb.pivoting, lane, isA, live, pos, nu2, thr_nd2);
         }
 
         // ---- R: lds[i*32 + l] holds R(i, final position of original column l).  The packed upper

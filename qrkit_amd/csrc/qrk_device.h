@@ -98,5 +98,37 @@ __device__ __forceinline__ int row16_min_i32(int v)
     return v;
 }
 
+// Max / min over each half of the wave (lanes 0..31 and 32..63 separately), result in every lane of
+// the half: four DPP stages inside the rows of 16, then v_permlane16_swap to combine the two rows.
+__device__ __forceinline__ int half32_max_i32(int v)
+{
+    v = max(v, dpp_i32<0xB1>(v));
+    v = max(v, dpp_i32<0x4E>(v));
+    v = max(v, dpp_i32<0x141>(v));
+    v = max(v, dpp_i32<0x140>(v));
+    const auto r = __builtin_amdgcn_permlane16_swap((unsigned)v, (unsigned)v, false, false);
+    return max((int)r[0], (int)r[1]);
+}
+
+__device__ __forceinline__ unsigned half32_max_u32(unsigned v)
+{
+    v = max(v, (unsigned)dpp_i32<0xB1>((int)v));
+    v = max(v, (unsigned)dpp_i32<0x4E>((int)v));
+    v = max(v, (unsigned)dpp_i32<0x141>((int)v));
+    v = max(v, (unsigned)dpp_i32<0x140>((int)v));
+    const auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+    return max((unsigned)r[0], (unsigned)r[1]);
+}
+
+__device__ __forceinline__ int half32_min_i32(int v)
+{
+    v = min(v, dpp_i32<0xB1>(v));
+    v = min(v, dpp_i32<0x4E>(v));
+    v = min(v, dpp_i32<0x141>(v));
+    v = min(v, dpp_i32<0x140>(v));
+    const auto r = __builtin_amdgcn_permlane16_swap((unsigned)v, (unsigned)v, false, false);
+    return min((int)r[0], (int)r[1]);
+}
+
 }  // namespace qrk
 #endif
