@@ -98,6 +98,30 @@ __device__ __forceinline__ int row16_min_i32(int v)
     return v;
 }
 
+// DPP-fused integer max (one VALU instruction per stage).  The s_nop covers the "VALU write ->
+// DPP read of the same VGPR" hazard (2 wait states), which hipcc does not pad inside asm.
+#define QRK_DPP_OP(NAME, OP, CTRL)                                                              \
+    __device__ __forceinline__ int NAME(int v)                                                  \
+    {                                                                                           \
+        int r;                                                                                  \
+        asm("s_nop 1\n\t" OP " %0, %1, %1 " CTRL " row_mask:0xf bank_mask:0xf"         \
+                     : "=v"(r) : "v"(v));                                                       \
+        return r;                                                                               \
+    }
+QRK_DPP_OP(max_i32_xor1, "v_max_i32_dpp", "quad_perm:[1,0,3,2]")
+QRK_DPP_OP(max_i32_xor2, "v_max_i32_dpp", "quad_perm:[2,3,0,1]")
+QRK_DPP_OP(max_i32_hmir, "v_max_i32_dpp", "row_half_mirror")
+QRK_DPP_OP(max_i32_mir, "v_max_i32_dpp", "row_mirror")
+#undef QRK_DPP_OP
+
+// Max over each half of the wave (lanes 0..31 / 32..63), result in every lane of the half.
+__device__ __forceinline__ int half32_max_i32_fast(int v)
+{
+    v = max_i32_mir(max_i32_hmir(max_i32_xor2(max_i32_xor1(v))));
+    const auto r = __builtin_amdgcn_permlane16_swap((unsigned)v, (unsigned)v, false, false);
+    return max((int)r[0], (int)r[1]);
+}
+
 // Max / min over each half of the wave (lanes 0..31 and 32..63 separately), result in every lane of
 // the half: four DPP stages inside the rows of 16, then v_permlane16_swap to combine the two rows.
 __device__ __forceinline__ int half32_max_i32(int v)
