@@ -8,6 +8,7 @@
 #include "qrk_device.h"
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -23,6 +24,7 @@ struct qrk_context_s {
     int device = 0;
     hipStream_t stream = nullptr;
     int num_cus = 256;
+    bool use_pair_kernel = true;   // two tiles per wavefront (bdqr_pair.hip); QRK_KERNEL=wave selects bdqr_wave.hip
     std::string error;
 };
 
@@ -130,12 +132,14 @@ qrk_status enqueue_factorize(qrk_bd_plan_s* p, const double* tiles, double* q, d
         const bool full32 = p->r == 32 && p->c == 32 &&
                             ((reinterpret_cast<uintptr_t>(tiles) | reinterpret_cast<uintptr_t>(q) |
                               reinterpret_cast<uintptr_t>(r)) & 15u) == 0;
-        qrk::launch_bdqr_wave(nb, full32, tiles, q, r, perm, hc, max_blocks, h->stream);
+        if (h->use_pair_kernel) qrk::launch_bdqr_pair(nb, full32, tiles, q, r, perm, hc, max_blocks, h->stream);
+        else qrk::launch_bdqr_wave(nb, full32, tiles, q, r, perm, hc, max_blocks, h->stream);
     } else {
         nb.num_tiles = p->n_wave; nb.tile_ids = p->d_wave_ids;
         nb.t_rows = p->d_rows; nb.t_cols = p->d_cols; nb.t_off = p->d_toff;
         nb.q_off = p->d_qoff; nb.r_off = p->d_roff; nb.c_off = p->d_coff;
-        qrk::launch_bdqr_wave(nb, false, tiles, q, r, perm, hc, max_blocks, h->stream);
+        if (h->use_pair_kernel) qrk::launch_bdqr_pair(nb, false, tiles, q, r, perm, hc, max_blocks, h->stream);
+        else qrk::launch_bdqr_wave(nb, false, tiles, q, r, perm, hc, max_blocks, h->stream);
     }
     qrk::launch_bd_q_tail_ones(q, p->nnz_q_tiles, p->nnz_q - p->nnz_q_tiles, h->stream);
     QRK_HIP(h, hipGetLastError());
@@ -169,6 +173,7 @@ qrk_status qrk_create(qrk_handle* out, int device, void* stream)
     if (!h) return fail(nullptr, QRK_STATUS_ALLOC_FAILED, "qrk_create: out of host memory");
     h->device = device;
     h->stream = static_cast<hipStream_t>(stream);
+    if (const char* k = std::getenv("QRK_KERNEL")) h->use_pair_kernel = std::strcmp(k, "wave") != 0;
     if (hipSetDevice(device) != hipSuccess) {
         delete h;
         return fail(nullptr, QRK_STATUS_HIP_ERROR, "qrk_create: hipSetDevice failed");

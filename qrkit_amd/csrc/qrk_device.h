@@ -45,6 +45,9 @@ struct TileGeom {
 void launch_bdqr_wave(const WaveBatch& nb, bool full32, const double* tiles, double* q_vals,
                       double* r_vals, int32_t* perm, double* hcoeffs, int max_blocks,
                       hipStream_t stream);
+void launch_bdqr_pair(const WaveBatch& nb, bool full32, const double* tiles, double* q_vals,
+                      double* r_vals, int32_t* perm, double* hcoeffs, int max_blocks,
+                      hipStream_t stream);
 void launch_bd_pattern(const TileGeom& g, int64_t nnz_r, int32_t* q_rowptr, int32_t* q_colidx,
                        int32_t* r_colptr, int32_t* r_rowidx, hipStream_t stream);
 void launch_bd_q_tail_ones(double* q_vals, int64_t start, int64_t count, hipStream_t stream);
