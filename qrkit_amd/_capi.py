@@ -47,11 +47,12 @@ def lib() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    path = os.environ.get("QRKIT_AMD_LIB", LIB_PATH)   # diagnostic builds (tools/stamp_run.py) only
+    if not os.path.exists(path):
         raise ImportError(
-            f"{LIB_PATH} is missing: build the HIP library first (make, or __graft_entry__.build()). "
+            f"{path} is missing: build the HIP library first (make, or __graft_entry__.build()). "
             "qrkit_amd has no CPU fallback.")
-    L = C.CDLL(LIB_PATH)
+    L = C.CDLL(path)
     vp, dp, ip = C.c_void_p, C.c_void_p, C.c_void_p  # device or host addresses travel as integers
     L.qrk_version.restype = C.c_int
     L.qrk_device_count.restype = C.c_int
