@@ -181,12 +181,14 @@ __device__ __forceinline__ void pair_step(double (&a)[WR], double (&q)[WR], doub
     // ---- d = x_tail^T c_tail for the A column and the Q^T column (pivot lane: dA = |x_tail|^2)
     const double ak = a[K], qk = q[K];
     const double xk = hl[L_XBUF + K];
-    double dA = 0.0, dQ = 0.0;
+    double dA0 = 0.0, dQ0 = 0.0, dA1 = 0.0, dQ1 = 0.0;   // two accumulators per chain: half the dependent latency
 #pragma unroll
     for (int i = K + 1; i < WR; ++i) {
         const double xv = hl[L_XBUF + i];   // broadcast read
-        fmac2_shared_a(dA, dQ, xv, a[i], q[i]);
+        if ((i - K) & 1) fmac2_shared_a(dA0, dQ0, xv, a[i], q[i]);
+        else fmac2_shared_a(dA1, dQ1, xv, a[i], q[i]);
     }
+    const double dA = dA0 + dA1, dQ = dQ0 + dQ1;
 
     // ---- makeHouseholder + applyHouseholderOnTheLeft (Eigen/src/Householder/Householder.h) in the
     // un-normalised form: with beta = -sign(x0) sqrt(x0^2 + |tail|^2) and w = beta - x0,
@@ -216,7 +218,7 @@ __device__ __forceinline__ void pair_step(double (&a)[WR], double (&q)[WR], doub
     // Re-read the pivot column from LDS for the update (a broadcast read is nearly free); the opaque
     // offset keeps hipcc from carrying the 31 values of the dot pass in registers / scratch instead.
     int xo = L_XBUF;
-    asm volatile("" : "+v"(xo));
+    // (no launder)
     const double* xb = hl + xo;
 #pragma unroll
     for (int i = K + 1; i < WR; ++i) {
@@ -261,12 +263,11 @@ bdqr_pair_kernel(WaveBatch nb, const double* __restrict__ tiles, double* __restr
 {
     using namespace pair;
     __shared__ __attribute__((aligned(16))) double lds[2 * L_HALF];
-    const int64_t npairs = (nb.num_tiles + 1) / 2;
-    for (int64_t pi = blockIdx.x; pi < npairs; pi += gridDim.x) {
-        // Re-derive the lane id per pair behind an opaque barrier: otherwise hipcc hoists the
-        // identity-column constants and the LDS addresses out of the loop and spills them.
-        int lane = threadIdx.x;
-        asm volatile("" : "+v"(lane));
+    // One pair per workgroup (no grid-stride loop: a loop makes hipcc hoist per-lane addresses out of
+    // it and keep them in scratch across the whole factorisation).
+    {
+        const int64_t pi = blockIdx.x;
+        const int lane = threadIdx.x;
         const int half = lane >> 5, j = lane & 31;
         double* hl = lds + half * L_HALF;
         const int64_t t = 2 * pi + half;
@@ -291,11 +292,13 @@ bdqr_pair_kernel(WaveBatch nb, const double* __restrict__ tiles, double* __restr
         if (FULL32) {
             if (valid) {
                 const double2* src = reinterpret_cast<const double2*>(tiles + toff);
+                for (int q0 = 0; q0 < 16; q0 += 8) {   // two batches of eight 16-B loads per lane
 #pragma unroll
-                for (int qq = 0; qq < 16; ++qq) {
-                    const int e2 = j + 32 * qq;           // double2 index, 16 per column
-                    const double2 v = src[e2];
-                    *reinterpret_cast<double2*>(&hl[L_IMG + (e2 >> 4) * LDP + ((e2 & 15) << 1)]) = v;
+                    for (int qq = 0; qq < 8; ++qq) {
+                        const int e2 = j + 32 * (q0 + qq);    // double2 index, 16 per column
+                        const double2 v = src[e2];
+                        *reinterpret_cast<double2*>(&hl[L_IMG + (e2 >> 4) * LDP + ((e2 & 15) << 1)]) = v;
+                    }
                 }
             }
         } else {
@@ -393,10 +396,12 @@ bdqr_pair_kernel(WaveBatch nb, const double* __restrict__ tiles, double* __restr
         if (FULL32) {
             if (valid) {
                 double2* dst = reinterpret_cast<double2*>(q_vals + qoff);
+                for (int q0 = 0; q0 < 16; q0 += 8) {
 #pragma unroll
-                for (int qq = 0; qq < 16; ++qq) {
-                    const int e2 = j + 32 * qq;
-                    dst[e2] = *reinterpret_cast<const double2*>(&hl[L_IMG + (e2 >> 4) * LDP + ((e2 & 15) << 1)]);
+                    for (int qq = 0; qq < 8; ++qq) {
+                        const int e2 = j + 32 * (q0 + qq);
+                        dst[e2] = *reinterpret_cast<const double2*>(&hl[L_IMG + (e2 >> 4) * LDP + ((e2 & 15) << 1)]);
+                    }
                 }
             }
         } else {
@@ -415,9 +420,9 @@ void launch_bdqr_pair(const WaveBatch& nb, bool full32, const double* tiles, dou
                       hipStream_t stream)
 {
     if (nb.num_tiles <= 0) return;
+    (void)max_blocks;
     const int64_t npairs = (nb.num_tiles + 1) / 2;
-    const int64_t want = npairs < (int64_t)max_blocks ? npairs : (int64_t)max_blocks;
-    const dim3 grid((unsigned)want), block(64);
+    const dim3 grid((unsigned)npairs), block(64);
     if (full32)
         hipLaunchKernelGGL(bdqr_pair_kernel<true>, grid, block, 0, stream, nb, tiles, q_vals, r_vals,
                            perm, hcoeffs);
