@@ -143,6 +143,40 @@ bd_solve_kernel(TileGeom g, const double* __restrict__ q_vals, const double* __r
     }
 }
 
+// _solve_impl for tiles of any size: one workgroup per tile and right-hand side, y in LDS.
+__global__ void __launch_bounds__(256)
+bd_solve_wg_kernel(TileGeom g, const double* __restrict__ q_vals, const double* __restrict__ r_vals,
+                   const int32_t* __restrict__ perm, const double* __restrict__ b, int64_t nrhs,
+                   double* __restrict__ x)
+{
+    extern __shared__ double ysm[];
+    const int tid = threadIdx.x;
+    const int64_t total = g.num_tiles * nrhs;
+    for (int64_t w = blockIdx.x; w < total; w += gridDim.x) {
+        const int64_t t = w % g.num_tiles, rhs = w / g.num_tiles;
+        int r, c, base_row, base_col;
+        int64_t qoff, roff;
+        tile_geom(g, t, r, c, qoff, roff, base_row, base_col);
+        const double* bb = b + rhs * (int64_t)g.mat_rows + base_row;
+        for (int k = tid; k < c; k += blockDim.x) {
+            double s = 0.0;
+            for (int j = 0; j < r; ++j) s = fma(q_vals[qoff + (int64_t)j * r + k], bb[j], s);
+            ysm[k] = s;
+        }
+        __syncthreads();
+        for (int kk = c - 1; kk >= 0; --kk) {
+            const double* colk = r_vals + roff + (int64_t)kk * (kk + 1) / 2;
+            const double piv = ysm[kk] / colk[kk];
+            __syncthreads();
+            if (tid == 0) ysm[kk] = piv;
+            for (int j = tid; j < kk; j += blockDim.x) ysm[j] = fma(-colk[j], piv, ysm[j]);
+            __syncthreads();
+        }
+        for (int k = tid; k < c; k += blockDim.x) x[rhs * (int64_t)g.mat_cols + perm[base_col + k]] = ysm[k];
+        __syncthreads();
+    }
+}
+
 void launch_bd_pattern(const TileGeom& g, int64_t nnz_r, int32_t* q_rowptr, int32_t* q_colidx,
                        int32_t* r_colptr, int32_t* r_rowidx, hipStream_t stream)
 {
@@ -178,13 +212,17 @@ void launch_bd_apply_qt(const TileGeom& g, const double* q_vals, const double* b
                            b, nrhs, y);
 }
 
-void launch_bd_solve(const TileGeom& g, const double* q_vals, const double* r_vals, const int32_t* perm,
+void launch_bd_solve(const TileGeom& g, int max_cols, const double* q_vals, const double* r_vals, const int32_t* perm,
                      const double* b, int64_t nrhs, double* x, hipStream_t stream)
 {
     const int64_t total = g.num_tiles * nrhs;
     if (total <= 0) return;
     const unsigned grid = (unsigned)(total < 262144 ? total : 262144);
-    hipLaunchKernelGGL(bd_solve_kernel, dim3(grid), dim3(64), 0, stream, g, q_vals, r_vals, perm, b, nrhs, x);
+    if (max_cols <= 64)
+        hipLaunchKernelGGL(bd_solve_kernel, dim3(grid), dim3(64), 0, stream, g, q_vals, r_vals, perm, b, nrhs, x);
+    else
+        hipLaunchKernelGGL(bd_solve_wg_kernel, dim3(grid), dim3(256), (size_t)max_cols * sizeof(double), stream, g, q_vals,
+                           r_vals, perm, b, nrhs, x);
 }
 
 }  // namespace qrk

@@ -14,6 +14,8 @@
 #include <string>
 #include <vector>
 
+#define QRK_WG_MAX_DIM 2048
+
 namespace {
 
 thread_local std::string g_create_error;
@@ -42,8 +44,13 @@ struct qrk_bd_plan_s {
     // device-resident per-tile descriptors (mixed batches only)
     int32_t *d_rows = nullptr, *d_cols = nullptr, *d_coff = nullptr, *d_rowoff = nullptr;
     int64_t *d_toff = nullptr, *d_qoff = nullptr, *d_roff = nullptr;
-    int32_t* d_wave_ids = nullptr;   // tiles handled by the one-wave kernel
+    int32_t* d_wave_ids = nullptr;   // tiles with rows, cols <= 32: half-wave kernels
     int64_t n_wave = 0;
+    int32_t* d_wg_ids = nullptr;     // larger tiles: one workgroup each (bdqr_wg.hip)
+    int64_t n_wg = 0;
+    double* d_workspace = nullptr;   // per-workgroup working copies of the large tiles
+    int64_t ws_stride = 0;
+    int num_wg = 0;
 };
 
 namespace {
@@ -132,7 +139,9 @@ qrk_status enqueue_factorize(qrk_bd_plan_s* p, const double* tiles, double* q, d
         const bool full32 = p->r == 32 && p->c == 32 &&
                             ((reinterpret_cast<uintptr_t>(tiles) | reinterpret_cast<uintptr_t>(q) |
                               reinterpret_cast<uintptr_t>(r)) & 15u) == 0;
-        if (h->use_pair_kernel) qrk::launch_bdqr_pair(nb, full32, tiles, q, r, perm, hc, max_blocks, h->stream);
+        if (p->max_dim > 32)
+            qrk::launch_bdqr_wg(nb, tiles, q, r, perm, hc, p->d_workspace, p->ws_stride, p->num_wg, p->max_dim, h->stream);
+        else if (h->use_pair_kernel) qrk::launch_bdqr_pair(nb, full32, tiles, q, r, perm, hc, max_blocks, h->stream);
         else qrk::launch_bdqr_wave(nb, full32, tiles, q, r, perm, hc, max_blocks, h->stream);
     } else {
         nb.num_tiles = p->n_wave; nb.tile_ids = p->d_wave_ids;
@@ -140,6 +149,11 @@ qrk_status enqueue_factorize(qrk_bd_plan_s* p, const double* tiles, double* q, d
         nb.q_off = p->d_qoff; nb.r_off = p->d_roff; nb.c_off = p->d_coff;
         if (h->use_pair_kernel) qrk::launch_bdqr_pair(nb, false, tiles, q, r, perm, hc, max_blocks, h->stream);
         else qrk::launch_bdqr_wave(nb, false, tiles, q, r, perm, hc, max_blocks, h->stream);
+        if (p->n_wg > 0) {
+            qrk::WaveBatch lb = nb;
+            lb.num_tiles = p->n_wg; lb.tile_ids = p->d_wg_ids;
+            qrk::launch_bdqr_wg(lb, tiles, q, r, perm, hc, p->d_workspace, p->ws_stride, p->num_wg, p->max_dim, h->stream);
+        }
     }
     qrk::launch_bd_q_tail_ones(q, p->nnz_q_tiles, p->nnz_q - p->nnz_q_tiles, h->stream);
     QRK_HIP(h, hipGetLastError());
@@ -235,7 +249,8 @@ qrk_status qrk_bd_plan_create(qrk_handle h, const qrk_bd_layout* L, qrk_q_format
 
     const int64_t B = p->B;
     int64_t sum_rows = 0, sum_cols = 0;
-    std::vector<int32_t> coff, rowoff, wave_ids;
+    std::vector<int32_t> coff, rowoff, wave_ids, wg_ids;
+    int64_t ws_stride = 0;
     std::vector<int64_t> toff, qoff, roff;
     if (p->uniform) {
         p->r = L->block_rows; p->c = L->block_cols;
@@ -246,6 +261,7 @@ qrk_status qrk_bd_plan_create(qrk_handle h, const qrk_bd_layout* L, qrk_q_format
         p->nnz_r = B * (int64_t)(p->c * (p->c + 1) / 2);
         p->landscape = p->r < p->c;
         p->max_dim = p->r > p->c ? p->r : p->c;
+        if (p->max_dim > 32) ws_stride = (int64_t)p->r * p->c;
     } else {
         coff.resize(B); rowoff.resize(B); toff.resize(B); qoff.resize(B); roff.resize(B);
         for (int64_t i = 0; i < B; ++i) {
@@ -261,6 +277,7 @@ qrk_status qrk_bd_plan_create(qrk_handle h, const qrk_bd_layout* L, qrk_q_format
             const int32_t md = r > c ? r : c;
             if (md > p->max_dim) p->max_dim = md;
             if (md <= 32) wave_ids.push_back((int32_t)i);
+            else { wg_ids.push_back((int32_t)i); if ((int64_t)r * c > ws_stride) ws_stride = (int64_t)r * c; }
         }
     }
     if (sum_cols != p->mat_cols || sum_rows > p->mat_rows || sum_rows > INT32_MAX || sum_cols > INT32_MAX) {
@@ -270,9 +287,18 @@ qrk_status qrk_bd_plan_create(qrk_handle h, const qrk_bd_layout* L, qrk_q_format
     }
     p->sum_rows = (int32_t)sum_rows;
     p->nnz_q = p->nnz_q_tiles + (p->mat_rows - sum_rows);
-    if (p->max_dim > 32 && !p->landscape) {
+    if (p->max_dim > QRK_WG_MAX_DIM && !p->landscape) {
         delete p;
-        return fail(h, QRK_STATUS_UNSUPPORTED, "qrk_bd_plan_create: tiles larger than 32x32 are not supported yet");
+        return fail(h, QRK_STATUS_UNSUPPORTED, "qrk_bd_plan_create: tile dimension above 2048 is not supported");
+    }
+    if (ws_stride > 0 && !p->landscape) {
+        const int64_t n_large = p->uniform ? B : (int64_t)wg_ids.size();
+        p->num_wg = (int)(n_large < 2 * (int64_t)h->num_cus ? n_large : 2 * (int64_t)h->num_cus);
+        p->ws_stride = ws_stride;
+        if (hipMalloc((void**)&p->d_workspace, (size_t)p->num_wg * (size_t)ws_stride * sizeof(double)) != hipSuccess) {
+            delete p;
+            return fail(h, QRK_STATUS_ALLOC_FAILED, "qrk_bd_plan_create: cannot allocate the large-tile workspace");
+        }
     }
     if (!p->uniform) {
         std::vector<int32_t> rows(L->rows, L->rows + B), cols(L->cols, L->cols + B);
@@ -280,11 +306,13 @@ qrk_status qrk_bd_plan_create(qrk_handle h, const qrk_bd_layout* L, qrk_q_format
         if ((st = upload(h, rows, &p->d_rows)) || (st = upload(h, cols, &p->d_cols)) ||
             (st = upload(h, coff, &p->d_coff)) || (st = upload(h, rowoff, &p->d_rowoff)) ||
             (st = upload(h, toff, &p->d_toff)) || (st = upload(h, qoff, &p->d_qoff)) ||
-            (st = upload(h, roff, &p->d_roff)) || (st = upload(h, wave_ids, &p->d_wave_ids))) {
+            (st = upload(h, roff, &p->d_roff)) || (st = upload(h, wave_ids, &p->d_wave_ids)) ||
+            (st = upload(h, wg_ids, &p->d_wg_ids))) {
             qrk_bd_plan_destroy(p);
             return st;
         }
         p->n_wave = (int64_t)wave_ids.size();
+        p->n_wg = (int64_t)wg_ids.size();
     }
     *out = p;
     return QRK_STATUS_OK;
@@ -295,6 +323,7 @@ qrk_status qrk_bd_plan_destroy(qrk_bd_plan p)
     if (!p) return QRK_STATUS_OK;
     (void)hipFree(p->d_rows); (void)hipFree(p->d_cols); (void)hipFree(p->d_coff); (void)hipFree(p->d_rowoff);
     (void)hipFree(p->d_toff); (void)hipFree(p->d_qoff); (void)hipFree(p->d_roff); (void)hipFree(p->d_wave_ids);
+    (void)hipFree(p->d_wg_ids); (void)hipFree(p->d_workspace);
     delete p;
     return QRK_STATUS_OK;
 }
@@ -416,11 +445,10 @@ qrk_status qrk_bd_solve(qrk_bd_plan p, const double* q_vals, const double* r_val
     if (p->q_format != QRK_FULL_Q)
         return fail(h, QRK_STATUS_UNSUPPORTED,
                     "qrk_bd_solve: R is upper triangular only in the FullQ format (BlockDiagonalSparseQR.h:134-154)");
-    if (p->max_dim > 64) return fail(h, QRK_STATUS_UNSUPPORTED, "qrk_bd_solve: tiles wider than 64 columns not supported yet");
     QRK_HIP(h, hipSetDevice(h->device));
     const qrk::TileGeom g = make_geom(p);
     if (space == QRK_MEM_DEVICE) {
-        qrk::launch_bd_solve(g, q_vals, r_vals, perm, b, nrhs, x, h->stream);
+        qrk::launch_bd_solve(g, p->max_dim, q_vals, r_vals, perm, b, nrhs, x, h->stream);
         QRK_HIP(h, hipGetLastError());
         return QRK_STATUS_OK;
     }
@@ -432,7 +460,7 @@ qrk_status qrk_bd_solve(qrk_bd_plan p, const double* q_vals, const double* r_val
         (st = s.in(perm, (int64_t)p->mat_cols, &d_p)) || (st = s.in(b, nrhs * p->mat_rows, &d_b)) ||
         (st = s.out(nrhs * p->mat_cols, &d_x)))
         return st;
-    qrk::launch_bd_solve(g, d_q, d_r, d_p, d_b, nrhs, d_x, h->stream);
+    qrk::launch_bd_solve(g, p->max_dim, d_q, d_r, d_p, d_b, nrhs, d_x, h->stream);
     QRK_HIP(h, hipGetLastError());
     if ((st = s.back(x, d_x, nrhs * p->mat_cols))) return st;
     QRK_HIP(h, hipStreamSynchronize(h->stream));

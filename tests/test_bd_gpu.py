@@ -194,3 +194,38 @@ def test_full_size_properties(qa, ctx, B, r, c):
     np.testing.assert_array_equal(qr.colsPermutation()[:ns * c], ref.perm)
     assert rel_fro(qr.qValues()[:ns * r * r].cpu().numpy(), ref.Q_vals) <= RTOL
     assert rel_fro(qr.rValues()[:ns * (c * (c + 1) // 2)].cpu().numpy(), ref.R_vals) <= RTOL
+
+
+@pytest.mark.parametrize("B,r,c,seed", [(12, 64, 64, 1), (7, 100, 37, 2), (5, 33, 33, 3), (3, 256, 256, 4), (4, 200, 129, 5)])
+@pytest.mark.parametrize("solver", [0, 1])
+def test_large_tiles_match_oracle(qa, ctx, B, r, c, seed, solver):
+    """Tiles larger than 32x32 (workgroup-per-tile kernel), sizes of BASELINE configs[4] (8..256)."""
+    tiles = seeded_tiles(seed, -1.0, 1.0, B * r * c)
+    rows, cols = np.full(B, r, np.int32), np.full(B, c, np.int32)
+    _, qr = run_gpu(qa, ctx, rows, cols, tiles, solver=solver)
+    _, ref = oracle_factorize(rows, cols, tiles, block_solver=solver)
+    compare(qr, ref)
+
+
+def test_mixed_sizes_8_to_256_match_oracle(qa, ctx):
+    """BASELINE configs[4] shape at reduced count: square tiles n ~ U{8..256}, mixed in one batch
+    (small ones go to the half-wave kernel, large ones to the workgroup kernel)."""
+    rng = np.random.default_rng(12345)
+    B = 120
+    n = rng.integers(8, 257, B).astype(np.int32)
+    tiles = seeded_tiles(21, -1.0, 1.0, int((n.astype(np.int64) ** 2).sum()))
+    _, qr = run_gpu(qa, ctx, n, n, tiles)
+    prob, ref = oracle_factorize(n, n, tiles)
+    compare(qr, ref)
+    for got, want in zip(qr.pattern(), prob.pattern()):
+        np.testing.assert_array_equal(got, want)
+
+
+def test_solve_large_tiles(qa, ctx):
+    B, r, c = 6, 150, 90
+    tiles = seeded_tiles(8, -1.0, 1.0, B * r * c)
+    rows, cols = np.full(B, r, np.int32), np.full(B, c, np.int32)
+    _, qr = run_gpu(qa, ctx, rows, cols, tiles)
+    prob, ref = oracle_factorize(rows, cols, tiles)
+    b = np.random.default_rng(2).uniform(-1, 1, (B * r, 2))
+    assert rel_fro(qr.solve(b), prob.solve(ref, b)) <= 1e-10
