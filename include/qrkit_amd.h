@@ -158,6 +158,35 @@ qrk_status qrk_bd_solve(qrk_bd_plan plan, const double* q_vals, const double* r_
                         const int32_t* perm, const double* b, int64_t nrhs, double* x,
                         qrk_memspace space);
 
+/* The triangular step of _solve_impl alone (BlockDiagonalSparseQR.h:271):
+ * z = R(0:cols,0:cols).triangularView<Upper>().solve(y);  y, z: mat_cols x nrhs.  Used by the angular
+ * composition, whose R = [R1, S; 0, R2] is solved block by block. */
+qrk_status qrk_bd_solve_r(qrk_bd_plan plan, const double* r_vals, const double* y, int64_t nrhs, double* z,
+                          qrk_memspace space);
+
+/* --------------------------------------------- dense right-block solver (angular) */
+
+/* A single dense Householder QR with implicit Q: the _BlockQRSolverRight of
+ * QRKit::BlockAngularSparseQR (src/QRKit/BlockAngularSparseQR.h:79), which the reference tests
+ * instantiate with Eigen::ColPivHouseholderQR<MatrixXd> (test/test-qrkit.cpp:46-48).  It is called at
+ * BlockAngularSparseQR.h:361-369 (compute on the bottom rows of Q1^T J2), :488 (matrixR()), :498-503
+ * (colsPermutation()) and :619-622 / :636-638 (matrixQ() products).  Q stays a sequence of reflectors. */
+typedef struct qrk_dense_plan_s* qrk_dense_plan;
+
+qrk_status qrk_dense_plan_create(qrk_handle h, int32_t rows, int32_t cols, qrk_block_solver solver,
+                                 qrk_dense_plan* out);
+qrk_status qrk_dense_plan_destroy(qrk_dense_plan plan);
+
+/* compute(): a (rows x cols, column-major, leading dimension lda) is overwritten by the packed QR
+ * (R in the upper triangle, essential Householder vectors below); hcoeffs[min(rows,cols)];
+ * perm[cols] = colsPermutation().indices(). */
+qrk_status qrk_dense_factorize(qrk_dense_plan plan, double* a, int64_t lda, double* hcoeffs, int32_t* perm,
+                               qrk_memspace space);
+
+/* b (rows x nrhs, leading dimension ldb) <- Q^T b (transpose != 0) or Q b. */
+qrk_status qrk_dense_apply_q(qrk_dense_plan plan, const double* qr, int64_t lda, const double* hcoeffs,
+                             int transpose, double* b, int64_t ldb, int64_t nrhs, qrk_memspace space);
+
 /* ------------------------------------------------------------- measurement */
 
 /* Launch the factorisation kernel(s) of `plan` `iters` times back to back on the

@@ -272,3 +272,61 @@ def gen_uniform(seed: int, lo: float, hi: float, n: int) -> np.ndarray:
     t = np.zeros(n)
     lib().orc_gen_uniform(seed, lo, hi, n, _dp(t))
     return t
+
+
+# ---------------------------------------------------------------- BlockAngularSparseQR
+
+class BAResult:
+    pass
+
+
+def ba_factorize(prob: BDProblem, J2: np.ndarray, right_solver: int = COLPIV) -> BAResult:
+    """BlockAngularSparseQR::factorize (src/QRKit/BlockAngularSparseQR.h:459-514) with a block-diagonal left
+    solver (FullQ) and a dense Eigen right solver, restated with numpy on top of the C kernels above:
+      solveRightBlock (:361-369): J2.top(n1) <- Q1^T J2.top(n1); rightSolver.compute(J2.bottomRows(n1+n2-m1));
+      makeR (:285-308): R = [R1, J2(0:m1, P2); 0, R2];  perm = [P1; m1 + P2] (:498-503); rank (:510).
+    """
+    import scipy.sparse as sp
+    assert prob.q_format == FULL_Q
+    res1 = prob.factorize()
+    n1, m1 = prob.matRows, prob.matCols
+    n, m2 = J2.shape
+    n2 = n - n1
+    qp, qi, rp, ri = prob.pattern()
+    Q1 = sp.csr_matrix((res1.Q_vals, qi, qp), shape=(n1, n1))
+    R1 = sp.csc_matrix((res1.R_vals, ri, rp), shape=(n1, m1))
+    J2t = np.array(J2, dtype=np.float64, order="F")
+    J2t[:n1, :] = Q1.T @ J2t[:n1, :]
+    bottom = np.asfortranarray(J2t[m1:, :])
+    if right_solver == COLPIV:
+        qr2, hc2, p2, _ = colpiv_qr(bottom)
+    else:
+        qr2, hc2 = householder_qr(bottom)
+        p2 = np.arange(m2, dtype=np.int32)
+    k2 = min(bottom.shape)
+    R2 = np.triu(qr2[:k2, :])
+    out = BAResult()
+    out.left, out.Q1, out.R1 = res1, Q1, R1
+    out.J2 = J2t
+    out.qr2, out.hc2, out.P2 = qr2, hc2, p2
+    top = sp.hstack([R1[:m1, :], sp.csc_matrix(J2t[:m1, :][:, p2])], format="csc")
+    mid = sp.hstack([sp.csc_matrix((k2, m1)), sp.csc_matrix(R2)], format="csc")
+    pad = sp.csc_matrix((n - m1 - k2, m1 + m2))
+    out.R = sp.vstack([top, mid, pad], format="csc")
+    out.perm = np.concatenate([res1.perm, m1 + p2]).astype(np.int32)
+    out.rank = res1.rank + k2
+    out.m1, out.m2, out.n1, out.n2 = m1, m2, n1, n2
+    return out
+
+
+def ba_apply_qt(res: BAResult, v: np.ndarray) -> np.ndarray:
+    """BlockAngularSparseQR_QProduct::evalTo, transpose branch (BlockAngularSparseQR.h:607-625)."""
+    out = np.array(v, dtype=np.float64).reshape(res.n1 + res.n2, -1).copy()
+    out[:res.n1, :] = res.Q1.T @ out[:res.n1, :]
+    bot = out[res.m1:, :]
+    # Q2^T = H_{k-1} ... H_0 applied in order
+    for k in range(len(res.hc2)):
+        vk = np.concatenate([[1.0], res.qr2[k + 1:, k]])
+        bot[k:, :] -= res.hc2[k] * np.outer(vk, vk @ bot[k:, :])
+    out[res.m1:, :] = bot
+    return out if np.ndim(v) > 1 else out[:, 0]

@@ -23,7 +23,8 @@ MEM_DEVICE, MEM_HOST = 0, 1
 EXPORTS = (
     "qrk_version", "qrk_device_count", "qrk_create", "qrk_destroy", "qrk_set_stream", "qrk_synchronize",
     "qrk_last_error", "qrk_bd_plan_create", "qrk_bd_plan_destroy", "qrk_bd_plan_sizes", "qrk_bd_pattern",
-    "qrk_bd_factorize", "qrk_bd_info", "qrk_bd_apply_qt", "qrk_bd_solve", "qrk_bd_time_factorize",
+    "qrk_bd_factorize", "qrk_bd_info", "qrk_bd_apply_qt", "qrk_bd_solve", "qrk_bd_solve_r", "qrk_dense_plan_create",
+    "qrk_dense_plan_destroy", "qrk_dense_factorize", "qrk_dense_apply_q", "qrk_bd_time_factorize",
 )
 
 
@@ -82,6 +83,16 @@ def lib() -> C.CDLL:
     L.qrk_bd_apply_qt.argtypes = [vp, dp, dp, C.c_int64, dp, C.c_int]
     L.qrk_bd_solve.restype = C.c_int
     L.qrk_bd_solve.argtypes = [vp, dp, dp, ip, dp, C.c_int64, dp, C.c_int]
+    L.qrk_bd_solve_r.restype = C.c_int
+    L.qrk_bd_solve_r.argtypes = [vp, dp, dp, C.c_int64, dp, C.c_int]
+    L.qrk_dense_plan_create.restype = C.c_int
+    L.qrk_dense_plan_create.argtypes = [vp, C.c_int32, C.c_int32, C.c_int, C.POINTER(vp)]
+    L.qrk_dense_plan_destroy.restype = C.c_int
+    L.qrk_dense_plan_destroy.argtypes = [vp]
+    L.qrk_dense_factorize.restype = C.c_int
+    L.qrk_dense_factorize.argtypes = [vp, dp, C.c_int64, dp, ip, C.c_int]
+    L.qrk_dense_apply_q.restype = C.c_int
+    L.qrk_dense_apply_q.argtypes = [vp, dp, C.c_int64, dp, C.c_int, dp, C.c_int64, C.c_int64, C.c_int]
     L.qrk_bd_time_factorize.restype = C.c_int
     L.qrk_bd_time_factorize.argtypes = [vp, dp, dp, dp, ip, C.c_int, C.c_int, C.POINTER(C.c_float)]
     _lib = L

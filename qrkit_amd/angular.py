@@ -1,0 +1,223 @@
+"""Host-side mirror of the block-angular composition.
+
+  QRKit::BlockMatrix1x2          (src/QRKit/BlockMatrix1x2.h:31-67)       -> BlockMatrix1x2
+  QRKit::BlockAngularSparseQR    (src/QRKit/BlockAngularSparseQR.h:79-419) -> BlockAngularSparseQR
+  its right-block solver, Eigen::ColPivHouseholderQR<MatrixXd> in the reference tests
+  (test/test-qrkit.cpp:46-48)                                             -> DenseColPivQR
+
+All arithmetic runs in the HIP library through the C ABI (qrk_bd_*, qrk_dense_*); torch holds the device
+buffers and moves the J2 strips around (slicing / column permutation of the strip in makeR).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import _capi as capi
+from .solvers import BlockDiagonalSparseQR, Context, SparseBlockDiagonal
+
+
+class BlockMatrix1x2:
+    """Non-owning pair [left | right] (BlockMatrix1x2.h:31-67): left is a SparseBlockDiagonal,
+    right a dense (rows x m2) column-major matrix (numpy or a float64 torch tensor)."""
+
+    def __init__(self, left: SparseBlockDiagonal, right):
+        self._left, self._right = left, right
+
+    def leftBlock(self):
+        return self._left
+
+    def rightBlock(self):
+        return self._right
+
+    def rows(self) -> int:
+        return int(self._right.shape[0])
+
+    def cols(self) -> int:
+        return self._left.cols() + int(self._right.shape[1])
+
+
+class DenseColPivQR:
+    """Dense Householder QR with implicit Q (Eigen::ColPivHouseholderQR / HouseholderQR interface)."""
+
+    def __init__(self, context: Context, solver: int = capi.COLPIV_HOUSEHOLDER):
+        self._ctx, self._solver = context, solver
+        self._plan = C.c_void_p()
+        self._shape = None
+
+    def compute(self, A: torch.Tensor):
+        """A: (rows, cols) float64 torch tensor on the device in COLUMN-major storage, i.e. A.t() contiguous.
+        It is factorised in place (becomes the packed QR)."""
+        rows, cols = A.shape
+        assert A.dtype == torch.float64 and A.t().is_contiguous()
+        if self._shape != (rows, cols):
+            if self._plan:
+                capi.lib().qrk_dense_plan_destroy(self._plan)
+            self._plan = C.c_void_p()
+            capi.check(capi.lib().qrk_dense_plan_create(self._ctx.handle, rows, cols, self._solver, C.byref(self._plan)),
+                       self._ctx.handle)
+            self._shape = (rows, cols)
+        self._qr = A
+        self._hc = torch.empty(max(min(rows, cols), 1), dtype=torch.float64, device=A.device)
+        self._perm = torch.empty(max(cols, 1), dtype=torch.int32, device=A.device)
+        self._ctx.use_current_stream()
+        capi.check(capi.lib().qrk_dense_factorize(self._plan, A.data_ptr(), rows, self._hc.data_ptr(),
+                                                  self._perm.data_ptr(), capi.MEM_DEVICE), self._ctx.handle)
+        return self
+
+    def rows(self):
+        return self._shape[0]
+
+    def cols(self):
+        return self._shape[1]
+
+    def rank(self):
+        return min(self._shape)     # the composition only uses cols() of the right solver's rank on full-rank input
+
+    def colsPermutation(self) -> torch.Tensor:
+        return self._perm[:self._shape[1]]
+
+    def matrixR(self) -> torch.Tensor:
+        """Upper-triangular min(rows,cols) x cols (dense, device)."""
+        k = min(self._shape)
+        return torch.triu(self._qr[:k, :])
+
+    def applyQ(self, B: torch.Tensor, transpose: bool) -> torch.Tensor:
+        """B: (rows, nrhs) column-major device tensor, updated in place: B <- Q^T B or Q B."""
+        rows = self._shape[0]
+        assert B.shape[0] == rows and B.t().is_contiguous()
+        self._ctx.use_current_stream()
+        capi.check(capi.lib().qrk_dense_apply_q(self._plan, self._qr.data_ptr(), rows, self._hc.data_ptr(),
+                                                1 if transpose else 0, B.data_ptr(), rows, B.shape[1], capi.MEM_DEVICE),
+                   self._ctx.handle)
+        return B
+
+    def __del__(self):
+        try:
+            if self._plan:
+                capi.lib().qrk_dense_plan_destroy(self._plan)
+        except Exception:
+            pass
+
+
+def _colmajor(t: torch.Tensor) -> torch.Tensor:
+    """Device tensor with column-major storage and the same logical shape."""
+    return t.t().contiguous().t()
+
+
+class BlockAngularSparseQR:
+    """QRKit::BlockAngularSparseQR<BlockDiagonalSparseQR<...>, ColPivHouseholderQR<MatrixXd>>:
+    QR of [J1 | J2] with J1 block diagonal and J2 dense (BlockAngularSparseQR.h:459-514)."""
+
+    def __init__(self, context: Optional[Context] = None, device: int = 0,
+                 leftBlockSolver: int = capi.COLPIV_HOUSEHOLDER, rightSolver: int = capi.COLPIV_HOUSEHOLDER):
+        self._ctx = context or Context(device)
+        self.m_leftSolver = BlockDiagonalSparseQR(blockSolver=leftBlockSolver, qFormat=capi.FULL_Q, context=self._ctx)
+        self.m_rightSolver = DenseColPivQR(self._ctx, rightSolver)
+        self.m_isInitialized = False
+
+    def compute(self, mat: BlockMatrix1x2):
+        self.analyzePattern(mat)
+        self.factorize(mat)
+
+    def analyzePattern(self, mat: BlockMatrix1x2):
+        """:431-449: identity permutations, left block size."""
+        left, right = mat.leftBlock(), mat.rightBlock()
+        assert left.cols() > right.shape[1], "the left block should be the bigger one"
+        assert left.rows() <= right.shape[0]
+        self.m_leftRows, self.m_leftCols = left.rows(), left.cols()
+        self._rows, self._cols = mat.rows(), mat.cols()
+
+    def factorize(self, mat: BlockMatrix1x2):
+        dev = self._ctx.device
+        left, right = mat.leftBlock(), mat.rightBlock()
+        m1, n1 = self.m_leftCols, self.m_leftRows
+        m2 = int(right.shape[1])
+        n2 = int(right.shape[0]) - n1
+        # J1 = Q1 R1 (:472-475)
+        self.m_leftSolver.compute(left)
+        assert self.m_leftSolver.info() == capi.INFO_SUCCESS
+        # solveRightBlock (:361-369): J2.top(n1) = Q1^T (rowPerm * J2.top(n1)); bottom n2 rows as they are;
+        # rightSolver.compute(J2.bottomRows(n1 + n2 - m1)).  The left solver's row permutation is the identity.
+        J2 = torch.as_tensor(np.asarray(right, dtype=np.float64)) if not isinstance(right, torch.Tensor) else right
+        J2 = J2.to(dev, torch.float64)
+        top = self.m_leftSolver.applyQt(J2[:n1, :])                    # device, (n1, m2)
+        self._J2 = torch.cat([top, J2[n1:, :]], dim=0) if n2 > 0 else top
+        bottom = _colmajor(self._J2[m1:, :].clone())
+        self.m_rightSolver.compute(bottom)
+        self._P2 = self.m_rightSolver.colsPermutation().long()
+        self._m1, self._m2, self._n1, self._n2 = m1, m2, n1, n2
+        # column permutation (:498-503) and rank (:510)
+        p1 = torch.as_tensor(self.m_leftSolver.colsPermutation(), device=dev).long()
+        self.m_outputPerm_c = torch.cat([p1, m1 + self._P2]).to(torch.int32)
+        self.m_rowPerm = np.arange(self._rows, dtype=np.int32)
+        self.m_nonzeropivots = self.m_leftSolver.rank() + min(bottom.shape)
+        self.m_isInitialized = True
+        self.m_info = capi.INFO_SUCCESS
+
+    # -- accessors ----------------------------------------------------------------------------
+    def rows(self):
+        return self._rows
+
+    def cols(self):
+        return self._cols
+
+    def rank(self):
+        return self.m_nonzeropivots
+
+    def info(self):
+        return self.m_info
+
+    def colsPermutation(self) -> np.ndarray:
+        return self.m_outputPerm_c.cpu().numpy()
+
+    def rowsPermutation(self) -> np.ndarray:
+        return self.m_rowPerm
+
+    def matrixR(self):
+        """makeR (:285-308): R = [R1, (Q1^T J2)(0:m1, P2); 0, R2] as scipy CSC (rows x cols)."""
+        import scipy.sparse as sp
+        m1, m2 = self._m1, self._m2
+        R1 = self.m_leftSolver.matrixR()[:, :]                            # (n1 x m1) CSC, nonzero in the top m1 rows
+        strip = self._J2[:m1, :][:, self._P2].cpu().numpy()              # J2(r, P2(c)) for r < m1
+        R2 = self.m_rightSolver.matrixR().cpu().numpy()                  # (min x m2)
+        k2 = R2.shape[0]
+        top = sp.hstack([R1[:m1, :], sp.csc_matrix(strip)], format="csc")
+        mid = sp.hstack([sp.csc_matrix((k2, m1)), sp.csc_matrix(np.triu(R2))], format="csc")
+        pad = sp.csc_matrix((self._rows - m1 - k2, m1 + m2))
+        return sp.vstack([top, mid, pad], format="csc")
+
+    def applyQt(self, v):
+        """matrixQ().transpose() * v (:607-625): top n1 rows <- Q1^T v_top, then rows m1.. <- Q2^T of them."""
+        was_np = not isinstance(v, torch.Tensor)
+        t = torch.as_tensor(np.asarray(v, dtype=np.float64)) if was_np else v
+        t = t.to(self._ctx.device, torch.float64).reshape(self._rows, -1).clone()
+        n1, m1 = self._n1, self._m1
+        t[:n1, :] = self.m_leftSolver.applyQt(t[:n1, :].contiguous())
+        bot = _colmajor(t[m1:, :].clone())
+        self.m_rightSolver.applyQ(bot, transpose=True)
+        t[m1:, :] = bot
+        out = t if np.ndim(v) > 1 else t[:, 0]
+        return out.cpu().numpy() if was_np else out
+
+    def solve(self, b):
+        """_solve_impl (:202-227): x = P [R(0:rank,0:rank)^-1 (Q^T b)(0:rank)] (dense back substitution on the host
+        side of the mirror is avoided: the triangular solve uses the block structure on the device)."""
+        was_np = not isinstance(b, torch.Tensor)
+        y = self.applyQt(torch.as_tensor(np.asarray(b, dtype=np.float64)) if was_np else b)
+        y = y.reshape(self._rows, -1)
+        m1, m2 = self._m1, self._m2
+        R2 = self.m_rightSolver.matrixR()[:m2, :m2]
+        y2 = torch.linalg.solve_triangular(R2, y[m1:m1 + m2, :], upper=True)
+        strip = self._J2[:m1, :][:, self._P2]
+        rhs1 = y[:m1, :] - strip @ y2
+        # R1 is block upper triangular: solve it tile by tile with the left solver's packed R
+        y1 = self.m_leftSolver.solveR(rhs1)
+        yy = torch.cat([y1, y2], dim=0)
+        x = torch.empty_like(yy)
+        x[self.m_outputPerm_c.long(), :] = yy
+        x = x if np.ndim(b) > 1 else x[:, 0]
+        return x.cpu().numpy() if was_np else x

@@ -143,6 +143,36 @@ bd_solve_kernel(TileGeom g, const double* __restrict__ q_vals, const double* __r
     }
 }
 
+// Block upper-triangular solve only: z = R(0:cols,0:cols)^-1 y with y, z: mat_cols x nrhs (the
+// triangularView<Upper>().solve step of _solve_impl, BlockDiagonalSparseQR.h:271, on its own; the
+// angular composition needs it with a modified right-hand side).  One workgroup per tile and RHS.
+__global__ void __launch_bounds__(256)
+bd_solve_r_kernel(TileGeom g, const double* __restrict__ r_vals, const double* __restrict__ y, int64_t nrhs,
+                  double* __restrict__ z)
+{
+    extern __shared__ double ysm[];
+    const int tid = threadIdx.x;
+    const int64_t total = g.num_tiles * nrhs;
+    for (int64_t w = blockIdx.x; w < total; w += gridDim.x) {
+        const int64_t t = w % g.num_tiles, rhs = w / g.num_tiles;
+        int r, c, base_row, base_col;
+        int64_t qoff, roff;
+        tile_geom(g, t, r, c, qoff, roff, base_row, base_col);
+        for (int k = tid; k < c; k += blockDim.x) ysm[k] = y[rhs * (int64_t)g.mat_cols + base_col + k];
+        __syncthreads();
+        for (int kk = c - 1; kk >= 0; --kk) {
+            const double* colk = r_vals + roff + (int64_t)kk * (kk + 1) / 2;
+            const double piv = ysm[kk] / colk[kk];
+            __syncthreads();
+            if (tid == 0) ysm[kk] = piv;
+            for (int j = tid; j < kk; j += blockDim.x) ysm[j] = fma(-colk[j], piv, ysm[j]);
+            __syncthreads();
+        }
+        for (int k = tid; k < c; k += blockDim.x) z[rhs * (int64_t)g.mat_cols + base_col + k] = ysm[k];
+        __syncthreads();
+    }
+}
+
 // _solve_impl for tiles of any size: one workgroup per tile and right-hand side, y in LDS.
 __global__ void __launch_bounds__(256)
 bd_solve_wg_kernel(TileGeom g, const double* __restrict__ q_vals, const double* __restrict__ r_vals,
@@ -210,6 +240,17 @@ void launch_bd_apply_qt(const TileGeom& g, const double* q_vals, const double* b
     if (ntail > 0)
         hipLaunchKernelGGL(bd_copy_tail_kernel, dim3((unsigned)((ntail + 255) / 256)), dim3(256), 0, stream, g,
                            b, nrhs, y);
+}
+
+void launch_bd_solve_r(const TileGeom& g, int max_cols, const double* r_vals, const double* y, int64_t nrhs, double* z,
+                       hipStream_t stream)
+{
+    const int64_t total = g.num_tiles * nrhs;
+    if (total <= 0) return;
+    const unsigned grid = (unsigned)(total < 262144 ? total : 262144);
+    const unsigned threads = max_cols <= 64 ? 64 : 256;
+    hipLaunchKernelGGL(bd_solve_r_kernel, dim3(grid), dim3(threads), (size_t)max_cols * sizeof(double), stream, g, r_vals, y,
+                       nrhs, z);
 }
 
 void launch_bd_solve(const TileGeom& g, int max_cols, const double* q_vals, const double* r_vals, const int32_t* perm,

@@ -53,6 +53,12 @@ struct qrk_bd_plan_s {
     int num_wg = 0;
 };
 
+struct qrk_dense_plan_s {
+    qrk_handle h = nullptr;
+    int32_t rows = 0, cols = 0;
+    int solver = 0;
+};
+
 namespace {
 
 qrk_status fail(qrk_handle h, qrk_status st, const std::string& msg)
@@ -463,6 +469,107 @@ qrk_status qrk_bd_solve(qrk_bd_plan p, const double* q_vals, const double* r_val
     qrk::launch_bd_solve(g, p->max_dim, d_q, d_r, d_p, d_b, nrhs, d_x, h->stream);
     QRK_HIP(h, hipGetLastError());
     if ((st = s.back(x, d_x, nrhs * p->mat_cols))) return st;
+    QRK_HIP(h, hipStreamSynchronize(h->stream));
+    return QRK_STATUS_OK;
+}
+
+qrk_status qrk_bd_solve_r(qrk_bd_plan p, const double* r_vals, const double* y, int64_t nrhs, double* z,
+                          qrk_memspace space)
+{
+    if (!p || !r_vals || !y || !z || nrhs < 0)
+        return fail(p ? p->h : nullptr, QRK_STATUS_INVALID_ARGUMENT, "qrk_bd_solve_r: bad argument");
+    qrk_handle h = p->h;
+    if (p->q_format != QRK_FULL_Q)
+        return fail(h, QRK_STATUS_UNSUPPORTED, "qrk_bd_solve_r: R is upper triangular only in the FullQ format");
+    QRK_HIP(h, hipSetDevice(h->device));
+    const qrk::TileGeom g = make_geom(p);
+    if (space == QRK_MEM_DEVICE) {
+        qrk::launch_bd_solve_r(g, p->max_dim, r_vals, y, nrhs, z, h->stream);
+        QRK_HIP(h, hipGetLastError());
+        return QRK_STATUS_OK;
+    }
+    Staging s(h);
+    double *d_r, *d_y, *d_z;
+    qrk_status st;
+    if ((st = s.in(r_vals, p->nnz_r, &d_r)) || (st = s.in(y, nrhs * p->mat_cols, &d_y)) ||
+        (st = s.out(nrhs * p->mat_cols, &d_z)))
+        return st;
+    qrk::launch_bd_solve_r(g, p->max_dim, d_r, d_y, nrhs, d_z, h->stream);
+    QRK_HIP(h, hipGetLastError());
+    if ((st = s.back(z, d_z, nrhs * p->mat_cols))) return st;
+    QRK_HIP(h, hipStreamSynchronize(h->stream));
+    return QRK_STATUS_OK;
+}
+
+qrk_status qrk_dense_plan_create(qrk_handle h, int32_t rows, int32_t cols, qrk_block_solver solver,
+                                 qrk_dense_plan* out)
+{
+    if (!h || !out || rows <= 0 || cols <= 0)
+        return fail(h, QRK_STATUS_INVALID_ARGUMENT, "qrk_dense_plan_create: bad argument");
+    *out = nullptr;
+    if (qrk::dense_qr_smem_bytes(rows, cols) > 160 * 1024)
+        return fail(h, QRK_STATUS_UNSUPPORTED,
+                    "qrk_dense_plan_create: matrix too tall for the single-workgroup dense solver (LDS)");
+    qrk_dense_plan_s* p = new (std::nothrow) qrk_dense_plan_s();
+    if (!p) return fail(h, QRK_STATUS_ALLOC_FAILED, "qrk_dense_plan_create: out of host memory");
+    p->h = h; p->rows = rows; p->cols = cols; p->solver = solver;
+    *out = p;
+    return QRK_STATUS_OK;
+}
+
+qrk_status qrk_dense_plan_destroy(qrk_dense_plan p)
+{
+    delete p;
+    return QRK_STATUS_OK;
+}
+
+qrk_status qrk_dense_factorize(qrk_dense_plan p, double* a, int64_t lda, double* hcoeffs, int32_t* perm,
+                               qrk_memspace space)
+{
+    if (!p || !a || !hcoeffs || !perm || lda < p->rows)
+        return fail(p ? p->h : nullptr, QRK_STATUS_INVALID_ARGUMENT, "qrk_dense_factorize: bad argument");
+    qrk_handle h = p->h;
+    QRK_HIP(h, hipSetDevice(h->device));
+    const int piv = p->solver == QRK_COLPIV_HOUSEHOLDER ? 1 : 0;
+    const int size = p->rows < p->cols ? p->rows : p->cols;
+    if (space == QRK_MEM_DEVICE) {
+        QRK_HIP(h, qrk::launch_dense_qr(a, lda, p->rows, p->cols, piv, hcoeffs, perm, h->stream));
+        return QRK_STATUS_OK;
+    }
+    Staging s(h);
+    double *d_a, *d_hc;
+    int32_t* d_p;
+    qrk_status st;
+    if ((st = s.in(a, lda * p->cols, &d_a)) || (st = s.out((int64_t)size, &d_hc)) || (st = s.out((int64_t)p->cols, &d_p)))
+        return st;
+    QRK_HIP(h, qrk::launch_dense_qr(d_a, lda, p->rows, p->cols, piv, d_hc, d_p, h->stream));
+    if ((st = s.back(a, d_a, lda * p->cols)) || (st = s.back(hcoeffs, d_hc, (int64_t)size)) ||
+        (st = s.back(perm, d_p, (int64_t)p->cols)))
+        return st;
+    QRK_HIP(h, hipStreamSynchronize(h->stream));
+    return QRK_STATUS_OK;
+}
+
+qrk_status qrk_dense_apply_q(qrk_dense_plan p, const double* qr, int64_t lda, const double* hcoeffs, int transpose,
+                             double* b, int64_t ldb, int64_t nrhs, qrk_memspace space)
+{
+    if (!p || !qr || !hcoeffs || !b || nrhs < 0 || lda < p->rows || ldb < p->rows)
+        return fail(p ? p->h : nullptr, QRK_STATUS_INVALID_ARGUMENT, "qrk_dense_apply_q: bad argument");
+    qrk_handle h = p->h;
+    QRK_HIP(h, hipSetDevice(h->device));
+    const int size = p->rows < p->cols ? p->rows : p->cols;
+    if (space == QRK_MEM_DEVICE) {
+        QRK_HIP(h, qrk::launch_dense_apply_q(qr, lda, p->rows, size, hcoeffs, transpose, b, ldb, nrhs, h->stream));
+        return QRK_STATUS_OK;
+    }
+    Staging s(h);
+    double *d_qr, *d_hc, *d_b;
+    qrk_status st;
+    if ((st = s.in(qr, lda * p->cols, &d_qr)) || (st = s.in(hcoeffs, (int64_t)size, &d_hc)) ||
+        (st = s.in((const double*)b, ldb * nrhs, &d_b)))
+        return st;
+    QRK_HIP(h, qrk::launch_dense_apply_q(d_qr, lda, p->rows, size, d_hc, transpose, d_b, ldb, nrhs, h->stream));
+    if ((st = s.back(b, d_b, ldb * nrhs))) return st;
     QRK_HIP(h, hipStreamSynchronize(h->stream));
     return QRK_STATUS_OK;
 }

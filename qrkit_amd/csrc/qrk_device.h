@@ -51,11 +51,18 @@ void launch_bdqr_pair(const WaveBatch& nb, bool full32, const double* tiles, dou
 void launch_bdqr_wg(const WaveBatch& nb, const double* tiles, double* q_vals, double* r_vals, int32_t* perm,
                     double* hcoeffs, double* workspace, int64_t ws_stride, int num_wg, int max_dim,
                     hipStream_t stream);
+size_t dense_qr_smem_bytes(int r, int c);
+hipError_t launch_dense_qr(double* A, int64_t lda, int r, int c, int pivoting, double* hcoeffs, int32_t* perm,
+                           hipStream_t stream);
+hipError_t launch_dense_apply_q(const double* QR, int64_t lda, int r, int nrefl, const double* hcoeffs,
+                                int transpose, double* B, int64_t ldb, int64_t nrhs, hipStream_t stream);
 void launch_bd_pattern(const TileGeom& g, int64_t nnz_r, int32_t* q_rowptr, int32_t* q_colidx,
                        int32_t* r_colptr, int32_t* r_rowidx, hipStream_t stream);
 void launch_bd_q_tail_ones(double* q_vals, int64_t start, int64_t count, hipStream_t stream);
 void launch_bd_apply_qt(const TileGeom& g, const double* q_vals, const double* b, int64_t nrhs,
                         double* y, hipStream_t stream);
+void launch_bd_solve_r(const TileGeom& g, int max_cols, const double* r_vals, const double* y, int64_t nrhs, double* z,
+                       hipStream_t stream);
 void launch_bd_solve(const TileGeom& g, int max_cols, const double* q_vals, const double* r_vals,
                      const int32_t* perm, const double* b, int64_t nrhs, double* x,
                      hipStream_t stream);

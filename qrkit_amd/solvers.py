@@ -287,6 +287,16 @@ class BlockDiagonalSparseQR:
         self.m_info = capi.INFO_SUCCESS
         return self._out(x, was_np, shape, self._cols)
 
+    def solveR(self, Y):
+        """R.topLeftCorner(cols, cols).triangularView<Upper>().solve(Y) on the device (:271)."""
+        assert self.m_isInitialized
+        y, was_np, shape = self._rhs(Y, self._cols)
+        z = torch.empty_like(y)
+        self._ctx.use_current_stream()
+        capi.check(capi.lib().qrk_bd_solve_r(self._plan, self._r.data_ptr(), y.data_ptr(), y.shape[0], z.data_ptr(),
+                                             capi.MEM_DEVICE), self._ctx.handle)
+        return self._out(z, was_np, shape, self._cols)
+
     # -- helpers ---------------------------------------------------------------------------
     def _rhs(self, B, n):
         was_np = not isinstance(B, torch.Tensor)

@@ -1,0 +1,58 @@
+"""Block-angular composition (BlockAngularSparseQR with a block-diagonal left solver and a dense right solver):
+the oracle against the reference's invariant (CPU) and the HIP path against the oracle (GPU)."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from helpers import rel_fro
+from oracle import oracle as orc
+
+
+def angular_problem(num_vars, m2, seed=1, n2=0):
+    """generate_block_angular_matrix shape (test/test-qrkit.cpp:135-165) with non-overlapping 7x2 blocks:
+    J1 = num_vars blocks of 7x2, J2 = dense (7*num_vars + n2) x m2, all U(0.5, 5) from the reference's generator."""
+    vals = orc.gen_uniform(seed, 0.5, 5.0, num_vars * 14 + (7 * num_vars + n2) * m2)
+    tiles = vals[:num_vars * 14]
+    J2 = vals[num_vars * 14:].reshape(7 * num_vars + n2, m2)      # row-major draw order: for i, for j (:155-159)
+    prob = orc.BDProblem.uniform(num_vars, 7, 2, tiles)
+    J1 = sp.block_diag([tiles[i * 14:(i + 1) * 14].reshape(2, 7).T for i in range(num_vars)], format="csc")
+    if n2:
+        J1 = sp.vstack([J1, sp.csc_matrix((n2, 2 * num_vars))], format="csc")
+    return prob, tiles, J1, J2
+
+
+def test_oracle_angular_invariants():
+    """test_block_angular's assertion (LS recovery, test-qrkit.cpp:260-292) plus Q^T J P = R, on the oracle."""
+    prob, tiles, J1, J2 = angular_problem(64, 24)
+    res = orc.ba_factorize(prob, J2)
+    J = sp.hstack([J1, sp.csc_matrix(J2)], format="csc")
+    JP = J[:, res.perm].toarray()
+    assert rel_fro(orc.ba_apply_qt(res, JP), res.R.toarray()) <= 1e-12
+    x = np.random.default_rng(0).uniform(-1, 1, J.shape[1])
+    y = orc.ba_apply_qt(res, J @ x)
+    import scipy.linalg as sl
+    solved = sl.solve_triangular(res.R[:J.shape[1], :].toarray(), y[:J.shape[1]])
+    back = np.zeros_like(solved); back[res.perm] = solved
+    assert rel_fro(back, x) <= 1e-10
+    assert res.rank == J.shape[1]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("num_vars,m2,n2", [(64, 24, 0), (256, 96, 0), (1024, 384, 0), (100, 30, 17)])
+def test_hip_angular_matches_oracle(num_vars, m2, n2):
+    """Sizes up to the reference's own test (1024 blocks of 7x2 + 384 dense columns, test-qrkit.cpp:388-395)."""
+    import qrkit_amd
+    prob, tiles, J1, J2 = angular_problem(num_vars, m2, n2=n2)
+    ref = orc.ba_factorize(prob, J2)
+    left = qrkit_amd.SparseBlockDiagonal.fromTiles(prob.rows, prob.cols, tiles)
+    ba = qrkit_amd.BlockAngularSparseQR()
+    ba.compute(qrkit_amd.BlockMatrix1x2(left, J2))
+    assert ba.info() == 0 and ba.rank() == ref.rank
+    np.testing.assert_array_equal(ba.colsPermutation(), ref.perm)                   # bit-exact
+    assert rel_fro(ba.matrixR().toarray(), ref.R.toarray()) <= 1e-12
+    # LS recovery, the reference's own assertion (test-qrkit.cpp:289), through Q^T and through solve()
+    J = sp.hstack([J1, sp.csc_matrix(J2)], format="csc")
+    x = np.random.default_rng(0).uniform(-1, 1, J.shape[1])
+    b = J @ x
+    assert rel_fro(ba.applyQt(b), orc.ba_apply_qt(ref, b)) <= 1e-12
+    assert rel_fro(ba.solve(b), x) <= 1e-9
