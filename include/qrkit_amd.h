@@ -187,6 +187,56 @@ qrk_status qrk_dense_factorize(qrk_dense_plan plan, double* a, int64_t lda, doub
 qrk_status qrk_dense_apply_q(qrk_dense_plan plan, const double* qr, int64_t lda, const double* hcoeffs,
                              int transpose, double* b, int64_t ldb, int64_t nrhs, qrk_memspace space);
 
+/* ------------------------------------------------------------ block-banded solver */
+
+/* QRKit::BandedBlockedSparseQR<SparseMatrix, HouseholderQR<MatrixXd>, Dynamic, SuggestedBlockCols>
+ * (src/QRKit/BandedBlockedSparseQR.h:122-366), generic-pattern path.
+ *
+ * qrk_bb_plan_create = analyzePattern (:391-433): AsBandedAsPossible row ordering
+ * (src/QRKit/SparseQROrdering.h:66-119), band detection and mergeBlocks
+ * (src/QRKit/SparseQRUtils.h:186-253,308-385) on the CSR pattern of the matrix (HOST arrays), plus
+ * the panel chain of factorize() (:457-508) as device descriptors.  Fails with
+ * QRK_STATUS_INVALID_ARGUMENT where the reference itself is outside its domain (its mergeBlocks reads
+ * back() of an empty vector for non-portrait strips, SparseQRUtils.h:375). */
+typedef struct qrk_bb_plan_s* qrk_bb_plan;
+
+qrk_status qrk_bb_plan_create(qrk_handle h, int32_t rows, int32_t cols, const int32_t* csr_rowptr,
+                              const int32_t* csr_colidx, int32_t suggested_block_cols, qrk_bb_plan* out);
+qrk_status qrk_bb_plan_destroy(qrk_bb_plan plan);
+
+/* The same structure analysis without a device (pure host integer logic): writes up to `cap` blocks as
+ * (idxRow, idxCol, numRows, numCols) and, when row_perm != NULL, the row permutation indices;
+ * *num_blocks receives the block count.  Lets the reference's known answers
+ * (test/test-utils.cpp:199-205,228-241,264-271) be checked anywhere. */
+qrk_status qrk_bb_analyze_host(int32_t rows, int32_t cols, const int32_t* csr_rowptr, const int32_t* csr_colidx,
+                               int32_t suggested_block_cols, int32_t cap, int32_t* num_blocks, int32_t* blocks,
+                               int32_t* row_perm, int32_t* has_row_perm);
+
+/* num_blocks merged blocks; nnz_r entries of m_R (explicit zeros of the emitted rows included, :487-491);
+ * y_len / t_len doubles of the implicit Q: per block Y (activeRows x numCols, unit lower, column-major)
+ * and T (numCols x numCols, upper, NEGATED as the reference stores it, :477); has_row_perm as
+ * AsBandedAsPossible::hasPermutation. */
+qrk_status qrk_bb_plan_info(qrk_bb_plan plan, int32_t* num_blocks, int64_t* nnz_r, int64_t* y_len,
+                            int64_t* t_len, int32_t* has_row_perm);
+
+/* Host outputs: blocks[4*num_blocks] = (idxRow, idxCol, numRows, numCols) of m_blockInfo in order;
+ * row_perm[rows] = rowsPermutation().indices(): (P*M).row(row_perm[i]) = M.row(i);
+ * yty[6*num_blocks] = per block (rowIndex, numZeros, rows(Y), cols(Y), ... ) see INTEGRATION.md. */
+qrk_status qrk_bb_plan_blocks(qrk_bb_plan plan, int32_t* blocks, int32_t* row_perm, int64_t* yty);
+
+/* CSC pattern of m_R (cols+1 pointers, nnz_r row indices). */
+qrk_status qrk_bb_pattern(qrk_bb_plan plan, int32_t* r_colptr, int32_t* r_rowidx, qrk_memspace space);
+
+/* factorize() (:443-519): csr_vals are the values of the UNPERMUTED matrix in the CSR order given to
+ * qrk_bb_plan_create; r_vals [nnz_r] in CSC order; y_vals [y_len]; t_vals [t_len]. */
+qrk_status qrk_bb_factorize(qrk_bb_plan plan, const double* csr_vals, int64_t nnz, double* r_vals,
+                            double* y_vals, double* t_vals, qrk_memspace space);
+
+/* v (rows x nrhs, ld = rows) <- Q^T v (transpose != 0; blocks ascending with T^T) or Q v (descending
+ * with T): SparseBlockYTY_VecProduct (src/QRKit/SparseBlockYTY.h:100-139). */
+qrk_status qrk_bb_apply_q(qrk_bb_plan plan, const double* y_vals, const double* t_vals, int transpose,
+                          double* v, int64_t nrhs, qrk_memspace space);
+
 /* ------------------------------------------------------------- measurement */
 
 /* Launch the factorisation kernel(s) of `plan` `iters` times back to back on the

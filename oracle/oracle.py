@@ -330,3 +330,97 @@ def ba_apply_qt(res: BAResult, v: np.ndarray) -> np.ndarray:
         bot[k:, :] -= res.hc2[k] * np.outer(vk, vk @ bot[k:, :])
     out[res.m1:, :] = bot
     return out if np.ndim(v) > 1 else out[:, 0]
+
+
+# ---------------------------------------------------------------- BandedBlockedSparseQR
+
+class BBResult:
+    pass
+
+
+def bb_analyze(J, suggested: int = 2):
+    """BandedBlockedSparseQR::analyzePattern, generic path (src/QRKit/BandedBlockedSparseQR.h:409-427):
+    AsBandedAsPossible row ordering, then BlockBandedMatrixInfo::operator() on the permuted row-major matrix.
+    Returns (row_perm, blocks); (P*M).row(row_perm[i]) = M.row(i)."""
+    import scipy.sparse as sp
+    M = sp.csr_matrix(J)
+    M.sort_indices()
+    has, perm = as_banded_as_possible(M.shape[0], M.shape[1], M.indptr, M.indices)
+    if has:
+        inv = np.empty_like(perm); inv[perm] = np.arange(len(perm), dtype=perm.dtype)
+        M = M[inv]
+        M.sort_indices()
+    else:
+        perm = np.arange(M.shape[0], dtype=np.int32)
+    blocks = block_info_from_csr(M.shape[0], M.shape[1], M.indptr, M.indices, suggested)
+    return perm, blocks
+
+
+def bb_factorize(J, suggested: int = 2) -> BBResult:
+    """BandedBlockedSparseQR::factorize (BandedBlockedSparseQR.h:443-519) restated with numpy on top of the C
+    kernels (orc_householder_qr, orc_block_triangular_factor): sequential chain of dense panels, each the
+    leftover triangle of the previous panel stacked on the next block rows; R rows emitted per panel incl. explicit
+    zeros (:484-491); Y (unit lower) and negated T per panel (:471-481) with (row, numZeros) for the implicit Q."""
+    import scipy.sparse as sp
+    perm, blocks = bb_analyze(J, suggested)
+    assert blocks is not None, "reference would hit undefined behaviour (mergeBlocks on an empty vector)"
+    inv = np.empty_like(perm); inv[perm] = np.arange(len(perm), dtype=perm.dtype)
+    pmat = sp.csr_matrix(J)[inv].toarray()           # m_pmat = m_rowPerm * mat  (:446)
+    rows, cols = pmat.shape
+    nb = len(blocks)
+    Rd = np.zeros((rows, cols))
+    Rmask = np.zeros((rows, cols), dtype=bool)
+    yty = []
+    bi = blocks[0]
+    Ji = pmat[bi[0]:bi[0] + bi[2], bi[1]:bi[1] + bi[3]].copy()
+    activeRows, numZeros = int(bi[2]), 0
+    for i in range(nb):
+        bi = blocks[i]
+        idxRow, idxCol, numRows, numCols = (int(v) for v in bi)
+        qr, hc = householder_qr(Ji)                                           # houseqr.compute(Ji) (:468)
+        Y = np.eye(activeRows, numCols)
+        for bc in range(numCols):
+            Y[bc + 1:, bc] = qr[bc + 1:, bc]                                  # essentialVector(bc) (:472-475)
+        T = -block_triangular_factor(Y, hc[:numCols])                         # (:476-477)
+        yty.append((Y, T, idxCol, numZeros))                                  # BlockYTY(Y, T, diagIdx, diagIdx, numZeros) (:480-481)
+        V = np.triu(qr)
+        solved = numRows if i == nb - 1 else int(blocks[i + 1][1]) - idxCol   # (:486)
+        for br in range(solved):
+            Rd[idxCol + br, idxCol:idxCol + numCols] = V[br, :numCols] if br < V.shape[0] else 0.0
+            Rmask[idxCol + br, idxCol:idxCol + numCols] = True
+        if i < nb - 1:
+            nx = blocks[i + 1]
+            nRow, nCol, nRows, nCols = (int(v) for v in nx)
+            overlap = (idxCol + numCols) - nCol
+            colInc = numCols - overlap
+            activeRows = numRows + nRows - colInc
+            numZeros = max((nRow + nRows) - activeRows - nCol, 0)
+            ncols = nCols if nCols >= overlap else overlap
+            Ji = pmat[idxRow + colInc:idxRow + colInc + activeRows, nCol:nCol + ncols].copy()
+            if overlap > 0:
+                lr = activeRows - nRows
+                Ji[:lr, :overlap] = V[colInc:colInc + lr, colInc:colInc + overlap]
+    out = BBResult()
+    out.row_perm, out.blocks, out.yty = perm, blocks, yty
+    rr, cc = np.nonzero(Rmask)
+    order = np.lexsort((rr, cc))
+    out.R = sp.csc_matrix((Rd[rr[order], cc[order]], (rr[order], cc[order])), shape=(rows, cols))
+    out.R_dense = Rd
+    out.R_mask = Rmask
+    out.rank = cols
+    return out
+
+
+def bb_apply_q(res: BBResult, v: np.ndarray, transpose: bool) -> np.ndarray:
+    """SparseBlockYTY_VecProduct::evalTo (src/QRKit/SparseBlockYTY.h:100-139) with the two-segment gather/scatter
+    of BlockYTY_VecProduct (BlockYTY.h:152-172, SparseQRUtils.h:47-89)."""
+    out = np.array(v, dtype=np.float64).reshape(len(res.row_perm), -1).copy()
+    seq = res.yty if transpose else res.yty[::-1]
+    for (Y, T, row, nz) in seq:
+        m, n = Y.shape
+        idx = np.concatenate([np.arange(row, row + n), np.arange(row + n + nz, row + n + nz + (m - n))])
+        seg = out[idx, :]
+        TT = T.T if transpose else T
+        seg = seg + Y @ (TT @ (Y.T @ seg))
+        out[idx, :] = seg
+    return out if np.ndim(v) > 1 else out[:, 0]

@@ -8,8 +8,9 @@ a ctypes binding (`_capi`) and a mirror of the reference's solver interface
 from . import _capi
 from ._capi import (BLOCK_DIAGONAL_Q, COLPIV_HOUSEHOLDER, FULL_Q, HOUSEHOLDER, INFO_INVALID_INPUT,
                     INFO_SUCCESS, QrkError)
+from .banded import BandedBlockedSparseQR
 from .angular import BlockAngularSparseQR, BlockMatrix1x2, DenseColPivQR
 from .solvers import BlockDiagonalSparseQR, Context, SparseBlockDiagonal
 
-__all__ = ["_capi", "QrkError", "Context", "SparseBlockDiagonal", "BlockDiagonalSparseQR", "BlockMatrix1x2", "BlockAngularSparseQR", "DenseColPivQR", "FULL_Q",
+__all__ = ["_capi", "QrkError", "Context", "SparseBlockDiagonal", "BlockDiagonalSparseQR", "BlockMatrix1x2", "BlockAngularSparseQR", "DenseColPivQR", "BandedBlockedSparseQR", "FULL_Q",
            "BLOCK_DIAGONAL_Q", "COLPIV_HOUSEHOLDER", "HOUSEHOLDER", "INFO_SUCCESS", "INFO_INVALID_INPUT"]

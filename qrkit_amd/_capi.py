@@ -24,7 +24,8 @@ EXPORTS = (
     "qrk_version", "qrk_device_count", "qrk_create", "qrk_destroy", "qrk_set_stream", "qrk_synchronize",
     "qrk_last_error", "qrk_bd_plan_create", "qrk_bd_plan_destroy", "qrk_bd_plan_sizes", "qrk_bd_pattern",
     "qrk_bd_factorize", "qrk_bd_info", "qrk_bd_apply_qt", "qrk_bd_solve", "qrk_bd_solve_r", "qrk_dense_plan_create",
-    "qrk_dense_plan_destroy", "qrk_dense_factorize", "qrk_dense_apply_q", "qrk_bd_time_factorize",
+    "qrk_dense_plan_destroy", "qrk_dense_factorize", "qrk_dense_apply_q", "qrk_bb_plan_create", "qrk_bb_plan_destroy", "qrk_bb_analyze_host",
+    "qrk_bb_plan_info", "qrk_bb_plan_blocks", "qrk_bb_pattern", "qrk_bb_factorize", "qrk_bb_apply_q", "qrk_bd_time_factorize",
 )
 
 
@@ -93,6 +94,24 @@ def lib() -> C.CDLL:
     L.qrk_dense_factorize.argtypes = [vp, dp, C.c_int64, dp, ip, C.c_int]
     L.qrk_dense_apply_q.restype = C.c_int
     L.qrk_dense_apply_q.argtypes = [vp, dp, C.c_int64, dp, C.c_int, dp, C.c_int64, C.c_int64, C.c_int]
+    L.qrk_bb_plan_create.restype = C.c_int
+    L.qrk_bb_plan_create.argtypes = [vp, C.c_int32, C.c_int32, ip, ip, C.c_int32, C.POINTER(vp)]
+    L.qrk_bb_plan_destroy.restype = C.c_int
+    L.qrk_bb_plan_destroy.argtypes = [vp]
+    L.qrk_bb_analyze_host.restype = C.c_int
+    L.qrk_bb_analyze_host.argtypes = [C.c_int32, C.c_int32, ip, ip, C.c_int32, C.c_int32, C.POINTER(C.c_int32), ip, ip,
+                                      C.POINTER(C.c_int32)]
+    L.qrk_bb_plan_info.restype = C.c_int
+    L.qrk_bb_plan_info.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64),
+                                   C.POINTER(C.c_int32)]
+    L.qrk_bb_plan_blocks.restype = C.c_int
+    L.qrk_bb_plan_blocks.argtypes = [vp, ip, ip, ip]
+    L.qrk_bb_pattern.restype = C.c_int
+    L.qrk_bb_pattern.argtypes = [vp, ip, ip, C.c_int]
+    L.qrk_bb_factorize.restype = C.c_int
+    L.qrk_bb_factorize.argtypes = [vp, dp, C.c_int64, dp, dp, dp, C.c_int]
+    L.qrk_bb_apply_q.restype = C.c_int
+    L.qrk_bb_apply_q.argtypes = [vp, dp, dp, C.c_int, dp, C.c_int64, C.c_int]
     L.qrk_bd_time_factorize.restype = C.c_int
     L.qrk_bd_time_factorize.argtypes = [vp, dp, dp, dp, ip, C.c_int, C.c_int, C.POINTER(C.c_float)]
     _lib = L

@@ -1,0 +1,154 @@
+"""Host-side mirror of QRKit::BandedBlockedSparseQR (src/QRKit/BandedBlockedSparseQR.h:122-366), generic
+pattern path: compute(sparse matrix) = analyzePattern (as-banded-as-possible row ordering, band detection,
+block merge) + factorize (sequential chain of dense Householder panels); matrixR(); implicit Q as the
+ordered (Y, T) blocks with matrixQ() products; rowsPermutation(); solve().  Arithmetic and the structure
+analysis both live in the HIP library (qrk_bb_*); this file only marshals buffers."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import _capi as capi
+from .solvers import Context
+
+
+def analyze_host(J, suggestedBlockCols: int = 2):
+    """The product's structure analysis without a device: (row_perm, blocks[n,4], hasPermutation)."""
+    import scipy.sparse as sp
+    M = sp.csr_matrix(J)
+    M.sort_indices()
+    rows, cols = M.shape
+    rp = np.ascontiguousarray(M.indptr, dtype=np.int32)
+    ci = np.ascontiguousarray(M.indices, dtype=np.int32)
+    nb, has = C.c_int32(), C.c_int32()
+    blocks = np.zeros(4 * rows, np.int32)
+    perm = np.zeros(rows, np.int32)
+    capi.check(capi.lib().qrk_bb_analyze_host(rows, cols, rp.ctypes.data, ci.ctypes.data, suggestedBlockCols, rows,
+                                              C.byref(nb), blocks.ctypes.data, perm.ctypes.data, C.byref(has)))
+    return perm, blocks[:4 * nb.value].reshape(-1, 4), bool(has.value)
+
+
+class BandedBlockedSparseQR:
+    def __init__(self, suggestedBlockCols: int = 2, context: Optional[Context] = None, device: int = 0):
+        self._ctx = context or Context(device)
+        self._suggested = suggestedBlockCols
+        self._plan = C.c_void_p()
+        self.m_isInitialized = False
+        self.m_analysisIsok = False
+
+    def compute(self, mat, forcePatternAlaysis: bool = False):
+        """BandedBlockedSparseQR.h:170-182: the pattern analysis is cached unless forced."""
+        if not self.m_analysisIsok or forcePatternAlaysis:
+            self.analyzePattern(mat)
+        self.factorize(mat)
+
+    def analyzePattern(self, mat):
+        import scipy.sparse as sp
+        M = sp.csr_matrix(mat)
+        M.sort_indices()
+        self._rows, self._cols = M.shape
+        self._rp = np.ascontiguousarray(M.indptr, dtype=np.int32)
+        self._ci = np.ascontiguousarray(M.indices, dtype=np.int32)
+        if self._plan:
+            capi.lib().qrk_bb_plan_destroy(self._plan)
+            self._plan = C.c_void_p()
+        capi.check(capi.lib().qrk_bb_plan_create(self._ctx.handle, self._rows, self._cols, self._rp.ctypes.data,
+                                                 self._ci.ctypes.data, self._suggested, C.byref(self._plan)), self._ctx.handle)
+        nb, has = C.c_int32(), C.c_int32()
+        nr, yl, tl = C.c_int64(), C.c_int64(), C.c_int64()
+        capi.check(capi.lib().qrk_bb_plan_info(self._plan, C.byref(nb), C.byref(nr), C.byref(yl), C.byref(tl), C.byref(has)),
+                   self._ctx.handle)
+        self._nb, self._nnz_r, self._ylen, self._tlen, self.hasPermutation = nb.value, nr.value, yl.value, tl.value, bool(has.value)
+        self.blocks = np.zeros((self._nb, 4), np.int32)
+        self.m_rowPerm = np.zeros(self._rows, np.int32)
+        self.yty = np.zeros((self._nb, 6), np.int64)
+        capi.check(capi.lib().qrk_bb_plan_blocks(self._plan, self.blocks.ctypes.data, self.m_rowPerm.ctypes.data,
+                                                 self.yty.ctypes.data), self._ctx.handle)
+        self.m_analysisIsok = True
+
+    def factorize(self, mat):
+        import scipy.sparse as sp
+        M = sp.csr_matrix(mat)
+        M.sort_indices()
+        assert M.nnz == len(self._ci), "the sparsity pattern differs from the analysed one"
+        dev = self._ctx.device
+        vals = torch.from_numpy(np.ascontiguousarray(M.data, dtype=np.float64)).to(dev)
+        self._r = torch.empty(max(self._nnz_r, 1), dtype=torch.float64, device=dev)
+        self._y = torch.empty(max(self._ylen, 1), dtype=torch.float64, device=dev)
+        self._t = torch.empty(max(self._tlen, 1), dtype=torch.float64, device=dev)
+        self._ctx.use_current_stream()
+        capi.check(capi.lib().qrk_bb_factorize(self._plan, vals.data_ptr(), M.nnz, self._r.data_ptr(), self._y.data_ptr(),
+                                               self._t.data_ptr(), capi.MEM_DEVICE), self._ctx.handle)
+        self.m_nonzeropivots = self._cols          # :513 "assuming all cols are nonzero"
+        self.m_isInitialized = True
+        self.m_info = capi.INFO_SUCCESS
+
+    def rows(self):
+        return self._rows
+
+    def cols(self):
+        return self._cols
+
+    def rank(self):
+        return self.m_nonzeropivots
+
+    def info(self):
+        return self.m_info
+
+    def rowsPermutation(self) -> np.ndarray:
+        return self.m_rowPerm
+
+    def colsPermutation(self) -> np.ndarray:
+        return np.arange(self._cols, dtype=np.int32)
+
+    def matrixR(self):
+        import scipy.sparse as sp
+        cp = np.zeros(self._cols + 1, np.int32)
+        ri = np.zeros(max(self._nnz_r, 1), np.int32)
+        capi.check(capi.lib().qrk_bb_pattern(self._plan, cp.ctypes.data, ri.ctypes.data, capi.MEM_HOST), self._ctx.handle)
+        return sp.csc_matrix((self._r[:self._nnz_r].cpu().numpy(), ri[:self._nnz_r], cp), shape=(self._rows, self._cols))
+
+    def blockYTY(self, k: int):
+        """(Y, T, rowIndex, numZeros) of block k, as the reference's m_blocksYT[k] (T is stored negated)."""
+        row, nz, m, n, yo, to = (int(v) for v in self.yty[k])
+        Y = self._y[yo:yo + m * n].cpu().numpy().reshape(n, m).T
+        T = self._t[to:to + n * n].cpu().numpy().reshape(n, n).T
+        return Y, T, row, nz
+
+    def _apply(self, v, transpose: bool):
+        was_np = not isinstance(v, torch.Tensor)
+        t = torch.as_tensor(np.asarray(v, dtype=np.float64)) if was_np else v
+        shape = tuple(t.shape)
+        assert shape[0] == self._rows
+        x = t.reshape(self._rows, -1).t().contiguous().to(self._ctx.device, torch.float64)   # [nrhs, rows] = column-major
+        self._ctx.use_current_stream()
+        capi.check(capi.lib().qrk_bb_apply_q(self._plan, self._y.data_ptr(), self._t.data_ptr(), 1 if transpose else 0,
+                                             x.data_ptr(), x.shape[0], capi.MEM_DEVICE), self._ctx.handle)
+        out = x.t().reshape(shape)
+        return out.cpu().numpy() if was_np else out
+
+    def applyQt(self, v):
+        """matrixQ().transpose() * v"""
+        return self._apply(v, True)
+
+    def applyQ(self, v):
+        """matrixQ() * v"""
+        return self._apply(v, False)
+
+    def solve(self, B):
+        """_solve_impl (:290-311): y = Q^T B (B already row-permuted by the caller, as in the tests :235);
+        x = R(0:rank,0:rank)^-1 y(0:rank); identity column permutation."""
+        import scipy.sparse.linalg as spl
+        y = self.applyQt(B)
+        R = self.matrixR().tocsr()[:self._cols, :]
+        return spl.spsolve_triangular(R, np.asarray(y)[:self._cols], lower=False)
+
+    def __del__(self):
+        try:
+            if self._plan:
+                capi.lib().qrk_bb_plan_destroy(self._plan)
+        except Exception:
+            pass

@@ -6,6 +6,7 @@
 // qrk_bd_solve = _solve_impl (:257-280).  There is no CPU fallback anywhere in this file.
 #include "../../include/qrkit_amd.h"
 #include "qrk_device.h"
+#include "banded_host.h"
 
 #include <cstdio>
 #include <cstdlib>
@@ -51,6 +52,15 @@ struct qrk_bd_plan_s {
     double* d_workspace = nullptr;   // per-workgroup working copies of the large tiles
     int64_t ws_stride = 0;
     int num_wg = 0;
+};
+
+struct qrk_bb_plan_s {
+    qrk_handle h = nullptr;
+    qrk::BandedStructure st;
+    qrk::BBPanel* d_panels = nullptr;
+    int32_t *d_prowptr = nullptr, *d_pcol = nullptr, *d_rcolptr = nullptr, *d_rrowidx = nullptr;
+    int64_t *d_pmap = nullptr, *d_rsrc = nullptr;
+    double *d_W = nullptr, *d_lo = nullptr, *d_stage = nullptr;
 };
 
 struct qrk_dense_plan_s {
@@ -570,6 +580,177 @@ qrk_status qrk_dense_apply_q(qrk_dense_plan p, const double* qr, int64_t lda, co
         return st;
     QRK_HIP(h, qrk::launch_dense_apply_q(d_qr, lda, p->rows, size, d_hc, transpose, d_b, ldb, nrhs, h->stream));
     if ((st = s.back(b, d_b, ldb * nrhs))) return st;
+    QRK_HIP(h, hipStreamSynchronize(h->stream));
+    return QRK_STATUS_OK;
+}
+
+qrk_status qrk_bb_plan_create(qrk_handle h, int32_t rows, int32_t cols, const int32_t* csr_rowptr,
+                              const int32_t* csr_colidx, int32_t suggested_block_cols, qrk_bb_plan* out)
+{
+    if (!h || !out || !csr_rowptr || !csr_colidx || rows <= 0 || cols <= 0 || suggested_block_cols <= 0)
+        return fail(h, QRK_STATUS_INVALID_ARGUMENT, "qrk_bb_plan_create: bad argument");
+    *out = nullptr;
+    QRK_HIP(h, hipSetDevice(h->device));
+    qrk_bb_plan_s* p = new (std::nothrow) qrk_bb_plan_s();
+    if (!p) return fail(h, QRK_STATUS_ALLOC_FAILED, "qrk_bb_plan_create: out of host memory");
+    p->h = h;
+    std::string err;
+    if (!qrk::analyze_banded(rows, cols, csr_rowptr, csr_colidx, suggested_block_cols, p->st, err)) {
+        delete p;
+        return fail(h, QRK_STATUS_INVALID_ARGUMENT, "qrk_bb_plan_create: " + err);
+    }
+    const qrk::BandedStructure& st = p->st;
+    if (qrk::bb_chain_smem(st.max_act_rows, st.max_ncols) > 150 * 1024) {
+        delete p;
+        return fail(h, QRK_STATUS_UNSUPPORTED, "qrk_bb_plan_create: panel too large for the single-workgroup chain kernel");
+    }
+    qrk_status s;
+    if ((s = upload(h, st.panels, &p->d_panels)) || (s = upload(h, st.prowptr, &p->d_prowptr)) ||
+        (s = upload(h, st.pcol, &p->d_pcol)) || (s = upload(h, st.pmap, &p->d_pmap)) ||
+        (s = upload(h, st.r_src, &p->d_rsrc)) || (s = upload(h, st.r_colptr, &p->d_rcolptr)) ||
+        (s = upload(h, st.r_rowidx, &p->d_rrowidx))) {
+        qrk_bb_plan_destroy(p);
+        return s;
+    }
+    const size_t wlen = (size_t)st.max_act_rows * (size_t)st.max_ncols;
+    if (hipMalloc((void**)&p->d_W, wlen * sizeof(double)) != hipSuccess ||
+        hipMalloc((void**)&p->d_lo, wlen * sizeof(double)) != hipSuccess ||
+        hipMalloc((void**)&p->d_stage, (size_t)(st.stage_len > 0 ? st.stage_len : 1) * sizeof(double)) != hipSuccess) {
+        qrk_bb_plan_destroy(p);
+        return fail(h, QRK_STATUS_ALLOC_FAILED, "qrk_bb_plan_create: cannot allocate workspaces");
+    }
+    *out = p;
+    return QRK_STATUS_OK;
+}
+
+qrk_status qrk_bb_analyze_host(int32_t rows, int32_t cols, const int32_t* csr_rowptr, const int32_t* csr_colidx,
+                               int32_t suggested_block_cols, int32_t cap, int32_t* num_blocks, int32_t* blocks,
+                               int32_t* row_perm, int32_t* has_row_perm)
+{
+    if (!csr_rowptr || !csr_colidx || !num_blocks || rows <= 0 || cols <= 0 || suggested_block_cols <= 0)
+        return fail(nullptr, QRK_STATUS_INVALID_ARGUMENT, "qrk_bb_analyze_host: bad argument");
+    qrk::BandedStructure st;
+    std::string err;
+    if (!qrk::analyze_banded(rows, cols, csr_rowptr, csr_colidx, suggested_block_cols, st, err))
+        return fail(nullptr, QRK_STATUS_INVALID_ARGUMENT, "qrk_bb_analyze_host: " + err);
+    *num_blocks = (int32_t)st.blocks.size();
+    if (blocks)
+        for (size_t i = 0; i < st.blocks.size() && (int32_t)i < cap; ++i) {
+            blocks[4 * i] = st.blocks[i].idxRow; blocks[4 * i + 1] = st.blocks[i].idxCol;
+            blocks[4 * i + 2] = st.blocks[i].numRows; blocks[4 * i + 3] = st.blocks[i].numCols;
+        }
+    if (row_perm) std::memcpy(row_perm, st.row_perm.data(), st.row_perm.size() * sizeof(int32_t));
+    if (has_row_perm) *has_row_perm = st.has_row_perm ? 1 : 0;
+    return QRK_STATUS_OK;
+}
+
+qrk_status qrk_bb_plan_destroy(qrk_bb_plan p)
+{
+    if (!p) return QRK_STATUS_OK;
+    (void)hipFree(p->d_panels); (void)hipFree(p->d_prowptr); (void)hipFree(p->d_pcol); (void)hipFree(p->d_pmap);
+    (void)hipFree(p->d_rsrc); (void)hipFree(p->d_rcolptr); (void)hipFree(p->d_rrowidx);
+    (void)hipFree(p->d_W); (void)hipFree(p->d_lo); (void)hipFree(p->d_stage);
+    delete p;
+    return QRK_STATUS_OK;
+}
+
+qrk_status qrk_bb_plan_info(qrk_bb_plan p, int32_t* num_blocks, int64_t* nnz_r, int64_t* y_len, int64_t* t_len,
+                            int32_t* has_row_perm)
+{
+    if (!p) return QRK_STATUS_INVALID_ARGUMENT;
+    if (num_blocks) *num_blocks = (int32_t)p->st.blocks.size();
+    if (nnz_r) *nnz_r = p->st.nnz_r;
+    if (y_len) *y_len = p->st.y_len;
+    if (t_len) *t_len = p->st.t_len;
+    if (has_row_perm) *has_row_perm = p->st.has_row_perm ? 1 : 0;
+    return QRK_STATUS_OK;
+}
+
+qrk_status qrk_bb_plan_blocks(qrk_bb_plan p, int32_t* blocks, int32_t* row_perm, int64_t* yty)
+{
+    if (!p) return QRK_STATUS_INVALID_ARGUMENT;
+    const qrk::BandedStructure& st = p->st;
+    if (blocks)
+        for (size_t i = 0; i < st.blocks.size(); ++i) {
+            blocks[4 * i] = st.blocks[i].idxRow; blocks[4 * i + 1] = st.blocks[i].idxCol;
+            blocks[4 * i + 2] = st.blocks[i].numRows; blocks[4 * i + 3] = st.blocks[i].numCols;
+        }
+    if (row_perm) std::memcpy(row_perm, st.row_perm.data(), st.row_perm.size() * sizeof(int32_t));
+    if (yty)
+        for (size_t i = 0; i < st.panels.size(); ++i) {
+            const qrk::BBPanel& q = st.panels[i];
+            yty[6 * i] = q.yrow; yty[6 * i + 1] = q.num_zeros; yty[6 * i + 2] = q.act_rows; yty[6 * i + 3] = q.ncols;
+            yty[6 * i + 4] = q.y_off; yty[6 * i + 5] = q.t_off;
+        }
+    return QRK_STATUS_OK;
+}
+
+qrk_status qrk_bb_pattern(qrk_bb_plan p, int32_t* r_colptr, int32_t* r_rowidx, qrk_memspace space)
+{
+    if (!p || !r_colptr || !r_rowidx) return fail(p ? p->h : nullptr, QRK_STATUS_INVALID_ARGUMENT, "qrk_bb_pattern: NULL argument");
+    qrk_handle h = p->h;
+    const qrk::BandedStructure& st = p->st;
+    if (space == QRK_MEM_HOST) {
+        std::memcpy(r_colptr, st.r_colptr.data(), st.r_colptr.size() * sizeof(int32_t));
+        std::memcpy(r_rowidx, st.r_rowidx.data(), st.r_rowidx.size() * sizeof(int32_t));
+        return QRK_STATUS_OK;
+    }
+    QRK_HIP(h, hipMemcpyAsync(r_colptr, p->d_rcolptr, st.r_colptr.size() * sizeof(int32_t), hipMemcpyDeviceToDevice, h->stream));
+    QRK_HIP(h, hipMemcpyAsync(r_rowidx, p->d_rrowidx, st.r_rowidx.size() * sizeof(int32_t), hipMemcpyDeviceToDevice, h->stream));
+    return QRK_STATUS_OK;
+}
+
+qrk_status qrk_bb_factorize(qrk_bb_plan p, const double* csr_vals, int64_t nnz, double* r_vals, double* y_vals,
+                            double* t_vals, qrk_memspace space)
+{
+    if (!p || !csr_vals || !r_vals || !y_vals || !t_vals)
+        return fail(p ? p->h : nullptr, QRK_STATUS_INVALID_ARGUMENT, "qrk_bb_factorize: NULL argument");
+    qrk_handle h = p->h;
+    const qrk::BandedStructure& st = p->st;
+    if (nnz != (int64_t)st.pmap.size()) return fail(h, QRK_STATUS_INVALID_ARGUMENT, "qrk_bb_factorize: nnz differs from the analysed pattern");
+    QRK_HIP(h, hipSetDevice(h->device));
+    if (space == QRK_MEM_DEVICE) {
+        QRK_HIP(h, qrk::launch_bb_chain(p->d_panels, (int)st.panels.size(), p->d_prowptr, p->d_pcol, p->d_pmap, csr_vals, p->d_W,
+                                        p->d_lo, y_vals, t_vals, p->d_stage, p->d_rsrc, st.nnz_r, r_vals, st.max_act_rows,
+                                        st.max_ncols, h->stream));
+        return QRK_STATUS_OK;
+    }
+    Staging s(h);
+    double *d_v, *d_r, *d_y, *d_t;
+    qrk_status stt;
+    if ((stt = s.in(csr_vals, nnz, &d_v)) || (stt = s.out(st.nnz_r, &d_r)) || (stt = s.out(st.y_len, &d_y)) ||
+        (stt = s.out(st.t_len, &d_t)))
+        return stt;
+    QRK_HIP(h, qrk::launch_bb_chain(p->d_panels, (int)st.panels.size(), p->d_prowptr, p->d_pcol, p->d_pmap, d_v, p->d_W, p->d_lo,
+                                    d_y, d_t, p->d_stage, p->d_rsrc, st.nnz_r, d_r, st.max_act_rows, st.max_ncols, h->stream));
+    if ((stt = s.back(r_vals, d_r, st.nnz_r)) || (stt = s.back(y_vals, d_y, st.y_len)) || (stt = s.back(t_vals, d_t, st.t_len)))
+        return stt;
+    QRK_HIP(h, hipStreamSynchronize(h->stream));
+    return QRK_STATUS_OK;
+}
+
+qrk_status qrk_bb_apply_q(qrk_bb_plan p, const double* y_vals, const double* t_vals, int transpose, double* v,
+                          int64_t nrhs, qrk_memspace space)
+{
+    if (!p || !y_vals || !t_vals || !v || nrhs < 0)
+        return fail(p ? p->h : nullptr, QRK_STATUS_INVALID_ARGUMENT, "qrk_bb_apply_q: bad argument");
+    qrk_handle h = p->h;
+    const qrk::BandedStructure& st = p->st;
+    QRK_HIP(h, hipSetDevice(h->device));
+    if (space == QRK_MEM_DEVICE) {
+        QRK_HIP(h, qrk::launch_bb_apply_q(p->d_panels, (int)st.panels.size(), y_vals, t_vals, transpose, v, st.rows, nrhs,
+                                          st.max_act_rows, st.max_ncols, h->stream));
+        return QRK_STATUS_OK;
+    }
+    Staging s(h);
+    double *d_y, *d_t, *d_v;
+    qrk_status stt;
+    if ((stt = s.in(y_vals, st.y_len, &d_y)) || (stt = s.in(t_vals, st.t_len, &d_t)) ||
+        (stt = s.in((const double*)v, nrhs * st.rows, &d_v)))
+        return stt;
+    QRK_HIP(h, qrk::launch_bb_apply_q(p->d_panels, (int)st.panels.size(), d_y, d_t, transpose, d_v, st.rows, nrhs,
+                                      st.max_act_rows, st.max_ncols, h->stream));
+    if ((stt = s.back(v, d_v, nrhs * st.rows))) return stt;
     QRK_HIP(h, hipStreamSynchronize(h->stream));
     return QRK_STATUS_OK;
 }

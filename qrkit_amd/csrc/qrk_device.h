@@ -56,6 +56,15 @@ hipError_t launch_dense_qr(double* A, int64_t lda, int r, int c, int pivoting, d
                            hipStream_t stream);
 hipError_t launch_dense_apply_q(const double* QR, int64_t lda, int r, int nrefl, const double* hcoeffs,
                                 int transpose, double* B, int64_t ldb, int64_t nrhs, hipStream_t stream);
+struct BBPanel;
+hipError_t launch_bb_chain(const BBPanel* panels, int num_panels, const int32_t* prowptr, const int32_t* pcol,
+                           const int64_t* pmap, const double* vals, double* W, double* lo, double* y_vals,
+                           double* t_vals, double* r_stage, const int64_t* r_src, int64_t nnz_r, double* r_vals,
+                           int max_act_rows, int max_ncols, hipStream_t stream);
+hipError_t launch_bb_apply_q(const BBPanel* panels, int num_panels, const double* y_vals, const double* t_vals,
+                             int transpose, double* v, int64_t ldv, int64_t nrhs, int max_act_rows, int max_ncols,
+                             hipStream_t stream);
+size_t bb_chain_smem(int max_act_rows, int max_ncols);
 void launch_bd_pattern(const TileGeom& g, int64_t nnz_r, int32_t* q_rowptr, int32_t* q_colidx,
                        int32_t* r_colptr, int32_t* r_rowidx, hipStream_t stream);
 void launch_bd_q_tail_ones(double* q_vals, int64_t start, int64_t count, hipStream_t stream);
