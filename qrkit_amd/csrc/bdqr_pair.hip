@@ -85,6 +85,11 @@ __device__ __forceinline__ void fmac2_shared_a(double& d0, double& d1, double x,
 {
     asm("v_fmac_f64_e32 %0, %2, %3\n\tv_fmac_f64_e32 %1, %2, %4" : "+v"(d0), "+v"(d1) : "v"(x), "v"(c0), "v"(c1));
 }
+// d0 = x*c0; d1 = x*c1 (starts the two chains without zeroing accumulators).
+__device__ __forceinline__ void mul2_shared_a(double& d0, double& d1, double x, double c0, double c1)
+{
+    asm("v_mul_f64 %0, %2, %3\n\tv_mul_f64 %1, %2, %4" : "=&v"(d0), "=&v"(d1) : "v"(x), "v"(c0), "v"(c1));
+}
 // c0 += n0*x; c1 += n1*x.
 __device__ __forceinline__ void fmac2_shared_b(double& c0, double& c1, double n0, double n1, double x)
 {
@@ -104,13 +109,50 @@ __device__ __forceinline__ void tri_unpack(int e, int& p, int& i)
 // Per-lane state that lives across the steps.
 struct LaneState {
     int lane, j, half;
+    int sh8;         // 8 * half: bit offset of this half's field in packed wave-uniform words
+    int hb4;         // 128 * half: ds_bpermute byte address of lane 0 of this half
     bool live;       // this lane's A column is not yet chosen as a pivot
-    int pos;         // current position of this column (Eigen swaps columns physically)
-    int rows;        // tile rows of this half (rows >= this are zero padding)
+    unsigned long long livemask;   // the same as a wave-uniform lane mask
+    int kstep;       // step at which this column was chosen (= its final position), 64 = not yet
+    int rows, cols;  // tile shape of this half (rows/cols beyond are zero padding)
     double nu2;      // m_colNormsUpdated^2
     double thr_nd2;  // sqrt(eps) * m_colNormsDirect^2
     double h[RB];    // entry j of the pivot columns of the last RB steps
 };
+
+__device__ __forceinline__ unsigned long long ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+
+__device__ __forceinline__ double bpermute_f64(int byte_addr, double v)
+{
+    const int lo = __builtin_amdgcn_ds_bpermute(byte_addr, __double2loint(v));
+    const int hi = __builtin_amdgcn_ds_bpermute(byte_addr, __double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+
+// Rare path of the pivot search: several live columns share the high word of the largest squared
+// norm.  Compare the low words, then apply Eigen's first-maximum rule = smallest CURRENT position
+// among exact ties.  Positions are not tracked in the hot path (the final position of a column is
+// simply the step that chose it); here they are rebuilt by replaying the column transpositions of
+// steps 0..K-1 (ColPivHouseholderQR.h: m_qr.col(k).swap(m_qr.col(biggest_col_index))).
+// Returns a one-hot (per half) pivot flag.
+__device__ __forceinline__ bool resolve_ties(int K, int lane, int kstep, unsigned klo, bool cand)
+{
+    const int half = lane >> 5;
+    const unsigned ml = half32_max_u32(cand ? klo : 0u);
+    cand = cand && klo == ml;
+    int p = lane & 31;
+#pragma unroll 1
+    for (int k = 0; k < K; ++k) {
+        const unsigned long long m = ballot64(kstep == k);
+        const unsigned mh = half ? (unsigned)(m >> 32) : (unsigned)m;
+        const int l = (mh ? __ffs((int)mh) - 1 : 0) + 32 * half;
+        const int pl = __builtin_amdgcn_ds_bpermute(l * 4, p);
+        if (mh) p = (lane == l) ? k : (p == k ? pl : p);
+    }
+    const int pc = cand ? p : 64;
+    const int pmin = half32_min_i32(pc);
+    return pc == pmin && pc != 64;
+}
 
 // One step of ColPivHouseholderQR::computeInPlace (Eigen/src/QR/ColPivHouseholderQR.h) on both
 // wave-resident tiles: pivot search, reflector, trailing update of A and of Q^T, norm downdate.
@@ -120,60 +162,62 @@ struct LaneState {
 // temp (normUpd/normDir)^2 <= sqrt(eps)  is  nu2_new <= sqrt(eps) normDir^2: the same quantities
 // without two FP64 divisions and a square root per step; the first maximum is the same column
 // because squaring is monotone.
-template <int K, bool FULL32>
+//
+// The kernel is bound by the number of VALU instructions a wave issues (two waves per SIMD), so the
+// step is written to keep everything that is uniform per half out of VGPR selects: the pivot lane is
+// a lane mask, its index reaches the lanes as one bit-field extract of a packed scalar, and |tail|^2
+// comes from the pivot lane by ds_bpermute.  Columns that were already chosen are NOT masked out of
+// the arithmetic: nothing below the diagonal of R is ever read, so their lanes compute garbage.
+template <int K, bool FULL32, bool PIVOT, bool HC>
 __device__ __forceinline__ void pair_step(double (&a)[WR], double (&q)[WR], double* hl /* this half's LDS */,
-                                          LaneState& st, int pivoting, double* __restrict__ hcoeffs_tile)
+                                          LaneState& st, double* __restrict__ hcoeffs_tile)
 {
-    const int lane = st.lane, j = st.j;
-    // ---- pivot: first maximum of the updated norms over positions K..c-1, per half.  Non-negative
-    // doubles order like their bit patterns, so the max is an integer max on (hi, lo).
-    int lb;          // pivot lane of this lane's half
-    int lbA, lbB;    // pivot lanes of half 0 / half 1 (wave-uniform)
-    bool act;        // this half still has a column to eliminate at step K
-    if (pivoting) {
-        const int khi = st.live ? __double2hiint(st.nu2) : (int)0x80000000;
-        const int mh = half32_max_i32_fast(khi);
-        unsigned long long tie = __ballot(st.live && khi == mh);
-        unsigned tlo = (unsigned)tie, thi = (unsigned)(tie >> 32);
-        if (__popc(tlo) > 1 || __popc(thi) > 1) {
-            // several columns share the high word: compare the low words, then Eigen's first-maximum
-            // rule = smallest CURRENT position among exact ties
-            const unsigned klo = (unsigned)__double2loint(st.nu2);
-            const bool cand = (tie >> lane) & 1ull;
-            const unsigned ml = half32_max_u32(cand ? klo : 0u);
-            tie = __ballot(cand && klo == ml);
-            const int pc = ((tie >> lane) & 1ull) ? st.pos : 64;
-            const int pmin = half32_min_i32(pc);
-            tie = __ballot(pc == pmin && pc != 64);
-            tlo = (unsigned)tie; thi = (unsigned)(tie >> 32);
+    const int j = st.j;
+    // this half still has a column to eliminate at step K (always, for 32x32 tiles)
+    const bool act = FULL32 ? true : K < st.cols;
+    bool ispiv;      // this lane's column is the pivot of step K
+    int lbl;         // pivot lane of this lane's half, 0..31
+    if (PIVOT) {
+        // first maximum of the updated norms over the live columns, per half.  Non-negative doubles
+        // order like their bit patterns, so the max is an integer max on the high word (chosen
+        // columns carry a negative norm, see below) ...
+        const int khi = __double2hiint(st.nu2);
+        const int mh = half32_max_i32_fused(khi);
+        unsigned long long pm;
+        if (FULL32) {
+            pm = __builtin_amdgcn_uicmp(khi, mh, 32 /* ICMP_EQ */);   // a live column exists: mh >= 0
+            ispiv = khi == mh;
+        } else {
+            ispiv = st.live && khi == mh;
+            pm = ballot64(ispiv);
         }
-        lbA = tlo ? __ffs((int)tlo) - 1 : 0;
-        lbB = thi ? __ffs((int)thi) + 31 : 32;
-        lb = st.half ? lbB : lbA;
-        act = (st.half ? thi : tlo) != 0u;
-        const int bposA = __builtin_amdgcn_readlane(st.pos, lbA);
-        const int bposB = __builtin_amdgcn_readlane(st.pos, lbB);
-        const int bpos = st.half ? bposB : bposA;
-        if (lane == lb) st.pos = act ? K : st.pos;
-        else if (st.live && st.pos == K) st.pos = bpos;
+        unsigned tlo = (unsigned)pm, thi = (unsigned)(pm >> 32);
+        if (((tlo & (tlo - 1u)) | (thi & (thi - 1u))) != 0u) {
+            // ... unless several columns share it
+            ispiv = resolve_ties(K, st.lane, st.kstep, (unsigned)__double2loint(st.nu2), ispiv);
+            pm = ballot64(ispiv);
+            tlo = (unsigned)pm; thi = (unsigned)(pm >> 32);
+        }
+        const int lA = FULL32 ? __builtin_ctz(tlo) : (tlo ? __builtin_ctz(tlo) : 0);
+        const int lB = FULL32 ? __builtin_ctz(thi) : (thi ? __builtin_ctz(thi) : 0);
+        lbl = (int)__builtin_amdgcn_ubfe((unsigned)(lA | (lB << 8)), (unsigned)st.sh8, 5u);
+        st.livemask &= ~pm;
+        // a chosen column leaves the search: negative "norm" (it only decreases from here on)
+        st.nu2 = __hiloint2double(ispiv ? (int)0xBF800000 : khi, __double2loint(st.nu2));
     } else {
-        const unsigned long long lv = __ballot(st.live);
-        act = ((st.half ? (unsigned)(lv >> 32) : (unsigned)lv)) != 0u;   // HouseholderQR: column K
-        lbA = K; lbB = 32 + K;
-        lb = 32 * st.half + K;
+        ispiv = act && j == K;   // HouseholderQR: column K
+        lbl = K;
     }
-    const bool ispiv = act && lane == lb;
-    if (ispiv) st.live = false;
-    const int lbl = lb & 31;
+    if (ispiv) { st.live = false; st.kstep = K; }
 
-    // ---- pivot column: element (j, lb) of the LDS image (exact through step K0-1) plus the rank-1
+    // ---- pivot column: element (j, lbl) of the LDS image (exact through step K0-1) plus the rank-1
     // corrections of steps K0..K-1, then published for broadcast reads.
     constexpr int K0 = (K / RB) * RB;
     {
         double xi = hl[L_IMG + lbl * LDP + j];
 #pragma unroll
         for (int m = K0; m < K; ++m) xi = fma(hl[L_WBUF + (m % RB) * WR + lbl], st.h[m % RB], xi);
-        xi = (act && (FULL32 || j < st.rows)) ? xi : 0.0;
+        if (!FULL32) xi = (act && j < st.rows) ? xi : 0.0;
         st.h[K % RB] = xi;
         hl[L_XBUF + j] = xi;
     }
@@ -181,14 +225,10 @@ __device__ __forceinline__ void pair_step(double (&a)[WR], double (&q)[WR], doub
     // ---- d = x_tail^T c_tail for the A column and the Q^T column (pivot lane: dA = |x_tail|^2)
     const double ak = a[K], qk = q[K];
     const double xk = hl[L_XBUF + K];
-    double dA0 = 0.0, dQ0 = 0.0, dA1 = 0.0, dQ1 = 0.0;   // two accumulators per chain: half the dependent latency
+    double dA = 0.0, dQ = 0.0;
+    if (K + 1 < WR) mul2_shared_a(dA, dQ, hl[L_XBUF + K + 1], a[K + 1 < WR ? K + 1 : 0], q[K + 1 < WR ? K + 1 : 0]);
 #pragma unroll
-    for (int i = K + 1; i < WR; ++i) {
-        const double xv = hl[L_XBUF + i];   // broadcast read
-        if ((i - K) & 1) fmac2_shared_a(dA0, dQ0, xv, a[i], q[i]);
-        else fmac2_shared_a(dA1, dQ1, xv, a[i], q[i]);
-    }
-    const double dA = dA0 + dA1, dQ = dQ0 + dQ1;
+    for (int i = K + 2; i < WR; ++i) fmac2_shared_a(dA, dQ, hl[L_XBUF + i], a[i], q[i]);   // broadcast reads
 
     // ---- makeHouseholder + applyHouseholderOnTheLeft (Eigen/src/Householder/Householder.h) in the
     // un-normalised form: with beta = -sign(x0) sqrt(x0^2 + |tail|^2) and w = beta - x0,
@@ -196,38 +236,38 @@ __device__ __forceinline__ void pair_step(double (&a)[WR], double (&q)[WR], doub
     //   gamma = (d - w c_k) / (beta w):   c_k <- c_k + w gamma  (= c_k - tau tmp),
     //                                     c_i <- c_i - gamma x_i (= c_i - tau ess_i tmp),
     // which needs one square root and one reciprocal (of beta*w > 0) per step and no division.
-    const double tsA = readlane_f64(dA, lbA);
-    const double tsB = readlane_f64(dA, lbB);
-    const double tailSq = st.half ? tsB : tsA;
-    const bool degen = !act || tailSq <= DBL_MIN;   // Eigen: tau = 0, beta = x0, H = I
+    // Kept here: nb = -beta = copysign(norm, x0), s = -w = nb + x0, ng = -1/(beta w).
+    const double tailSq = bpermute_f64((lbl << 2) + st.hb4, dA);
     const double nrm = sqrt_pos(fma(xk, xk, tailSq));
-    double beta = xk >= 0.0 ? -nrm : nrm;
-    double w = beta - xk;
-    double g = recip(beta * w);
-    if (degen) { g = 0.0; beta = xk; w = 0.0; }   // (nrm may be NaN here: rsq(0) = inf)
-    if (hcoeffs_tile && ispiv) hcoeffs_tile[K] = (w * w) * g;     // tau = w/beta = w^2/(beta w)
-
-    // A column: chosen columns keep their R entries untouched (zero coefficient).
-    const double gamA = st.live ? fma(-w, ak, dA) * g : 0.0;
-    double an = fma(w, gamA, ak);
-    if (ispiv) an = beta;
-    const double gamQ = fma(-w, qk, dQ) * g;
-    q[K] = fma(w, gamQ, qk);
-    const double ncA = -gamA, ncQ = -gamQ;
-    hl[L_WBUF + (K % RB) * WR + j] = ncA;
-    // Re-read the pivot column from LDS for the update (a broadcast read is nearly free); the opaque
-    // offset keeps hipcc from carrying the 31 values of the dot pass in registers / scratch instead.
-    int xo = L_XBUF;
-    // (no launder)
-    const double* xb = hl + xo;
-#pragma unroll
-    for (int i = K + 1; i < WR; ++i) {
-        const double xv = xb[i];
-        fmac2_shared_b(a[i], q[i], ncA, ncQ, xv);
+    // Eigen: if (c0 >= 0) beta = -beta; -0.0 counts as >= 0, hence the + 0.0
+    double nb = __hiloint2double((__double2hiint(nrm) & 0x7fffffff) | (__double2hiint(xk + 0.0) & (int)0x80000000),
+                                 __double2loint(nrm));
+    double s = nb + xk;
+    double ng = -recip(nb * s);
+    // Eigen: tailSqNorm <= min() gives tau = 0, beta = x0, H = I.  Rare, so a real branch (the empty
+    // asm keeps hipcc from flattening it into selects); s = 0 leaves c_k = x0 in the pivot lane.
+    const bool degen = !act || !(tailSq > DBL_MIN);
+    const unsigned long long dm = FULL32 ? __builtin_amdgcn_fcmp(tailSq, DBL_MIN, 13 /* FCMP_ULE */) : ballot64(degen);
+    bool setdiag = ispiv;
+    if (__builtin_expect(dm != 0ull, 0)) {
+        asm volatile("");
+        if (degen) { ng = 0.0; s = 0.0; setdiag = false; }   // (nrm may be NaN here: rsq(0) = inf)
+    }
+    if (HC) {
+        if (hcoeffs_tile && ispiv) hcoeffs_tile[K] = -(s * s) * ng;   // tau = w/beta = w^2/(beta w)
     }
 
+    const double ngA = fma(s, ak, dA) * ng;      // -gamma for the A column
+    double an = fma(s, ngA, ak);
+    if (setdiag) an = -nb;                       // R(k,k) = beta
+    const double ngQ = fma(s, qk, dQ) * ng;
+    q[K] = fma(s, ngQ, qk);
+    hl[L_WBUF + (K % RB) * WR + j] = ngA;
+#pragma unroll
+    for (int i = K + 1; i < WR; ++i) fmac2_shared_b(a[i], q[i], ngA, ngQ, hl[L_XBUF + i]);
+
     // Row K of R is final: park it in the LDS slot of the pivot column (never read as a column again).
-    if (act && (st.live || ispiv)) hl[L_IMG + lbl * LDP + j] = an;
+    if (FULL32 || act) hl[L_IMG + lbl * LDP + j] = an;
 
     // ---- refresh the LDS image of the live columns after every RB-th step
     if (K % RB == RB - 1 && K + 1 < WR) {
@@ -238,16 +278,18 @@ __device__ __forceinline__ void pair_step(double (&a)[WR], double (&q)[WR], doub
     }
 
     // ---- LAWN-176 norm downdate for the remaining columns (squared form, see above)
-    if (pivoting) {
-        double nn = fma(-an, an, st.nu2);
-        nn = nn > 0.0 ? nn : 0.0;
-        const bool need = st.live && nn <= st.thr_nd2;
+    // No clamp at zero: a negative value is <= the threshold and is recomputed exactly.
+    if (PIVOT && K + 1 < WR) {
+        const double nn = fma(-an, an, st.nu2);
         st.nu2 = nn;
-        if (__any(need)) {
-            double s = 0.0;
+        const unsigned long long nm = __builtin_amdgcn_fcmp(nn, st.thr_nd2, 5 /* FCMP_OLE */) & st.livemask;
+        if (__builtin_expect(nm != 0ull, 0)) {
+            asm volatile("");
+            const bool need = st.live && nn <= st.thr_nd2;
+            double sq = 0.0;
 #pragma unroll
-            for (int i = K + 1; i < WR; ++i) s = fma(a[i], a[i], s);
-            if (need) { st.nu2 = s; st.thr_nd2 = s * SQRT_EPS; }
+            for (int i = K + 1; i < WR; ++i) sq = fma(a[i], a[i], sq);
+            if (need) { st.nu2 = sq; st.thr_nd2 = sq * SQRT_EPS; }
         }
     }
 }
@@ -255,7 +297,8 @@ __device__ __forceinline__ void pair_step(double (&a)[WR], double (&q)[WR], doub
 }  // namespace pair
 
 // FULL32: every tile is 32x32 and all arrays are 16-byte aligned (uniform batch).
-template <bool FULL32>
+// PIVOT: ColPivHouseholderQR (else HouseholderQR).  HC: also emit the Householder coefficients.
+template <bool FULL32, bool PIVOT, bool HC>
 __global__ void __launch_bounds__(64, 2)
 bdqr_pair_kernel(WaveBatch nb, const double* __restrict__ tiles, double* __restrict__ q_vals,
                  double* __restrict__ r_vals, int32_t* __restrict__ perm,
@@ -300,6 +343,11 @@ bdqr_pair_kernel(WaveBatch nb, const double* __restrict__ tiles, double* __restr
                         *reinterpret_cast<double2*>(&hl[L_IMG + (e2 >> 4) * LDP + ((e2 & 15) << 1)]) = v;
                     }
                 }
+            } else {
+                // missing partner of an odd last tile: diag(64..33) -- distinct norms, no tie-breaking;
+                // nothing of it is stored
+#pragma unroll 4
+                for (int i = 0; i < WR; ++i) hl[L_IMG + j * LDP + i] = (i == j) ? (double)(64 - j) : 0.0;
             }
         } else {
             const double* src = tiles + toff;
@@ -314,15 +362,17 @@ bdqr_pair_kernel(WaveBatch nb, const double* __restrict__ tiles, double* __restr
         double a[WR], q[WR];
 #pragma unroll
         for (int i = 0; i < WR; ++i) {
-            if (FULL32) a[i] = valid ? hl[L_IMG + j * LDP + i] : 0.0;
+            if (FULL32) a[i] = hl[L_IMG + j * LDP + i];
             else a[i] = (j < c && i < r) ? hl[L_IMG + j * LDP + i] : 0.0;
             q[i] = (i == j && j < r) ? 1.0 : 0.0;
         }
         // (no barrier: the image stays valid, it is the source of the pivot columns)
 
         LaneState st;
-        st.lane = lane; st.j = j; st.half = half; st.pos = j; st.rows = r;
-        st.live = j < c;
+        st.lane = lane; st.j = j; st.half = half; st.kstep = 64; st.rows = r; st.cols = c;
+        st.sh8 = half * 8; st.hb4 = half * 128;
+        st.live = FULL32 ? true : j < c;
+        st.livemask = FULL32 ? ~0ull : __builtin_amdgcn_ballot_w64(j < c);
 #pragma unroll
         for (int m = 0; m < RB; ++m) st.h[m] = 0.0;
         {
@@ -341,7 +391,7 @@ bdqr_pair_kernel(WaveBatch nb, const double* __restrict__ tiles, double* __restr
         // The k loop is expanded by the preprocessor: every row-register index is a compile-time
         // constant.  (A rolled loop dispatching through a uniform switch makes hipcc's CFG
         // structurizer copy the whole register tile at every merge point.)
-#define QRK_STEP(K) if (FULL32 || K < cmax) pair_step<K, FULL32>(a, q, hl, st, nb.pivoting, hc_tile);
+#define QRK_STEP(K) if (FULL32 || K < cmax) pair_step<K, FULL32, PIVOT, HC>(a, q, hl, st, hc_tile);
         QRK_0_31(QRK_STEP)
 #undef QRK_STEP
 
@@ -350,8 +400,9 @@ bdqr_pair_kernel(WaveBatch nb, const double* __restrict__ tiles, double* __restr
         // (BlockDiagonalSparseQR.h:475-479): element e -> (column p, row i), gathered through lane_of_pos.
         int* lane_of_pos = reinterpret_cast<int*>(&hl[L_POS]);
         if (j < c) {
-            lane_of_pos[st.pos] = j;
-            perm[cbase + st.pos] = cbase + j;     // m_outputPerm_c.indices()(base_col+j) (:519-521)
+            // the column chosen at step k ends at position k
+            lane_of_pos[st.kstep] = j;
+            perm[cbase + st.kstep] = cbase + j;   // m_outputPerm_c.indices()(base_col+j) (:519-521)
         }
         __syncthreads();
         if (FULL32) {
@@ -423,12 +474,16 @@ void launch_bdqr_pair(const WaveBatch& nb, bool full32, const double* tiles, dou
     (void)max_blocks;
     const int64_t npairs = (nb.num_tiles + 1) / 2;
     const dim3 grid((unsigned)npairs), block(64);
-    if (full32)
-        hipLaunchKernelGGL(bdqr_pair_kernel<true>, grid, block, 0, stream, nb, tiles, q_vals, r_vals,
-                           perm, hcoeffs);
-    else
-        hipLaunchKernelGGL(bdqr_pair_kernel<false>, grid, block, 0, stream, nb, tiles, q_vals, r_vals,
-                           perm, hcoeffs);
+#define QRK_LAUNCH(F, P, H)                                                                        \
+    hipLaunchKernelGGL((bdqr_pair_kernel<F, P, H>), grid, block, 0, stream, nb, tiles, q_vals, r_vals, perm, hcoeffs)
+    const bool piv = nb.pivoting != 0, hc = hcoeffs != nullptr;
+    if (full32) {
+        if (piv) { if (hc) QRK_LAUNCH(true, true, true); else QRK_LAUNCH(true, true, false); }
+        else { if (hc) QRK_LAUNCH(true, false, true); else QRK_LAUNCH(true, false, false); }
+    } else {
+        if (piv) QRK_LAUNCH(false, true, true); else QRK_LAUNCH(false, false, true);
+    }
+#undef QRK_LAUNCH
 }
 
 }  // namespace qrk

@@ -144,6 +144,24 @@ __device__ __forceinline__ int half32_max_i32_fast(int v)
     return max((int)r[0], (int)r[1]);
 }
 
+// Same reduction with the four DPP stages in ONE asm statement (hipcc pads every asm statement that
+// ends in a VALU write with another s_nop).
+__device__ __forceinline__ int half32_max_i32_fused(int v)
+{
+    int m;
+    asm("s_nop 1\n\t"
+        "v_max_i32_dpp %0, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_i32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_i32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_i32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf"
+        : "=&v"(m) : "v"(v));
+    const auto r = __builtin_amdgcn_permlane16_swap((unsigned)m, (unsigned)m, false, false);
+    return max((int)r[0], (int)r[1]);
+}
+
 // Max / min over each half of the wave (lanes 0..31 and 32..63 separately), result in every lane of
 // the half: four DPP stages inside the rows of 16, then v_permlane16_swap to combine the two rows.
 __device__ __forceinline__ int half32_max_i32(int v)
