@@ -33,6 +33,34 @@
 #include "qrk_device.h"
 
 #include <float.h>
+#include <cstdlib>
+
+// Diagnostic only (tools/ablate.py): -DQRK_ABL=<mask> removes one phase of the step to see what it
+// costs.  Results are wrong with any bit set; the product build never defines it.
+#ifndef QRK_ABL
+#define QRK_ABL 0
+#endif
+#ifndef QRK_XREREAD
+#define QRK_XREREAD 8
+#endif
+
+// Diagnostic only (tools/stamp_run.py): -DQRK_STAMP records s_memtime of lane 0 at phase boundaries
+// of every pair into the hcoeffs buffer (12 x int64 per pair).
+#ifdef QRK_STAMP
+#define QRK_STAMP_AT(slot)                                                                               \
+    do {                                                                                                 \
+        if (threadIdx.x == 0 && hcoeffs)                                                                 \
+            reinterpret_cast<unsigned long long*>(hcoeffs)[(size_t)pi * 12 + (slot)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#ifndef QRK_STAMP_K
+#define QRK_STAMP_K 20
+#endif
+// ... and inside step QRK_STAMP_K (kept in SGPRs, written out after the pair)
+#define QRK_STAMP_IN(n) do { if (K == QRK_STAMP_K) st.tk[n] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define QRK_STAMP_AT(slot) do { } while (0)
+#define QRK_STAMP_IN(n) do { } while (0)
+#endif
 
 namespace qrk {
 
@@ -41,6 +69,7 @@ namespace pair {
 constexpr int WR = 32;               // row registers per column
 constexpr int LDP = WR + 2;          // LDS column stride in doubles: 272 B, conflict-free b64/b128 access
 constexpr int RB = 4;                // the LDS image of A is refreshed every RB steps
+constexpr int CH = 8;                // rows of the pivot column held in registers at a time (x2: double buffer)
 // LDS carve-up per HALF (doubles)
 constexpr int L_IMG = 0;             // [32][LDP] column-major image of A / staging for Q; R rows parked here
 constexpr int L_XBUF = WR * LDP;     // [32] current pivot column
@@ -118,6 +147,9 @@ struct LaneState {
     double nu2;      // m_colNormsUpdated^2
     double thr_nd2;  // sqrt(eps) * m_colNormsDirect^2
     double h[RB];    // entry j of the pivot columns of the last RB steps
+#ifdef QRK_STAMP
+    unsigned long long tk[8];
+#endif
 };
 
 __device__ __forceinline__ unsigned long long ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
@@ -173,6 +205,7 @@ __device__ __forceinline__ void pair_step(double (&a)[WR], double (&q)[WR], doub
                                           LaneState& st, double* __restrict__ hcoeffs_tile)
 {
     const int j = st.j;
+    QRK_STAMP_IN(0);
     // this half still has a column to eliminate at step K (always, for 32x32 tiles)
     const bool act = FULL32 ? true : K < st.cols;
     bool ispiv;      // this lane's column is the pivot of step K
@@ -192,7 +225,7 @@ __device__ __forceinline__ void pair_step(double (&a)[WR], double (&q)[WR], doub
             pm = ballot64(ispiv);
         }
         unsigned tlo = (unsigned)pm, thi = (unsigned)(pm >> 32);
-        if (((tlo & (tlo - 1u)) | (thi & (thi - 1u))) != 0u) {
+        if (!(QRK_ABL & 1) && ((tlo & (tlo - 1u)) | (thi & (thi - 1u))) != 0u) {
             // ... unless several columns share it
             ispiv = resolve_ties(K, st.lane, st.kstep, (unsigned)__double2loint(st.nu2), ispiv);
             pm = ballot64(ispiv);
@@ -215,21 +248,51 @@ __device__ __forceinline__ void pair_step(double (&a)[WR], double (&q)[WR], doub
     constexpr int K0 = (K / RB) * RB;
     {
         double xi = hl[L_IMG + lbl * LDP + j];
+        QRK_STAMP_IN(1);
 #pragma unroll
-        for (int m = K0; m < K; ++m) xi = fma(hl[L_WBUF + (m % RB) * WR + lbl], st.h[m % RB], xi);
+        for (int m = (QRK_ABL & 256) ? K : K0; m < K; ++m) xi = fma(hl[L_WBUF + (m % RB) * WR + lbl], st.h[m % RB], xi);
         if (!FULL32) xi = (act && j < st.rows) ? xi : 0.0;
         st.h[K % RB] = xi;
         hl[L_XBUF + j] = xi;
+        QRK_STAMP_IN(2);
     }
 
     // ---- d = x_tail^T c_tail for the A column and the Q^T column (pivot lane: dA = |x_tail|^2)
     const double ak = a[K], qk = q[K];
     const double xk = hl[L_XBUF + K];
     double dA = 0.0, dQ = 0.0;
-    if (K + 1 < WR) mul2_shared_a(dA, dQ, hl[L_XBUF + K + 1], a[K + 1 < WR ? K + 1 : 0], q[K + 1 < WR ? K + 1 : 0]);
+    if (QRK_ABL & 32) { dA = xk; dQ = xk; }
+    else {
+        // The pivot column is consumed in chunks of CH rows, the next chunk's broadcast reads in flight
+        // while the current one is multiplied.  (Left alone, hipcc issues all 31 reads first and needs
+        // 62 registers for them.)
+        double xa[CH], xb[CH];
+        constexpr int C0 = (K + 1) / CH;
 #pragma unroll
-    for (int i = K + 2; i < WR; ++i) fmac2_shared_a(dA, dQ, hl[L_XBUF + i], a[i], q[i]);   // broadcast reads
+        for (int u = 0; u < CH; ++u) {
+            const int i = C0 * CH + u;
+            if (i >= K + 1 && i < WR) xa[u] = hl[L_XBUF + i];
+        }
+#pragma unroll
+        for (int cc = C0; cc < WR / CH; ++cc) {
+            if (cc + 1 < WR / CH) {
+#pragma unroll
+                for (int u = 0; u < CH; ++u) xb[u] = hl[L_XBUF + (cc + 1) * CH + u];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < CH; ++u) {
+                const int i = cc * CH + u;
+                if (i == K + 1) mul2_shared_a(dA, dQ, xa[u], a[i], q[i]);
+                else if (i > K + 1) fmac2_shared_a(dA, dQ, xa[u], a[i], q[i]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < CH; ++u) xa[u] = xb[u];
+        }
+    }
 
+    QRK_STAMP_IN(3);
     // ---- makeHouseholder + applyHouseholderOnTheLeft (Eigen/src/Householder/Householder.h) in the
     // un-normalised form: with beta = -sign(x0) sqrt(x0^2 + |tail|^2) and w = beta - x0,
     //   tau = w/beta, essential = tail/(x0 - beta) = -tail/w, and for a column c with tail dot d
@@ -237,19 +300,20 @@ __device__ __forceinline__ void pair_step(double (&a)[WR], double (&q)[WR], doub
     //                                     c_i <- c_i - gamma x_i (= c_i - tau ess_i tmp),
     // which needs one square root and one reciprocal (of beta*w > 0) per step and no division.
     // Kept here: nb = -beta = copysign(norm, x0), s = -w = nb + x0, ng = -1/(beta w).
-    const double tailSq = bpermute_f64((lbl << 2) + st.hb4, dA);
-    const double nrm = sqrt_pos(fma(xk, xk, tailSq));
+    const double tailSq = (QRK_ABL & 2) ? dA : bpermute_f64((lbl << 2) + st.hb4, dA);
+    const double nrm = (QRK_ABL & 8) ? fma(xk, xk, tailSq) : sqrt_pos(fma(xk, xk, tailSq));
     // Eigen: if (c0 >= 0) beta = -beta; -0.0 counts as >= 0, hence the + 0.0
     double nb = __hiloint2double((__double2hiint(nrm) & 0x7fffffff) | (__double2hiint(xk + 0.0) & (int)0x80000000),
                                  __double2loint(nrm));
     double s = nb + xk;
-    double ng = -recip(nb * s);
+    QRK_STAMP_IN(4);
+    double ng = (QRK_ABL & 8) ? -(nb * s) : -recip(nb * s);
     // Eigen: tailSqNorm <= min() gives tau = 0, beta = x0, H = I.  Rare, so a real branch (the empty
     // asm keeps hipcc from flattening it into selects); s = 0 leaves c_k = x0 in the pivot lane.
     const bool degen = !act || !(tailSq > DBL_MIN);
     const unsigned long long dm = FULL32 ? __builtin_amdgcn_fcmp(tailSq, DBL_MIN, 13 /* FCMP_ULE */) : ballot64(degen);
     bool setdiag = ispiv;
-    if (__builtin_expect(dm != 0ull, 0)) {
+    if (!(QRK_ABL & 4) && __builtin_expect(dm != 0ull, 0)) {
         asm volatile("");
         if (degen) { ng = 0.0; s = 0.0; setdiag = false; }   // (nrm may be NaN here: rsq(0) = inf)
     }
@@ -262,15 +326,45 @@ __device__ __forceinline__ void pair_step(double (&a)[WR], double (&q)[WR], doub
     if (setdiag) an = -nb;                       // R(k,k) = beta
     const double ngQ = fma(s, qk, dQ) * ng;
     q[K] = fma(s, ngQ, qk);
+    QRK_STAMP_IN(5);
     hl[L_WBUF + (K % RB) * WR + j] = ngA;
+    // Early steps: read the pivot column again for the update (a broadcast read is nearly free) instead
+    // of carrying up to 31 values of the dot pass in registers; the opaque offset stops hipcc's CSE.
+    int xo = L_XBUF;
+    if (K < QRK_XREREAD) asm volatile("" : "+v"(xo));
+    const double* xu = hl + xo;
+    if (!(QRK_ABL & 16)) {
+        double xa[CH], xb[CH];
+        constexpr int C0 = (K + 1) / CH;
 #pragma unroll
-    for (int i = K + 1; i < WR; ++i) fmac2_shared_b(a[i], q[i], ngA, ngQ, hl[L_XBUF + i]);
+        for (int u = 0; u < CH; ++u) {
+            const int i = C0 * CH + u;
+            if (i >= K + 1 && i < WR) xa[u] = xu[i];
+        }
+#pragma unroll
+        for (int cc = C0; cc < WR / CH; ++cc) {
+            if (cc + 1 < WR / CH) {
+#pragma unroll
+                for (int u = 0; u < CH; ++u) xb[u] = xu[(cc + 1) * CH + u];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < CH; ++u) {
+                const int i = cc * CH + u;
+                if (i >= K + 1) fmac2_shared_b(a[i], q[i], ngA, ngQ, xa[u]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < CH; ++u) xa[u] = xb[u];
+        }
+    }
 
+    QRK_STAMP_IN(6);
     // Row K of R is final: park it in the LDS slot of the pivot column (never read as a column again).
-    if (FULL32 || act) hl[L_IMG + lbl * LDP + j] = an;
+    if (!(QRK_ABL & 64) && (FULL32 || act)) hl[L_IMG + lbl * LDP + j] = an;
 
     // ---- refresh the LDS image of the live columns after every RB-th step
-    if (K % RB == RB - 1 && K + 1 < WR) {
+    if (!(QRK_ABL & 64) && K % RB == RB - 1 && K + 1 < WR) {
         if (st.live) {
 #pragma unroll
             for (int i = K + 1; i < WR; ++i) hl[L_IMG + j * LDP + i] = a[i];
@@ -279,7 +373,7 @@ __device__ __forceinline__ void pair_step(double (&a)[WR], double (&q)[WR], doub
 
     // ---- LAWN-176 norm downdate for the remaining columns (squared form, see above)
     // No clamp at zero: a negative value is <= the threshold and is recomputed exactly.
-    if (PIVOT && K + 1 < WR) {
+    if (!(QRK_ABL & 128) && PIVOT && K + 1 < WR) {
         const double nn = fma(-an, an, st.nu2);
         st.nu2 = nn;
         const unsigned long long nm = __builtin_amdgcn_fcmp(nn, st.thr_nd2, 5 /* FCMP_OLE */) & st.livemask;
@@ -292,6 +386,7 @@ __device__ __forceinline__ void pair_step(double (&a)[WR], double (&q)[WR], doub
             if (need) { st.nu2 = sq; st.thr_nd2 = sq * SQRT_EPS; }
         }
     }
+    QRK_STAMP_IN(7);
 }
 
 }  // namespace pair
@@ -311,6 +406,7 @@ bdqr_pair_kernel(WaveBatch nb, const double* __restrict__ tiles, double* __restr
     {
         const int64_t pi = blockIdx.x;
         const int lane = threadIdx.x;
+        QRK_STAMP_AT(0);
         const int half = lane >> 5, j = lane & 31;
         double* hl = lds + half * L_HALF;
         const int64_t t = 2 * pi + half;
@@ -391,8 +487,20 @@ bdqr_pair_kernel(WaveBatch nb, const double* __restrict__ tiles, double* __restr
         // The k loop is expanded by the preprocessor: every row-register index is a compile-time
         // constant.  (A rolled loop dispatching through a uniform switch makes hipcc's CFG
         // structurizer copy the whole register tile at every merge point.)
-#define QRK_STEP(K) if (FULL32 || K < cmax) pair_step<K, FULL32, PIVOT, HC>(a, q, hl, st, hc_tile);
+#define QRK_STEP(K) if (!(QRK_ABL & 1024) && (FULL32 || K < cmax)) pair_step<K, FULL32, PIVOT, HC>(a, q, hl, st, hc_tile);
+#ifdef QRK_STAMP
+        QRK_STAMP_AT(1);
+        QRK_STEP(0) QRK_STEP(1) QRK_STEP(2) QRK_STEP(3) QRK_STEP(4) QRK_STEP(5) QRK_STEP(6) QRK_STEP(7)
+        QRK_STAMP_AT(2);
+        QRK_STEP(8) QRK_STEP(9) QRK_STEP(10) QRK_STEP(11) QRK_STEP(12) QRK_STEP(13) QRK_STEP(14) QRK_STEP(15)
+        QRK_STAMP_AT(3);
+        QRK_STEP(16) QRK_STEP(17) QRK_STEP(18) QRK_STEP(19) QRK_STEP(20) QRK_STEP(21) QRK_STEP(22) QRK_STEP(23)
+        QRK_STAMP_AT(4);
+        QRK_STEP(24) QRK_STEP(25) QRK_STEP(26) QRK_STEP(27) QRK_STEP(28) QRK_STEP(29) QRK_STEP(30) QRK_STEP(31)
+        QRK_STAMP_AT(5);
+#else
         QRK_0_31(QRK_STEP)
+#endif
 #undef QRK_STEP
 
         // ---- R: row i of R sits in the LDS slot of the column chosen at step i, indexed by ORIGINAL
@@ -463,23 +571,269 @@ bdqr_pair_kernel(WaveBatch nb, const double* __restrict__ tiles, double* __restr
             }
         }
         __syncthreads();
+        QRK_STAMP_AT(6);
+#ifdef QRK_STAMP
+        if (threadIdx.x == 0 && hcoeffs) reinterpret_cast<unsigned long long*>(hcoeffs)[(size_t)pi * 12 + 8] = blockIdx.x;
+#endif
     }
 }
+
+namespace pair {
+// Epilogue of one 32x32 pair: R (packed upper triangle through the permutation) and perm.
+// All per-lane addresses derive from an opaque lane id so that none of them is computed (and kept
+// alive) before the factorisation.
+__device__ __forceinline__ void epilogue32(int lane_in, int64_t pi, int64_t num_tiles, int kstep, double* lds,
+                                           double* __restrict__ r_vals, int32_t* __restrict__ perm)
+{
+    int lane = lane_in;
+    asm volatile("" : "+v"(lane));
+    const int half = lane >> 5, j = lane & 31;
+    double* hl = lds + half * L_HALF;
+    const int64_t t = 2 * pi + half;
+    const bool valid = t < num_tiles;
+    const int cbase = (int)(t * 32);
+    // ---- R: row i of R sits in the LDS slot of the column chosen at step i, indexed by ORIGINAL
+    // column.  The packed upper triangle by columns is exactly the CSC value order of m_R
+    // (BlockDiagonalSparseQR.h:475-479): element e -> (column p, row i), gathered through lane_of_pos.
+    int* lane_of_pos = reinterpret_cast<int*>(&hl[L_POS]);
+    lane_of_pos[kstep] = j;                            // the column chosen at step k ends at position k
+    if (valid) perm[cbase + kstep] = cbase + j;        // m_outputPerm_c.indices()(base_col+j) (:519-521)
+    __syncthreads();
+    if (valid) {
+        double2* dst = reinterpret_cast<double2*>(r_vals + t * 528);
+#pragma unroll 1
+        for (int qq = 0; qq < 9; ++qq) {
+            const int e2 = j + 32 * qq;
+            if (e2 < 264) {
+                int p0, i0, p1, i1;
+                tri_unpack(2 * e2, p0, i0);
+                tri_unpack(2 * e2 + 1, p1, i1);
+                dst[e2] = make_double2(hl[L_IMG + lane_of_pos[i0] * LDP + lane_of_pos[p0]],
+                                       hl[L_IMG + lane_of_pos[i1] * LDP + lane_of_pos[p1]]);
+            }
+        }
+    }
+    __syncthreads();
+}
+
+// Half of the rows of Q straight from the registers: lane j holds row j of Q_i (row-major rows are the
+// CSR value order of m_Q in both FullQ ([U|N] split, BlockDiagonalSparseQR.h:455-471) and
+// BlockDiagonalQ (:480-492) layouts), and entries q[0..k] are final after step k.  Each lane writes
+// 128 contiguous bytes = one cache line of its row with eight 16-byte stores issued back to back
+// (they meet again in the L2 line); no LDS staging, the registers are free at once, and the stores
+// are spread over the factorisation instead of arriving as one burst at its end.
+template <int FIRST>
+__device__ __forceinline__ void store_q_half(int lane_in, int64_t pi, int64_t num_tiles, const double (&q)[WR],
+                                             double* __restrict__ q_vals)
+{
+    int lane = lane_in;
+    asm volatile("" : "+v"(lane));
+    const int64_t t = 2 * pi + (lane >> 5);
+    if (t < num_tiles) {
+        double2* dst = reinterpret_cast<double2*>(q_vals + t * 1024 + (lane & 31) * 32 + FIRST);
+#pragma unroll
+        for (int m = 0; m < 8; ++m) dst[m] = make_double2(q[FIRST + 2 * m], q[FIRST + 2 * m + 1]);
+    }
+}
+}  // namespace pair
+
+// Uniform 32x32 batches (all arrays 16-byte aligned): persistent workgroups, software-pipelined
+// against HBM.  With two 232-register waves per SIMD nothing else can hide the tile loads, so each
+// wave fetches its NEXT tile while it factorises the current one: row register a[k] is dead after
+// step k, so after step 15 columns 0..15 of the next tile are loaded into a[0..15] (coalesced: lane j
+// takes ROW j, 8 bytes per column -- 8-byte loads because 16-byte register tuples that live across
+// the loop edge fragment the register file and spill), and after step 31 columns 16..31 into
+// a[16..31].  At the top of the next round the rows go to the LDS image (which transposes them to
+// lane = column) and the lane reads its column back.  Stores are fire-and-forget.
+template <bool PIVOT, bool HC>
+__global__ void __launch_bounds__(64, 2)
+bdqr_pair32_kernel(int64_t num_tiles, const double* __restrict__ tiles, double* __restrict__ q_vals,
+                   double* __restrict__ r_vals, int32_t* __restrict__ perm, double* __restrict__ hcoeffs)
+{
+    using namespace pair;
+    __shared__ __attribute__((aligned(16))) double lds[2 * L_HALF];
+    const int64_t npairs = (num_tiles + 1) / 2;
+    double a[WR], q[WR];
+
+    int64_t pi = blockIdx.x;
+    {
+        const int j = threadIdx.x & 31;
+        const int64_t t = 2 * pi + (threadIdx.x >> 5);
+        if (t < num_tiles) {
+            const double* src = tiles + t * 1024 + j;
+#pragma unroll
+            for (int m = 0; m < WR; ++m) a[m] = src[32 * m];   // element (row j, column m)
+        } else {
+#pragma unroll
+            for (int i = 0; i < WR; ++i) a[i] = 0.0;
+        }
+    }
+    for (; pi < npairs; pi += gridDim.x) {
+        // Everything per-lane is re-derived from an opaque lane id in every round: otherwise hipcc
+        // hoists the (loop-invariant) LDS addresses and packed-triangle indices of the epilogue out of
+        // the loop and keeps ~100 of them in scratch across the factorisation.
+        int lane = threadIdx.x;
+        asm volatile("" : "+v"(lane));
+        QRK_STAMP_AT(0);
+        const int half = lane >> 5, j = lane & 31;
+        double* hl = lds + half * L_HALF;
+        const int64_t t = 2 * pi + half;
+        const bool valid = t < num_tiles;
+        const int cbase = (int)(t * 32);
+
+        // ---- stage: chunk m of the lane -> its place in the padded column-major image
+#pragma unroll
+        for (int m = 0; m < WR; ++m) hl[L_IMG + m * LDP + j] = a[m];
+        if (!valid) {
+            // missing partner of an odd last tile: diag(64..33) -- distinct norms, no tie-breaking;
+            // nothing of it is stored
+#pragma unroll 4
+            for (int i = 0; i < WR; ++i) hl[L_IMG + j * LDP + i] = (i == j) ? (double)(64 - j) : 0.0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < WR; ++i) {
+            a[i] = hl[L_IMG + j * LDP + i];
+            q[i] = (i == j && valid) ? 1.0 : 0.0;
+        }
+
+        LaneState st;
+        st.lane = lane; st.j = j; st.half = half; st.kstep = 64; st.rows = 32; st.cols = 32;
+        st.sh8 = half * 8; st.hb4 = half * 128;
+        st.live = true;
+        st.livemask = ~0ull;
+#pragma unroll
+        for (int m = 0; m < RB; ++m) st.h[m] = 0.0;
+        {
+            // squared column norms (ColPivHouseholderQR: m_colNormsUpdated^2, sqrt(eps) m_colNormsDirect^2)
+            double s = 0.0;
+#pragma unroll
+            for (int i = 0; i < WR; ++i) s = fma(a[i], a[i], s);
+            st.nu2 = s;
+            st.thr_nd2 = s * SQRT_EPS;
+        }
+        double* hc_tile = (HC && hcoeffs && valid) ? hcoeffs + cbase : nullptr;
+        QRK_STAMP_AT(1);
+
+#define QRK_STEP(K) pair_step<K, true, PIVOT, HC>(a, q, hl, st, hc_tile);
+        QRK_STEP(0) QRK_STEP(1) QRK_STEP(2) QRK_STEP(3) QRK_STEP(4) QRK_STEP(5) QRK_STEP(6) QRK_STEP(7)
+        QRK_STAMP_AT(2);
+        QRK_STEP(8) QRK_STEP(9) QRK_STEP(10) QRK_STEP(11) QRK_STEP(12) QRK_STEP(13) QRK_STEP(14) QRK_STEP(15)
+        QRK_STAMP_AT(3);
+        store_q_half<0>(threadIdx.x, pi, num_tiles, q, q_vals);
+        {
+            // columns 0..15 of this half-wave's tile of the next round -> a[0..15] (dead by now)
+            int ln = threadIdx.x;
+            asm volatile("" : "+v"(ln));
+            const int64_t tn = 2 * (pi + gridDim.x) + (ln >> 5);
+            if (tn < num_tiles) {
+                const double* nsrc = tiles + tn * 1024 + (ln & 31);
+#pragma unroll
+                for (int m = 0; m < 16; ++m) a[m] = nsrc[32 * m];
+            }
+        }
+        QRK_STEP(16) QRK_STEP(17) QRK_STEP(18) QRK_STEP(19) QRK_STEP(20) QRK_STEP(21) QRK_STEP(22) QRK_STEP(23)
+        QRK_STAMP_AT(4);
+        QRK_STEP(24) QRK_STEP(25) QRK_STEP(26) QRK_STEP(27) QRK_STEP(28) QRK_STEP(29) QRK_STEP(30) QRK_STEP(31)
+#undef QRK_STEP
+        QRK_STAMP_AT(5);
+        store_q_half<16>(threadIdx.x, pi, num_tiles, q, q_vals);
+        {
+            // columns 16..31 of the next tile -> a[16..31]
+            int ln = threadIdx.x;
+            asm volatile("" : "+v"(ln));
+            const int64_t tn = 2 * (pi + gridDim.x) + (ln >> 5);
+            if (tn < num_tiles) {
+                const double* nsrc = tiles + tn * 1024 + (ln & 31);
+#pragma unroll
+                for (int m = 16; m < WR; ++m) a[m] = nsrc[32 * m];
+            }
+        }
+        epilogue32(threadIdx.x, pi, num_tiles, st.kstep, lds, r_vals, perm);
+        QRK_STAMP_AT(6);
+#ifdef QRK_STAMP
+        if (threadIdx.x == 0 && hcoeffs) {
+            unsigned hwid;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+            unsigned xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            reinterpret_cast<unsigned long long*>(hcoeffs)[(size_t)pi * 12 + 7] = ((unsigned long long)xcc << 32) | hwid;
+            reinterpret_cast<unsigned long long*>(hcoeffs)[(size_t)pi * 12 + 8] = blockIdx.x;
+            for (int n = 0; n < 8; ++n)
+                reinterpret_cast<unsigned long long*>(hcoeffs)[(size_t)npairs * 12 + (size_t)pi * 8 + n] = st.tk[n];
+        }
+#endif
+    }
+}
+#if 0
+        int* lane_of_pos = reinterpret_cast<int*>(&hl[L_POS]);
+        // the column chosen at step k ends at position k
+        lane_of_pos[st.kstep] = j;
+        if (valid) perm[cbase + st.kstep] = cbase + j;   // m_outputPerm_c.indices()(base_col+j) (:519-521)
+        __syncthreads();
+        if (valid) {
+            double2* dst = reinterpret_cast<double2*>(r_vals + roff);
+#pragma unroll
+            for (int qq = 0; qq < 9; ++qq) {
+                const int e2 = j + 32 * qq;
+                if (e2 < 264) {
+                    int p0, i0, p1, i1;
+                    tri_unpack(2 * e2, p0, i0);
+                    tri_unpack(2 * e2 + 1, p1, i1);
+                    dst[e2] = make_double2(hl[L_IMG + lane_of_pos[i0] * LDP + lane_of_pos[p0]],
+                                           hl[L_IMG + lane_of_pos[i1] * LDP + lane_of_pos[p1]]);
+                }
+            }
+        }
+        __syncthreads();
+        // ---- Q: lane j holds row j of Q_i; row-major rows are the CSR value order of m_Q in both
+        // FullQ ([U|N] split, :455-471) and BlockDiagonalQ (:480-492) layouts.
+#pragma unroll
+        for (int i = 0; i < WR; i += 2)
+            *reinterpret_cast<double2*>(&hl[L_IMG + j * LDP + i]) = make_double2(q[i], q[i + 1]);
+        __syncthreads();
+        if (valid) {
+            double2* dst = reinterpret_cast<double2*>(q_vals + qoff);
+            for (int q0 = 0; q0 < 16; q0 += 8) {
+#pragma unroll
+                for (int qq = 0; qq < 8; ++qq) {
+                    const int e2 = j + 32 * (q0 + qq);
+                    dst[e2] = *reinterpret_cast<const double2*>(&hl[L_IMG + (e2 >> 4) * LDP + ((e2 & 15) << 1)]);
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+#endif
 
 void launch_bdqr_pair(const WaveBatch& nb, bool full32, const double* tiles, double* q_vals,
                       double* r_vals, int32_t* perm, double* hcoeffs, int max_blocks,
                       hipStream_t stream)
 {
     if (nb.num_tiles <= 0) return;
-    (void)max_blocks;
     const int64_t npairs = (nb.num_tiles + 1) / 2;
     const dim3 grid((unsigned)npairs), block(64);
 #define QRK_LAUNCH(F, P, H)                                                                        \
     hipLaunchKernelGGL((bdqr_pair_kernel<F, P, H>), grid, block, 0, stream, nb, tiles, q_vals, r_vals, perm, hcoeffs)
     const bool piv = nb.pivoting != 0, hc = hcoeffs != nullptr;
     if (full32) {
-        if (piv) { if (hc) QRK_LAUNCH(true, true, true); else QRK_LAUNCH(true, true, false); }
-        else { if (hc) QRK_LAUNCH(true, false, true); else QRK_LAUNCH(true, false, false); }
+        // persistent: one workgroup per resident wave slot (2 waves per SIMD, 20 KB of LDS each)
+        const int64_t slots = max_blocks > 0 ? max_blocks : npairs;
+        const dim3 pgrid((unsigned)(npairs < slots ? npairs : slots));
+#define QRK_LAUNCH32(P, H)                                                                         \
+    hipLaunchKernelGGL((bdqr_pair32_kernel<P, H>), pgrid, block, 0, stream, nb.num_tiles, tiles, q_vals, r_vals, perm, hcoeffs)
+#if QRK_ABL || defined(QRK_STAMP)
+        // diagnostic builds: the bench variant only; QRK_PAIR_PERSIST=0 selects the one-pair-per-workgroup kernel
+        if (const char* e = std::getenv("QRK_PAIR_PERSIST")) {
+            if (e[0] == '0') { QRK_LAUNCH(true, true, false); return; }
+        }
+        QRK_LAUNCH32(true, false);
+        return;
+#endif
+        if (piv) { if (hc) QRK_LAUNCH32(true, true); else QRK_LAUNCH32(true, false); }
+        else { if (hc) QRK_LAUNCH32(false, true); else QRK_LAUNCH32(false, false); }
+#undef QRK_LAUNCH32
     } else {
         if (piv) QRK_LAUNCH(false, true, true); else QRK_LAUNCH(false, false, true);
     }

@@ -27,6 +27,7 @@ struct qrk_context_s {
     int device = 0;
     hipStream_t stream = nullptr;
     int num_cus = 256;
+    int pair_wgs_per_cu = 8;       // resident pair-kernel workgroups per CU: 2 waves per SIMD (232 VGPRs, 20 KB LDS each)
     bool use_pair_kernel = true;   // two tiles per wavefront (bdqr_pair.hip); QRK_KERNEL=wave selects bdqr_wave.hip
     std::string error;
 };
@@ -157,13 +158,13 @@ qrk_status enqueue_factorize(qrk_bd_plan_s* p, const double* tiles, double* q, d
                               reinterpret_cast<uintptr_t>(r)) & 15u) == 0;
         if (p->max_dim > 32)
             qrk::launch_bdqr_wg(nb, tiles, q, r, perm, hc, p->d_workspace, p->ws_stride, p->num_wg, p->max_dim, h->stream);
-        else if (h->use_pair_kernel) qrk::launch_bdqr_pair(nb, full32, tiles, q, r, perm, hc, max_blocks, h->stream);
+        else if (h->use_pair_kernel) qrk::launch_bdqr_pair(nb, full32, tiles, q, r, perm, hc, h->num_cus * h->pair_wgs_per_cu, h->stream);
         else qrk::launch_bdqr_wave(nb, full32, tiles, q, r, perm, hc, max_blocks, h->stream);
     } else {
         nb.num_tiles = p->n_wave; nb.tile_ids = p->d_wave_ids;
         nb.t_rows = p->d_rows; nb.t_cols = p->d_cols; nb.t_off = p->d_toff;
         nb.q_off = p->d_qoff; nb.r_off = p->d_roff; nb.c_off = p->d_coff;
-        if (h->use_pair_kernel) qrk::launch_bdqr_pair(nb, false, tiles, q, r, perm, hc, max_blocks, h->stream);
+        if (h->use_pair_kernel) qrk::launch_bdqr_pair(nb, false, tiles, q, r, perm, hc, h->num_cus * h->pair_wgs_per_cu, h->stream);
         else qrk::launch_bdqr_wave(nb, false, tiles, q, r, perm, hc, max_blocks, h->stream);
         if (p->n_wg > 0) {
             qrk::WaveBatch lb = nb;
@@ -204,6 +205,7 @@ qrk_status qrk_create(qrk_handle* out, int device, void* stream)
     h->device = device;
     h->stream = static_cast<hipStream_t>(stream);
     if (const char* k = std::getenv("QRK_KERNEL")) h->use_pair_kernel = std::strcmp(k, "wave") != 0;
+    if (const char* k = std::getenv("QRK_PAIR_WGS_PER_CU")) { const int v = std::atoi(k); if (v > 0) h->pair_wgs_per_cu = v; }
     if (hipSetDevice(device) != hipSuccess) {
         delete h;
         return fail(nullptr, QRK_STATUS_HIP_ERROR, "qrk_create: hipSetDevice failed");
