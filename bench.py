@@ -188,7 +188,7 @@ def main():
             "gflops": fact_per_s * BLOCKS * FLOPS_PER_TILE / 1e9,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": _traffic(),
-                         "kernel": "qrk::bdqr_pair_kernel<true>", "avg_launch_ms": kernel_ms,
+                         "kernel": "qrk::bdqr_pair32_kernel<true, false>", "avg_launch_ms": kernel_ms,
                          "algorithmic_bytes_per_launch": bytes_per_launch},
         }
         if not args.no_cpu_baseline:

@@ -25,11 +25,16 @@
 // 32-double vector that the half then reads by broadcast.  No barrier inside the factorisation
 // (one wave, in-order LDS queue).
 //
-// Columns are never physically swapped: each lane tracks the current position of its A column
-// (Eigen's m_colsTranspositions bookkeeping), so the "first maximum" tie rule and the final
-// permutation are those of Eigen's ColPivHouseholderQR.  Row k of R is final after step k and is
-// parked in the LDS slot of the pivot column (dead from then on); the epilogue gathers the packed
-// upper triangle through the permutation.  All global accesses are coalesced 16-B accesses via LDS.
+// Columns are never physically swapped.  The column chosen at step k ends at position k, which is
+// all the final permutation needs; the current positions that Eigen's "first maximum" tie rule
+// looks at (m_colsTranspositions bookkeeping) are rebuilt only when an exact tie occurs.  Row k of R
+// is final after step k and is parked in the LDS slot of the pivot column (dead from then on); the
+// epilogue gathers the packed upper triangle through the permutation.
+//
+// Two kernels share the step: bdqr_pair_kernel (one pair per workgroup, any tile shape <= 32x32,
+// coalesced I/O staged through LDS) and bdqr_pair32_kernel (uniform 32x32 batches: persistent
+// workgroups that prefetch their next tile into dead registers and store Q rows straight from
+// registers).  Measured history and the per-phase cycle counts are in DESIGN.md.
 #include "qrk_device.h"
 
 #include <float.h>
@@ -39,9 +44,6 @@
 // costs.  Results are wrong with any bit set; the product build never defines it.
 #ifndef QRK_ABL
 #define QRK_ABL 0
-#endif
-#ifndef QRK_XREREAD
-#define QRK_XREREAD 8
 #endif
 
 // Diagnostic only (tools/stamp_run.py): -DQRK_STAMP records s_memtime of lane 0 at phase boundaries
@@ -69,7 +71,6 @@ namespace pair {
 constexpr int WR = 32;               // row registers per column
 constexpr int LDP = WR + 2;          // LDS column stride in doubles: 272 B, conflict-free b64/b128 access
 constexpr int RB = 4;                // the LDS image of A is refreshed every RB steps
-constexpr int CH = 8;                // rows of the pivot column held in registers at a time (x2: double buffer)
 // LDS carve-up per HALF (doubles)
 constexpr int L_IMG = 0;             // [32][LDP] column-major image of A / staging for Q; R rows parked here
 constexpr int L_XBUF = WR * LDP;     // [32] current pivot column
@@ -141,6 +142,8 @@ struct LaneState {
     int sh8;         // 8 * half: bit offset of this half's field in packed wave-uniform words
     int hb4;         // 128 * half: ds_bpermute byte address of lane 0 of this half
     bool live;       // this lane's A column is not yet chosen as a pivot
+    bool ispiv;      // this lane's column is the pivot of the step whose head (search_fetch) ran last
+    int lbl;         // ... and the pivot lane of this half, 0..31
     unsigned long long livemask;   // the same as a wave-uniform lane mask
     int kstep;       // step at which this column was chosen (= its final position), 64 = not yet
     int rows, cols;  // tile shape of this half (rows/cols beyond are zero padding)
@@ -200,9 +203,16 @@ __device__ __forceinline__ bool resolve_ties(int K, int lane, int kstep, unsigne
 // a lane mask, its index reaches the lanes as one bit-field extract of a packed scalar, and |tail|^2
 // comes from the pivot lane by ds_bpermute.  Columns that were already chosen are NOT masked out of
 // the arithmetic: nothing below the diagonal of R is ever read, so their lanes compute garbage.
-template <int K, bool FULL32, bool PIVOT, bool HC>
-__device__ __forceinline__ void pair_step(double (&a)[WR], double (&q)[WR], double* hl /* this half's LDS */,
-                                          LaneState& st, double* __restrict__ hcoeffs_tile)
+//
+// The steps are software-pipelined: a lone wave stalls ~1100 cycles per step on the chain
+// search -> image read -> publish -> broadcast read (tools/stamp_run.py), and with 232 registers only
+// two waves share a SIMD.  So the head of step K+1 (search_fetch: pivot search, image read, corrections,
+// publish) is issued inside step K, BEFORE the trailing update of step K, whose ~4(31-K) FMAs then
+// cover those LDS round trips.  The update therefore works from the pivot column kept in registers
+// (x[] below; XBUF already holds the next column), and search_fetch<K+1> sees an image that is one
+// update older: it applies the corrections of steps ((K)/RB)*RB .. K (1..RB of them).
+template <int K, bool FULL32, bool PIVOT>
+__device__ __forceinline__ void search_fetch(double* hl /* this half's LDS */, LaneState& st)
 {
     const int j = st.j;
     QRK_STAMP_IN(0);
@@ -242,53 +252,47 @@ __device__ __forceinline__ void pair_step(double (&a)[WR], double (&q)[WR], doub
         lbl = K;
     }
     if (ispiv) { st.live = false; st.kstep = K; }
+    st.ispiv = ispiv;
+    st.lbl = lbl;
 
-    // ---- pivot column: element (j, lbl) of the LDS image (exact through step K0-1) plus the rank-1
-    // corrections of steps K0..K-1, then published for broadcast reads.
-    constexpr int K0 = (K / RB) * RB;
+    // ---- pivot column: element (j, lbl) of the LDS image (exact through step KR-1) plus the rank-1
+    // corrections of steps KR..K-1, then published for broadcast reads.  The image is refreshed after
+    // the update of every RB-th step, i.e. after the search_fetch of the following step has run.
+    constexpr int KR = K == 0 ? 0 : ((K - 1) / RB) * RB;
     {
         double xi = hl[L_IMG + lbl * LDP + j];
         QRK_STAMP_IN(1);
 #pragma unroll
-        for (int m = (QRK_ABL & 256) ? K : K0; m < K; ++m) xi = fma(hl[L_WBUF + (m % RB) * WR + lbl], st.h[m % RB], xi);
+        for (int m = (QRK_ABL & 256) ? K : KR; m < K; ++m) xi = fma(hl[L_WBUF + (m % RB) * WR + lbl], st.h[m % RB], xi);
         if (!FULL32) xi = (act && j < st.rows) ? xi : 0.0;
         st.h[K % RB] = xi;
         hl[L_XBUF + j] = xi;
         QRK_STAMP_IN(2);
     }
+}
+
+template <int K, bool FULL32, bool PIVOT, bool HC>
+__device__ __forceinline__ void pair_step(double (&a)[WR], double (&q)[WR], double* hl /* this half's LDS */,
+                                          LaneState& st, double* __restrict__ hcoeffs_tile)
+{
+    const int j = st.j;
+    const bool act = FULL32 ? true : K < st.cols;
+    const bool ispiv = st.ispiv;     // set by search_fetch<K>
+    const int lbl = st.lbl;
 
     // ---- d = x_tail^T c_tail for the A column and the Q^T column (pivot lane: dA = |x_tail|^2)
     const double ak = a[K], qk = q[K];
     const double xk = hl[L_XBUF + K];
+    double x[WR];                    // rows K+1.. of the pivot column (broadcast reads)
+#pragma unroll
+    for (int i = K + 1; i < WR; ++i) x[i] = hl[L_XBUF + i];
     double dA = 0.0, dQ = 0.0;
     if (QRK_ABL & 32) { dA = xk; dQ = xk; }
     else {
-        // The pivot column is consumed in chunks of CH rows, the next chunk's broadcast reads in flight
-        // while the current one is multiplied.  (Left alone, hipcc issues all 31 reads first and needs
-        // 62 registers for them.)
-        double xa[CH], xb[CH];
-        constexpr int C0 = (K + 1) / CH;
 #pragma unroll
-        for (int u = 0; u < CH; ++u) {
-            const int i = C0 * CH + u;
-            if (i >= K + 1 && i < WR) xa[u] = hl[L_XBUF + i];
-        }
-#pragma unroll
-        for (int cc = C0; cc < WR / CH; ++cc) {
-            if (cc + 1 < WR / CH) {
-#pragma unroll
-                for (int u = 0; u < CH; ++u) xb[u] = hl[L_XBUF + (cc + 1) * CH + u];
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int u = 0; u < CH; ++u) {
-                const int i = cc * CH + u;
-                if (i == K + 1) mul2_shared_a(dA, dQ, xa[u], a[i], q[i]);
-                else if (i > K + 1) fmac2_shared_a(dA, dQ, xa[u], a[i], q[i]);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int u = 0; u < CH; ++u) xa[u] = xb[u];
+        for (int i = K + 1; i < WR; ++i) {
+            if (i == K + 1) mul2_shared_a(dA, dQ, x[i], a[i], q[i]);
+            else fmac2_shared_a(dA, dQ, x[i], a[i], q[i]);
         }
     }
 
@@ -328,62 +332,43 @@ __device__ __forceinline__ void pair_step(double (&a)[WR], double (&q)[WR], doub
     q[K] = fma(s, ngQ, qk);
     QRK_STAMP_IN(5);
     hl[L_WBUF + (K % RB) * WR + j] = ngA;
-    // Early steps: read the pivot column again for the update (a broadcast read is nearly free) instead
-    // of carrying up to 31 values of the dot pass in registers; the opaque offset stops hipcc's CSE.
-    int xo = L_XBUF;
-    if (K < QRK_XREREAD) asm volatile("" : "+v"(xo));
-    const double* xu = hl + xo;
-    if (!(QRK_ABL & 16)) {
-        double xa[CH], xb[CH];
-        constexpr int C0 = (K + 1) / CH;
-#pragma unroll
-        for (int u = 0; u < CH; ++u) {
-            const int i = C0 * CH + u;
-            if (i >= K + 1 && i < WR) xa[u] = xu[i];
-        }
-#pragma unroll
-        for (int cc = C0; cc < WR / CH; ++cc) {
-            if (cc + 1 < WR / CH) {
-#pragma unroll
-                for (int u = 0; u < CH; ++u) xb[u] = xu[(cc + 1) * CH + u];
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int u = 0; u < CH; ++u) {
-                const int i = cc * CH + u;
-                if (i >= K + 1) fmac2_shared_b(a[i], q[i], ngA, ngQ, xa[u]);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int u = 0; u < CH; ++u) xa[u] = xb[u];
-        }
-    }
-
-    QRK_STAMP_IN(6);
     // Row K of R is final: park it in the LDS slot of the pivot column (never read as a column again).
     if (!(QRK_ABL & 64) && (FULL32 || act)) hl[L_IMG + lbl * LDP + j] = an;
 
-    // ---- refresh the LDS image of the live columns after every RB-th step
-    if (!(QRK_ABL & 64) && K % RB == RB - 1 && K + 1 < WR) {
-        if (st.live) {
-#pragma unroll
-            for (int i = K + 1; i < WR; ++i) hl[L_IMG + j * LDP + i] = a[i];
-        }
-    }
-
-    // ---- LAWN-176 norm downdate for the remaining columns (squared form, see above)
+    // ---- LAWN-176 norm downdate for the remaining columns (squared form, see above).
     // No clamp at zero: a negative value is <= the threshold and is recomputed exactly.
+    bool updated = false;
     if (!(QRK_ABL & 128) && PIVOT && K + 1 < WR) {
         const double nn = fma(-an, an, st.nu2);
         st.nu2 = nn;
         const unsigned long long nm = __builtin_amdgcn_fcmp(nn, st.thr_nd2, 5 /* FCMP_OLE */) & st.livemask;
         if (__builtin_expect(nm != 0ull, 0)) {
+            // rare: a column norm has to be recomputed from the updated column before the next search
             asm volatile("");
+#pragma unroll
+            for (int i = K + 1; i < WR; ++i) fmac2_shared_b(a[i], q[i], ngA, ngQ, x[i]);
+            updated = true;
             const bool need = st.live && nn <= st.thr_nd2;
             double sq = 0.0;
 #pragma unroll
             for (int i = K + 1; i < WR; ++i) sq = fma(a[i], a[i], sq);
             if (need) { st.nu2 = sq; st.thr_nd2 = sq * SQRT_EPS; }
+        }
+    }
+
+    // ---- head of the next step, then the trailing update of this one
+    if (K + 1 < WR) search_fetch<(K + 1 < WR ? K + 1 : K), FULL32, PIVOT>(hl, st);
+    if (!(QRK_ABL & 16) && !updated) {
+#pragma unroll
+        for (int i = K + 1; i < WR; ++i) fmac2_shared_b(a[i], q[i], ngA, ngQ, x[i]);
+    }
+    QRK_STAMP_IN(6);
+
+    // ---- refresh the LDS image of the live columns after every RB-th step
+    if (!(QRK_ABL & 64) && K % RB == RB - 1 && K + 1 < WR) {
+        if (st.live) {   // (the column just chosen for step K+1 is skipped: it was fetched already)
+#pragma unroll
+            for (int i = K + 1; i < WR; ++i) hl[L_IMG + j * LDP + i] = a[i];
         }
     }
     QRK_STAMP_IN(7);
@@ -488,6 +473,7 @@ bdqr_pair_kernel(WaveBatch nb, const double* __restrict__ tiles, double* __restr
         // constant.  (A rolled loop dispatching through a uniform switch makes hipcc's CFG
         // structurizer copy the whole register tile at every merge point.)
 #define QRK_STEP(K) if (!(QRK_ABL & 1024) && (FULL32 || K < cmax)) pair_step<K, FULL32, PIVOT, HC>(a, q, hl, st, hc_tile);
+        search_fetch<0, FULL32, PIVOT>(hl, st);   // head of step 0; every step issues the head of the next one
 #ifdef QRK_STAMP
         QRK_STAMP_AT(1);
         QRK_STEP(0) QRK_STEP(1) QRK_STEP(2) QRK_STEP(3) QRK_STEP(4) QRK_STEP(5) QRK_STEP(6) QRK_STEP(7)
@@ -598,10 +584,10 @@ __device__ __forceinline__ void epilogue32(int lane_in, int64_t pi, int64_t num_
     int* lane_of_pos = reinterpret_cast<int*>(&hl[L_POS]);
     lane_of_pos[kstep] = j;                            // the column chosen at step k ends at position k
     if (valid) perm[cbase + kstep] = cbase + j;        // m_outputPerm_c.indices()(base_col+j) (:519-521)
-    __syncthreads();
+    __builtin_amdgcn_wave_barrier();   // one wave per workgroup: LDS is in order, no s_barrier (its fence would wait for the prefetch)
     if (valid) {
         double2* dst = reinterpret_cast<double2*>(r_vals + t * 528);
-#pragma unroll 1
+#pragma unroll
         for (int qq = 0; qq < 9; ++qq) {
             const int e2 = j + 32 * qq;
             if (e2 < 264) {
@@ -613,7 +599,7 @@ __device__ __forceinline__ void epilogue32(int lane_in, int64_t pi, int64_t num_
             }
         }
     }
-    __syncthreads();
+    __builtin_amdgcn_wave_barrier();   // one wave per workgroup: LDS is in order, no s_barrier (its fence would wait for the prefetch)
 }
 
 // Half of the rows of Q straight from the registers: lane j holds row j of Q_i (row-major rows are the
@@ -690,7 +676,7 @@ bdqr_pair32_kernel(int64_t num_tiles, const double* __restrict__ tiles, double* 
 #pragma unroll 4
             for (int i = 0; i < WR; ++i) hl[L_IMG + j * LDP + i] = (i == j) ? (double)(64 - j) : 0.0;
         }
-        __syncthreads();
+        __builtin_amdgcn_wave_barrier();   // one wave per workgroup: LDS is in order, no s_barrier (its fence would wait for the prefetch)
 #pragma unroll
         for (int i = 0; i < WR; ++i) {
             a[i] = hl[L_IMG + j * LDP + i];
@@ -716,6 +702,7 @@ bdqr_pair32_kernel(int64_t num_tiles, const double* __restrict__ tiles, double* 
         QRK_STAMP_AT(1);
 
 #define QRK_STEP(K) pair_step<K, true, PIVOT, HC>(a, q, hl, st, hc_tile);
+        search_fetch<0, true, PIVOT>(hl, st);     // head of step 0; every step issues the head of the next one
         QRK_STEP(0) QRK_STEP(1) QRK_STEP(2) QRK_STEP(3) QRK_STEP(4) QRK_STEP(5) QRK_STEP(6) QRK_STEP(7)
         QRK_STAMP_AT(2);
         QRK_STEP(8) QRK_STEP(9) QRK_STEP(10) QRK_STEP(11) QRK_STEP(12) QRK_STEP(13) QRK_STEP(14) QRK_STEP(15)
@@ -765,48 +752,6 @@ bdqr_pair32_kernel(int64_t num_tiles, const double* __restrict__ tiles, double* 
 #endif
     }
 }
-#if 0
-        int* lane_of_pos = reinterpret_cast<int*>(&hl[L_POS]);
-        // the column chosen at step k ends at position k
-        lane_of_pos[st.kstep] = j;
-        if (valid) perm[cbase + st.kstep] = cbase + j;   // m_outputPerm_c.indices()(base_col+j) (:519-521)
-        __syncthreads();
-        if (valid) {
-            double2* dst = reinterpret_cast<double2*>(r_vals + roff);
-#pragma unroll
-            for (int qq = 0; qq < 9; ++qq) {
-                const int e2 = j + 32 * qq;
-                if (e2 < 264) {
-                    int p0, i0, p1, i1;
-                    tri_unpack(2 * e2, p0, i0);
-                    tri_unpack(2 * e2 + 1, p1, i1);
-                    dst[e2] = make_double2(hl[L_IMG + lane_of_pos[i0] * LDP + lane_of_pos[p0]],
-                                           hl[L_IMG + lane_of_pos[i1] * LDP + lane_of_pos[p1]]);
-                }
-            }
-        }
-        __syncthreads();
-        // ---- Q: lane j holds row j of Q_i; row-major rows are the CSR value order of m_Q in both
-        // FullQ ([U|N] split, :455-471) and BlockDiagonalQ (:480-492) layouts.
-#pragma unroll
-        for (int i = 0; i < WR; i += 2)
-            *reinterpret_cast<double2*>(&hl[L_IMG + j * LDP + i]) = make_double2(q[i], q[i + 1]);
-        __syncthreads();
-        if (valid) {
-            double2* dst = reinterpret_cast<double2*>(q_vals + qoff);
-            for (int q0 = 0; q0 < 16; q0 += 8) {
-#pragma unroll
-                for (int qq = 0; qq < 8; ++qq) {
-                    const int e2 = j + 32 * (q0 + qq);
-                    dst[e2] = *reinterpret_cast<const double2*>(&hl[L_IMG + (e2 >> 4) * LDP + ((e2 & 15) << 1)]);
-                }
-            }
-        }
-        __syncthreads();
-    }
-}
-#endif
-
 void launch_bdqr_pair(const WaveBatch& nb, bool full32, const double* tiles, double* q_vals,
                       double* r_vals, int32_t* perm, double* hcoeffs, int max_blocks,
                       hipStream_t stream)
