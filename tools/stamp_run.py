@@ -66,3 +66,11 @@ for label, sel in (("all pairs", np.arange(NP)), ("tail round (1 wave/SIMD mostl
         print(f"  {label:34s}" + " ".join(f"{x:8.0f}" for x in dk[sel].mean(axis=0)) + f"   total {dk[sel].sum(axis=1).mean():8.0f}")
 xcc = (s[:, 7] >> 32) & 0xf
 print("pairs per XCC:", np.bincount(xcc.astype(np.int64)))
+# where do the workgroups of the tail round sit?  HW_ID (gfx9): wave[3:0] simd[5:4] pipe[7:6] cu[11:8] sh[12] se[15:13]
+hw = s[:, 7] & 0xffffffff
+cu_key = (xcc.astype(np.int64) << 16) | (((hw >> 13) & 7) << 8) | (((hw >> 12) & 1) << 4) | ((hw >> 8) & 15)
+for r in range(3):
+    sel = np.arange(r * nwg_, min((r + 1) * nwg_, NP))
+    if len(sel):
+        u, c = np.unique(cu_key[sel], return_counts=True)
+        print(f"round {r}: {len(sel)} pairs on {len(u)} distinct CUs, per-CU min/mean/max = {c.min()}/{c.mean():.2f}/{c.max()}")
