@@ -10,12 +10,14 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
 #include <new>
 #include <string>
 #include <vector>
 
 #define QRK_WG_MAX_DIM 2048
+#define QRK_COL_MAX_DIM 256     // bdqr_col.hip: one thread per column of [A | Q^T], at most 512 columns
 
 namespace {
 
@@ -53,6 +55,13 @@ struct qrk_bd_plan_s {
     double* d_workspace = nullptr;   // per-workgroup working copies of the large tiles
     int64_t ws_stride = 0;
     int num_wg = 0;
+    // mid-size tiles (32 < max dim <= QRK_COL_MAX_DIM): one thread per column of [A | Q^T] (bdqr_col.hip)
+    int32_t* d_col_ids = nullptr;    // mixed batches: their tile ids, largest first
+    int64_t n_col = 0;
+    double* d_col_workspace = nullptr;
+    int64_t col_ws_stride = 0;       // max rows * (cols + rows) over those tiles
+    int num_col_wg = 0;
+    int col_max_rows = 0, col_max_ld = 0;
 };
 
 struct qrk_bb_plan_s {
@@ -156,7 +165,10 @@ qrk_status enqueue_factorize(qrk_bd_plan_s* p, const double* tiles, double* q, d
         const bool full32 = p->r == 32 && p->c == 32 &&
                             ((reinterpret_cast<uintptr_t>(tiles) | reinterpret_cast<uintptr_t>(q) |
                               reinterpret_cast<uintptr_t>(r)) & 15u) == 0;
-        if (p->max_dim > 32)
+        if (p->max_dim > 32 && p->max_dim <= QRK_COL_MAX_DIM)
+            QRK_HIP(h, qrk::launch_bdqr_col(nb, tiles, q, r, perm, hc, p->d_col_workspace, p->col_ws_stride, p->num_col_wg,
+                                            p->col_max_rows, p->col_max_ld, h->stream));
+        else if (p->max_dim > 32)
             qrk::launch_bdqr_wg(nb, tiles, q, r, perm, hc, p->d_workspace, p->ws_stride, p->num_wg, p->max_dim, h->stream);
         else if (h->use_pair_kernel) qrk::launch_bdqr_pair(nb, full32, tiles, q, r, perm, hc, h->num_cus * h->pair_wgs_per_cu, h->stream);
         else qrk::launch_bdqr_wave(nb, full32, tiles, q, r, perm, hc, max_blocks, h->stream);
@@ -166,6 +178,12 @@ qrk_status enqueue_factorize(qrk_bd_plan_s* p, const double* tiles, double* q, d
         nb.q_off = p->d_qoff; nb.r_off = p->d_roff; nb.c_off = p->d_coff;
         if (h->use_pair_kernel) qrk::launch_bdqr_pair(nb, false, tiles, q, r, perm, hc, h->num_cus * h->pair_wgs_per_cu, h->stream);
         else qrk::launch_bdqr_wave(nb, false, tiles, q, r, perm, hc, max_blocks, h->stream);
+        if (p->n_col > 0) {
+            qrk::WaveBatch cb = nb;
+            cb.num_tiles = p->n_col; cb.tile_ids = p->d_col_ids;
+            QRK_HIP(h, qrk::launch_bdqr_col(cb, tiles, q, r, perm, hc, p->d_col_workspace, p->col_ws_stride, p->num_col_wg,
+                                            p->col_max_rows, p->col_max_ld, h->stream));
+        }
         if (p->n_wg > 0) {
             qrk::WaveBatch lb = nb;
             lb.num_tiles = p->n_wg; lb.tile_ids = p->d_wg_ids;
@@ -267,7 +285,7 @@ qrk_status qrk_bd_plan_create(qrk_handle h, const qrk_bd_layout* L, qrk_q_format
 
     const int64_t B = p->B;
     int64_t sum_rows = 0, sum_cols = 0;
-    std::vector<int32_t> coff, rowoff, wave_ids, wg_ids;
+    std::vector<int32_t> coff, rowoff, wave_ids, wg_ids, col_ids;
     int64_t ws_stride = 0;
     std::vector<int64_t> toff, qoff, roff;
     if (p->uniform) {
@@ -279,7 +297,11 @@ qrk_status qrk_bd_plan_create(qrk_handle h, const qrk_bd_layout* L, qrk_q_format
         p->nnz_r = B * (int64_t)(p->c * (p->c + 1) / 2);
         p->landscape = p->r < p->c;
         p->max_dim = p->r > p->c ? p->r : p->c;
-        if (p->max_dim > 32) ws_stride = (int64_t)p->r * p->c;
+        if (p->max_dim > QRK_COL_MAX_DIM) ws_stride = (int64_t)p->r * p->c;
+        else if (p->max_dim > 32 && !p->landscape) {
+            p->col_ws_stride = (int64_t)p->r * (p->c + p->r);
+            p->col_max_rows = p->r; p->col_max_ld = p->c + p->r;
+        }
     } else {
         coff.resize(B); rowoff.resize(B); toff.resize(B); qoff.resize(B); roff.resize(B);
         for (int64_t i = 0; i < B; ++i) {
@@ -295,6 +317,12 @@ qrk_status qrk_bd_plan_create(qrk_handle h, const qrk_bd_layout* L, qrk_q_format
             const int32_t md = r > c ? r : c;
             if (md > p->max_dim) p->max_dim = md;
             if (md <= 32) wave_ids.push_back((int32_t)i);
+            else if (md <= QRK_COL_MAX_DIM && r >= c) {
+                col_ids.push_back((int32_t)i);
+                if ((int64_t)r * (c + r) > p->col_ws_stride) p->col_ws_stride = (int64_t)r * (c + r);
+                if (r > p->col_max_rows) p->col_max_rows = r;
+                if (c + r > p->col_max_ld) p->col_max_ld = c + r;
+            }
             else { wg_ids.push_back((int32_t)i); if ((int64_t)r * c > ws_stride) ws_stride = (int64_t)r * c; }
         }
     }
@@ -308,6 +336,18 @@ qrk_status qrk_bd_plan_create(qrk_handle h, const qrk_bd_layout* L, qrk_q_format
     if (p->max_dim > QRK_WG_MAX_DIM && !p->landscape) {
         delete p;
         return fail(h, QRK_STATUS_UNSUPPORTED, "qrk_bd_plan_create: tile dimension above 2048 is not supported");
+    }
+    if (p->col_ws_stride > 0 && !p->landscape) {
+        // largest tiles first: the grid-stride assignment then ends with the small ones
+        std::stable_sort(col_ids.begin(), col_ids.end(), [&](int32_t a, int32_t b) {
+            return (int64_t)L->rows[a] * L->rows[a] * L->cols[a] > (int64_t)L->rows[b] * L->rows[b] * L->cols[b];
+        });
+        const int64_t n_mid = p->uniform ? B : (int64_t)col_ids.size();
+        p->num_col_wg = (int)(n_mid < 2 * (int64_t)h->num_cus ? n_mid : 2 * (int64_t)h->num_cus);
+        if (hipMalloc((void**)&p->d_col_workspace, (size_t)p->num_col_wg * (size_t)p->col_ws_stride * sizeof(double)) != hipSuccess) {
+            delete p;
+            return fail(h, QRK_STATUS_ALLOC_FAILED, "qrk_bd_plan_create: cannot allocate the mid-size-tile workspace");
+        }
     }
     if (ws_stride > 0 && !p->landscape) {
         const int64_t n_large = p->uniform ? B : (int64_t)wg_ids.size();
@@ -325,12 +365,13 @@ qrk_status qrk_bd_plan_create(qrk_handle h, const qrk_bd_layout* L, qrk_q_format
             (st = upload(h, coff, &p->d_coff)) || (st = upload(h, rowoff, &p->d_rowoff)) ||
             (st = upload(h, toff, &p->d_toff)) || (st = upload(h, qoff, &p->d_qoff)) ||
             (st = upload(h, roff, &p->d_roff)) || (st = upload(h, wave_ids, &p->d_wave_ids)) ||
-            (st = upload(h, wg_ids, &p->d_wg_ids))) {
+            (st = upload(h, wg_ids, &p->d_wg_ids)) || (st = upload(h, col_ids, &p->d_col_ids))) {
             qrk_bd_plan_destroy(p);
             return st;
         }
         p->n_wave = (int64_t)wave_ids.size();
         p->n_wg = (int64_t)wg_ids.size();
+        p->n_col = (int64_t)col_ids.size();
     }
     *out = p;
     return QRK_STATUS_OK;
@@ -342,6 +383,7 @@ qrk_status qrk_bd_plan_destroy(qrk_bd_plan p)
     (void)hipFree(p->d_rows); (void)hipFree(p->d_cols); (void)hipFree(p->d_coff); (void)hipFree(p->d_rowoff);
     (void)hipFree(p->d_toff); (void)hipFree(p->d_qoff); (void)hipFree(p->d_roff); (void)hipFree(p->d_wave_ids);
     (void)hipFree(p->d_wg_ids); (void)hipFree(p->d_workspace);
+    (void)hipFree(p->d_col_ids); (void)hipFree(p->d_col_workspace);
     delete p;
     return QRK_STATUS_OK;
 }
