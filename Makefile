@@ -26,6 +26,8 @@ cpptest: $(LIB)
 	@mkdir -p build
 	g++ -O2 -std=c++14 -Wall -Iinclude tests/cpp/test_block_diagonal.cpp -Lqrkit_amd/lib -lqrkit_amd \
 	    -Wl,-rpath,'$$ORIGIN/../qrkit_amd/lib' -o build/test_block_diagonal
+	g++ -O2 -std=c++14 -Wall -Iinclude tests/cpp/test_compositions.cpp -Lqrkit_amd/lib -lqrkit_amd \
+	    -Wl,-rpath,'$$ORIGIN/../qrkit_amd/lib' -o build/test_compositions
 
 clean:
 	rm -rf build $(LIB)

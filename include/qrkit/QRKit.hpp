@@ -320,6 +320,363 @@ class BlockDiagonalSparseQR {
     qrk_bd_plan m_plan;
 };
 
+// ---------------------------------------------------------------------------------------------
+// Helpers shared by the compositions (host side, small).
+
+// CSR copy (sorted column indices) of a sparse matrix in either storage order.
+template <bool RowMajor>
+inline void toCsr(const SparseMatrix<RowMajor>& m, std::vector<int>& rowptr, std::vector<int>& colidx, std::vector<double>& vals) {
+    const Index rows = m.rows();
+    rowptr.assign((size_t)rows + 1, 0);
+    if (RowMajor) {
+        rowptr = m.outerIndex(); colidx = m.innerIndex(); vals = m.values();
+        return;
+    }
+    for (int r : m.innerIndex()) rowptr[(size_t)r + 1]++;
+    for (Index i = 0; i < rows; ++i) rowptr[(size_t)i + 1] += rowptr[(size_t)i];
+    colidx.assign(m.innerIndex().size(), 0); vals.assign(m.innerIndex().size(), 0.0);
+    std::vector<int> fill(rowptr.begin(), rowptr.end() - 1);
+    for (Index c = 0; c < m.cols(); ++c)      // columns ascending => column indices sorted inside every row
+        for (int p = m.outerIndex()[(size_t)c]; p < m.outerIndex()[(size_t)c + 1]; ++p) {
+            const int q = fill[(size_t)m.innerIndex()[(size_t)p]]++;
+            colidx[(size_t)q] = (int)c; vals[(size_t)q] = m.values()[(size_t)p];
+        }
+}
+
+// x = R(0:n,0:n).triangularView<Upper>().solve(y) for a CSC matrix with sorted row indices
+// (the step every _solve_impl of the reference ends with).
+inline Vector solveUpperCsc(const SparseMatrixColMajor& R, Index n, const Vector& y) {
+    Vector x(y.begin(), y.begin() + n);
+    for (Index k = n - 1; k >= 0; --k) {
+        const int p0 = R.outerIndex()[(size_t)k], p1 = R.outerIndex()[(size_t)k + 1];
+        double diag = 0.0;
+        for (int p = p0; p < p1; ++p) if (R.innerIndex()[(size_t)p] == k) diag = R.values()[(size_t)p];
+        x[(size_t)k] /= diag;
+        for (int p = p0; p < p1; ++p) { const int i = R.innerIndex()[(size_t)p]; if (i < k) x[(size_t)i] -= R.values()[(size_t)p] * x[(size_t)k]; }
+    }
+    return x;
+}
+
+// matrixQ() of the compositions: an expression that only supports products, like the reference's
+// SparseBlockYTY / BlockAngularSparseQRMatrixQReturnType.  v may hold several columns (rows x nrhs).
+template <typename Solver>
+class QProduct {
+  public:
+    QProduct(const Solver& s, bool transposed) : m_s(s), m_t(transposed) {}
+    QProduct transpose() const { return QProduct(m_s, !m_t); }
+    Vector operator*(const Vector& v) const { return m_t ? m_s.applyQt(v) : m_s.applyQ(v); }
+    Matrix operator*(const Matrix& v) const {
+        Vector in(v.data(), v.data() + v.rows() * v.cols());
+        Vector out = (*this) * in;
+        Matrix r(v.rows(), v.cols());
+        std::copy(out.begin(), out.end(), r.data());
+        return r;
+    }
+  private:
+    const Solver& m_s;
+    bool m_t;
+};
+
+// ---------------------------------------------------------------------------------------------
+// QRKit::BandedBlockedSparseQR<SparseMatrix, HouseholderQR<MatrixXd>, Dynamic, SuggestedBlockCols>
+// (BandedBlockedSparseQR.h:122-366), generic-pattern path: as-banded-as-possible row ordering, band
+// detection + block merge, sequential chain of dense Householder panels with Q kept as (Y, T) blocks.
+template <int SuggestedBlockCols = 2>
+class BandedBlockedSparseQR {
+  public:
+    typedef SparseMatrixColMajor MatrixRType;
+    typedef PermutationMatrix PermutationType;
+    typedef QProduct<BandedBlockedSparseQR> MatrixQType;
+
+    explicit BandedBlockedSparseQR(int device = 0)
+        : m_info(Success), m_nonzeropivots(0), m_isInitialized(false), m_analysisIsok(false), m_handle(0), m_plan(0), m_rows(0), m_cols(0),
+          m_nnzR(0), m_hasRowPermutation(false) {
+        if (qrk_create(&m_handle, device, 0) != QRK_STATUS_OK)
+            throw std::runtime_error(std::string("qrkit: ") + qrk_last_error(0));
+    }
+    ~BandedBlockedSparseQR() { if (m_plan) qrk_bb_plan_destroy(m_plan); if (m_handle) qrk_destroy(m_handle); }
+    BandedBlockedSparseQR(const BandedBlockedSparseQR&) = delete;
+    BandedBlockedSparseQR& operator=(const BandedBlockedSparseQR&) = delete;
+
+    // :170-182 -- the pattern analysis is cached unless forced
+    template <bool RM>
+    void compute(const SparseMatrix<RM>& mat, bool forcePatternAlaysis = false) {
+        if (!m_analysisIsok || forcePatternAlaysis) analyzePattern(mat);
+        factorize(mat);
+    }
+    // :391-433
+    template <bool RM>
+    void analyzePattern(const SparseMatrix<RM>& mat) {
+        std::vector<double> vals;
+        toCsr(mat, m_rowptr, m_colidx, vals);
+        m_rows = mat.rows(); m_cols = mat.cols();
+        if (m_plan) { qrk_bb_plan_destroy(m_plan); m_plan = 0; }
+        check(qrk_bb_plan_create(m_handle, (int32_t)m_rows, (int32_t)m_cols, m_rowptr.data(), m_colidx.data(), SuggestedBlockCols, &m_plan));
+        int32_t nb = 0, has = 0; int64_t yl = 0, tl = 0;
+        check(qrk_bb_plan_info(m_plan, &nb, &m_nnzR, &yl, &tl, &has));
+        m_hasRowPermutation = has != 0;
+        m_blocks.assign((size_t)4 * nb, 0);
+        m_yty.assign((size_t)6 * nb, 0);
+        m_rowPerm.setIdentity(m_rows);
+        check(qrk_bb_plan_blocks(m_plan, m_blocks.data(), m_rowPerm.indices().data(), m_yty.data()));
+        m_y.assign((size_t)std::max<int64_t>(yl, 1), 0.0);
+        m_t.assign((size_t)std::max<int64_t>(tl, 1), 0.0);
+        m_outputPerm_c.setIdentity(m_cols);
+        m_analysisIsok = true;
+    }
+    // :443-519
+    template <bool RM>
+    void factorize(const SparseMatrix<RM>& mat) {
+        assert(m_analysisIsok && "analyzePattern() should be called first");
+        std::vector<int> rp, ci; std::vector<double> vals;
+        toCsr(mat, rp, ci, vals);
+        assert(ci.size() == m_colidx.size() && "the sparsity pattern differs from the analysed one");
+        m_R.resize(m_rows, m_cols);
+        m_R.values().assign((size_t)m_nnzR, 0.0); m_R.innerIndex().assign((size_t)m_nnzR, 0);
+        check(qrk_bb_factorize(m_plan, vals.data(), (int64_t)vals.size(), m_R.values().data(), m_y.data(), m_t.data(), QRK_MEM_HOST));
+        check(qrk_bb_pattern(m_plan, m_R.outerIndex().data(), m_R.innerIndex().data(), QRK_MEM_HOST));
+        m_nonzeropivots = m_cols;                 // :513 "assuming all cols are nonzero"
+        m_isInitialized = true;
+        m_info = Success;
+    }
+
+    Index rows() const { return m_rows; }
+    Index cols() const { return m_cols; }
+    Index rank() const { assert(m_isInitialized); return m_nonzeropivots; }
+    ComputationInfo info() const { return m_info; }
+    const MatrixRType& matrixR() const { return m_R; }
+    MatrixQType matrixQ() const { return MatrixQType(*this, false); }
+    const PermutationType& colsPermutation() const { return m_outputPerm_c; }     // identity (:253-257)
+    const PermutationType& rowsPermutation() const { return m_rowPerm; }
+    bool hasRowPermutation() const { return m_hasRowPermutation; }
+    Index numBlocks() const { return (Index)m_blocks.size() / 4; }
+    // (idxRow, idxCol, numRows, numCols) of merged block k -- m_blockInfo
+    const int32_t* blockInfo(Index k) const { return &m_blocks[(size_t)4 * k]; }
+
+    // SparseBlockYTY products (SparseBlockYTY.h:100-139); v: rows x nrhs, column-major
+    Vector applyQ(const Vector& v) const { return apply(v, 0); }
+    Vector applyQt(const Vector& v) const { return apply(v, 1); }
+
+    // _solve_impl (:290-311): y = Q^T B (B already row-permuted by the caller, as in the reference test),
+    // x = R(0:rank,0:rank)^-1 y(0:rank); the column permutation is the identity.
+    Vector solve(const Vector& B) const {
+        assert(m_isInitialized && "The factorization should be called first, use compute()");
+        const Vector y = applyQt(B);
+        return solveUpperCsc(m_R, m_cols, y);
+    }
+
+  protected:
+    Vector apply(const Vector& v, int transpose) const {
+        assert(m_isInitialized && (Index)v.size() % m_rows == 0);
+        Vector out(v);
+        check(qrk_bb_apply_q(m_plan, m_y.data(), m_t.data(), transpose, out.data(), (int64_t)v.size() / m_rows, QRK_MEM_HOST));
+        return out;
+    }
+    void check(qrk_status st) const {
+        if (st != QRK_STATUS_OK) throw std::runtime_error(std::string("qrkit: ") + qrk_last_error(m_handle));
+    }
+    ComputationInfo m_info;
+    Index m_nonzeropivots;
+    bool m_isInitialized, m_analysisIsok;
+    qrk_handle m_handle;
+    qrk_bb_plan m_plan;
+    Index m_rows, m_cols;
+    int64_t m_nnzR;
+    bool m_hasRowPermutation;
+    std::vector<int> m_rowptr, m_colidx;
+    std::vector<int32_t> m_blocks;
+    std::vector<int64_t> m_yty;
+    std::vector<double> m_y, m_t;
+    MatrixRType m_R;
+    PermutationType m_rowPerm, m_outputPerm_c;
+};
+
+// ---------------------------------------------------------------------------------------------
+// QRKit::BlockMatrix1x2 (BlockMatrix1x2.h:31-67): non-owning [left | right].
+template <typename LeftBlockType, typename RightBlockType = Matrix>
+class BlockMatrix1x2 {
+  public:
+    BlockMatrix1x2(const LeftBlockType& l, const RightBlockType& r) : m_left(l), m_right(r) {}
+    const LeftBlockType& leftBlock() const { return m_left; }
+    const RightBlockType& rightBlock() const { return m_right; }
+    Index rows() const { return (Index)m_right.rows(); }
+    Index cols() const { return (Index)m_left.cols() + (Index)m_right.cols(); }
+  private:
+    const LeftBlockType& m_left;
+    const RightBlockType& m_right;
+};
+
+// Uniform "Q^T v / Q v on several columns" access to the left solvers.
+template <typename BS, int QF>
+inline Vector leftApplyQ(const BlockDiagonalSparseQR<BS, QF>& s, const Vector& v, bool transpose) {
+    if (transpose) return s.applyQt(v);
+    const SparseMatrixRowMajor Q = s.matrixQ();        // Q v: host SpMV with the explicit Q
+    const Index rows = s.rows(), nrhs = (Index)v.size() / rows;
+    Vector out(v.size());
+    for (Index c = 0; c < nrhs; ++c) {
+        Vector col(v.begin() + c * rows, v.begin() + (c + 1) * rows);
+        Vector r = Q * col;
+        std::copy(r.begin(), r.end(), out.begin() + c * rows);
+    }
+    return out;
+}
+template <int SBC>
+inline Vector leftApplyQ(const BandedBlockedSparseQR<SBC>& s, const Vector& v, bool transpose) {
+    return transpose ? s.applyQt(v) : s.applyQ(v);
+}
+
+// QRKit::BlockAngularSparseQR<LeftSolver, RightSolver> (BlockAngularSparseQR.h:79-419): QR of [J1 | J2],
+// J1 handled by LeftSolver (block diagonal or banded), J2 dense; the right solver is the dense
+// ColPivHouseholderQR / HouseholderQR of the library (the reference tests use
+// Eigen::ColPivHouseholderQR<MatrixXd>, test/test-qrkit.cpp:46-48).
+template <typename LeftSolver, typename RightSolverTag = ColPivHouseholderQR>
+class BlockAngularSparseQR {
+  public:
+    typedef SparseMatrixColMajor MatrixRType;
+    typedef PermutationMatrix PermutationType;
+    typedef QProduct<BlockAngularSparseQR> MatrixQType;
+
+    explicit BlockAngularSparseQR(int device = 0)
+        : m_leftSolver(device), m_info(Success), m_nonzeropivots(0), m_isInitialized(false), m_handle(0), m_dense(0),
+          m_rows(0), m_cols(0), m_m1(0), m_m2(0), m_n1(0), m_k2(0) {
+        if (qrk_create(&m_handle, device, 0) != QRK_STATUS_OK)
+            throw std::runtime_error(std::string("qrkit: ") + qrk_last_error(0));
+    }
+    ~BlockAngularSparseQR() { if (m_dense) qrk_dense_plan_destroy(m_dense); if (m_handle) qrk_destroy(m_handle); }
+    BlockAngularSparseQR(const BlockAngularSparseQR&) = delete;
+    BlockAngularSparseQR& operator=(const BlockAngularSparseQR&) = delete;
+
+    template <typename LeftMat>
+    void compute(const BlockMatrix1x2<LeftMat, Matrix>& mat) { analyzePattern(mat); factorize(mat); }
+
+    // :431-449
+    template <typename LeftMat>
+    void analyzePattern(const BlockMatrix1x2<LeftMat, Matrix>& mat) {
+        assert(mat.leftBlock().cols() > mat.rightBlock().cols() && "the left block should be the bigger one");
+        m_rows = mat.rows(); m_cols = mat.cols();
+        m_rowPerm.setIdentity(m_rows);
+    }
+
+    // :459-514
+    template <typename LeftMat>
+    void factorize(const BlockMatrix1x2<LeftMat, Matrix>& mat) {
+        const Matrix& J2in = mat.rightBlock();
+        m_m1 = mat.leftBlock().cols(); m_n1 = mat.leftBlock().rows(); m_m2 = J2in.cols();
+        // J1 = Q1 R1 (:472-475)
+        m_leftSolver.compute(mat.leftBlock());
+        m_info = m_leftSolver.info();
+        if (m_info != Success) return;
+        // solveRightBlock (:361-369): J2.top(n1) <- Q1^T (rowPerm1 * J2.top(n1)); the rows below stay
+        m_J2 = J2in;
+        {
+            Vector top((size_t)(m_n1 * m_m2));
+            const std::vector<int>& rp = m_leftSolver.rowsPermutation().indices();
+            for (Index c = 0; c < m_m2; ++c)
+                for (Index r = 0; r < m_n1; ++r) top[(size_t)(c * m_n1 + rp[(size_t)r])] = J2in(r, c);
+            top = leftApplyQ(m_leftSolver, top, true);
+            for (Index c = 0; c < m_m2; ++c)
+                for (Index r = 0; r < m_n1; ++r) m_J2(r, c) = top[(size_t)(c * m_n1 + r)];
+            for (Index r = 0; r < m_n1; ++r) m_rowPerm.indices()[(size_t)r] = rp[(size_t)r];
+        }
+        // rightSolver.compute(J2.bottomRows(rows - m1))
+        const Index rb = m_rows - m_m1;
+        m_bottom = Matrix(rb, m_m2);
+        for (Index c = 0; c < m_m2; ++c) for (Index r = 0; r < rb; ++r) m_bottom(r, c) = m_J2(m_m1 + r, c);
+        if (m_dense) { qrk_dense_plan_destroy(m_dense); m_dense = 0; }
+        check(qrk_dense_plan_create(m_handle, (int32_t)rb, (int32_t)m_m2, (qrk_block_solver)RightSolverTag::kSolver, &m_dense));
+        m_k2 = std::min(rb, m_m2);
+        m_hc.assign((size_t)std::max<Index>(m_k2, 1), 0.0);
+        std::vector<int32_t> p2((size_t)std::max<Index>(m_m2, 1), 0);
+        check(qrk_dense_factorize(m_dense, m_bottom.data(), rb, m_hc.data(), p2.data(), QRK_MEM_HOST));
+        // column permutation (:498-503) and rank (:510)
+        m_outputPerm_c.setIdentity(m_cols);
+        for (Index j = 0; j < m_m1; ++j) m_outputPerm_c.indices()[(size_t)j] = m_leftSolver.colsPermutation().indices()[(size_t)j];
+        for (Index j = 0; j < m_m2; ++j) m_outputPerm_c.indices()[(size_t)(m_m1 + j)] = (int)(m_m1 + p2[(size_t)j]);
+        m_P2.assign(p2.begin(), p2.begin() + m_m2);
+        m_nonzeropivots = m_leftSolver.rank() + m_k2;
+        makeR();
+        m_isInitialized = true;
+    }
+
+    Index rows() const { return m_rows; }
+    Index cols() const { return m_cols; }
+    Index rank() const { assert(m_isInitialized); return m_nonzeropivots; }
+    ComputationInfo info() const { return m_info; }
+    const MatrixRType& matrixR() const { return m_R; }
+    MatrixQType matrixQ() const { return MatrixQType(*this, false); }
+    const PermutationType& colsPermutation() const { return m_outputPerm_c; }
+    const PermutationType& rowsPermutation() const { return m_rowPerm; }
+    const LeftSolver& leftSolver() const { return m_leftSolver; }
+
+    // matrixQ().transpose() * v (:607-625): rows [0,n1) <- Q1^T, then rows [m1, rows) <- Q2^T
+    Vector applyQt(const Vector& v) const {
+        const Index nrhs = (Index)v.size() / m_rows;
+        Vector out(v);
+        leftPart(out, nrhs, true);
+        rightPart(out, nrhs, true);
+        return out;
+    }
+    // matrixQ() * v (:627-645): the same two factors in the opposite order
+    Vector applyQ(const Vector& v) const {
+        const Index nrhs = (Index)v.size() / m_rows;
+        Vector out(v);
+        rightPart(out, nrhs, false);
+        leftPart(out, nrhs, false);
+        return out;
+    }
+    // _solve_impl (:202-227): x = P [R(0:rank,0:rank)^-1 (Q^T b)(0:rank)], b already row-permuted
+    Vector solve(const Vector& b) const {
+        assert(m_isInitialized && "The factorization should be called first, use compute()");
+        const Vector y = applyQt(b);
+        const Vector z = solveUpperCsc(m_R, m_cols, y);
+        return m_outputPerm_c * z;
+    }
+
+  protected:
+    void leftPart(Vector& v, Index nrhs, bool transpose) const {
+        Vector top((size_t)(m_n1 * nrhs));
+        for (Index c = 0; c < nrhs; ++c) std::copy(v.begin() + c * m_rows, v.begin() + c * m_rows + m_n1, top.begin() + c * m_n1);
+        top = leftApplyQ(m_leftSolver, top, transpose);
+        for (Index c = 0; c < nrhs; ++c) std::copy(top.begin() + c * m_n1, top.begin() + (c + 1) * m_n1, v.begin() + c * m_rows);
+    }
+    void rightPart(Vector& v, Index nrhs, bool transpose) const {
+        const Index rb = m_rows - m_m1;
+        Vector bot((size_t)(rb * nrhs));
+        for (Index c = 0; c < nrhs; ++c) std::copy(v.begin() + c * m_rows + m_m1, v.begin() + (c + 1) * m_rows, bot.begin() + c * rb);
+        check(qrk_dense_apply_q(m_dense, m_bottom.data(), rb, m_hc.data(), transpose ? 1 : 0, bot.data(), rb, nrhs, QRK_MEM_HOST));
+        for (Index c = 0; c < nrhs; ++c) std::copy(bot.begin() + c * rb, bot.begin() + (c + 1) * rb, v.begin() + c * m_rows + m_m1);
+    }
+    // makeR (:285-335): R = [R1(0:m1,:), (Q1^T J2)(0:m1, P2); 0, R2; 0, 0]
+    void makeR() {
+        std::vector<Triplet> t;
+        const SparseMatrixColMajor& R1 = m_leftSolver.matrixR();
+        for (Index c = 0; c < m_m1; ++c)
+            for (int p = R1.outerIndex()[(size_t)c]; p < R1.outerIndex()[(size_t)c + 1]; ++p)
+                if (R1.innerIndex()[(size_t)p] < m_m1) t.emplace_back(R1.innerIndex()[(size_t)p], (int)c, R1.values()[(size_t)p]);
+        for (Index c = 0; c < m_m2; ++c)
+            for (Index r = 0; r < m_m1; ++r) t.emplace_back((int)r, (int)(m_m1 + c), m_J2(r, m_P2[(size_t)c]));
+        for (Index c = 0; c < m_m2; ++c)
+            for (Index r = 0; r <= std::min(c, m_k2 - 1); ++r) t.emplace_back((int)(m_m1 + r), (int)(m_m1 + c), m_bottom(r, c));
+        m_R.resize(m_rows, m_cols);
+        m_R.setFromTriplets(t);
+    }
+    void check(qrk_status st) const {
+        if (st != QRK_STATUS_OK) throw std::runtime_error(std::string("qrkit: ") + qrk_last_error(m_handle));
+    }
+    LeftSolver m_leftSolver;
+    ComputationInfo m_info;
+    Index m_nonzeropivots;
+    bool m_isInitialized;
+    qrk_handle m_handle;
+    qrk_dense_plan m_dense;
+    Index m_rows, m_cols, m_m1, m_m2, m_n1, m_k2;
+    Matrix m_J2, m_bottom;              // [Q1^T J2.top; J2.bottom] and the packed QR of its rows m1..
+    std::vector<double> m_hc;
+    std::vector<int> m_P2;
+    MatrixRType m_R;
+    PermutationType m_outputPerm_c, m_rowPerm;
+};
+
 }  // namespace qrkit
 
 #endif  // QRKIT_FACADE_HPP

@@ -1,0 +1,181 @@
+// C++ parity tests of the compositions through the facade (include/qrkit/QRKit.hpp):
+//   test_banded_blocked  (test/test-qrkit.cpp:208-258) on the reference's three banded inputs
+//                        (main(), :369-384: block diagonal, overlapping, overlapping + shuffled rows),
+//   test_block_angular   (:260-293) on the reference's block-angular input (:386-395) with the banded
+//                        left solver it uses (typedefs :43-48), and with a BlockDiagonalSparseQR left
+//                        solver on a block-diagonal left part (BASELINE configs[3] shape).
+// The reference checks at 1e-6 (test/test.h:31); the bars here are 1e-10 / 1e-8.
+#include <cmath>
+#include <cstdio>
+#include <numeric>
+#include <random>
+
+#include "qrkit/QRKit.hpp"
+
+using namespace qrkit;
+
+typedef BandedBlockedSparseQR<8> BandedBlockedQRSolver;          // SuggestedBlockCols = 8 (test-qrkit.cpp:44)
+
+static double frob(const Matrix& a) { double s = 0; for (Index i = 0; i < a.rows() * a.cols(); ++i) s += a.data()[i] * a.data()[i]; return std::sqrt(s); }
+static bool approx(const Matrix& a, const Matrix& b, double prec) {   // Eigen isApprox
+    Matrix d(a.rows(), a.cols());
+    for (Index i = 0; i < a.rows() * a.cols(); ++i) d.data()[i] = a.data()[i] - b.data()[i];
+    return frob(d) <= prec * std::min(frob(a), frob(b));
+}
+static bool approxVec(const Vector& a, const Vector& b, double prec) {
+    double d = 0, na = 0, nb = 0;
+    for (size_t i = 0; i < a.size(); ++i) { d += (a[i] - b[i]) * (a[i] - b[i]); na += a[i] * a[i]; nb += b[i] * b[i]; }
+    return std::sqrt(d) <= prec * std::sqrt(std::min(na, nb));
+}
+static Matrix matmul(const Matrix& a, const Matrix& b, bool transA) {
+    const Index m = transA ? a.cols() : a.rows(), k = transA ? a.rows() : a.cols(), n = b.cols();
+    Matrix c(m, n);
+    for (Index j = 0; j < n; ++j) for (Index p = 0; p < k; ++p) { const double bv = b(p, j); if (bv == 0) continue;
+        for (Index i = 0; i < m; ++i) c(i, j) += (transA ? a(p, i) : a(i, p)) * bv; }
+    return c;
+}
+static Matrix identity(Index n) { Matrix I(n, n); for (Index i = 0; i < n; ++i) I(i, i) = 1.0; return I; }
+
+// generate_block_diagonal_matrix / generate_overlapping_block_diagonal_matrix (test-qrkit.cpp:62-128)
+static void generate_banded(Index numParams, Index numResiduals, bool overlap, int shuffleSeed, SparseMatrixColMajor& spJ) {
+    std::default_random_engine gen;
+    std::uniform_real_distribution<double> dist(0.5, 5.0);
+    const int stride = 7;
+    std::vector<Triplet> jvals;
+    for (int i = 0; i < numParams; i++)
+        for (int j = i * 2; j < (i * 2) + 2 && j < numParams; j++) {
+            for (int r = 0; r < 7; ++r) jvals.emplace_back(i * stride + r, j, dist(gen));
+            if (overlap && j < numParams - 2) jvals.emplace_back(i * stride + 6, j + 2, dist(gen));
+        }
+    if (shuffleSeed) {   // spJ = perm * spJ with a random row permutation
+        std::vector<int> perm((size_t)numResiduals);
+        std::iota(perm.begin(), perm.end(), 0);
+        std::mt19937 rng((unsigned)shuffleSeed);
+        std::shuffle(perm.begin(), perm.end(), rng);
+        for (Triplet& t : jvals) t.row = perm[(size_t)t.row];
+    }
+    spJ.resize(numResiduals, numParams);
+    spJ.setFromTriplets(jvals);
+}
+
+// generate_block_angular_matrix (:132-165)
+static void generate_block_angular(Index numParams, Index numAngularParams, Index numResiduals, bool overlap, SparseMatrixColMajor& left, Matrix& right) {
+    std::default_random_engine gen;
+    std::uniform_real_distribution<double> dist(0.5, 5.0);
+    const int stride = 7;
+    std::vector<Triplet> jvals;
+    for (int i = 0; i < numParams; i++)
+        for (int j = i * 2; j < (i * 2) + 2 && j < numParams; j++) {
+            for (int r = 0; r < 7; ++r) jvals.emplace_back(i * stride + r, j, dist(gen));
+            if (overlap && j < numParams - 2) jvals.emplace_back(i * stride + 6, j + 2, dist(gen));
+        }
+    right = Matrix(numResiduals, numAngularParams);
+    for (Index i = 0; i < numResiduals; i++) for (Index j = 0; j < numAngularParams; j++) right(i, j) = dist(gen);
+    left.resize(numResiduals, numParams);
+    left.setFromTriplets(jvals);
+}
+
+static int test_banded_blocked(const SparseMatrixColMajor& spJ, const char* name) {
+    int fails = 0;
+    BandedBlockedQRSolver slvr;
+    slvr.compute(spJ);
+    const Index rows = spJ.rows(), cols = spJ.cols();
+    const Matrix I = identity(rows);
+    const Matrix slvrQ = slvr.matrixQ() * I;                          // Q * I      (:221-222)
+    const Matrix slvrQt = slvr.matrixQ().transpose() * I;             // Q.T * I    (:224-225)
+
+    std::mt19937_64 rng(7);
+    std::uniform_real_distribution<double> ud(-1.0, 1.0);
+    Vector x((size_t)cols);
+    for (double& v : x) v = ud(rng);
+    Vector b = slvr.rowsPermutation() * (spJ * x);                    // (:229-233)
+    const Vector y = slvr.matrixQ().transpose() * b;
+    const Vector solved = solveUpperCsc(slvr.matrixR(), cols, y);     // R.topLeftCorner.triangularView<Upper>().solve (:239)
+    Vector backperm((size_t)cols, 0.0);
+    for (Index i = 0; i < cols; ++i) backperm[(size_t)slvr.colsPermutation().indices()[(size_t)i]] = solved[(size_t)i];
+
+    // spJRowPerm = rowsPermutation() * spJ (:246)
+    const Matrix J = spJ.toDense();
+    Matrix JP(rows, cols);
+    for (Index i = 0; i < rows; ++i) for (Index j = 0; j < cols; ++j) JP(slvr.rowsPermutation().indices()[(size_t)i], j) = J(i, j);
+    const Matrix Rd = slvr.matrixR().toDense();
+    if (!approx(matmul(slvrQ, Rd, false), JP, 1e-10)) { std::printf("  Q*R != P*J\n"); ++fails; }                 // (:249)
+    if (!approx(matmul(slvrQ, JP, true), Rd, 1e-10)) { std::printf("  Q^T*P*J != R\n"); ++fails; }               // (:250)
+    if (!approx(matmul(slvrQt, Rd, true), JP, 1e-10)) { std::printf("  (Q^T)^T*R != P*J\n"); ++fails; }          // (:251)
+    if (!approx(matmul(slvrQt, JP, false), Rd, 1e-10)) { std::printf("  (Q^T)*P*J != R\n"); ++fails; }           // (:252)
+    if (!approxVec(x, backperm, 1e-8)) { std::printf("  LS recovery failed\n"); ++fails; }                        // (:253)
+    if (!approxVec(x, slvr.solve(b), 1e-8)) { std::printf("  solve() recovery failed\n"); ++fails; }
+    std::printf("test_banded_blocked [%s] %lld blocks: %s\n", name, (long long)slvr.numBlocks(), fails ? "Failed." : "Passed.");
+    return fails;
+}
+
+template <typename Solver, typename LeftMat>
+static int test_block_angular(const LeftMat& leftForSolver, const SparseMatrixColMajor& leftSparse, const Matrix& right, const char* name) {
+    int fails = 0;
+    Solver baqr;
+    BlockMatrix1x2<LeftMat, Matrix> blkAngular(leftForSolver, right);
+    baqr.compute(blkAngular);
+    const Index rows = right.rows(), m1 = leftSparse.cols(), m2 = right.cols(), cols = m1 + m2;
+    if (baqr.info() != Success || baqr.rank() != cols) { std::printf("  info/rank wrong\n"); ++fails; }
+    std::mt19937_64 rng(11);
+    std::uniform_real_distribution<double> ud(-1.0, 1.0);
+    Vector x((size_t)cols);
+    for (double& v : x) v = ud(rng);
+    // b = spJ * x with spJ = [left | right]
+    Vector xl(x.begin(), x.begin() + m1);
+    Vector b = leftSparse * xl;
+    for (Index j = 0; j < m2; ++j) for (Index i = 0; i < rows; ++i) b[(size_t)i] += right(i, j) * x[(size_t)(m1 + j)];
+    b = baqr.rowsPermutation() * b;                                                    // (:275)
+    const Vector y = baqr.matrixQ().transpose() * b;                                   // (:279)
+    const Vector solved = solveUpperCsc(baqr.matrixR(), cols, y);                      // (:283)
+    Vector backperm((size_t)cols, 0.0);
+    for (Index i = 0; i < cols; ++i) backperm[(size_t)baqr.colsPermutation().indices()[(size_t)i]] = solved[(size_t)i];   // (:286-288)
+    if (!approxVec(x, backperm, 1e-8)) { std::printf("  LS recovery failed\n"); ++fails; }                    // (:290)
+    if (!approxVec(x, baqr.solve(b), 1e-8)) { std::printf("  solve() recovery failed\n"); ++fails; }
+    // Q Q^T b = b and |Q^T b| = |b|
+    const Vector back = baqr.matrixQ() * y;
+    if (!approxVec(b, back, 1e-10)) { std::printf("  Q*(Q^T*b) != b\n"); ++fails; }
+    // Q^T [J1 | J2] P = R on a few columns: column c of J*P
+    const Matrix Rd = baqr.matrixR().toDense();
+    for (Index c : {Index(0), m1 / 2, m1, cols - 1}) {
+        const Index src = baqr.colsPermutation().indices()[(size_t)c];
+        Vector col((size_t)rows, 0.0);
+        if (src < m1) { Vector e((size_t)m1, 0.0); e[(size_t)src] = 1.0; col = leftSparse * e; }
+        else for (Index i = 0; i < rows; ++i) col[(size_t)i] = right(i, src - m1);
+        col = baqr.rowsPermutation() * col;
+        const Vector qc = baqr.matrixQ().transpose() * col;
+        Vector rc((size_t)rows);
+        for (Index i = 0; i < rows; ++i) rc[(size_t)i] = Rd(i, c);
+        double d = 0, n = 0;
+        for (Index i = 0; i < rows; ++i) { d += (qc[(size_t)i] - rc[(size_t)i]) * (qc[(size_t)i] - rc[(size_t)i]); n += rc[(size_t)i] * rc[(size_t)i]; }
+        if (std::sqrt(d) > 1e-10 * std::sqrt(n)) { std::printf("  Q^T (J P)(:,%lld) != R(:,%lld)\n", (long long)c, (long long)c); ++fails; }
+    }
+    std::printf("test_block_angular [%s] %lld + %lld columns: %s\n", name, (long long)m1, (long long)m2, fails ? "Failed." : "Passed.");
+    return fails;
+}
+
+int main() {
+    int fails = 0;
+    {   // main(), test-qrkit.cpp:363-384
+        const Index numVars = 256, numParams = numVars * 2, numResiduals = numVars * 3 + numVars + numVars * 3;
+        SparseMatrixColMajor spJ;
+        generate_banded(numParams, numResiduals, false, 0, spJ);
+        fails += test_banded_blocked(spJ, "block diagonal");
+        generate_banded(numParams, numResiduals, true, 0, spJ);
+        fails += test_banded_blocked(spJ, "overlapping");
+        generate_banded(numParams, numResiduals, true, 5, spJ);
+        fails += test_banded_blocked(spJ, "overlapping, rows shuffled");
+    }
+    {   // :386-395 at a quarter of the reference's size (numVars = 1024, 384 angular parameters there)
+        const Index numVars = 256, numParams = numVars * 2, numResiduals = numVars * 3 + numVars + numVars * 3, numAngular = 96;
+        SparseMatrixColMajor left; Matrix right;
+        generate_block_angular(numParams, numAngular, numResiduals, true, left, right);
+        fails += test_block_angular<BlockAngularSparseQR<BandedBlockedQRSolver, ColPivHouseholderQR> >(left, left, right, "banded left solver");
+        // block-diagonal left part (7x2 tiles) through BlockDiagonalSparseQR
+        generate_block_angular(numParams, numAngular, numResiduals, false, left, right);
+        SparseBlockDiagonal blk;
+        blk.fromBlockDiagonalPattern(left, 7, 2);
+        fails += test_block_angular<BlockAngularSparseQR<BlockDiagonalSparseQR<ColPivHouseholderQR>, ColPivHouseholderQR> >(blk, left, right, "block-diagonal left solver");
+    }
+    return fails ? 1 : 0;
+}

@@ -16,7 +16,19 @@ def test_cpp_facade_block_diagonal():
     assert "Failed." not in out.stdout and out.stdout.count("Passed.") == 3
 
 
+@pytest.mark.gpu
+def test_cpp_facade_compositions():
+    """The reference's test_banded_blocked (3 inputs) and test_block_angular (banded and block-diagonal left
+    solver) written against the C++ facade classes BandedBlockedSparseQR / BlockAngularSparseQR."""
+    subprocess.check_call(["make", "-C", ROOT, "-s", "cpptest"])
+    out = subprocess.run([os.path.join(ROOT, "build", "test_compositions")], capture_output=True, text=True, timeout=600)
+    print(out.stdout, out.stderr)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "Failed." not in out.stdout and out.stdout.count("Passed.") == 5
+
+
 def test_cpp_facade_compiles():
     """CPU: the facade and its test compile and link against the library (no GPU needed)."""
     subprocess.check_call(["make", "-C", ROOT, "-s", "cpptest"])
     assert os.path.exists(os.path.join(ROOT, "build", "test_block_diagonal"))
+    assert os.path.exists(os.path.join(ROOT, "build", "test_compositions"))
