@@ -6,27 +6,26 @@
 // blockSolver.compute and HouseholderSequence behind matrixQ()), for the mid-size tiles of mixed
 // batches (BASELINE configs[4]: sizes 8..256).
 //
-// One THREAD per column of the working matrix W = [A | Q^T] (rows x (cols + rows), ROW-major, so that the
-// threads of a wave touch consecutive addresses).  W lives in LDS when it fits in 64 KB (tiles up to
-// 64x64), otherwise in a per-workgroup global workspace.  With 512 workgroups in flight that workspace
-// (256 KB for a 128x128 tile) does not fit the L2, and the kernel then runs at the bandwidth of the
-// Infinity Cache / HBM (measured 6.8 TB/s of sweep traffic on 128x128 tiles, 1.1 TFLOP/s): the next
-// step for these sizes is the panel-blocked (dlaqps-style) variant, which reads only the A part once per
-// column and applies the updates as GEMMs.  A reflector
-// is the same operation on every column, c <- c - gamma x, so A -> R and I -> Q^T advance together and
-// no cross-lane reduction is needed: every thread walks down its own column.
-//
-// The level-2 algorithm needs two sweeps over the trailing matrix per step (dot products, then the
-// update).  They are fused across steps into ONE read-modify-write sweep: the dot products of step k
-// give row k of the updated matrix (c_k + w gamma), that row is all the LAWN-176 norm downdate needs,
-// so the pivot of step k+1 is known BEFORE the update of step k is applied; its column is brought up
-// to date on the fly (x' = W(:,p') - gamma_p' x) and the sweep that applies update k also accumulates
-// the dot products with x' (and |x'_tail|^2, and the recomputed column norms).  Only when Eigen's
+// Phase 1 -- R and the reflectors.  One THREAD per column of A, the matrix row-major in LDS (tiles up to
+// 36 KB, e.g. 64x64) or in a per-workgroup global workspace, so that the threads of a wave touch consecutive
+// addresses and no cross-lane reduction exists: every thread walks down its own column.  The two
+// sweeps of the level-2 step (dot products, update) are fused across steps into ONE read-modify-write
+// sweep: the dot products of step k give row k of the updated matrix (c_k + w gamma), that row is all
+// the LAWN-176 norm downdate needs, so the pivot of step k+1 is known BEFORE the update of step k is
+// applied; its column is brought up to date on the fly (x' = A(:,p') - gamma_p' x) and the sweep that
+// applies update k also accumulates the dot products with x' (and |x'_tail|^2).  Only when Eigen's
 // recompute test fires (rare) the step falls back to separate sweeps, because then the next pivot
-// depends on the recomputed norms.
-//
+// depends on the recomputed norms.  A chosen column stops sweeping: its thread stores the essential
+// part of the reflector (x_tail / (x0 - beta), Eigen's packed form) in its place.
 // Columns are never swapped: the column chosen at step k ends at position k; the "first maximum" tie
-// rule compares current positions, which every A thread tracks (Eigen's transpositions).
+// rule compares current positions, which every thread tracks (Eigen's transpositions).
+//
+// Phase 2 -- Q_i = H_0 H_1 ... H_{c-1} (HouseholderSequence::evalTo) by BLOCKED backward accumulation
+// directly in the output array (row-major Q_i is the CSR value order of m_Q): panels of NB reflectors
+// as I - V T V^T (T by the larft recurrence from V^T V), applied to Q(kp:, kp:) with one thread per
+// column of Q: w = V^T q, u = T w, q -= V u.  Q is read and written once per PANEL instead of once per
+// reflector, which is what makes tiles above 64x64 affordable: carrying Q^T through the level-2
+// sweeps (the first version of this kernel) moved 3x the bytes and ran at Infinity-Cache speed.
 #include "qrk_device.h"
 
 #include <float.h>
@@ -36,7 +35,9 @@ namespace qrk {
 namespace col {
 
 constexpr double SQRT_EPS = 1.4901161193847656e-08;   // sqrt(DBL_EPSILON), Eigen's norm_downdate_threshold
-constexpr int W_LDS_DOUBLES = 8192;                   // 64 KB of LDS for W when the tile fits
+constexpr int W_LDS_DOUBLES = 4608;                   // 36 KB of LDS for A when the tile fits (two workgroups per CU)
+constexpr int NB = 16;                                // reflectors per block in the formation of Q
+constexpr int MAXR = 256;                             // largest tile dimension of this kernel
 
 struct Cand {          // candidate of the pivot search
     double val;        // squared updated norm, < 0 = none
@@ -66,62 +67,45 @@ __device__ __forceinline__ Cand wave_best(Cand c)
 
 }  // namespace col
 
+// Everything of one tile.  Called once with W in LDS and once with W in global memory, so that after
+// inlining hipcc knows the address space of every access: through one generic pointer it has to assume
+// that a store to W may alias the LDS vectors and serialises the sweeps on the store latency.
 template <int CT>
-__global__ void __launch_bounds__(CT)
-bdqr_col_kernel(WaveBatch nb, const double* __restrict__ tiles, double* __restrict__ q_vals,
-                double* __restrict__ r_vals, int32_t* __restrict__ perm, double* __restrict__ hcoeffs,
-                double* __restrict__ workspace, int64_t ws_stride, int max_rows)
+__device__ __forceinline__ void factor_tile(double* __restrict__ W, double* smem, int r, int c, int cbase, int pivoting,
+                                            const double* __restrict__ src, double* __restrict__ Q,
+                                            double* __restrict__ rv, int32_t* __restrict__ perm,
+                                            double* __restrict__ hcoeffs)
 {
     using namespace col;
     constexpr int NW = CT / 64;
-    extern __shared__ __attribute__((aligned(16))) double smem[];
-    double* wl = smem;                                   // [W_LDS_DOUBLES] W when it fits
-    double* xv0 = wl + W_LDS_DOUBLES;                    // [max_rows] pivot column, even steps
-    double* xv1 = xv0 + max_rows;                        // [max_rows] odd steps
-    double* cval = xv1 + max_rows;                       // [NW] candidates of the waves
+    double* vs = smem + W_LDS_DOUBLES;                   // [MAXR * NB] V panel of phase 2, row-major
+    double* xv0 = vs + MAXR * NB;                        // [MAXR] pivot column, even steps
+    double* xv1 = xv0 + MAXR;                            // [MAXR] odd steps
+    double* taus = xv1 + MAXR;                           // [MAXR] Householder coefficients
+    double* gm = taus + MAXR;                            // [NB * NB] V^T V of a panel
+    double* tm = gm + NB * NB;                           // [NB * NB] T of a panel
+    double* cval = tm + NB * NB;                         // [NW] candidates of the waves
     double* cngam = cval + NW;                           // [NW]
     int* cpos = reinterpret_cast<int*>(cngam + NW);      // [NW]
     int* ctid = cpos + NW;                               // [NW]
     int* flags = ctid + NW;                              // [2] any-need flags (double buffered)
-    int* col_of_pos = flags + 2;                         // [max cols <= max_rows]
-
+    int* col_of_pos = flags + 2;                         // [MAXR] column chosen at step k
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-
-    for (int64_t t = blockIdx.x; t < nb.num_tiles; t += gridDim.x) {
-        const int gidx = nb.tile_ids ? nb.tile_ids[t] : (int)t;
-        int r, c, cbase;
-        int64_t toff, qoff, roff;
-        if (nb.t_rows) {
-            r = nb.t_rows[gidx]; c = nb.t_cols[gidx];
-            toff = nb.t_off[gidx]; qoff = nb.q_off[gidx]; roff = nb.r_off[gidx]; cbase = nb.c_off[gidx];
-        } else {
-            r = nb.rows; c = nb.cols;
-            toff = t * (int64_t)r * c; qoff = t * (int64_t)r * r; roff = t * (int64_t)(c * (c + 1) / 2);
-            cbase = (int)(t * c);
-        }
-        const int ld = c + r;                             // columns of W (<= CT)
-        const bool in_lds = (int64_t)r * ld <= W_LDS_DOUBLES;
-        double* W = in_lds ? wl : workspace + (int64_t)blockIdx.x * ws_stride;
-        const double* src = tiles + toff;
-
-        // ---- W = [A | I], row-major (A arrives column-major)
-        for (int e = tid; e < r * c; e += CT) {
+    const int ld = c;                                    // A row-major: W(i, j) = W[i * ld + j]
+    {
+        {
+        for (int e = tid; e < r * c; e += CT) {           // (A arrives column-major)
             const int i = e / c, j = e - i * c;
             W[(int64_t)i * ld + j] = src[(int64_t)j * r + i];
-        }
-        for (int e = tid; e < r * r; e += CT) {
-            const int i = e / r, j = e - i * r;
-            W[(int64_t)i * ld + c + j] = (i == j) ? 1.0 : 0.0;
         }
         if (tid < 2) flags[tid] = 0;
         __syncthreads();
 
-        const bool mine = tid < ld;          // this thread owns column tid of W
-        const bool isA = tid < c;            // ... a column of A
-        double* wc = W + tid;                // wc[i * ld] = W(i, tid)
+        // ================= phase 1: R, reflectors, permutation =================
+        const bool isA = tid < c;            // this thread owns column tid of A  (c <= CT)
+        double* wc = W + tid;                // wc[i * ld] = A(i, tid)
         bool live = isA;
-        int pos = tid;                       // current position of an A column
-        int kstep = -1;                      // step that chose it = final position
+        int pos = tid;                       // current position of the column
         double nu2 = -1.0, thr = 0.0;
         if (isA) {
             // squared column norms (ColPivHouseholderQR: m_colNormsUpdated^2, sqrt(eps) m_colNormsDirect^2)
@@ -133,7 +117,7 @@ bdqr_col_kernel(WaveBatch nb, const double* __restrict__ tiles, double* __restri
         // ---- head of step 0: pivot, its column to LDS, dot products
         int P;                               // pivot thread of the current step
         {
-            if (nb.pivoting) {
+            if (pivoting) {
                 Cand cd{live ? nu2 : -1.0, pos, tid, 0.0};
                 cd = wave_best(cd);
                 if (lane == 0) { cval[wave] = cd.val; cpos[wave] = cd.pos; ctid[wave] = cd.tidx; }
@@ -147,12 +131,12 @@ bdqr_col_kernel(WaveBatch nb, const double* __restrict__ tiles, double* __restri
             } else {
                 P = 0;
             }
-            if (tid == P) { live = false; kstep = 0; }
+            if (tid == P) { live = false; col_of_pos[0] = tid; }
             for (int i = tid; i < r; i += CT) xv0[i] = W[(int64_t)i * ld + P];
             __syncthreads();
         }
         double d = 0.0, tsq = 0.0, ak = 0.0;   // tsq = |x_tail|^2, accumulated by every column thread itself
-        if (mine) {
+        if (isA) {
             ak = wc[0];
             for (int i = 1; i < r; ++i) { const double xi = xv0[i]; d = fma(xi, wc[(int64_t)i * ld], d); tsq = fma(xi, xi, tsq); }
         }
@@ -160,11 +144,12 @@ bdqr_col_kernel(WaveBatch nb, const double* __restrict__ tiles, double* __restri
         for (int k = 0; k < c; ++k) {
             double* xc = (k & 1) ? xv1 : xv0;     // x of this step
             double* xn = (k & 1) ? xv0 : xv1;     // x of the next one
+            const bool active = live || tid == P; // columns that still take part in step k
             // ---- makeHouseholder in the un-normalised form of bdqr_pair.hip:
-            // nb_ = -beta = copysign(norm, x0), s = -w = nb_ + x0, ng = -1/(beta w); degenerate -> H = I
+            // nb_ = -beta = copysign(norm, x0), s = -w = nb_ + x0 (= x0 - beta), ng = -1/(beta w); degenerate -> H = I
             const double xk = xc[k];
             double nb_, s, ng;
-            bool degen = !(tsq > DBL_MIN);
+            const bool degen = !(tsq > DBL_MIN);
             if (degen) { nb_ = -xk; s = 0.0; ng = 0.0; }
             else {
                 const double nrm = sqrt(fma(xk, xk, tsq));
@@ -172,23 +157,25 @@ bdqr_col_kernel(WaveBatch nb, const double* __restrict__ tiles, double* __restri
                 s = nb_ + xk;
                 ng = -1.0 / (nb_ * s);
             }
-            const double ngam = mine ? fma(s, ak, d) * ng : 0.0;      // -gamma of this column
+            const double ngam = active ? fma(s, ak, d) * ng : 0.0;    // -gamma of this column
             double an = fma(s, ngam, ak);
             if (tid == P && !degen) an = -nb_;                        // R(k,k) = beta
-            if (mine) wc[(int64_t)k * ld] = an;                       // row k of W is final
-            if (tid == P && hcoeffs) hcoeffs[cbase + k] = -(s * s) * ng;   // tau = w/beta
+            if (active) wc[(int64_t)k * ld] = an;                     // row k of R
+            if (tid == P) {
+                const double tau = -(s * s) * ng;                     // w / beta
+                taus[k] = tau;
+                if (hcoeffs) hcoeffs[cbase + k] = tau;
+            }
+            const double inv_s = degen ? 0.0 : 1.0 / s;               // essential part = x_tail / (x0 - beta), 0 if H = I
 
             if (k + 1 == c) {
-                // last reflector: only Q^T still needs its update
-                if (mine && !isA) {
-                    for (int i = k + 1; i < r; ++i) wc[(int64_t)i * ld] = fma(ngam, xc[i], wc[(int64_t)i * ld]);
-                }
+                if (tid == P) for (int i = k + 1; i < r; ++i) wc[(int64_t)i * ld] = xc[i] * inv_s;
                 break;
             }
 
             // ---- LAWN-176 norm downdate (squared form, see bdqr_pair.hip) and the search for step k+1
             bool need = false;
-            if (nb.pivoting) {
+            if (pivoting) {
                 if (live) {
                     const double nn = fma(-an, an, nu2);
                     nu2 = nn;
@@ -201,47 +188,52 @@ bdqr_col_kernel(WaveBatch nb, const double* __restrict__ tiles, double* __restri
                 if (tid == 0) flags[(k + 1) & 1] = 0;
             }
             __syncthreads();
-            const bool any_need = nb.pivoting && flags[k & 1] != 0;
+            const bool any_need = pivoting && flags[k & 1] != 0;
             int Pn;                          // pivot thread of step k+1
             int ppos = k + 1;
             double ngP = 0.0;
 
             if (!any_need) {
-                if (nb.pivoting) {
+                if (pivoting) {
                     Cand b{cval[0], cpos[0], ctid[0], cngam[0]};
 #pragma unroll
                     for (int w = 1; w < NW; ++w) { Cand o{cval[w], cpos[w], ctid[w], cngam[w]}; if (better(o, b)) b = o; }
                     Pn = b.tidx; ppos = b.pos; ngP = b.ngam;
-                    // x' = column Pn after update k, built by the threads row-wise
-                    for (int i = k + 1 + tid; i < r; i += CT) xn[i] = fma(ngP, xc[i], W[(int64_t)i * ld + Pn]);
                 } else {
                     Pn = k + 1;
-                    // -gamma of column k+1 is only known to its thread: publish it first
-                    if (tid == Pn) cngam[0] = ngam;
+                    if (tid == Pn) cngam[0] = ngam;   // -gamma of column k+1 is only known to its thread
                     __syncthreads();
                     ngP = cngam[0];
-                    for (int i = k + 1 + tid; i < r; i += CT) xn[i] = fma(ngP, xc[i], W[(int64_t)i * ld + Pn]);
                 }
+                // x' = column Pn after update k, built by the threads row-wise
+                for (int i = k + 1 + tid; i < r; i += CT) xn[i] = fma(ngP, xc[i], W[(int64_t)i * ld + Pn]);
                 __syncthreads();
                 // ---- fused sweep: apply update k, accumulate the dot products of step k+1
                 d = 0.0; tsq = 0.0;
-                if (mine) {
+                if (tid == P) {
+                    for (int i = k + 1; i < r; ++i) wc[(int64_t)i * ld] = xc[i] * inv_s;   // the reflector replaces the column
+                } else if (live) {
                     int i = k + 1;
                     {
                         const double w0 = fma(ngam, xc[i], wc[(int64_t)i * ld]);
                         wc[(int64_t)i * ld] = w0;
                         ak = w0;
                     }
-                    for (i = k + 2; i + 3 < r; i += 4) {
-                        double w0 = wc[(int64_t)i * ld], w1 = wc[(int64_t)(i + 1) * ld];
-                        double w2 = wc[(int64_t)(i + 2) * ld], w3 = wc[(int64_t)(i + 3) * ld];
-                        w0 = fma(ngam, xc[i], w0); w1 = fma(ngam, xc[i + 1], w1);
-                        w2 = fma(ngam, xc[i + 2], w2); w3 = fma(ngam, xc[i + 3], w3);
-                        wc[(int64_t)i * ld] = w0; wc[(int64_t)(i + 1) * ld] = w1;
-                        wc[(int64_t)(i + 2) * ld] = w2; wc[(int64_t)(i + 3) * ld] = w3;
-                        const double x0 = xn[i], x1 = xn[i + 1], x2 = xn[i + 2], x3 = xn[i + 3];
-                        d = fma(x0, w0, d); d = fma(x1, w1, d); d = fma(x2, w2, d); d = fma(x3, w3, d);
-                        tsq = fma(x0, x0, tsq); tsq = fma(x1, x1, tsq); tsq = fma(x2, x2, tsq); tsq = fma(x3, x3, tsq);
+                    // rows in chunks of U with all U loads issued first: the sweep is bound by the latency of
+                    // the loads (LDS or L2/Infinity Cache), not by bandwidth
+                    constexpr int U = 16;
+                    for (i = k + 2; i + U <= r; i += U) {
+                        double wv[U];
+#pragma unroll
+                        for (int u = 0; u < U; ++u) wv[u] = wc[(int64_t)(i + u) * ld];
+#pragma unroll
+                        for (int u = 0; u < U; ++u) {
+                            const double w0 = fma(ngam, xc[i + u], wv[u]);
+                            wc[(int64_t)(i + u) * ld] = w0;
+                            const double x0 = xn[i + u];
+                            d = fma(x0, w0, d);
+                            tsq = fma(x0, x0, tsq);
+                        }
                     }
                     for (; i < r; ++i) {
                         const double w0 = fma(ngam, xc[i], wc[(int64_t)i * ld]);
@@ -254,7 +246,9 @@ bdqr_col_kernel(WaveBatch nb, const double* __restrict__ tiles, double* __restri
             } else {
                 // ---- rare: a column norm has to be recomputed from the updated column before the search
                 double s2 = 0.0;
-                if (mine) {
+                if (tid == P) {
+                    for (int i = k + 1; i < r; ++i) wc[(int64_t)i * ld] = xc[i] * inv_s;
+                } else if (live) {
                     for (int i = k + 1; i < r; ++i) {
                         const double w0 = fma(ngam, xc[i], wc[(int64_t)i * ld]);
                         wc[(int64_t)i * ld] = w0;
@@ -274,64 +268,184 @@ bdqr_col_kernel(WaveBatch nb, const double* __restrict__ tiles, double* __restri
                 for (int i = k + 1 + tid; i < r; i += CT) xn[i] = W[(int64_t)i * ld + Pn];
                 __syncthreads();
                 d = 0.0; tsq = 0.0;
-                if (mine) {
+                if (live) {
                     ak = wc[(int64_t)(k + 1) * ld];
                     for (int i = k + 2; i < r; ++i) { const double xi = xn[i]; d = fma(xi, wc[(int64_t)i * ld], d); tsq = fma(xi, xi, tsq); }
                 }
             }
             // Eigen swaps columns k+1 and the pivot: the column that sat at k+1 takes the pivot's place
-            if (isA && nb.pivoting) { if (tid == Pn) pos = k + 1; else if (pos == k + 1) pos = ppos; }
-            if (tid == Pn) { live = false; kstep = k + 1; }
+            if (isA && pivoting) { if (tid == Pn) pos = k + 1; else if (pos == k + 1) pos = ppos; }
+            if (tid == Pn) { live = false; col_of_pos[k + 1] = tid; }
             P = Pn;
             __syncthreads();     // every column is up to date before the next x' is read across threads
         }
         __syncthreads();
 
-        // ---- outputs.  Row i of R is row i of W; column at position p is the thread with kstep == p.
-        if (isA) {
-            col_of_pos[kstep] = tid;
-            perm[cbase + kstep] = cbase + tid;     // m_outputPerm_c.indices()(base_col+j) (:519-521)
-        }
-        __syncthreads();
-        for (int p = wave; p < c; p += NW) {       // packed upper triangle by columns = CSC value order of m_R
+        // ---- R (packed upper triangle by columns = CSC value order of m_R) and the permutation splice:
+        // row i of R is row i of W; the column at position p is col_of_pos[p].
+        for (int p = tid; p < c; p += CT) perm[cbase + p] = cbase + col_of_pos[p];   // m_outputPerm_c.indices() (:519-521)
+        for (int p = wave; p < c; p += NW) {
             const int tc = col_of_pos[p];
-            for (int i = lane; i <= p; i += 64) r_vals[roff + (int64_t)p * (p + 1) / 2 + i] = W[(int64_t)i * ld + tc];
+            for (int i = lane; i <= p; i += 64) rv[(int64_t)p * (p + 1) / 2 + i] = W[(int64_t)i * ld + tc];
         }
-        // Q_i row-major: Q(j, i) = Q^T(i, j) = W(i, c + j)
-        for (int e = tid; e < r * r; e += CT) {
-            const int j = e / r, i = e - j * r;
-            q_vals[qoff + e] = W[(int64_t)i * ld + c + j];
+
+        // ================= phase 2: Q = H_0 ... H_{c-1}, blocked backward accumulation =================
+        for (int e = tid; e < r * r; e += CT) { const int i = e / r; Q[e] = (e - i * r == i) ? 1.0 : 0.0; }
+        __syncthreads();
+#ifdef QRK_COL_SKIP_Q
+        if (r > 0) return;   // diagnostic: time phase 1 alone
+#endif
+        for (int kp = ((c - 1) / NB) * NB; kp >= 0; kp -= NB) {
+            const int kb = (c - kp) < NB ? (c - kp) : NB;
+            const int m = r - kp;
+            // V panel (m x kb, unit lower trapezoidal) to LDS, row-major with stride NB
+            for (int e = tid; e < m * NB; e += CT) {
+                const int i = e / NB, l = e - i * NB;
+                double v = 0.0;
+                if (l < kb) {
+                    if (i == l) v = 1.0;
+                    else if (i > l) v = W[(int64_t)(kp + i) * ld + col_of_pos[kp + l]];
+                }
+                vs[e] = v;
+            }
+            __syncthreads();
+            // G = V^T V (upper part), one pair per thread
+            for (int e = tid; e < NB * NB; e += CT) {
+                const int a = e / NB, b = e - a * NB;
+                double g = 0.0;
+                if (a <= b && b < kb) for (int i = b; i < m; ++i) g = fma(vs[i * NB + a], vs[i * NB + b], g);
+                gm[e] = g;
+            }
+            __syncthreads();
+            // T (forward, columnwise -- LAPACK larft): T(l,l) = tau_l, T(0:l,l) = -tau_l T(0:l,0:l) (V(:,0:l)^T v_l)
+            if (tid < NB) {
+                const int a = tid;
+                for (int l = 0; l < NB; ++l) tm[a * NB + l] = 0.0;
+                for (int l = 0; l < kb; ++l) {
+                    const double tau = taus[kp + l];
+                    double tv = 0.0;
+                    if (a == l) tv = tau;
+                    else if (a < l) {
+                        double acc = 0.0;
+                        for (int b = a; b < l; ++b) acc = fma(tm[a * NB + b], gm[b * NB + l], acc);
+                        tv = -tau * acc;
+                    }
+                    tm[a * NB + l] = tv;     // row a only depends on row a: no synchronisation needed
+                }
+            }
+            __syncthreads();
+            // Q(kp:, kp:) <- (I - V T V^T) Q(kp:, kp:), one thread per column
+            for (int j = kp + tid; j < r; j += CT) {
+                double* qc = Q + (int64_t)kp * r + j;     // qc[i * r] = Q(kp + i, j)
+                double w[NB];
+#pragma unroll
+                for (int l = 0; l < NB; ++l) w[l] = 0.0;
+                // rows in chunks of U: the U loads of Q are independent and in flight together (the loop is
+                // bound by their latency otherwise)
+                constexpr int U = 8;
+                int i = 0;
+                for (; i + U <= m; i += U) {
+                    double qv[U];
+#pragma unroll
+                    for (int u2 = 0; u2 < U; ++u2) qv[u2] = qc[(int64_t)(i + u2) * r];
+#pragma unroll
+                    for (int u2 = 0; u2 < U; ++u2) {
+#pragma unroll
+                        for (int l = 0; l < NB; ++l) w[l] = fma(vs[(i + u2) * NB + l], qv[u2], w[l]);
+                    }
+                }
+                for (; i < m; ++i) {
+                    const double qv = qc[(int64_t)i * r];
+#pragma unroll
+                    for (int l = 0; l < NB; ++l) w[l] = fma(vs[i * NB + l], qv, w[l]);
+                }
+                double u[NB];
+#pragma unroll
+                for (int a = 0; a < NB; ++a) {
+                    double acc = 0.0;
+#pragma unroll
+                    for (int b = 0; b < NB; ++b) if (b >= a) acc = fma(tm[a * NB + b], w[b], acc);
+                    u[a] = acc;
+                }
+                for (i = 0; i + U <= m; i += U) {
+                    double qv[U];
+#pragma unroll
+                    for (int u2 = 0; u2 < U; ++u2) qv[u2] = qc[(int64_t)(i + u2) * r];
+#pragma unroll
+                    for (int u2 = 0; u2 < U; ++u2) {
+#pragma unroll
+                        for (int l = 0; l < NB; ++l) qv[u2] = fma(-vs[(i + u2) * NB + l], u[l], qv[u2]);
+                        qc[(int64_t)(i + u2) * r] = qv[u2];
+                    }
+                }
+                for (; i < m; ++i) {
+                    double qv = qc[(int64_t)i * r];
+#pragma unroll
+                    for (int l = 0; l < NB; ++l) qv = fma(-vs[i * NB + l], u[l], qv);
+                    qc[(int64_t)i * r] = qv;
+                }
+            }
+            __syncthreads();
         }
         __syncthreads();
+        }
     }
 }
 
-size_t bdqr_col_smem_bytes(int max_rows, int threads)
+template <int CT>
+__global__ void __launch_bounds__(CT)
+bdqr_col_kernel(WaveBatch nb, const double* __restrict__ tiles, double* __restrict__ q_vals,
+                double* __restrict__ r_vals, int32_t* __restrict__ perm, double* __restrict__ hcoeffs,
+                double* __restrict__ workspace, int64_t ws_stride)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    for (int64_t t = blockIdx.x; t < nb.num_tiles; t += gridDim.x) {
+        const int gidx = nb.tile_ids ? nb.tile_ids[t] : (int)t;
+        int r, c, cbase;
+        int64_t toff, qoff, roff;
+        if (nb.t_rows) {
+            r = nb.t_rows[gidx]; c = nb.t_cols[gidx];
+            toff = nb.t_off[gidx]; qoff = nb.q_off[gidx]; roff = nb.r_off[gidx]; cbase = nb.c_off[gidx];
+        } else {
+            r = nb.rows; c = nb.cols;
+            toff = t * (int64_t)r * c; qoff = t * (int64_t)r * r; roff = t * (int64_t)(c * (c + 1) / 2);
+            cbase = (int)(t * c);
+        }
+        if (r * c <= col::W_LDS_DOUBLES)
+            factor_tile<CT>(smem, smem, r, c, cbase, nb.pivoting, tiles + toff, q_vals + qoff, r_vals + roff, perm, hcoeffs);
+        else
+            factor_tile<CT>(workspace + (int64_t)blockIdx.x * ws_stride, smem, r, c, cbase, nb.pivoting, tiles + toff,
+                            q_vals + qoff, r_vals + roff, perm, hcoeffs);
+    }
+}
+
+size_t bdqr_col_smem_bytes(int threads)
 {
     const int nw = threads / 64;
-    return (size_t)(col::W_LDS_DOUBLES + 2 * max_rows + 2 * nw) * sizeof(double) +
-           (size_t)(2 * nw + 2 + max_rows) * sizeof(int) + 16;
+    return (size_t)(col::W_LDS_DOUBLES + col::MAXR * col::NB + 3 * col::MAXR + 2 * col::NB * col::NB + 2 * nw) * sizeof(double) +
+           (size_t)(2 * nw + 2 + col::MAXR) * sizeof(int) + 16;
 }
 
 hipError_t launch_bdqr_col(const WaveBatch& nb, const double* tiles, double* q_vals, double* r_vals, int32_t* perm,
                            double* hcoeffs, double* workspace, int64_t ws_stride, int num_wg, int max_rows,
-                           int max_ld, hipStream_t stream)
+                           int max_cols, hipStream_t stream)
 {
     if (nb.num_tiles <= 0) return hipSuccess;
+    if (max_rows > col::MAXR || max_cols > max_rows) return hipErrorInvalidValue;
     const int64_t want = nb.num_tiles < (int64_t)num_wg ? nb.num_tiles : (int64_t)num_wg;
-    const int threads = max_ld <= 128 ? 128 : (max_ld <= 256 ? 256 : 512);
-    const size_t smem = bdqr_col_smem_bytes(max_rows, threads);
+    const int threads = max_cols <= 64 ? 64 : (max_cols <= 128 ? 128 : 256);
+    const size_t smem = bdqr_col_smem_bytes(threads);
 #define QRK_COL_LAUNCH(T)                                                                                   \
     do {                                                                                                    \
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(bdqr_col_kernel<T>),               \
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);          \
         if (e != hipSuccess) return e;                                                                      \
         hipLaunchKernelGGL((bdqr_col_kernel<T>), dim3((unsigned)want), dim3(T), smem, stream, nb, tiles, q_vals, \
-                           r_vals, perm, hcoeffs, workspace, ws_stride, max_rows);                          \
+                           r_vals, perm, hcoeffs, workspace, ws_stride);                                    \
     } while (0)
-    if (threads == 128) QRK_COL_LAUNCH(128);
-    else if (threads == 256) QRK_COL_LAUNCH(256);
-    else QRK_COL_LAUNCH(512);
+    if (threads == 64) QRK_COL_LAUNCH(64);
+    else if (threads == 128) QRK_COL_LAUNCH(128);
+    else QRK_COL_LAUNCH(256);
 #undef QRK_COL_LAUNCH
     return hipGetLastError();
 }

@@ -59,9 +59,9 @@ struct qrk_bd_plan_s {
     int32_t* d_col_ids = nullptr;    // mixed batches: their tile ids, largest first
     int64_t n_col = 0;
     double* d_col_workspace = nullptr;
-    int64_t col_ws_stride = 0;       // max rows * (cols + rows) over those tiles
+    int64_t col_ws_stride = 0;       // max rows * cols over those tiles
     int num_col_wg = 0;
-    int col_max_rows = 0, col_max_ld = 0;
+    int col_max_rows = 0, col_max_ld = 0;   // largest rows / largest cols of those tiles
 };
 
 struct qrk_bb_plan_s {
@@ -299,8 +299,8 @@ qrk_status qrk_bd_plan_create(qrk_handle h, const qrk_bd_layout* L, qrk_q_format
         p->max_dim = p->r > p->c ? p->r : p->c;
         if (p->max_dim > QRK_COL_MAX_DIM) ws_stride = (int64_t)p->r * p->c;
         else if (p->max_dim > 32 && !p->landscape) {
-            p->col_ws_stride = (int64_t)p->r * (p->c + p->r);
-            p->col_max_rows = p->r; p->col_max_ld = p->c + p->r;
+            p->col_ws_stride = (int64_t)p->r * p->c;
+            p->col_max_rows = p->r; p->col_max_ld = p->c;
         }
     } else {
         coff.resize(B); rowoff.resize(B); toff.resize(B); qoff.resize(B); roff.resize(B);
@@ -319,9 +319,9 @@ qrk_status qrk_bd_plan_create(qrk_handle h, const qrk_bd_layout* L, qrk_q_format
             if (md <= 32) wave_ids.push_back((int32_t)i);
             else if (md <= QRK_COL_MAX_DIM && r >= c) {
                 col_ids.push_back((int32_t)i);
-                if ((int64_t)r * (c + r) > p->col_ws_stride) p->col_ws_stride = (int64_t)r * (c + r);
+                if ((int64_t)r * c > p->col_ws_stride) p->col_ws_stride = (int64_t)r * c;
                 if (r > p->col_max_rows) p->col_max_rows = r;
-                if (c + r > p->col_max_ld) p->col_max_ld = c + r;
+                if (c > p->col_max_ld) p->col_max_ld = c;
             }
             else { wg_ids.push_back((int32_t)i); if ((int64_t)r * c > ws_stride) ws_stride = (int64_t)r * c; }
         }
@@ -343,7 +343,9 @@ qrk_status qrk_bd_plan_create(qrk_handle h, const qrk_bd_layout* L, qrk_q_format
             return (int64_t)L->rows[a] * L->rows[a] * L->cols[a] > (int64_t)L->rows[b] * L->rows[b] * L->cols[b];
         });
         const int64_t n_mid = p->uniform ? B : (int64_t)col_ids.size();
-        p->num_col_wg = (int)(n_mid < 2 * (int64_t)h->num_cus ? n_mid : 2 * (int64_t)h->num_cus);
+        int64_t col_wgs = 2 * (int64_t)h->num_cus;
+        if (const char* e = std::getenv("QRK_COL_WGS")) { const long v = std::atol(e); if (v > 0) col_wgs = v; }
+        p->num_col_wg = (int)(n_mid < col_wgs ? n_mid : col_wgs);
         if (hipMalloc((void**)&p->d_col_workspace, (size_t)p->num_col_wg * (size_t)p->col_ws_stride * sizeof(double)) != hipSuccess) {
             delete p;
             return fail(h, QRK_STATUS_ALLOC_FAILED, "qrk_bd_plan_create: cannot allocate the mid-size-tile workspace");

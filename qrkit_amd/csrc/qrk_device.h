@@ -48,10 +48,10 @@ void launch_bdqr_wave(const WaveBatch& nb, bool full32, const double* tiles, dou
 void launch_bdqr_pair(const WaveBatch& nb, bool full32, const double* tiles, double* q_vals,
                       double* r_vals, int32_t* perm, double* hcoeffs, int max_blocks,
                       hipStream_t stream);
-// Mid-size tiles (32 < max(rows, cols) <= 256, rows >= cols): one thread per column of [A | Q^T] (bdqr_col.hip).
+// Mid-size tiles (32 < max(rows, cols) <= 256, rows >= cols): one thread per column of A, blocked Q (bdqr_col.hip).
 hipError_t launch_bdqr_col(const WaveBatch& nb, const double* tiles, double* q_vals, double* r_vals, int32_t* perm,
                            double* hcoeffs, double* workspace, int64_t ws_stride, int num_wg, int max_rows,
-                           int max_ld, hipStream_t stream);
+                           int max_cols, hipStream_t stream);
 void launch_bdqr_wg(const WaveBatch& nb, const double* tiles, double* q_vals, double* r_vals, int32_t* perm,
                     double* hcoeffs, double* workspace, int64_t ws_stride, int num_wg, int max_dim,
                     hipStream_t stream);
