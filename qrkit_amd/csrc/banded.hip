@@ -16,6 +16,7 @@
 #include "qrk_device.h"
 
 #include <float.h>
+#include <cstdlib>
 
 namespace qrk {
 
@@ -166,6 +167,300 @@ bb_chain_kernel(const BBPanel* __restrict__ panels, int num_panels, const int32_
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Second version of the chain (panels up to 256 columns): the panel is kept ROW-major and worked on by
+// 1024 threads as a 2-D grid, column slot cs = tid % 256, row group rg = tid / 256 (rows interleaved
+// modulo 4), so every sweep is coalesced and there is no cross-lane reduction:
+//   * Householder QR with the dot and update sweeps FUSED across steps (no pivoting here, the pivot of
+//     step k+1 is column k+1): the sweep that applies reflector k to column c also accumulates
+//     x'^T c for the next reflector x' = W(:,k+1) - gamma_{k+1} x, two barriers per reflector;
+//   * G = Y^T Y by 4x4 register tiles over LDS-staged row chunks, written into the T output;
+//   * T by the forward (larft) recurrence T(0:c,c) = -h_c T(0:c,0:c) G(0:c,c), in place, T kept packed
+//     in LDS when it fits (n <= 192), the negation the reference stores (:477) applied at the end.
+// The first version spent ~16 ms per 448x192 panel (BASELINE configs[2] shape), mostly in wave-wide
+// reductions: one per column and reflector in the QR, one per (i, c) pair in the T recurrence.
+constexpr int BC_THREADS = 1024;
+constexpr int BC_CW = 256;                 // most columns of a panel
+constexpr int BC_RC = 16;                  // rows per LDS chunk in the Gram matrix
+
+__global__ void __launch_bounds__(BC_THREADS)
+bb_chain2_kernel(const BBPanel* __restrict__ panels, int num_panels, const int32_t* __restrict__ prowptr,
+                 const int32_t* __restrict__ pcol, const int64_t* __restrict__ pmap, const double* __restrict__ vals,
+                 double* __restrict__ W, double* __restrict__ lo, double* __restrict__ y_vals,
+                 double* __restrict__ t_vals, double* __restrict__ r_stage, int max_act_rows, int max_ncols,
+                 int t_in_lds)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double* hc = smem;                         // [BC_CW] hCoeffs of the panel
+    double* dpart = hc + BC_CW;                // [RG * CW <= BC_THREADS] partial dot products / partial sums
+    double* akv = dpart + BC_THREADS;          // [BC_CW] row k of the trailing columns
+    double* tq = akv + BC_CW;                  // [RG <= 16] partial |x_tail|^2
+    double* uni = tq + 16;                     // union: QR vectors / Gram chunk / packed T + g column
+    double* xv0 = uni;                         // [max_act_rows]
+    double* xv1 = xv0 + max_act_rows;          // [max_act_rows]
+    double* ys = uni;                          // [BC_RC * n]
+    double* tl = uni;                          // [n (n + 1) / 2] packed upper T by columns
+    const int tid = threadIdx.x;
+#ifdef QRK_BB_PROF
+    unsigned long long pt[6] = {0, 0, 0, 0, 0, 0}, t0 = 0;
+#define BB_TICK(n) do { const unsigned long long t1 = __builtin_amdgcn_s_memtime(); pt[n] += t1 - t0; t0 = t1; } while (0)
+#else
+#define BB_TICK(n) do { } while (0)
+#endif
+
+    for (int pi = 0; pi < num_panels; ++pi) {
+        const BBPanel p = panels[pi];
+        const int m = p.act_rows, n = p.ncols;          // W is m x n, row-major: W(i, j) = W[i * n + j]
+        // 2-D thread grid of this panel: CW column slots (n rounded up to a wave), RG row groups
+        const int CW = ((n + 63) / 64) * 64, RG = BC_THREADS / CW;
+        const bool on = tid < CW * RG;                  // (threads beyond the grid only help with the copies)
+        const int cs = on ? tid % CW : CW - 1, rg = on ? tid / CW : 0;
+        double* gv = tl + (int64_t)n * (n + 1) / 2;     // [n] column of G in the T recurrence (only with t_in_lds)
+
+#ifdef QRK_BB_PROF
+        t0 = __builtin_amdgcn_s_memtime();
+#endif
+        // ---- Ji = pmat.block(row0, col0, m, n).toDense() (:458, :503) ...
+        for (int64_t e = tid; e < (int64_t)m * n; e += BC_THREADS) W[e] = 0.0;
+        __syncthreads();
+        for (int r = tid >> 6; r < m; r += BC_THREADS / 64) {
+            const int gr = p.row0 + r;
+            for (int e = prowptr[gr] + (tid & 63); e < prowptr[gr + 1]; e += 64) {
+                const int c = pcol[e] - p.col0;
+                if (c >= 0 && c < n) W[(int64_t)r * n + c] = vals[pmap[e]];
+            }
+        }
+        __syncthreads();
+        // ... with its top-left corner replaced by the leftover block of the previous panel (:504-506)
+        for (int e = tid; e < p.lo_rows * p.lo_cols; e += BC_THREADS) {
+            const int i = e % p.lo_rows, j = e / p.lo_rows;
+            W[(int64_t)i * n + j] = lo[e];
+        }
+        __syncthreads();
+
+        BB_TICK(0);
+        // ---- Eigen::HouseholderQR of the panel
+        const int c = on ? cs : n;              // this thread's column (n <= BC_CW); none for the spare threads
+        double* wc = W + c;
+        const int nsteps = m < n ? m : n;       // (m >= n is guaranteed by the host analysis)
+        for (int i = tid; i < m; i += BC_THREADS) xv0[i] = W[(int64_t)i * n];
+        __syncthreads();
+        {   // dot products with x = column 0, row 0 of every column, |x_tail|^2
+            double dp = 0.0, tp = 0.0;
+            if (c < n && c > 0) for (int i = 1 + rg; i < m; i += RG) dp = fma(xv0[i], wc[(int64_t)i * n], dp);
+            if (on && cs == 0) for (int i = 1 + rg; i < m; i += RG) tp = fma(xv0[i], xv0[i], tp);
+            if (on) dpart[rg * CW + cs] = dp;
+            if (on && cs == 0) tq[rg] = tp;
+            if (rg == 0 && c < n) akv[c] = wc[0];
+        }
+        __syncthreads();
+        for (int k = 0; k < nsteps; ++k) {
+            double* xc = (k & 1) ? xv1 : xv0;
+            double* xn = (k & 1) ? xv0 : xv1;
+            double tsq = 0.0;
+            for (int g = 0; g < RG; ++g) tsq += tq[g];
+            const double xk = xc[k];
+            // makeHouseholder (Eigen/src/Householder/Householder.h), un-normalised form of bdqr_pair.hip
+            double nb_, s, ng, tau, inv_s;
+            const bool degen = !(tsq > DBL_MIN);
+            if (degen) { nb_ = -xk; s = 0.0; ng = 0.0; tau = 0.0; inv_s = 0.0; }
+            else {
+                const double nrm = sqrt(fma(xk, xk, tsq));
+                nb_ = xk >= 0.0 ? nrm : -nrm;
+                s = nb_ + xk;                    // x0 - beta
+                ng = -1.0 / (nb_ * s);
+                tau = -(s * s) * ng;             // (beta - x0) / beta
+                inv_s = 1.0 / s;
+            }
+            if (tid == 0) hc[k] = tau;
+            double ngam = 0.0;
+            if (c < n && c > k) {
+                double d = 0.0;
+                for (int g = 0; g < RG; ++g) d += dpart[g * CW + c];
+                const double ak = akv[c];
+                ngam = fma(s, ak, d) * ng;
+                if (rg == 0) wc[(int64_t)k * n] = fma(s, ngam, ak);        // row k of R
+            } else if (c == k && rg == 0) {
+                wc[(int64_t)k * n] = -nb_;                                  // beta (= x0 when H = I)
+            }
+            if (k + 1 >= n) {
+                if (c == k) for (int i = k + 1 + rg; i < m; i += RG) wc[(int64_t)i * n] = xc[i] * inv_s;
+                break;
+            }
+            // next reflector: column k+1 after update k, built row-wise by all threads
+            double ngP;
+            {
+                double d = 0.0;
+                for (int g = 0; g < RG; ++g) d += dpart[g * CW + k + 1];
+                ngP = fma(s, akv[k + 1], d) * ng;
+            }
+            for (int i = k + 1 + tid; i < m; i += BC_THREADS) xn[i] = fma(ngP, xc[i], W[(int64_t)i * n + k + 1]);
+            __syncthreads();
+            BB_TICK(5);
+            // fused sweep: apply reflector k, accumulate the dot products with the next one
+            double dp = 0.0, tp = 0.0;
+            if (c == k) {
+                for (int i = k + 1 + rg; i < m; i += RG) wc[(int64_t)i * n] = xc[i] * inv_s;   // essential part (:471-475)
+            } else if (c < n && c > k) {
+                // chunks of U rows per thread, all U loads issued before the first use (predicated at the
+                // end of the column: a scalar remainder loop would pay the L2 latency once per row)
+                constexpr int U = 8;
+                for (int i = k + 1 + rg; i < m; i += U * RG) {
+                    double wv[U];
+#pragma unroll
+                    for (int u = 0; u < U; ++u) { const int ii = i + u * RG; wv[u] = ii < m ? wc[(int64_t)ii * n] : 0.0; }
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const int ii = i + u * RG;
+                        if (ii < m) {
+                            const double w0 = fma(ngam, xc[ii], wv[u]);
+                            wc[(int64_t)ii * n] = w0;
+                            if (ii == k + 1) akv[c] = w0; else dp = fma(xn[ii], w0, dp);
+                        }
+                    }
+                }
+            }
+            if (on && cs == 0) for (int i = k + 2 + rg; i < m; i += RG) tp = fma(xn[i], xn[i], tp);
+            if (on) dpart[rg * CW + cs] = dp;
+            if (on && cs == 0) tq[rg] = tp;
+            __syncthreads();
+            BB_TICK(1);
+        }
+        __syncthreads();
+
+        BB_TICK(1);
+        // ---- rows of R solved by this panel: V = triu(packed QR), explicit zeros kept (:484-491)
+        for (int e = tid; e < p.solved * n; e += BC_THREADS) {
+            const int br = e % p.solved, bc = e / p.solved;
+            r_stage[p.r_off + e] = (br <= bc && br < m) ? W[(int64_t)br * n + bc] : 0.0;
+        }
+        // ---- leftover block for the next panel: V.block(lo_from, lo_from, lo_rows, lo_cols) (:505)
+        if (pi + 1 < num_panels) {
+            const BBPanel q = panels[pi + 1];
+            for (int e = tid; e < q.lo_rows * q.lo_cols; e += BC_THREADS) {
+                const int i = e % q.lo_rows, j = e / q.lo_rows;
+                const int vr = q.lo_from + i, vc = q.lo_from + j;
+                lo[e] = (vr <= vc && vr < m && vc < n) ? W[(int64_t)vr * n + vc] : 0.0;
+            }
+        }
+        // ---- Y = unit-lower essentials (:471-475), column-major m x n
+        double* Y = y_vals + p.y_off;
+        for (int64_t e = tid; e < (int64_t)m * n; e += BC_THREADS) {
+            const int i = (int)(e % m), j = (int)(e / m);
+            Y[e] = i < j ? 0.0 : (i == j ? 1.0 : W[(int64_t)i * n + j]);
+        }
+        __syncthreads();
+
+        BB_TICK(2);
+        // ---- G = Y^T Y (strict upper part) into the T output: T[c * n + b] = G(b, c), b < c
+        double* T = t_vals + p.t_off;
+        {
+            const int nbk = (n + 3) / 4;                 // 4x4 tiles, one per thread and pass
+            const int npass = (nbk * nbk + BC_THREADS - 1) / BC_THREADS;
+            for (int q = 0; q < npass; ++q) {
+                const int tile = tid + q * BC_THREADS;
+                const int bi = tile / nbk, bc = tile - bi * nbk;
+                const bool mine = bi < nbk && bi <= bc;
+                double acc[16];
+#pragma unroll
+                for (int z = 0; z < 16; ++z) acc[z] = 0.0;
+                for (int r0 = 0; r0 < m; r0 += BC_RC) {
+                    const int rc = (m - r0) < BC_RC ? (m - r0) : BC_RC;
+                    __syncthreads();
+                    for (int e = tid; e < rc * n; e += BC_THREADS) {
+                        const int i = r0 + e / n, j = e % n;
+                        ys[e] = i < j ? 0.0 : (i == j ? 1.0 : W[(int64_t)i * n + j]);
+                    }
+                    __syncthreads();
+                    if (mine) {
+                        for (int rr = 0; rr < rc; ++rr) {
+                            double a[4], b[4];
+#pragma unroll
+                            for (int z = 0; z < 4; ++z) {
+                                a[z] = (4 * bi + z < n) ? ys[rr * n + 4 * bi + z] : 0.0;
+                                b[z] = (4 * bc + z < n) ? ys[rr * n + 4 * bc + z] : 0.0;
+                            }
+#pragma unroll
+                            for (int za = 0; za < 4; ++za)
+#pragma unroll
+                                for (int zb = 0; zb < 4; ++zb) acc[za * 4 + zb] = fma(a[za], b[zb], acc[za * 4 + zb]);
+                        }
+                    }
+                }
+                if (mine) {
+#pragma unroll
+                    for (int za = 0; za < 4; ++za)
+#pragma unroll
+                        for (int zb = 0; zb < 4; ++zb) {
+                            const int gi = 4 * bi + za, gc = 4 * bc + zb;
+                            if (gi < gc && gc < n) T[(int64_t)gc * n + gi] = acc[za * 4 + zb];
+                        }
+                }
+            }
+        }
+        __syncthreads();
+
+        BB_TICK(3);
+        // ---- T = make_block_householder_triangular_factor(Y, hCoeffs) (:476), forward recurrence, in place
+        for (int cc = 0; cc < n; ++cc) {
+            const double hcc = hc[cc];
+            if (t_in_lds) {
+                for (int b = tid; b < cc; b += BC_THREADS) gv[b] = T[(int64_t)cc * n + b];
+                __syncthreads();
+                // thread (a = cs, rg): partial sum over b = a + rg, a + rg + RG, ... < cc of T(a, b) g(b)
+                double part = 0.0;
+                if (on && cs < cc) for (int b = cs + rg; b < cc; b += RG) part = fma(tl[(int64_t)b * (b + 1) / 2 + cs], gv[b], part);
+                if (on) dpart[rg * CW + cs] = part;
+                __syncthreads();
+                if (on && rg == 0 && cs < cc) {
+                    double sum = 0.0;
+                    for (int g = 0; g < RG; ++g) sum += dpart[g * CW + cs];
+                    tl[(int64_t)cc * (cc + 1) / 2 + cs] = -hcc * sum;
+                }
+                if (tid == 0) tl[(int64_t)cc * (cc + 1) / 2 + cc] = hcc;
+                __syncthreads();
+            } else {
+                double part = 0.0;
+                if (on && cs < cc) for (int b = cs + rg; b < cc; b += RG) part = fma(T[(int64_t)b * n + cs], T[(int64_t)cc * n + b], part);
+                if (on) dpart[rg * CW + cs] = part;
+                __syncthreads();     // every G(b, cc) has been read before column cc is overwritten
+                if (on && rg == 0 && cs < cc) {
+                    double sum = 0.0;
+                    for (int g = 0; g < RG; ++g) sum += dpart[g * CW + cs];
+                    T[(int64_t)cc * n + cs] = -hcc * sum;
+                }
+                if (tid == 0) T[(int64_t)cc * n + cc] = hcc;
+                __syncthreads();
+            }
+        }
+        // the reference stores -T (:477); lower part zero
+        for (int64_t e = tid; e < (int64_t)n * n; e += BC_THREADS) {
+            const int a = (int)(e % n), b = (int)(e / n);
+            double v = 0.0;
+            if (a <= b) v = t_in_lds ? -tl[(int64_t)b * (b + 1) / 2 + a] : -T[e];
+            T[e] = v;
+        }
+        __syncthreads();
+        BB_TICK(4);
+#ifdef QRK_BB_PROF
+        if (pi == num_panels - 1 && tid == 0) for (int z = 0; z < 5; ++z) T[z] = (double)pt[z];
+        if (pi == num_panels - 1 && tid == 0) T[5] = (double)pt[5];
+#endif
+    }
+}
+
+size_t bb_chain2_smem(int max_act_rows, int max_ncols, int* t_in_lds)
+{
+    const size_t fixed = (size_t)(BC_CW + BC_THREADS + BC_CW + 16) * sizeof(double);
+    const size_t qr = (size_t)2 * max_act_rows * sizeof(double);
+    const size_t gram = (size_t)BC_RC * max_ncols * sizeof(double);
+    const size_t tpk = ((size_t)max_ncols * (max_ncols + 1) / 2 + max_ncols) * sizeof(double);
+    size_t uni = qr > gram ? qr : gram;
+    *t_in_lds = 0;
+    if (fixed + (tpk > uni ? tpk : uni) <= (size_t)160 * 1024) { *t_in_lds = 1; if (tpk > uni) uni = tpk; }
+    return fixed + uni;
+}
+
 __global__ void __launch_bounds__(256)
 bb_gather_r_kernel(const double* __restrict__ r_stage, const int64_t* __restrict__ r_src, int64_t nnz,
                    double* __restrict__ r_vals)
@@ -227,12 +522,22 @@ hipError_t launch_bb_chain(const BBPanel* panels, int num_panels, const int32_t*
                            double* r_stage, const int64_t* r_src, int64_t nnz_r, double* r_vals, int max_act_rows,
                            int max_ncols, hipStream_t stream)
 {
-    const size_t smem = bb_chain_smem(max_act_rows, max_ncols);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(bb_chain_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(bb_chain_kernel, dim3(1), dim3(BB_THREADS), smem, stream, panels, num_panels, prowptr, pcol, pmap, vals,
-                       W, lo, y_vals, t_vals, r_stage, max_act_rows, max_ncols);
+    int t_in_lds = 0;
+    const size_t smem2 = bb_chain2_smem(max_act_rows, max_ncols, &t_in_lds);
+    if (max_ncols <= BC_CW && smem2 <= (size_t)160 * 1024 && !std::getenv("QRK_BB_CHAIN_V1")) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(bb_chain2_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem2);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(bb_chain2_kernel, dim3(1), dim3(BC_THREADS), smem2, stream, panels, num_panels, prowptr, pcol, pmap,
+                           vals, W, lo, y_vals, t_vals, r_stage, max_act_rows, max_ncols, t_in_lds);
+    } else {
+        const size_t smem = bb_chain_smem(max_act_rows, max_ncols);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(bb_chain_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(bb_chain_kernel, dim3(1), dim3(BB_THREADS), smem, stream, panels, num_panels, prowptr, pcol, pmap, vals,
+                           W, lo, y_vals, t_vals, r_stage, max_act_rows, max_ncols);
+    }
     if (nnz_r > 0)
         hipLaunchKernelGGL(bb_gather_r_kernel, dim3((unsigned)((nnz_r + 255) / 256)), dim3(256), 0, stream, r_stage, r_src,
                            nnz_r, r_vals);

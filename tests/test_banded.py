@@ -89,7 +89,18 @@ def test_hip_banded_matches_oracle(num_vars, overlap, shuffle, suggested):
     R = qr.matrixR()
     np.testing.assert_array_equal(R.indptr, ref.R.indptr)
     np.testing.assert_array_equal(R.indices, ref.R.indices)
-    assert rel_fro(R.data, ref.R.data) <= 1e-12
+    # Sign of a row of R: where the leading entry of a reflector is exactly zero in exact arithmetic (the last
+    # column of a merged panel: its only entry inside the panel is the overlap element), beta = -sign(x0)|x| takes
+    # the sign of rounding noise, so a row of R (and the matching column of Q) may come out negated.  At most one
+    # such row per panel; everything is compared after aligning those signs.
+    n_rows, n_cols = J.shape
+    dg, dgo = R.diagonal(), ref.R.diagonal()
+    flip = np.where(np.sign(dg) != np.sign(dgo))[0]
+    assert len(flip) <= len(ref.blocks), flip
+    D = np.ones(n_rows); D[flip] = -1.0
+    Rs = sp.diags(D) @ R
+    Rs = sp.csc_matrix(Rs); Rs.sort_indices()
+    assert rel_fro(Rs.toarray(), ref.R.toarray()) <= 1e-12
     # The merged panels of these inputs are numerically rank deficient in their last column (its only entry
     # inside the panel is the overlap element), so the last reflector of a panel is fixed by rounding noise and
     # Y/T are NOT comparable element by element between implementations (LAPACK disagrees with Eigen's algorithm
@@ -111,5 +122,5 @@ def test_hip_banded_matches_oracle(num_vars, overlap, shuffle, suggested):
     assert rel_fro(qr.applyQt(PJ), Rd) <= 1e-12                                   # Q^T Pr J = R (:252)
     x = np.random.default_rng(0).uniform(-1, 1, m)
     b = np.random.default_rng(1).uniform(-1, 1, n)
-    assert rel_fro(qr.applyQt(b)[:m], orc.bb_apply_q(ref, b, transpose=True)[:m]) <= 1e-11   # range part of Q^T b
+    assert rel_fro(D[:m] * qr.applyQt(b)[:m], orc.bb_apply_q(ref, b, transpose=True)[:m]) <= 1e-11   # range part of Q^T b
     assert rel_fro(qr.solve((J @ x)[inv]), x) <= 1e-9                             # LS recovery  (:255)
