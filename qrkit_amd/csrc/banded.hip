@@ -182,6 +182,8 @@ bb_chain_kernel(const BBPanel* __restrict__ panels, int num_panels, const int32_
 constexpr int BC_THREADS = 1024;
 constexpr int BC_CW = 256;                 // most columns of a panel
 constexpr int BC_RC = 16;                  // rows per LDS chunk in the Gram matrix
+constexpr int BC_NB = 8;                   // columns of a sub-panel of the blocked Householder QR
+constexpr int BC_RGT = 4;                  // most row groups in the trailing update (LDS for the partial sums)
 
 __global__ void __launch_bounds__(BC_THREADS)
 bb_chain2_kernel(const BBPanel* __restrict__ panels, int num_panels, const int32_t* __restrict__ prowptr,
@@ -192,12 +194,13 @@ bb_chain2_kernel(const BBPanel* __restrict__ panels, int num_panels, const int32
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double* hc = smem;                         // [BC_CW] hCoeffs of the panel
-    double* dpart = hc + BC_CW;                // [RG * CW <= BC_THREADS] partial dot products / partial sums
-    double* akv = dpart + BC_THREADS;          // [BC_CW] row k of the trailing columns
-    double* tq = akv + BC_CW;                  // [RG <= 16] partial |x_tail|^2
-    double* uni = tq + 16;                     // union: QR vectors / Gram chunk / packed T + g column
-    double* xv0 = uni;                         // [max_act_rows]
-    double* xv1 = xv0 + max_act_rows;          // [max_act_rows]
+    double* dpart = hc + BC_CW;                // [BC_THREADS] partial sums of the T recurrence
+    double* gs = dpart + BC_THREADS;           // [BC_NB * BC_NB] V^T V of a sub-panel
+    double* ts = gs + BC_NB * BC_NB;           // [BC_NB * BC_NB] T of a sub-panel
+    double* sc = ts + BC_NB * BC_NB;           // [8] scalars of the current reflector
+    double* uni = sc + 8;                      // union: {sub-panel, partial V^T W} / Gram chunk / {packed T, g column}
+    double* sp = uni;                          // [max_act_rows * BC_NB] sub-panel, row-major
+    double* wpart = sp + (int64_t)max_act_rows * BC_NB;   // [BC_RGT * BC_NB * BC_CW] partial V^T W per row group
     double* ys = uni;                          // [BC_RC * n]
     double* tl = uni;                          // [n (n + 1) / 2] packed upper T by columns
     const int tid = threadIdx.x;
@@ -239,92 +242,168 @@ bb_chain2_kernel(const BBPanel* __restrict__ panels, int num_panels, const int32
         __syncthreads();
 
         BB_TICK(0);
-        // ---- Eigen::HouseholderQR of the panel
-        const int c = on ? cs : n;              // this thread's column (n <= BC_CW); none for the spare threads
-        double* wc = W + c;
-        const int nsteps = m < n ? m : n;       // (m >= n is guaranteed by the host analysis)
-        for (int i = tid; i < m; i += BC_THREADS) xv0[i] = W[(int64_t)i * n];
-        __syncthreads();
-        {   // dot products with x = column 0, row 0 of every column, |x_tail|^2
-            double dp = 0.0, tp = 0.0;
-            if (c < n && c > 0) for (int i = 1 + rg; i < m; i += RG) dp = fma(xv0[i], wc[(int64_t)i * n], dp);
-            if (on && cs == 0) for (int i = 1 + rg; i < m; i += RG) tp = fma(xv0[i], xv0[i], tp);
-            if (on) dpart[rg * CW + cs] = dp;
-            if (on && cs == 0) tq[rg] = tp;
-            if (rg == 0 && c < n) akv[c] = wc[0];
-        }
-        __syncthreads();
-        for (int k = 0; k < nsteps; ++k) {
-            double* xc = (k & 1) ? xv1 : xv0;
-            double* xn = (k & 1) ? xv0 : xv1;
-            double tsq = 0.0;
-            for (int g = 0; g < RG; ++g) tsq += tq[g];
-            const double xk = xc[k];
-            // makeHouseholder (Eigen/src/Householder/Householder.h), un-normalised form of bdqr_pair.hip
-            double nb_, s, ng, tau, inv_s;
-            const bool degen = !(tsq > DBL_MIN);
-            if (degen) { nb_ = -xk; s = 0.0; ng = 0.0; tau = 0.0; inv_s = 0.0; }
-            else {
-                const double nrm = sqrt(fma(xk, xk, tsq));
-                nb_ = xk >= 0.0 ? nrm : -nrm;
-                s = nb_ + xk;                    // x0 - beta
-                ng = -1.0 / (nb_ * s);
-                tau = -(s * s) * ng;             // (beta - x0) / beta
-                inv_s = 1.0 / s;
+        // ---- Eigen::HouseholderQR of the panel, blocked: sub-panels of BC_NB columns are factorised in LDS
+        // (one wave per column, rows over the lanes), then the block reflector I - V T^T V^T of the sub-panel
+        // is applied to the columns to its right in one read-modify-write sweep.  The one-reflector-at-a-time
+        // version moved 0.5-1.4 MB per reflector through this CU's L2 port; this one moves it once per
+        // BC_NB reflectors.
+        for (int jb = 0; jb < n; jb += BC_NB) {
+            const int kb = (n - jb) < BC_NB ? (n - jb) : BC_NB;
+            const int mr = m - jb;                       // rows jb.. of the panel take part
+            const int wv_ = tid >> 6, ln = tid & 63;     // wave = column of the sub-panel
+            // A. sub-panel to LDS, row-major with stride BC_NB
+            for (int e = tid; e < mr * BC_NB; e += BC_THREADS) {
+                const int i = e / BC_NB, l = e - i * BC_NB;
+                sp[e] = l < kb ? W[(int64_t)(jb + i) * n + jb + l] : 0.0;
             }
-            if (tid == 0) hc[k] = tau;
-            double ngam = 0.0;
-            if (c < n && c > k) {
-                double d = 0.0;
-                for (int g = 0; g < RG; ++g) d += dpart[g * CW + c];
-                const double ak = akv[c];
-                ngam = fma(s, ak, d) * ng;
-                if (rg == 0) wc[(int64_t)k * n] = fma(s, ngam, ak);        // row k of R
-            } else if (c == k && rg == 0) {
-                wc[(int64_t)k * n] = -nb_;                                  // beta (= x0 when H = I)
-            }
-            if (k + 1 >= n) {
-                if (c == k) for (int i = k + 1 + rg; i < m; i += RG) wc[(int64_t)i * n] = xc[i] * inv_s;
-                break;
-            }
-            // next reflector: column k+1 after update k, built row-wise by all threads
-            double ngP;
-            {
-                double d = 0.0;
-                for (int g = 0; g < RG; ++g) d += dpart[g * CW + k + 1];
-                ngP = fma(s, akv[k + 1], d) * ng;
-            }
-            for (int i = k + 1 + tid; i < m; i += BC_THREADS) xn[i] = fma(ngP, xc[i], W[(int64_t)i * n + k + 1]);
             __syncthreads();
-            BB_TICK(5);
-            // fused sweep: apply reflector k, accumulate the dot products with the next one
-            double dp = 0.0, tp = 0.0;
-            if (c == k) {
-                for (int i = k + 1 + rg; i < m; i += RG) wc[(int64_t)i * n] = xc[i] * inv_s;   // essential part (:471-475)
-            } else if (c < n && c > k) {
-                // chunks of U rows per thread, all U loads issued before the first use (predicated at the
-                // end of the column: a scalar remainder loop would pay the L2 latency once per row)
-                constexpr int U = 8;
-                for (int i = k + 1 + rg; i < m; i += U * RG) {
-                    double wv[U];
+            // B. Householder QR of the sub-panel in LDS (makeHouseholder + applyHouseholderOnTheLeft,
+            //    un-normalised form of bdqr_pair.hip)
+            for (int j = 0; j < kb; ++j) {
+                if (wv_ == j) {
+                    double part = 0.0;
+                    for (int i = j + 1 + ln; i < mr; i += 64) { const double v = sp[i * BC_NB + j]; part = fma(v, v, part); }
+                    const double tsq = bb_wave_sum(part);
+                    const double xk = sp[j * BC_NB + j];
+                    double nb_, s2, ng, tau;
+                    if (!(tsq > DBL_MIN)) { nb_ = -xk; s2 = 0.0; ng = 0.0; tau = 0.0; }
+                    else {
+                        const double nrm = sqrt(fma(xk, xk, tsq));
+                        nb_ = xk >= 0.0 ? nrm : -nrm;
+                        s2 = nb_ + xk;                   // x0 - beta
+                        ng = -1.0 / (nb_ * s2);
+                        tau = -(s2 * s2) * ng;           // (beta - x0) / beta
+                    }
+                    if (ln == 0) { sc[0] = s2; sc[1] = ng; sc[2] = -nb_; hc[jb + j] = tau; }
+                }
+                __syncthreads();
+                const double s2 = sc[0], ng = sc[1], betaj = sc[2];   // (read now: the next step's wave rewrites sc)
+                if (wv_ > j && wv_ < kb) {
+                    const int l = wv_;
+                    double part = 0.0;
+                    for (int i = j + 1 + ln; i < mr; i += 64) part = fma(sp[i * BC_NB + j], sp[i * BC_NB + l], part);
+                    const double d = bb_wave_sum(part);
+                    const double ak = sp[j * BC_NB + l];
+                    const double ngam = fma(s2, ak, d) * ng;
+                    for (int i = j + 1 + ln; i < mr; i += 64) sp[i * BC_NB + l] = fma(ngam, sp[i * BC_NB + j], sp[i * BC_NB + l]);
+                    if (ln == 0) sp[j * BC_NB + l] = fma(s2, ngam, ak);       // row j of R
+                }
+                __syncthreads();
+                if (wv_ == j) {
+                    const double inv_s = s2 != 0.0 ? 1.0 / s2 : 0.0;
+                    for (int i = j + 1 + ln; i < mr; i += 64) sp[i * BC_NB + j] *= inv_s;   // essential part (:471-475)
+                    if (ln == 0) sp[j * BC_NB + j] = betaj;                                 // beta
+                }
+                // (no barrier: the next step reads column j+1 and its wave only touches that column until the
+                //  barrier after its scalars; column j is not read again before the barrier below)
+            }
+            __syncthreads();
+            // C. packed sub-panel back to the panel
+            for (int e = tid; e < mr * BC_NB; e += BC_THREADS) {
+                const int i = e / BC_NB, l = e - i * BC_NB;
+                if (l < kb) W[(int64_t)(jb + i) * n + jb + l] = sp[e];
+            }
+            const int nt = n - jb - kb;                  // columns to the right
+            if (nt <= 0) { __syncthreads(); continue; }
+            // D. V = unit-lower view of the sub-panel (in place), Ts = larft(V, tau)
+            __syncthreads();
+            for (int e = tid; e < kb * BC_NB; e += BC_THREADS) {
+                const int i = e / BC_NB, l = e - i * BC_NB;
+                if (l < kb) { if (i == l) sp[e] = 1.0; else if (i < l) sp[e] = 0.0; }
+            }
+            __syncthreads();
+            for (int pr = wv_; pr < BC_NB * BC_NB; pr += BC_THREADS / 64) {     // G_s = V^T V, one pair per wave pass
+                const int a = pr / BC_NB, b2 = pr - a * BC_NB;
+                if (a < b2 && b2 < kb) {
+                    double part = 0.0;
+                    for (int i = b2 + ln; i < mr; i += 64) part = fma(sp[i * BC_NB + a], sp[i * BC_NB + b2], part);
+                    part = bb_wave_sum(part);
+                    if (ln == 0) gs[pr] = part;
+                }
+            }
+            __syncthreads();
+            if (tid < BC_NB) {
+                const int a = tid;
+                for (int l = 0; l < BC_NB; ++l) ts[a * BC_NB + l] = 0.0;
+                for (int l = 0; l < kb; ++l) {
+                    const double tau = hc[jb + l];
+                    double tv = 0.0;
+                    if (a == l) tv = tau;
+                    else if (a < l) {
+                        double acc = 0.0;
+                        for (int b2 = a; b2 < l; ++b2) acc = fma(ts[a * BC_NB + b2], gs[b2 * BC_NB + l], acc);
+                        tv = -tau * acc;
+                    }
+                    ts[a * BC_NB + l] = tv;        // row a only depends on row a
+                }
+            }
+            __syncthreads();
+            // E. W(jb:, c) <- (I - V Ts^T V^T) W(jb:, c) for the columns c to the right
+            {
+                const int CWt = ((nt + 63) / 64) * 64;
+                int RGt = BC_THREADS / CWt; if (RGt > BC_RGT) RGt = BC_RGT;
+                const bool ont = tid < CWt * RGt;
+                const int ct = ont ? tid % CWt : 0, rgt = ont ? tid / CWt : 0;
+                const bool colok = ont && ct < nt;
+                double* wcol = W + (int64_t)jb * n + jb + kb + ct;        // wcol[i * n] = W(jb + i, jb + kb + ct)
+                double w[BC_NB];
 #pragma unroll
-                    for (int u = 0; u < U; ++u) { const int ii = i + u * RG; wv[u] = ii < m ? wc[(int64_t)ii * n] : 0.0; }
+                for (int l = 0; l < BC_NB; ++l) w[l] = 0.0;
+                if (colok) {
+                    constexpr int U = 8;
+                    for (int i = rgt; i < mr; i += U * RGt) {
+                        double xv[U];
 #pragma unroll
-                    for (int u = 0; u < U; ++u) {
-                        const int ii = i + u * RG;
-                        if (ii < m) {
-                            const double w0 = fma(ngam, xc[ii], wv[u]);
-                            wc[(int64_t)ii * n] = w0;
-                            if (ii == k + 1) akv[c] = w0; else dp = fma(xn[ii], w0, dp);
+                        for (int u = 0; u < U; ++u) { const int ii = i + u * RGt; xv[u] = ii < mr ? wcol[(int64_t)ii * n] : 0.0; }
+#pragma unroll
+                        for (int u = 0; u < U; ++u) {
+                            const int ii = i + u * RGt;
+                            if (ii < mr) {
+#pragma unroll
+                                for (int l = 0; l < BC_NB; ++l) w[l] = fma(sp[ii * BC_NB + l], xv[u], w[l]);
+                            }
+                        }
+                    }
+                }
+                if (ont) {
+#pragma unroll
+                    for (int l = 0; l < BC_NB; ++l) wpart[(rgt * BC_NB + l) * CWt + ct] = w[l];
+                }
+                __syncthreads();
+                if (colok) {
+                    double wt[BC_NB], u2[BC_NB];
+#pragma unroll
+                    for (int l = 0; l < BC_NB; ++l) {
+                        double acc = 0.0;
+                        for (int g = 0; g < RGt; ++g) acc += wpart[(g * BC_NB + l) * CWt + ct];
+                        wt[l] = acc;
+                    }
+#pragma unroll
+                    for (int a = 0; a < BC_NB; ++a) {          // u = Ts^T w
+                        double acc = 0.0;
+#pragma unroll
+                        for (int b2 = 0; b2 < BC_NB; ++b2) if (b2 <= a) acc = fma(ts[b2 * BC_NB + a], wt[b2], acc);
+                        u2[a] = acc;
+                    }
+                    constexpr int U = 8;
+                    for (int i = rgt; i < mr; i += U * RGt) {
+                        double xv[U];
+#pragma unroll
+                        for (int u = 0; u < U; ++u) { const int ii = i + u * RGt; xv[u] = ii < mr ? wcol[(int64_t)ii * n] : 0.0; }
+#pragma unroll
+                        for (int u = 0; u < U; ++u) {
+                            const int ii = i + u * RGt;
+                            if (ii < mr) {
+                                double v = xv[u];
+#pragma unroll
+                                for (int l = 0; l < BC_NB; ++l) v = fma(-sp[ii * BC_NB + l], u2[l], v);
+                                wcol[(int64_t)ii * n] = v;
+                            }
                         }
                     }
                 }
             }
-            if (on && cs == 0) for (int i = k + 2 + rg; i < m; i += RG) tp = fma(xn[i], xn[i], tp);
-            if (on) dpart[rg * CW + cs] = dp;
-            if (on && cs == 0) tq[rg] = tp;
             __syncthreads();
-            BB_TICK(1);
         }
         __syncthreads();
 
@@ -451,8 +530,8 @@ bb_chain2_kernel(const BBPanel* __restrict__ panels, int num_panels, const int32
 
 size_t bb_chain2_smem(int max_act_rows, int max_ncols, int* t_in_lds)
 {
-    const size_t fixed = (size_t)(BC_CW + BC_THREADS + BC_CW + 16) * sizeof(double);
-    const size_t qr = (size_t)2 * max_act_rows * sizeof(double);
+    const size_t fixed = (size_t)(BC_CW + BC_THREADS + 2 * BC_NB * BC_NB + 8) * sizeof(double);
+    const size_t qr = ((size_t)max_act_rows * BC_NB + (size_t)BC_RGT * BC_NB * BC_CW) * sizeof(double);
     const size_t gram = (size_t)BC_RC * max_ncols * sizeof(double);
     const size_t tpk = ((size_t)max_ncols * (max_ncols + 1) / 2 + max_ncols) * sizeof(double);
     size_t uni = qr > gram ? qr : gram;
