@@ -77,6 +77,10 @@ struct qrk_dense_plan_s {
     qrk_handle h = nullptr;
     int32_t rows = 0, cols = 0;
     int solver = 0;
+    // multi-workgroup row-slab path (dense_qr_tall.hip): anything but small matrices
+    bool tall = false;
+    void* d_ws = nullptr;
+    int G = 0, cpad = 0, rows_per = 0;
 };
 
 namespace {
@@ -563,18 +567,36 @@ qrk_status qrk_dense_plan_create(qrk_handle h, int32_t rows, int32_t cols, qrk_b
     if (!h || !out || rows <= 0 || cols <= 0)
         return fail(h, QRK_STATUS_INVALID_ARGUMENT, "qrk_dense_plan_create: bad argument");
     *out = nullptr;
-    if (qrk::dense_qr_smem_bytes(rows, cols) > 160 * 1024)
-        return fail(h, QRK_STATUS_UNSUPPORTED,
-                    "qrk_dense_plan_create: matrix too tall for the single-workgroup dense solver (LDS)");
+    QRK_HIP(h, hipSetDevice(h->device));
     qrk_dense_plan_s* p = new (std::nothrow) qrk_dense_plan_s();
     if (!p) return fail(h, QRK_STATUS_ALLOC_FAILED, "qrk_dense_plan_create: out of host memory");
     p->h = h; p->rows = rows; p->cols = cols; p->solver = solver;
+    // The single-workgroup kernel keeps a column in LDS and sweeps with one CU; from 256x256 elements on (and
+    // always when it does not fit) the row-slab path over all CUs is used.  QRK_DENSE_PATH=single|tall overrides.
+    const bool fits = qrk::dense_qr_smem_bytes(rows, cols) <= 150 * 1024;
+    p->tall = !fits || (int64_t)rows * cols >= 65536;
+    if (const char* e = std::getenv("QRK_DENSE_PATH")) {
+        if (!std::strcmp(e, "tall")) p->tall = true;
+        else if (!std::strcmp(e, "single") && fits) p->tall = false;
+    }
+    if (p->tall) {
+        const size_t bytes = qrk::dense_tall_workspace_bytes(rows, cols, h->num_cus, &p->G, &p->cpad, &p->rows_per);
+        if ((size_t)2 * p->rows_per * sizeof(double) > 150 * 1024) {
+            delete p;
+            return fail(h, QRK_STATUS_UNSUPPORTED, "qrk_dense_plan_create: more than ~2.4 M rows are not supported");
+        }
+        if (hipMalloc(&p->d_ws, bytes) != hipSuccess) {
+            delete p;
+            return fail(h, QRK_STATUS_ALLOC_FAILED, "qrk_dense_plan_create: cannot allocate the workspace");
+        }
+    }
     *out = p;
     return QRK_STATUS_OK;
 }
 
 qrk_status qrk_dense_plan_destroy(qrk_dense_plan p)
 {
+    if (p && p->d_ws) (void)hipFree(p->d_ws);
     delete p;
     return QRK_STATUS_OK;
 }
@@ -589,7 +611,11 @@ qrk_status qrk_dense_factorize(qrk_dense_plan p, double* a, int64_t lda, double*
     const int piv = p->solver == QRK_COLPIV_HOUSEHOLDER ? 1 : 0;
     const int size = p->rows < p->cols ? p->rows : p->cols;
     if (space == QRK_MEM_DEVICE) {
-        QRK_HIP(h, qrk::launch_dense_qr(a, lda, p->rows, p->cols, piv, hcoeffs, perm, h->stream));
+        if (p->tall)
+            QRK_HIP(h, qrk::launch_dense_qr_tall(a, lda, p->rows, p->cols, piv, hcoeffs, perm, p->d_ws, p->G, p->cpad, p->rows_per,
+                                                 h->stream));
+        else
+            QRK_HIP(h, qrk::launch_dense_qr(a, lda, p->rows, p->cols, piv, hcoeffs, perm, h->stream));
         return QRK_STATUS_OK;
     }
     Staging s(h);
@@ -598,7 +624,11 @@ qrk_status qrk_dense_factorize(qrk_dense_plan p, double* a, int64_t lda, double*
     qrk_status st;
     if ((st = s.in(a, lda * p->cols, &d_a)) || (st = s.out((int64_t)size, &d_hc)) || (st = s.out((int64_t)p->cols, &d_p)))
         return st;
-    QRK_HIP(h, qrk::launch_dense_qr(d_a, lda, p->rows, p->cols, piv, d_hc, d_p, h->stream));
+    if (p->tall)
+        QRK_HIP(h, qrk::launch_dense_qr_tall(d_a, lda, p->rows, p->cols, piv, d_hc, d_p, p->d_ws, p->G, p->cpad, p->rows_per,
+                                             h->stream));
+    else
+        QRK_HIP(h, qrk::launch_dense_qr(d_a, lda, p->rows, p->cols, piv, d_hc, d_p, h->stream));
     if ((st = s.back(a, d_a, lda * p->cols)) || (st = s.back(hcoeffs, d_hc, (int64_t)size)) ||
         (st = s.back(perm, d_p, (int64_t)p->cols)))
         return st;
@@ -615,7 +645,10 @@ qrk_status qrk_dense_apply_q(qrk_dense_plan p, const double* qr, int64_t lda, co
     QRK_HIP(h, hipSetDevice(h->device));
     const int size = p->rows < p->cols ? p->rows : p->cols;
     if (space == QRK_MEM_DEVICE) {
-        QRK_HIP(h, qrk::launch_dense_apply_q(qr, lda, p->rows, size, hcoeffs, transpose, b, ldb, nrhs, h->stream));
+        if ((size_t)(p->rows + 4) * sizeof(double) > 150 * 1024)
+            QRK_HIP(h, qrk::launch_dense_apply_q_tall(qr, lda, p->rows, size, hcoeffs, transpose, b, ldb, nrhs, h->stream));
+        else
+            QRK_HIP(h, qrk::launch_dense_apply_q(qr, lda, p->rows, size, hcoeffs, transpose, b, ldb, nrhs, h->stream));
         return QRK_STATUS_OK;
     }
     Staging s(h);
@@ -624,7 +657,10 @@ qrk_status qrk_dense_apply_q(qrk_dense_plan p, const double* qr, int64_t lda, co
     if ((st = s.in(qr, lda * p->cols, &d_qr)) || (st = s.in(hcoeffs, (int64_t)size, &d_hc)) ||
         (st = s.in((const double*)b, ldb * nrhs, &d_b)))
         return st;
-    QRK_HIP(h, qrk::launch_dense_apply_q(d_qr, lda, p->rows, size, d_hc, transpose, d_b, ldb, nrhs, h->stream));
+    if ((size_t)(p->rows + 4) * sizeof(double) > 150 * 1024)
+        QRK_HIP(h, qrk::launch_dense_apply_q_tall(d_qr, lda, p->rows, size, d_hc, transpose, d_b, ldb, nrhs, h->stream));
+    else
+        QRK_HIP(h, qrk::launch_dense_apply_q(d_qr, lda, p->rows, size, d_hc, transpose, d_b, ldb, nrhs, h->stream));
     if ((st = s.back(b, d_b, ldb * nrhs))) return st;
     QRK_HIP(h, hipStreamSynchronize(h->stream));
     return QRK_STATUS_OK;

@@ -1,0 +1,410 @@
+// dense_qr_tall.hip -- dense Householder QR with implicit Q for TALL right blocks, on the whole GPU.
+//
+// Same seam as dense_qr.hip: the right-block solver of QRKit::BlockAngularSparseQR (Eigen
+// ColPivHouseholderQR / HouseholderQR, src/QRKit/BlockAngularSparseQR.h:361-369, :488, :498-503),
+// for matrices that do not fit the single-workgroup kernel -- BASELINE configs[3] has a 40000 x 2000
+// bottom block.
+//
+// The rows are cut into slabs, one workgroup per slab; a reflector is applied slab by slab and only
+// per-column scalars cross the slabs.  Per step k the level-2 algorithm is FUSED as in bdqr_col.hip:
+// the dot products of step k give row k of the updated matrix, hence the downdated norms and the next
+// pivot, so one read-modify-write sweep applies update k, swaps the next pivot column into place and
+// accumulates the partial dot products with it.  A step is a short sequence of kernels on the caller's
+// stream (no host synchronisation, no spin barriers):
+//   head   (1 workgroup)  reduce the slab partials, reflector scalars, row k of R, norm downdate,
+//                         next pivot -- or "slow" when Eigen's norm-recompute test fires;
+//   sweep  (all slabs)    update + swap + partial dots with the next reflector (slow: update + partial
+//                         column norms only);
+//   recompute / swap_dots (slow steps only; no-ops otherwise) recomputed norms, pivot, then the dots.
+// Traffic: the trailing matrix is read and written once per step (1.3 TB for 40000 x 2000).
+#include "qrk_device.h"
+
+#include <float.h>
+
+namespace qrk {
+
+namespace tall {
+
+constexpr int TT = 1024;                 // threads per workgroup
+constexpr int TW = TT / 64;
+constexpr double SQRT_EPS = 1.4901161193847656e-08;
+
+struct State {
+    double s, ng, inv_s;     // reflector of the current step: s = x0 - beta, ng = -1/(beta w), 1/s (0 if H = I)
+    int P;                   // column to swap into position k+1 (already swapped in the bookkeeping arrays)
+    int slow;                // the norm-recompute test fired in this step
+};
+
+struct Work {                // device workspace of a plan
+    double* partial;         // [G][cpad] partial dot products with the next reflector
+    double* sqpart;          // [G][cpad] partial squared column norms
+    double* tpart;           // [G] partial |x_tail|^2
+    double* nu2;             // [cpad] m_colNormsUpdated^2
+    double* thr;             // [cpad] sqrt(eps) m_colNormsDirect^2
+    double* ngamv;           // [cpad] -gamma per column for the step being applied
+    int* need;               // [cpad] recompute flags
+    int* pidx;               // [cpad] permutation indices
+    State* st;
+    int G, cpad, rows_per;
+};
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+// Block-wide first maximum of (val, idx): larger val wins, ties -> smaller idx.  red/ired: [TW].
+__device__ __forceinline__ void block_argmax(double& best, int& bi, double* red, int* ired)
+{
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const double ob = __shfl_xor(best, off);
+        const int oi = __shfl_xor(bi, off);
+        if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+    }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = best; ired[threadIdx.x >> 6] = bi; }
+    __syncthreads();
+    best = red[0]; bi = ired[0];
+#pragma unroll
+    for (int w = 1; w < TW; ++w)
+        if (red[w] > best || (red[w] == best && ired[w] < bi)) { best = red[w]; bi = ired[w]; }
+}
+
+// partial squared column norms of every slab
+__global__ void __launch_bounds__(TT)
+norms_kernel(const double* __restrict__ A, int64_t lda, int r, int c, Work w)
+{
+    const int g = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r0 = g * w.rows_per, r1 = min(r, r0 + w.rows_per);
+    for (int jc = wave; jc < c; jc += TW) {
+        double s = 0.0;
+        for (int i = r0 + lane; i < r1; i += 64) { const double v = A[(int64_t)jc * lda + i]; s = fma(v, v, s); }
+        s = wave_sum(s);
+        if (lane == 0) w.sqpart[(int64_t)g * w.cpad + jc] = s;
+    }
+}
+
+// Pivot of position `kpos` among columns kpos..c-1 by the bookkeeping norms, then swap the bookkeeping.
+__device__ __forceinline__ void choose_and_swap(int kpos, int c, int pivoting, Work& w, double* red, int* ired)
+{
+    int P = kpos;
+    if (pivoting) {
+        double best = -1.0; int bi = c;
+        for (int jc = kpos + threadIdx.x; jc < c; jc += TT) { const double v = w.nu2[jc]; if (v > best) { best = v; bi = jc; } }
+        block_argmax(best, bi, red, ired);
+        P = bi < c ? bi : kpos;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        w.st->P = P;
+        if (P != kpos) {
+            double t = w.nu2[kpos]; w.nu2[kpos] = w.nu2[P]; w.nu2[P] = t;
+            t = w.thr[kpos]; w.thr[kpos] = w.thr[P]; w.thr[P] = t;
+            const int tp = w.pidx[kpos]; w.pidx[kpos] = w.pidx[P]; w.pidx[P] = tp;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(TT)
+init_kernel(int c, int pivoting, Work w)
+{
+    __shared__ double red[TW];
+    __shared__ int ired[TW];
+    for (int jc = threadIdx.x; jc < c; jc += TT) {
+        double s = 0.0;
+        for (int g = 0; g < w.G; ++g) s += w.sqpart[(int64_t)g * w.cpad + jc];
+        w.nu2[jc] = s; w.thr[jc] = s * SQRT_EPS; w.pidx[jc] = jc;
+    }
+    if (threadIdx.x == 0) w.st->slow = 0;
+    __syncthreads();
+    choose_and_swap(0, c, pivoting, w, red, ired);
+}
+
+// Swap columns kpos and st->P (all rows of the slab), then partial dots of x = column kpos (rows > kpos)
+// with every column to its right, and the partial |x_tail|^2.  No-op unless `always` or the step was slow.
+__global__ void __launch_bounds__(TT)
+swap_dots_kernel(double* __restrict__ A, int64_t lda, int r, int c, int kpos, int always, Work w)
+{
+    extern __shared__ double xs[];     // [rows_per]
+    if (!always && !w.st->slow) return;
+    const int g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r0 = g * w.rows_per, r1 = min(r, r0 + w.rows_per);
+    const int P = w.st->P;
+    if (P != kpos) {
+        for (int i = r0 + tid; i < r1; i += TT) {
+            const double t = A[(int64_t)kpos * lda + i];
+            A[(int64_t)kpos * lda + i] = A[(int64_t)P * lda + i];
+            A[(int64_t)P * lda + i] = t;
+        }
+    }
+    __syncthreads();
+    for (int i = r0 + tid; i < r1; i += TT) xs[i - r0] = A[(int64_t)kpos * lda + i];
+    __syncthreads();
+    const int i0 = max(r0, kpos + 1);
+    if (wave == 0) {
+        double t = 0.0;
+        for (int i = i0 + lane; i < r1; i += 64) t = fma(xs[i - r0], xs[i - r0], t);
+        t = wave_sum(t);
+        if (lane == 0) w.tpart[g] = t;
+    }
+    for (int jc = kpos + 1 + wave; jc < c; jc += TW) {
+        double d = 0.0;
+        for (int i = i0 + lane; i < r1; i += 64) d = fma(xs[i - r0], A[(int64_t)jc * lda + i], d);
+        d = wave_sum(d);
+        if (lane == 0) w.partial[(int64_t)g * w.cpad + jc] = d;
+    }
+}
+
+// Head of step k: reflector scalars, row k of R, norm downdate, next pivot (or slow).
+__global__ void __launch_bounds__(TT)
+head_kernel(double* __restrict__ A, int64_t lda, int r, int c, int k, int pivoting, double* __restrict__ hcoeffs,
+            int32_t* __restrict__ perm, Work w)
+{
+    __shared__ double red[TW];
+    __shared__ int ired[TW];
+    __shared__ int anyneed;
+    const int tid = threadIdx.x;
+    if (tid == 0) anyneed = 0;
+    double tsq = 0.0;
+    for (int g = 0; g < w.G; ++g) tsq += w.tpart[g];
+    const double xk = A[(int64_t)k * lda + k];
+    // makeHouseholder, un-normalised form of bdqr_pair.hip: nb = -beta, s = x0 - beta, ng = -1/(beta w)
+    double nb, s, ng, tau;
+    const bool degen = !(tsq > DBL_MIN);
+    if (degen) { nb = -xk; s = 0.0; ng = 0.0; tau = 0.0; }
+    else {
+        const double nrm = sqrt(fma(xk, xk, tsq));
+        nb = xk >= 0.0 ? nrm : -nrm;
+        s = nb + xk;
+        ng = -1.0 / (nb * s);
+        tau = -(s * s) * ng;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        w.st->s = s; w.st->ng = ng; w.st->inv_s = degen ? 0.0 : 1.0 / s;
+        A[(int64_t)k * lda + k] = -nb;            // beta (= x0 when H = I)
+        hcoeffs[k] = tau;
+    }
+    const int size = r < c ? r : c;
+    for (int jc = k + 1 + tid; jc < c; jc += TT) {
+        double d = 0.0;
+        for (int g = 0; g < w.G; ++g) d += w.partial[(int64_t)g * w.cpad + jc];
+        const double ak = A[(int64_t)jc * lda + k];
+        const double ngam = fma(s, ak, d) * ng;
+        const double an = fma(s, ngam, ak);
+        w.ngamv[jc] = ngam;
+        A[(int64_t)jc * lda + k] = an;            // row k of R
+        int nd = 0;
+        if (pivoting) {
+            // LAWN-176 downdate in squared form (see bdqr_pair.hip); no clamp: a negative value is recomputed
+            const double nn = fma(-an, an, w.nu2[jc]);
+            w.nu2[jc] = nn;
+            nd = nn <= w.thr[jc];
+            if (nd) anyneed = 1;
+        }
+        w.need[jc] = nd;
+    }
+    __syncthreads();
+    if (k + 1 >= size) {
+        if (tid == 0) { w.st->slow = 0; w.st->P = k + 1; }
+        for (int jc = tid; jc < c; jc += TT) perm[jc] = w.pidx[jc];     // colsPermutation().indices()
+        return;
+    }
+    if (anyneed) { if (tid == 0) w.st->slow = 1; return; }
+    if (tid == 0) w.st->slow = 0;
+    choose_and_swap(k + 1, c, pivoting, w, red, ired);
+}
+
+// Sweep of step k over every slab.
+__global__ void __launch_bounds__(TT)
+sweep_kernel(double* __restrict__ A, int64_t lda, int r, int c, int k, Work w)
+{
+    extern __shared__ double sm[];
+    double* xs = sm;                    // [rows_per] x = column k
+    double* xp = sm + w.rows_per;       // [rows_per] x' = next reflector column
+    const int g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r0 = g * w.rows_per, r1 = min(r, r0 + w.rows_per);
+    const double inv_s = w.st->inv_s;
+    const int slow = w.st->slow;
+    const int P = w.st->P;
+    const int size = r < c ? r : c;
+    const bool last = k + 1 >= size;
+    for (int i = r0 + tid; i < r1; i += TT) {
+        const double v = A[(int64_t)k * lda + i];
+        xs[i - r0] = v;
+        if (i > k) A[(int64_t)k * lda + i] = v * inv_s;      // essential part x_tail / (x0 - beta), 0 if H = I
+    }
+    __syncthreads();
+    const int iu = max(r0, k + 1);           // first row the update touches
+    if (slow || last) {
+        // update only (+ partial squared norms for the recompute)
+        for (int jc = k + 1 + wave; jc < c; jc += TW) {
+            const double ngam = w.ngamv[jc];
+            double s2 = 0.0;
+            for (int i = iu + lane; i < r1; i += 64) {
+                const double a = fma(ngam, xs[i - r0], A[(int64_t)jc * lda + i]);
+                A[(int64_t)jc * lda + i] = a;
+                s2 = fma(a, a, s2);
+            }
+            s2 = wave_sum(s2);
+            if (lane == 0) w.sqpart[(int64_t)g * w.cpad + jc] = s2;
+        }
+        return;
+    }
+    // fused: the next pivot column P goes to position k+1, everything is updated, dots with x' accumulate
+    const int id = max(r0, k + 2);           // first row of the next reflector's tail
+    {
+        const double ngP = w.ngamv[P], ngK = w.ngamv[k + 1];
+        for (int i = r0 + tid; i < r1; i += TT) {
+            const double a2 = A[(int64_t)P * lda + i];
+            if (i > k) {
+                const double x = xs[i - r0];
+                const double v = fma(ngP, x, a2);
+                xp[i - r0] = v;
+                if (P != k + 1) {
+                    const double a1 = A[(int64_t)(k + 1) * lda + i];
+                    A[(int64_t)P * lda + i] = fma(ngK, x, a1);
+                }
+                A[(int64_t)(k + 1) * lda + i] = v;
+            } else if (P != k + 1) {           // rows of R: plain swap
+                const double a1 = A[(int64_t)(k + 1) * lda + i];
+                A[(int64_t)(k + 1) * lda + i] = a2;
+                A[(int64_t)P * lda + i] = a1;
+            }
+        }
+    }
+    __syncthreads();
+    if (wave == 0) {
+        double t = 0.0;
+        for (int i = id + lane; i < r1; i += 64) t = fma(xp[i - r0], xp[i - r0], t);
+        t = wave_sum(t);
+        if (lane == 0) w.tpart[g] = t;
+    }
+    for (int jc = k + 2 + wave; jc < c; jc += TW) {
+        double d = 0.0;
+        if (jc == P) {
+            // already updated above (it holds the old column k+1): dots only
+            for (int i = id + lane; i < r1; i += 64) d = fma(xp[i - r0], A[(int64_t)jc * lda + i], d);
+        } else {
+            const double ngam = w.ngamv[jc];
+            for (int i = iu + lane; i < r1; i += 64) {
+                const double a = fma(ngam, xs[i - r0], A[(int64_t)jc * lda + i]);
+                A[(int64_t)jc * lda + i] = a;
+                if (i >= id) d = fma(xp[i - r0], a, d);
+            }
+        }
+        d = wave_sum(d);
+        if (lane == 0) w.partial[(int64_t)g * w.cpad + jc] = d;
+    }
+}
+
+// Slow steps only: recomputed norms for the flagged columns, then the pivot of position k+1.
+__global__ void __launch_bounds__(TT)
+recompute_kernel(int c, int k, int pivoting, Work w)
+{
+    __shared__ double red[TW];
+    __shared__ int ired[TW];
+    if (!w.st->slow) return;
+    for (int jc = k + 1 + threadIdx.x; jc < c; jc += TT) {
+        if (w.need[jc]) {
+            double s = 0.0;
+            for (int g = 0; g < w.G; ++g) s += w.sqpart[(int64_t)g * w.cpad + jc];
+            w.nu2[jc] = s; w.thr[jc] = s * SQRT_EPS;
+        }
+    }
+    __syncthreads();
+    choose_and_swap(k + 1, c, pivoting, w, red, ired);
+}
+
+// B <- Q^T B or Q B for tall B: the column stays in global memory.
+__global__ void __launch_bounds__(TT)
+apply_q_kernel(const double* __restrict__ QR, int64_t lda, int r, int nrefl, const double* __restrict__ hcoeffs,
+               int transpose, double* __restrict__ B, int64_t ldb, int64_t nrhs)
+{
+    __shared__ double red[TW];
+    const int tid = threadIdx.x;
+    for (int64_t col = blockIdx.x; col < nrhs; col += gridDim.x) {
+        double* b = B + col * ldb;
+        for (int s = 0; s < nrefl; ++s) {
+            const int k = transpose ? s : nrefl - 1 - s;
+            const double tau = hcoeffs[k];
+            const double* v = QR + (int64_t)k * lda;
+            double part = 0.0;
+            for (int i = k + 1 + tid; i < r; i += TT) part = fma(v[i], b[i], part);
+            part = wave_sum(part);
+            __syncthreads();
+            if ((tid & 63) == 0) red[tid >> 6] = part;
+            __syncthreads();
+            double tmp = b[k];
+#pragma unroll
+            for (int wv = 0; wv < TW; ++wv) tmp += red[wv];
+            const double tt = tau * tmp;
+            __syncthreads();
+            if (tid == 0) b[k] -= tt;
+            for (int i = k + 1 + tid; i < r; i += TT) b[i] = fma(-tt, v[i], b[i]);
+            __syncthreads();
+        }
+    }
+}
+
+}  // namespace tall
+
+size_t dense_tall_workspace_bytes(int r, int c, int num_cus, int* G_out, int* cpad_out, int* rows_per_out)
+{
+    int G = (r + 127) / 128;
+    if (G > num_cus) G = num_cus;
+    if (G < 1) G = 1;
+    int rows_per = ((r + G - 1) / G + 63) / 64 * 64;
+    G = (r + rows_per - 1) / rows_per;
+    const int cpad = (c + 63) / 64 * 64;
+    *G_out = G; *cpad_out = cpad; *rows_per_out = rows_per;
+    return (size_t)(2 * (size_t)G * cpad + G + 3 * cpad) * sizeof(double) + (size_t)2 * cpad * sizeof(int) + 256;
+}
+
+hipError_t launch_dense_qr_tall(double* A, int64_t lda, int r, int c, int pivoting, double* hcoeffs, int32_t* perm,
+                                void* workspace, int G, int cpad, int rows_per, hipStream_t stream)
+{
+    using namespace tall;
+    Work w;
+    char* p = static_cast<char*>(workspace);
+    w.partial = reinterpret_cast<double*>(p); p += (size_t)G * cpad * sizeof(double);
+    w.sqpart = reinterpret_cast<double*>(p); p += (size_t)G * cpad * sizeof(double);
+    w.tpart = reinterpret_cast<double*>(p); p += (size_t)G * sizeof(double);
+    w.nu2 = reinterpret_cast<double*>(p); p += (size_t)cpad * sizeof(double);
+    w.thr = reinterpret_cast<double*>(p); p += (size_t)cpad * sizeof(double);
+    w.ngamv = reinterpret_cast<double*>(p); p += (size_t)cpad * sizeof(double);
+    w.need = reinterpret_cast<int*>(p); p += (size_t)cpad * sizeof(int);
+    w.pidx = reinterpret_cast<int*>(p); p += (size_t)cpad * sizeof(int);
+    p = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(p) + 63) & ~(uintptr_t)63);
+    w.st = reinterpret_cast<State*>(p);
+    w.G = G; w.cpad = cpad; w.rows_per = rows_per;
+    const int size = r < c ? r : c;
+    const size_t sm1 = (size_t)rows_per * sizeof(double), sm2 = 2 * sm1;
+    hipLaunchKernelGGL(norms_kernel, dim3(G), dim3(TT), 0, stream, A, lda, r, c, w);
+    hipLaunchKernelGGL(init_kernel, dim3(1), dim3(TT), 0, stream, c, pivoting, w);
+    hipLaunchKernelGGL(swap_dots_kernel, dim3(G), dim3(TT), sm1, stream, A, lda, r, c, 0, 1, w);
+    for (int k = 0; k < size; ++k) {
+        hipLaunchKernelGGL(head_kernel, dim3(1), dim3(TT), 0, stream, A, lda, r, c, k, pivoting, hcoeffs, perm, w);
+        hipLaunchKernelGGL(sweep_kernel, dim3(G), dim3(TT), sm2, stream, A, lda, r, c, k, w);
+        if (pivoting && k + 1 < size) {
+            hipLaunchKernelGGL(recompute_kernel, dim3(1), dim3(TT), 0, stream, c, k, pivoting, w);
+            hipLaunchKernelGGL(swap_dots_kernel, dim3(G), dim3(TT), sm1, stream, A, lda, r, c, k + 1, 0, w);
+        }
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_dense_apply_q_tall(const double* QR, int64_t lda, int r, int nrefl, const double* hcoeffs, int transpose,
+                                     double* B, int64_t ldb, int64_t nrhs, hipStream_t stream)
+{
+    if (nrhs <= 0) return hipSuccess;
+    const unsigned grid = (unsigned)(nrhs < 4096 ? nrhs : 4096);
+    hipLaunchKernelGGL(tall::apply_q_kernel, dim3(grid), dim3(tall::TT), 0, stream, QR, lda, r, nrefl, hcoeffs, transpose, B,
+                       ldb, nrhs);
+    return hipGetLastError();
+}
+
+}  // namespace qrk

@@ -1,0 +1,64 @@
+"""GPU: the dense right-block solver (qrk_dense_*: Eigen ColPivHouseholderQR / HouseholderQR with implicit Q, the
+_BlockQRSolverRight of BlockAngularSparseQR, src/QRKit/BlockAngularSparseQR.h:361-369) against the oracle, on both
+device paths: the single-workgroup kernel (dense_qr.hip) and the row-slab path over all CUs (dense_qr_tall.hip)."""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import rel_fro
+from oracle import oracle as orc
+
+
+def _factor(A, solver, path):
+    import torch
+    import qrkit_amd
+    from qrkit_amd.angular import DenseColPivQR
+    old = os.environ.get("QRK_DENSE_PATH")
+    if path:
+        os.environ["QRK_DENSE_PATH"] = path
+    try:
+        ctx = qrkit_amd.Context(0)
+        qr = DenseColPivQR(ctx, solver)
+        At = torch.from_numpy(np.asfortranarray(A).T.copy()).cuda().t()      # column-major storage on the device
+        qr.compute(At)
+        return qr, At
+    finally:
+        if old is None:
+            os.environ.pop("QRK_DENSE_PATH", None)
+        else:
+            os.environ["QRK_DENSE_PATH"] = old
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows,cols,path", [(64, 20, "single"), (64, 20, "tall"), (300, 300, "tall"), (1000, 37, "single"),
+                                             (1000, 37, "tall"), (5000, 64, "tall"), (30000, 24, None), (40, 60, "tall")])
+@pytest.mark.parametrize("solver", [0, 1])
+def test_dense_qr_matches_oracle(rows, cols, path, solver):
+    rng = np.random.default_rng(rows * 7 + cols)
+    A = rng.uniform(-1.0, 1.0, (rows, cols))
+    if solver == 0 and cols >= 20:
+        A[:, 3] = A[:, 1]                      # an exact tie of column norms and a rank deficiency
+    qr, At = _factor(A, solver, path)
+    got = At.cpu().numpy()
+    k = min(rows, cols)
+    if solver == 0:
+        ref, hc, perm, _ = orc.colpiv_qr(A)
+        np.testing.assert_array_equal(qr.colsPermutation().cpu().numpy(), perm)      # bit-exact
+    else:
+        ref, hc = orc.householder_qr(A)
+        np.testing.assert_array_equal(qr.colsPermutation().cpu().numpy(), np.arange(cols))
+    # R and the reflectors of the numerically non-null part (a duplicated column leaves noise below its pivot)
+    keep = k - (1 if (solver == 0 and cols >= 20) else 0)
+    assert rel_fro(np.triu(got[:k, :])[:keep], np.triu(ref[:k, :])[:keep]) <= 1e-11
+    assert rel_fro(qr._hc.cpu().numpy()[:keep], hc[:keep]) <= 1e-11
+    assert rel_fro(np.tril(got, -1)[:, :keep], np.tril(ref, -1)[:, :keep]) <= 1e-10
+    # Q^T A P = R and Q Q^T b = b through the implicit Q
+    import torch
+    P = qr.colsPermutation().cpu().numpy()
+    B = torch.from_numpy(np.asfortranarray(A[:, P]).T.copy()).cuda().t()
+    qr.applyQ(B, transpose=True)
+    Rfull = np.zeros((rows, cols)); Rfull[:k, :] = np.triu(got[:k, :])
+    assert rel_fro(B.cpu().numpy(), Rfull) <= 1e-11
+    qr.applyQ(B, transpose=False)
+    assert rel_fro(B.cpu().numpy(), A[:, P]) <= 1e-11
