@@ -174,7 +174,8 @@ bb_chain_kernel(const BBPanel* __restrict__ panels, int num_panels, const int32_
 //   * Householder QR with the dot and update sweeps FUSED across steps (no pivoting here, the pivot of
 //     step k+1 is column k+1): the sweep that applies reflector k to column c also accumulates
 //     x'^T c for the next reflector x' = W(:,k+1) - gamma_{k+1} x, two barriers per reflector;
-//   * G = Y^T Y by 4x4 register tiles over LDS-staged row chunks, written into the T output;
+//   * G = Y^T Y on v_mfma_f64_16x16x4_f64 (16x16 tiles, operands from LDS-staged row chunks), written
+//     into the T output;
 //   * T by the forward (larft) recurrence T(0:c,c) = -h_c T(0:c,0:c) G(0:c,c), in place, T kept packed
 //     in LDS when it fits (n <= 192), the negation the reference stores (:477) applied at the end.
 // The first version spent ~16 ms per 448x192 panel (BASELINE configs[2] shape), mostly in wave-wide
@@ -431,49 +432,56 @@ bb_chain2_kernel(const BBPanel* __restrict__ panels, int num_panels, const int32
         __syncthreads();
 
         BB_TICK(2);
-        // ---- G = Y^T Y (strict upper part) into the T output: T[c * n + b] = G(b, c), b < c
+        // ---- G = Y^T Y (strict upper part) into the T output: T[c * n + b] = G(b, c), b < c.
+        // A real GEMM (n x m by m x n): v_mfma_f64_16x16x4_f64 on 16x16 tiles of G, the operands read from an
+        // LDS chunk of 16 rows of Y (unit-lower view of the packed panel); every wave owns up to 9 upper tiles.
+        // Lane maps (cdna_hip_programming.md): A[row = l & 15][k = l >> 4], B[k = l >> 4][col = l & 15],
+        // D[row = (l >> 4) + 4 j][col = l & 15] in result register j.
         double* T = t_vals + p.t_off;
         {
-            const int nbk = (n + 3) / 4;                 // 4x4 tiles, one per thread and pass
-            const int npass = (nbk * nbk + BC_THREADS - 1) / BC_THREADS;
-            for (int q = 0; q < npass; ++q) {
-                const int tile = tid + q * BC_THREADS;
-                const int bi = tile / nbk, bc = tile - bi * nbk;
-                const bool mine = bi < nbk && bi <= bc;
-                double acc[16];
+            typedef double d4 __attribute__((ext_vector_type(4)));
+            const int nbt = (n + 15) / 16, n16 = nbt * 16;
+            const int ntile = nbt * (nbt + 1) / 2;
+            const int wv = tid >> 6, ln = tid & 63;
+            constexpr int MAXQ = 9;                      // 16 * 17 / 2 = 136 tiles over 16 waves
+            d4 acc[MAXQ];
+            int tbi[MAXQ], tbc[MAXQ];
 #pragma unroll
-                for (int z = 0; z < 16; ++z) acc[z] = 0.0;
-                for (int r0 = 0; r0 < m; r0 += BC_RC) {
-                    const int rc = (m - r0) < BC_RC ? (m - r0) : BC_RC;
-                    __syncthreads();
-                    for (int e = tid; e < rc * n; e += BC_THREADS) {
-                        const int i = r0 + e / n, j = e % n;
-                        ys[e] = i < j ? 0.0 : (i == j ? 1.0 : W[(int64_t)i * n + j]);
-                    }
-                    __syncthreads();
-                    if (mine) {
-                        for (int rr = 0; rr < rc; ++rr) {
-                            double a[4], b[4];
+            for (int q = 0; q < MAXQ; ++q) {
+                acc[q] = d4{0.0, 0.0, 0.0, 0.0};
+                int t = wv + q * (BC_THREADS / 64), bi = 0;
+                if (t >= ntile) { tbi[q] = -1; tbc[q] = 0; continue; }
+                while (t >= nbt - bi) { t -= nbt - bi; ++bi; }   // upper tiles enumerated row by row
+                tbi[q] = bi; tbc[q] = bi + t;
+            }
+            for (int r0 = 0; r0 < m; r0 += BC_RC) {
+                __syncthreads();
+                for (int e = tid; e < BC_RC * n16; e += BC_THREADS) {
+                    const int i = r0 + e / n16, j = e % n16;
+                    ys[e] = (i >= m || j >= n || i < j) ? 0.0 : (i == j ? 1.0 : W[(int64_t)i * n + j]);
+                }
+                __syncthreads();
 #pragma unroll
-                            for (int z = 0; z < 4; ++z) {
-                                a[z] = (4 * bi + z < n) ? ys[rr * n + 4 * bi + z] : 0.0;
-                                b[z] = (4 * bc + z < n) ? ys[rr * n + 4 * bc + z] : 0.0;
-                            }
+                for (int q = 0; q < MAXQ; ++q) {
+                    if (tbi[q] >= 0) {
 #pragma unroll
-                            for (int za = 0; za < 4; ++za)
-#pragma unroll
-                                for (int zb = 0; zb < 4; ++zb) acc[za * 4 + zb] = fma(a[za], b[zb], acc[za * 4 + zb]);
+                        for (int ks = 0; ks < BC_RC / 4; ++ks) {
+                            const int row = 4 * ks + (ln >> 4);
+                            const double av = ys[row * n16 + 16 * tbi[q] + (ln & 15)];
+                            const double bv = ys[row * n16 + 16 * tbc[q] + (ln & 15)];
+                            acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[q], 0, 0, 0);
                         }
                     }
                 }
-                if (mine) {
+            }
 #pragma unroll
-                    for (int za = 0; za < 4; ++za)
+            for (int q = 0; q < MAXQ; ++q) {
+                if (tbi[q] >= 0) {
 #pragma unroll
-                        for (int zb = 0; zb < 4; ++zb) {
-                            const int gi = 4 * bi + za, gc = 4 * bc + zb;
-                            if (gi < gc && gc < n) T[(int64_t)gc * n + gi] = acc[za * 4 + zb];
-                        }
+                    for (int j = 0; j < 4; ++j) {
+                        const int gi = 16 * tbi[q] + (ln >> 4) + 4 * j, gc = 16 * tbc[q] + (ln & 15);
+                        if (gi < gc && gc < n) T[(int64_t)gc * n + gi] = acc[q][j];
+                    }
                 }
             }
         }
@@ -532,11 +540,12 @@ size_t bb_chain2_smem(int max_act_rows, int max_ncols, int* t_in_lds)
 {
     const size_t fixed = (size_t)(BC_CW + BC_THREADS + 2 * BC_NB * BC_NB + 8) * sizeof(double);
     const size_t qr = ((size_t)max_act_rows * BC_NB + (size_t)BC_RGT * BC_NB * BC_CW) * sizeof(double);
-    const size_t gram = (size_t)BC_RC * max_ncols * sizeof(double);
+    const size_t gram = (size_t)BC_RC * ((max_ncols + 15) / 16 * 16) * sizeof(double);
     const size_t tpk = ((size_t)max_ncols * (max_ncols + 1) / 2 + max_ncols) * sizeof(double);
     size_t uni = qr > gram ? qr : gram;
     *t_in_lds = 0;
-    if (fixed + (tpk > uni ? tpk : uni) <= (size_t)160 * 1024) { *t_in_lds = 1; if (tpk > uni) uni = tpk; }
+    // (QRK_BB_T_GLOBAL forces the in-place T recurrence: lets the tests cover it)
+    if (fixed + (tpk > uni ? tpk : uni) <= (size_t)160 * 1024 && !std::getenv("QRK_BB_T_GLOBAL")) { *t_in_lds = 1; if (tpk > uni) uni = tpk; }
     return fixed + uni;
 }
 
