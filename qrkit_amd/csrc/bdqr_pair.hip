@@ -45,6 +45,9 @@
 #ifndef QRK_ABL
 #define QRK_ABL 0
 #endif
+#ifndef QRK_QSTORE_EVERY
+#define QRK_QSTORE_EVERY 8     // 4, 8 or 16
+#endif
 
 // Diagnostic only (tools/stamp_run.py): -DQRK_STAMP records s_memtime of lane 0 at phase boundaries
 // of every pair into the hcoeffs buffer (12 x int64 per pair).
@@ -608,7 +611,7 @@ __device__ __forceinline__ void epilogue32(int lane_in, int64_t pi, int64_t num_
 // 128 contiguous bytes = one cache line of its row with eight 16-byte stores issued back to back
 // (they meet again in the L2 line); no LDS staging, the registers are free at once, and the stores
 // are spread over the factorisation instead of arriving as one burst at its end.
-template <int FIRST>
+template <int FIRST, int COUNT = 16>
 __device__ __forceinline__ void store_q_half(int lane_in, int64_t pi, int64_t num_tiles, const double (&q)[WR],
                                              double* __restrict__ q_vals)
 {
@@ -618,7 +621,7 @@ __device__ __forceinline__ void store_q_half(int lane_in, int64_t pi, int64_t nu
     if (t < num_tiles) {
         double2* dst = reinterpret_cast<double2*>(q_vals + t * 1024 + (lane & 31) * 32 + FIRST);
 #pragma unroll
-        for (int m = 0; m < 8; ++m) dst[m] = make_double2(q[FIRST + 2 * m], q[FIRST + 2 * m + 1]);
+        for (int m = 0; m < COUNT / 2; ++m) dst[m] = make_double2(q[FIRST + 2 * m], q[FIRST + 2 * m + 1]);
     }
 }
 }  // namespace pair
@@ -703,11 +706,16 @@ bdqr_pair32_kernel(int64_t num_tiles, const double* __restrict__ tiles, double* 
 
 #define QRK_STEP(K) pair_step<K, true, PIVOT, HC>(a, q, hl, st, hc_tile);
         search_fetch<0, true, PIVOT>(hl, st);     // head of step 0; every step issues the head of the next one
-        QRK_STEP(0) QRK_STEP(1) QRK_STEP(2) QRK_STEP(3) QRK_STEP(4) QRK_STEP(5) QRK_STEP(6) QRK_STEP(7)
+        // q[0..k] are final after step k: every QRK_QSTORE_EVERY steps the finished entries of the lane's
+        // Q row go out (16-byte stores; the pieces of a cache line meet again in L2) and free their registers
+#define QRK_QS(FIRST) store_q_half<FIRST, QRK_QSTORE_EVERY>(threadIdx.x, pi, num_tiles, q, q_vals);
+#define QRK_QS4(FIRST) if (QRK_QSTORE_EVERY == 4) QRK_QS(FIRST)
+#define QRK_QS8(FIRST) if (QRK_QSTORE_EVERY == 4) QRK_QS(FIRST + 4) else if (QRK_QSTORE_EVERY == 8) QRK_QS(FIRST)
+        QRK_STEP(0) QRK_STEP(1) QRK_STEP(2) QRK_STEP(3) QRK_QS4(0) QRK_STEP(4) QRK_STEP(5) QRK_STEP(6) QRK_STEP(7) QRK_QS8(0)
         QRK_STAMP_AT(2);
-        QRK_STEP(8) QRK_STEP(9) QRK_STEP(10) QRK_STEP(11) QRK_STEP(12) QRK_STEP(13) QRK_STEP(14) QRK_STEP(15)
+        QRK_STEP(8) QRK_STEP(9) QRK_STEP(10) QRK_STEP(11) QRK_QS4(8) QRK_STEP(12) QRK_STEP(13) QRK_STEP(14) QRK_STEP(15)
         QRK_STAMP_AT(3);
-        store_q_half<0>(threadIdx.x, pi, num_tiles, q, q_vals);
+        if (QRK_QSTORE_EVERY == 16) { QRK_QS(0) } else { QRK_QS8(8) }
         {
             // columns 0..15 of this half-wave's tile of the next round -> a[0..15] (dead by now)
             int ln = threadIdx.x;
@@ -719,12 +727,15 @@ bdqr_pair32_kernel(int64_t num_tiles, const double* __restrict__ tiles, double* 
                 for (int m = 0; m < 16; ++m) a[m] = nsrc[32 * m];
             }
         }
-        QRK_STEP(16) QRK_STEP(17) QRK_STEP(18) QRK_STEP(19) QRK_STEP(20) QRK_STEP(21) QRK_STEP(22) QRK_STEP(23)
+        QRK_STEP(16) QRK_STEP(17) QRK_STEP(18) QRK_STEP(19) QRK_QS4(16) QRK_STEP(20) QRK_STEP(21) QRK_STEP(22) QRK_STEP(23) QRK_QS8(16)
         QRK_STAMP_AT(4);
-        QRK_STEP(24) QRK_STEP(25) QRK_STEP(26) QRK_STEP(27) QRK_STEP(28) QRK_STEP(29) QRK_STEP(30) QRK_STEP(31)
+        QRK_STEP(24) QRK_STEP(25) QRK_STEP(26) QRK_STEP(27) QRK_QS4(24) QRK_STEP(28) QRK_STEP(29) QRK_STEP(30) QRK_STEP(31)
 #undef QRK_STEP
         QRK_STAMP_AT(5);
-        store_q_half<16>(threadIdx.x, pi, num_tiles, q, q_vals);
+        if (QRK_QSTORE_EVERY == 16) { QRK_QS(16) } else { QRK_QS8(24) }
+#undef QRK_QS
+#undef QRK_QS4
+#undef QRK_QS8
         {
             // columns 16..31 of the next tile -> a[16..31]
             int ln = threadIdx.x;
