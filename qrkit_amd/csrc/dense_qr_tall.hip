@@ -283,21 +283,36 @@ sweep_kernel(double* __restrict__ A, int64_t lda, int r, int c, int k, Work w)
         t = wave_sum(t);
         if (lane == 0) w.tpart[g] = t;
     }
-    for (int jc = k + 2 + wave; jc < c; jc += TW) {
-        double d = 0.0;
-        if (jc == P) {
-            // already updated above (it holds the old column k+1): dots only
-            for (int i = id + lane; i < r1; i += 64) d = fma(xp[i - r0], A[(int64_t)jc * lda + i], d);
-        } else {
-            const double ngam = w.ngamv[jc];
-            for (int i = iu + lane; i < r1; i += 64) {
-                const double a = fma(ngam, xs[i - r0], A[(int64_t)jc * lda + i]);
-                A[(int64_t)jc * lda + i] = a;
-                if (i >= id) d = fma(xp[i - r0], a, d);
+    // CB columns per wave pass: their loads are independent, so CB row-chunks are in flight per lane (one
+    // column at a time the wave waits a full memory round trip per 64 rows)
+    constexpr int CB = 4;
+    for (int j0 = k + 2 + wave * CB; j0 < c; j0 += TW * CB) {
+        double d[CB], ngam[CB];
+        bool upd[CB];
+#pragma unroll
+        for (int u = 0; u < CB; ++u) {
+            const int jc = j0 + u;
+            d[u] = 0.0;
+            upd[u] = jc < c && jc != P;          // column P already holds the updated old column k+1: dots only
+            ngam[u] = upd[u] ? w.ngamv[jc] : 0.0;
+        }
+        for (int i = iu + lane; i < r1; i += 64) {
+            double av[CB];
+#pragma unroll
+            for (int u = 0; u < CB; ++u) av[u] = (j0 + u < c) ? A[(int64_t)(j0 + u) * lda + i] : 0.0;
+            const double x = xs[i - r0], x2 = i >= id ? xp[i - r0] : 0.0;
+#pragma unroll
+            for (int u = 0; u < CB; ++u) {
+                const double a = fma(ngam[u], x, av[u]);
+                if (upd[u]) A[(int64_t)(j0 + u) * lda + i] = a;
+                d[u] = fma(x2, a, d[u]);
             }
         }
-        d = wave_sum(d);
-        if (lane == 0) w.partial[(int64_t)g * w.cpad + jc] = d;
+#pragma unroll
+        for (int u = 0; u < CB; ++u) {
+            const double dd = wave_sum(d[u]);
+            if (lane == 0 && j0 + u < c) w.partial[(int64_t)g * w.cpad + j0 + u] = dd;
+        }
     }
 }
 
