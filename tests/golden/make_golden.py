@@ -71,5 +71,40 @@ def main():
     make_case("u11_30x20_colpiv", 4, 30, 20, orc.gen_uniform(7, -1.0, 1.0, 4 * 600))
 
 
+def make_compositions():
+    """Mid-size tiles (bdqr_col.hip), the dense right-block solver and the two compositions: inputs from the
+    reference's generators / seeded uniforms, expected outputs from the oracle."""
+    import scipy.sparse as sp
+    sys.path.insert(0, os.path.dirname(HERE))
+    from test_banded import banded_matrix
+    from test_angular import angular_problem
+    make_case("u11_64x64_colpiv", 2, 64, 64, orc.gen_uniform(8, -1.0, 1.0, 2 * 4096))
+    make_case("u11_100x37_colpiv", 2, 100, 37, orc.gen_uniform(9, -1.0, 1.0, 2 * 3700))
+    # dense ColPivHouseholderQR with implicit Q (the right-block solver)
+    A = orc.gen_uniform(10, -1.0, 1.0, 300 * 40).reshape(40, 300).T.copy()
+    qr, hc, perm, _ = orc.colpiv_qr(A)
+    Qs, Rs, Ps = sl.qr(A, pivoting=True)
+    assert np.array_equal(Ps, perm) and np.abs(np.triu(qr[:40]) - Rs[:40]).max() <= 1e-12 * np.abs(Rs).max()
+    np.savez_compressed(os.path.join(HERE, "dense_300x40_colpiv.npz"), kind="dense", A=A, packed=qr, hcoeffs=hc, perm=perm)
+    print("dense_300x40_colpiv ok")
+    # banded: the reference's overlapping input (test-qrkit.cpp:62-128) at 32 variables, SuggestedBlockCols = 8
+    J = banded_matrix(32, True, None)
+    res = orc.bb_factorize(J, 8)
+    R = sp.csc_matrix(res.R); R.sort_indices()
+    np.savez_compressed(os.path.join(HERE, "banded_overlap_32.npz"), kind="banded", indptr=J.indptr, indices=J.indices,
+                        data=J.data, shape=np.array(J.shape), suggested=8, blocks=np.array(res.blocks, dtype=np.int32),
+                        row_perm=res.row_perm, r_indptr=R.indptr, r_indices=R.indices, r_data=R.data)
+    print("banded_overlap_32 ok:", len(res.blocks), "blocks")
+    # angular: 64 tiles of 7x2 + 24 dense columns
+    prob, tiles, J1, J2 = angular_problem(64, 24)
+    ref = orc.ba_factorize(prob, J2)
+    R = sp.csc_matrix(ref.R); R.sort_indices()
+    np.savez_compressed(os.path.join(HERE, "angular_64x7x2_24.npz"), kind="angular", rows=prob.rows, cols=prob.cols,
+                        tiles=tiles, J2=J2, perm=ref.perm, rank=ref.rank, r_indptr=R.indptr, r_indices=R.indices,
+                        r_data=R.data)
+    print("angular_64x7x2_24 ok")
+
+
 if __name__ == "__main__":
     main()
+    make_compositions()
