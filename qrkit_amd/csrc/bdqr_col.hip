@@ -30,6 +30,10 @@
 
 #include <float.h>
 
+#ifndef QRK_COL_BLOCKED
+#define QRK_COL_BLOCKED 1      // tiles in global memory: panel-blocked phase 1 (0 = fused level-2 sweeps)
+#endif
+
 namespace qrk {
 
 namespace col {
@@ -51,6 +55,13 @@ __device__ __forceinline__ bool better(const Cand& a, const Cand& b)   // a beat
     return a.val > b.val || (a.val == b.val && a.pos < b.pos);
 }
 
+__device__ __forceinline__ double wave_sum_d(double v)
+{
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
 __device__ __forceinline__ Cand wave_best(Cand c)
 {
 #pragma unroll
@@ -70,7 +81,7 @@ __device__ __forceinline__ Cand wave_best(Cand c)
 // Everything of one tile.  Called once with W in LDS and once with W in global memory, so that after
 // inlining hipcc knows the address space of every access: through one generic pointer it has to assume
 // that a store to W may alias the LDS vectors and serialises the sweeps on the store latency.
-template <int CT>
+template <int CT, bool BLOCKED>
 __device__ __forceinline__ void factor_tile(double* __restrict__ W, double* smem, int r, int c, int cbase, int pivoting,
                                             const double* __restrict__ src, double* __restrict__ Q,
                                             double* __restrict__ rv, int32_t* __restrict__ perm,
@@ -114,6 +125,151 @@ __device__ __forceinline__ void factor_tile(double* __restrict__ W, double* smem
             nu2 = s; thr = s * SQRT_EPS;
         }
 
+        if (BLOCKED) {
+        // ---- panel-blocked form (LAPACK dlaqps) for tiles whose matrix lives in global memory: inside a panel of
+        // NBP columns the trailing matrix is only READ -- per column one pass F(:, j) = tau A^T v, corrected for
+        // the reflectors of the panel not yet applied -- while the chosen column and row k of R are brought up to
+        // date on demand from V (LDS) and F (registers); the trailing matrix is updated once per panel,
+        // A -= V F^T.  Half the bytes of the fused level-2 sweeps, and mostly reads.
+        constexpr int NBP = NB;
+        double* vp = vs;                      // [rows k0.. x NBP] V of the current panel, row-major
+        double* xv = xv0;                     // [r] x, then v, of the current reflector
+        double* fP = gm;                      // [NBP] F row of the pivot column
+        double* cvec = gm + NBP;              // [NBP] V^T v
+        double* red = tm;                     // [NW] block reduction
+        double F[NBP];
+        for (int k0 = 0; k0 < c; k0 += NBP) {
+            const int kb = (c - k0) < NBP ? (c - k0) : NBP;
+#pragma unroll
+            for (int l = 0; l < NBP; ++l) F[l] = 0.0;
+            for (int j = 0; j < kb; ++j) {
+                const int k = k0 + j;
+                int P = k, ppos = k;
+                if (pivoting) {
+                    Cand cd{live ? nu2 : -1.0, pos, tid, 0.0};
+                    cd = wave_best(cd);
+                    if (lane == 0) { cval[wave] = cd.val; cpos[wave] = cd.pos; ctid[wave] = cd.tidx; }
+                    __syncthreads();
+                    Cand bb{cval[0], cpos[0], ctid[0], 0.0};
+#pragma unroll
+                    for (int w = 1; w < NW; ++w) { Cand o{cval[w], cpos[w], ctid[w], 0.0}; if (better(o, bb)) bb = o; }
+                    P = bb.tidx; ppos = bb.pos;
+                    if (isA) { if (tid == P) pos = k; else if (pos == k) pos = ppos; }
+                }
+                if (tid == P) {
+                    live = false; col_of_pos[k] = tid;
+#pragma unroll
+                    for (int l = 0; l < NBP; ++l) fP[l] = F[l];
+                }
+                __syncthreads();
+                // x = column P brought up to date (rows k..): A(k:, P) - V(k:, 0:j) F(P, 0:j)^T
+                double part = 0.0;
+                for (int i = k + tid; i < r; i += CT) {
+                    double x = W[(int64_t)i * ld + P];
+#pragma unroll
+                    for (int l = 0; l < NBP; ++l) if (l < j) x = fma(-vp[(i - k0) * NBP + l], fP[l], x);
+                    xv[i] = x;
+                    if (i > k) part = fma(x, x, part);
+                }
+                part = wave_sum_d(part);
+                if (lane == 0) red[wave] = part;
+                __syncthreads();
+                double tsq = 0.0;
+#pragma unroll
+                for (int w = 0; w < NW; ++w) tsq += red[w];
+                const double xk = xv[k];
+                double beta, tau, inv_s;
+                if (!(tsq > DBL_MIN)) { beta = xk; tau = 0.0; inv_s = 0.0; }     // makeHouseholder: H = I
+                else {
+                    const double nrm = sqrt(fma(xk, xk, tsq));
+                    beta = xk >= 0.0 ? -nrm : nrm;
+                    inv_s = 1.0 / (xk - beta);
+                    tau = (beta - xk) / beta;
+                }
+                __syncthreads();        // every x has been read (xk, the reduction) before it becomes v
+                for (int i = k0 + tid; i < r; i += CT) {
+                    double v = 0.0;
+                    if (i == k) v = 1.0; else if (i > k) v = xv[i] * inv_s;
+                    vp[(i - k0) * NBP + j] = v;
+                    if (i >= k) { xv[i] = v; W[(int64_t)i * ld + P] = (i == k) ? beta : v; }   // packed QR: beta, essential part
+                }
+                if (tid == 0) { taus[k] = tau; if (hcoeffs) hcoeffs[cbase + k] = tau; }
+                __syncthreads();
+                // c_l = V(:, l)^T v for the earlier reflectors of the panel (one wave per l)
+                for (int l = wave; l < j; l += NW) {
+                    double cp = 0.0;
+                    for (int i = k + lane; i < r; i += 64) cp = fma(vp[(i - k0) * NBP + l], xv[i], cp);
+                    cp = wave_sum_d(cp);
+                    if (lane == 0) cvec[l] = cp;
+                }
+                __syncthreads();
+                if (live) {
+                    // F(t, j) = tau (A(k:, t)^T v - F(t, 0:j) c): read-only pass over this thread's column
+                    double f = 0.0;
+                    {
+                        constexpr int U = 16;
+                        int i = k;
+                        for (; i + U <= r; i += U) {
+                            double wv[U];
+#pragma unroll
+                            for (int u = 0; u < U; ++u) wv[u] = wc[(int64_t)(i + u) * ld];
+#pragma unroll
+                            for (int u = 0; u < U; ++u) f = fma(wv[u], xv[i + u], f);
+                        }
+                        for (; i < r; ++i) f = fma(wc[(int64_t)i * ld], xv[i], f);
+                    }
+#pragma unroll
+                    for (int l = 0; l < NBP; ++l) if (l < j) f = fma(-F[l], cvec[l], f);
+                    f *= tau;
+#pragma unroll
+                    for (int l = 0; l < NBP; ++l) if (l == j) F[l] = f;
+                    // row k of R: A(k, t) - V(k, 0:j+1) F(t, 0:j+1)^T
+                    double an = wc[(int64_t)k * ld];
+#pragma unroll
+                    for (int l = 0; l < NBP; ++l) if (l <= j) an = fma(-vp[(k - k0) * NBP + l], F[l], an);
+                    wc[(int64_t)k * ld] = an;
+                    if (pivoting) {
+                        // LAWN-176 downdate (squared form); Eigen's recompute uses the up-to-date column
+                        const double nn = fma(-an, an, nu2);
+                        nu2 = nn;
+                        if (nn <= thr) {
+                            double s2 = 0.0;
+                            for (int i = k + 1; i < r; ++i) {
+                                double a = wc[(int64_t)i * ld];
+#pragma unroll
+                                for (int l = 0; l < NBP; ++l) if (l <= j) a = fma(-vp[(i - k0) * NBP + l], F[l], a);
+                                s2 = fma(a, a, s2);
+                            }
+                            nu2 = s2; thr = s2 * SQRT_EPS;
+                        }
+                    }
+                }
+            }
+            // trailing update of the live columns: A(k0+kb:, t) -= V(k0+kb:, :) F(t, :)^T
+            if (live) {
+                constexpr int U = 8;
+                int i = k0 + kb;
+                for (; i + U <= r; i += U) {
+                    double wv[U];
+#pragma unroll
+                    for (int u = 0; u < U; ++u) wv[u] = wc[(int64_t)(i + u) * ld];
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+#pragma unroll
+                        for (int l = 0; l < NBP; ++l) wv[u] = fma(-vp[(i + u - k0) * NBP + l], F[l], wv[u]);
+                        wc[(int64_t)(i + u) * ld] = wv[u];
+                    }
+                }
+                for (; i < r; ++i) {
+                    double a = wc[(int64_t)i * ld];
+#pragma unroll
+                    for (int l = 0; l < NBP; ++l) a = fma(-vp[(i - k0) * NBP + l], F[l], a);
+                    wc[(int64_t)i * ld] = a;
+                }
+            }
+            __syncthreads();
+        }
+        } else {
         // ---- head of step 0: pivot, its column to LDS, dot products
         int P;                               // pivot thread of the current step
         {
@@ -281,6 +437,7 @@ __device__ __forceinline__ void factor_tile(double* __restrict__ W, double* smem
         }
         __syncthreads();
 
+        }
         // ---- R (packed upper triangle by columns = CSC value order of m_R) and the permutation splice:
         // row i of R is row i of W; the column at position p is col_of_pos[p].
         for (int p = tid; p < c; p += CT) perm[cbase + p] = cbase + col_of_pos[p];   // m_outputPerm_c.indices() (:519-521)
@@ -412,9 +569,9 @@ bdqr_col_kernel(WaveBatch nb, const double* __restrict__ tiles, double* __restri
             cbase = (int)(t * c);
         }
         if (r * c <= col::W_LDS_DOUBLES)
-            factor_tile<CT>(smem, smem, r, c, cbase, nb.pivoting, tiles + toff, q_vals + qoff, r_vals + roff, perm, hcoeffs);
+            factor_tile<CT, false>(smem, smem, r, c, cbase, nb.pivoting, tiles + toff, q_vals + qoff, r_vals + roff, perm, hcoeffs);
         else
-            factor_tile<CT>(workspace + (int64_t)blockIdx.x * ws_stride, smem, r, c, cbase, nb.pivoting, tiles + toff,
+            factor_tile<CT, QRK_COL_BLOCKED != 0>(workspace + (int64_t)blockIdx.x * ws_stride, smem, r, c, cbase, nb.pivoting, tiles + toff,
                             q_vals + qoff, r_vals + roff, perm, hcoeffs);
     }
 }
