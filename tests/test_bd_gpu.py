@@ -229,3 +229,36 @@ def test_solve_large_tiles(qa, ctx):
     prob, ref = oracle_factorize(rows, cols, tiles)
     b = np.random.default_rng(2).uniform(-1, 1, (B * r, 2))
     assert rel_fro(qr.solve(b), prob.solve(ref, b)) <= 1e-10
+
+
+def test_mixed_8_to_256_properties_and_determinism(qa, ctx):
+    """BASELINE configs[4] shape at 1/100 of its count (1000 square tiles, n ~ U{8..256}): the size-independent
+    properties on every tile -- A P = Q R, Q^T Q = I, valid permutation, non-increasing |R_kk| -- and bitwise
+    identical results when the same batch is factorised again (no atomics, no order dependence)."""
+    rng = np.random.default_rng(2024)
+    B = 1000
+    n = rng.integers(8, 257, B).astype(np.int32)
+    tiles = seeded_tiles(33, -1.0, 1.0, int((n.astype(np.int64) ** 2).sum()))
+    _, qr = run_gpu(qa, ctx, n, n, tiles)
+    assert qr.info() == 0 and qr.rank() == int(n.sum())
+    Qv, Rv, perm = qr.qValues().cpu().numpy().copy(), qr.rValues().cpu().numpy().copy(), qr.colsPermutation().copy()
+    toff = qoff = roff = coff = 0
+    worst_qr = worst_orth = 0.0
+    for i in range(B):
+        c = int(n[i])
+        A = tiles[toff:toff + c * c].reshape(c, c).T
+        Q = Qv[qoff:qoff + c * c].reshape(c, c)
+        li = np.tril_indices(c)
+        R = np.zeros((c, c)); R[li[1], li[0]] = Rv[roff:roff + c * (c + 1) // 2]
+        P = perm[coff:coff + c] - coff
+        assert np.array_equal(np.sort(P), np.arange(c))
+        worst_qr = max(worst_qr, np.linalg.norm(Q @ R - A[:, P]) / np.linalg.norm(A))
+        worst_orth = max(worst_orth, np.linalg.norm(Q.T @ Q - np.eye(c)))
+        d = np.abs(np.diag(R))
+        assert np.all(d[1:] <= d[:-1] * (1 + 1e-12))
+        toff += c * c; qoff += c * c; roff += c * (c + 1) // 2; coff += c
+    assert worst_qr <= 1e-13 and worst_orth <= 1e-12, (worst_qr, worst_orth)
+    _, qr2 = run_gpu(qa, ctx, n, n, tiles)
+    np.testing.assert_array_equal(qr2.colsPermutation(), perm)
+    np.testing.assert_array_equal(qr2.qValues().cpu().numpy(), Qv)
+    np.testing.assert_array_equal(qr2.rValues().cpu().numpy(), Rv)
