@@ -342,7 +342,8 @@ bb_chain2_kernel(const BBPanel* __restrict__ panels, int num_panels, const int32
             // E. W(jb:, c) <- (I - V Ts^T V^T) W(jb:, c) for the columns c to the right
             {
                 const int CWt = ((nt + 63) / 64) * 64;
-                int RGt = BC_THREADS / CWt; if (RGt > BC_RGT) RGt = BC_RGT;
+                int RGt = BC_THREADS / CWt;                       // row groups: as many as threads and the LDS for
+                if (RGt > BC_RGT * BC_CW / CWt) RGt = BC_RGT * BC_CW / CWt;   // the partial sums (wpart) allow
                 const bool ont = tid < CWt * RGt;
                 const int ct = ont ? tid % CWt : 0, rgt = ont ? tid / CWt : 0;
                 const bool colok = ont && ct < nt;
@@ -492,7 +493,12 @@ bb_chain2_kernel(const BBPanel* __restrict__ panels, int num_panels, const int32
         for (int cc = 0; cc < n; ++cc) {
             const double hcc = hc[cc];
             if (t_in_lds) {
-                for (int b = tid; b < cc; b += BC_THREADS) gv[b] = T[(int64_t)cc * n + b];
+                // column cc of G is in gv (loaded during the previous step); fetch column cc + 1 now, park it after
+                // the barriers of this step: its L2 latency overlaps the recurrence
+                if (cc == 0 && tid < 1 && n > 1) gv[0] = T[(int64_t)n];            // G(0, 1)
+                double gnext = 0.0;
+                const bool pf = cc + 1 < n && tid < cc + 1 && cc >= 1;
+                if (pf) gnext = T[(int64_t)(cc + 1) * n + tid];
                 __syncthreads();
                 // thread (a = cs, rg): partial sum over b = a + rg, a + rg + RG, ... < cc of T(a, b) g(b)
                 double part = 0.0;
@@ -505,6 +511,7 @@ bb_chain2_kernel(const BBPanel* __restrict__ panels, int num_panels, const int32
                     tl[(int64_t)cc * (cc + 1) / 2 + cs] = -hcc * sum;
                 }
                 if (tid == 0) tl[(int64_t)cc * (cc + 1) / 2 + cc] = hcc;
+                if (pf) gv[tid] = gnext;
                 __syncthreads();
             } else {
                 double part = 0.0;
