@@ -206,10 +206,12 @@ bb_chain2_kernel(const BBPanel* __restrict__ panels, int num_panels, const int32
     double* tl = uni;                          // [n (n + 1) / 2] packed upper T by columns
     const int tid = threadIdx.x;
 #ifdef QRK_BB_PROF
-    unsigned long long pt[6] = {0, 0, 0, 0, 0, 0}, t0 = 0;
+    unsigned long long pt[6] = {0, 0, 0, 0, 0, 0}, t0 = 0, qt[4] = {0, 0, 0, 0}, q0 = 0;
+#define BB_QTICK(n) do { const unsigned long long t1 = __builtin_amdgcn_s_memtime(); qt[n] += t1 - q0; q0 = t1; } while (0)
 #define BB_TICK(n) do { const unsigned long long t1 = __builtin_amdgcn_s_memtime(); pt[n] += t1 - t0; t0 = t1; } while (0)
 #else
 #define BB_TICK(n) do { } while (0)
+#define BB_QTICK(n) do { } while (0)
 #endif
 
     for (int pi = 0; pi < num_panels; ++pi) {
@@ -219,7 +221,6 @@ bb_chain2_kernel(const BBPanel* __restrict__ panels, int num_panels, const int32
         const int CW = ((n + 63) / 64) * 64, RG = BC_THREADS / CW;
         const bool on = tid < CW * RG;                  // (threads beyond the grid only help with the copies)
         const int cs = on ? tid % CW : CW - 1, rg = on ? tid / CW : 0;
-        double* gv = tl + (int64_t)n * (n + 1) / 2;     // [n] column of G in the T recurrence (only with t_in_lds)
 
 #ifdef QRK_BB_PROF
         t0 = __builtin_amdgcn_s_memtime();
@@ -252,12 +253,16 @@ bb_chain2_kernel(const BBPanel* __restrict__ panels, int num_panels, const int32
             const int kb = (n - jb) < BC_NB ? (n - jb) : BC_NB;
             const int mr = m - jb;                       // rows jb.. of the panel take part
             const int wv_ = tid >> 6, ln = tid & 63;     // wave = column of the sub-panel
+#ifdef QRK_BB_PROF
+            q0 = __builtin_amdgcn_s_memtime();
+#endif
             // A. sub-panel to LDS, row-major with stride BC_NB
             for (int e = tid; e < mr * BC_NB; e += BC_THREADS) {
                 const int i = e / BC_NB, l = e - i * BC_NB;
                 sp[e] = l < kb ? W[(int64_t)(jb + i) * n + jb + l] : 0.0;
             }
             __syncthreads();
+            BB_QTICK(0);
             // B. Householder QR of the sub-panel in LDS (makeHouseholder + applyHouseholderOnTheLeft,
             //    un-normalised form of bdqr_pair.hip)
             for (int j = 0; j < kb; ++j) {
@@ -299,6 +304,7 @@ bb_chain2_kernel(const BBPanel* __restrict__ panels, int num_panels, const int32
                 //  barrier after its scalars; column j is not read again before the barrier below)
             }
             __syncthreads();
+            BB_QTICK(1);
             // C. packed sub-panel back to the panel
             for (int e = tid; e < mr * BC_NB; e += BC_THREADS) {
                 const int i = e / BC_NB, l = e - i * BC_NB;
@@ -339,6 +345,7 @@ bb_chain2_kernel(const BBPanel* __restrict__ panels, int num_panels, const int32
                 }
             }
             __syncthreads();
+            BB_QTICK(2);
             // E. W(jb:, c) <- (I - V Ts^T V^T) W(jb:, c) for the columns c to the right
             {
                 const int CWt = ((nt + 63) / 64) * 64;
@@ -406,6 +413,7 @@ bb_chain2_kernel(const BBPanel* __restrict__ panels, int num_panels, const int32
                 }
             }
             __syncthreads();
+            BB_QTICK(3);
         }
         __syncthreads();
 
@@ -489,31 +497,108 @@ bb_chain2_kernel(const BBPanel* __restrict__ panels, int num_panels, const int32
         __syncthreads();
 
         BB_TICK(3);
-        // ---- T = make_block_householder_triangular_factor(Y, hCoeffs) (:476), forward recurrence, in place
-        for (int cc = 0; cc < n; ++cc) {
-            const double hcc = hc[cc];
-            if (t_in_lds) {
-                // column cc of G is in gv (loaded during the previous step); fetch column cc + 1 now, park it after
-                // the barriers of this step: its L2 latency overlaps the recurrence
-                if (cc == 0 && tid < 1 && n > 1) gv[0] = T[(int64_t)n];            // G(0, 1)
-                double gnext = 0.0;
-                const bool pf = cc + 1 < n && tid < cc + 1 && cc >= 1;
-                if (pf) gnext = T[(int64_t)(cc + 1) * n + tid];
-                __syncthreads();
-                // thread (a = cs, rg): partial sum over b = a + rg, a + rg + RG, ... < cc of T(a, b) g(b)
-                double part = 0.0;
-                if (on && cs < cc) for (int b = cs + rg; b < cc; b += RG) part = fma(tl[(int64_t)b * (b + 1) / 2 + cs], gv[b], part);
-                if (on) dpart[rg * CW + cs] = part;
-                __syncthreads();
-                if (on && rg == 0 && cs < cc) {
+        // ---- T = make_block_householder_triangular_factor(Y, hCoeffs) (:476).
+        // With T in LDS: the recursive form of the same factor.  T = [T11 T12; 0 T22] with
+        // T12 = -T11 (Y1^T Y2) T22, so the BC_THREADS/64 diagonal blocks are built by the column recurrence, one
+        // wave each and without workgroup barriers, and merged pairwise in log2(16) rounds of two triangular
+        // products (every thread a few entries).  The column recurrence over the whole panel spent 2.7 us per
+        // column in barriers and LDS latency (0.5 ms of a 1.9 ms panel).
+        if (t_in_lds) {
+            const int wv = tid >> 6, ln = tid & 63;
+            constexpr int NBLK = BC_THREADS / 64;
+            const int s0 = (n + NBLK - 1) / NBLK;          // <= 16 for n <= 256
+            // packed upper storage, by columns: (a, b), a <= b, at b (b + 1) / 2 + a.  G above the diagonal, tau on it
+            for (int b = wv; b < n; b += NBLK) {
+                const int cb = b * (b + 1) / 2;
+                for (int a = ln; a < b; a += 64) tl[cb + a] = T[(int64_t)b * n + a];
+                if (ln == 0) tl[cb + b] = hc[b];
+            }
+            __syncthreads();
+            {   // diagonal block wv: t(a, c) = -tau_c sum_{b = a}^{c - 1} T(a, b) G(b, c) inside the block
+                const int base = wv * s0, len = (n - base) < s0 ? (n - base) : s0;
+                for (int j = 1; j < len; ++j) {
+                    const int c = base + j, cc2 = c * (c + 1) / 2;
                     double sum = 0.0;
-                    for (int g = 0; g < RG; ++g) sum += dpart[g * CW + cs];
-                    tl[(int64_t)cc * (cc + 1) / 2 + cs] = -hcc * sum;
+                    if (ln < j) {
+                        const int a = base + ln;
+                        int ib = (a * (a + 1)) / 2 + a;          // (a, b = a)
+                        for (int b = a; b < c; ++b) { sum = fma(tl[ib], tl[cc2 + b], sum); ib += b + 1; }
+                    }
+                    const double tc = tl[cc2 + c];
+                    __builtin_amdgcn_wave_barrier();
+                    if (ln < j) tl[cc2 + base + ln] = -tc * sum;
+                    __builtin_amdgcn_wave_barrier();
                 }
-                if (tid == 0) tl[(int64_t)cc * (cc + 1) / 2 + cc] = hcc;
-                if (pf) gv[tid] = gnext;
+            }
+            __syncthreads();
+            constexpr int MAXO = (BC_CW / 2) * (BC_CW / 2) / BC_THREADS;      // entries per thread in the last merge
+            for (int sz = s0; sz < n; sz *= 2) {
+                const int ss = sz * sz, npair = (n + 2 * sz - 1) / (2 * sz), total = npair * ss;
+                double xr[MAXO];
+                // X = G12 T22 (in place of G12): X(i, j) = sum_{k <= j} G12(i, k) T22(k, j)
+#pragma unroll
+                for (int t = 0; t < MAXO; ++t) {
+                    const int o = tid + t * BC_THREADS;
+                    xr[t] = 0.0;
+                    if (o < total) {
+                        const int q = o / ss, rem = o - q * ss, j = rem / sz, i = rem - j * sz;
+                        const int r0 = 2 * q * sz, c0 = r0 + sz, cj = c0 + j;
+                        if (cj < n) {
+                            const int cj2 = cj * (cj + 1) / 2 + c0;
+                            int ia = c0 * (c0 + 1) / 2 + r0 + i;
+                            double acc = 0.0;
+#pragma unroll 4
+                            for (int k = 0; k <= j; ++k) { acc = fma(tl[ia], tl[cj2 + k], acc); ia += c0 + k + 1; }
+                            xr[t] = acc;
+                        }
+                    }
+                }
                 __syncthreads();
-            } else {
+#pragma unroll
+                for (int t = 0; t < MAXO; ++t) {
+                    const int o = tid + t * BC_THREADS;
+                    if (o < total) {
+                        const int q = o / ss, rem = o - q * ss, j = rem / sz, i = rem - j * sz;
+                        const int r0 = 2 * q * sz, cj = r0 + sz + j;
+                        if (cj < n) tl[cj * (cj + 1) / 2 + r0 + i] = xr[t];
+                    }
+                }
+                __syncthreads();
+                // T12 = -T11 X: T12(i, j) = -sum_{k >= i} T11(i, k) X(k, j)
+#pragma unroll
+                for (int t = 0; t < MAXO; ++t) {
+                    const int o = tid + t * BC_THREADS;
+                    xr[t] = 0.0;
+                    if (o < total) {
+                        const int q = o / ss, rem = o - q * ss, j = rem / sz, i = rem - j * sz;
+                        const int r0 = 2 * q * sz, cj = r0 + sz + j;
+                        if (cj < n) {
+                            const int cj2 = cj * (cj + 1) / 2 + r0;
+                            const int ri = r0 + i;
+                            int ia = ri * (ri + 1) / 2 + ri;     // (ri, ri)
+                            double acc = 0.0;
+#pragma unroll 4
+                            for (int k = i; k < sz; ++k) { acc = fma(tl[ia], tl[cj2 + k], acc); ia += r0 + k + 1; }
+                            xr[t] = -acc;
+                        }
+                    }
+                }
+                __syncthreads();
+#pragma unroll
+                for (int t = 0; t < MAXO; ++t) {
+                    const int o = tid + t * BC_THREADS;
+                    if (o < total) {
+                        const int q = o / ss, rem = o - q * ss, j = rem / sz, i = rem - j * sz;
+                        const int r0 = 2 * q * sz, cj = r0 + sz + j;
+                        if (cj < n) tl[cj * (cj + 1) / 2 + r0 + i] = xr[t];
+                    }
+                }
+                __syncthreads();
+            }
+        } else {
+            // in place in global memory, forward recurrence by columns (panels whose packed T does not fit the LDS)
+            for (int cc = 0; cc < n; ++cc) {
+                const double hcc = hc[cc];
                 double part = 0.0;
                 if (on && cs < cc) for (int b = cs + rg; b < cc; b += RG) part = fma(T[(int64_t)b * n + cs], T[(int64_t)cc * n + b], part);
                 if (on) dpart[rg * CW + cs] = part;
@@ -539,6 +624,7 @@ bb_chain2_kernel(const BBPanel* __restrict__ panels, int num_panels, const int32
 #ifdef QRK_BB_PROF
         if (pi == num_panels - 1 && tid == 0) for (int z = 0; z < 5; ++z) T[z] = (double)pt[z];
         if (pi == num_panels - 1 && tid == 0) T[5] = (double)pt[5];
+        if (pi == num_panels - 1 && tid == 0) for (int z = 0; z < 4; ++z) T[6 + z] = (double)qt[z];
 #endif
     }
 }
