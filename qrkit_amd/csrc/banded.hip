@@ -183,35 +183,333 @@ bb_chain_kernel(const BBPanel* __restrict__ panels, int num_panels, const int32_
 constexpr int BC_THREADS = 1024;
 constexpr int BC_CW = 256;                 // most columns of a panel
 constexpr int BC_RC = 16;                  // rows per LDS chunk in the Gram matrix
-constexpr int BC_NB = 8;                   // columns of a sub-panel of the blocked Householder QR
-constexpr int BC_RGT = 4;                  // most row groups in the trailing update (LDS for the partial sums)
+
+// Sum over the 64 lanes, the same value in every lane: four DPP steps inside the rows of 16, then the four row sums
+// through SGPRs.  (A fixed order: results do not depend on timing.)
+__device__ __forceinline__ double bb_wave_sum_dpp(double v)
+{
+    v += dpp_f64<0xB1>(v);    // quad_perm [1,0,3,2]
+    v += dpp_f64<0x4E>(v);    // quad_perm [2,3,0,1]
+    v += dpp_f64<0x141>(v);   // row_half_mirror
+    v += dpp_f64<0x140>(v);   // row_mirror
+    return (readlane_f64(v, 0) + readlane_f64(v, 16)) + (readlane_f64(v, 32) + readlane_f64(v, 48));
+}
+
+typedef double bb_d4 __attribute__((ext_vector_type(4)));
+
+// LDS doubles the blocked QR needs next to the OB-column block: T of the block, then the larger of {two published
+// Householder vectors, partial V^T W of 8 column strips}
+__host__ __device__ constexpr int bb_qr_aux_doubles(int OB) { return OB * OB + 8 * (OB / 16) * 256; }
+
+// Eigen::HouseholderQR of the m x n panel W (row-major, in place, packed; hCoeffs to hc), blocked two ways:
+//  - a block of OB columns lives in registers, one or two columns per wave with the rows over the lanes, and is
+//    factorised one reflector at a time (makeHouseholder + applyHouseholderOnTheLeft in the un-normalised form of
+//    bdqr_pair.hip): the wave that owns column j publishes its tail in LDS, one barrier, every wave updates its own
+//    columns.  No memory traffic but the published vector.
+//  - the block reflector I - V T^T V^T of those OB reflectors is then applied to the columns to the right with
+//    v_mfma_f64_16x16x4_f64: w = V^T W (V from the LDS block, W streamed from global memory), u = T^T w (the result
+//    registers of one MFMA are laid out as the B operand of the next, so w and u never leave the registers),
+//    W -= V u.  W crosses this CU's L2 port twice per OB reflectors; with one reflector, or eight, at a time that
+//    port was the bound (0.55 ms of a 1.6 ms panel).
+// uni: [OB * ld] block (column-major, ld = m | 1), then bb_qr_aux_doubles(OB).
+template <int OB>
+__device__ __forceinline__ void bb_panel_qr(double* __restrict__ W, const int m, const int n, double* hc, double* sc,
+                                            double* uni, const int tid
+#ifdef QRK_BB_PROF
+                                            , unsigned long long* qt
+#endif
+                                            )
+{
+    constexpr int CPW = OB / 16;               // columns of the block per wave
+    constexpr int NR = 256 / OB;               // rows per lane: 512 rows with OB = 32, 1024 with OB = 16
+    constexpr int MT = OB / 16;                // 16-row tiles of reflectors
+    const int wv = tid >> 6, ln = tid & 63;
+    const int ld = m | 1;
+    double* blk = uni;
+    double* tb = blk + (int64_t)OB * ld;       // [OB * OB] T of the block (row-major, upper; G above the diagonal first)
+    double* vcol = tb + OB * OB;               // [2 * ld] published Householder tails
+    double* red = vcol;                        // [8 * MT * 256] partial sums of w (after the factorisation)
+#ifdef QRK_BB_PROF
+    unsigned long long q0 = __builtin_amdgcn_s_memtime();
+#define BB_QTICK(z) do { const unsigned long long t1 = __builtin_amdgcn_s_memtime(); qt[z] += t1 - q0; q0 = t1; } while (0)
+#else
+#define BB_QTICK(z) do { } while (0)
+#endif
+
+    for (int jb = 0; jb < n; jb += OB) {
+        const int ob = (n - jb) < OB ? (n - jb) : OB;
+        const int mr = m - jb;                 // rows jb.. of the panel take part (local row i = panel row jb + i)
+        // 1. block to LDS (coalesced rows of W), then to the registers of the owning waves
+        for (int e = tid; e < mr * OB; e += BC_THREADS) {
+            const int i = e / OB, l = e - i * OB;
+            blk[l * ld + i] = l < ob ? W[(int64_t)(jb + i) * n + jb + l] : 0.0;
+        }
+        __syncthreads();
+        double col[CPW][NR];
+#pragma unroll
+        for (int s = 0; s < CPW; ++s) {
+            const int c = wv + 16 * s;
+#pragma unroll
+            for (int r = 0; r < NR; ++r) { const int i = r * 64 + ln; col[s][r] = (i < mr && c < ob) ? blk[c * ld + i] : 0.0; }
+        }
+        BB_QTICK(0);
+        // 2. the reflectors of the block
+        for (int j = 0; j < ob; ++j) {
+            double* vj = vcol + (j & 1) * ld;
+            double* scj = sc + (j & 1) * 4;
+            if (j >= mr) { if (tid == 0) hc[jb + j] = 0.0; continue; }      // (no rows left: identity)
+            const int rj = j >> 6, lj = j & 63;
+            if (wv == (j & 15)) {
+                const int os = j >> 4;
+                double x[NR];
+#pragma unroll
+                for (int r = 0; r < NR; ++r) x[r] = (CPW > 1 && os == 1) ? col[CPW - 1][r] : col[0][r];
+                double part = 0.0, xsel = 0.0;
+#pragma unroll
+                for (int r = 0; r < NR; ++r) {
+                    const int i = r * 64 + ln;
+                    if (i > j) part = fma(x[r], x[r], part);       // (rows >= mr hold zeros)
+                    if (r == rj) xsel = x[r];
+                }
+                const double tsq = bb_wave_sum_dpp(part);
+                const double xk = readlane_f64(xsel, lj);
+                double nb_, s2, ng, tau;
+                if (!(tsq > DBL_MIN)) { nb_ = -xk; s2 = 0.0; ng = 0.0; tau = 0.0; }
+                else {
+                    const double nrm = sqrt(fma(xk, xk, tsq));
+                    nb_ = xk >= 0.0 ? nrm : -nrm;
+                    s2 = nb_ + xk;                   // x0 - beta
+                    ng = -1.0 / (nb_ * s2);
+                    tau = -(s2 * s2) * ng;           // (beta - x0) / beta
+                }
+                if (ln == 0) { scj[0] = s2; scj[1] = ng; hc[jb + j] = tau; }
+                const double inv_s = s2 != 0.0 ? 1.0 / s2 : 0.0;
+#pragma unroll
+                for (int r = 0; r < NR; ++r) {
+                    const int i = r * 64 + ln;
+                    if (i > j && i < mr) vj[i] = x[r];
+                    x[r] = i > j ? x[r] * inv_s : (i == j ? -nb_ : x[r]);     // essential part (:471-475), beta
+                }
+#pragma unroll
+                for (int r = 0; r < NR; ++r) { if (CPW > 1 && os == 1) col[CPW - 1][r] = x[r]; else col[0][r] = x[r]; }
+            }
+            __syncthreads();
+            const double s2 = scj[0], ng = scj[1];
+            bool any = false;
+#pragma unroll
+            for (int s = 0; s < CPW; ++s) any = any || (wv + 16 * s > j && wv + 16 * s < ob);
+            if (any) {
+                double v[NR];
+#pragma unroll
+                for (int r = 0; r < NR; ++r) { const int i = r * 64 + ln; v[r] = (i > j && i < mr) ? vj[i] : 0.0; }
+#pragma unroll
+                for (int s = 0; s < CPW; ++s) {
+                    const int c = wv + 16 * s;
+                    if (c > j && c < ob) {
+                        double part = 0.0, asel = 0.0;
+#pragma unroll
+                        for (int r = 0; r < NR; ++r) { part = fma(v[r], col[s][r], part); if (r == rj) asel = col[s][r]; }
+                        const double d = bb_wave_sum_dpp(part);
+                        const double ak = readlane_f64(asel, lj);
+                        const double ngam = fma(s2, ak, d) * ng;
+                        const double rjv = fma(s2, ngam, ak);              // row j of R
+#pragma unroll
+                        for (int r = 0; r < NR; ++r) {
+                            const int i = r * 64 + ln;
+                            col[s][r] = i == j ? rjv : fma(ngam, v[r], col[s][r]);   // (v is zero outside j < i < mr)
+                        }
+                    }
+                }
+            }
+        }
+        BB_QTICK(1);
+        // 3. packed block back to LDS and to the panel
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < CPW; ++s) {
+            const int c = wv + 16 * s;
+#pragma unroll
+            for (int r = 0; r < NR; ++r) { const int i = r * 64 + ln; if (i < mr && c < ob) blk[c * ld + i] = col[s][r]; }
+        }
+        __syncthreads();
+        for (int e = tid; e < mr * OB; e += BC_THREADS) {
+            const int i = e / OB, l = e - i * OB;
+            if (l < ob) W[(int64_t)(jb + i) * n + jb + l] = blk[l * ld + i];
+        }
+        const int c_first = jb + OB, nt = n - c_first;     // columns to the right
+        if (nt <= 0) { __syncthreads(); BB_QTICK(2); continue; }
+        __syncthreads();
+        // 4. V = unit-lower view of the block (in place); T of the block, recursive form (as for the panel's T below)
+        for (int e = tid; e < OB * OB; e += BC_THREADS) {
+            const int i = e / OB, l = e - i * OB;
+            if (i < mr) { if (i == l) blk[l * ld + i] = 1.0; else if (i < l) blk[l * ld + i] = 0.0; }
+            tb[e] = i == l ? hc[jb + l] : 0.0;
+        }
+        __syncthreads();
+        {
+            int cnt = 0;
+            for (int b = 1; b < OB; ++b)
+                for (int a = 0; a < b; ++a, ++cnt) {
+                    if ((cnt & 15) != wv) continue;
+                    double part = 0.0;
+                    for (int i = b + ln; i < mr; i += 64) part = fma(blk[a * ld + i], blk[b * ld + i], part);
+                    part = bb_wave_sum_dpp(part);
+                    if (ln == 0) tb[a * OB + b] = part;
+                }
+        }
+        __syncthreads();
+        if (wv < OB / 8) {          // diagonal 8 x 8 blocks by the column recurrence, one wave each
+            const int base = 8 * wv;
+            for (int j = 1; j < 8; ++j) {
+                const int c = base + j;
+                double sum = 0.0;
+                if (ln < j) { const int a = base + ln; for (int b = a; b < c; ++b) sum = fma(tb[a * OB + b], tb[b * OB + c], sum); }
+                const double tc = tb[c * OB + c];
+                __builtin_amdgcn_wave_barrier();
+                if (ln < j) tb[(base + ln) * OB + c] = -tc * sum;
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        __syncthreads();
+        for (int sz = 8; sz < OB; sz *= 2) {       // T12 = -T11 G12 T22, pair by pair
+            const int ss = sz * sz, total = (OB / (2 * sz)) * ss;
+            const int q = tid / ss, rem = tid - q * ss, jj = rem / sz, ii = rem - jj * sz;
+            const int r0 = 2 * q * sz, c0 = r0 + sz;
+            double acc = 0.0;
+            if (tid < total) for (int k = 0; k <= jj; ++k) acc = fma(tb[(r0 + ii) * OB + c0 + k], tb[(c0 + k) * OB + c0 + jj], acc);
+            __syncthreads();
+            if (tid < total) tb[(r0 + ii) * OB + c0 + jj] = acc;
+            __syncthreads();
+            acc = 0.0;
+            if (tid < total) for (int k = ii; k < sz; ++k) acc = fma(tb[(r0 + ii) * OB + r0 + k], tb[(r0 + k) * OB + c0 + jj], acc);
+            __syncthreads();
+            if (tid < total) tb[(r0 + ii) * OB + c0 + jj] = -acc;
+            __syncthreads();
+        }
+        BB_QTICK(2);
+        // 5. W(jb:, c_first:) <- (I - V T^T V^T) W(jb:, c_first:): strips of 16 columns, the rows split over the waves
+        //    that are left
+        {
+            const int S = (nt + 15) >> 4;
+            int P = 16 / S; if (P < 1) P = 1; if (P > 4) P = 4;
+            const bool act = wv < S * P;
+            const int strip = act ? wv % S : 0, part = act ? wv / S : 0;
+            const int colg = c_first + 16 * strip + (ln & 15);
+            const bool cok = act && colg < n;
+            const int kq = ln >> 4, l15 = ln & 15;
+            double* wcol = W + (int64_t)jb * n + colg;                // wcol[i * n] = W(jb + i, colg)
+            bb_d4 acc[MT];
+#pragma unroll
+            for (int t = 0; t < MT; ++t) acc[t] = bb_d4{0.0, 0.0, 0.0, 0.0};
+            if (act) {
+                const int K = (mr + 3) >> 2;
+                const int k0 = part * K / P, k1 = (part + 1) * K / P;
+                constexpr int U = 8;
+                for (int k = k0; k < k1; k += U) {
+                    double bv[U];
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const int row = 4 * (k + u) + kq;
+                        bv[u] = (k + u < k1 && row < mr && cok) ? wcol[(int64_t)row * n] : 0.0;
+                    }
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        if (k + u < k1) {
+                            int row = 4 * (k + u) + kq; if (row > mr - 1) row = mr - 1;
+#pragma unroll
+                            for (int t = 0; t < MT; ++t)
+                                acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(blk[(16 * t + l15) * ld + row], bv[u], acc[t], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+            if (P > 1) {                       // partial sums of the row parts, added in a fixed order
+                for (int pp = 0; pp < P; ++pp) {
+                    if (act && part == pp) {
+#pragma unroll
+                        for (int t = 0; t < MT; ++t)
+#pragma unroll
+                            for (int z = 0; z < 4; ++z) {
+                                const int idx = ((strip * MT + t) * 4 + z) * 64 + ln;
+                                red[idx] = pp == 0 ? acc[t][z] : red[idx] + acc[t][z];
+                            }
+                    }
+                    __syncthreads();
+                }
+                if (act) {
+#pragma unroll
+                    for (int t = 0; t < MT; ++t)
+#pragma unroll
+                        for (int z = 0; z < 4; ++z) acc[t][z] = red[((strip * MT + t) * 4 + z) * 64 + ln];
+                }
+            }
+            if (act) {
+                // u = -T^T w: the result layout D[row = (lane >> 4) + 4 z][col = lane & 15] of tile t is the B operand
+                // [k = lane >> 4][col] of the k-step 4 t + z
+                bb_d4 uu[MT];
+#pragma unroll
+                for (int t = 0; t < MT; ++t) {
+                    uu[t] = bb_d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                    for (int ks = 0; ks < 4 * MT; ++ks)
+                        uu[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(tb[(4 * ks + kq) * OB + 16 * t + l15], acc[ks >> 2][ks & 3], uu[t], 0, 0, 0);
+                    uu[t] = -uu[t];
+                }
+                const int RT = (mr + 15) >> 4;
+                const int t0 = part * RT / P, t1 = (part + 1) * RT / P;
+                constexpr int UT = 2;
+                for (int rt = t0; rt < t1; rt += UT) {
+                    bb_d4 dv[UT];
+#pragma unroll
+                    for (int u = 0; u < UT; ++u)
+#pragma unroll
+                        for (int z = 0; z < 4; ++z) {
+                            const int row = 16 * (rt + u) + kq + 4 * z;
+                            dv[u][z] = (rt + u < t1 && row < mr && cok) ? wcol[(int64_t)row * n] : 0.0;
+                        }
+#pragma unroll
+                    for (int u = 0; u < UT; ++u) {
+                        if (rt + u < t1) {
+                            int arow = 16 * (rt + u) + l15; if (arow > mr - 1) arow = mr - 1;
+#pragma unroll
+                            for (int ks = 0; ks < 4 * MT; ++ks)
+                                dv[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(blk[(4 * ks + kq) * ld + arow], uu[ks >> 2][ks & 3], dv[u], 0, 0, 0);
+#pragma unroll
+                            for (int z = 0; z < 4; ++z) {
+                                const int row = 16 * (rt + u) + kq + 4 * z;
+                                if (row < mr && cok) wcol[(int64_t)row * n] = dv[u][z];
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        BB_QTICK(3);
+    }
+#undef BB_QTICK
+}
 
 __global__ void __launch_bounds__(BC_THREADS)
 bb_chain2_kernel(const BBPanel* __restrict__ panels, int num_panels, const int32_t* __restrict__ prowptr,
                  const int32_t* __restrict__ pcol, const int64_t* __restrict__ pmap, const double* __restrict__ vals,
                  double* __restrict__ W, double* __restrict__ lo, double* __restrict__ y_vals,
                  double* __restrict__ t_vals, double* __restrict__ r_stage, int max_act_rows, int max_ncols,
-                 int t_in_lds)
+                 int t_in_lds, int uni_doubles)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double* hc = smem;                         // [BC_CW] hCoeffs of the panel
-    double* dpart = hc + BC_CW;                // [BC_THREADS] partial sums of the T recurrence
-    double* gs = dpart + BC_THREADS;           // [BC_NB * BC_NB] V^T V of a sub-panel
-    double* ts = gs + BC_NB * BC_NB;           // [BC_NB * BC_NB] T of a sub-panel
-    double* sc = ts + BC_NB * BC_NB;           // [8] scalars of the current reflector
-    double* uni = sc + 8;                      // union: {sub-panel, partial V^T W} / Gram chunk / {packed T, g column}
-    double* sp = uni;                          // [max_act_rows * BC_NB] sub-panel, row-major
-    double* wpart = sp + (int64_t)max_act_rows * BC_NB;   // [BC_RGT * BC_NB * BC_CW] partial V^T W per row group
+    double* sc = hc + BC_CW;                   // [8] scalars of the current reflector (two sets)
+    double* uni = sc + 8;                      // union: blocked QR (bb_panel_qr) / Gram chunk / packed T / partial sums
+    double* dpart = uni;                       // [BC_THREADS] partial sums of the T recurrence in global memory
     double* ys = uni;                          // [BC_RC * n]
     double* tl = uni;                          // [n (n + 1) / 2] packed upper T by columns
     const int tid = threadIdx.x;
 #ifdef QRK_BB_PROF
-    unsigned long long pt[6] = {0, 0, 0, 0, 0, 0}, t0 = 0, qt[4] = {0, 0, 0, 0}, q0 = 0;
-#define BB_QTICK(n) do { const unsigned long long t1 = __builtin_amdgcn_s_memtime(); qt[n] += t1 - q0; q0 = t1; } while (0)
+    unsigned long long pt[6] = {0, 0, 0, 0, 0, 0}, t0 = 0, qt[4] = {0, 0, 0, 0};
 #define BB_TICK(n) do { const unsigned long long t1 = __builtin_amdgcn_s_memtime(); pt[n] += t1 - t0; t0 = t1; } while (0)
 #else
 #define BB_TICK(n) do { } while (0)
-#define BB_QTICK(n) do { } while (0)
 #endif
 
     for (int pi = 0; pi < num_panels; ++pi) {
@@ -244,176 +542,20 @@ bb_chain2_kernel(const BBPanel* __restrict__ panels, int num_panels, const int32
         __syncthreads();
 
         BB_TICK(0);
-        // ---- Eigen::HouseholderQR of the panel, blocked: sub-panels of BC_NB columns are factorised in LDS
-        // (one wave per column, rows over the lanes), then the block reflector I - V T^T V^T of the sub-panel
-        // is applied to the columns to its right in one read-modify-write sweep.  The one-reflector-at-a-time
-        // version moved 0.5-1.4 MB per reflector through this CU's L2 port; this one moves it once per
-        // BC_NB reflectors.
-        for (int jb = 0; jb < n; jb += BC_NB) {
-            const int kb = (n - jb) < BC_NB ? (n - jb) : BC_NB;
-            const int mr = m - jb;                       // rows jb.. of the panel take part
-            const int wv_ = tid >> 6, ln = tid & 63;     // wave = column of the sub-panel
+        // ---- Eigen::HouseholderQR of the panel (:459-470): blocks of 32 columns when the block fits the LDS
+        // next to its T and the partial sums (m <= ~470), else of 16
+        if ((int64_t)32 * (m | 1) + bb_qr_aux_doubles(32) <= (int64_t)uni_doubles) {
 #ifdef QRK_BB_PROF
-            q0 = __builtin_amdgcn_s_memtime();
+            bb_panel_qr<32>(W, m, n, hc, sc, uni, tid, qt);
+#else
+            bb_panel_qr<32>(W, m, n, hc, sc, uni, tid);
 #endif
-            // A. sub-panel to LDS, row-major with stride BC_NB
-            for (int e = tid; e < mr * BC_NB; e += BC_THREADS) {
-                const int i = e / BC_NB, l = e - i * BC_NB;
-                sp[e] = l < kb ? W[(int64_t)(jb + i) * n + jb + l] : 0.0;
-            }
-            __syncthreads();
-            BB_QTICK(0);
-            // B. Householder QR of the sub-panel in LDS (makeHouseholder + applyHouseholderOnTheLeft,
-            //    un-normalised form of bdqr_pair.hip)
-            for (int j = 0; j < kb; ++j) {
-                if (wv_ == j) {
-                    double part = 0.0;
-                    for (int i = j + 1 + ln; i < mr; i += 64) { const double v = sp[i * BC_NB + j]; part = fma(v, v, part); }
-                    const double tsq = bb_wave_sum(part);
-                    const double xk = sp[j * BC_NB + j];
-                    double nb_, s2, ng, tau;
-                    if (!(tsq > DBL_MIN)) { nb_ = -xk; s2 = 0.0; ng = 0.0; tau = 0.0; }
-                    else {
-                        const double nrm = sqrt(fma(xk, xk, tsq));
-                        nb_ = xk >= 0.0 ? nrm : -nrm;
-                        s2 = nb_ + xk;                   // x0 - beta
-                        ng = -1.0 / (nb_ * s2);
-                        tau = -(s2 * s2) * ng;           // (beta - x0) / beta
-                    }
-                    if (ln == 0) { sc[0] = s2; sc[1] = ng; sc[2] = -nb_; hc[jb + j] = tau; }
-                }
-                __syncthreads();
-                const double s2 = sc[0], ng = sc[1], betaj = sc[2];   // (read now: the next step's wave rewrites sc)
-                if (wv_ > j && wv_ < kb) {
-                    const int l = wv_;
-                    double part = 0.0;
-                    for (int i = j + 1 + ln; i < mr; i += 64) part = fma(sp[i * BC_NB + j], sp[i * BC_NB + l], part);
-                    const double d = bb_wave_sum(part);
-                    const double ak = sp[j * BC_NB + l];
-                    const double ngam = fma(s2, ak, d) * ng;
-                    for (int i = j + 1 + ln; i < mr; i += 64) sp[i * BC_NB + l] = fma(ngam, sp[i * BC_NB + j], sp[i * BC_NB + l]);
-                    if (ln == 0) sp[j * BC_NB + l] = fma(s2, ngam, ak);       // row j of R
-                }
-                __syncthreads();
-                if (wv_ == j) {
-                    const double inv_s = s2 != 0.0 ? 1.0 / s2 : 0.0;
-                    for (int i = j + 1 + ln; i < mr; i += 64) sp[i * BC_NB + j] *= inv_s;   // essential part (:471-475)
-                    if (ln == 0) sp[j * BC_NB + j] = betaj;                                 // beta
-                }
-                // (no barrier: the next step reads column j+1 and its wave only touches that column until the
-                //  barrier after its scalars; column j is not read again before the barrier below)
-            }
-            __syncthreads();
-            BB_QTICK(1);
-            // C. packed sub-panel back to the panel
-            for (int e = tid; e < mr * BC_NB; e += BC_THREADS) {
-                const int i = e / BC_NB, l = e - i * BC_NB;
-                if (l < kb) W[(int64_t)(jb + i) * n + jb + l] = sp[e];
-            }
-            const int nt = n - jb - kb;                  // columns to the right
-            if (nt <= 0) { __syncthreads(); continue; }
-            // D. V = unit-lower view of the sub-panel (in place), Ts = larft(V, tau)
-            __syncthreads();
-            for (int e = tid; e < kb * BC_NB; e += BC_THREADS) {
-                const int i = e / BC_NB, l = e - i * BC_NB;
-                if (l < kb) { if (i == l) sp[e] = 1.0; else if (i < l) sp[e] = 0.0; }
-            }
-            __syncthreads();
-            for (int pr = wv_; pr < BC_NB * BC_NB; pr += BC_THREADS / 64) {     // G_s = V^T V, one pair per wave pass
-                const int a = pr / BC_NB, b2 = pr - a * BC_NB;
-                if (a < b2 && b2 < kb) {
-                    double part = 0.0;
-                    for (int i = b2 + ln; i < mr; i += 64) part = fma(sp[i * BC_NB + a], sp[i * BC_NB + b2], part);
-                    part = bb_wave_sum(part);
-                    if (ln == 0) gs[pr] = part;
-                }
-            }
-            __syncthreads();
-            if (tid < BC_NB) {
-                const int a = tid;
-                for (int l = 0; l < BC_NB; ++l) ts[a * BC_NB + l] = 0.0;
-                for (int l = 0; l < kb; ++l) {
-                    const double tau = hc[jb + l];
-                    double tv = 0.0;
-                    if (a == l) tv = tau;
-                    else if (a < l) {
-                        double acc = 0.0;
-                        for (int b2 = a; b2 < l; ++b2) acc = fma(ts[a * BC_NB + b2], gs[b2 * BC_NB + l], acc);
-                        tv = -tau * acc;
-                    }
-                    ts[a * BC_NB + l] = tv;        // row a only depends on row a
-                }
-            }
-            __syncthreads();
-            BB_QTICK(2);
-            // E. W(jb:, c) <- (I - V Ts^T V^T) W(jb:, c) for the columns c to the right
-            {
-                const int CWt = ((nt + 63) / 64) * 64;
-                int RGt = BC_THREADS / CWt;                       // row groups: as many as threads and the LDS for
-                if (RGt > BC_RGT * BC_CW / CWt) RGt = BC_RGT * BC_CW / CWt;   // the partial sums (wpart) allow
-                const bool ont = tid < CWt * RGt;
-                const int ct = ont ? tid % CWt : 0, rgt = ont ? tid / CWt : 0;
-                const bool colok = ont && ct < nt;
-                double* wcol = W + (int64_t)jb * n + jb + kb + ct;        // wcol[i * n] = W(jb + i, jb + kb + ct)
-                double w[BC_NB];
-#pragma unroll
-                for (int l = 0; l < BC_NB; ++l) w[l] = 0.0;
-                if (colok) {
-                    constexpr int U = 8;
-                    for (int i = rgt; i < mr; i += U * RGt) {
-                        double xv[U];
-#pragma unroll
-                        for (int u = 0; u < U; ++u) { const int ii = i + u * RGt; xv[u] = ii < mr ? wcol[(int64_t)ii * n] : 0.0; }
-#pragma unroll
-                        for (int u = 0; u < U; ++u) {
-                            const int ii = i + u * RGt;
-                            if (ii < mr) {
-#pragma unroll
-                                for (int l = 0; l < BC_NB; ++l) w[l] = fma(sp[ii * BC_NB + l], xv[u], w[l]);
-                            }
-                        }
-                    }
-                }
-                if (ont) {
-#pragma unroll
-                    for (int l = 0; l < BC_NB; ++l) wpart[(rgt * BC_NB + l) * CWt + ct] = w[l];
-                }
-                __syncthreads();
-                if (colok) {
-                    double wt[BC_NB], u2[BC_NB];
-#pragma unroll
-                    for (int l = 0; l < BC_NB; ++l) {
-                        double acc = 0.0;
-                        for (int g = 0; g < RGt; ++g) acc += wpart[(g * BC_NB + l) * CWt + ct];
-                        wt[l] = acc;
-                    }
-#pragma unroll
-                    for (int a = 0; a < BC_NB; ++a) {          // u = Ts^T w
-                        double acc = 0.0;
-#pragma unroll
-                        for (int b2 = 0; b2 < BC_NB; ++b2) if (b2 <= a) acc = fma(ts[b2 * BC_NB + a], wt[b2], acc);
-                        u2[a] = acc;
-                    }
-                    constexpr int U = 8;
-                    for (int i = rgt; i < mr; i += U * RGt) {
-                        double xv[U];
-#pragma unroll
-                        for (int u = 0; u < U; ++u) { const int ii = i + u * RGt; xv[u] = ii < mr ? wcol[(int64_t)ii * n] : 0.0; }
-#pragma unroll
-                        for (int u = 0; u < U; ++u) {
-                            const int ii = i + u * RGt;
-                            if (ii < mr) {
-                                double v = xv[u];
-#pragma unroll
-                                for (int l = 0; l < BC_NB; ++l) v = fma(-sp[ii * BC_NB + l], u2[l], v);
-                                wcol[(int64_t)ii * n] = v;
-                            }
-                        }
-                    }
-                }
-            }
-            __syncthreads();
-            BB_QTICK(3);
+        } else {
+#ifdef QRK_BB_PROF
+            bb_panel_qr<16>(W, m, n, hc, sc, uni, tid, qt);
+#else
+            bb_panel_qr<16>(W, m, n, hc, sc, uni, tid);
+#endif
         }
         __syncthreads();
 
@@ -629,17 +771,20 @@ bb_chain2_kernel(const BBPanel* __restrict__ panels, int num_panels, const int32
     }
 }
 
-size_t bb_chain2_smem(int max_act_rows, int max_ncols, int* t_in_lds)
+// LDS of bb_chain2_kernel: all of it (one workgroup per chain), 0 if the 16-column block of the tallest panel does not fit
+size_t bb_chain2_smem(int max_act_rows, int max_ncols, int* t_in_lds, int* uni_doubles)
 {
-    const size_t fixed = (size_t)(BC_CW + BC_THREADS + 2 * BC_NB * BC_NB + 8) * sizeof(double);
-    const size_t qr = ((size_t)max_act_rows * BC_NB + (size_t)BC_RGT * BC_NB * BC_CW) * sizeof(double);
+    const size_t all = (size_t)160 * 1024;
+    const size_t fixed = (size_t)(BC_CW + 8) * sizeof(double);
+    const size_t qr = ((size_t)16 * (max_act_rows | 1) + bb_qr_aux_doubles(16)) * sizeof(double);
     const size_t gram = (size_t)BC_RC * ((max_ncols + 15) / 16 * 16) * sizeof(double);
-    const size_t tpk = ((size_t)max_ncols * (max_ncols + 1) / 2 + max_ncols) * sizeof(double);
-    size_t uni = qr > gram ? qr : gram;
-    *t_in_lds = 0;
+    const size_t tpk = (size_t)max_ncols * (max_ncols + 1) / 2 * sizeof(double);
+    *t_in_lds = 0; *uni_doubles = 0;
+    if (fixed + qr > all || fixed + gram > all || fixed + BC_THREADS * sizeof(double) > all) return 0;
     // (QRK_BB_T_GLOBAL forces the in-place T recurrence: lets the tests cover it)
-    if (fixed + (tpk > uni ? tpk : uni) <= (size_t)160 * 1024 && !std::getenv("QRK_BB_T_GLOBAL")) { *t_in_lds = 1; if (tpk > uni) uni = tpk; }
-    return fixed + uni;
+    if (fixed + tpk <= all && !std::getenv("QRK_BB_T_GLOBAL")) *t_in_lds = 1;
+    *uni_doubles = (int)((all - fixed) / sizeof(double));
+    return all;
 }
 
 __global__ void __launch_bounds__(256)
@@ -703,14 +848,14 @@ hipError_t launch_bb_chain(const BBPanel* panels, int num_panels, const int32_t*
                            double* r_stage, const int64_t* r_src, int64_t nnz_r, double* r_vals, int max_act_rows,
                            int max_ncols, hipStream_t stream)
 {
-    int t_in_lds = 0;
-    const size_t smem2 = bb_chain2_smem(max_act_rows, max_ncols, &t_in_lds);
-    if (max_ncols <= BC_CW && smem2 <= (size_t)160 * 1024 && !std::getenv("QRK_BB_CHAIN_V1")) {
+    int t_in_lds = 0, uni_doubles = 0;
+    const size_t smem2 = bb_chain2_smem(max_act_rows, max_ncols, &t_in_lds, &uni_doubles);
+    if (max_ncols <= BC_CW && smem2 > 0 && !std::getenv("QRK_BB_CHAIN_V1")) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(bb_chain2_kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem2);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(bb_chain2_kernel, dim3(1), dim3(BC_THREADS), smem2, stream, panels, num_panels, prowptr, pcol, pmap,
-                           vals, W, lo, y_vals, t_vals, r_stage, max_act_rows, max_ncols, t_in_lds);
+                           vals, W, lo, y_vals, t_vals, r_stage, max_act_rows, max_ncols, t_in_lds, uni_doubles);
     } else {
         const size_t smem = bb_chain_smem(max_act_rows, max_ncols);
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(bb_chain_kernel),
