@@ -197,6 +197,27 @@ __device__ __forceinline__ double bb_wave_sum_dpp(double v)
 
 typedef double bb_d4 __attribute__((ext_vector_type(4)));
 
+// sqrt and reciprocal without the FP64 division sequences (as in bdqr_pair.hip: v_rsq / v_rcp seeds, <= 1 ulp)
+__device__ __forceinline__ double bb_sqrt_pos(double x)
+{
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = 0.5 * y;
+    const double e = fma(-h, g, 0.5);
+    g = fma(g, e, g);
+    h = fma(h, e, h);
+    const double d = fma(-g, g, x);
+    return fma(d, h, g);
+}
+__device__ __forceinline__ double bb_recip(double x)
+{
+    double y = __builtin_amdgcn_rcp(x);
+    double e = fma(-x, y, 1.0);
+    y = fma(y, e, y);
+    e = fma(-x, y, 1.0);
+    y = fma(y, e, y);
+    return y;
+}
+
 // LDS doubles the blocked QR needs next to the OB-column block: T of the block, then the larger of {two published
 // Householder vectors, partial V^T W of 8 column strips}
 __host__ __device__ constexpr int bb_qr_aux_doubles(int OB) { return OB * OB + 8 * (OB / 16) * 256; }
@@ -213,13 +234,19 @@ __host__ __device__ constexpr int bb_qr_aux_doubles(int OB) { return OB * OB + 8
 //    port was the bound (0.55 ms of a 1.6 ms panel).
 // uni: [OB * ld] block (column-major, ld = m | 1), then bb_qr_aux_doubles(OB).
 template <int OB>
-__device__ __forceinline__ void bb_panel_qr(double* __restrict__ W, const int m, const int n, double* hc, double* sc,
-                                            double* uni, const int tid
+__device__ __attribute__((noinline)) void bb_panel_qr(double* __restrict__ W, const int m, const int n
 #ifdef QRK_BB_PROF
                                             , unsigned long long* qt
 #endif
                                             )
 {
+    // (not inlined: the kernel around it keeps ~100 values live across the panel loop, and the register allocation
+    //  of this function should not pay for them.  The LDS carve-up is the kernel's: hc, sc, uni.)
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double* hc = smem;
+    double* sc = hc + BC_CW;
+    double* uni = sc + 8;
+    const int tid = threadIdx.x;
     constexpr int CPW = OB / 16;               // columns of the block per wave
     constexpr int NR = 256 / OB;               // rows per lane: 512 rows with OB = 32, 1024 with OB = 16
     constexpr int MT = OB / 16;                // 16-row tiles of reflectors
@@ -244,6 +271,7 @@ __device__ __forceinline__ void bb_panel_qr(double* __restrict__ W, const int m,
             const int i = e / OB, l = e - i * OB;
             blk[l * ld + i] = l < ob ? W[(int64_t)(jb + i) * n + jb + l] : 0.0;
         }
+        for (int e = tid; e < OB * OB; e += BC_THREADS) tb[e] = 0.0;
         __syncthreads();
         double col[CPW][NR];
 #pragma unroll
@@ -273,17 +301,17 @@ __device__ __forceinline__ void bb_panel_qr(double* __restrict__ W, const int m,
                 }
                 const double tsq = bb_wave_sum_dpp(part);
                 const double xk = readlane_f64(xsel, lj);
-                double nb_, s2, ng, tau;
-                if (!(tsq > DBL_MIN)) { nb_ = -xk; s2 = 0.0; ng = 0.0; tau = 0.0; }
+                double nb_, s2, ng, tau, inv_s;
+                if (!(tsq > DBL_MIN)) { nb_ = -xk; s2 = 0.0; ng = 0.0; tau = 0.0; inv_s = 0.0; }
                 else {
-                    const double nrm = sqrt(fma(xk, xk, tsq));
+                    const double nrm = bb_sqrt_pos(fma(xk, xk, tsq));
                     nb_ = xk >= 0.0 ? nrm : -nrm;
                     s2 = nb_ + xk;                   // x0 - beta
-                    ng = -1.0 / (nb_ * s2);
+                    inv_s = bb_recip(s2);
+                    ng = -bb_recip(nb_) * inv_s;     // -1 / (beta (beta - x0))
                     tau = -(s2 * s2) * ng;           // (beta - x0) / beta
                 }
-                if (ln == 0) { scj[0] = s2; scj[1] = ng; hc[jb + j] = tau; }
-                const double inv_s = s2 != 0.0 ? 1.0 / s2 : 0.0;
+                if (ln == 0) { scj[0] = s2; scj[1] = ng; scj[2] = inv_s; hc[jb + j] = tau; tb[j * OB + j] = tau; }
 #pragma unroll
                 for (int r = 0; r < NR; ++r) {
                     const int i = r * 64 + ln;
@@ -294,10 +322,10 @@ __device__ __forceinline__ void bb_panel_qr(double* __restrict__ W, const int m,
                 for (int r = 0; r < NR; ++r) { if (CPW > 1 && os == 1) col[CPW - 1][r] = x[r]; else col[0][r] = x[r]; }
             }
             __syncthreads();
-            const double s2 = scj[0], ng = scj[1];
+            const double s2 = scj[0], ng = scj[1], inv_s = scj[2];
             bool any = false;
 #pragma unroll
-            for (int s = 0; s < CPW; ++s) any = any || (wv + 16 * s > j && wv + 16 * s < ob);
+            for (int s = 0; s < CPW; ++s) any = any || (wv + 16 * s != j && wv + 16 * s < ob);
             if (any) {
                 double v[NR];
 #pragma unroll
@@ -318,6 +346,14 @@ __device__ __forceinline__ void bb_panel_qr(double* __restrict__ W, const int m,
                             const int i = r * 64 + ln;
                             col[s][r] = i == j ? rjv : fma(ngam, v[r], col[s][r]);   // (v is zero outside j < i < mr)
                         }
+                    } else if (c < j) {
+                        // a finished column: its entry of G = V^T V for the block's T, (V_c . v_j) with v_j = (1, x / s)
+                        double part = 0.0, asel = 0.0;
+#pragma unroll
+                        for (int r = 0; r < NR; ++r) { part = fma(v[r], col[s][r], part); if (r == rj) asel = col[s][r]; }
+                        const double d = bb_wave_sum_dpp(part);
+                        const double vcj = readlane_f64(asel, lj);
+                        if (ln == 0) tb[c * OB + j] = fma(d, inv_s, vcj);
                     }
                 }
             }
@@ -339,25 +375,12 @@ __device__ __forceinline__ void bb_panel_qr(double* __restrict__ W, const int m,
         const int c_first = jb + OB, nt = n - c_first;     // columns to the right
         if (nt <= 0) { __syncthreads(); BB_QTICK(2); continue; }
         __syncthreads();
-        // 4. V = unit-lower view of the block (in place); T of the block, recursive form (as for the panel's T below)
+        // 4. V = unit-lower view of the block (in place); T of the block from G (gathered during the sweep above) in the
+        //    recursive form (as for the panel's T below)
         for (int e = tid; e < OB * OB; e += BC_THREADS) {
             const int i = e / OB, l = e - i * OB;
             if (i < mr) { if (i == l) blk[l * ld + i] = 1.0; else if (i < l) blk[l * ld + i] = 0.0; }
-            tb[e] = i == l ? hc[jb + l] : 0.0;
         }
-        __syncthreads();
-        {
-            int cnt = 0;
-            for (int b = 1; b < OB; ++b)
-                for (int a = 0; a < b; ++a, ++cnt) {
-                    if ((cnt & 15) != wv) continue;
-                    double part = 0.0;
-                    for (int i = b + ln; i < mr; i += 64) part = fma(blk[a * ld + i], blk[b * ld + i], part);
-                    part = bb_wave_sum_dpp(part);
-                    if (ln == 0) tb[a * OB + b] = part;
-                }
-        }
-        __syncthreads();
         if (wv < OB / 8) {          // diagonal 8 x 8 blocks by the column recurrence, one wave each
             const int base = 8 * wv;
             for (int j = 1; j < 8; ++j) {
@@ -389,12 +412,13 @@ __device__ __forceinline__ void bb_panel_qr(double* __restrict__ W, const int m,
         BB_QTICK(2);
         // 5. W(jb:, c_first:) <- (I - V T^T V^T) W(jb:, c_first:): strips of 16 columns, the rows split over the waves
         //    that are left
-        {
-            const int S = (nt + 15) >> 4;
-            int P = 16 / S; if (P < 1) P = 1; if (P > 4) P = 4;
+        const int S_all = (nt + 15) >> 4;
+        for (int g0 = 0; g0 < S_all; g0 += 8) {            // (at most 8 strips at a time: LDS for their partial sums)
+            const int S = (S_all - g0) < 8 ? (S_all - g0) : 8;
+            int P = 16 / S; if (P > 8) P = 8;
             const bool act = wv < S * P;
             const int strip = act ? wv % S : 0, part = act ? wv / S : 0;
-            const int colg = c_first + 16 * strip + (ln & 15);
+            const int colg = c_first + 16 * (g0 + strip) + (ln & 15);
             const bool cok = act && colg < n;
             const int kq = ln >> 4, l15 = ln & 15;
             double* wcol = W + (int64_t)jb * n + colg;                // wcol[i * n] = W(jb + i, colg)
@@ -404,7 +428,7 @@ __device__ __forceinline__ void bb_panel_qr(double* __restrict__ W, const int m,
             if (act) {
                 const int K = (mr + 3) >> 2;
                 const int k0 = part * K / P, k1 = (part + 1) * K / P;
-                constexpr int U = 8;
+                constexpr int U = 16;               // W loads in flight per wave: the latency of this CU's path to L2
                 for (int k = k0; k < k1; k += U) {
                     double bv[U];
 #pragma unroll
@@ -457,7 +481,7 @@ __device__ __forceinline__ void bb_panel_qr(double* __restrict__ W, const int m,
                 }
                 const int RT = (mr + 15) >> 4;
                 const int t0 = part * RT / P, t1 = (part + 1) * RT / P;
-                constexpr int UT = 2;
+                constexpr int UT = 4;
                 for (int rt = t0; rt < t1; rt += UT) {
                     bb_d4 dv[UT];
 #pragma unroll
@@ -483,8 +507,8 @@ __device__ __forceinline__ void bb_panel_qr(double* __restrict__ W, const int m,
                     }
                 }
             }
+            __syncthreads();
         }
-        __syncthreads();
         BB_QTICK(3);
     }
 #undef BB_QTICK
@@ -546,15 +570,15 @@ bb_chain2_kernel(const BBPanel* __restrict__ panels, int num_panels, const int32
         // next to its T and the partial sums (m <= ~470), else of 16
         if ((int64_t)32 * (m | 1) + bb_qr_aux_doubles(32) <= (int64_t)uni_doubles) {
 #ifdef QRK_BB_PROF
-            bb_panel_qr<32>(W, m, n, hc, sc, uni, tid, qt);
+            bb_panel_qr<32>(W, m, n, qt);
 #else
-            bb_panel_qr<32>(W, m, n, hc, sc, uni, tid);
+            bb_panel_qr<32>(W, m, n);
 #endif
         } else {
 #ifdef QRK_BB_PROF
-            bb_panel_qr<16>(W, m, n, hc, sc, uni, tid, qt);
+            bb_panel_qr<16>(W, m, n, qt);
 #else
-            bb_panel_qr<16>(W, m, n, hc, sc, uni, tid);
+            bb_panel_qr<16>(W, m, n);
 #endif
         }
         __syncthreads();
