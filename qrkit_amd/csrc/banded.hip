@@ -254,7 +254,8 @@ __device__ __attribute__((noinline)) void bb_panel_qr(double* __restrict__ W, co
     const int ld = m | 1;
     double* blk = uni;
     double* tb = blk + (int64_t)OB * ld;       // [OB * OB] T of the block (row-major, upper; G above the diagonal first)
-    double* vcol = tb + OB * OB;               // [2 * ld] published Householder tails
+    constexpr int VL = NR * 64;                // rows a published Householder tail can have
+    double* vcol = tb + OB * OB;               // [2 * VL] published Householder tails (zero beyond the rows of the block)
     double* red = vcol;                        // [8 * MT * 256] partial sums of w (after the factorisation)
 #ifdef QRK_BB_PROF
     unsigned long long q0 = __builtin_amdgcn_s_memtime();
@@ -272,6 +273,7 @@ __device__ __attribute__((noinline)) void bb_panel_qr(double* __restrict__ W, co
             blk[l * ld + i] = l < ob ? W[(int64_t)(jb + i) * n + jb + l] : 0.0;
         }
         for (int e = tid; e < OB * OB; e += BC_THREADS) tb[e] = 0.0;
+        for (int e = tid; e < 2 * VL; e += BC_THREADS) vcol[e] = 0.0;
         __syncthreads();
         double col[CPW][NR];
 #pragma unroll
@@ -281,79 +283,61 @@ __device__ __attribute__((noinline)) void bb_panel_qr(double* __restrict__ W, co
             for (int r = 0; r < NR; ++r) { const int i = r * 64 + ln; col[s][r] = (i < mr && c < ob) ? blk[c * ld + i] : 0.0; }
         }
         BB_QTICK(0);
-        // 2. the reflectors of the block
+        // 2. the reflectors of the block.  Local row j is the pivot row of reflector j: lane j of the first row register.
+        //    Rows beyond mr hold zeros in col[] and in the published vectors, so only that register needs a mask.
         for (int j = 0; j < ob; ++j) {
-            double* vj = vcol + (j & 1) * ld;
+            double* vj = vcol + (j & 1) * VL;
             double* scj = sc + (j & 1) * 4;
             if (j >= mr) { if (tid == 0) hc[jb + j] = 0.0; continue; }      // (no rows left: identity)
-            const int rj = j >> 6, lj = j & 63;
             if (wv == (j & 15)) {
-                const int os = j >> 4;
-                double x[NR];
+                auto head = [&](double (&x)[NR]) {
+                    double part = ln > j ? x[0] * x[0] : 0.0;
 #pragma unroll
-                for (int r = 0; r < NR; ++r) x[r] = (CPW > 1 && os == 1) ? col[CPW - 1][r] : col[0][r];
-                double part = 0.0, xsel = 0.0;
+                    for (int r = 1; r < NR; ++r) part = fma(x[r], x[r], part);
+                    const double tsq = bb_wave_sum_dpp(part);
+                    const double xk = readlane_f64(x[0], j);
+                    double nb_, s2, ng, tau, inv_s;
+                    if (!(tsq > DBL_MIN)) { nb_ = -xk; s2 = 0.0; ng = 0.0; tau = 0.0; inv_s = 0.0; }
+                    else {
+                        const double nrm = bb_sqrt_pos(fma(xk, xk, tsq));
+                        nb_ = xk >= 0.0 ? nrm : -nrm;
+                        s2 = nb_ + xk;                   // x0 - beta
+                        inv_s = bb_recip(s2);
+                        ng = -bb_recip(nb_) * inv_s;     // -1 / (beta (beta - x0))
+                        tau = -(s2 * s2) * ng;           // (beta - x0) / beta
+                    }
+                    if (ln == 0) { scj[0] = s2; scj[1] = ng; hc[jb + j] = tau; tb[j * OB + j] = tau; }
+                    if (ln > j) vj[ln] = x[0];
+                    x[0] = ln > j ? x[0] * inv_s : (ln == j ? -nb_ : x[0]);      // essential part (:471-475), beta
 #pragma unroll
-                for (int r = 0; r < NR; ++r) {
-                    const int i = r * 64 + ln;
-                    if (i > j) part = fma(x[r], x[r], part);       // (rows >= mr hold zeros)
-                    if (r == rj) xsel = x[r];
-                }
-                const double tsq = bb_wave_sum_dpp(part);
-                const double xk = readlane_f64(xsel, lj);
-                double nb_, s2, ng, tau, inv_s;
-                if (!(tsq > DBL_MIN)) { nb_ = -xk; s2 = 0.0; ng = 0.0; tau = 0.0; inv_s = 0.0; }
-                else {
-                    const double nrm = bb_sqrt_pos(fma(xk, xk, tsq));
-                    nb_ = xk >= 0.0 ? nrm : -nrm;
-                    s2 = nb_ + xk;                   // x0 - beta
-                    inv_s = bb_recip(s2);
-                    ng = -bb_recip(nb_) * inv_s;     // -1 / (beta (beta - x0))
-                    tau = -(s2 * s2) * ng;           // (beta - x0) / beta
-                }
-                if (ln == 0) { scj[0] = s2; scj[1] = ng; scj[2] = inv_s; hc[jb + j] = tau; tb[j * OB + j] = tau; }
-#pragma unroll
-                for (int r = 0; r < NR; ++r) {
-                    const int i = r * 64 + ln;
-                    if (i > j && i < mr) vj[i] = x[r];
-                    x[r] = i > j ? x[r] * inv_s : (i == j ? -nb_ : x[r]);     // essential part (:471-475), beta
-                }
-#pragma unroll
-                for (int r = 0; r < NR; ++r) { if (CPW > 1 && os == 1) col[CPW - 1][r] = x[r]; else col[0][r] = x[r]; }
+                    for (int r = 1; r < NR; ++r) { vj[r * 64 + ln] = x[r]; x[r] *= inv_s; }
+                };
+                if (CPW == 1 || (j >> 4) == 0) head(col[0]); else head(col[CPW - 1]);
             }
             __syncthreads();
-            const double s2 = scj[0], ng = scj[1], inv_s = scj[2];
+            const double s2 = scj[0], ng = scj[1];
             bool any = false;
 #pragma unroll
-            for (int s = 0; s < CPW; ++s) any = any || (wv + 16 * s != j && wv + 16 * s < ob);
+            for (int s = 0; s < CPW; ++s) any = any || (wv + 16 * s > j && wv + 16 * s < ob);
             if (any) {
                 double v[NR];
+                v[0] = ln > j ? vj[ln] : 0.0;
 #pragma unroll
-                for (int r = 0; r < NR; ++r) { const int i = r * 64 + ln; v[r] = (i > j && i < mr) ? vj[i] : 0.0; }
+                for (int r = 1; r < NR; ++r) v[r] = vj[r * 64 + ln];
 #pragma unroll
                 for (int s = 0; s < CPW; ++s) {
                     const int c = wv + 16 * s;
                     if (c > j && c < ob) {
-                        double part = 0.0, asel = 0.0;
+                        double part = 0.0;
 #pragma unroll
-                        for (int r = 0; r < NR; ++r) { part = fma(v[r], col[s][r], part); if (r == rj) asel = col[s][r]; }
+                        for (int r = 0; r < NR; ++r) part = fma(v[r], col[s][r], part);
                         const double d = bb_wave_sum_dpp(part);
-                        const double ak = readlane_f64(asel, lj);
+                        const double ak = readlane_f64(col[s][0], j);
                         const double ngam = fma(s2, ak, d) * ng;
                         const double rjv = fma(s2, ngam, ak);              // row j of R
+                        col[s][0] = ln == j ? rjv : fma(ngam, v[0], col[s][0]);
 #pragma unroll
-                        for (int r = 0; r < NR; ++r) {
-                            const int i = r * 64 + ln;
-                            col[s][r] = i == j ? rjv : fma(ngam, v[r], col[s][r]);   // (v is zero outside j < i < mr)
-                        }
-                    } else if (c < j) {
-                        // a finished column: its entry of G = V^T V for the block's T, (V_c . v_j) with v_j = (1, x / s)
-                        double part = 0.0, asel = 0.0;
-#pragma unroll
-                        for (int r = 0; r < NR; ++r) { part = fma(v[r], col[s][r], part); if (r == rj) asel = col[s][r]; }
-                        const double d = bb_wave_sum_dpp(part);
-                        const double vcj = readlane_f64(asel, lj);
-                        if (ln == 0) tb[c * OB + j] = fma(d, inv_s, vcj);
+                        for (int r = 1; r < NR; ++r) col[s][r] = fma(ngam, v[r], col[s][r]);
                     }
                 }
             }
@@ -375,12 +359,40 @@ __device__ __attribute__((noinline)) void bb_panel_qr(double* __restrict__ W, co
         const int c_first = jb + OB, nt = n - c_first;     // columns to the right
         if (nt <= 0) { __syncthreads(); BB_QTICK(2); continue; }
         __syncthreads();
-        // 4. V = unit-lower view of the block (in place); T of the block from G (gathered during the sweep above) in the
-        //    recursive form (as for the panel's T below)
+        // 4. V = unit-lower view of the block (in place); T of the block in the recursive form (as for the panel's T
+        //    below)
         for (int e = tid; e < OB * OB; e += BC_THREADS) {
             const int i = e / OB, l = e - i * OB;
             if (i < mr) { if (i == l) blk[l * ld + i] = 1.0; else if (i < l) blk[l * ld + i] = 0.0; }
         }
+        __syncthreads();
+        {   // G = V^T V above the diagonal (v_mfma_f64_16x16x4_f64, the rows split over the waves), into tb
+            constexpr int NT = MT * (MT + 1) / 2, PG = OB == 32 ? 5 : 8;      // tiles of G, row parts: NT * PG <= 16 waves
+            const int tile = wv % NT, part = wv / NT;
+            const int ta = tile == 2 ? 1 : 0, tbn = tile == 0 ? 0 : 1;       // (0,0) (0,1) (1,1)
+            const int kq = ln >> 4, l15 = ln & 15;
+            if (wv < NT * PG) {
+                const int K = (mr + 3) >> 2, k0 = part * K / PG, k1 = (part + 1) * K / PG;
+                bb_d4 g = bb_d4{0.0, 0.0, 0.0, 0.0};
+                for (int k = k0; k < k1; ++k) {
+                    const int row = 4 * k + kq;
+                    const double av = row < mr ? blk[(16 * ta + l15) * ld + row] : 0.0;
+                    const double bv = row < mr ? blk[(16 * tbn + l15) * ld + row] : 0.0;
+                    g = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, g, 0, 0, 0);
+                }
+#pragma unroll
+                for (int z = 0; z < 4; ++z) red[((tile * PG + part) * 4 + z) * 64 + ln] = g[z];
+            }
+            __syncthreads();
+            for (int e = tid; e < NT * 256; e += BC_THREADS) {
+                const int t = e >> 8, z = (e >> 6) & 3, l = e & 63;
+                double sum = 0.0;
+                for (int pp = 0; pp < PG; ++pp) sum += red[((t * PG + pp) * 4 + z) * 64 + l];
+                const int a = 16 * (t == 2 ? 1 : 0) + (l >> 4) + 4 * z, b = 16 * (t == 0 ? 0 : 1) + (l & 15);
+                if (a < b) tb[a * OB + b] = sum;
+            }
+        }
+        __syncthreads();
         if (wv < OB / 8) {          // diagonal 8 x 8 blocks by the column recurrence, one wave each
             const int base = 8 * wv;
             for (int j = 1; j < 8; ++j) {
