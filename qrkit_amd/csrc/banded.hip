@@ -531,15 +531,12 @@ bb_chain2_kernel(const BBPanel* __restrict__ panels, int num_panels, const int32
                  const int32_t* __restrict__ pcol, const int64_t* __restrict__ pmap, const double* __restrict__ vals,
                  double* __restrict__ W, double* __restrict__ lo, double* __restrict__ y_vals,
                  double* __restrict__ t_vals, double* __restrict__ r_stage, int max_act_rows, int max_ncols,
-                 int t_in_lds, int uni_doubles)
+                 int uni_doubles)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double* hc = smem;                         // [BC_CW] hCoeffs of the panel
     double* sc = hc + BC_CW;                   // [8] scalars of the current reflector (two sets)
-    double* uni = sc + 8;                      // union: blocked QR (bb_panel_qr) / Gram chunk / packed T / partial sums
-    double* dpart = uni;                       // [BC_THREADS] partial sums of the T recurrence in global memory
-    double* ys = uni;                          // [BC_RC * n]
-    double* tl = uni;                          // [n (n + 1) / 2] packed upper T by columns
+    double* uni = sc + 8;                      // the blocked QR's (bb_panel_qr)
     const int tid = threadIdx.x;
 #ifdef QRK_BB_PROF
     unsigned long long pt[6] = {0, 0, 0, 0, 0, 0}, t0 = 0, qt[4] = {0, 0, 0, 0};
@@ -551,11 +548,6 @@ bb_chain2_kernel(const BBPanel* __restrict__ panels, int num_panels, const int32
     for (int pi = 0; pi < num_panels; ++pi) {
         const BBPanel p = panels[pi];
         const int m = p.act_rows, n = p.ncols;          // W is m x n, row-major: W(i, j) = W[i * n + j]
-        // 2-D thread grid of this panel: CW column slots (n rounded up to a wave), RG row groups
-        const int CW = ((n + 63) / 64) * 64, RG = BC_THREADS / CW;
-        const bool on = tid < CW * RG;                  // (threads beyond the grid only help with the copies)
-        const int cs = on ? tid % CW : CW - 1, rg = on ? tid / CW : 0;
-
 #ifdef QRK_BB_PROF
         t0 = __builtin_amdgcn_s_memtime();
 #endif
@@ -619,208 +611,251 @@ bb_chain2_kernel(const BBPanel* __restrict__ panels, int num_panels, const int32
         __syncthreads();
 
         BB_TICK(2);
-        // ---- G = Y^T Y (strict upper part) into the T output: T[c * n + b] = G(b, c), b < c.
-        // A real GEMM (n x m by m x n): v_mfma_f64_16x16x4_f64 on 16x16 tiles of G, the operands read from an
-        // LDS chunk of 16 rows of Y (unit-lower view of the packed panel); every wave owns up to 9 upper tiles.
-        // Lane maps (cdna_hip_programming.md): A[row = l & 15][k = l >> 4], B[k = l >> 4][col = l & 15],
-        // D[row = (l >> 4) + 4 j][col = l & 15] in result register j.
-        double* T = t_vals + p.t_off;
+        // ---- hCoeffs parked on the diagonal of the T output: bb_t_kernel (one workgroup per panel, after the chain)
+        // builds T from Y and these.  T is not needed by the next panel, so it is not the chain's work.
         {
-            typedef double d4 __attribute__((ext_vector_type(4)));
-            const int nbt = (n + 15) / 16, n16 = nbt * 16;
-            const int ntile = nbt * (nbt + 1) / 2;
-            const int wv = tid >> 6, ln = tid & 63;
-            constexpr int MAXQ = 9;                      // 16 * 17 / 2 = 136 tiles over 16 waves
-            d4 acc[MAXQ];
-            int tbi[MAXQ], tbc[MAXQ];
-#pragma unroll
-            for (int q = 0; q < MAXQ; ++q) {
-                acc[q] = d4{0.0, 0.0, 0.0, 0.0};
-                int t = wv + q * (BC_THREADS / 64), bi = 0;
-                if (t >= ntile) { tbi[q] = -1; tbc[q] = 0; continue; }
-                while (t >= nbt - bi) { t -= nbt - bi; ++bi; }   // upper tiles enumerated row by row
-                tbi[q] = bi; tbc[q] = bi + t;
-            }
-            for (int r0 = 0; r0 < m; r0 += BC_RC) {
-                __syncthreads();
-                for (int e = tid; e < BC_RC * n16; e += BC_THREADS) {
-                    const int i = r0 + e / n16, j = e % n16;
-                    ys[e] = (i >= m || j >= n || i < j) ? 0.0 : (i == j ? 1.0 : W[(int64_t)i * n + j]);
-                }
-                __syncthreads();
-#pragma unroll
-                for (int q = 0; q < MAXQ; ++q) {
-                    if (tbi[q] >= 0) {
-#pragma unroll
-                        for (int ks = 0; ks < BC_RC / 4; ++ks) {
-                            const int row = 4 * ks + (ln >> 4);
-                            const double av = ys[row * n16 + 16 * tbi[q] + (ln & 15)];
-                            const double bv = ys[row * n16 + 16 * tbc[q] + (ln & 15)];
-                            acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[q], 0, 0, 0);
-                        }
-                    }
-                }
-            }
-#pragma unroll
-            for (int q = 0; q < MAXQ; ++q) {
-                if (tbi[q] >= 0) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int gi = 16 * tbi[q] + (ln >> 4) + 4 * j, gc = 16 * tbc[q] + (ln & 15);
-                        if (gi < gc && gc < n) T[(int64_t)gc * n + gi] = acc[q][j];
-                    }
-                }
-            }
+            double* T = t_vals + p.t_off;
+            for (int c = tid; c < n; c += BC_THREADS) T[(int64_t)c * n + c] = hc[c];
         }
         __syncthreads();
-
-        BB_TICK(3);
-        // ---- T = make_block_householder_triangular_factor(Y, hCoeffs) (:476).
-        // With T in LDS: the recursive form of the same factor.  T = [T11 T12; 0 T22] with
-        // T12 = -T11 (Y1^T Y2) T22, so the BC_THREADS/64 diagonal blocks are built by the column recurrence, one
-        // wave each and without workgroup barriers, and merged pairwise in log2(16) rounds of two triangular
-        // products (every thread a few entries).  The column recurrence over the whole panel spent 2.7 us per
-        // column in barriers and LDS latency (0.5 ms of a 1.9 ms panel).
-        if (t_in_lds) {
-            const int wv = tid >> 6, ln = tid & 63;
-            constexpr int NBLK = BC_THREADS / 64;
-            const int s0 = (n + NBLK - 1) / NBLK;          // <= 16 for n <= 256
-            // packed upper storage, by columns: (a, b), a <= b, at b (b + 1) / 2 + a.  G above the diagonal, tau on it
-            for (int b = wv; b < n; b += NBLK) {
-                const int cb = b * (b + 1) / 2;
-                for (int a = ln; a < b; a += 64) tl[cb + a] = T[(int64_t)b * n + a];
-                if (ln == 0) tl[cb + b] = hc[b];
-            }
-            __syncthreads();
-            {   // diagonal block wv: t(a, c) = -tau_c sum_{b = a}^{c - 1} T(a, b) G(b, c) inside the block
-                const int base = wv * s0, len = (n - base) < s0 ? (n - base) : s0;
-                for (int j = 1; j < len; ++j) {
-                    const int c = base + j, cc2 = c * (c + 1) / 2;
-                    double sum = 0.0;
-                    if (ln < j) {
-                        const int a = base + ln;
-                        int ib = (a * (a + 1)) / 2 + a;          // (a, b = a)
-                        for (int b = a; b < c; ++b) { sum = fma(tl[ib], tl[cc2 + b], sum); ib += b + 1; }
-                    }
-                    const double tc = tl[cc2 + c];
-                    __builtin_amdgcn_wave_barrier();
-                    if (ln < j) tl[cc2 + base + ln] = -tc * sum;
-                    __builtin_amdgcn_wave_barrier();
-                }
-            }
-            __syncthreads();
-            constexpr int MAXO = (BC_CW / 2) * (BC_CW / 2) / BC_THREADS;      // entries per thread in the last merge
-            for (int sz = s0; sz < n; sz *= 2) {
-                const int ss = sz * sz, npair = (n + 2 * sz - 1) / (2 * sz), total = npair * ss;
-                double xr[MAXO];
-                // X = G12 T22 (in place of G12): X(i, j) = sum_{k <= j} G12(i, k) T22(k, j)
-#pragma unroll
-                for (int t = 0; t < MAXO; ++t) {
-                    const int o = tid + t * BC_THREADS;
-                    xr[t] = 0.0;
-                    if (o < total) {
-                        const int q = o / ss, rem = o - q * ss, j = rem / sz, i = rem - j * sz;
-                        const int r0 = 2 * q * sz, c0 = r0 + sz, cj = c0 + j;
-                        if (cj < n) {
-                            const int cj2 = cj * (cj + 1) / 2 + c0;
-                            int ia = c0 * (c0 + 1) / 2 + r0 + i;
-                            double acc = 0.0;
-#pragma unroll 4
-                            for (int k = 0; k <= j; ++k) { acc = fma(tl[ia], tl[cj2 + k], acc); ia += c0 + k + 1; }
-                            xr[t] = acc;
-                        }
-                    }
-                }
-                __syncthreads();
-#pragma unroll
-                for (int t = 0; t < MAXO; ++t) {
-                    const int o = tid + t * BC_THREADS;
-                    if (o < total) {
-                        const int q = o / ss, rem = o - q * ss, j = rem / sz, i = rem - j * sz;
-                        const int r0 = 2 * q * sz, cj = r0 + sz + j;
-                        if (cj < n) tl[cj * (cj + 1) / 2 + r0 + i] = xr[t];
-                    }
-                }
-                __syncthreads();
-                // T12 = -T11 X: T12(i, j) = -sum_{k >= i} T11(i, k) X(k, j)
-#pragma unroll
-                for (int t = 0; t < MAXO; ++t) {
-                    const int o = tid + t * BC_THREADS;
-                    xr[t] = 0.0;
-                    if (o < total) {
-                        const int q = o / ss, rem = o - q * ss, j = rem / sz, i = rem - j * sz;
-                        const int r0 = 2 * q * sz, cj = r0 + sz + j;
-                        if (cj < n) {
-                            const int cj2 = cj * (cj + 1) / 2 + r0;
-                            const int ri = r0 + i;
-                            int ia = ri * (ri + 1) / 2 + ri;     // (ri, ri)
-                            double acc = 0.0;
-#pragma unroll 4
-                            for (int k = i; k < sz; ++k) { acc = fma(tl[ia], tl[cj2 + k], acc); ia += r0 + k + 1; }
-                            xr[t] = -acc;
-                        }
-                    }
-                }
-                __syncthreads();
-#pragma unroll
-                for (int t = 0; t < MAXO; ++t) {
-                    const int o = tid + t * BC_THREADS;
-                    if (o < total) {
-                        const int q = o / ss, rem = o - q * ss, j = rem / sz, i = rem - j * sz;
-                        const int r0 = 2 * q * sz, cj = r0 + sz + j;
-                        if (cj < n) tl[cj * (cj + 1) / 2 + r0 + i] = xr[t];
-                    }
-                }
-                __syncthreads();
-            }
-        } else {
-            // in place in global memory, forward recurrence by columns (panels whose packed T does not fit the LDS)
-            for (int cc = 0; cc < n; ++cc) {
-                const double hcc = hc[cc];
-                double part = 0.0;
-                if (on && cs < cc) for (int b = cs + rg; b < cc; b += RG) part = fma(T[(int64_t)b * n + cs], T[(int64_t)cc * n + b], part);
-                if (on) dpart[rg * CW + cs] = part;
-                __syncthreads();     // every G(b, cc) has been read before column cc is overwritten
-                if (on && rg == 0 && cs < cc) {
-                    double sum = 0.0;
-                    for (int g = 0; g < RG; ++g) sum += dpart[g * CW + cs];
-                    T[(int64_t)cc * n + cs] = -hcc * sum;
-                }
-                if (tid == 0) T[(int64_t)cc * n + cc] = hcc;
-                __syncthreads();
-            }
-        }
-        // the reference stores -T (:477); lower part zero
-        for (int64_t e = tid; e < (int64_t)n * n; e += BC_THREADS) {
-            const int a = (int)(e % n), b = (int)(e / n);
-            double v = 0.0;
-            if (a <= b) v = t_in_lds ? -tl[(int64_t)b * (b + 1) / 2 + a] : -T[e];
-            T[e] = v;
-        }
-        __syncthreads();
-        BB_TICK(4);
 #ifdef QRK_BB_PROF
-        if (pi == num_panels - 1 && tid == 0) for (int z = 0; z < 5; ++z) T[z] = (double)pt[z];
-        if (pi == num_panels - 1 && tid == 0) T[5] = (double)pt[5];
-        if (pi == num_panels - 1 && tid == 0) for (int z = 0; z < 4; ++z) T[6 + z] = (double)qt[z];
+        if (pi == num_panels - 1 && tid == 0) {
+            double* T = t_vals + p.t_off;
+            for (int z = 0; z < 6; ++z) T[z] = (double)pt[z];
+            for (int z = 0; z < 4; ++z) T[6 + z] = (double)qt[z];
+        }
 #endif
     }
 }
 
+// T of every panel from its Y and hCoeffs (parked on T's diagonal by the chain): one workgroup per panel.
+__global__ void __launch_bounds__(BC_THREADS)
+bb_t_kernel(const BBPanel* __restrict__ panels, int num_panels, const double* __restrict__ y_vals,
+            double* __restrict__ t_vals, int t_in_lds)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double* hc = smem;                         // [BC_CW] hCoeffs of the panel
+    double* uni = hc + BC_CW;
+    double* dpart = uni;                       // [BC_THREADS] partial sums of the T recurrence in global memory
+    double* ys = uni;                          // [BC_RC * (n16 + 1)] rows of Y
+    double* tl = uni;                          // [n (n + 1) / 2] packed upper T by columns
+    const int tid = threadIdx.x;
+    const int pi = blockIdx.x;
+#ifdef QRK_BB_PROF
+    if (pi == num_panels - 1) return;          // (the chain left its tick counts in this panel's T)
+#endif
+    const BBPanel p = panels[pi];
+    const int m = p.act_rows, n = p.ncols;
+    const int CW = ((n + 63) / 64) * 64, RG = BC_THREADS / CW;
+    const bool on = tid < CW * RG;
+    const int cs = on ? tid % CW : CW - 1, rg = on ? tid / CW : 0;
+    const double* Y = y_vals + p.y_off;
+    double* T = t_vals + p.t_off;
+    for (int c = tid; c < n; c += BC_THREADS) hc[c] = T[(int64_t)c * n + c];
+    __syncthreads();
+    // ---- G = Y^T Y (strict upper part) into the T output: T[c * n + b] = G(b, c), b < c.
+    // A real GEMM (n x m by m x n): v_mfma_f64_16x16x4_f64 on 16x16 tiles of G, the operands read from an
+    // LDS chunk of 16 rows of Y (unit-lower view of the packed panel); every wave owns up to 9 upper tiles.
+    // Lane maps (cdna_hip_programming.md): A[row = l & 15][k = l >> 4], B[k = l >> 4][col = l & 15],
+    // D[row = (l >> 4) + 4 j][col = l & 15] in result register j.
+    {
+        typedef double d4 __attribute__((ext_vector_type(4)));
+        const int nbt = (n + 15) / 16, n16 = nbt * 16, ysld = n16 + 1;
+        const int ntile = nbt * (nbt + 1) / 2;
+        const int wv = tid >> 6, ln = tid & 63;
+        constexpr int MAXQ = 9;                      // 16 * 17 / 2 = 136 tiles over 16 waves
+        d4 acc[MAXQ];
+        int tbi[MAXQ], tbc[MAXQ];
+#pragma unroll
+        for (int q = 0; q < MAXQ; ++q) {
+            acc[q] = d4{0.0, 0.0, 0.0, 0.0};
+            int t = wv + q * (BC_THREADS / 64), bi = 0;
+            if (t >= ntile) { tbi[q] = -1; tbc[q] = 0; continue; }
+            while (t >= nbt - bi) { t -= nbt - bi; ++bi; }   // upper tiles enumerated row by row
+            tbi[q] = bi; tbc[q] = bi + t;
+        }
+        for (int r0 = 0; r0 < m; r0 += BC_RC) {
+            __syncthreads();
+            for (int e = tid; e < BC_RC * n16; e += BC_THREADS) {
+                const int il = e % BC_RC, j = e / BC_RC, i = r0 + il;
+                ys[il * ysld + j] = (i < m && j < n) ? Y[(int64_t)j * m + i] : 0.0;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < MAXQ; ++q) {
+                if (tbi[q] >= 0) {
+#pragma unroll
+                    for (int ks = 0; ks < BC_RC / 4; ++ks) {
+                        const int row = 4 * ks + (ln >> 4);
+                        const double av = ys[row * ysld + 16 * tbi[q] + (ln & 15)];
+                        const double bv = ys[row * ysld + 16 * tbc[q] + (ln & 15)];
+                        acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[q], 0, 0, 0);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < MAXQ; ++q) {
+            if (tbi[q] >= 0) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int gi = 16 * tbi[q] + (ln >> 4) + 4 * j, gc = 16 * tbc[q] + (ln & 15);
+                    if (gi < gc && gc < n) T[(int64_t)gc * n + gi] = acc[q][j];
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- T = make_block_householder_triangular_factor(Y, hCoeffs) (:476).
+    // With T in LDS: the recursive form of the same factor.  T = [T11 T12; 0 T22] with
+    // T12 = -T11 (Y1^T Y2) T22, so the BC_THREADS/64 diagonal blocks are built by the column recurrence, one
+    // wave each and without workgroup barriers, and merged pairwise in log2(16) rounds of two triangular
+    // products (every thread a few entries).  The column recurrence over the whole panel spent 2.7 us per
+    // column in barriers and LDS latency (0.5 ms of a 1.9 ms panel).
+    if (t_in_lds) {
+        const int wv = tid >> 6, ln = tid & 63;
+        constexpr int NBLK = BC_THREADS / 64;
+        const int s0 = (n + NBLK - 1) / NBLK;          // <= 16 for n <= 256
+        // packed upper storage, by columns: (a, b), a <= b, at b (b + 1) / 2 + a.  G above the diagonal, tau on it
+        for (int b = wv; b < n; b += NBLK) {
+            const int cb = b * (b + 1) / 2;
+            for (int a = ln; a < b; a += 64) tl[cb + a] = T[(int64_t)b * n + a];
+            if (ln == 0) tl[cb + b] = hc[b];
+        }
+        __syncthreads();
+        {   // diagonal block wv: t(a, c) = -tau_c sum_{b = a}^{c - 1} T(a, b) G(b, c) inside the block
+            const int base = wv * s0, len = (n - base) < s0 ? (n - base) : s0;
+            for (int j = 1; j < len; ++j) {
+                const int c = base + j, cc2 = c * (c + 1) / 2;
+                double sum = 0.0;
+                if (ln < j) {
+                    const int a = base + ln;
+                    int ib = (a * (a + 1)) / 2 + a;          // (a, b = a)
+                    for (int b = a; b < c; ++b) { sum = fma(tl[ib], tl[cc2 + b], sum); ib += b + 1; }
+                }
+                const double tc = tl[cc2 + c];
+                __builtin_amdgcn_wave_barrier();
+                if (ln < j) tl[cc2 + base + ln] = -tc * sum;
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        __syncthreads();
+        constexpr int MAXO = (BC_CW / 2) * (BC_CW / 2) / BC_THREADS;      // entries per thread in the last merge
+        for (int sz = s0; sz < n; sz *= 2) {
+            const int ss = sz * sz, npair = (n + 2 * sz - 1) / (2 * sz), total = npair * ss;
+            double xr[MAXO];
+            // X = G12 T22 (in place of G12): X(i, j) = sum_{k <= j} G12(i, k) T22(k, j)
+#pragma unroll
+            for (int t = 0; t < MAXO; ++t) {
+                const int o = tid + t * BC_THREADS;
+                xr[t] = 0.0;
+                if (o < total) {
+                    const int q = o / ss, rem = o - q * ss, j = rem / sz, i = rem - j * sz;
+                    const int r0 = 2 * q * sz, c0 = r0 + sz, cj = c0 + j;
+                    if (cj < n) {
+                        const int cj2 = cj * (cj + 1) / 2 + c0;
+                        int ia = c0 * (c0 + 1) / 2 + r0 + i;
+                        double acc = 0.0;
+#pragma unroll 4
+                        for (int k = 0; k <= j; ++k) { acc = fma(tl[ia], tl[cj2 + k], acc); ia += c0 + k + 1; }
+                        xr[t] = acc;
+                    }
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int t = 0; t < MAXO; ++t) {
+                const int o = tid + t * BC_THREADS;
+                if (o < total) {
+                    const int q = o / ss, rem = o - q * ss, j = rem / sz, i = rem - j * sz;
+                    const int r0 = 2 * q * sz, cj = r0 + sz + j;
+                    if (cj < n) tl[cj * (cj + 1) / 2 + r0 + i] = xr[t];
+                }
+            }
+            __syncthreads();
+            // T12 = -T11 X: T12(i, j) = -sum_{k >= i} T11(i, k) X(k, j)
+#pragma unroll
+            for (int t = 0; t < MAXO; ++t) {
+                const int o = tid + t * BC_THREADS;
+                xr[t] = 0.0;
+                if (o < total) {
+                    const int q = o / ss, rem = o - q * ss, j = rem / sz, i = rem - j * sz;
+                    const int r0 = 2 * q * sz, cj = r0 + sz + j;
+                    if (cj < n) {
+                        const int cj2 = cj * (cj + 1) / 2 + r0;
+                        const int ri = r0 + i;
+                        int ia = ri * (ri + 1) / 2 + ri;     // (ri, ri)
+                        double acc = 0.0;
+#pragma unroll 4
+                        for (int k = i; k < sz; ++k) { acc = fma(tl[ia], tl[cj2 + k], acc); ia += r0 + k + 1; }
+                        xr[t] = -acc;
+                    }
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int t = 0; t < MAXO; ++t) {
+                const int o = tid + t * BC_THREADS;
+                if (o < total) {
+                    const int q = o / ss, rem = o - q * ss, j = rem / sz, i = rem - j * sz;
+                    const int r0 = 2 * q * sz, cj = r0 + sz + j;
+                    if (cj < n) tl[cj * (cj + 1) / 2 + r0 + i] = xr[t];
+                }
+            }
+            __syncthreads();
+        }
+    } else {
+        // in place in global memory, forward recurrence by columns (panels whose packed T does not fit the LDS)
+        for (int cc = 0; cc < n; ++cc) {
+            const double hcc = hc[cc];
+            double part = 0.0;
+            if (on && cs < cc) for (int b = cs + rg; b < cc; b += RG) part = fma(T[(int64_t)b * n + cs], T[(int64_t)cc * n + b], part);
+            if (on) dpart[rg * CW + cs] = part;
+            __syncthreads();     // every G(b, cc) has been read before column cc is overwritten
+            if (on && rg == 0 && cs < cc) {
+                double sum = 0.0;
+                for (int g = 0; g < RG; ++g) sum += dpart[g * CW + cs];
+                T[(int64_t)cc * n + cs] = -hcc * sum;
+            }
+            if (tid == 0) T[(int64_t)cc * n + cc] = hcc;
+            __syncthreads();
+        }
+    }
+    // the reference stores -T (:477); lower part zero
+    for (int64_t e = tid; e < (int64_t)n * n; e += BC_THREADS) {
+        const int a = (int)(e % n), b = (int)(e / n);
+        double v = 0.0;
+        if (a <= b) v = t_in_lds ? -tl[(int64_t)b * (b + 1) / 2 + a] : -T[e];
+        T[e] = v;
+    }
+    __syncthreads();
+}
+
 // LDS of bb_chain2_kernel: all of it (one workgroup per chain), 0 if the 16-column block of the tallest panel does not fit
-size_t bb_chain2_smem(int max_act_rows, int max_ncols, int* t_in_lds, int* uni_doubles)
+size_t bb_chain2_smem(int max_act_rows, int* uni_doubles)
 {
     const size_t all = (size_t)160 * 1024;
     const size_t fixed = (size_t)(BC_CW + 8) * sizeof(double);
     const size_t qr = ((size_t)16 * (max_act_rows | 1) + bb_qr_aux_doubles(16)) * sizeof(double);
-    const size_t gram = (size_t)BC_RC * ((max_ncols + 15) / 16 * 16) * sizeof(double);
-    const size_t tpk = (size_t)max_ncols * (max_ncols + 1) / 2 * sizeof(double);
-    *t_in_lds = 0; *uni_doubles = 0;
-    if (fixed + qr > all || fixed + gram > all || fixed + BC_THREADS * sizeof(double) > all) return 0;
-    // (QRK_BB_T_GLOBAL forces the in-place T recurrence: lets the tests cover it)
-    if (fixed + tpk <= all && !std::getenv("QRK_BB_T_GLOBAL")) *t_in_lds = 1;
+    *uni_doubles = 0;
+    if (fixed + qr > all) return 0;
     *uni_doubles = (int)((all - fixed) / sizeof(double));
     return all;
+}
+
+// LDS of bb_t_kernel
+size_t bb_t_smem(int max_ncols, int* t_in_lds)
+{
+    const size_t all = (size_t)160 * 1024;
+    const size_t fixed = (size_t)BC_CW * sizeof(double);
+    const size_t gram = (size_t)BC_RC * ((max_ncols + 15) / 16 * 16 + 1) * sizeof(double);
+    const size_t tpk = (size_t)max_ncols * (max_ncols + 1) / 2 * sizeof(double);
+    size_t uni = gram > BC_THREADS * sizeof(double) ? gram : BC_THREADS * sizeof(double);
+    *t_in_lds = 0;
+    // (QRK_BB_T_GLOBAL forces the in-place T recurrence: lets the tests cover it)
+    if (fixed + tpk <= all && !std::getenv("QRK_BB_T_GLOBAL")) { *t_in_lds = 1; if (tpk > uni) uni = tpk; }
+    return fixed + uni;
 }
 
 __global__ void __launch_bounds__(256)
@@ -885,13 +920,19 @@ hipError_t launch_bb_chain(const BBPanel* panels, int num_panels, const int32_t*
                            int max_ncols, hipStream_t stream)
 {
     int t_in_lds = 0, uni_doubles = 0;
-    const size_t smem2 = bb_chain2_smem(max_act_rows, max_ncols, &t_in_lds, &uni_doubles);
+    const size_t smem2 = bb_chain2_smem(max_act_rows, &uni_doubles);
     if (max_ncols <= BC_CW && smem2 > 0 && !std::getenv("QRK_BB_CHAIN_V1")) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(bb_chain2_kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem2);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(bb_chain2_kernel, dim3(1), dim3(BC_THREADS), smem2, stream, panels, num_panels, prowptr, pcol, pmap,
-                           vals, W, lo, y_vals, t_vals, r_stage, max_act_rows, max_ncols, t_in_lds, uni_doubles);
+                           vals, W, lo, y_vals, t_vals, r_stage, max_act_rows, max_ncols, uni_doubles);
+        const size_t smem_t = bb_t_smem(max_ncols, &t_in_lds);
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(bb_t_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)smem_t);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(bb_t_kernel, dim3((unsigned)num_panels), dim3(BC_THREADS), smem_t, stream, panels, num_panels,
+                           y_vals, t_vals, t_in_lds);
     } else {
         const size_t smem = bb_chain_smem(max_act_rows, max_ncols);
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(bb_chain_kernel),
