@@ -234,7 +234,7 @@ __host__ __device__ constexpr int bb_qr_aux_doubles(int OB) { return OB * OB + 8
 //    port was the bound (0.55 ms of a 1.6 ms panel).
 // uni: [OB * ld] block (column-major, ld = m | 1), then bb_qr_aux_doubles(OB).
 template <int OB>
-__device__ __attribute__((noinline)) void bb_panel_qr(double* __restrict__ W, const int m, const int n
+__device__ __attribute__((noinline)) void bb_panel_qr(double* __restrict__ W, double* __restrict__ Y, const int m, const int n
 #ifdef QRK_BB_PROF
                                             , unsigned long long* qt
 #endif
@@ -355,6 +355,11 @@ __device__ __attribute__((noinline)) void bb_panel_qr(double* __restrict__ W, co
         for (int e = tid; e < mr * OB; e += BC_THREADS) {
             const int i = e / OB, l = e - i * OB;
             if (l < ob) W[(int64_t)(jb + i) * n + jb + l] = blk[l * ld + i];
+        }
+        // ... and its unit-lower view to Y (:471-475; column-major m x n, zero above the diagonal)
+        for (int e = tid; e < m * ob; e += BC_THREADS) {
+            const int l = e / m, pr = e - l * m, i = pr - jb;
+            Y[(int64_t)(jb + l) * m + pr] = i < l ? 0.0 : (i == l ? 1.0 : blk[l * ld + i]);
         }
         const int c_first = jb + OB, nt = n - c_first;     // columns to the right
         if (nt <= 0) { __syncthreads(); BB_QTICK(2); continue; }
@@ -551,20 +556,42 @@ bb_chain2_kernel(const BBPanel* __restrict__ panels, int num_panels, const int32
 #ifdef QRK_BB_PROF
         t0 = __builtin_amdgcn_s_memtime();
 #endif
-        // ---- Ji = pmat.block(row0, col0, m, n).toDense() (:458, :503) ...
-        for (int64_t e = tid; e < (int64_t)m * n; e += BC_THREADS) W[e] = 0.0;
-        __syncthreads();
-        for (int r = tid >> 6; r < m; r += BC_THREADS / 64) {
-            const int gr = p.row0 + r;
-            for (int e = prowptr[gr] + (tid & 63); e < prowptr[gr + 1]; e += 64) {
-                const int c = pcol[e] - p.col0;
-                if (c >= 0 && c < n) W[(int64_t)r * n + c] = vals[pmap[e]];
+        // ---- Ji = pmat.block(row0, col0, m, n).toDense() (:458, :503): the rows of the panel are one contiguous run of
+        // CSR entries; every thread walks it with stride BC_THREADS (coalesced index loads, eight entries in flight) and
+        // finds the row of its entry by stepping through the row pointers kept in LDS ...
+        {
+            int* ptrs = reinterpret_cast<int*>(uni);           // [m + 1]
+            for (int i = tid; i <= m; i += BC_THREADS) ptrs[i] = prowptr[p.row0 + i];
+            for (int64_t e = tid; e < (int64_t)m * n; e += BC_THREADS) W[e] = 0.0;
+            __syncthreads();
+            const int e0 = ptrs[0], e1 = ptrs[m];
+            int r = 0;
+            constexpr int U = 8;
+            for (int e = e0 + tid; e < e1; e += U * BC_THREADS) {
+                // (indices clamped instead of predicated loads: every value is defined on every path)
+                int cc[U]; int64_t pm[U]; double vv[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    int ee = e + u * BC_THREADS; if (ee > e1 - 1) ee = e1 - 1;
+                    cc[u] = pcol[ee]; pm[u] = pmap[ee];
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) vv[u] = vals[pm[u]];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int ee = e + u * BC_THREADS;
+                    if (ee < e1) {
+                        while (ee >= ptrs[r + 1]) ++r;
+                        const int c = cc[u] - p.col0;
+                        if (c >= 0 && c < n) W[(int64_t)r * n + c] = vv[u];
+                    }
+                }
             }
+            __syncthreads();
         }
-        __syncthreads();
         // ... with its top-left corner replaced by the leftover block of the previous panel (:504-506)
         for (int e = tid; e < p.lo_rows * p.lo_cols; e += BC_THREADS) {
-            const int i = e % p.lo_rows, j = e / p.lo_rows;
+            const int i = e / p.lo_cols, j = e - i * p.lo_cols;
             W[(int64_t)i * n + j] = lo[e];
         }
         __syncthreads();
@@ -574,40 +601,45 @@ bb_chain2_kernel(const BBPanel* __restrict__ panels, int num_panels, const int32
         // next to its T and the partial sums (m <= ~470), else of 16
         if ((int64_t)32 * (m | 1) + bb_qr_aux_doubles(32) <= (int64_t)uni_doubles) {
 #ifdef QRK_BB_PROF
-            bb_panel_qr<32>(W, m, n, qt);
+            bb_panel_qr<32>(W, y_vals + p.y_off, m, n, qt);
 #else
-            bb_panel_qr<32>(W, m, n);
+            bb_panel_qr<32>(W, y_vals + p.y_off, m, n);
 #endif
         } else {
 #ifdef QRK_BB_PROF
-            bb_panel_qr<16>(W, m, n, qt);
+            bb_panel_qr<16>(W, y_vals + p.y_off, m, n, qt);
 #else
-            bb_panel_qr<16>(W, m, n);
+            bb_panel_qr<16>(W, y_vals + p.y_off, m, n);
 #endif
         }
         __syncthreads();
 
         BB_TICK(1);
-        // ---- rows of R solved by this panel: V = triu(packed QR), explicit zeros kept (:484-491)
-        for (int e = tid; e < p.solved * n; e += BC_THREADS) {
-            const int br = e % p.solved, bc = e / p.solved;
-            r_stage[p.r_off + e] = (br <= bc && br < m) ? W[(int64_t)br * n + bc] : 0.0;
+        // ---- rows of R solved by this panel: V = triu(packed QR), explicit zeros kept (:484-491).  r_stage is
+        // column-major (solved x n): the rows go through an LDS tile so that both sides are coalesced.
+        for (int b0 = 0; b0 < p.solved; b0 += 64) {
+            const int nr = (p.solved - b0) < 64 ? (p.solved - b0) : 64, tld = n | 1;
+            __syncthreads();
+            for (int e = tid; e < nr * n; e += BC_THREADS) {
+                const int il = e / n, bc = e - il * n, br = b0 + il;
+                uni[il * tld + bc] = (br <= bc && br < m) ? W[(int64_t)br * n + bc] : 0.0;
+            }
+            __syncthreads();
+            for (int e = tid; e < nr * n; e += BC_THREADS) {
+                const int bc = e / nr, il = e - bc * nr;
+                r_stage[p.r_off + (int64_t)bc * p.solved + b0 + il] = uni[il * tld + bc];
+            }
         }
-        // ---- leftover block for the next panel: V.block(lo_from, lo_from, lo_rows, lo_cols) (:505)
+        // ---- leftover block for the next panel: V.block(lo_from, lo_from, lo_rows, lo_cols) (:505), row-major
         if (pi + 1 < num_panels) {
             const BBPanel q = panels[pi + 1];
             for (int e = tid; e < q.lo_rows * q.lo_cols; e += BC_THREADS) {
-                const int i = e % q.lo_rows, j = e / q.lo_rows;
+                const int i = e / q.lo_cols, j = e - i * q.lo_cols;
                 const int vr = q.lo_from + i, vc = q.lo_from + j;
                 lo[e] = (vr <= vc && vr < m && vc < n) ? W[(int64_t)vr * n + vc] : 0.0;
             }
         }
-        // ---- Y = unit-lower essentials (:471-475), column-major m x n
-        double* Y = y_vals + p.y_off;
-        for (int64_t e = tid; e < (int64_t)m * n; e += BC_THREADS) {
-            const int i = (int)(e % m), j = (int)(e / m);
-            Y[e] = i < j ? 0.0 : (i == j ? 1.0 : W[(int64_t)i * n + j]);
-        }
+        // (Y = unit-lower essentials (:471-475) was written by bb_panel_qr, block by block)
         __syncthreads();
 
         BB_TICK(2);
