@@ -114,7 +114,10 @@ class BandedBlockedSparseQR:
     def blockYTY(self, k: int):
         """(Y, T, rowIndex, numZeros) of block k, as the reference's m_blocksYT[k] (T is stored negated)."""
         row, nz, m, n, yo, to = (int(v) for v in self.yty[k])
-        Y = self._y[yo:yo + m * n].cpu().numpy().reshape(n, m).T
+        # the panel is stored factorised in place (row-major m x n): Y is its unit-lower view
+        P = self._y[yo:yo + m * n].cpu().numpy().reshape(m, n)
+        Y = np.tril(P, -1)
+        Y[np.arange(min(m, n)), np.arange(min(m, n))] = 1.0
         T = self._t[to:to + n * n].cpu().numpy().reshape(n, n).T
         return Y, T, row, nz
 

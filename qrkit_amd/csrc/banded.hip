@@ -119,10 +119,10 @@ bb_chain_kernel(const BBPanel* __restrict__ panels, int num_panels, const int32_
             __syncthreads();
         }
 
-        // ---- Y = unit-lower essentials (:471-475)
+        // ---- Y = unit-lower essentials (:471-475), stored as the panel itself: row-major m x n (see bb_chain2_kernel)
         double* Y = y_vals + p.y_off;
         for (int64_t e = tid; e < (int64_t)m * n; e += BB_THREADS) {
-            const int i = (int)(e % m), j = (int)(e / m);
+            const int i = (int)(e / n), j = (int)(e % n);
             Y[e] = i < j ? 0.0 : (i == j ? 1.0 : W[(int64_t)j * ld + i]);
         }
         // ---- T = -make_block_householder_triangular_factor(Y, hCoeffs) (:476-477), rows n-1 .. 0:
@@ -234,7 +234,7 @@ __host__ __device__ constexpr int bb_qr_aux_doubles(int OB) { return OB * OB + 8
 //    port was the bound (0.55 ms of a 1.6 ms panel).
 // uni: [OB * ld] block (column-major, ld = m | 1), then bb_qr_aux_doubles(OB).
 template <int OB>
-__device__ __attribute__((noinline)) void bb_panel_qr(double* __restrict__ W, double* __restrict__ Y, const int m, const int n
+__device__ __attribute__((noinline)) void bb_panel_qr(double* __restrict__ W, const int m, const int n
 #ifdef QRK_BB_PROF
                                             , unsigned long long* qt
 #endif
@@ -355,11 +355,6 @@ __device__ __attribute__((noinline)) void bb_panel_qr(double* __restrict__ W, do
         for (int e = tid; e < mr * OB; e += BC_THREADS) {
             const int i = e / OB, l = e - i * OB;
             if (l < ob) W[(int64_t)(jb + i) * n + jb + l] = blk[l * ld + i];
-        }
-        // ... and its unit-lower view to Y (:471-475; column-major m x n, zero above the diagonal)
-        for (int e = tid; e < m * ob; e += BC_THREADS) {
-            const int l = e / m, pr = e - l * m, i = pr - jb;
-            Y[(int64_t)(jb + l) * m + pr] = i < l ? 0.0 : (i == l ? 1.0 : blk[l * ld + i]);
         }
         const int c_first = jb + OB, nt = n - c_first;     // columns to the right
         if (nt <= 0) { __syncthreads(); BB_QTICK(2); continue; }
@@ -531,17 +526,60 @@ __device__ __attribute__((noinline)) void bb_panel_qr(double* __restrict__ W, do
 #undef BB_QTICK
 }
 
+// Dense inputs of all the panels (Ji = pmat.block(row0, col0, m, n).toDense(), :458/:503) into the panels' own
+// storage in y_vals, row-major m x n: one workgroup per panel, before the chain.  The rows of a panel are one
+// contiguous run of CSR entries; every thread walks it with stride BC_THREADS (coalesced index loads, eight entries in
+// flight) and finds the row of its entry by stepping through the row pointers kept in LDS.  (The top-left corner is
+// replaced by the previous panel's leftover block inside the chain.)
+__global__ void __launch_bounds__(BC_THREADS)
+bb_scatter_kernel(const BBPanel* __restrict__ panels, const int32_t* __restrict__ prowptr, const int32_t* __restrict__ pcol,
+                  const int64_t* __restrict__ pmap, const double* __restrict__ vals, double* __restrict__ y_vals)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    int* ptrs = reinterpret_cast<int*>(smem);           // [m + 1]
+    const int tid = threadIdx.x;
+    const BBPanel p = panels[blockIdx.x];
+    const int m = p.act_rows, n = p.ncols;
+    double* W = y_vals + p.y_off;
+    for (int i = tid; i <= m; i += BC_THREADS) ptrs[i] = prowptr[p.row0 + i];
+    for (int64_t e = tid; e < (int64_t)m * n; e += BC_THREADS) W[e] = 0.0;
+    __syncthreads();
+    const int e0 = ptrs[0], e1 = ptrs[m];
+    int r = 0;
+    constexpr int U = 8;
+    for (int e = e0 + tid; e < e1; e += U * BC_THREADS) {
+        // (indices clamped instead of predicated loads: every value is defined on every path)
+        int cc[U]; int64_t pm[U]; double vv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            int ee = e + u * BC_THREADS; if (ee > e1 - 1) ee = e1 - 1;
+            cc[u] = pcol[ee]; pm[u] = pmap[ee];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) vv[u] = vals[pm[u]];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int ee = e + u * BC_THREADS;
+            if (ee < e1) {
+                while (ee >= ptrs[r + 1]) ++r;
+                const int c = cc[u] - p.col0;
+                if (c >= 0 && c < n) W[(int64_t)r * n + c] = vv[u];
+            }
+        }
+    }
+}
+
 __global__ void __launch_bounds__(BC_THREADS)
 bb_chain2_kernel(const BBPanel* __restrict__ panels, int num_panels, const int32_t* __restrict__ prowptr,
                  const int32_t* __restrict__ pcol, const int64_t* __restrict__ pmap, const double* __restrict__ vals,
-                 double* __restrict__ W, double* __restrict__ lo, double* __restrict__ y_vals,
+                 double* __restrict__ lo, double* __restrict__ y_vals,
                  double* __restrict__ t_vals, double* __restrict__ r_stage, int max_act_rows, int max_ncols,
                  int uni_doubles)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double* hc = smem;                         // [BC_CW] hCoeffs of the panel
     double* sc = hc + BC_CW;                   // [8] scalars of the current reflector (two sets)
-    double* uni = sc + 8;                      // the blocked QR's (bb_panel_qr)
+    double* uni = sc + 8;                      // the blocked QR's (bb_panel_qr); a tile of R rows on the way out
     const int tid = threadIdx.x;
 #ifdef QRK_BB_PROF
     unsigned long long pt[6] = {0, 0, 0, 0, 0, 0}, t0 = 0, qt[4] = {0, 0, 0, 0};
@@ -556,39 +594,9 @@ bb_chain2_kernel(const BBPanel* __restrict__ panels, int num_panels, const int32
 #ifdef QRK_BB_PROF
         t0 = __builtin_amdgcn_s_memtime();
 #endif
-        // ---- Ji = pmat.block(row0, col0, m, n).toDense() (:458, :503): the rows of the panel are one contiguous run of
-        // CSR entries; every thread walks it with stride BC_THREADS (coalesced index loads, eight entries in flight) and
-        // finds the row of its entry by stepping through the row pointers kept in LDS ...
-        {
-            int* ptrs = reinterpret_cast<int*>(uni);           // [m + 1]
-            for (int i = tid; i <= m; i += BC_THREADS) ptrs[i] = prowptr[p.row0 + i];
-            for (int64_t e = tid; e < (int64_t)m * n; e += BC_THREADS) W[e] = 0.0;
-            __syncthreads();
-            const int e0 = ptrs[0], e1 = ptrs[m];
-            int r = 0;
-            constexpr int U = 8;
-            for (int e = e0 + tid; e < e1; e += U * BC_THREADS) {
-                // (indices clamped instead of predicated loads: every value is defined on every path)
-                int cc[U]; int64_t pm[U]; double vv[U];
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    int ee = e + u * BC_THREADS; if (ee > e1 - 1) ee = e1 - 1;
-                    cc[u] = pcol[ee]; pm[u] = pmap[ee];
-                }
-#pragma unroll
-                for (int u = 0; u < U; ++u) vv[u] = vals[pm[u]];
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const int ee = e + u * BC_THREADS;
-                    if (ee < e1) {
-                        while (ee >= ptrs[r + 1]) ++r;
-                        const int c = cc[u] - p.col0;
-                        if (c >= 0 && c < n) W[(int64_t)r * n + c] = vv[u];
-                    }
-                }
-            }
-            __syncthreads();
-        }
+        // ---- Ji = pmat.block(row0, col0, m, n).toDense() (:458, :503) was written by bb_scatter_kernel into the panel's
+        // own storage (the factorisation works in place there: what is left below the diagonal is Y) ...
+        double* W = y_vals + p.y_off;
         // ... with its top-left corner replaced by the leftover block of the previous panel (:504-506)
         for (int e = tid; e < p.lo_rows * p.lo_cols; e += BC_THREADS) {
             const int i = e / p.lo_cols, j = e - i * p.lo_cols;
@@ -601,15 +609,15 @@ bb_chain2_kernel(const BBPanel* __restrict__ panels, int num_panels, const int32
         // next to its T and the partial sums (m <= ~470), else of 16
         if ((int64_t)32 * (m | 1) + bb_qr_aux_doubles(32) <= (int64_t)uni_doubles) {
 #ifdef QRK_BB_PROF
-            bb_panel_qr<32>(W, y_vals + p.y_off, m, n, qt);
+            bb_panel_qr<32>(W, m, n, qt);
 #else
-            bb_panel_qr<32>(W, y_vals + p.y_off, m, n);
+            bb_panel_qr<32>(W, m, n);
 #endif
         } else {
 #ifdef QRK_BB_PROF
-            bb_panel_qr<16>(W, y_vals + p.y_off, m, n, qt);
+            bb_panel_qr<16>(W, m, n, qt);
 #else
-            bb_panel_qr<16>(W, y_vals + p.y_off, m, n);
+            bb_panel_qr<16>(W, m, n);
 #endif
         }
         __syncthreads();
@@ -639,7 +647,7 @@ bb_chain2_kernel(const BBPanel* __restrict__ panels, int num_panels, const int32
                 lo[e] = (vr <= vc && vr < m && vc < n) ? W[(int64_t)vr * n + vc] : 0.0;
             }
         }
-        // (Y = unit-lower essentials (:471-475) was written by bb_panel_qr, block by block)
+        // (Y = unit-lower essentials (:471-475) is the part of the panel below the diagonal: nothing to write)
         __syncthreads();
 
         BB_TICK(2);
@@ -709,8 +717,8 @@ bb_t_kernel(const BBPanel* __restrict__ panels, int num_panels, const double* __
         for (int r0 = 0; r0 < m; r0 += BC_RC) {
             __syncthreads();
             for (int e = tid; e < BC_RC * n16; e += BC_THREADS) {
-                const int il = e % BC_RC, j = e / BC_RC, i = r0 + il;
-                ys[il * ysld + j] = (i < m && j < n) ? Y[(int64_t)j * m + i] : 0.0;
+                const int il = e / n16, j = e - il * n16, i = r0 + il;      // unit-lower view of the packed panel
+                ys[il * ysld + j] = (i >= m || j >= n || i < j) ? 0.0 : (i == j ? 1.0 : Y[(int64_t)i * n + j]);
             }
             __syncthreads();
 #pragma unroll
@@ -919,11 +927,12 @@ bb_apply_q_kernel(const BBPanel* __restrict__ panels, int num_panels, const doub
             const double* T = t_vals + p.t_off;
             for (int i = tid; i < m; i += BB_THREADS) seg[i] = x[i < n ? p.yrow + i : seg2 + (i - n)];
             __syncthreads();
-            for (int j = wave; j < n; j += BB_WAVES) {
-                double d = 0.0;
-                for (int i = lane; i < m; i += 64) d = fma(Y[(int64_t)j * m + i], seg[i], d);
-                d = bb_wave_sum(d);
-                if (lane == 0) w1[j] = d;
+            // Y = unit-lower view of the packed panel (row-major m x n): w1 = Y^T seg, a thread per column
+            for (int j = tid; j < n; j += BB_THREADS) {
+                double d = j < m ? seg[j] : 0.0;
+#pragma unroll 8
+                for (int i = j + 1; i < m; ++i) d = fma(Y[(int64_t)i * n + j], seg[i], d);
+                w1[j] = d;
             }
             __syncthreads();
             for (int i = tid; i < n; i += BB_THREADS) {
@@ -933,10 +942,12 @@ bb_apply_q_kernel(const BBPanel* __restrict__ panels, int num_panels, const doub
                 w2[i] = d;
             }
             __syncthreads();
-            for (int i = tid; i < m; i += BB_THREADS) {
-                double d = seg[i];
-                for (int j = 0; j < n; ++j) d = fma(Y[(int64_t)j * m + i], w2[j], d);
-                x[i < n ? p.yrow + i : seg2 + (i - n)] = d;
+            for (int i = wave; i < m; i += BB_WAVES) {          // seg += Y w2, a wave per row
+                const int je = i < n ? i : n;                    // columns left of the diagonal
+                double d = 0.0;
+                for (int j = lane; j < je; j += 64) d = fma(Y[(int64_t)i * n + j], w2[j], d);
+                d = bb_wave_sum(d);
+                if (lane == 0) x[i < n ? p.yrow + i : seg2 + (i - n)] = seg[i] + d + (i < n ? w2[i] : 0.0);
             }
             __syncthreads();
         }
@@ -957,8 +968,10 @@ hipError_t launch_bb_chain(const BBPanel* panels, int num_panels, const int32_t*
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(bb_chain2_kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem2);
         if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(bb_scatter_kernel, dim3((unsigned)num_panels), dim3(BC_THREADS),
+                           (size_t)(max_act_rows + 2) * sizeof(int), stream, panels, prowptr, pcol, pmap, vals, y_vals);
         hipLaunchKernelGGL(bb_chain2_kernel, dim3(1), dim3(BC_THREADS), smem2, stream, panels, num_panels, prowptr, pcol, pmap,
-                           vals, W, lo, y_vals, t_vals, r_stage, max_act_rows, max_ncols, uni_doubles);
+                           vals, lo, y_vals, t_vals, r_stage, max_act_rows, max_ncols, uni_doubles);
         const size_t smem_t = bb_t_smem(max_ncols, &t_in_lds);
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(bb_t_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)smem_t);
