@@ -879,7 +879,7 @@ size_t bb_chain2_smem(int max_act_rows, int* uni_doubles)
     const size_t fixed = (size_t)(BC_CW + 8) * sizeof(double);
     const size_t qr = ((size_t)16 * (max_act_rows | 1) + bb_qr_aux_doubles(16)) * sizeof(double);
     *uni_doubles = 0;
-    if (fixed + qr > all) return 0;
+    if (fixed + qr > all || max_act_rows > 1024) return 0;      // (bb_panel_qr<16> keeps 16 x 64 rows of a column per wave)
     *uni_doubles = (int)((all - fixed) / sizeof(double));
     return all;
 }

@@ -124,3 +124,51 @@ def test_hip_banded_matches_oracle(num_vars, overlap, shuffle, suggested):
     b = np.random.default_rng(1).uniform(-1, 1, n)
     assert rel_fro(D[:m] * qr.applyQt(b)[:m], orc.bb_apply_q(ref, b, transpose=True)[:m]) <= 1e-11   # range part of Q^T b
     assert rel_fro(qr.solve((J @ x)[inv]), x) <= 1e-9                             # LS recovery  (:255)
+
+
+def strip_matrix(num_strips, strip_rows, strip_cols, step_cols, seed=3):
+    """Dense strips of strip_rows x strip_cols, strip i at rows strip_rows*i, columns step_cols*i (BASELINE configs[2]
+    uses 256 x 192 strips stepping by 64 columns: SURVEY.md section 8d)."""
+    rng = np.random.default_rng(seed)
+    ncols = step_cols * num_strips
+    rows, cols = [], []
+    for i in range(num_strips):
+        w = min(strip_cols, ncols - step_cols * i)
+        r, c = np.meshgrid(np.arange(strip_rows * i, strip_rows * i + strip_rows), np.arange(step_cols * i, step_cols * i + w),
+                           indexing="ij")
+        rows.append(r.ravel()); cols.append(c.ravel())
+    rows = np.concatenate(rows); cols = np.concatenate(cols)
+    J = sp.csr_matrix((rng.uniform(0.5, 5.0, len(rows)), (rows, cols)), shape=(strip_rows * num_strips, ncols))
+    J.sort_indices()
+    return J
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("strip_rows,env", [(256, None), (256, "QRK_BB_T_GLOBAL"), (256, "QRK_BB_CHAIN_V1"), (600, None)])
+def test_hip_banded_baseline_shaped_panels(strip_rows, env, monkeypatch):
+    """Panels of the BASELINE configs[2] shape (448 x 192 after merging: the 32-column blocks of the chain kernel), taller
+    ones (16-column blocks), and the two fall-back paths, against the oracle and the reference's invariants."""
+    import qrkit_amd
+    if env:
+        monkeypatch.setenv(env, "1")
+    J = strip_matrix(6, strip_rows, 192, 64)
+    ref = orc.bb_factorize(J, 2)
+    qr = qrkit_amd.BandedBlockedSparseQR(suggestedBlockCols=2)
+    qr.compute(J)
+    np.testing.assert_array_equal(qr.blocks, ref.blocks)
+    assert max(int(b[2]) for b in qr.blocks) >= strip_rows and max(int(b[3]) for b in qr.blocks) == 192
+    R = qr.matrixR()
+    np.testing.assert_array_equal(R.indptr, ref.R.indptr)
+    np.testing.assert_array_equal(R.indices, ref.R.indices)
+    assert rel_fro(R.toarray(), ref.R.toarray()) <= 1e-12
+    for k in (0, len(ref.yty) - 1):
+        Y, T, row, nz = qr.blockYTY(k)
+        Yo, To, rowo, nzo = ref.yty[k]
+        assert (row, nz) == (rowo, nzo)
+        assert rel_fro(Y, Yo) <= 1e-12 and rel_fro(T, To) <= 1e-12
+    n, m = J.shape
+    Jd = J.toarray(); Rd = R.toarray()
+    assert rel_fro(qr.applyQ(Rd), Jd) <= 1e-12                                    # Q R = J   (:251)
+    assert rel_fro(qr.applyQt(Jd), Rd) <= 1e-12                                   # Q^T J = R (:252)
+    x = np.random.default_rng(0).uniform(-1, 1, m)
+    assert rel_fro(qr.solve(J @ x), x) <= 1e-10                                   # LS recovery (:255)
