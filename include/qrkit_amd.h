@@ -213,8 +213,10 @@ qrk_status qrk_bb_analyze_host(int32_t rows, int32_t cols, const int32_t* csr_ro
                                int32_t* row_perm, int32_t* has_row_perm);
 
 /* num_blocks merged blocks; nnz_r entries of m_R (explicit zeros of the emitted rows included, :487-491);
- * y_len / t_len doubles of the implicit Q: per block Y (activeRows x numCols, unit lower, column-major)
- * and T (numCols x numCols, upper, NEGATED as the reference stores it, :477); has_row_perm as
+ * y_len / t_len doubles of the implicit Q: per block the panel factorised in place (activeRows x numCols,
+ * ROW-major; Y of the reference's BlockYTY, :471-475, is its unit-lower view - the diagonal and what lies
+ * above it are to be ignored) and T (numCols x numCols, upper, column-major, NEGATED as the reference stores
+ * it, :477); has_row_perm as
  * AsBandedAsPossible::hasPermutation. */
 qrk_status qrk_bb_plan_info(qrk_bb_plan plan, int32_t* num_blocks, int64_t* nnz_r, int64_t* y_len,
                             int64_t* t_len, int32_t* has_row_perm);

@@ -30,7 +30,7 @@ struct BBPanel {
     int32_t lo_from;    // V.block(lo_from, lo_from, lo_rows, lo_cols) of the previous panel
     int32_t yrow;       // BlockYTY row index (= idxCol)
     int32_t num_zeros;  // BlockYTY zero gap between its two row segments
-    int64_t y_off;      // offset of Y (act_rows x ncols, column-major) in y_vals
+    int64_t y_off;      // offset of the panel (act_rows x ncols, row-major; Y = its unit-lower view) in y_vals
     int64_t t_off;      // offset of T (ncols x ncols, column-major, negated) in t_vals
     int64_t r_off;      // offset of the emitted R rows (solved x ncols, column-major) in the staging array
 };
