@@ -196,6 +196,9 @@ __device__ __forceinline__ double bb_wave_sum_dpp(double v)
 }
 
 typedef double bb_d4 __attribute__((ext_vector_type(4)));
+#ifndef QRK_BB_ABL
+#define QRK_BB_ABL 0      // timing experiments only (wrong results): 1 = no MFMA in the block update, 2 = no W loads, 4 = no W stores
+#endif
 
 // sqrt and reciprocal without the FP64 division sequences (as in bdqr_pair.hip: v_rsq / v_rcp seeds, <= 1 ulp)
 __device__ __forceinline__ double bb_sqrt_pos(double x)
@@ -446,7 +449,7 @@ __device__ __attribute__((noinline)) void bb_panel_qr(double* __restrict__ W, co
 #pragma unroll
                     for (int u = 0; u < U; ++u) {
                         const int row = 4 * (k + u) + kq;
-                        bv[u] = (k + u < k1 && row < mr && cok) ? wcol[(int64_t)row * n] : 0.0;
+                        bv[u] = (QRK_BB_ABL & 2) ? (double)row : ((k + u < k1 && row < mr && cok) ? wcol[(int64_t)row * n] : 0.0);
                     }
 #pragma unroll
                     for (int u = 0; u < U; ++u) {
@@ -454,11 +457,13 @@ __device__ __attribute__((noinline)) void bb_panel_qr(double* __restrict__ W, co
                             int row = 4 * (k + u) + kq; if (row > mr - 1) row = mr - 1;
 #pragma unroll
                             for (int t = 0; t < MT; ++t)
+                                if (QRK_BB_ABL & 1) acc[t][0] += bv[u]; else
                                 acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(blk[(16 * t + l15) * ld + row], bv[u], acc[t], 0, 0, 0);
                         }
                     }
                 }
             }
+            BB_QTICK(4);
             if (P > 1) {                       // partial sums of the row parts, added in a fixed order
                 for (int pp = 0; pp < P; ++pp) {
                     if (act && part == pp) {
@@ -479,6 +484,7 @@ __device__ __attribute__((noinline)) void bb_panel_qr(double* __restrict__ W, co
                         for (int z = 0; z < 4; ++z) acc[t][z] = red[((strip * MT + t) * 4 + z) * 64 + ln];
                 }
             }
+            BB_QTICK(5);
             if (act) {
                 // u = -T^T w: the result layout D[row = (lane >> 4) + 4 z][col = lane & 15] of tile t is the B operand
                 // [k = lane >> 4][col] of the k-step 4 t + z
@@ -491,6 +497,7 @@ __device__ __attribute__((noinline)) void bb_panel_qr(double* __restrict__ W, co
                         uu[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(tb[(4 * ks + kq) * OB + 16 * t + l15], acc[ks >> 2][ks & 3], uu[t], 0, 0, 0);
                     uu[t] = -uu[t];
                 }
+                BB_QTICK(6);
                 const int RT = (mr + 15) >> 4;
                 const int t0 = part * RT / P, t1 = (part + 1) * RT / P;
                 constexpr int UT = 4;
@@ -501,7 +508,7 @@ __device__ __attribute__((noinline)) void bb_panel_qr(double* __restrict__ W, co
 #pragma unroll
                         for (int z = 0; z < 4; ++z) {
                             const int row = 16 * (rt + u) + kq + 4 * z;
-                            dv[u][z] = (rt + u < t1 && row < mr && cok) ? wcol[(int64_t)row * n] : 0.0;
+                            dv[u][z] = (QRK_BB_ABL & 2) ? (double)row : ((rt + u < t1 && row < mr && cok) ? wcol[(int64_t)row * n] : 0.0);
                         }
 #pragma unroll
                     for (int u = 0; u < UT; ++u) {
@@ -509,19 +516,21 @@ __device__ __attribute__((noinline)) void bb_panel_qr(double* __restrict__ W, co
                             int arow = 16 * (rt + u) + l15; if (arow > mr - 1) arow = mr - 1;
 #pragma unroll
                             for (int ks = 0; ks < 4 * MT; ++ks)
+                                if (QRK_BB_ABL & 1) dv[u][0] += uu[ks >> 2][ks & 3]; else
                                 dv[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(blk[(4 * ks + kq) * ld + arow], uu[ks >> 2][ks & 3], dv[u], 0, 0, 0);
 #pragma unroll
                             for (int z = 0; z < 4; ++z) {
                                 const int row = 16 * (rt + u) + kq + 4 * z;
-                                if (row < mr && cok) wcol[(int64_t)row * n] = dv[u][z];
+                                if (row < mr && cok && !((QRK_BB_ABL & 4) && dv[u][z] != 12345.678)) wcol[(int64_t)row * n] = dv[u][z];
                             }
                         }
                     }
                 }
             }
+            BB_QTICK(7);
             __syncthreads();
+            BB_QTICK(3);
         }
-        BB_QTICK(3);
     }
 #undef BB_QTICK
 }
@@ -582,7 +591,7 @@ bb_chain2_kernel(const BBPanel* __restrict__ panels, int num_panels, const int32
     double* uni = sc + 8;                      // the blocked QR's (bb_panel_qr); a tile of R rows on the way out
     const int tid = threadIdx.x;
 #ifdef QRK_BB_PROF
-    unsigned long long pt[6] = {0, 0, 0, 0, 0, 0}, t0 = 0, qt[4] = {0, 0, 0, 0};
+    unsigned long long pt[6] = {0, 0, 0, 0, 0, 0}, t0 = 0, qt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #define BB_TICK(n) do { const unsigned long long t1 = __builtin_amdgcn_s_memtime(); pt[n] += t1 - t0; t0 = t1; } while (0)
 #else
 #define BB_TICK(n) do { } while (0)
@@ -662,7 +671,7 @@ bb_chain2_kernel(const BBPanel* __restrict__ panels, int num_panels, const int32
         if (pi == num_panels - 1 && tid == 0) {
             double* T = t_vals + p.t_off;
             for (int z = 0; z < 6; ++z) T[z] = (double)pt[z];
-            for (int z = 0; z < 4; ++z) T[6 + z] = (double)qt[z];
+            for (int z = 0; z < 8; ++z) T[6 + z] = (double)qt[z];
         }
 #endif
     }

@@ -37,6 +37,6 @@ xs = qr.solve(b)
 print("LS recovery rel. error", np.linalg.norm(xs - x) / np.linalg.norm(x))
 if os.environ.get("QRK_BB_PROF"):
     n = int(qr.blocks[-1][3])
-    tv = qr._t[qr._tlen - n * n: qr._tlen - n * n + 10].cpu().numpy()
-    names = ["scatter+leftover", "householder QR", "R/leftover/Y out", "Gram Y^T Y", "T recurrence + write", "  (of QR: step heads incl. x' build)", "  QR A load sub-panel", "  QR B sub-panel QR", "  QR C+D store, larft", "  QR E trailing update"]
+    tv = qr._t[qr._tlen - n * n: qr._tlen - n * n + 14].cpu().numpy()
+    names = ["scatter+leftover", "householder QR", "R/leftover/Y out", "Gram Y^T Y", "T recurrence + write", "  (of QR: step heads incl. x' build)", "  QR A load sub-panel", "  QR B sub-panel QR", "  QR C+D store, larft", "  QR E (barrier waits)", "   E pass 1 w = V^T W", "   E reduce over row parts", "   E u = -T^T w", "   E pass 2 W += V u"]
     print("per panel (us at 100 MHz s_memtime? ticks / panels):", {k: round(float(v) / nb, 1) for k, v in zip(names, tv)})
