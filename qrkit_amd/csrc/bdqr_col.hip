@@ -81,26 +81,31 @@ __device__ __forceinline__ Cand wave_best(Cand c)
 // Everything of one tile.  Called once with W in LDS and once with W in global memory, so that after
 // inlining hipcc knows the address space of every access: through one generic pointer it has to assume
 // that a store to W may alias the LDS vectors and serialises the sweeps on the store latency.
-template <int CT, bool BLOCKED>
+template <int CT, bool BLOCKED, bool DYN>
 __device__ __forceinline__ void factor_tile(double* __restrict__ W, double* smem, int r, int c, int cbase, int pivoting,
                                             const double* __restrict__ src, double* __restrict__ Q,
                                             double* __restrict__ rv, int32_t* __restrict__ perm,
-                                            double* __restrict__ hcoeffs)
+                                            double* __restrict__ hcoeffs, const int w_lds_dyn, const int max_r_dyn)
 {
+    // LDS carve-up.  DYN (launches of tiles with at most 64 columns): w_lds doubles for A of the tiles that fit and
+    // vectors of max_r rows, the largest tile of the launch - small tiles then leave room for many workgroups per
+    // CU.  Otherwise the fixed layout (two workgroups per CU): the offsets are then compile-time constants, which
+    // is worth 5-8 % on the large tiles.
     using namespace col;
+    const int w_lds = DYN ? w_lds_dyn : W_LDS_DOUBLES, max_r = DYN ? max_r_dyn : MAXR;
     constexpr int NW = CT / 64;
-    double* vs = smem + W_LDS_DOUBLES;                   // [MAXR * NB] V panel of phase 2, row-major
-    double* xv0 = vs + MAXR * NB;                        // [MAXR] pivot column, even steps
-    double* xv1 = xv0 + MAXR;                            // [MAXR] odd steps
-    double* taus = xv1 + MAXR;                           // [MAXR] Householder coefficients
-    double* gm = taus + MAXR;                            // [NB * NB] V^T V of a panel
+    double* vs = smem + w_lds;                           // [max_r * NB] V panel of phase 2, row-major
+    double* xv0 = vs + max_r * NB;                       // [max_r] pivot column, even steps
+    double* xv1 = xv0 + max_r;                           // [max_r] odd steps
+    double* taus = xv1 + max_r;                          // [max_r] Householder coefficients
+    double* gm = taus + max_r;                           // [NB * NB] V^T V of a panel
     double* tm = gm + NB * NB;                           // [NB * NB] T of a panel
     double* cval = tm + NB * NB;                         // [NW] candidates of the waves
     double* cngam = cval + NW;                           // [NW]
     int* cpos = reinterpret_cast<int*>(cngam + NW);      // [NW]
     int* ctid = cpos + NW;                               // [NW]
     int* flags = ctid + NW;                              // [2] any-need flags (double buffered)
-    int* col_of_pos = flags + 2;                         // [MAXR] column chosen at step k
+    int* col_of_pos = flags + 2;                         // [max_r] column chosen at step k
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ld = c;                                    // A row-major: W(i, j) = W[i * ld + j]
     {
@@ -553,7 +558,7 @@ template <int CT>
 __global__ void __launch_bounds__(CT)
 bdqr_col_kernel(WaveBatch nb, const double* __restrict__ tiles, double* __restrict__ q_vals,
                 double* __restrict__ r_vals, int32_t* __restrict__ perm, double* __restrict__ hcoeffs,
-                double* __restrict__ workspace, int64_t ws_stride)
+                double* __restrict__ workspace, int64_t ws_stride, int w_lds, int max_r)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     for (int64_t t = blockIdx.x; t < nb.num_tiles; t += gridDim.x) {
@@ -568,37 +573,63 @@ bdqr_col_kernel(WaveBatch nb, const double* __restrict__ tiles, double* __restri
             toff = t * (int64_t)r * c; qoff = t * (int64_t)r * r; roff = t * (int64_t)(c * (c + 1) / 2);
             cbase = (int)(t * c);
         }
-        if (r * c <= col::W_LDS_DOUBLES)
-            factor_tile<CT, false>(smem, smem, r, c, cbase, nb.pivoting, tiles + toff, q_vals + qoff, r_vals + roff, perm, hcoeffs);
+        constexpr bool DYN = CT == 64;
+        if (r * c <= (DYN ? w_lds : col::W_LDS_DOUBLES))
+            factor_tile<CT, false, DYN>(smem, smem, r, c, cbase, nb.pivoting, tiles + toff, q_vals + qoff, r_vals + roff, perm, hcoeffs,
+                                        w_lds, max_r);
         else
-            factor_tile<CT, QRK_COL_BLOCKED != 0>(workspace + (int64_t)blockIdx.x * ws_stride, smem, r, c, cbase, nb.pivoting, tiles + toff,
-                            q_vals + qoff, r_vals + roff, perm, hcoeffs);
+            factor_tile<CT, QRK_COL_BLOCKED != 0, DYN>(workspace + (int64_t)blockIdx.x * ws_stride, smem, r, c, cbase, nb.pivoting,
+                                                       tiles + toff, q_vals + qoff, r_vals + roff, perm, hcoeffs, w_lds, max_r);
     }
 }
 
-size_t bdqr_col_smem_bytes(int threads)
+size_t bdqr_col_smem_bytes(int threads, int w_lds, int max_r)
 {
     const int nw = threads / 64;
-    return (size_t)(col::W_LDS_DOUBLES + col::MAXR * col::NB + 3 * col::MAXR + 2 * col::NB * col::NB + 2 * nw) * sizeof(double) +
-           (size_t)(2 * nw + 2 + col::MAXR) * sizeof(int) + 16;
+    if (threads > 64) { w_lds = col::W_LDS_DOUBLES; max_r = col::MAXR; }       // fixed layout (see factor_tile)
+    return (size_t)(w_lds + max_r * col::NB + 3 * max_r + 2 * col::NB * col::NB + 2 * nw) * sizeof(double) +
+           (size_t)(2 * nw + 2 + max_r) * sizeof(int) + 16;
+}
+
+int bdqr_col_threads(int max_cols) { return max_cols <= 64 ? 64 : (max_cols <= 128 ? 128 : 256); }
+
+// LDS doubles for A in a launch whose largest tile holds max_rc entries: the tile itself when it fits the budget of
+// the LDS-resident form, else nothing at all unless smaller tiles of the launch can use it (mixed launches)
+int bdqr_col_w_lds(int64_t max_rc, int64_t max_rc_fitting)
+{
+    if (max_rc <= col::W_LDS_DOUBLES) return (int)max_rc;
+    return (int)max_rc_fitting;     // largest r*c <= W_LDS_DOUBLES present in the launch (0 if none)
+}
+
+// Workgroups of one launch that can be resident per CU (LDS and the 16 waves a CU holds at this kernel's register count)
+int bdqr_col_wgs_per_cu(int max_cols, int w_lds, int max_r)
+{
+    const int threads = bdqr_col_threads(max_cols);
+    const size_t smem = bdqr_col_smem_bytes(threads, w_lds, max_r);
+    int by_lds = (int)((size_t)160 * 1024 / smem), by_waves = 16 / (threads / 64);
+    int n = by_lds < by_waves ? by_lds : by_waves;
+    // tiles wider than 64 columns work mostly in global memory: more than two workgroups per CU only makes them
+    // slower (measured: 256x256 50.0k -> 46.3k tiles/s, 96x96 475k -> 450k at four); the small ones gain (33x33 2.9M -> 5.2M)
+    if (max_cols > 64 && n > 2) n = 2;
+    return n < 1 ? 1 : n;
 }
 
 hipError_t launch_bdqr_col(const WaveBatch& nb, const double* tiles, double* q_vals, double* r_vals, int32_t* perm,
                            double* hcoeffs, double* workspace, int64_t ws_stride, int num_wg, int max_rows,
-                           int max_cols, hipStream_t stream)
+                           int max_cols, int w_lds, hipStream_t stream)
 {
     if (nb.num_tiles <= 0) return hipSuccess;
-    if (max_rows > col::MAXR || max_cols > max_rows) return hipErrorInvalidValue;
+    if (max_rows > col::MAXR || max_cols > max_rows || w_lds > col::W_LDS_DOUBLES) return hipErrorInvalidValue;
     const int64_t want = nb.num_tiles < (int64_t)num_wg ? nb.num_tiles : (int64_t)num_wg;
-    const int threads = max_cols <= 64 ? 64 : (max_cols <= 128 ? 128 : 256);
-    const size_t smem = bdqr_col_smem_bytes(threads);
+    const int threads = bdqr_col_threads(max_cols);
+    const size_t smem = bdqr_col_smem_bytes(threads, w_lds, max_rows);
 #define QRK_COL_LAUNCH(T)                                                                                   \
     do {                                                                                                    \
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(bdqr_col_kernel<T>),               \
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);          \
         if (e != hipSuccess) return e;                                                                      \
         hipLaunchKernelGGL((bdqr_col_kernel<T>), dim3((unsigned)want), dim3(T), smem, stream, nb, tiles, q_vals, \
-                           r_vals, perm, hcoeffs, workspace, ws_stride);                                    \
+                           r_vals, perm, hcoeffs, workspace, ws_stride, w_lds, max_rows);                   \
     } while (0)
     if (threads == 64) QRK_COL_LAUNCH(64);
     else if (threads == 128) QRK_COL_LAUNCH(128);

@@ -31,6 +31,9 @@ struct qrk_context_s {
     int num_cus = 256;
     int pair_wgs_per_cu = 8;       // resident pair-kernel workgroups per CU: 2 waves per SIMD (232 VGPRs, 20 KB LDS each)
     bool use_pair_kernel = true;   // two tiles per wavefront (bdqr_pair.hip); QRK_KERNEL=wave selects bdqr_wave.hip
+    // side streams for the size classes of a mixed batch (fork after / join into `stream`), created on first use
+    hipStream_t side[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
     std::string error;
 };
 
@@ -56,12 +59,18 @@ struct qrk_bd_plan_s {
     int64_t ws_stride = 0;
     int num_wg = 0;
     // mid-size tiles (32 < max dim <= QRK_COL_MAX_DIM): one thread per column of [A | Q^T] (bdqr_col.hip)
-    int32_t* d_col_ids = nullptr;    // mixed batches: their tile ids, largest first
+    // in three size classes (columns <= 64, <= 128, <= 256), one launch each: the LDS of a launch is carved for the
+    // largest tile of its class, so that small tiles run with many workgroups per CU
+    struct ColClass {
+        int64_t off = 0, n = 0;          // range of d_col_ids (mixed batches), largest tiles first
+        int64_t ws_stride = 0;           // max rows * cols
+        int64_t ws_off = 0;              // this class's part of d_col_workspace (the classes run concurrently)
+        int64_t max_rc_fitting = 0;      // largest rows * cols that fits the LDS-resident form
+        int max_rows = 0, max_cols = 0, w_lds = 0, num_wg = 0;
+    } col_cls[3];
+    int32_t* d_col_ids = nullptr;
     int64_t n_col = 0;
-    double* d_col_workspace = nullptr;
-    int64_t col_ws_stride = 0;       // max rows * cols over those tiles
-    int num_col_wg = 0;
-    int col_max_rows = 0, col_max_ld = 0;   // largest rows / largest cols of those tiles
+    double* d_col_workspace = nullptr;   // one part per class
 };
 
 struct qrk_bb_plan_s {
@@ -169,10 +178,11 @@ qrk_status enqueue_factorize(qrk_bd_plan_s* p, const double* tiles, double* q, d
         const bool full32 = p->r == 32 && p->c == 32 &&
                             ((reinterpret_cast<uintptr_t>(tiles) | reinterpret_cast<uintptr_t>(q) |
                               reinterpret_cast<uintptr_t>(r)) & 15u) == 0;
-        if (p->max_dim > 32 && p->max_dim <= QRK_COL_MAX_DIM)
-            QRK_HIP(h, qrk::launch_bdqr_col(nb, tiles, q, r, perm, hc, p->d_col_workspace, p->col_ws_stride, p->num_col_wg,
-                                            p->col_max_rows, p->col_max_ld, h->stream));
-        else if (p->max_dim > 32)
+        if (p->max_dim > 32 && p->max_dim <= QRK_COL_MAX_DIM) {
+            const auto& k = p->col_cls[0];
+            QRK_HIP(h, qrk::launch_bdqr_col(nb, tiles, q, r, perm, hc, p->d_col_workspace, k.ws_stride, k.num_wg, k.max_rows,
+                                            k.max_cols, k.w_lds, h->stream));
+        } else if (p->max_dim > 32)
             qrk::launch_bdqr_wg(nb, tiles, q, r, perm, hc, p->d_workspace, p->ws_stride, p->num_wg, p->max_dim, h->stream);
         else if (h->use_pair_kernel) qrk::launch_bdqr_pair(nb, full32, tiles, q, r, perm, hc, h->num_cus * h->pair_wgs_per_cu, h->stream);
         else qrk::launch_bdqr_wave(nb, full32, tiles, q, r, perm, hc, max_blocks, h->stream);
@@ -182,11 +192,29 @@ qrk_status enqueue_factorize(qrk_bd_plan_s* p, const double* tiles, double* q, d
         nb.q_off = p->d_qoff; nb.r_off = p->d_roff; nb.c_off = p->d_coff;
         if (h->use_pair_kernel) qrk::launch_bdqr_pair(nb, false, tiles, q, r, perm, hc, h->num_cus * h->pair_wgs_per_cu, h->stream);
         else qrk::launch_bdqr_wave(nb, false, tiles, q, r, perm, hc, max_blocks, h->stream);
+        // the size classes are independent of each other and of the small tiles above: each on its own side stream
+        // (forked after what is already queued on the caller's stream, joined back below), so that the tail of one
+        // launch overlaps the others
         if (p->n_col > 0) {
-            qrk::WaveBatch cb = nb;
-            cb.num_tiles = p->n_col; cb.tile_ids = p->d_col_ids;
-            QRK_HIP(h, qrk::launch_bdqr_col(cb, tiles, q, r, perm, hc, p->d_col_workspace, p->col_ws_stride, p->num_col_wg,
-                                            p->col_max_rows, p->col_max_ld, h->stream));
+            if (!h->ev_fork) {
+                QRK_HIP(h, hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+                for (int z = 0; z < 3; ++z) {
+                    QRK_HIP(h, hipStreamCreateWithFlags(&h->side[z], hipStreamNonBlocking));
+                    QRK_HIP(h, hipEventCreateWithFlags(&h->ev_join[z], hipEventDisableTiming));
+                }
+            }
+            QRK_HIP(h, hipEventRecord(h->ev_fork, h->stream));
+            for (int z = 2; z >= 0; --z) {            // (largest class first)
+                const auto& k = p->col_cls[z];
+                if (k.n <= 0) continue;
+                qrk::WaveBatch cb = nb;
+                cb.num_tiles = k.n; cb.tile_ids = p->d_col_ids + k.off;
+                QRK_HIP(h, hipStreamWaitEvent(h->side[z], h->ev_fork, 0));
+                QRK_HIP(h, qrk::launch_bdqr_col(cb, tiles, q, r, perm, hc, p->d_col_workspace + k.ws_off, k.ws_stride, k.num_wg,
+                                                k.max_rows, k.max_cols, k.w_lds, h->side[z]));
+                QRK_HIP(h, hipEventRecord(h->ev_join[z], h->side[z]));
+                QRK_HIP(h, hipStreamWaitEvent(h->stream, h->ev_join[z], 0));
+            }
         }
         if (p->n_wg > 0) {
             qrk::WaveBatch lb = nb;
@@ -248,6 +276,13 @@ qrk_status qrk_create(qrk_handle* out, int device, void* stream)
 
 qrk_status qrk_destroy(qrk_handle h)
 {
+    if (h) {
+        for (int z = 0; z < 3; ++z) {
+            if (h->side[z]) (void)hipStreamDestroy(h->side[z]);
+            if (h->ev_join[z]) (void)hipEventDestroy(h->ev_join[z]);
+        }
+        if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    }
     delete h;
     return QRK_STATUS_OK;
 }
@@ -289,7 +324,7 @@ qrk_status qrk_bd_plan_create(qrk_handle h, const qrk_bd_layout* L, qrk_q_format
 
     const int64_t B = p->B;
     int64_t sum_rows = 0, sum_cols = 0;
-    std::vector<int32_t> coff, rowoff, wave_ids, wg_ids, col_ids;
+    std::vector<int32_t> coff, rowoff, wave_ids, wg_ids, col_ids, col_bin[3];
     int64_t ws_stride = 0;
     std::vector<int64_t> toff, qoff, roff;
     if (p->uniform) {
@@ -303,8 +338,9 @@ qrk_status qrk_bd_plan_create(qrk_handle h, const qrk_bd_layout* L, qrk_q_format
         p->max_dim = p->r > p->c ? p->r : p->c;
         if (p->max_dim > QRK_COL_MAX_DIM) ws_stride = (int64_t)p->r * p->c;
         else if (p->max_dim > 32 && !p->landscape) {
-            p->col_ws_stride = (int64_t)p->r * p->c;
-            p->col_max_rows = p->r; p->col_max_ld = p->c;
+            auto& k = p->col_cls[0];
+            k.n = B; k.ws_stride = (int64_t)p->r * p->c; k.max_rows = p->r; k.max_cols = p->c;
+            if (k.ws_stride <= qrk::QRK_COL_W_LDS_MAX) k.max_rc_fitting = k.ws_stride;
         }
     } else {
         coff.resize(B); rowoff.resize(B); toff.resize(B); qoff.resize(B); roff.resize(B);
@@ -322,10 +358,16 @@ qrk_status qrk_bd_plan_create(qrk_handle h, const qrk_bd_layout* L, qrk_q_format
             if (md > p->max_dim) p->max_dim = md;
             if (md <= 32) wave_ids.push_back((int32_t)i);
             else if (md <= QRK_COL_MAX_DIM && r >= c) {
-                col_ids.push_back((int32_t)i);
-                if ((int64_t)r * c > p->col_ws_stride) p->col_ws_stride = (int64_t)r * c;
-                if (r > p->col_max_rows) p->col_max_rows = r;
-                if (c > p->col_max_ld) p->col_max_ld = c;
+                // two classes in use: up to 64 columns (many workgroups per CU), and the rest in ONE launch, largest
+                // first - splitting 65..128 from 129..256 cost 15 % on a mixed 8..256 batch (two tails instead of one)
+                const int z = c <= 64 ? 0 : 2;
+                auto& k = p->col_cls[z];
+                col_bin[z].push_back((int32_t)i);
+                const int64_t rc = (int64_t)r * c;
+                if (rc > k.ws_stride) k.ws_stride = rc;
+                if (rc <= qrk::QRK_COL_W_LDS_MAX && rc > k.max_rc_fitting) k.max_rc_fitting = rc;
+                if (r > k.max_rows) k.max_rows = r;
+                if (c > k.max_cols) k.max_cols = c;
             }
             else { wg_ids.push_back((int32_t)i); if ((int64_t)r * c > ws_stride) ws_stride = (int64_t)r * c; }
         }
@@ -341,16 +383,29 @@ qrk_status qrk_bd_plan_create(qrk_handle h, const qrk_bd_layout* L, qrk_q_format
         delete p;
         return fail(h, QRK_STATUS_UNSUPPORTED, "qrk_bd_plan_create: tile dimension above 2048 is not supported");
     }
-    if (p->col_ws_stride > 0 && !p->landscape) {
-        // largest tiles first: the grid-stride assignment then ends with the small ones
-        std::stable_sort(col_ids.begin(), col_ids.end(), [&](int32_t a, int32_t b) {
-            return (int64_t)L->rows[a] * L->rows[a] * L->cols[a] > (int64_t)L->rows[b] * L->rows[b] * L->cols[b];
-        });
-        const int64_t n_mid = p->uniform ? B : (int64_t)col_ids.size();
-        int64_t col_wgs = 2 * (int64_t)h->num_cus;
-        if (const char* e = std::getenv("QRK_COL_WGS")) { const long v = std::atol(e); if (v > 0) col_wgs = v; }
-        p->num_col_wg = (int)(n_mid < col_wgs ? n_mid : col_wgs);
-        if (hipMalloc((void**)&p->d_col_workspace, (size_t)p->num_col_wg * (size_t)p->col_ws_stride * sizeof(double)) != hipSuccess) {
+    if (!p->landscape) {
+        size_t ws_doubles = 0;
+        for (int z = 0; z < 3; ++z) {
+            auto& k = p->col_cls[z];
+            if (!p->uniform) {
+                // largest tiles first: the grid-stride assignment then ends with the small ones
+                std::stable_sort(col_bin[z].begin(), col_bin[z].end(), [&](int32_t a, int32_t b) {
+                    return (int64_t)L->rows[a] * L->rows[a] * L->cols[a] > (int64_t)L->rows[b] * L->rows[b] * L->cols[b];
+                });
+                k.off = (int64_t)col_ids.size(); k.n = (int64_t)col_bin[z].size();
+                col_ids.insert(col_ids.end(), col_bin[z].begin(), col_bin[z].end());
+            }
+            if (k.n <= 0 || k.ws_stride <= 0) { k.n = p->uniform ? k.n : 0; continue; }
+            k.w_lds = qrk::bdqr_col_w_lds(k.ws_stride, k.max_rc_fitting);
+            int64_t wgs = (int64_t)h->num_cus * qrk::bdqr_col_wgs_per_cu(k.max_cols, k.w_lds, k.max_rows);
+            if (const char* e = std::getenv("QRK_COL_WGS")) { const long v = std::atol(e); if (v > 0) wgs = v; }
+            k.num_wg = (int)(k.n < wgs ? k.n : wgs);
+            if (k.ws_stride > k.w_lds) {       // some tile of the class works in global memory
+                k.ws_off = (int64_t)ws_doubles;
+                ws_doubles += (size_t)k.num_wg * (size_t)k.ws_stride;
+            }
+        }
+        if (ws_doubles > 0 && hipMalloc((void**)&p->d_col_workspace, ws_doubles * sizeof(double)) != hipSuccess) {
             delete p;
             return fail(h, QRK_STATUS_ALLOC_FAILED, "qrk_bd_plan_create: cannot allocate the mid-size-tile workspace");
         }

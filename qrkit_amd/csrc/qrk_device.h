@@ -49,9 +49,13 @@ void launch_bdqr_pair(const WaveBatch& nb, bool full32, const double* tiles, dou
                       double* r_vals, int32_t* perm, double* hcoeffs, int max_blocks,
                       hipStream_t stream);
 // Mid-size tiles (32 < max(rows, cols) <= 256, rows >= cols): one thread per column of A, blocked Q (bdqr_col.hip).
+// One launch serves one size class (columns <= 64, <= 128, <= 256): its LDS is carved for the largest tile of the class.
 hipError_t launch_bdqr_col(const WaveBatch& nb, const double* tiles, double* q_vals, double* r_vals, int32_t* perm,
                            double* hcoeffs, double* workspace, int64_t ws_stride, int num_wg, int max_rows,
-                           int max_cols, hipStream_t stream);
+                           int max_cols, int w_lds, hipStream_t stream);
+int bdqr_col_w_lds(int64_t max_rc, int64_t max_rc_fitting);
+int bdqr_col_wgs_per_cu(int max_cols, int w_lds, int max_r);
+constexpr int QRK_COL_W_LDS_MAX = 4608;     // doubles of LDS for A in the LDS-resident form (bdqr_col.hip)
 void launch_bdqr_wg(const WaveBatch& nb, const double* tiles, double* q_vals, double* r_vals, int32_t* perm,
                     double* hcoeffs, double* workspace, int64_t ws_stride, int num_wg, int max_dim,
                     hipStream_t stream);
