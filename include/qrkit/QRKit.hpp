@@ -461,8 +461,13 @@ class BandedBlockedSparseQR {
     // x = R(0:rank,0:rank)^-1 y(0:rank); the column permutation is the identity.
     Vector solve(const Vector& B) const {
         assert(m_isInitialized && "The factorization should be called first, use compute()");
-        const Vector y = applyQt(B);
-        return solveUpperCsc(m_R, m_cols, y);
+        // y = Q^T B, then the back substitution with R, both on the device (qrk_bb_apply_q, qrk_bb_solve_r)
+        Vector y = applyQt(B);
+        const int64_t nrhs = (int64_t)B.size() / m_rows;
+        check(qrk_bb_solve_r(m_plan, y.data(), (int64_t)m_rows, nrhs, QRK_MEM_HOST));
+        Vector x((size_t)(m_cols * nrhs));
+        for (int64_t c = 0; c < nrhs; ++c) std::copy(y.begin() + c * m_rows, y.begin() + c * m_rows + m_cols, x.begin() + c * m_cols);
+        return x;
     }
 
   protected:

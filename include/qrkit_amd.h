@@ -239,6 +239,12 @@ qrk_status qrk_bb_factorize(qrk_bb_plan plan, const double* csr_vals, int64_t nn
 qrk_status qrk_bb_apply_q(qrk_bb_plan plan, const double* y_vals, const double* t_vals, int transpose,
                           double* v, int64_t nrhs, qrk_memspace space);
 
+/* v(0:cols, :) <- R(0:cols, 0:cols).triangularView<Upper>().solve(v(0:cols, :)) in place for nrhs columns (leading
+ * dimension ldv >= cols): the back substitution that ends BandedBlockedSparseQR::_solve_impl
+ * (src/QRKit/BandedBlockedSparseQR.h:290-311, after y = Q^T b).  R is the one of the last qrk_bb_factorize of this
+ * plan (the plan keeps its rows on the device). */
+qrk_status qrk_bb_solve_r(qrk_bb_plan plan, double* v, int64_t ldv, int64_t nrhs, qrk_memspace space);
+
 /* ------------------------------------------------------------- measurement */
 
 /* Launch the factorisation kernel(s) of `plan` `iters` times back to back on the

@@ -144,10 +144,18 @@ class BandedBlockedSparseQR:
     def solve(self, B):
         """_solve_impl (:290-311): y = Q^T B (B already row-permuted by the caller, as in the tests :235);
         x = R(0:rank,0:rank)^-1 y(0:rank); identity column permutation."""
-        import scipy.sparse.linalg as spl
-        y = self.applyQt(B)
-        R = self.matrixR().tocsr()[:self._cols, :]
-        return spl.spsolve_triangular(R, np.asarray(y)[:self._cols], lower=False)
+        was_np = not isinstance(B, torch.Tensor)
+        t = torch.as_tensor(np.asarray(B, dtype=np.float64)) if was_np else B
+        shape = tuple(t.shape)
+        assert shape[0] == self._rows
+        x = t.reshape(self._rows, -1).t().contiguous().to(self._ctx.device, torch.float64)   # [nrhs, rows] = column-major
+        self._ctx.use_current_stream()
+        capi.check(capi.lib().qrk_bb_apply_q(self._plan, self._y.data_ptr(), self._t.data_ptr(), 1, x.data_ptr(), x.shape[0],
+                                             capi.MEM_DEVICE), self._ctx.handle)
+        # back substitution with the banded R on the device (qrk_bb_solve_r), in place in the first cols entries
+        capi.check(capi.lib().qrk_bb_solve_r(self._plan, x.data_ptr(), self._rows, x.shape[0], capi.MEM_DEVICE), self._ctx.handle)
+        out = x[:, :self._cols].t().reshape((self._cols,) + shape[1:])
+        return out.cpu().numpy() if was_np else out.contiguous()
 
     def __del__(self):
         try:

@@ -907,6 +907,69 @@ size_t bb_t_smem(int max_ncols, int* t_in_lds)
     return fixed + uni;
 }
 
+// x(0:cols) = R(0:cols, 0:cols).triangularView<Upper>().solve(v(0:cols)), in place: the last step of
+// BandedBlockedSparseQR::_solve_impl (src/QRKit/BandedBlockedSparseQR.h:290-311).  R is read from the staging array the
+// chain leaves behind (panel p: the dense rows [col0, col0 + solved) x [col0, col0 + ncols), column-major), panels in
+// descending order, 64 rows at a time: the columns to the right of the 64 x 64 diagonal block are a matrix-vector
+// product with entries of x that are already final (256 threads, rows over the lanes: coalesced), the block itself is
+// solved by one wave from LDS (lane = row, the pivot value broadcast with v_readlane).  One workgroup per right-hand
+// side; the chain over the panels is sequential (x of a panel needs the x of the panels after it).
+constexpr int BS_THREADS = 256;
+__global__ void __launch_bounds__(BS_THREADS)
+bb_solve_r_kernel(const BBPanel* __restrict__ panels, int num_panels, const double* __restrict__ r_stage, int cols,
+                  double* __restrict__ v, int64_t ldv)
+{
+    __shared__ double blk[64 * 65];          // diagonal block, blk[j * 65 + i] = R(i, j)
+    __shared__ double part[4 * 64];          // partial sums of the four column groups
+    const int tid = threadIdx.x, ln = tid & 63, grp = tid >> 6;
+    double* x = v + (int64_t)blockIdx.x * ldv;
+    for (int pi = num_panels - 1; pi >= 0; --pi) {
+        const BBPanel p = panels[pi];
+        const int n = p.ncols, sv = p.solved;
+        int ns = sv < n ? sv : n;                        // rows of this panel inside the triangle
+        if (p.col0 + ns > cols) ns = cols - p.col0;
+        if (ns <= 0) continue;
+        const double* R = r_stage + p.r_off;             // R(i, j) = R[j * sv + i]
+        for (int c1 = ns; c1 > 0; c1 -= 64) {            // rows [c0, c1) of the panel, last chunk first
+            const int c0 = c1 > 64 ? c1 - 64 : 0, nr = c1 - c0;
+            __syncthreads();                             // (x of the previous chunk is visible; blk and part are free)
+            // diagonal block to LDS
+            for (int e = tid; e < nr * nr; e += BS_THREADS) {
+                const int j = e / nr, i = e - j * nr;
+                blk[j * 65 + i] = R[(int64_t)(c0 + j) * sv + c0 + i];
+            }
+            // t_i = v_i - sum_{j >= c1} R(i, j) x_j, the columns dealt round-robin to the four waves
+            double acc = 0.0;
+            if (ln < nr) {
+                constexpr int U = 8;
+                for (int j = c1 + grp; j < n; j += 4 * U) {
+                    double rv[U], xv[U];
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const int jj = j + 4 * u, jc = jj < n ? jj : n - 1;
+                        rv[u] = R[(int64_t)jc * sv + c0 + ln];
+                        xv[u] = jj < n ? x[p.col0 + jc] : 0.0;
+                    }
+#pragma unroll
+                    for (int u = 0; u < U; ++u) acc = fma(rv[u], xv[u], acc);
+                }
+            }
+            part[grp * 64 + ln] = acc;
+            __syncthreads();
+            if (grp == 0) {
+                double t = 0.0;
+                if (ln < nr) t = x[p.col0 + c0 + ln] - ((part[ln] + part[64 + ln]) + (part[128 + ln] + part[192 + ln]));
+                for (int i = nr - 1; i >= 0; --i) {      // back substitution inside the block
+                    const double xi = readlane_f64(t, i) / blk[i * 65 + i];
+                    if (ln < i) t = fma(-blk[i * 65 + ln], xi, t);
+                    else if (ln == i) t = xi;
+                }
+                if (ln < nr) x[p.col0 + c0 + ln] = t;
+            }
+        }
+    }
+}
+
 __global__ void __launch_bounds__(256)
 bb_gather_r_kernel(const double* __restrict__ r_stage, const int64_t* __restrict__ r_src, int64_t nnz,
                    double* __restrict__ r_vals)
@@ -1013,6 +1076,14 @@ hipError_t launch_bb_apply_q(const BBPanel* panels, int num_panels, const double
     const unsigned grid = (unsigned)(nrhs < 1024 ? nrhs : 1024);
     hipLaunchKernelGGL(bb_apply_q_kernel, dim3(grid), dim3(BB_THREADS), smem, stream, panels, num_panels, y_vals, t_vals,
                        transpose, v, ldv, nrhs, max_act_rows, max_ncols);
+    return hipGetLastError();
+}
+
+hipError_t launch_bb_solve_r(const BBPanel* panels, int num_panels, const double* r_stage, int cols, double* v, int64_t ldv,
+                             int64_t nrhs, hipStream_t stream)
+{
+    if (nrhs <= 0 || num_panels <= 0) return hipSuccess;
+    hipLaunchKernelGGL(bb_solve_r_kernel, dim3((unsigned)nrhs), dim3(BS_THREADS), 0, stream, panels, num_panels, r_stage, cols, v, ldv);
     return hipGetLastError();
 }
 

@@ -80,6 +80,7 @@ struct qrk_bb_plan_s {
     int32_t *d_prowptr = nullptr, *d_pcol = nullptr, *d_rcolptr = nullptr, *d_rrowidx = nullptr;
     int64_t *d_pmap = nullptr, *d_rsrc = nullptr;
     double *d_W = nullptr, *d_lo = nullptr, *d_stage = nullptr;
+    bool factorized = false;       // d_stage holds the rows of R of the last factorize
 };
 
 struct qrk_dense_plan_s {
@@ -850,6 +851,7 @@ qrk_status qrk_bb_factorize(qrk_bb_plan p, const double* csr_vals, int64_t nnz, 
         QRK_HIP(h, qrk::launch_bb_chain(p->d_panels, (int)st.panels.size(), p->d_prowptr, p->d_pcol, p->d_pmap, csr_vals, p->d_W,
                                         p->d_lo, y_vals, t_vals, p->d_stage, p->d_rsrc, st.nnz_r, r_vals, st.max_act_rows,
                                         st.max_ncols, h->stream));
+        p->factorized = true;
         return QRK_STATUS_OK;
     }
     Staging s(h);
@@ -862,6 +864,29 @@ qrk_status qrk_bb_factorize(qrk_bb_plan p, const double* csr_vals, int64_t nnz, 
                                     d_y, d_t, p->d_stage, p->d_rsrc, st.nnz_r, d_r, st.max_act_rows, st.max_ncols, h->stream));
     if ((stt = s.back(r_vals, d_r, st.nnz_r)) || (stt = s.back(y_vals, d_y, st.y_len)) || (stt = s.back(t_vals, d_t, st.t_len)))
         return stt;
+    QRK_HIP(h, hipStreamSynchronize(h->stream));
+    p->factorized = true;
+    return QRK_STATUS_OK;
+}
+
+qrk_status qrk_bb_solve_r(qrk_bb_plan p, double* v, int64_t ldv, int64_t nrhs, qrk_memspace space)
+{
+    if (!p || !v || nrhs < 0) return fail(p ? p->h : nullptr, QRK_STATUS_INVALID_ARGUMENT, "qrk_bb_solve_r: bad argument");
+    qrk_handle h = p->h;
+    const qrk::BandedStructure& st = p->st;
+    if (ldv < st.cols) return fail(h, QRK_STATUS_INVALID_ARGUMENT, "qrk_bb_solve_r: ldv is smaller than the number of columns");
+    if (!p->factorized) return fail(h, QRK_STATUS_INVALID_ARGUMENT, "qrk_bb_solve_r: qrk_bb_factorize has not run on this plan");
+    QRK_HIP(h, hipSetDevice(h->device));
+    if (space == QRK_MEM_DEVICE) {
+        QRK_HIP(h, qrk::launch_bb_solve_r(p->d_panels, (int)st.panels.size(), p->d_stage, st.cols, v, ldv, nrhs, h->stream));
+        return QRK_STATUS_OK;
+    }
+    Staging s(h);
+    double* d_v;
+    qrk_status stt;
+    if ((stt = s.in((const double*)v, nrhs * ldv, &d_v))) return stt;
+    QRK_HIP(h, qrk::launch_bb_solve_r(p->d_panels, (int)st.panels.size(), p->d_stage, st.cols, d_v, ldv, nrhs, h->stream));
+    if ((stt = s.back(v, d_v, nrhs * ldv))) return stt;
     QRK_HIP(h, hipStreamSynchronize(h->stream));
     return QRK_STATUS_OK;
 }

@@ -172,3 +172,38 @@ def test_hip_banded_baseline_shaped_panels(strip_rows, env, monkeypatch):
     assert rel_fro(qr.applyQt(Jd), Rd) <= 1e-12                                   # Q^T J = R (:252)
     x = np.random.default_rng(0).uniform(-1, 1, m)
     assert rel_fro(qr.solve(J @ x), x) <= 1e-10                                   # LS recovery (:255)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["reference", "strips"])
+def test_hip_banded_solve_r_on_device(case):
+    """qrk_bb_solve_r (back substitution of _solve_impl, :290-311) against a host triangular solve with the same R,
+    several right-hand sides, both memory spaces."""
+    import ctypes as C
+    import scipy.sparse.linalg as spl
+    import torch
+    import qrkit_amd
+    from qrkit_amd import _capi as capi
+    J = banded_matrix(100, True, 7) if case == "reference" else strip_matrix(5, 256, 192, 64)
+    qr = qrkit_amd.BandedBlockedSparseQR(suggestedBlockCols=2)
+    qr.compute(J)
+    rows, cols = J.shape
+    R = qr.matrixR().tocsr()[:cols, :]
+    rng = np.random.default_rng(5)
+    Y = rng.uniform(-1, 1, (rows, 3))
+    want = spl.spsolve_triangular(R, Y[:cols], lower=False)
+    # device buffers
+    v = torch.as_tensor(Y.T.copy(), device="cuda")                      # [nrhs, rows] = column-major, ld = rows
+    capi.check(capi.lib().qrk_bb_solve_r(qr._plan, v.data_ptr(), rows, 3, capi.MEM_DEVICE), qr._ctx.handle)
+    torch.cuda.synchronize()
+    got = v.cpu().numpy()[:, :cols].T
+    assert rel_fro(got, want) <= 1e-11
+    np.testing.assert_array_equal(v.cpu().numpy()[:, cols:].T, Y[cols:])   # rows beyond cols untouched
+    # host buffers
+    h = np.asfortranarray(Y.copy())
+    capi.check(capi.lib().qrk_bb_solve_r(qr._plan, h.ctypes.data_as(C.POINTER(C.c_double)), rows, 3, capi.MEM_HOST), qr._ctx.handle)
+    np.testing.assert_array_equal(h[:cols], got)
+    # the mirror's solve(): LS recovery with several right-hand sides (:255)
+    X = rng.uniform(-1, 1, (cols, 2))
+    inv = np.empty_like(qr.rowsPermutation()); inv[qr.rowsPermutation()] = np.arange(rows)
+    assert rel_fro(qr.solve((J @ X)[inv]), X) <= 1e-9

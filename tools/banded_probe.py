@@ -33,7 +33,11 @@ print(f"analyzePattern {1e3 * (t1 - t0):.1f} ms (host);  factorize {1e3 * (t3 - 
       f"  -> {50000 * (t3 - t2) / reps / nb:.1f} s for 50 000 strips")
 x = rng.uniform(-1, 1, ncols)
 b = (J @ x)[np.argsort(qr.rowsPermutation())] if qr.hasPermutation else J @ x
-xs = qr.solve(b)
+xs = qr.solve(b); torch.cuda.synchronize()
+t4 = time.perf_counter(); xs = qr.solve(b); torch.cuda.synchronize(); t5 = time.perf_counter()
+bt = torch.as_tensor(b, device="cuda")
+t6 = time.perf_counter(); qr.applyQt(bt); torch.cuda.synchronize(); t7 = time.perf_counter()
+print(f"solve (1 rhs, host vector in/out) {1e3 * (t5 - t4):.1f} ms; Q^T b on the device {1e3 * (t7 - t6):.1f} ms = {1e3 * (t7 - t6) / nb:.3f} ms per panel")
 print("LS recovery rel. error", np.linalg.norm(xs - x) / np.linalg.norm(x))
 if os.environ.get("QRK_BB_PROF"):
     n = int(qr.blocks[-1][3])
