@@ -187,6 +187,12 @@ qrk_status qrk_dense_factorize(qrk_dense_plan plan, double* a, int64_t lda, doub
 qrk_status qrk_dense_apply_q(qrk_dense_plan plan, const double* qr, int64_t lda, const double* hcoeffs,
                              int transpose, double* b, int64_t ldb, int64_t nrhs, qrk_memspace space);
 
+/* b(0:cols, :) <- R^-1 b(0:cols, :) in place, R = the upper triangle of the packed QR (rows >= cols): the back
+ * substitution of ColPivHouseholderQR::solve / of BlockAngularSparseQR::_solve_impl on its R2 block
+ * (src/QRKit/BlockAngularSparseQR.h:202-227); the column permutation is the caller's. */
+qrk_status qrk_dense_solve_r(qrk_dense_plan plan, const double* qr, int64_t lda, double* b, int64_t ldb, int64_t nrhs,
+                             qrk_memspace space);
+
 /* ------------------------------------------------------------ block-banded solver */
 
 /* QRKit::BandedBlockedSparseQR<SparseMatrix, HouseholderQR<MatrixXd>, Dynamic, SuggestedBlockCols>

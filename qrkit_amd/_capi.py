@@ -25,7 +25,7 @@ EXPORTS = (
     "qrk_last_error", "qrk_bd_plan_create", "qrk_bd_plan_destroy", "qrk_bd_plan_sizes", "qrk_bd_pattern",
     "qrk_bd_factorize", "qrk_bd_info", "qrk_bd_apply_qt", "qrk_bd_solve", "qrk_bd_solve_r", "qrk_dense_plan_create",
     "qrk_dense_plan_destroy", "qrk_dense_factorize", "qrk_dense_apply_q", "qrk_bb_plan_create", "qrk_bb_plan_destroy", "qrk_bb_analyze_host",
-    "qrk_bb_plan_info", "qrk_bb_plan_blocks", "qrk_bb_pattern", "qrk_bb_factorize", "qrk_bb_apply_q", "qrk_bb_solve_r", "qrk_bd_time_factorize",
+    "qrk_bb_plan_info", "qrk_bb_plan_blocks", "qrk_bb_pattern", "qrk_bb_factorize", "qrk_bb_apply_q", "qrk_bb_solve_r", "qrk_dense_solve_r", "qrk_bd_time_factorize",
 )
 
 
@@ -112,6 +112,8 @@ def lib() -> C.CDLL:
     L.qrk_bb_factorize.argtypes = [vp, dp, C.c_int64, dp, dp, dp, C.c_int]
     L.qrk_bb_apply_q.restype = C.c_int
     L.qrk_bb_apply_q.argtypes = [vp, dp, dp, C.c_int, dp, C.c_int64, C.c_int]
+    L.qrk_dense_solve_r.restype = C.c_int
+    L.qrk_dense_solve_r.argtypes = [vp, dp, C.c_int64, dp, C.c_int64, C.c_int64, C.c_int]
     L.qrk_bb_solve_r.restype = C.c_int
     L.qrk_bb_solve_r.argtypes = [vp, dp, C.c_int64, C.c_int64, C.c_int]
     L.qrk_bd_time_factorize.restype = C.c_int

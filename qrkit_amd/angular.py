@@ -95,6 +95,16 @@ class DenseColPivQR:
                    self._ctx.handle)
         return B
 
+    def solveR(self, B: torch.Tensor) -> torch.Tensor:
+        """B: (cols, nrhs) column-major device tensor, updated in place: B <- R^-1 B with the upper triangle of the
+        packed QR (qrk_dense_solve_r; the column permutation is the caller's)."""
+        rows, cols = self._shape
+        assert B.shape[0] == cols and B.t().is_contiguous()
+        self._ctx.use_current_stream()
+        capi.check(capi.lib().qrk_dense_solve_r(self._plan, self._qr.data_ptr(), rows, B.data_ptr(), cols, B.shape[1],
+                                                capi.MEM_DEVICE), self._ctx.handle)
+        return B
+
     def __del__(self):
         try:
             if self._plan:
@@ -210,8 +220,7 @@ class BlockAngularSparseQR:
         y = self.applyQt(torch.as_tensor(np.asarray(b, dtype=np.float64)) if was_np else b)
         y = y.reshape(self._rows, -1)
         m1, m2 = self._m1, self._m2
-        R2 = self.m_rightSolver.matrixR()[:m2, :m2]
-        y2 = torch.linalg.solve_triangular(R2, y[m1:m1 + m2, :], upper=True)
+        y2 = self.m_rightSolver.solveR(_colmajor(y[m1:m1 + m2, :].clone()))       # R2^-1 y2 on the device (qrk_dense_solve_r)
         strip = self._J2[:m1, :][:, self._P2]
         rhs1 = y[:m1, :] - strip @ y2
         # R1 is block upper triangular: solve it tile by tile with the left solver's packed R

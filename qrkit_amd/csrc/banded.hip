@@ -916,15 +916,16 @@ size_t bb_t_smem(int max_ncols, int* t_in_lds)
 // side; the chain over the panels is sequential (x of a panel needs the x of the panels after it).
 constexpr int BS_THREADS = 256;
 __global__ void __launch_bounds__(BS_THREADS)
-bb_solve_r_kernel(const BBPanel* __restrict__ panels, int num_panels, const double* __restrict__ r_stage, int cols,
-                  double* __restrict__ v, int64_t ldv)
+bb_solve_r_kernel(const BBPanel* __restrict__ panels, const BBPanel single, int num_panels, const double* __restrict__ r_stage,
+                  int cols, double* __restrict__ v, int64_t ldv)
 {
+    // (panels == nullptr: one dense upper triangle described by `single` - qrk_dense_solve_r)
     __shared__ double blk[64 * 65];          // diagonal block, blk[j * 65 + i] = R(i, j)
     __shared__ double part[4 * 64];          // partial sums of the four column groups
     const int tid = threadIdx.x, ln = tid & 63, grp = tid >> 6;
     double* x = v + (int64_t)blockIdx.x * ldv;
     for (int pi = num_panels - 1; pi >= 0; --pi) {
-        const BBPanel p = panels[pi];
+        const BBPanel p = panels ? panels[pi] : single;
         const int n = p.ncols, sv = p.solved;
         int ns = sv < n ? sv : n;                        // rows of this panel inside the triangle
         if (p.col0 + ns > cols) ns = cols - p.col0;
@@ -1132,7 +1133,20 @@ hipError_t launch_bb_solve_r(const BBPanel* panels, int num_panels, const double
                              int64_t nrhs, hipStream_t stream)
 {
     if (nrhs <= 0 || num_panels <= 0) return hipSuccess;
-    hipLaunchKernelGGL(bb_solve_r_kernel, dim3((unsigned)nrhs), dim3(BS_THREADS), 0, stream, panels, num_panels, r_stage, cols, v, ldv);
+    hipLaunchKernelGGL(bb_solve_r_kernel, dim3((unsigned)nrhs), dim3(BS_THREADS), 0, stream, panels, BBPanel{}, num_panels, r_stage,
+                       cols, v, ldv);
+    return hipGetLastError();
+}
+
+// b(0:n, :) <- R^-1 b(0:n, :) for the upper triangle R (n x n) of a column-major array with leading dimension lda
+hipError_t launch_dense_solve_r(const double* qr, int64_t lda, int n, double* b, int64_t ldb, int64_t nrhs, hipStream_t stream)
+{
+    if (nrhs <= 0 || n <= 0) return hipSuccess;
+    if (lda > INT32_MAX) return hipErrorInvalidValue;
+    BBPanel one{};
+    one.col0 = 0; one.ncols = n; one.solved = (int32_t)lda; one.r_off = 0;     // R(i, j) = qr[j * lda + i]
+    hipLaunchKernelGGL(bb_solve_r_kernel, dim3((unsigned)nrhs), dim3(BS_THREADS), 0, stream, (const BBPanel*)nullptr, one, 1, qr, n, b,
+                       ldb);
     return hipGetLastError();
 }
 

@@ -722,6 +722,27 @@ qrk_status qrk_dense_apply_q(qrk_dense_plan p, const double* qr, int64_t lda, co
     return QRK_STATUS_OK;
 }
 
+qrk_status qrk_dense_solve_r(qrk_dense_plan p, const double* qr, int64_t lda, double* b, int64_t ldb, int64_t nrhs,
+                             qrk_memspace space)
+{
+    if (!p || !qr || !b || nrhs < 0 || lda < p->rows || ldb < p->cols || p->rows < p->cols)
+        return fail(p ? p->h : nullptr, QRK_STATUS_INVALID_ARGUMENT, "qrk_dense_solve_r: bad argument");
+    qrk_handle h = p->h;
+    QRK_HIP(h, hipSetDevice(h->device));
+    if (space == QRK_MEM_DEVICE) {
+        QRK_HIP(h, qrk::launch_dense_solve_r(qr, lda, p->cols, b, ldb, nrhs, h->stream));
+        return QRK_STATUS_OK;
+    }
+    Staging s(h);
+    double *d_qr, *d_b;
+    qrk_status st;
+    if ((st = s.in(qr, lda * p->cols, &d_qr)) || (st = s.in((const double*)b, ldb * nrhs, &d_b))) return st;
+    QRK_HIP(h, qrk::launch_dense_solve_r(d_qr, lda, p->cols, d_b, ldb, nrhs, h->stream));
+    if ((st = s.back(b, d_b, ldb * nrhs))) return st;
+    QRK_HIP(h, hipStreamSynchronize(h->stream));
+    return QRK_STATUS_OK;
+}
+
 qrk_status qrk_bb_plan_create(qrk_handle h, int32_t rows, int32_t cols, const int32_t* csr_rowptr,
                               const int32_t* csr_colidx, int32_t suggested_block_cols, qrk_bb_plan* out)
 {

@@ -62,3 +62,30 @@ def test_dense_qr_matches_oracle(rows, cols, path, solver):
     assert rel_fro(B.cpu().numpy(), Rfull) <= 1e-11
     qr.applyQ(B, transpose=False)
     assert rel_fro(B.cpu().numpy(), A[:, P]) <= 1e-11
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows,cols", [(64, 20), (300, 300), (1000, 130)])
+def test_dense_solve_r_on_device(rows, cols):
+    """qrk_dense_solve_r: back substitution with the upper triangle of the packed QR (the R2 block of
+    BlockAngularSparseQR::_solve_impl, :202-227) against a host triangular solve with the same R; several
+    right-hand sides; and the whole least-squares solve x = P R^-1 (Q^T b)(0:cols)."""
+    import scipy.linalg as sl
+    import torch
+    rng = np.random.default_rng(rows + cols)
+    A = rng.uniform(-1.0, 1.0, (rows, cols))
+    qr, _ = _factor(A, 0, None)
+    R = qr.matrixR().cpu().numpy()[:cols, :cols]
+    Y = rng.uniform(-1, 1, (cols, 3))
+    want = sl.solve_triangular(R, Y, lower=False)
+    B = torch.from_numpy(Y.T.copy()).cuda().t()                      # column-major on the device
+    qr.solveR(B)
+    torch.cuda.synchronize()
+    assert rel_fro(B.cpu().numpy(), want) <= 1e-10 * max(1.0, np.linalg.cond(R) * 1e-6)
+    x = rng.uniform(-1, 1, cols)
+    b = torch.from_numpy((A @ x)[None, :].copy()).cuda().t()
+    qr.applyQ(b, transpose=True)
+    z = b[:cols, :].t().contiguous().t()
+    qr.solveR(z)
+    xs = np.empty(cols); xs[qr.colsPermutation().cpu().numpy()] = z.cpu().numpy()[:, 0]
+    assert rel_fro(xs, x) <= 1e-9
