@@ -297,6 +297,13 @@ class BlockDiagonalSparseQR {
         return true;
     }
     Vector solve(const Vector& B) const { Vector x; _solve_impl(B, x); return x; }
+    // the triangular step alone, on the device: z = R(0:cols,0:cols).triangularView<Upper>().solve(y) (:271); y: cols x nrhs
+    Vector solveR(const Vector& y) const {
+        assert(m_isInitialized && (Index)y.size() % cols() == 0);
+        Vector z(y.size());
+        check(qrk_bd_solve_r(m_plan, m_R.values().data(), y.data(), (int64_t)y.size() / cols(), z.data(), QRK_MEM_HOST));
+        return z;
+    }
     // matrixQ().transpose() * B on the device (test/test-qrkit.cpp:187)
     Vector applyQt(const Vector& B) const {
         const int64_t nrhs = (int64_t)B.size() / rows();
@@ -469,6 +476,13 @@ class BandedBlockedSparseQR {
         for (int64_t c = 0; c < nrhs; ++c) std::copy(y.begin() + c * m_rows, y.begin() + c * m_rows + m_cols, x.begin() + c * m_cols);
         return x;
     }
+    // the triangular step alone, on the device (qrk_bb_solve_r); y: cols x nrhs
+    Vector solveR(const Vector& y) const {
+        assert(m_isInitialized && (Index)y.size() % m_cols == 0);
+        Vector z(y);
+        check(qrk_bb_solve_r(m_plan, z.data(), (int64_t)m_cols, (int64_t)y.size() / m_cols, QRK_MEM_HOST));
+        return z;
+    }
 
   protected:
     Vector apply(const Vector& v, int transpose) const {
@@ -633,7 +647,19 @@ class BlockAngularSparseQR {
     Vector solve(const Vector& b) const {
         assert(m_isInitialized && "The factorization should be called first, use compute()");
         const Vector y = applyQt(b);
-        const Vector z = solveUpperCsc(m_R, m_cols, y);
+        if (m_rows - m_m1 < m_m2) return m_outputPerm_c * solveUpperCsc(m_R, m_cols, y);   // (fewer bottom rows than right columns)
+        // R = [R1 S; 0 R2], block by block: z2 = R2^-1 y2 (qrk_dense_solve_r) and z1 = R1^-1 (y1 - S z2) (the left
+        // solver's triangular step) on the device; S = (Q1^T J2)(0:m1, P2) is applied here
+        Vector z2(y.begin() + m_m1, y.begin() + m_m1 + m_m2);
+        check(qrk_dense_solve_r(m_dense, m_bottom.data(), (int64_t)m_bottom.rows(), z2.data(), (int64_t)m_m2, 1, QRK_MEM_HOST));
+        Vector rhs1(y.begin(), y.begin() + m_m1);
+        for (Index c = 0; c < m_m2; ++c) {
+            const double zc = z2[(size_t)c];
+            const Index jc = m_P2[(size_t)c];
+            for (Index r = 0; r < m_m1; ++r) rhs1[(size_t)r] -= m_J2(r, jc) * zc;
+        }
+        Vector z = m_leftSolver.solveR(rhs1);
+        z.insert(z.end(), z2.begin(), z2.end());
         return m_outputPerm_c * z;
     }
 
