@@ -29,6 +29,7 @@
 #include "qrk_device.h"
 
 #include <float.h>
+#include <cstdlib>
 
 #ifndef QRK_COL_BLOCKED
 #define QRK_COL_BLOCKED 1      // tiles in global memory: panel-blocked phase 1 (0 = fused level-2 sweeps)
@@ -39,7 +40,7 @@ namespace qrk {
 namespace col {
 
 constexpr double SQRT_EPS = 1.4901161193847656e-08;   // sqrt(DBL_EPSILON), Eigen's norm_downdate_threshold
-constexpr int W_LDS_DOUBLES = 4608;                   // 36 KB of LDS for A when the tile fits (two workgroups per CU)
+constexpr int W_LDS_DOUBLES = 4352;                   // 34 KB of LDS for A when the tile fits (two workgroups of the fixed layout per CU)
 constexpr int NB = 16;                                // reflectors per block in the formation of Q
 constexpr int MAXR = 256;                             // largest tile dimension of this kernel
 
@@ -94,8 +95,8 @@ __device__ __forceinline__ void factor_tile(double* __restrict__ W, double* smem
     using namespace col;
     const int w_lds = DYN ? w_lds_dyn : W_LDS_DOUBLES, max_r = DYN ? max_r_dyn : MAXR;
     constexpr int NW = CT / 64;
-    double* vs = smem + w_lds;                           // [max_r * NB] V panel of phase 2, row-major
-    double* xv0 = vs + max_r * NB;                       // [max_r] pivot column, even steps
+    double* vs = smem + w_lds;                           // [max_r * (NB + 1)] V panel: phase 1 stride NB, phase 2 NB + 1
+    double* xv0 = vs + max_r * (NB + 1);                 // [max_r] pivot column, even steps
     double* xv1 = xv0 + max_r;                           // [max_r] odd steps
     double* taus = xv1 + max_r;                          // [max_r] Householder coefficients
     double* gm = taus + max_r;                           // [NB * NB] V^T V of a panel
@@ -460,7 +461,9 @@ __device__ __forceinline__ void factor_tile(double* __restrict__ W, double* smem
         for (int kp = ((c - 1) / NB) * NB; kp >= 0; kp -= NB) {
             const int kb = (c - kp) < NB ? (c - kp) : NB;
             const int m = r - kp;
-            // V panel (m x kb, unit lower trapezoidal) to LDS, row-major with stride NB
+            // V panel (m x kb, unit lower trapezoidal) to LDS, row-major with stride NB + 1 (the MFMA operand reads below
+            // walk it both by rows and by columns)
+            constexpr int VS = NB + 1;
             for (int e = tid; e < m * NB; e += CT) {
                 const int i = e / NB, l = e - i * NB;
                 double v = 0.0;
@@ -468,14 +471,14 @@ __device__ __forceinline__ void factor_tile(double* __restrict__ W, double* smem
                     if (i == l) v = 1.0;
                     else if (i > l) v = W[(int64_t)(kp + i) * ld + col_of_pos[kp + l]];
                 }
-                vs[e] = v;
+                vs[i * VS + l] = v;
             }
             __syncthreads();
             // G = V^T V (upper part), one pair per thread
             for (int e = tid; e < NB * NB; e += CT) {
                 const int a = e / NB, b = e - a * NB;
                 double g = 0.0;
-                if (a <= b && b < kb) for (int i = b; i < m; ++i) g = fma(vs[i * NB + a], vs[i * NB + b], g);
+                if (a <= b && b < kb) for (int i = b; i < m; ++i) g = fma(vs[i * VS + a], vs[i * VS + b], g);
                 gm[e] = g;
             }
             __syncthreads();
@@ -496,55 +499,63 @@ __device__ __forceinline__ void factor_tile(double* __restrict__ W, double* smem
                 }
             }
             __syncthreads();
-            // Q(kp:, kp:) <- (I - V T V^T) Q(kp:, kp:), one thread per column
-            for (int j = kp + tid; j < r; j += CT) {
-                double* qc = Q + (int64_t)kp * r + j;     // qc[i * r] = Q(kp + i, j)
-                double w[NB];
+            // Q(kp:, kp:) <- (I - V T V^T) Q(kp:, kp:) with v_mfma_f64_16x16x4_f64, a wave per strip of 16 columns of Q:
+            //   w = V^T q   A[row = lane & 15][k = lane >> 4] = V(4 k' + k, row) from LDS, B = Q(4 k' + k, col) from memory
+            //   u = -T w    the result registers D[row = (lane >> 4) + 4 z][col] of w are the B operand of k-step z
+            //   q += V u    A = V(16 t + row, 4 k' + k), B = u, D = the 16 x 16 tile of Q, read-modify-write
+            // (one thread per column with scalar FMAs spent 3.8 ms of a 256 x 256 tile's 10 ms here)
+            {
+                typedef double d4 __attribute__((ext_vector_type(4)));
+                const int kq = lane >> 4, l15 = lane & 15;
+                const int S = (m + 15) >> 4, K = (m + 3) >> 2;
+                for (int sidx = wave; sidx < S; sidx += NW) {
+                    const int colq = kp + 16 * sidx + l15;
+                    const bool cok = colq < r;
+                    double* qc = Q + (int64_t)kp * r + colq;              // qc[i * r] = Q(kp + i, colq)
+                    d4 acc = d4{0.0, 0.0, 0.0, 0.0};
+                    constexpr int U = 8;
+                    for (int k = 0; k < K; k += U) {
+                        double bv[U];
 #pragma unroll
-                for (int l = 0; l < NB; ++l) w[l] = 0.0;
-                // rows in chunks of U: the U loads of Q are independent and in flight together (the loop is
-                // bound by their latency otherwise)
-                constexpr int U = 8;
-                int i = 0;
-                for (; i + U <= m; i += U) {
-                    double qv[U];
+                        for (int u2 = 0; u2 < U; ++u2) {
+                            const int row = 4 * (k + u2) + kq;
+                            bv[u2] = (row < m && cok) ? qc[(int64_t)row * r] : 0.0;
+                        }
 #pragma unroll
-                    for (int u2 = 0; u2 < U; ++u2) qv[u2] = qc[(int64_t)(i + u2) * r];
-#pragma unroll
-                    for (int u2 = 0; u2 < U; ++u2) {
-#pragma unroll
-                        for (int l = 0; l < NB; ++l) w[l] = fma(vs[(i + u2) * NB + l], qv[u2], w[l]);
+                        for (int u2 = 0; u2 < U; ++u2) {
+                            int row = 4 * (k + u2) + kq; if (row > m - 1) row = m - 1;      // (bv is zero beyond m)
+                            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(vs[row * VS + l15], bv[u2], acc, 0, 0, 0);
+                        }
                     }
-                }
-                for (; i < m; ++i) {
-                    const double qv = qc[(int64_t)i * r];
+                    d4 uu = d4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-                    for (int l = 0; l < NB; ++l) w[l] = fma(vs[i * NB + l], qv, w[l]);
-                }
-                double u[NB];
+                    for (int ks = 0; ks < 4; ++ks)
+                        uu = __builtin_amdgcn_mfma_f64_16x16x4f64(tm[l15 * NB + 4 * ks + kq], acc[ks], uu, 0, 0, 0);
+                    uu = -uu;
+                    const int RT = (m + 15) >> 4;
+                    constexpr int UT = 2;
+                    for (int rt = 0; rt < RT; rt += UT) {
+                        d4 dv[UT];
 #pragma unroll
-                for (int a = 0; a < NB; ++a) {
-                    double acc = 0.0;
+                        for (int u2 = 0; u2 < UT; ++u2)
 #pragma unroll
-                    for (int b = 0; b < NB; ++b) if (b >= a) acc = fma(tm[a * NB + b], w[b], acc);
-                    u[a] = acc;
-                }
-                for (i = 0; i + U <= m; i += U) {
-                    double qv[U];
+                            for (int z = 0; z < 4; ++z) {
+                                const int row = 16 * (rt + u2) + kq + 4 * z;
+                                dv[u2][z] = (row < m && cok) ? qc[(int64_t)row * r] : 0.0;
+                            }
 #pragma unroll
-                    for (int u2 = 0; u2 < U; ++u2) qv[u2] = qc[(int64_t)(i + u2) * r];
+                        for (int u2 = 0; u2 < UT; ++u2) {
+                            int arow = 16 * (rt + u2) + l15; if (arow > m - 1) arow = m - 1;
 #pragma unroll
-                    for (int u2 = 0; u2 < U; ++u2) {
+                            for (int ks = 0; ks < 4; ++ks)
+                                dv[u2] = __builtin_amdgcn_mfma_f64_16x16x4f64(vs[arow * VS + 4 * ks + kq], uu[ks], dv[u2], 0, 0, 0);
 #pragma unroll
-                        for (int l = 0; l < NB; ++l) qv[u2] = fma(-vs[(i + u2) * NB + l], u[l], qv[u2]);
-                        qc[(int64_t)(i + u2) * r] = qv[u2];
+                            for (int z = 0; z < 4; ++z) {
+                                const int row = 16 * (rt + u2) + kq + 4 * z;
+                                if (row < m && cok) qc[(int64_t)row * r] = dv[u2][z];
+                            }
+                        }
                     }
-                }
-                for (; i < m; ++i) {
-                    double qv = qc[(int64_t)i * r];
-#pragma unroll
-                    for (int l = 0; l < NB; ++l) qv = fma(-vs[i * NB + l], u[l], qv);
-                    qc[(int64_t)i * r] = qv;
                 }
             }
             __syncthreads();
@@ -555,7 +566,7 @@ __device__ __forceinline__ void factor_tile(double* __restrict__ W, double* smem
 }
 
 template <int CT>
-__global__ void __launch_bounds__(CT)
+__global__ void __launch_bounds__(CT) __attribute__((amdgpu_waves_per_eu(CT == 64 ? 3 : 1)))
 bdqr_col_kernel(WaveBatch nb, const double* __restrict__ tiles, double* __restrict__ q_vals,
                 double* __restrict__ r_vals, int32_t* __restrict__ perm, double* __restrict__ hcoeffs,
                 double* __restrict__ workspace, int64_t ws_stride, int w_lds, int max_r)
@@ -586,12 +597,16 @@ bdqr_col_kernel(WaveBatch nb, const double* __restrict__ tiles, double* __restri
 size_t bdqr_col_smem_bytes(int threads, int w_lds, int max_r)
 {
     const int nw = threads / 64;
-    if (threads > 64) { w_lds = col::W_LDS_DOUBLES; max_r = col::MAXR; }       // fixed layout (see factor_tile)
-    return (size_t)(w_lds + max_r * col::NB + 3 * max_r + 2 * col::NB * col::NB + 2 * nw) * sizeof(double) +
+    if (threads > 64) { w_lds = col::W_LDS_DOUBLES; max_r = col::MAXR; }   // fixed layout (see factor_tile)
+    return (size_t)(w_lds + max_r * (col::NB + 1) + 3 * max_r + 2 * col::NB * col::NB + 2 * nw) * sizeof(double) +
            (size_t)(2 * nw + 2 + max_r) * sizeof(int) + 16;
 }
 
-int bdqr_col_threads(int max_cols) { return max_cols <= 64 ? 64 : (max_cols <= 128 ? 128 : 256); }
+int bdqr_col_threads(int max_cols)
+{
+    if (const char* e = std::getenv("QRK_COL_THREADS")) { const int v = std::atoi(e); if (v == 64 || v == 128 || v == 256) return v >= max_cols ? v : 256; }
+    return max_cols <= 64 ? 64 : (max_cols <= 128 ? 128 : 256);
+}
 
 // LDS doubles for A in a launch whose largest tile holds max_rc entries: the tile itself when it fits the budget of
 // the LDS-resident form, else nothing at all unless smaller tiles of the launch can use it (mixed launches)
@@ -606,7 +621,10 @@ int bdqr_col_wgs_per_cu(int max_cols, int w_lds, int max_r)
 {
     const int threads = bdqr_col_threads(max_cols);
     const size_t smem = bdqr_col_smem_bytes(threads, w_lds, max_r);
-    int by_lds = (int)((size_t)160 * 1024 / smem), by_waves = 16 / (threads / 64);
+    // waves a CU holds at the register count of the instantiation: 3 per SIMD for the 64-thread one (168 VGPRs by
+    // amdgpu_waves_per_eu), 2 for the others (~210)
+    const int cu_waves = threads == 64 ? 12 : 8;
+    int by_lds = (int)((size_t)160 * 1024 / smem), by_waves = cu_waves / (threads / 64);
     int n = by_lds < by_waves ? by_lds : by_waves;
     // tiles wider than 64 columns work mostly in global memory: more than two workgroups per CU only makes them
     // slower (measured: 256x256 50.0k -> 46.3k tiles/s, 96x96 475k -> 450k at four); the small ones gain (33x33 2.9M -> 5.2M)
