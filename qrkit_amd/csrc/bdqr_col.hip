@@ -565,8 +565,13 @@ __device__ __forceinline__ void factor_tile(double* __restrict__ W, double* smem
     }
 }
 
-template <int CT>
-__global__ void __launch_bounds__(CT) __attribute__((amdgpu_waves_per_eu(CT == 64 ? 3 : 1)))
+// Two instantiations per thread count.  BIG (launches whose largest tile has more than 160 rows): the register
+// allocator's own choice (~210 VGPRs, two waves per SIMD) and the fixed LDS layout with compile-time offsets - two
+// workgroups of 256 threads per CU is all their 80 KB allow anyway.  Otherwise 168 VGPRs (three waves per SIMD, ~20
+// spilled) and LDS carved for the largest tile of the launch: 96x96 533k -> 757k tiles/s, 128x128 326k -> 443k, while
+// the same settings cost the 192...256 tiles 3 % and a mixed 8...256 batch 6 %.
+template <int CT, bool BIG>
+__global__ void __launch_bounds__(CT) __attribute__((amdgpu_waves_per_eu(BIG ? 2 : 3)))
 bdqr_col_kernel(WaveBatch nb, const double* __restrict__ tiles, double* __restrict__ q_vals,
                 double* __restrict__ r_vals, int32_t* __restrict__ perm, double* __restrict__ hcoeffs,
                 double* __restrict__ workspace, int64_t ws_stride, int w_lds, int max_r)
@@ -584,7 +589,7 @@ bdqr_col_kernel(WaveBatch nb, const double* __restrict__ tiles, double* __restri
             toff = t * (int64_t)r * c; qoff = t * (int64_t)r * r; roff = t * (int64_t)(c * (c + 1) / 2);
             cbase = (int)(t * c);
         }
-        constexpr bool DYN = CT == 64;
+        constexpr bool DYN = !BIG;
         if (r * c <= (DYN ? w_lds : col::W_LDS_DOUBLES))
             factor_tile<CT, false, DYN>(smem, smem, r, c, cbase, nb.pivoting, tiles + toff, q_vals + qoff, r_vals + roff, perm, hcoeffs,
                                         w_lds, max_r);
@@ -594,16 +599,21 @@ bdqr_col_kernel(WaveBatch nb, const double* __restrict__ tiles, double* __restri
     }
 }
 
+bool bdqr_col_big(int max_rows) { return max_rows > 160; }
+
 size_t bdqr_col_smem_bytes(int threads, int w_lds, int max_r)
 {
     const int nw = threads / 64;
-    if (threads > 64) { w_lds = col::W_LDS_DOUBLES; max_r = col::MAXR; }   // fixed layout (see factor_tile)
+    if (bdqr_col_big(max_r)) { w_lds = col::W_LDS_DOUBLES; max_r = col::MAXR; }   // fixed layout (see bdqr_col_kernel)
     return (size_t)(w_lds + max_r * (col::NB + 1) + 3 * max_r + 2 * col::NB * col::NB + 2 * nw) * sizeof(double) +
            (size_t)(2 * nw + 2 + max_r) * sizeof(int) + 16;
 }
 
-int bdqr_col_threads(int max_cols)
+bool bdqr_col_big(int max_rows);
+
+int bdqr_col_threads(int max_cols, int max_rows)
 {
+    if (bdqr_col_big(max_rows)) return 256;        // (only that instantiation exists for the large class)
     if (const char* e = std::getenv("QRK_COL_THREADS")) { const int v = std::atoi(e); if (v == 64 || v == 128 || v == 256) return v >= max_cols ? v : 256; }
     return max_cols <= 64 ? 64 : (max_cols <= 128 ? 128 : 256);
 }
@@ -619,16 +629,15 @@ int bdqr_col_w_lds(int64_t max_rc, int64_t max_rc_fitting)
 // Workgroups of one launch that can be resident per CU (LDS and the 16 waves a CU holds at this kernel's register count)
 int bdqr_col_wgs_per_cu(int max_cols, int w_lds, int max_r)
 {
-    const int threads = bdqr_col_threads(max_cols);
+    const int threads = bdqr_col_threads(max_cols, max_r);
     const size_t smem = bdqr_col_smem_bytes(threads, w_lds, max_r);
-    // waves a CU holds at the register count of the instantiation: 3 per SIMD for the 64-thread one (168 VGPRs by
-    // amdgpu_waves_per_eu), 2 for the others (~210)
-    const int cu_waves = threads == 64 ? 12 : 8;
+    // waves a CU holds at the register count of the instantiation (see bdqr_col_kernel)
+    const int cu_waves = bdqr_col_big(max_r) ? 8 : 12;
     int by_lds = (int)((size_t)160 * 1024 / smem), by_waves = cu_waves / (threads / 64);
     int n = by_lds < by_waves ? by_lds : by_waves;
     // tiles wider than 64 columns work mostly in global memory: more than two workgroups per CU only makes them
     // slower (measured: 256x256 50.0k -> 46.3k tiles/s, 96x96 475k -> 450k at four); the small ones gain (33x33 2.9M -> 5.2M)
-    if (max_cols > 64 && n > 2) n = 2;
+    if (const char* e = std::getenv("QRK_COL_WGS_PER_CU")) { const int v = std::atoi(e); if (v > 0 && v < n) n = v; }
     return n < 1 ? 1 : n;
 }
 
@@ -639,19 +648,20 @@ hipError_t launch_bdqr_col(const WaveBatch& nb, const double* tiles, double* q_v
     if (nb.num_tiles <= 0) return hipSuccess;
     if (max_rows > col::MAXR || max_cols > max_rows || w_lds > col::W_LDS_DOUBLES) return hipErrorInvalidValue;
     const int64_t want = nb.num_tiles < (int64_t)num_wg ? nb.num_tiles : (int64_t)num_wg;
-    const int threads = bdqr_col_threads(max_cols);
+    const int threads = bdqr_col_threads(max_cols, max_rows);
     const size_t smem = bdqr_col_smem_bytes(threads, w_lds, max_rows);
-#define QRK_COL_LAUNCH(T)                                                                                   \
+#define QRK_COL_LAUNCH(T, G)                                                                                \
     do {                                                                                                    \
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(bdqr_col_kernel<T>),               \
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(bdqr_col_kernel<T, G>),            \
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);          \
         if (e != hipSuccess) return e;                                                                      \
-        hipLaunchKernelGGL((bdqr_col_kernel<T>), dim3((unsigned)want), dim3(T), smem, stream, nb, tiles, q_vals, \
+        hipLaunchKernelGGL((bdqr_col_kernel<T, G>), dim3((unsigned)want), dim3(T), smem, stream, nb, tiles, q_vals, \
                            r_vals, perm, hcoeffs, workspace, ws_stride, w_lds, max_rows);                   \
     } while (0)
-    if (threads == 64) QRK_COL_LAUNCH(64);
-    else if (threads == 128) QRK_COL_LAUNCH(128);
-    else QRK_COL_LAUNCH(256);
+    if (bdqr_col_big(max_rows)) QRK_COL_LAUNCH(256, true);      // (more than 160 rows >= cols: 256 threads unless the tiles are narrow)
+    else if (threads == 64) QRK_COL_LAUNCH(64, false);
+    else if (threads == 128) QRK_COL_LAUNCH(128, false);
+    else QRK_COL_LAUNCH(256, false);
 #undef QRK_COL_LAUNCH
     return hipGetLastError();
 }

