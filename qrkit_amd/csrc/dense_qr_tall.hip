@@ -33,6 +33,8 @@ struct State {
     double s, ng, inv_s;     // reflector of the current step: s = x0 - beta, ng = -1/(beta w), 1/s (0 if H = I)
     int P;                   // column to swap into position k+1 (already swapped in the bookkeeping arrays)
     int slow;                // the norm-recompute test fired in this step
+    unsigned ticket;         // head_kernel: workgroups that have finished their columns (reset by the last one)
+    int anyneed;             // head_kernel: some column failed the downdate test (reset by the last one)
 };
 
 struct Work {                // device workspace of a plan
@@ -118,7 +120,7 @@ init_kernel(int c, int pivoting, Work w)
         for (int g = 0; g < w.G; ++g) s += w.sqpart[(int64_t)g * w.cpad + jc];
         w.nu2[jc] = s; w.thr[jc] = s * SQRT_EPS; w.pidx[jc] = jc;
     }
-    if (threadIdx.x == 0) w.st->slow = 0;
+    if (threadIdx.x == 0) { w.st->slow = 0; w.st->ticket = 0u; w.st->anyneed = 0; }
     __syncthreads();
     choose_and_swap(0, c, pivoting, w, red, ired);
 }
@@ -159,18 +161,33 @@ swap_dots_kernel(double* __restrict__ A, int64_t lda, int r, int c, int kpos, in
 }
 
 // Head of step k: reflector scalars, row k of R, norm downdate, next pivot (or slow).
+// The slab partials of a step are G x (c - k) doubles (4 MB at 40000 x 2000): summed by ONE workgroup they cost as
+// much as the sweep itself (97 us per step, one CU's path to L2).  So the columns are dealt to several workgroups
+// (128 columns each, eight groups of slabs per column, combined through LDS in a fixed order), and the part that needs
+// all the columns - the slow/fast decision and the next pivot - is done by the workgroup that finishes last
+// (a ticket counter after a device-scope fence: no workgroup ever waits for another).
+constexpr int HC = 128;                  // columns per workgroup
+constexpr int HG = TT / HC;              // slab groups per column
 __global__ void __launch_bounds__(TT)
 head_kernel(double* __restrict__ A, int64_t lda, int r, int c, int k, int pivoting, double* __restrict__ hcoeffs,
             int32_t* __restrict__ perm, Work w)
 {
     __shared__ double red[TW];
     __shared__ int ired[TW];
-    __shared__ int anyneed;
+    __shared__ double part[TT];
+    __shared__ unsigned s_ticket;
+    __shared__ int s_any;
     const int tid = threadIdx.x;
-    if (tid == 0) anyneed = 0;
+    // |x_tail|^2 from the slab partials (every workgroup: it needs the reflector scalars)
+    double t = 0.0;
+    for (int g = tid; g < w.G; g += TT) t += w.tpart[g];
+    t = wave_sum(t);
+    if ((tid & 63) == 0) red[tid >> 6] = t;
+    __syncthreads();
     double tsq = 0.0;
-    for (int g = 0; g < w.G; ++g) tsq += w.tpart[g];
-    const double xk = A[(int64_t)k * lda + k];
+#pragma unroll
+    for (int q = 0; q < TW; ++q) tsq += red[q];
+    const double xk = A[(int64_t)k * lda + k];       // (rewritten with beta by the last workgroup only)
     // makeHouseholder, un-normalised form of bdqr_pair.hip: nb = -beta, s = x0 - beta, ng = -1/(beta w)
     double nb, s, ng, tau;
     const bool degen = !(tsq > DBL_MIN);
@@ -182,38 +199,56 @@ head_kernel(double* __restrict__ A, int64_t lda, int r, int c, int k, int pivoti
         ng = -1.0 / (nb * s);
         tau = -(s * s) * ng;
     }
+    // this workgroup's columns
+    {
+        const int cl = tid % HC, gg = tid / HC;
+        const int jc = k + 1 + (int)blockIdx.x * HC + cl;
+        double d = 0.0;
+        if (jc < c) for (int g = gg; g < w.G; g += HG) d += w.partial[(int64_t)g * w.cpad + jc];
+        part[gg * HC + cl] = d;
+        __syncthreads();
+        if (gg == 0 && jc < c) {
+            d = 0.0;
+#pragma unroll
+            for (int q = 0; q < HG; ++q) d += part[q * HC + cl];
+            const double ak = A[(int64_t)jc * lda + k];
+            const double ngam = fma(s, ak, d) * ng;
+            const double an = fma(s, ngam, ak);
+            w.ngamv[jc] = ngam;
+            A[(int64_t)jc * lda + k] = an;            // row k of R
+            int nd = 0;
+            if (pivoting) {
+                // LAWN-176 downdate in squared form (see bdqr_pair.hip); no clamp: a negative value is recomputed
+                const double nn = fma(-an, an, w.nu2[jc]);
+                w.nu2[jc] = nn;
+                nd = nn <= w.thr[jc];
+                if (nd) atomicOr(&w.st->anyneed, 1);
+            }
+            w.need[jc] = nd;
+        }
+    }
+    __threadfence();
     __syncthreads();
+    if (tid == 0) s_ticket = atomicAdd(&w.st->ticket, 1u);
+    __syncthreads();
+    if (s_ticket != gridDim.x - 1) return;
+    // ---- the last workgroup: every column of the step is in memory
+    __threadfence();
     if (tid == 0) {
+        s_any = atomicOr(&w.st->anyneed, 0);
+        w.st->anyneed = 0; w.st->ticket = 0u;
         w.st->s = s; w.st->ng = ng; w.st->inv_s = degen ? 0.0 : 1.0 / s;
         A[(int64_t)k * lda + k] = -nb;            // beta (= x0 when H = I)
         hcoeffs[k] = tau;
     }
-    const int size = r < c ? r : c;
-    for (int jc = k + 1 + tid; jc < c; jc += TT) {
-        double d = 0.0;
-        for (int g = 0; g < w.G; ++g) d += w.partial[(int64_t)g * w.cpad + jc];
-        const double ak = A[(int64_t)jc * lda + k];
-        const double ngam = fma(s, ak, d) * ng;
-        const double an = fma(s, ngam, ak);
-        w.ngamv[jc] = ngam;
-        A[(int64_t)jc * lda + k] = an;            // row k of R
-        int nd = 0;
-        if (pivoting) {
-            // LAWN-176 downdate in squared form (see bdqr_pair.hip); no clamp: a negative value is recomputed
-            const double nn = fma(-an, an, w.nu2[jc]);
-            w.nu2[jc] = nn;
-            nd = nn <= w.thr[jc];
-            if (nd) anyneed = 1;
-        }
-        w.need[jc] = nd;
-    }
     __syncthreads();
+    const int size = r < c ? r : c;
     if (k + 1 >= size) {
         if (tid == 0) { w.st->slow = 0; w.st->P = k + 1; }
         for (int jc = tid; jc < c; jc += TT) perm[jc] = w.pidx[jc];     // colsPermutation().indices()
         return;
     }
-    if (anyneed) { if (tid == 0) w.st->slow = 1; return; }
+    if (s_any) { if (tid == 0) w.st->slow = 1; return; }
     if (tid == 0) w.st->slow = 0;
     choose_and_swap(k + 1, c, pivoting, w, red, ired);
 }
@@ -402,7 +437,8 @@ hipError_t launch_dense_qr_tall(double* A, int64_t lda, int r, int c, int pivoti
     hipLaunchKernelGGL(init_kernel, dim3(1), dim3(TT), 0, stream, c, pivoting, w);
     hipLaunchKernelGGL(swap_dots_kernel, dim3(G), dim3(TT), sm1, stream, A, lda, r, c, 0, 1, w);
     for (int k = 0; k < size; ++k) {
-        hipLaunchKernelGGL(head_kernel, dim3(1), dim3(TT), 0, stream, A, lda, r, c, k, pivoting, hcoeffs, perm, w);
+        const int nh = (c - k - 1 + HC - 1) / HC;
+        hipLaunchKernelGGL(head_kernel, dim3(nh > 0 ? nh : 1), dim3(TT), 0, stream, A, lda, r, c, k, pivoting, hcoeffs, perm, w);
         hipLaunchKernelGGL(sweep_kernel, dim3(G), dim3(TT), sm2, stream, A, lda, r, c, k, w);
         if (pivoting && k + 1 < size) {
             hipLaunchKernelGGL(recompute_kernel, dim3(1), dim3(TT), 0, stream, c, k, pivoting, w);
