@@ -159,18 +159,32 @@ class SparseBlockDiagonal {
 
     // SparseBlockDiagonal.h:71-89 with the block map of SparseQRUtils.h:255-272:
     // numBlocks = matCols / blockCols blocks (i*blockRows, i*blockCols, blockRows, blockCols).
-    template <typename SparseMat>
-    void fromBlockDiagonalPattern(const SparseMat& mat, StorageIndex blockRows, StorageIndex blockCols) {
+    // The tiles are cut on the device (qrk_bd_tiles_from_sparse); mat is a compressed SparseMatrix<RowMajor?>.
+    template <bool RM>
+    void fromBlockDiagonalPattern(const SparseMatrix<RM>& mat, StorageIndex blockRows, StorageIndex blockCols, int device = 0) {
         clear();
         nRows = (StorageIndex)mat.rows();
         nCols = (StorageIndex)mat.cols();
         const StorageIndex numBlocks = nCols / blockCols;
-        for (StorageIndex i = 0; i < numBlocks; ++i) {
-            Matrix b(blockRows, blockCols);
-            for (StorageIndex c = 0; c < blockCols; ++c)
-                for (StorageIndex r = 0; r < blockRows; ++r) b(r, c) = mat.coeff(i * blockRows + r, i * blockCols + c);
-            insertBack(b);
-        }
+        m_rows.assign((size_t)numBlocks, (int32_t)blockRows);
+        m_cols.assign((size_t)numBlocks, (int32_t)blockCols);
+        m_tiles.assign((size_t)numBlocks * (size_t)blockRows * (size_t)blockCols, 0.0);
+        if (numBlocks == 0) return;
+        qrk_handle h = 0;
+        if (qrk_create(&h, device, 0) != QRK_STATUS_OK) throw std::runtime_error(std::string("qrkit: ") + qrk_last_error(0));
+        qrk_bd_layout lay;
+        lay.num_blocks = numBlocks; lay.block_rows = blockRows; lay.block_cols = blockCols;
+        lay.rows = lay.cols = 0;
+        lay.mat_rows = nRows; lay.mat_cols = numBlocks * blockCols;
+        qrk_bd_plan plan = 0;
+        qrk_status st = qrk_bd_plan_create(h, &lay, QRK_FULL_Q, QRK_COLPIV_HOUSEHOLDER, &plan);
+        if (st == QRK_STATUS_OK)
+            st = qrk_bd_tiles_from_sparse(plan, RM ? 1 : 0, mat.outerIndex().data(), mat.innerIndex().data(), mat.values().data(),
+                                          (int64_t)mat.nonZeros(), m_tiles.data(), QRK_MEM_HOST);
+        const std::string msg = st == QRK_STATUS_OK ? std::string() : std::string("qrkit: ") + qrk_last_error(h);
+        if (plan) qrk_bd_plan_destroy(plan);
+        qrk_destroy(h);
+        if (st != QRK_STATUS_OK) throw std::runtime_error(msg);
     }
     void insertBack(const Matrix& elem) {
         m_rows.push_back((int32_t)elem.rows());

@@ -128,6 +128,20 @@ qrk_status qrk_bd_plan_sizes(qrk_bd_plan plan, int64_t* tiles_len, int64_t* nnz_
 qrk_status qrk_bd_pattern(qrk_bd_plan plan, int32_t* q_rowptr, int32_t* q_colidx, int32_t* r_colptr,
                           int32_t* r_rowidx, qrk_memspace space);
 
+/* ------------------------------------------- block-diagonal: cutting the tiles */
+
+/* SparseBlockDiagonal::fromBlockDiagonalPattern (SparseBlockDiagonal.h:71-89): tile i =
+ * dense copy of mat.block(base_row_i, base_col_i, rows_i, cols_i), the block map being
+ * BlockBandedMatrixInfo::fromBlockDiagonalPattern (SparseQRUtils.h:255-272; base_row / base_col
+ * are the running sums of the plan's layout, = i*blockRows / i*blockCols for equal blocks).
+ * `mat` is a compressed sparse matrix with int32 indices: column-major (CSC: mat_cols+1 outer
+ * pointers, row indices) when row_major == 0, row-major (CSR: mat_rows+1 outer pointers, column
+ * indices) otherwise.  Entries of `mat` outside the blocks are ignored, as block() ignores them.
+ *   tiles [tiles_len] out: tile i column-major at the running offset (the input of qrk_bd_factorize) */
+qrk_status qrk_bd_tiles_from_sparse(qrk_bd_plan plan, int row_major, const int32_t* outer_ptr,
+                                    const int32_t* inner_idx, const double* vals, int64_t nnz, double* tiles,
+                                    qrk_memspace space);
+
 /* ------------------------------------------------- block-diagonal: factorize */
 
 /* factorize(): per tile A_i P_i = Q_i R_i (BlockDiagonalSparseQR.h:432-526).

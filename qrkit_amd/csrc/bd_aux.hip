@@ -237,6 +237,72 @@ bd_solve_wg_kernel(TileGeom g, const double* __restrict__ q_vals, const double* 
     }
 }
 
+// Tiles cut out of a sparse matrix on the device: SparseBlockDiagonal::fromBlockDiagonalPattern
+// (SparseBlockDiagonal.h:71-89), i.e. BlockMatrixType(mat.block(idxRow, idxCol, numRows, numCols)) for the blocks
+// (base_row, base_col, rows, cols) of BlockBandedMatrixInfo::fromBlockDiagonalPattern (SparseQRUtils.h:255-272).
+// One workgroup per tile.  The tile is assembled piece by piece in LDS (a piece = PR rows x PC columns, at most
+// CUT_BUF doubles) and leaves as coalesced column-major stores, so HBM sees each tile element written once.
+// The entries of a piece's outer range (columns for CSC, rows for CSR) are one contiguous run of the value
+// array: the threads walk it with stride 256 and find the outer index of an entry by bisection of the
+// outer pointers kept in LDS.  Entries outside the block (the reference's block() ignores them) are skipped.
+constexpr int CUT_BUF = 4096;      // doubles of LDS per piece
+constexpr int CUT_OUTER = 1024;    // outer indices per piece at most
+
+template <bool CSR>
+__global__ void __launch_bounds__(256)
+bd_cut_tiles_kernel(TileGeom g, const int64_t* __restrict__ t_off, const int32_t* __restrict__ outer_ptr,
+                    const int32_t* __restrict__ inner_idx, const double* __restrict__ vals,
+                    double* __restrict__ tiles)
+{
+    __shared__ double buf[CUT_BUF];
+    __shared__ int32_t optr[CUT_OUTER + 1];
+    const int tid = threadIdx.x;
+    for (int64_t t = blockIdx.x; t < g.num_tiles; t += gridDim.x) {
+        int r, c, base_row, base_col;
+        int64_t qoff, roff;
+        tile_geom(g, t, r, c, qoff, roff, base_row, base_col);
+        const int64_t toff = t_off ? t_off[t] : t * (int64_t)r * c;
+        if (r <= 0 || c <= 0) continue;
+        // piece shape: as many whole columns as fit (CSC walks columns, CSR walks rows of the piece)
+        const int pr_max = r < CUT_BUF ? r : CUT_BUF;
+        int pc_max = CUT_BUF / pr_max;
+        if (pc_max > c) pc_max = c;
+        const int o_max = CSR ? (pr_max < CUT_OUTER ? pr_max : CUT_OUTER) : (pc_max < CUT_OUTER ? pc_max : CUT_OUTER);
+        const int prr = CSR ? o_max : pr_max;   // rows per piece
+        const int pcc = CSR ? pc_max : o_max;   // columns per piece
+        for (int c0 = 0; c0 < c; c0 += pcc) {
+            const int nc = c - c0 < pcc ? c - c0 : pcc;
+            for (int r0 = 0; r0 < r; r0 += prr) {
+                const int nr = r - r0 < prr ? r - r0 : prr;
+                const int n_outer = CSR ? nr : nc;
+                const int o_base = CSR ? base_row + r0 : base_col + c0;
+                for (int e = tid; e < nr * nc; e += 256) buf[e] = 0.0;
+                for (int o = tid; o <= n_outer; o += 256) optr[o] = outer_ptr[o_base + o];
+                __syncthreads();
+                const int e_begin = optr[0], e_end = optr[n_outer];
+                for (int e = e_begin + tid; e < e_end; e += 256) {
+                    int lo = 0, hi = n_outer;          // outer index o with optr[o] <= e < optr[o+1]
+                    while (hi - lo > 1) {
+                        const int mid = (lo + hi) >> 1;
+                        if (optr[mid] <= e) lo = mid; else hi = mid;
+                    }
+                    const int in = inner_idx[e] - (CSR ? base_col + c0 : base_row + r0);
+                    if (in >= 0 && in < (CSR ? nc : nr)) {
+                        const int row = CSR ? lo : in, col = CSR ? in : lo;
+                        buf[col * nr + row] = vals[e];
+                    }
+                }
+                __syncthreads();
+                for (int e = tid; e < nr * nc; e += 256) {
+                    const int col = e / nr, row = e - col * nr;
+                    tiles[toff + (int64_t)(c0 + col) * r + r0 + row] = buf[e];
+                }
+                __syncthreads();
+            }
+        }
+    }
+}
+
 void launch_bd_pattern(const TileGeom& g, int64_t nnz_r, int32_t* q_rowptr, int32_t* q_colidx,
                        int32_t* r_colptr, int32_t* r_rowidx, hipStream_t stream)
 {
@@ -304,6 +370,17 @@ void launch_bd_solve(const TileGeom& g, int max_cols, const double* q_vals, cons
     else
         hipLaunchKernelGGL(bd_solve_wg_kernel, dim3(grid), dim3(256), (size_t)max_cols * sizeof(double), stream, g, q_vals,
                            r_vals, perm, b, nrhs, x);
+}
+
+void launch_bd_cut_tiles(const TileGeom& g, const int64_t* t_off, int row_major, const int32_t* outer_ptr,
+                         const int32_t* inner_idx, const double* vals, double* tiles, hipStream_t stream)
+{
+    if (g.num_tiles <= 0) return;
+    const unsigned grid = (unsigned)(g.num_tiles < 262144 ? g.num_tiles : 262144);
+    if (row_major)
+        hipLaunchKernelGGL(bd_cut_tiles_kernel<true>, dim3(grid), dim3(256), 0, stream, g, t_off, outer_ptr, inner_idx, vals, tiles);
+    else
+        hipLaunchKernelGGL(bd_cut_tiles_kernel<false>, dim3(grid), dim3(256), 0, stream, g, t_off, outer_ptr, inner_idx, vals, tiles);
 }
 
 }  // namespace qrk

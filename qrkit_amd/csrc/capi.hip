@@ -490,6 +490,37 @@ qrk_status qrk_bd_pattern(qrk_bd_plan p, int32_t* q_rowptr, int32_t* q_colidx, i
     return QRK_STATUS_OK;
 }
 
+qrk_status qrk_bd_tiles_from_sparse(qrk_bd_plan p, int row_major, const int32_t* outer_ptr, const int32_t* inner_idx,
+                                    const double* vals, int64_t nnz, double* tiles, qrk_memspace space)
+{
+    if (!p || !outer_ptr || !tiles || nnz < 0 || (nnz > 0 && (!inner_idx || !vals)))
+        return fail(p ? p->h : nullptr, QRK_STATUS_INVALID_ARGUMENT, "qrk_bd_tiles_from_sparse: NULL argument");
+    qrk_handle h = p->h;
+    if (nnz > INT32_MAX)
+        return fail(h, QRK_STATUS_UNSUPPORTED, "qrk_bd_tiles_from_sparse: nnz exceeds the int32 StorageIndex of the reference");
+    QRK_HIP(h, hipSetDevice(h->device));
+    const qrk::TileGeom g = make_geom(p);
+    const int64_t* t_off = p->uniform ? nullptr : p->d_toff;
+    if (space == QRK_MEM_DEVICE) {
+        qrk::launch_bd_cut_tiles(g, t_off, row_major, outer_ptr, inner_idx, vals, tiles, h->stream);
+        QRK_HIP(h, hipGetLastError());
+        return QRK_STATUS_OK;
+    }
+    Staging s(h);
+    int32_t *d_ptr, *d_idx;
+    double *d_vals, *d_tiles;
+    qrk_status st;
+    const int64_t n_outer = (row_major ? p->mat_rows : p->mat_cols) + 1;
+    if ((st = s.in(outer_ptr, n_outer, &d_ptr)) || (st = s.in(inner_idx, nnz, &d_idx)) || (st = s.in(vals, nnz, &d_vals)) ||
+        (st = s.out(p->tiles_len, &d_tiles)))
+        return st;
+    qrk::launch_bd_cut_tiles(g, t_off, row_major, d_ptr, d_idx, d_vals, d_tiles, h->stream);
+    QRK_HIP(h, hipGetLastError());
+    if ((st = s.back(tiles, d_tiles, p->tiles_len))) return st;
+    QRK_HIP(h, hipStreamSynchronize(h->stream));
+    return QRK_STATUS_OK;
+}
+
 qrk_status qrk_bd_factorize(qrk_bd_plan p, const double* tiles, double* q_vals, double* r_vals,
                             int32_t* perm, double* hcoeffs, qrk_memspace space)
 {

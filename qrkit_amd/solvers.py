@@ -82,13 +82,17 @@ class SparseBlockDiagonal:
         self.nCols = int(self.block_cols.sum())
         return self
 
-    def fromBlockDiagonalPattern(self, mat, blockRows: int, blockCols: int):
+    def fromBlockDiagonalPattern(self, mat, blockRows: int, blockCols: int, context: "Optional[Context]" = None):
         """SparseBlockDiagonal::fromBlockDiagonalPattern (SparseBlockDiagonal.h:71-89) with the block
         map of BlockBandedMatrixInfo::fromBlockDiagonalPattern (SparseQRUtils.h:255-272):
         numBlocks = cols / blockCols tiles (i*blockRows, i*blockCols, blockRows, blockCols) cut out of
-        `mat` (scipy sparse or dense ndarray)."""
+        `mat` (scipy sparse or dense ndarray).  A compressed sparse `mat` is cut on the device
+        (qrk_bd_tiles_from_sparse) and the tiles stay there; the loop below serves dense input and the
+        host-logic tests."""
         nrows, ncols = mat.shape
         num_blocks = ncols // blockCols
+        if hasattr(mat, "indptr") and torch.cuda.is_available():
+            return self._cutOnDevice(mat, num_blocks, blockRows, blockCols, context)
         dense_block = (lambda r0, c0: mat[r0:r0 + blockRows, c0:c0 + blockCols].toarray()) \
             if hasattr(mat, "toarray") else (lambda r0, c0: np.asarray(mat[r0:r0 + blockRows, c0:c0 + blockCols]))
         tiles = np.empty(num_blocks * blockRows * blockCols)
@@ -99,6 +103,39 @@ class SparseBlockDiagonal:
         self.block_rows = np.full(num_blocks, blockRows, np.int32)
         self.block_cols = np.full(num_blocks, blockCols, np.int32)
         self.tiles, self.tiles_dev = tiles, None
+        self.nRows, self.nCols = int(nrows), int(ncols)
+        return self
+
+    def _cutOnDevice(self, mat, num_blocks: int, blockRows: int, blockCols: int, context=None):
+        """The tiles of a CSC/CSR matrix, cut by the HIP kernel behind qrk_bd_tiles_from_sparse."""
+        if mat.format not in ("csc", "csr"):
+            mat = mat.tocsc()
+        mat.sort_indices()
+        ctx = context or Context(0)
+        dev = ctx.device
+        nrows, ncols = mat.shape
+        lay = capi.BDLayout()
+        lay.num_blocks, lay.block_rows, lay.block_cols = num_blocks, blockRows, blockCols
+        lay.rows = lay.cols = None
+        lay.mat_rows, lay.mat_cols = int(nrows), int(num_blocks * blockCols)
+        plan = C.c_void_p()
+        ctx.use_current_stream()
+        capi.check(capi.lib().qrk_bd_plan_create(ctx.handle, C.byref(lay), capi.FULL_Q, capi.COLPIV_HOUSEHOLDER,
+                                                 C.byref(plan)), ctx.handle)
+        try:
+            ptr = torch.from_numpy(np.ascontiguousarray(mat.indptr, dtype=np.int32)).to(dev)
+            idx = torch.from_numpy(np.ascontiguousarray(mat.indices, dtype=np.int32)).to(dev)
+            vals = torch.from_numpy(np.ascontiguousarray(mat.data, dtype=np.float64)).to(dev)
+            tiles = torch.empty(max(num_blocks * blockRows * blockCols, 1), dtype=torch.float64, device=dev)
+            capi.check(capi.lib().qrk_bd_tiles_from_sparse(plan, 1 if mat.format == "csr" else 0, ptr.data_ptr(),
+                                                           idx.data_ptr(), vals.data_ptr(), int(mat.nnz),
+                                                           tiles.data_ptr(), capi.MEM_DEVICE), ctx.handle)
+            ctx.synchronize()
+        finally:
+            capi.lib().qrk_bd_plan_destroy(plan)
+        self.block_rows = np.full(num_blocks, blockRows, np.int32)
+        self.block_cols = np.full(num_blocks, blockCols, np.int32)
+        self.tiles, self.tiles_dev = None, tiles[:num_blocks * blockRows * blockCols]
         self.nRows, self.nCols = int(nrows), int(ncols)
         return self
 
