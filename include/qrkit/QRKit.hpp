@@ -525,6 +525,104 @@ class BandedBlockedSparseQR {
 };
 
 // ---------------------------------------------------------------------------------------------
+// QRKit::BlockedThinDenseQR<MatrixXd, HouseholderQR<MatrixXd>, SuggestedBlockCols> (BlockedThinDenseQR.h:53-176,
+// base BlockedThinQRBase.h:47-333) and QRKit::BlockedThinSparseQR (BlockedThinSparseQR.h:105-283 -- the same
+// factorisation fed from a sparse matrix): Householder QR of a thin dense matrix, no column pivoting, identity
+// row permutation.  The reference walks panels of SuggestedBlockCols columns (HouseholderQR of the panel, Y/T of
+// the panel, block-reflector update of the columns on the right, :152-173); the reflectors of that chain are
+// those of one HouseholderQR of the whole matrix, which is what the device computes (qrk_dense_factorize with
+// QRK_HOUSEHOLDER), Q stays implicit (qrk_dense_apply_q) as in the reference.  The class is also the
+// RightSolver argument of BlockAngularSparseQR (test/test-qrkit.cpp:294-362).
+template <int SuggestedBlockCols = 2>
+class BlockedThinDenseQR {
+  public:
+    static const int kSolver = QRK_HOUSEHOLDER;
+    typedef Matrix MatrixType;
+    typedef Matrix MatrixRType;
+    typedef PermutationMatrix PermutationType;
+    typedef QProduct<BlockedThinDenseQR> MatrixQType;
+
+    explicit BlockedThinDenseQR(int device = 0)
+        : m_info(Success), m_nonzeroPivots(0), m_isInitialized(false), m_handle(0), m_plan(0) {
+        if (qrk_create(&m_handle, device, 0) != QRK_STATUS_OK)
+            throw std::runtime_error(std::string("qrkit: ") + qrk_last_error(0));
+    }
+    explicit BlockedThinDenseQR(const Matrix& mat, int device = 0) : BlockedThinDenseQR(device) { compute(mat); }
+    ~BlockedThinDenseQR() { if (m_plan) qrk_dense_plan_destroy(m_plan); if (m_handle) qrk_destroy(m_handle); }
+    BlockedThinDenseQR(const BlockedThinDenseQR&) = delete;
+    BlockedThinDenseQR& operator=(const BlockedThinDenseQR&) = delete;
+
+    // BlockedThinDenseQR.h:104-136
+    void compute(const Matrix& mat) {
+        m_isInitialized = false;
+        analyzePattern(mat);
+        m_qr = mat;
+        const Index rows = mat.rows(), cols = mat.cols(), k = std::min(rows, cols);
+        if (m_plan) { qrk_dense_plan_destroy(m_plan); m_plan = 0; }
+        check(qrk_dense_plan_create(m_handle, (int32_t)rows, (int32_t)cols, QRK_HOUSEHOLDER, &m_plan));
+        m_hc.assign((size_t)std::max<Index>(k, 1), 0.0);
+        std::vector<int32_t> p((size_t)std::max<Index>(cols, 1), 0);
+        check(qrk_dense_factorize(m_plan, m_qr.data(), rows, m_hc.data(), p.data(), QRK_MEM_HOST));
+        m_R = Matrix(rows, cols);
+        for (Index c = 0; c < cols; ++c) for (Index r = 0; r <= std::min(c, k - 1); ++r) m_R(r, c) = m_qr(r, c);
+        m_nonzeroPivots = cols;     // (:132)
+        m_isInitialized = true;
+        m_info = Success;
+    }
+    template <bool RM>
+    void compute(const SparseMatrix<RM>& mat) { compute(mat.toDense()); }     // BlockedThinSparseQR: same chain on mat
+    // :137-145: no column permutation, no row permutation
+    void analyzePattern(const Matrix& mat) { m_outputPerm_c.setIdentity(mat.cols()); m_rowPerm.setIdentity(mat.rows()); }
+
+    Index rows() const { return m_qr.rows(); }
+    Index cols() const { return m_qr.cols(); }
+    Index rank() const { assert(m_isInitialized && "The factorization should be called first, use compute()"); return m_nonzeroPivots; }
+    ComputationInfo info() const { return m_info; }
+    const MatrixRType& matrixR() const { return m_R; }
+    MatrixQType matrixQ() const { return MatrixQType(*this, false); }
+    const PermutationType& colsPermutation() const { return m_outputPerm_c; }
+    const PermutationType& rowsPermutation() const { return m_rowPerm; }
+    const std::vector<double>& hCoeffs() const { return m_hc; }
+
+    Vector applyQt(const Vector& v) const { return applyQImpl(v, true); }
+    Vector applyQ(const Vector& v) const { return applyQImpl(v, false); }
+    // BlockedThinQRBase::_solve_impl (BlockedThinQRBase.h:223-247): x = R(0:rank,0:rank)^-1 (Q^T b)(0:rank)
+    Vector solve(const Vector& b) const {
+        assert(m_isInitialized && "The factorization should be called first, use compute()");
+        Vector y = applyQt(b);
+        Vector z(y.begin(), y.begin() + cols());
+        check(qrk_dense_solve_r(m_plan, m_qr.data(), (int64_t)rows(), z.data(), (int64_t)cols(), 1, QRK_MEM_HOST));
+        return z;
+    }
+
+  protected:
+    Vector applyQImpl(const Vector& v, bool transpose) const {
+        assert(m_isInitialized && "The factorization should be called first, use compute()");
+        const Index r = rows(), nrhs = (Index)v.size() / r;
+        Vector out(v);
+        check(qrk_dense_apply_q(m_plan, m_qr.data(), r, m_hc.data(), transpose ? 1 : 0, out.data(), r, nrhs, QRK_MEM_HOST));
+        return out;
+    }
+    void check(qrk_status st) const {
+        if (st != QRK_STATUS_OK) throw std::runtime_error(std::string("qrkit: ") + qrk_last_error(m_handle));
+    }
+    ComputationInfo m_info;
+    Index m_nonzeroPivots;
+    bool m_isInitialized;
+    qrk_handle m_handle;
+    qrk_dense_plan m_plan;
+    Matrix m_qr, m_R;
+    std::vector<double> m_hc;
+    PermutationType m_outputPerm_c, m_rowPerm;
+};
+template <int SuggestedBlockCols = 2>
+class BlockedThinSparseQR : public BlockedThinDenseQR<SuggestedBlockCols> {
+  public:
+    typedef SparseMatrixColMajor MatrixType;
+    explicit BlockedThinSparseQR(int device = 0) : BlockedThinDenseQR<SuggestedBlockCols>(device) {}
+};
+
+// ---------------------------------------------------------------------------------------------
 // QRKit::BlockMatrix1x2 (BlockMatrix1x2.h:31-67): non-owning [left | right].
 template <typename LeftBlockType, typename RightBlockType = Matrix>
 class BlockMatrix1x2 {
@@ -581,6 +679,13 @@ class BlockAngularSparseQR {
 
     template <typename LeftMat>
     void compute(const BlockMatrix1x2<LeftMat, Matrix>& mat) { analyzePattern(mat); factorize(mat); }
+    // sparse right block (BlockMatrix1x2<JacobianType, JacobianType>, test/test-qrkit.cpp:335): the right solver
+    // works on dense columns either way (BlockedThinSparseQR.h:131: m_R = mat)
+    template <typename LeftMat, bool RM>
+    void compute(const BlockMatrix1x2<LeftMat, SparseMatrix<RM> >& mat) {
+        const Matrix right = mat.rightBlock().toDense();
+        compute(BlockMatrix1x2<LeftMat, Matrix>(mat.leftBlock(), right));
+    }
 
     // :431-449
     template <typename LeftMat>

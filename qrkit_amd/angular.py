@@ -113,6 +113,41 @@ class DenseColPivQR:
             pass
 
 
+class BlockedThinDenseQR(DenseColPivQR):
+    """QRKit::BlockedThinDenseQR / BlockedThinSparseQR (BlockedThinDenseQR.h:53-176, BlockedThinSparseQR.h:105-283):
+    Householder QR of a thin dense matrix without column pivoting, Q implicit.  The reference walks panels of
+    SuggestedBlockCols columns (HouseholderQR of the panel, Y/T, block-reflector update of the columns to the right);
+    the reflectors of that chain are those of one HouseholderQR of the whole matrix, which the device computes."""
+
+    def __init__(self, context: Context, suggestedBlockCols: int = 2):
+        super().__init__(context, capi.HOUSEHOLDER)
+        self.suggestedBlockCols = suggestedBlockCols
+
+    def compute(self, A):
+        if hasattr(A, "toarray"):        # BlockedThinSparseQR: the same chain fed from a sparse matrix (:131)
+            A = A.toarray()
+        if not isinstance(A, torch.Tensor):
+            A = _colmajor(torch.from_numpy(np.ascontiguousarray(A, dtype=np.float64)).to(self._ctx.device))
+        return super().compute(A)
+
+    def rank(self):
+        return self._shape[1]            # m_nonzeroPivots = m_R.cols() (BlockedThinDenseQR.h:132)
+
+    def colsPermutation(self) -> torch.Tensor:
+        return torch.arange(self._shape[1], dtype=torch.int32, device=self._qr.device)   # identity (:139)
+
+    def rowsPermutation(self) -> torch.Tensor:
+        return torch.arange(self._shape[0], dtype=torch.int32, device=self._qr.device)   # identity (:142)
+
+    def solve(self, b: torch.Tensor) -> torch.Tensor:
+        """BlockedThinQRBase::_solve_impl (BlockedThinQRBase.h:223-247): x = R(0:n,0:n)^-1 (Q^T b)(0:n)."""
+        rows, cols = self._shape
+        y = _colmajor(b.reshape(rows, -1).clone())
+        self.applyQ(y, transpose=True)
+        z = _colmajor(y[:cols, :].clone())
+        return self.solveR(z)
+
+
 def _colmajor(t: torch.Tensor) -> torch.Tensor:
     """Device tensor with column-major storage and the same logical shape."""
     return t.t().contiguous().t()

@@ -109,11 +109,19 @@ static int test_banded_blocked(const SparseMatrixColMajor& spJ, const char* name
     return fails;
 }
 
+template <typename Solver, typename LeftMat, typename RightMat>
+static int test_block_angular_as(const LeftMat& leftForSolver, const SparseMatrixColMajor& leftSparse, const Matrix& right,
+                                 const RightMat& rightForSolver, const char* name);
 template <typename Solver, typename LeftMat>
 static int test_block_angular(const LeftMat& leftForSolver, const SparseMatrixColMajor& leftSparse, const Matrix& right, const char* name) {
+    return test_block_angular_as<Solver>(leftForSolver, leftSparse, right, right, name);
+}
+template <typename Solver, typename LeftMat, typename RightMat>
+static int test_block_angular_as(const LeftMat& leftForSolver, const SparseMatrixColMajor& leftSparse, const Matrix& right,
+                                 const RightMat& rightForSolver, const char* name) {
     int fails = 0;
     Solver baqr;
-    BlockMatrix1x2<LeftMat, Matrix> blkAngular(leftForSolver, right);
+    BlockMatrix1x2<LeftMat, RightMat> blkAngular(leftForSolver, rightForSolver);
     baqr.compute(blkAngular);
     const Index rows = right.rows(), m1 = leftSparse.cols(), m2 = right.cols(), cols = m1 + m2;
     if (baqr.info() != Success || baqr.rank() != cols) { std::printf("  info/rank wrong\n"); ++fails; }
@@ -154,6 +162,32 @@ static int test_block_angular(const LeftMat& leftForSolver, const SparseMatrixCo
     return fails;
 }
 
+// BlockedThinDenseQR on its own: the solver concept of BlockedThinQRBase.h:100-222 (compute, matrixR, matrixQ products,
+// identity permutations, rank, solve) checked with the invariants the reference checks on every solver (:201-203).
+static int test_blocked_thin(const Matrix& A) {
+    int fails = 0;
+    BlockedThinDenseQR<2> slvr;
+    slvr.compute(A);
+    const Index rows = A.rows(), cols = A.cols();
+    if (slvr.info() != Success || slvr.rank() != cols) { std::printf("  info/rank wrong\n"); ++fails; }
+    for (Index j = 0; j < cols; ++j) if (slvr.colsPermutation().indices()[(size_t)j] != j) { std::printf("  column permutation is not the identity\n"); ++fails; break; }
+    const Matrix& R = slvr.matrixR();
+    for (Index j = 0; j < cols && !fails; ++j) for (Index i = j + 1; i < rows; ++i) if (R(i, j) != 0.0) { std::printf("  R is not upper triangular\n"); ++fails; break; }
+    const Matrix QtA = slvr.matrixQ().transpose() * A;        // Q^T A = R
+    if (!approx(QtA, R, 1e-12)) { std::printf("  Q^T*A != R\n"); ++fails; }
+    const Matrix QR = slvr.matrixQ() * R;                     // Q R = A
+    if (!approx(QR, A, 1e-12)) { std::printf("  Q*R != A\n"); ++fails; }
+    std::mt19937_64 rng(5);
+    std::uniform_real_distribution<double> ud(-1.0, 1.0);
+    Vector x((size_t)cols);
+    for (double& v : x) v = ud(rng);
+    Vector b((size_t)rows, 0.0);
+    for (Index j = 0; j < cols; ++j) for (Index i = 0; i < rows; ++i) b[(size_t)i] += A(i, j) * x[(size_t)j];
+    if (!approxVec(x, slvr.solve(b), 1e-8)) { std::printf("  LS recovery failed\n"); ++fails; }
+    std::printf("test_blocked_thin %lld x %lld: %s\n", (long long)rows, (long long)cols, fails ? "Failed." : "Passed.");
+    return fails;
+}
+
 int main() {
     int fails = 0;
     {   // main(), test-qrkit.cpp:363-384
@@ -176,6 +210,18 @@ int main() {
         SparseBlockDiagonal blk;
         blk.fromBlockDiagonalPattern(left, 7, 2);
         fails += test_block_angular<BlockAngularSparseQR<BlockDiagonalSparseQR<ColPivHouseholderQR>, ColPivHouseholderQR> >(blk, left, right, "block-diagonal left solver");
+    }
+    {   // test_block_angular_denseblocked / _denseblocked_sparse (:294-362, typedefs :54-58): thin right solvers
+        const Index numVars = 256, numParams = numVars * 2, numResiduals = numVars * 3 + numVars + numVars * 3, numAngular = 96;
+        SparseMatrixColMajor left; Matrix right;
+        generate_block_angular(numParams, numAngular, numResiduals, true, left, right);
+        fails += test_block_angular<BlockAngularSparseQR<BandedBlockedQRSolver, BlockedThinDenseQR<2> > >(left, left, right, "banded left, BlockedThinDenseQR right");
+        std::vector<Triplet> rt;
+        for (Index j = 0; j < right.cols(); ++j) for (Index i = 0; i < right.rows(); ++i) rt.emplace_back((int)i, (int)j, right(i, j));
+        SparseMatrixColMajor rightSparse(right.rows(), right.cols());
+        rightSparse.setFromTriplets(rt);
+        fails += test_block_angular_as<BlockAngularSparseQR<BandedBlockedQRSolver, BlockedThinSparseQR<2> > >(left, left, right, rightSparse, "banded left, BlockedThinSparseQR right (sparse right block)");
+        fails += test_blocked_thin(right);
     }
     return fails ? 1 : 0;
 }

@@ -56,3 +56,24 @@ def test_hip_angular_matches_oracle(num_vars, m2, n2):
     b = J @ x
     assert rel_fro(ba.applyQt(b), orc.ba_apply_qt(ref, b)) <= 1e-12
     assert rel_fro(ba.solve(b), x) <= 1e-9
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("num_vars,m2", [(256, 96), (1024, 384)])
+def test_hip_angular_with_thin_right_solver(num_vars, m2):
+    """test_block_angular_denseblocked (test-qrkit.cpp:294-327): the right solver is BlockedThinDenseQR, i.e.
+    Householder QR without column pivoting; P2 is the identity."""
+    import qrkit_amd
+    prob, tiles, J1, J2 = angular_problem(num_vars, m2)
+    ref = orc.ba_factorize(prob, J2, right_solver=orc.NOPIV)
+    left = qrkit_amd.SparseBlockDiagonal.fromTiles(prob.rows, prob.cols, tiles)
+    ba = qrkit_amd.BlockAngularSparseQR(rightSolver=qrkit_amd.HOUSEHOLDER)
+    ba.compute(qrkit_amd.BlockMatrix1x2(left, J2))
+    assert ba.info() == 0 and ba.rank() == ref.rank
+    np.testing.assert_array_equal(ba.colsPermutation(), ref.perm)                   # bit-exact
+    m1 = J1.shape[1]
+    np.testing.assert_array_equal(ba.colsPermutation()[m1:], np.arange(m1, m1 + m2))
+    assert rel_fro(ba.matrixR().toarray(), ref.R.toarray()) <= 1e-12
+    J = sp.hstack([J1, sp.csc_matrix(J2)], format="csc")
+    x = np.random.default_rng(0).uniform(-1, 1, J.shape[1])
+    assert rel_fro(ba.solve(J @ x), x) <= 1e-9

@@ -18,13 +18,14 @@ def test_cpp_facade_block_diagonal():
 
 @pytest.mark.gpu
 def test_cpp_facade_compositions():
-    """The reference's test_banded_blocked (3 inputs) and test_block_angular (banded and block-diagonal left
-    solver) written against the C++ facade classes BandedBlockedSparseQR / BlockAngularSparseQR."""
+    """The reference's test_banded_blocked (3 inputs), test_block_angular (banded and block-diagonal left solver),
+    test_block_angular_denseblocked / _denseblocked_sparse (thin right solvers) and the thin solver on its own,
+    written against the C++ facade classes BandedBlockedSparseQR / BlockAngularSparseQR / BlockedThin*QR."""
     subprocess.check_call(["make", "-C", ROOT, "-s", "cpptest"])
     out = subprocess.run([os.path.join(ROOT, "build", "test_compositions")], capture_output=True, text=True, timeout=600)
     print(out.stdout, out.stderr)
     assert out.returncode == 0, out.stdout + out.stderr
-    assert "Failed." not in out.stdout and out.stdout.count("Passed.") == 5
+    assert "Failed." not in out.stdout and out.stdout.count("Passed.") == 8
 
 
 def test_cpp_facade_compiles():

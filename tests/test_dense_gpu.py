@@ -89,3 +89,29 @@ def test_dense_solve_r_on_device(rows, cols):
     qr.solveR(z)
     xs = np.empty(cols); xs[qr.colsPermutation().cpu().numpy()] = z.cpu().numpy()[:, 0]
     assert rel_fro(xs, x) <= 1e-9
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows,cols,sparse_in", [(2000, 96, False), (7168, 384, False), (500, 40, True)])
+def test_blocked_thin_dense_qr_matches_oracle(rows, cols, sparse_in):
+    """BlockedThinDenseQR / BlockedThinSparseQR (BlockedThinDenseQR.h:104-176; 7168 x 384 is the right block of the
+    reference's tests 5-6, test-qrkit.cpp:388-407): R, the reflectors, identity permutations, rank = cols, solve()."""
+    import scipy.sparse as sp
+    import torch
+    import qrkit_amd
+    rng = np.random.default_rng(rows + cols)
+    A = rng.uniform(0.5, 5.0, (rows, cols))
+    if sparse_in:
+        A *= rng.random((rows, cols)) < 0.3
+    ctx = qrkit_amd.Context(0)
+    qr = qrkit_amd.BlockedThinDenseQR(ctx, 2)
+    qr.compute(sp.csc_matrix(A) if sparse_in else A)
+    ref, hc = orc.householder_qr(A)
+    assert qr.rank() == cols and qr.rows() == rows and qr.cols() == cols
+    np.testing.assert_array_equal(qr.colsPermutation().cpu().numpy(), np.arange(cols))
+    np.testing.assert_array_equal(qr.rowsPermutation().cpu().numpy(), np.arange(rows))
+    assert rel_fro(qr.matrixR().cpu().numpy(), np.triu(ref[:cols, :])) <= 1e-11
+    assert rel_fro(qr._hc.cpu().numpy(), hc) <= 1e-11
+    x = rng.uniform(-1, 1, cols)
+    got = qr.solve(torch.from_numpy(A @ x).cuda()).cpu().numpy().ravel()
+    assert rel_fro(got, x) <= 1e-9
