@@ -106,8 +106,9 @@ class SparseBlockDiagonal:
         self.nRows, self.nCols = int(nrows), int(ncols)
         return self
 
-    def _cutOnDevice(self, mat, num_blocks: int, blockRows: int, blockCols: int, context=None):
-        """The tiles of a CSC/CSR matrix, cut by the HIP kernel behind qrk_bd_tiles_from_sparse."""
+    def _cutOnDevice(self, mat, num_blocks: int, blockRows, blockCols, context=None):
+        """The tiles of a CSC/CSR matrix, cut by the HIP kernel behind qrk_bd_tiles_from_sparse.  blockRows/blockCols
+        are either two ints (equal blocks) or per-block arrays; block i sits at the running sums of the sizes."""
         if mat.format not in ("csc", "csr"):
             mat = mat.tocsc()
         mat.sort_indices()
@@ -115,9 +116,19 @@ class SparseBlockDiagonal:
         dev = ctx.device
         nrows, ncols = mat.shape
         lay = capi.BDLayout()
-        lay.num_blocks, lay.block_rows, lay.block_cols = num_blocks, blockRows, blockCols
-        lay.rows = lay.cols = None
-        lay.mat_rows, lay.mat_cols = int(nrows), int(num_blocks * blockCols)
+        lay.num_blocks = num_blocks
+        if np.ndim(blockRows) == 0:
+            br = np.full(num_blocks, blockRows, np.int32)
+            bc = np.full(num_blocks, blockCols, np.int32)
+            lay.block_rows, lay.block_cols = int(blockRows), int(blockCols)
+            lay.rows = lay.cols = None
+        else:
+            br = np.ascontiguousarray(blockRows, dtype=np.int32)
+            bc = np.ascontiguousarray(blockCols, dtype=np.int32)
+            lay.rows = br.ctypes.data_as(C.POINTER(C.c_int32))
+            lay.cols = bc.ctypes.data_as(C.POINTER(C.c_int32))
+        n_tiles = int((br.astype(np.int64) * bc.astype(np.int64)).sum())
+        lay.mat_rows, lay.mat_cols = int(nrows), int(bc.sum())
         plan = C.c_void_p()
         ctx.use_current_stream()
         capi.check(capi.lib().qrk_bd_plan_create(ctx.handle, C.byref(lay), capi.FULL_Q, capi.COLPIV_HOUSEHOLDER,
@@ -126,18 +137,47 @@ class SparseBlockDiagonal:
             ptr = torch.from_numpy(np.ascontiguousarray(mat.indptr, dtype=np.int32)).to(dev)
             idx = torch.from_numpy(np.ascontiguousarray(mat.indices, dtype=np.int32)).to(dev)
             vals = torch.from_numpy(np.ascontiguousarray(mat.data, dtype=np.float64)).to(dev)
-            tiles = torch.empty(max(num_blocks * blockRows * blockCols, 1), dtype=torch.float64, device=dev)
+            tiles = torch.empty(max(n_tiles, 1), dtype=torch.float64, device=dev)
             capi.check(capi.lib().qrk_bd_tiles_from_sparse(plan, 1 if mat.format == "csr" else 0, ptr.data_ptr(),
                                                            idx.data_ptr(), vals.data_ptr(), int(mat.nnz),
                                                            tiles.data_ptr(), capi.MEM_DEVICE), ctx.handle)
             ctx.synchronize()
         finally:
             capi.lib().qrk_bd_plan_destroy(plan)
-        self.block_rows = np.full(num_blocks, blockRows, np.int32)
-        self.block_cols = np.full(num_blocks, blockCols, np.int32)
-        self.tiles, self.tiles_dev = None, tiles[:num_blocks * blockRows * blockCols]
+        self.block_rows, self.block_cols = br, bc
+        self.tiles, self.tiles_dev = None, tiles[:n_tiles]
         self.nRows, self.nCols = int(nrows), int(ncols)
         return self
+
+    def fromSparseMatrix(self, mat, context: "Optional[Context]" = None):
+        """SparseBlockDiagonal::fromSparseMatrix (SparseBlockDiagonal.h:95-130): as-banded-as-possible row ordering
+        (SparseQROrdering.h:52-120), generic block detection with SuggestedBlockCols = 3 (:57,
+        SparseQRUtils.h:186-253,308-385) -- both by the library's host analysis, qrk_bb_analyze_host -- then the
+        blocks cut on the device.  Returns (self, rowPerm); rowPerm has Eigen's meaning, (P*M).row(rowPerm[i]) =
+        M.row(i), and is the identity when the ordering found nothing to do.
+        The reference cuts the blocks out of the UN-permuted `mat` (:128), which only gives the diagonal blocks when no
+        permutation was needed; here they are cut out of the permuted matrix, the one the block map describes.
+        The blocks must tile the diagonal (block i at the running sums of the sizes): anything else is not block
+        diagonal and raises ValueError."""
+        import scipy.sparse as sp
+        from .banded import analyze_host
+        M = sp.csr_matrix(mat)
+        M.sort_indices()
+        perm, blocks, has = analyze_host(M, 3)
+        if has:
+            inv = np.empty_like(perm)
+            inv[perm] = np.arange(len(perm), dtype=perm.dtype)
+            M = M[inv]
+            M.sort_indices()
+        else:
+            perm = np.arange(M.shape[0], dtype=np.int32)
+        br, bc = blocks[:, 2].astype(np.int32), blocks[:, 3].astype(np.int32)
+        row0 = np.concatenate([[0], np.cumsum(br)[:-1]]) if len(br) else np.zeros(0, np.int64)
+        col0 = np.concatenate([[0], np.cumsum(bc)[:-1]]) if len(bc) else np.zeros(0, np.int64)
+        if not (np.array_equal(blocks[:, 0], row0) and np.array_equal(blocks[:, 1], col0) and int(bc.sum()) == M.shape[1]):
+            raise ValueError("fromSparseMatrix: the detected blocks do not tile the diagonal (not a block-diagonal matrix)")
+        self._cutOnDevice(M, len(br), br, bc, context)
+        return self, perm
 
     # -- reference accessors ---------------------------------------------------------------
     def size(self) -> int:

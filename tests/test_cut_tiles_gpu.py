@@ -119,3 +119,42 @@ def test_reference_flow_sparse_to_solution(qa, ctx):
     np.testing.assert_array_equal(qr.colsPermutation(), ref.perm)
     assert rel_fro(qr.rValues().cpu().numpy(), ref.R_vals) <= RTOL
     assert rel_fro(qr.qValues().cpu().numpy(), ref.Q_vals) <= RTOL
+
+
+def test_from_sparse_matrix_row_shuffled(qa, ctx):
+    """SparseBlockDiagonal::fromSparseMatrix (SparseBlockDiagonal.h:95-130) on a row-shuffled block-diagonal matrix
+    (the input of the reference's test 1, test-utils.cpp:182-209): the ordering and the block map come from the
+    library's host analysis, the blocks are cut on the device.  SuggestedBlockCols = 3 merges pairs of 7x2 blocks."""
+    B = 64
+    mat = block_diag_matrix(B, 7, 2, seed=1).tocsr()
+    p = np.random.default_rng(0).permutation(mat.shape[0])
+    shuffled = mat[p]
+    blk, row_perm = qa.SparseBlockDiagonal().fromSparseMatrix(shuffled, context=ctx)
+    # oracle: the reference's ordering + block detection restated in C
+    S = shuffled.copy(); S.sort_indices()
+    has, operm = orc.as_banded_as_possible(S.shape[0], S.shape[1], S.indptr, S.indices)
+    assert has
+    np.testing.assert_array_equal(row_perm, operm)
+    inv = np.empty_like(operm); inv[operm] = np.arange(len(operm))
+    Sp = S[inv]; Sp.sort_indices()
+    oblocks = orc.block_info_from_csr(Sp.shape[0], Sp.shape[1], Sp.indptr, Sp.indices, 3)
+    np.testing.assert_array_equal(blk.block_rows, oblocks[:, 2])
+    np.testing.assert_array_equal(blk.block_cols, oblocks[:, 3])
+    want = np.concatenate([Sp[r0:r0 + nr, c0:c0 + nc].toarray().ravel(order="F") for r0, c0, nr, nc in oblocks])
+    np.testing.assert_array_equal(blk.tiles_dev.cpu().numpy(), want)
+    # the permuted matrix is the block-diagonal one again (rows within a block may be ordered differently)
+    assert blk.rows() == mat.shape[0] and blk.cols() == mat.shape[1]
+    qr = qa.BlockDiagonalSparseQR(context=ctx)
+    qr.compute(blk)
+    x = np.random.default_rng(1).uniform(-1, 1, mat.shape[1])
+    b = np.empty(mat.shape[0]); b[row_perm] = shuffled @ x          # rowsPermutation * (J x)
+    assert rel_fro(qr.solve(b), x) <= 1e-10
+
+
+def test_from_sparse_matrix_rejects_banded(qa, ctx):
+    B = 32
+    m = block_diag_matrix(B, 7, 2, seed=2).tolil()
+    for i in range(B - 1):
+        m[7 * i + 6, 2 * i + 2] = 1.0          # overlap into the next block's columns
+    with pytest.raises(ValueError):
+        qa.SparseBlockDiagonal().fromSparseMatrix(m.tocsr(), context=ctx)
