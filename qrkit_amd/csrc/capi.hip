@@ -31,6 +31,7 @@ struct qrk_context_s {
     int num_cus = 256;
     int pair_wgs_per_cu = 8;       // resident pair-kernel workgroups per CU: 2 waves per SIMD (232 VGPRs, 20 KB LDS each)
     bool use_pair_kernel = true;   // two tiles per wavefront (bdqr_pair.hip); QRK_KERNEL=wave selects bdqr_wave.hip
+    bool use_small_kernel = true;  // uniform tiles with at most 16 rows: 64/G tiles per wavefront (bdqr_small.hip); QRK_SMALL=0 disables
     // side streams for the size classes of a mixed batch (fork after / join into `stream`), created on first use
     hipStream_t side[3] = {nullptr, nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
@@ -185,6 +186,8 @@ qrk_status enqueue_factorize(qrk_bd_plan_s* p, const double* tiles, double* q, d
                                             k.max_cols, k.w_lds, h->stream));
         } else if (p->max_dim > 32)
             qrk::launch_bdqr_wg(nb, tiles, q, r, perm, hc, p->d_workspace, p->ws_stride, p->num_wg, p->max_dim, h->stream);
+        else if (p->max_dim <= 16 && p->r >= p->c && h->use_small_kernel)   // 64/G tiles per wavefront (bdqr_small.hip)
+            qrk::launch_bdqr_small(p->B, p->r, p->c, nb.pivoting, tiles, q, r, perm, hc, h->num_cus * 32, h->stream);
         else if (h->use_pair_kernel) qrk::launch_bdqr_pair(nb, full32, tiles, q, r, perm, hc, h->num_cus * h->pair_wgs_per_cu, h->stream);
         else qrk::launch_bdqr_wave(nb, full32, tiles, q, r, perm, hc, max_blocks, h->stream);
     } else {
@@ -256,6 +259,7 @@ qrk_status qrk_create(qrk_handle* out, int device, void* stream)
     h->device = device;
     h->stream = static_cast<hipStream_t>(stream);
     if (const char* k = std::getenv("QRK_KERNEL")) h->use_pair_kernel = std::strcmp(k, "wave") != 0;
+    if (const char* k = std::getenv("QRK_SMALL")) h->use_small_kernel = k[0] != '0';
     if (const char* k = std::getenv("QRK_PAIR_WGS_PER_CU")) { const int v = std::atoi(k); if (v > 0) h->pair_wgs_per_cu = v; }
     if (hipSetDevice(device) != hipSuccess) {
         delete h;
