@@ -292,10 +292,15 @@ __device__ __forceinline__ void pair_step(double (&a)[WR], double (&q)[WR], doub
     double dA = 0.0, dQ = 0.0;
     if (QRK_ABL & 32) { dA = xk; dQ = xk; }
     else {
+        if (QRK_ABL & 2048) {       // diagnostic: the A columns only
+#pragma unroll
+            for (int i = K + 1; i < WR; ++i) dA = fma(x[i], a[i], dA);
+        } else {
 #pragma unroll
         for (int i = K + 1; i < WR; ++i) {
             if (i == K + 1) mul2_shared_a(dA, dQ, x[i], a[i], q[i]);
             else fmac2_shared_a(dA, dQ, x[i], a[i], q[i]);
+        }
         }
     }
 
@@ -331,8 +336,8 @@ __device__ __forceinline__ void pair_step(double (&a)[WR], double (&q)[WR], doub
     const double ngA = fma(s, ak, dA) * ng;      // -gamma for the A column
     double an = fma(s, ngA, ak);
     if (setdiag) an = -nb;                       // R(k,k) = beta
-    const double ngQ = fma(s, qk, dQ) * ng;
-    q[K] = fma(s, ngQ, qk);
+    const double ngQ = (QRK_ABL & 2048) ? 0.0 : fma(s, qk, dQ) * ng;
+    if (!(QRK_ABL & 2048)) q[K] = fma(s, ngQ, qk);
     QRK_STAMP_IN(5);
     hl[L_WBUF + (K % RB) * WR + j] = ngA;
     // Row K of R is final: park it in the LDS slot of the pivot column (never read as a column again).
@@ -349,7 +354,7 @@ __device__ __forceinline__ void pair_step(double (&a)[WR], double (&q)[WR], doub
             // rare: a column norm has to be recomputed from the updated column before the next search
             asm volatile("");
 #pragma unroll
-            for (int i = K + 1; i < WR; ++i) fmac2_shared_b(a[i], q[i], ngA, ngQ, x[i]);
+            for (int i = K + 1; i < WR; ++i) { if (QRK_ABL & 2048) a[i] = fma(ngA, x[i], a[i]); else fmac2_shared_b(a[i], q[i], ngA, ngQ, x[i]); }
             updated = true;
             const bool need = st.live && nn <= st.thr_nd2;
             double sq = 0.0;
@@ -363,7 +368,7 @@ __device__ __forceinline__ void pair_step(double (&a)[WR], double (&q)[WR], doub
     if (K + 1 < WR) search_fetch<(K + 1 < WR ? K + 1 : K), FULL32, PIVOT>(hl, st);
     if (!(QRK_ABL & 16) && !updated) {
 #pragma unroll
-        for (int i = K + 1; i < WR; ++i) fmac2_shared_b(a[i], q[i], ngA, ngQ, x[i]);
+        for (int i = K + 1; i < WR; ++i) { if (QRK_ABL & 2048) a[i] = fma(ngA, x[i], a[i]); else fmac2_shared_b(a[i], q[i], ngA, ngQ, x[i]); }
     }
     QRK_STAMP_IN(6);
 
@@ -708,7 +713,7 @@ bdqr_pair32_kernel(int64_t num_tiles, const double* __restrict__ tiles, double* 
         search_fetch<0, true, PIVOT>(hl, st);     // head of step 0; every step issues the head of the next one
         // q[0..k] are final after step k: every QRK_QSTORE_EVERY steps the finished entries of the lane's
         // Q row go out (16-byte stores; the pieces of a cache line meet again in L2) and free their registers
-#define QRK_QS(FIRST) store_q_half<FIRST, QRK_QSTORE_EVERY>(threadIdx.x, pi, num_tiles, q, q_vals);
+#define QRK_QS(FIRST) if (!(QRK_ABL & 2048)) store_q_half<FIRST, QRK_QSTORE_EVERY>(threadIdx.x, pi, num_tiles, q, q_vals);
 #define QRK_QS4(FIRST) if (QRK_QSTORE_EVERY == 4) QRK_QS(FIRST)
 #define QRK_QS8(FIRST) if (QRK_QSTORE_EVERY == 4) QRK_QS(FIRST + 4) else if (QRK_QSTORE_EVERY == 8) QRK_QS(FIRST)
         QRK_STEP(0) QRK_STEP(1) QRK_STEP(2) QRK_STEP(3) QRK_QS4(0) QRK_STEP(4) QRK_STEP(5) QRK_STEP(6) QRK_STEP(7) QRK_QS8(0)

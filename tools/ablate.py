@@ -14,7 +14,7 @@ import sys
 ROOT = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 MASKS = [int(x) for x in os.environ.get('QRK_MASKS', '0,1024,16,48,1+2+4+64+128+256'.replace('1+2+4+64+128+256', '455')).split(',')]
 NAMES = {1: "no tie branch", 2: "no bpermute", 4: "no degenerate branch", 8: "no sqrt/recip", 16: "no update FMAs",
-         32: "no dot FMAs", 64: "no refresh/parking", 128: "no norm downdate", 256: "no x corrections", 1024: "no steps at all"}
+         32: "no dot FMAs", 2048: "no Q (A columns only)", 64: "no refresh/parking", 128: "no norm downdate", 256: "no x corrections", 1024: "no steps at all"}
 
 
 def build():
