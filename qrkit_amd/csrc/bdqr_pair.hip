@@ -45,6 +45,9 @@
 #ifndef QRK_ABL
 #define QRK_ABL 0
 #endif
+#ifndef QRK_TAIL_LOCAL
+#define QRK_TAIL_LOCAL 0       // 1: |x_tail|^2 accumulated by every lane before the dots (rsq/rcp chains under the dot FMAs, no ds_bpermute): measured 90.0 vs 87.4 us, kept off
+#endif
 #ifndef QRK_QSTORE_EVERY
 #define QRK_QSTORE_EVERY 8     // 4, 8 or 16
 #endif
@@ -289,6 +292,25 @@ __device__ __forceinline__ void pair_step(double (&a)[WR], double (&q)[WR], doub
     double x[WR];                    // rows K+1.. of the pivot column (broadcast reads)
 #pragma unroll
     for (int i = K + 1; i < WR; ++i) x[i] = hl[L_XBUF + i];
+#if QRK_TAIL_LOCAL
+    // |x_tail|^2 in every lane (two chains), so that the square-root / reciprocal refinements below -- a long dependent
+    // chain of few instructions -- run under the dot FMAs instead of after them and after a ds_bpermute round trip
+    double tailSq;
+    {
+        double t0 = 0.0, t1 = 0.0;
+#pragma unroll
+        for (int i = K + 1; i < WR; i += 2) {
+            t0 = fma(x[i], x[i], t0);
+            if (i + 1 < WR) t1 = fma(x[i + 1], x[i + 1], t1);
+        }
+        tailSq = t0 + t1;
+    }
+    const double nrm = (QRK_ABL & 8) ? fma(xk, xk, tailSq) : sqrt_pos(fma(xk, xk, tailSq));
+    double nb = __hiloint2double((__double2hiint(nrm) & 0x7fffffff) | (__double2hiint(xk + 0.0) & (int)0x80000000),
+                                 __double2loint(nrm));
+    double s = nb + xk;
+    double ng = (QRK_ABL & 8) ? -(nb * s) : -recip(nb * s);
+#endif
     double dA = 0.0, dQ = 0.0;
     if (QRK_ABL & 32) { dA = xk; dQ = xk; }
     else {
@@ -312,14 +334,18 @@ __device__ __forceinline__ void pair_step(double (&a)[WR], double (&q)[WR], doub
     //                                     c_i <- c_i - gamma x_i (= c_i - tau ess_i tmp),
     // which needs one square root and one reciprocal (of beta*w > 0) per step and no division.
     // Kept here: nb = -beta = copysign(norm, x0), s = -w = nb + x0, ng = -1/(beta w).
+#if !QRK_TAIL_LOCAL
     const double tailSq = (QRK_ABL & 2) ? dA : bpermute_f64((lbl << 2) + st.hb4, dA);
     const double nrm = (QRK_ABL & 8) ? fma(xk, xk, tailSq) : sqrt_pos(fma(xk, xk, tailSq));
     // Eigen: if (c0 >= 0) beta = -beta; -0.0 counts as >= 0, hence the + 0.0
     double nb = __hiloint2double((__double2hiint(nrm) & 0x7fffffff) | (__double2hiint(xk + 0.0) & (int)0x80000000),
                                  __double2loint(nrm));
     double s = nb + xk;
+#endif
     QRK_STAMP_IN(4);
+#if !QRK_TAIL_LOCAL
     double ng = (QRK_ABL & 8) ? -(nb * s) : -recip(nb * s);
+#endif
     // Eigen: tailSqNorm <= min() gives tau = 0, beta = x0, H = I.  Rare, so a real branch (the empty
     // asm keeps hipcc from flattening it into selects); s = 0 leaves c_k = x0 in the pivot lane.
     const bool degen = !act || !(tailSq > DBL_MIN);
@@ -713,7 +739,7 @@ bdqr_pair32_kernel(int64_t num_tiles, const double* __restrict__ tiles, double* 
         search_fetch<0, true, PIVOT>(hl, st);     // head of step 0; every step issues the head of the next one
         // q[0..k] are final after step k: every QRK_QSTORE_EVERY steps the finished entries of the lane's
         // Q row go out (16-byte stores; the pieces of a cache line meet again in L2) and free their registers
-#define QRK_QS(FIRST) if (!(QRK_ABL & 2048)) store_q_half<FIRST, QRK_QSTORE_EVERY>(threadIdx.x, pi, num_tiles, q, q_vals);
+#define QRK_QS(FIRST) { if (!(QRK_ABL & 2048)) store_q_half<FIRST, QRK_QSTORE_EVERY>(threadIdx.x, pi, num_tiles, q, q_vals); }
 #define QRK_QS4(FIRST) if (QRK_QSTORE_EVERY == 4) QRK_QS(FIRST)
 #define QRK_QS8(FIRST) if (QRK_QSTORE_EVERY == 4) QRK_QS(FIRST + 4) else if (QRK_QSTORE_EVERY == 8) QRK_QS(FIRST)
         QRK_STEP(0) QRK_STEP(1) QRK_STEP(2) QRK_STEP(3) QRK_QS4(0) QRK_STEP(4) QRK_STEP(5) QRK_STEP(6) QRK_STEP(7) QRK_QS8(0)
