@@ -251,7 +251,7 @@ constexpr int CUT_OUTER = 1024;    // outer indices per piece at most
 template <bool CSR>
 __global__ void __launch_bounds__(256)
 bd_cut_tiles_kernel(TileGeom g, const int64_t* __restrict__ t_off, const int32_t* __restrict__ outer_ptr,
-                    const int32_t* __restrict__ inner_idx, const double* __restrict__ vals,
+                    const int32_t* __restrict__ inner_idx, const double* __restrict__ vals, int32_t nnz,
                     double* __restrict__ tiles)
 {
     __shared__ double buf[CUT_BUF];
@@ -279,7 +279,8 @@ bd_cut_tiles_kernel(TileGeom g, const int64_t* __restrict__ t_off, const int32_t
                 for (int e = tid; e < nr * nc; e += 256) buf[e] = 0.0;
                 for (int o = tid; o <= n_outer; o += 256) optr[o] = outer_ptr[o_base + o];
                 __syncthreads();
-                const int e_begin = optr[0], e_end = optr[n_outer];
+                // (clamped to the arrays: malformed outer pointers must not turn into out-of-bounds reads)
+                const int e_begin = optr[0] > 0 ? optr[0] : 0, e_end = optr[n_outer] < nnz ? optr[n_outer] : nnz;
                 for (int e = e_begin + tid; e < e_end; e += 256) {
                     int lo = 0, hi = n_outer;          // outer index o with optr[o] <= e < optr[o+1]
                     while (hi - lo > 1) {
@@ -373,14 +374,14 @@ void launch_bd_solve(const TileGeom& g, int max_cols, const double* q_vals, cons
 }
 
 void launch_bd_cut_tiles(const TileGeom& g, const int64_t* t_off, int row_major, const int32_t* outer_ptr,
-                         const int32_t* inner_idx, const double* vals, double* tiles, hipStream_t stream)
+                         const int32_t* inner_idx, const double* vals, int32_t nnz, double* tiles, hipStream_t stream)
 {
     if (g.num_tiles <= 0) return;
     const unsigned grid = (unsigned)(g.num_tiles < 262144 ? g.num_tiles : 262144);
     if (row_major)
-        hipLaunchKernelGGL(bd_cut_tiles_kernel<true>, dim3(grid), dim3(256), 0, stream, g, t_off, outer_ptr, inner_idx, vals, tiles);
+        hipLaunchKernelGGL(bd_cut_tiles_kernel<true>, dim3(grid), dim3(256), 0, stream, g, t_off, outer_ptr, inner_idx, vals, nnz, tiles);
     else
-        hipLaunchKernelGGL(bd_cut_tiles_kernel<false>, dim3(grid), dim3(256), 0, stream, g, t_off, outer_ptr, inner_idx, vals, tiles);
+        hipLaunchKernelGGL(bd_cut_tiles_kernel<false>, dim3(grid), dim3(256), 0, stream, g, t_off, outer_ptr, inner_idx, vals, nnz, tiles);
 }
 
 }  // namespace qrk

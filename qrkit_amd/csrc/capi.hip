@@ -506,19 +506,22 @@ qrk_status qrk_bd_tiles_from_sparse(qrk_bd_plan p, int row_major, const int32_t*
     const qrk::TileGeom g = make_geom(p);
     const int64_t* t_off = p->uniform ? nullptr : p->d_toff;
     if (space == QRK_MEM_DEVICE) {
-        qrk::launch_bd_cut_tiles(g, t_off, row_major, outer_ptr, inner_idx, vals, tiles, h->stream);
+        qrk::launch_bd_cut_tiles(g, t_off, row_major, outer_ptr, inner_idx, vals, (int32_t)nnz, tiles, h->stream);
         QRK_HIP(h, hipGetLastError());
         return QRK_STATUS_OK;
     }
+    const int64_t n_outer = (row_major ? p->mat_rows : p->mat_cols) + 1;
+    for (int64_t o = 0; o + 1 < n_outer; ++o)
+        if (outer_ptr[o] < 0 || outer_ptr[o] > outer_ptr[o + 1] || outer_ptr[o + 1] > nnz)
+            return fail(h, QRK_STATUS_INVALID_ARGUMENT, "qrk_bd_tiles_from_sparse: outer pointers are not a compressed layout of nnz entries");
     Staging s(h);
     int32_t *d_ptr, *d_idx;
     double *d_vals, *d_tiles;
     qrk_status st;
-    const int64_t n_outer = (row_major ? p->mat_rows : p->mat_cols) + 1;
     if ((st = s.in(outer_ptr, n_outer, &d_ptr)) || (st = s.in(inner_idx, nnz, &d_idx)) || (st = s.in(vals, nnz, &d_vals)) ||
         (st = s.out(p->tiles_len, &d_tiles)))
         return st;
-    qrk::launch_bd_cut_tiles(g, t_off, row_major, d_ptr, d_idx, d_vals, d_tiles, h->stream);
+    qrk::launch_bd_cut_tiles(g, t_off, row_major, d_ptr, d_idx, d_vals, (int32_t)nnz, d_tiles, h->stream);
     QRK_HIP(h, hipGetLastError());
     if ((st = s.back(tiles, d_tiles, p->tiles_len))) return st;
     QRK_HIP(h, hipStreamSynchronize(h->stream));

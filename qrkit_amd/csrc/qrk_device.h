@@ -88,7 +88,7 @@ size_t bb_chain_smem(int max_act_rows, int max_ncols);
 void launch_bd_pattern(const TileGeom& g, int64_t nnz_r, int32_t* q_rowptr, int32_t* q_colidx,
                        int32_t* r_colptr, int32_t* r_rowidx, hipStream_t stream);
 void launch_bd_cut_tiles(const TileGeom& g, const int64_t* t_off, int row_major, const int32_t* outer_ptr,
-                         const int32_t* inner_idx, const double* vals, double* tiles, hipStream_t stream);
+                         const int32_t* inner_idx, const double* vals, int32_t nnz, double* tiles, hipStream_t stream);
 void launch_bd_q_tail_ones(double* q_vals, int64_t start, int64_t count, hipStream_t stream);
 void launch_bd_apply_qt(const TileGeom& g, const double* q_vals, const double* b, int64_t nrhs,
                         double* y, hipStream_t stream);

@@ -66,7 +66,8 @@ def test_from_block_diagonal_pattern_matches_oracle():
     assert mat.size() == len(bm) == nv and mat.rows() == 7 * nv and mat.cols() == 2 * nv
     np.testing.assert_array_equal(mat.block_rows, bm[:, 2])
     np.testing.assert_array_equal(mat.block_cols, bm[:, 3])
-    np.testing.assert_array_equal(mat.tiles, tiles)
+    got = mat.tiles if mat.tiles is not None else mat.tiles_dev.cpu().numpy()      # (cut on the device when there is one)
+    np.testing.assert_array_equal(got, tiles)
     np.testing.assert_array_equal(mat[3], tiles[42:56].reshape(2, 7).T)
 
 
@@ -85,3 +86,9 @@ def test_shard_ranges_are_contiguous_and_balanced():
     assert cost.max() / cost.mean() < 1.05
     br, bc, qo, ro = shard_offsets(n, n, *rg[3])
     assert br == n[:rg[3][0]].sum() and qo == (n[:rg[3][0]].astype(np.int64) ** 2).sum()
+
+
+def test_tiles_from_sparse_rejects_null_arguments():
+    from qrkit_amd import _capi
+    lib = _capi.lib()
+    assert lib.qrk_bd_tiles_from_sparse(None, 0, None, None, None, 0, None, _capi.MEM_HOST) == _capi.STATUS_INVALID_ARGUMENT
