@@ -92,6 +92,7 @@ struct qrk_dense_plan_s {
     bool tall = false;
     void* d_ws = nullptr;
     int G = 0, cpad = 0, rows_per = 0;
+    bool persistent = false;   // the whole factorisation as ONE cooperative kernel (all slabs resident); QRK_DENSE_PERSISTENT=1 enables
 };
 
 namespace {
@@ -684,6 +685,13 @@ qrk_status qrk_dense_plan_create(qrk_handle h, int32_t rows, int32_t cols, qrk_b
             delete p;
             return fail(h, QRK_STATUS_ALLOC_FAILED, "qrk_dense_plan_create: cannot allocate the workspace");
         }
+        // (measured slower than the kernel sequence - 472 vs 363 ms at 40000 x 2000, 14.0 vs 12.9 ms at 5120 x 384: every
+        // workgroup's agent-scope fences write back / invalidate the XCD's L2 at each barrier - so it is opt-in)
+        if (const char* e = std::getenv("QRK_DENSE_PERSISTENT")) {
+            if (e[0] == '1')
+                p->persistent = (size_t)2 * p->rows_per * sizeof(double) <= 64 * 1024 &&
+                                qrk::dense_tall_persistent_ok(p->G, p->rows_per, h->num_cus);
+        }
     }
     *out = p;
     return QRK_STATUS_OK;
@@ -708,7 +716,7 @@ qrk_status qrk_dense_factorize(qrk_dense_plan p, double* a, int64_t lda, double*
     if (space == QRK_MEM_DEVICE) {
         if (p->tall)
             QRK_HIP(h, qrk::launch_dense_qr_tall(a, lda, p->rows, p->cols, piv, hcoeffs, perm, p->d_ws, p->G, p->cpad, p->rows_per,
-                                                 h->stream));
+                                                 p->persistent, h->stream));
         else
             QRK_HIP(h, qrk::launch_dense_qr(a, lda, p->rows, p->cols, piv, hcoeffs, perm, h->stream));
         return QRK_STATUS_OK;
@@ -721,7 +729,7 @@ qrk_status qrk_dense_factorize(qrk_dense_plan p, double* a, int64_t lda, double*
         return st;
     if (p->tall)
         QRK_HIP(h, qrk::launch_dense_qr_tall(d_a, lda, p->rows, p->cols, piv, d_hc, d_p, p->d_ws, p->G, p->cpad, p->rows_per,
-                                             h->stream));
+                                             p->persistent, h->stream));
     else
         QRK_HIP(h, qrk::launch_dense_qr(d_a, lda, p->rows, p->cols, piv, d_hc, d_p, h->stream));
     if ((st = s.back(a, d_a, lda * p->cols)) || (st = s.back(hcoeffs, d_hc, (int64_t)size)) ||

@@ -35,7 +35,14 @@ struct State {
     int slow;                // the norm-recompute test fired in this step
     unsigned ticket;         // head_kernel: workgroups that have finished their columns (reset by the last one)
     int anyneed;             // head_kernel: some column failed the downdate test (reset by the last one)
+    unsigned bar_count;      // persistent kernel: workgroups that have arrived at the grid barrier
+    unsigned bar_gen;        // ... and its generation
+    unsigned bar_abort;      // ... set when a workgroup gave up waiting (the kernel then drains without computing)
 };
+
+// Value another workgroup wrote during this kernel (persistent form): read at agent scope, never from a stale line.
+__device__ __forceinline__ int ld_agent(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ double ld_agent(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 struct Work {                // device workspace of a plan
     double* partial;         // [G][cpad] partial dot products with the next reflector
@@ -76,10 +83,9 @@ __device__ __forceinline__ void block_argmax(double& best, int& bi, double* red,
 }
 
 // partial squared column norms of every slab
-__global__ void __launch_bounds__(TT)
-norms_kernel(const double* __restrict__ A, int64_t lda, int r, int c, Work w)
+__device__ __forceinline__ void norms_body(const double* __restrict__ A, int64_t lda, int r, int c, Work w, int vb)
 {
-    const int g = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = vb, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r0 = g * w.rows_per, r1 = min(r, r0 + w.rows_per);
     for (int jc = wave; jc < c; jc += TW) {
         double s = 0.0;
@@ -110,8 +116,7 @@ __device__ __forceinline__ void choose_and_swap(int kpos, int c, int pivoting, W
     }
 }
 
-__global__ void __launch_bounds__(TT)
-init_kernel(int c, int pivoting, Work w)
+__device__ __forceinline__ void init_body(int c, int pivoting, Work w)
 {
     __shared__ double red[TW];
     __shared__ int ired[TW];
@@ -127,14 +132,12 @@ init_kernel(int c, int pivoting, Work w)
 
 // Swap columns kpos and st->P (all rows of the slab), then partial dots of x = column kpos (rows > kpos)
 // with every column to its right, and the partial |x_tail|^2.  No-op unless `always` or the step was slow.
-__global__ void __launch_bounds__(TT)
-swap_dots_kernel(double* __restrict__ A, int64_t lda, int r, int c, int kpos, int always, Work w)
+__device__ __forceinline__ void swap_dots_body(double* __restrict__ A, int64_t lda, int r, int c, int kpos, int always, Work w, int vb, double* xs)
 {
-    extern __shared__ double xs[];     // [rows_per]
-    if (!always && !w.st->slow) return;
-    const int g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (!always && !ld_agent(&w.st->slow)) return;
+    const int g = vb, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r0 = g * w.rows_per, r1 = min(r, r0 + w.rows_per);
-    const int P = w.st->P;
+    const int P = ld_agent(&w.st->P);
     if (P != kpos) {
         for (int i = r0 + tid; i < r1; i += TT) {
             const double t = A[(int64_t)kpos * lda + i];
@@ -168,9 +171,8 @@ swap_dots_kernel(double* __restrict__ A, int64_t lda, int r, int c, int kpos, in
 // (a ticket counter after a device-scope fence: no workgroup ever waits for another).
 constexpr int HC = 128;                  // columns per workgroup
 constexpr int HG = TT / HC;              // slab groups per column
-__global__ void __launch_bounds__(TT)
-head_kernel(double* __restrict__ A, int64_t lda, int r, int c, int k, int pivoting, double* __restrict__ hcoeffs,
-            int32_t* __restrict__ perm, Work w)
+__device__ __forceinline__ void head_body(double* __restrict__ A, int64_t lda, int r, int c, int k, int pivoting, double* __restrict__ hcoeffs,
+                                          int32_t* __restrict__ perm, Work w, int vb, int vgrid)
 {
     __shared__ double red[TW];
     __shared__ int ired[TW];
@@ -202,7 +204,7 @@ head_kernel(double* __restrict__ A, int64_t lda, int r, int c, int k, int pivoti
     // this workgroup's columns
     {
         const int cl = tid % HC, gg = tid / HC;
-        const int jc = k + 1 + (int)blockIdx.x * HC + cl;
+        const int jc = k + 1 + vb * HC + cl;
         double d = 0.0;
         if (jc < c) for (int g = gg; g < w.G; g += HG) d += w.partial[(int64_t)g * w.cpad + jc];
         part[gg * HC + cl] = d;
@@ -231,7 +233,7 @@ head_kernel(double* __restrict__ A, int64_t lda, int r, int c, int k, int pivoti
     __syncthreads();
     if (tid == 0) s_ticket = atomicAdd(&w.st->ticket, 1u);
     __syncthreads();
-    if (s_ticket != gridDim.x - 1) return;
+    if (s_ticket != (unsigned)vgrid - 1u) return;
     // ---- the last workgroup: every column of the step is in memory
     __threadfence();
     if (tid == 0) {
@@ -254,17 +256,15 @@ head_kernel(double* __restrict__ A, int64_t lda, int r, int c, int k, int pivoti
 }
 
 // Sweep of step k over every slab.
-__global__ void __launch_bounds__(TT)
-sweep_kernel(double* __restrict__ A, int64_t lda, int r, int c, int k, Work w)
+__device__ __forceinline__ void sweep_body(double* __restrict__ A, int64_t lda, int r, int c, int k, Work w, int vb, double* sm)
 {
-    extern __shared__ double sm[];
     double* xs = sm;                    // [rows_per] x = column k
     double* xp = sm + w.rows_per;       // [rows_per] x' = next reflector column
-    const int g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = vb, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r0 = g * w.rows_per, r1 = min(r, r0 + w.rows_per);
-    const double inv_s = w.st->inv_s;
-    const int slow = w.st->slow;
-    const int P = w.st->P;
+    const double inv_s = ld_agent(&w.st->inv_s);
+    const int slow = ld_agent(&w.st->slow);
+    const int P = ld_agent(&w.st->P);
     const int size = r < c ? r : c;
     const bool last = k + 1 >= size;
     for (int i = r0 + tid; i < r1; i += TT) {
@@ -352,12 +352,11 @@ sweep_kernel(double* __restrict__ A, int64_t lda, int r, int c, int k, Work w)
 }
 
 // Slow steps only: recomputed norms for the flagged columns, then the pivot of position k+1.
-__global__ void __launch_bounds__(TT)
-recompute_kernel(int c, int k, int pivoting, Work w)
+__device__ __forceinline__ void recompute_body(int c, int k, int pivoting, Work w)
 {
     __shared__ double red[TW];
     __shared__ int ired[TW];
-    if (!w.st->slow) return;
+    if (!ld_agent(&w.st->slow)) return;
     for (int jc = k + 1 + threadIdx.x; jc < c; jc += TT) {
         if (w.need[jc]) {
             double s = 0.0;
@@ -367,6 +366,108 @@ recompute_kernel(int c, int k, int pivoting, Work w)
     }
     __syncthreads();
     choose_and_swap(k + 1, c, pivoting, w, red, ired);
+}
+
+// ---- the steps as separate kernels on the caller's stream (fall-back when the slabs cannot all be resident)
+__global__ void __launch_bounds__(TT)
+norms_kernel(const double* __restrict__ A, int64_t lda, int r, int c, Work w) { norms_body(A, lda, r, c, w, blockIdx.x); }
+__global__ void __launch_bounds__(TT)
+init_kernel(int c, int pivoting, Work w) { init_body(c, pivoting, w); }
+__global__ void __launch_bounds__(TT)
+swap_dots_kernel(double* __restrict__ A, int64_t lda, int r, int c, int kpos, int always, Work w)
+{
+    extern __shared__ double dyn_sm[];
+    swap_dots_body(A, lda, r, c, kpos, always, w, blockIdx.x, dyn_sm);
+}
+__global__ void __launch_bounds__(TT)
+head_kernel(double* __restrict__ A, int64_t lda, int r, int c, int k, int pivoting, double* __restrict__ hcoeffs,
+            int32_t* __restrict__ perm, Work w)
+{
+    head_body(A, lda, r, c, k, pivoting, hcoeffs, perm, w, blockIdx.x, gridDim.x);
+}
+__global__ void __launch_bounds__(TT)
+sweep_kernel(double* __restrict__ A, int64_t lda, int r, int c, int k, Work w)
+{
+    extern __shared__ double dyn_sm[];
+    sweep_body(A, lda, r, c, k, w, blockIdx.x, dyn_sm);
+}
+__global__ void __launch_bounds__(TT)
+recompute_kernel(int c, int k, int pivoting, Work w) { recompute_body(c, k, pivoting, w); }
+
+// ---- the same steps inside ONE kernel (opt-in, QRK_DENSE_PERSISTENT=1): a workgroup per slab, all resident (cooperative
+// launch, G <= number of CUs), grid barriers where the kernel boundaries were.  The boundaries cost ~8.5 us each (4 per
+// reflector), which is why this was tried; measured, the barriers cost MORE: 472 vs 363 ms for the block-angular
+// BASELINE shape (40000 x 2000 bottom block), 14.0 vs 12.9 ms at the reference's test size (5120 x 384).  A barrier is
+// an atomic counter + generation word behind agent-scope fences, and on this chip every workgroup's release/acquire
+// pair writes back and invalidates its XCD's L2 (8 XCDs, 256 workgroups), which a kernel boundary does once.
+// Waiting is BOUNDED: a workgroup that does not see the generation change within ~2 s raises bar_abort, after which
+// every workgroup runs through the remaining barriers without waiting or computing, so the grid always drains.
+constexpr unsigned BAR_SPIN_LIMIT = 1u << 24;
+
+__device__ __forceinline__ bool grid_barrier(State* st, unsigned nblocks)
+{
+    __shared__ unsigned s_ok;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned ok = 1u;
+        if (__hip_atomic_load(&st->bar_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) ok = 0u;
+        else {
+            __threadfence();                                   // release: this workgroup's writes
+            const unsigned gen = __hip_atomic_load(&st->bar_gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (atomicAdd(&st->bar_count, 1u) == nblocks - 1u) {
+                atomicExch(&st->bar_count, 0u);
+                __threadfence();
+                atomicAdd(&st->bar_gen, 1u);
+            } else {
+                unsigned spins = 0;
+                while (__hip_atomic_load(&st->bar_gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gen) {
+                    __builtin_amdgcn_s_sleep(2);
+                    if (++spins > BAR_SPIN_LIMIT ||
+                        __hip_atomic_load(&st->bar_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                        atomicExch(&st->bar_abort, 1u);
+                        ok = 0u;
+                        break;
+                    }
+                }
+            }
+            __threadfence();                                   // acquire: the other workgroups' writes
+        }
+        s_ok = ok;
+    }
+    __syncthreads();
+    return s_ok != 0u;
+}
+
+__global__ void __launch_bounds__(TT)
+tall_persistent_kernel(double* __restrict__ A, int64_t lda, int r, int c, int pivoting, double* __restrict__ hcoeffs,
+                       int32_t* __restrict__ perm, Work w)
+{
+    extern __shared__ double dyn_sm[];          // [2 * rows_per]
+    const int g = blockIdx.x;
+    const unsigned nb = gridDim.x;              // = G
+    const int size = r < c ? r : c;
+    norms_body(A, lda, r, c, w, g);
+    if (!grid_barrier(w.st, nb)) return;
+    if (g == 0) init_body(c, pivoting, w);
+    if (!grid_barrier(w.st, nb)) return;
+    swap_dots_body(A, lda, r, c, 0, 1, w, g, dyn_sm);
+    if (!grid_barrier(w.st, nb)) return;
+    for (int k = 0; k < size; ++k) {
+        const int nh0 = (c - k - 1 + HC - 1) / HC, nh = nh0 > 0 ? nh0 : 1;
+        for (int hb = g; hb < nh; hb += (int)nb) {
+            head_body(A, lda, r, c, k, pivoting, hcoeffs, perm, w, hb, nh);
+            __syncthreads();
+        }
+        if (!grid_barrier(w.st, nb)) return;
+        sweep_body(A, lda, r, c, k, w, g, dyn_sm);
+        if (!grid_barrier(w.st, nb)) return;
+        if (pivoting && k + 1 < size && ld_agent(&w.st->slow)) {      // (uniform over the grid: written before the sweep)
+            if (g == 0) recompute_body(c, k, pivoting, w);
+            if (!grid_barrier(w.st, nb)) return;
+            swap_dots_body(A, lda, r, c, k + 1, 0, w, g, dyn_sm);
+            if (!grid_barrier(w.st, nb)) return;
+        }
+    }
 }
 
 // B <- Q^T B or Q B for tall B: the column stays in global memory.
@@ -414,8 +515,18 @@ size_t dense_tall_workspace_bytes(int r, int c, int num_cus, int* G_out, int* cp
     return (size_t)(2 * (size_t)G * cpad + G + 3 * cpad) * sizeof(double) + (size_t)2 * cpad * sizeof(int) + 256;
 }
 
+// Can the persistent form run: all G workgroups of 1024 threads resident at once (one per CU)?
+bool dense_tall_persistent_ok(int G, int rows_per, int num_cus)
+{
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, tall::tall_persistent_kernel, tall::TT,
+                                                     2 * (size_t)rows_per * sizeof(double)) != hipSuccess)
+        return false;
+    return per_cu >= 1 && G <= per_cu * num_cus;
+}
+
 hipError_t launch_dense_qr_tall(double* A, int64_t lda, int r, int c, int pivoting, double* hcoeffs, int32_t* perm,
-                                void* workspace, int G, int cpad, int rows_per, hipStream_t stream)
+                                void* workspace, int G, int cpad, int rows_per, bool persistent, hipStream_t stream)
 {
     using namespace tall;
     Work w;
@@ -433,6 +544,13 @@ hipError_t launch_dense_qr_tall(double* A, int64_t lda, int r, int c, int pivoti
     w.G = G; w.cpad = cpad; w.rows_per = rows_per;
     const int size = r < c ? r : c;
     const size_t sm1 = (size_t)rows_per * sizeof(double), sm2 = 2 * sm1;
+    if (persistent) {
+        // one kernel, a workgroup per slab, all resident (checked by the caller and again by the cooperative launch)
+        hipError_t e = hipMemsetAsync(&w.st->bar_count, 0, 3 * sizeof(unsigned), stream);
+        if (e != hipSuccess) return e;
+        void* args[] = {(void*)&A, (void*)&lda, (void*)&r, (void*)&c, (void*)&pivoting, (void*)&hcoeffs, (void*)&perm, (void*)&w};
+        return hipLaunchCooperativeKernel((const void*)tall_persistent_kernel, dim3(G), dim3(TT), args, (unsigned)sm2, stream);
+    }
     hipLaunchKernelGGL(norms_kernel, dim3(G), dim3(TT), 0, stream, A, lda, r, c, w);
     hipLaunchKernelGGL(init_kernel, dim3(1), dim3(TT), 0, stream, c, pivoting, w);
     hipLaunchKernelGGL(swap_dots_kernel, dim3(G), dim3(TT), sm1, stream, A, lda, r, c, 0, 1, w);

@@ -65,8 +65,9 @@ void launch_bdqr_wg(const WaveBatch& nb, const double* tiles, double* q_vals, do
 size_t dense_qr_smem_bytes(int r, int c);
 // Tall dense QR over all CUs (dense_qr_tall.hip): row slabs, one short kernel sequence per reflector.
 size_t dense_tall_workspace_bytes(int r, int c, int num_cus, int* G, int* cpad, int* rows_per);
+bool dense_tall_persistent_ok(int G, int rows_per, int num_cus);
 hipError_t launch_dense_qr_tall(double* A, int64_t lda, int r, int c, int pivoting, double* hcoeffs, int32_t* perm,
-                                void* workspace, int G, int cpad, int rows_per, hipStream_t stream);
+                                void* workspace, int G, int cpad, int rows_per, bool persistent, hipStream_t stream);
 hipError_t launch_dense_apply_q_tall(const double* QR, int64_t lda, int r, int nrefl, const double* hcoeffs, int transpose,
                                      double* B, int64_t ldb, int64_t nrhs, hipStream_t stream);
 hipError_t launch_dense_qr(double* A, int64_t lda, int r, int c, int pivoting, double* hcoeffs, int32_t* perm,

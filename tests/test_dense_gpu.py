@@ -115,3 +115,25 @@ def test_blocked_thin_dense_qr_matches_oracle(rows, cols, sparse_in):
     x = rng.uniform(-1, 1, cols)
     got = qr.solve(torch.from_numpy(A @ x).cuda()).cpu().numpy().ravel()
     assert rel_fro(got, x) <= 1e-9
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("solver", [0, 1])
+def test_dense_qr_persistent_form_matches_kernel_sequence(solver):
+    """QRK_DENSE_PERSISTENT=1: the same steps inside one cooperative kernel with grid barriers (opt-in: measured slower).
+    Bitwise the same result as the kernel sequence - same arithmetic, same order."""
+    rng = np.random.default_rng(12)
+    A = rng.uniform(-1.0, 1.0, (3000, 150))
+    A[:, 7] = A[:, 2]
+    out = []
+    for flag in ("1", None):
+        if flag:
+            os.environ["QRK_DENSE_PERSISTENT"] = flag
+        try:
+            qr, At = _factor(A, solver, "tall")
+        finally:
+            os.environ.pop("QRK_DENSE_PERSISTENT", None)
+        out.append((At.cpu().numpy().copy(), qr._hc.cpu().numpy().copy(), qr.colsPermutation().cpu().numpy().copy()))
+    np.testing.assert_array_equal(out[0][2], out[1][2])
+    np.testing.assert_array_equal(out[0][0], out[1][0])
+    np.testing.assert_array_equal(out[0][1], out[1][1])
