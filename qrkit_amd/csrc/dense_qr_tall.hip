@@ -15,7 +15,8 @@
 //                         next pivot -- or "slow" when Eigen's norm-recompute test fires;
 //   sweep  (all slabs)    update + swap + partial dots with the next reflector (slow: update + partial
 //                         column norms only);
-//   recompute / swap_dots (slow steps only; no-ops otherwise) recomputed norms, pivot, then the dots.
+//   swap_dots (slow steps only; a no-op otherwise) the dots with the pivot that the last workgroup of the slow sweep
+//                         chose from the recomputed norms.
 // Traffic: the trailing matrix is read and written once per step (1.3 TB for 40000 x 2000).
 #include "qrk_device.h"
 
@@ -35,6 +36,7 @@ struct State {
     int slow;                // the norm-recompute test fired in this step
     unsigned ticket;         // head_kernel: workgroups that have finished their columns (reset by the last one)
     int anyneed;             // head_kernel: some column failed the downdate test (reset by the last one)
+    unsigned ticket2;        // sweep / swap_dots: workgroups that have finished (reset by the last one), see slab_tail()
     unsigned bar_count;      // persistent kernel: workgroups that have arrived at the grid barrier
     unsigned bar_gen;        // ... and its generation
     unsigned bar_abort;      // ... set when a workgroup gave up waiting (the kernel then drains without computing)
@@ -125,11 +127,29 @@ __device__ __forceinline__ void init_body(int c, int pivoting, Work w)
         for (int g = 0; g < w.G; ++g) s += w.sqpart[(int64_t)g * w.cpad + jc];
         w.nu2[jc] = s; w.thr[jc] = s * SQRT_EPS; w.pidx[jc] = jc;
     }
-    if (threadIdx.x == 0) { w.st->slow = 0; w.st->ticket = 0u; w.st->anyneed = 0; }
+    if (threadIdx.x == 0) { w.st->slow = 0; w.st->ticket = 0u; w.st->anyneed = 0; w.st->ticket2 = 0u; }
     __syncthreads();
     choose_and_swap(0, c, pivoting, w, red, ired);
 }
 
+// The workgroup that finishes a slow sweep LAST also does what used to be a kernel of its own - the recomputed norms and
+// the next pivot - so that the sequence is one kernel shorter per reflector (a boundary costs ~8.5 us).  Same ticket scheme
+// as the head: device-scope fence, atomic ticket, nobody waits.  (Running the HEAD of the next step there as well, for
+// problems whose slab partials one workgroup can sum, was measured slower: 20.3 vs 12.9 ms at 5120 x 384.)
+enum { TAIL_NONE = 0, TAIL_RECOMPUTE = 1 };
+__device__ __forceinline__ void recompute_body(int c, int k, int pivoting, Work w);
+__device__ __forceinline__ bool slab_is_last(Work& w, int nslabs)
+{
+    __shared__ unsigned s_t2;
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) s_t2 = atomicAdd(&w.st->ticket2, 1u);
+    __syncthreads();
+    if (s_t2 != (unsigned)nslabs - 1u) return false;
+    __threadfence();
+    if (threadIdx.x == 0) w.st->ticket2 = 0u;
+    return true;
+}
 // Swap columns kpos and st->P (all rows of the slab), then partial dots of x = column kpos (rows > kpos)
 // with every column to its right, and the partial |x_tail|^2.  No-op unless `always` or the step was slow.
 __device__ __forceinline__ void swap_dots_body(double* __restrict__ A, int64_t lda, int r, int c, int kpos, int always, Work w, int vb, double* xs)
@@ -256,7 +276,8 @@ __device__ __forceinline__ void head_body(double* __restrict__ A, int64_t lda, i
 }
 
 // Sweep of step k over every slab.
-__device__ __forceinline__ void sweep_body(double* __restrict__ A, int64_t lda, int r, int c, int k, Work w, int vb, double* sm)
+__device__ __forceinline__ void sweep_body(double* __restrict__ A, int64_t lda, int r, int c, int k, Work w, int vb, double* sm,
+                                           int tail = TAIL_NONE, int pivoting = 0, int nslabs = 0)
 {
     double* xs = sm;                    // [rows_per] x = column k
     double* xp = sm + w.rows_per;       // [rows_per] x' = next reflector column
@@ -287,6 +308,7 @@ __device__ __forceinline__ void sweep_body(double* __restrict__ A, int64_t lda, 
             s2 = wave_sum(s2);
             if (lane == 0) w.sqpart[(int64_t)g * w.cpad + jc] = s2;
         }
+        if (tail != TAIL_NONE && slow && !last && slab_is_last(w, nslabs)) recompute_body(c, k, pivoting, w);
         return;
     }
     // fused: the next pivot column P goes to position k+1, everything is updated, dots with x' accumulate
@@ -386,13 +408,11 @@ head_kernel(double* __restrict__ A, int64_t lda, int r, int c, int k, int pivoti
     head_body(A, lda, r, c, k, pivoting, hcoeffs, perm, w, blockIdx.x, gridDim.x);
 }
 __global__ void __launch_bounds__(TT)
-sweep_kernel(double* __restrict__ A, int64_t lda, int r, int c, int k, Work w)
+sweep_kernel(double* __restrict__ A, int64_t lda, int r, int c, int k, int pivoting, Work w)
 {
     extern __shared__ double dyn_sm[];
-    sweep_body(A, lda, r, c, k, w, blockIdx.x, dyn_sm);
+    sweep_body(A, lda, r, c, k, w, blockIdx.x, dyn_sm, TAIL_RECOMPUTE, pivoting, gridDim.x);
 }
-__global__ void __launch_bounds__(TT)
-recompute_kernel(int c, int k, int pivoting, Work w) { recompute_body(c, k, pivoting, w); }
 
 // ---- the same steps inside ONE kernel (opt-in, QRK_DENSE_PERSISTENT=1): a workgroup per slab, all resident (cooperative
 // launch, G <= number of CUs), grid barriers where the kernel boundaries were.  The boundaries cost ~8.5 us each (4 per
@@ -557,11 +577,9 @@ hipError_t launch_dense_qr_tall(double* A, int64_t lda, int r, int c, int pivoti
     for (int k = 0; k < size; ++k) {
         const int nh = (c - k - 1 + HC - 1) / HC;
         hipLaunchKernelGGL(head_kernel, dim3(nh > 0 ? nh : 1), dim3(TT), 0, stream, A, lda, r, c, k, pivoting, hcoeffs, perm, w);
-        hipLaunchKernelGGL(sweep_kernel, dim3(G), dim3(TT), sm2, stream, A, lda, r, c, k, w);
-        if (pivoting && k + 1 < size) {
-            hipLaunchKernelGGL(recompute_kernel, dim3(1), dim3(TT), 0, stream, c, k, pivoting, w);
+        hipLaunchKernelGGL(sweep_kernel, dim3(G), dim3(TT), sm2, stream, A, lda, r, c, k, pivoting, w);   // (slow: + recompute)
+        if (pivoting && k + 1 < size)     // (a no-op unless the step was slow)
             hipLaunchKernelGGL(swap_dots_kernel, dim3(G), dim3(TT), sm1, stream, A, lda, r, c, k + 1, 0, w);
-        }
     }
     return hipGetLastError();
 }
