@@ -48,6 +48,9 @@
 #ifndef QRK_TAIL_LOCAL
 #define QRK_TAIL_LOCAL 0       // 1: |x_tail|^2 accumulated by every lane before the dots (rsq/rcp chains under the dot FMAs, no ds_bpermute): measured 90.0 vs 87.4 us, kept off
 #endif
+#ifndef QRK_RB
+#define QRK_RB 4               // steps between refreshes of the LDS image (measured on one box: 4 -> 87.1 us, 3 -> 87.4, 2 -> 91.0; 8 needs 22 KB of LDS per wave)
+#endif
 #ifndef QRK_QSTORE_EVERY
 #define QRK_QSTORE_EVERY 8     // 4, 8 or 16
 #endif
@@ -76,7 +79,7 @@ namespace pair {
 
 constexpr int WR = 32;               // row registers per column
 constexpr int LDP = WR + 2;          // LDS column stride in doubles: 272 B, conflict-free b64/b128 access
-constexpr int RB = 4;                // the LDS image of A is refreshed every RB steps
+constexpr int RB = QRK_RB;           // the LDS image of A is refreshed every RB steps
 // LDS carve-up per HALF (doubles)
 constexpr int L_IMG = 0;             // [32][LDP] column-major image of A / staging for Q; R rows parked here
 constexpr int L_XBUF = WR * LDP;     // [32] current pivot column
