@@ -325,6 +325,13 @@ class BlockDiagonalSparseQR {
         check(qrk_bd_apply_qt(m_plan, m_Q.values().data(), B.data(), nrhs, y.data(), QRK_MEM_HOST));
         return y;
     }
+    // matrixQ() * B on the device (the product with the explicit m_Q)
+    Vector applyQ(const Vector& B) const {
+        const int64_t nrhs = (int64_t)B.size() / rows();
+        Vector y(B.size());
+        check(qrk_bd_apply_q(m_plan, m_Q.values().data(), B.data(), nrhs, y.data(), QRK_MEM_HOST));
+        return y;
+    }
 
   protected:
     void check(qrk_status st) const {
@@ -640,16 +647,7 @@ class BlockMatrix1x2 {
 // Uniform "Q^T v / Q v on several columns" access to the left solvers.
 template <typename BS, int QF>
 inline Vector leftApplyQ(const BlockDiagonalSparseQR<BS, QF>& s, const Vector& v, bool transpose) {
-    if (transpose) return s.applyQt(v);
-    const SparseMatrixRowMajor Q = s.matrixQ();        // Q v: host SpMV with the explicit Q
-    const Index rows = s.rows(), nrhs = (Index)v.size() / rows;
-    Vector out(v.size());
-    for (Index c = 0; c < nrhs; ++c) {
-        Vector col(v.begin() + c * rows, v.begin() + (c + 1) * rows);
-        Vector r = Q * col;
-        std::copy(r.begin(), r.end(), out.begin() + c * rows);
-    }
-    return out;
+    return transpose ? s.applyQt(v) : s.applyQ(v);
 }
 template <int SBC>
 inline Vector leftApplyQ(const BandedBlockedSparseQR<SBC>& s, const Vector& v, bool transpose) {

@@ -166,6 +166,12 @@ qrk_status qrk_bd_info(qrk_bd_plan plan, qrk_info* info, int64_t* rank);
 qrk_status qrk_bd_apply_qt(qrk_bd_plan plan, const double* q_vals, const double* b, int64_t nrhs,
                            double* y, qrk_memspace space);
 
+/* y = Q b, matrixQ() * b with the explicit m_Q (BlockDiagonalSparseQR.h:235-237; the reference forms this
+ * product as a sparse matrix-vector product, e.g. test/test-qrkit.cpp:201 and BlockAngularSparseQR.h:627-645).
+ * b, y: nrhs columns of mat_rows entries; b and y must not alias. */
+qrk_status qrk_bd_apply_q(qrk_bd_plan plan, const double* q_vals, const double* b, int64_t nrhs,
+                          double* y, qrk_memspace space);
+
 /* _solve_impl (BlockDiagonalSparseQR.h:257-280), FullQ only:
  * x = P * [ R(0:rank,0:rank)^-1 (Q^T b)(0:rank) ];  b: mat_rows x nrhs, x: mat_cols x nrhs. */
 qrk_status qrk_bd_solve(qrk_bd_plan plan, const double* q_vals, const double* r_vals,

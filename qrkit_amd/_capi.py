@@ -23,7 +23,7 @@ MEM_DEVICE, MEM_HOST = 0, 1
 EXPORTS = (
     "qrk_version", "qrk_device_count", "qrk_create", "qrk_destroy", "qrk_set_stream", "qrk_synchronize",
     "qrk_last_error", "qrk_bd_plan_create", "qrk_bd_plan_destroy", "qrk_bd_plan_sizes", "qrk_bd_pattern",
-    "qrk_bd_tiles_from_sparse", "qrk_bd_factorize", "qrk_bd_info", "qrk_bd_apply_qt", "qrk_bd_solve", "qrk_bd_solve_r", "qrk_dense_plan_create",
+    "qrk_bd_tiles_from_sparse", "qrk_bd_factorize", "qrk_bd_info", "qrk_bd_apply_qt", "qrk_bd_apply_q", "qrk_bd_solve", "qrk_bd_solve_r", "qrk_dense_plan_create",
     "qrk_dense_plan_destroy", "qrk_dense_factorize", "qrk_dense_apply_q", "qrk_bb_plan_create", "qrk_bb_plan_destroy", "qrk_bb_analyze_host",
     "qrk_bb_plan_info", "qrk_bb_plan_blocks", "qrk_bb_pattern", "qrk_bb_factorize", "qrk_bb_apply_q", "qrk_bb_solve_r", "qrk_dense_solve_r", "qrk_bd_time_factorize",
 )
@@ -84,6 +84,8 @@ def lib() -> C.CDLL:
     L.qrk_bd_info.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int64)]
     L.qrk_bd_apply_qt.restype = C.c_int
     L.qrk_bd_apply_qt.argtypes = [vp, dp, dp, C.c_int64, dp, C.c_int]
+    L.qrk_bd_apply_q.restype = C.c_int
+    L.qrk_bd_apply_q.argtypes = [vp, dp, dp, C.c_int64, dp, C.c_int]
     L.qrk_bd_solve.restype = C.c_int
     L.qrk_bd_solve.argtypes = [vp, dp, dp, ip, dp, C.c_int64, dp, C.c_int]
     L.qrk_bd_solve_r.restype = C.c_int

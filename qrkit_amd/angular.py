@@ -139,6 +139,25 @@ class BlockedThinDenseQR(DenseColPivQR):
     def rowsPermutation(self) -> torch.Tensor:
         return torch.arange(self._shape[0], dtype=torch.int32, device=self._qr.device)   # identity (:142)
 
+    def _applyAny(self, v, transpose: bool):
+        was_np = not isinstance(v, torch.Tensor)
+        t = torch.as_tensor(np.asarray(v, dtype=np.float64)) if was_np else v
+        y = _colmajor(t.to(self._ctx.device, torch.float64).reshape(self._shape[0], -1).clone())
+        self.applyQ(y, transpose=transpose)
+        out = y if np.ndim(v) > 1 else y[:, 0]
+        return out.cpu().numpy() if was_np else out
+
+    def matrixQ(self):
+        """Product expression (BlockedThinQRBase.h:335-470)."""
+        from .qproduct import QProduct
+        slv = self
+
+        class _Ops:          # applyQ / applyQt with the (rows, nrhs) calling convention of the expression
+            def rows(self_inner): return slv.rows()
+            def applyQ(self_inner, v): return slv._applyAny(v, False)
+            def applyQt(self_inner, v): return slv._applyAny(v, True)
+        return QProduct(_Ops())
+
     def solve(self, b: torch.Tensor) -> torch.Tensor:
         """BlockedThinQRBase::_solve_impl (BlockedThinQRBase.h:223-247): x = R(0:n,0:n)^-1 (Q^T b)(0:n)."""
         rows, cols = self._shape
@@ -247,6 +266,24 @@ class BlockAngularSparseQR:
         t[m1:, :] = bot
         out = t if np.ndim(v) > 1 else t[:, 0]
         return out.cpu().numpy() if was_np else out
+
+    def applyQ(self, v):
+        """matrixQ() * v (:627-645): rows m1.. <- Q2 of them, then the top n1 rows <- Q1 of them."""
+        was_np = not isinstance(v, torch.Tensor)
+        t = torch.as_tensor(np.asarray(v, dtype=np.float64)) if was_np else v
+        t = t.to(self._ctx.device, torch.float64).reshape(self._rows, -1).clone()
+        n1, m1 = self._n1, self._m1
+        bot = _colmajor(t[m1:, :].clone())
+        self.m_rightSolver.applyQ(bot, transpose=False)
+        t[m1:, :] = bot
+        t[:n1, :] = self.m_leftSolver.applyQ(t[:n1, :].contiguous())
+        out = t if np.ndim(v) > 1 else t[:, 0]
+        return out.cpu().numpy() if was_np else out
+
+    def matrixQ(self):
+        """Product expression (BlockAngularSparseQR.h:651-701): matrixQ() @ v, .transpose() @ v, .toSparse()."""
+        from .qproduct import QProduct
+        return QProduct(self)
 
     def solve(self, b):
         """_solve_impl (:202-227): x = P [R(0:rank,0:rank)^-1 (Q^T b)(0:rank)] (dense back substitution on the host

@@ -141,6 +141,11 @@ class BandedBlockedSparseQR:
         """matrixQ() * v"""
         return self._apply(v, False)
 
+    def matrixQ(self):
+        """Product expression (BandedBlockedSparseQR.h:677-727): matrixQ() @ v, .transpose() @ v, .toSparse()."""
+        from .qproduct import QProduct
+        return QProduct(self)
+
     def solve(self, B):
         """_solve_impl (:290-311): y = Q^T B (B already row-permuted by the caller, as in the tests :235);
         x = R(0:rank,0:rank)^-1 y(0:rank); identity column permutation."""

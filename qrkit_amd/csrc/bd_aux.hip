@@ -134,6 +134,37 @@ bd_apply_qt_small_kernel(TileGeom g, const double* __restrict__ q_vals, const do
     }
 }
 
+// y = Q b, the product matrixQ() * b of the explicit m_Q (BlockDiagonalSparseQR.h:235-237, row j of Q_i = [U_i(j,:), N_i(j,:)],
+// :455-492): one lane per row of a tile, the rows of Q_i are contiguous in q_vals.  FullQ reads b at base_col + k (k < c)
+// and at N + m1 + (k - c) for the N part; BlockDiagonalQ at base_row + k.  The trailing identity rows copy b.
+__global__ void __launch_bounds__(64)
+bd_apply_q_kernel(TileGeom g, const double* __restrict__ q_vals, const double* __restrict__ b,
+                  int64_t nrhs, double* __restrict__ y)
+{
+    const int lane = threadIdx.x;
+    const int64_t total = g.num_tiles * nrhs;
+    for (int64_t w = blockIdx.x; w < total; w += gridDim.x) {
+        const int64_t t = w % g.num_tiles, rhs = w / g.num_tiles;
+        int r, c, base_row, base_col;
+        int64_t qoff, roff;
+        tile_geom(g, t, r, c, qoff, roff, base_row, base_col);
+        const double* bb = b + rhs * (int64_t)g.mat_rows;
+        double* yy = y + rhs * (int64_t)g.mat_rows + base_row;
+        const int m1 = base_row - base_col;
+        for (int j = lane; j < r; j += 64) {
+            const double* qrow = q_vals + qoff + (int64_t)j * r;
+            double s = 0.0;
+            for (int k = 0; k < r; ++k) {
+                int idx;
+                if (g.q_format == 0) idx = k < c ? base_col + k : g.mat_cols + m1 + (k - c);
+                else idx = base_row + k;
+                s = fma(qrow[k], bb[idx], s);
+            }
+            yy[j] = s;
+        }
+    }
+}
+
 __global__ void __launch_bounds__(256)
 bd_copy_tail_kernel(TileGeom g, const double* __restrict__ b, int64_t nrhs, double* __restrict__ y)
 {
@@ -347,6 +378,18 @@ void launch_bd_apply_qt(const TileGeom& g, const double* q_vals, const double* b
     if (ntail > 0)
         hipLaunchKernelGGL(bd_copy_tail_kernel, dim3((unsigned)((ntail + 255) / 256)), dim3(256), 0, stream, g,
                            b, nrhs, y);
+}
+
+void launch_bd_apply_q(const TileGeom& g, const double* q_vals, const double* b, int64_t nrhs, double* y, hipStream_t stream)
+{
+    const int64_t total = g.num_tiles * nrhs;
+    if (total > 0) {
+        const unsigned grid = (unsigned)(total < 262144 ? total : 262144);
+        hipLaunchKernelGGL(bd_apply_q_kernel, dim3(grid), dim3(64), 0, stream, g, q_vals, b, nrhs, y);
+    }
+    const int64_t ntail = ((int64_t)g.mat_rows - g.sum_rows) * nrhs;
+    if (ntail > 0)
+        hipLaunchKernelGGL(bd_copy_tail_kernel, dim3((unsigned)((ntail + 255) / 256)), dim3(256), 0, stream, g, b, nrhs, y);
 }
 
 void launch_bd_solve_r(const TileGeom& g, int max_cols, const double* r_vals, const double* y, int64_t nrhs, double* z,

@@ -598,6 +598,32 @@ qrk_status qrk_bd_apply_qt(qrk_bd_plan p, const double* q_vals, const double* b,
     return QRK_STATUS_OK;
 }
 
+qrk_status qrk_bd_apply_q(qrk_bd_plan p, const double* q_vals, const double* b, int64_t nrhs, double* y,
+                          qrk_memspace space)
+{
+    if (!p || !q_vals || !b || !y || nrhs < 0 || b == y)
+        return fail(p ? p->h : nullptr, QRK_STATUS_INVALID_ARGUMENT, "qrk_bd_apply_q: bad argument");
+    qrk_handle h = p->h;
+    QRK_HIP(h, hipSetDevice(h->device));
+    const qrk::TileGeom g = make_geom(p);
+    if (space == QRK_MEM_DEVICE) {
+        qrk::launch_bd_apply_q(g, q_vals, b, nrhs, y, h->stream);
+        QRK_HIP(h, hipGetLastError());
+        return QRK_STATUS_OK;
+    }
+    Staging s(h);
+    double *d_q, *d_b, *d_y;
+    qrk_status st;
+    if ((st = s.in(q_vals, p->nnz_q, &d_q)) || (st = s.in(b, nrhs * p->mat_rows, &d_b)) ||
+        (st = s.out(nrhs * p->mat_rows, &d_y)))
+        return st;
+    qrk::launch_bd_apply_q(g, d_q, d_b, nrhs, d_y, h->stream);
+    QRK_HIP(h, hipGetLastError());
+    if ((st = s.back(y, d_y, nrhs * p->mat_rows))) return st;
+    QRK_HIP(h, hipStreamSynchronize(h->stream));
+    return QRK_STATUS_OK;
+}
+
 qrk_status qrk_bd_solve(qrk_bd_plan p, const double* q_vals, const double* r_vals, const int32_t* perm,
                         const double* b, int64_t nrhs, double* x, qrk_memspace space)
 {

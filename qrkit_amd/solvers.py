@@ -353,6 +353,16 @@ class BlockDiagonalSparseQR:
                                               capi.MEM_DEVICE), self._ctx.handle)
         return self._out(y, was_np, shape, self._rows)
 
+    def applyQ(self, B):
+        """matrixQ() * B: the product with the explicit m_Q (:235-237) on the device (qrk_bd_apply_q)."""
+        assert self.m_isInitialized
+        b, was_np, shape = self._rhs(B, self._rows)
+        y = torch.empty_like(b)
+        self._ctx.use_current_stream()
+        capi.check(capi.lib().qrk_bd_apply_q(self._plan, self._q.data_ptr(), b.data_ptr(), b.shape[0], y.data_ptr(),
+                                             capi.MEM_DEVICE), self._ctx.handle)
+        return self._out(y, was_np, shape, self._rows)
+
     def solve(self, B):
         """_solve_impl, BlockDiagonalSparseQR.h:257-299."""
         assert self.m_isInitialized, "The factorization should be called first, use compute()"
