@@ -31,6 +31,8 @@ struct qrk_context_s {
     int num_cus = 256;
     int pair_wgs_per_cu = 8;       // resident pair-kernel workgroups per CU: 2 waves per SIMD (232 VGPRs, 20 KB LDS each)
     bool use_pair_kernel = true;   // two tiles per wavefront (bdqr_pair.hip); QRK_KERNEL=wave selects bdqr_wave.hip
+    bool use_split_kernel = false; // uniform 32x32, column pivoting: factorisation and Q formation as two kernels (bdqr_split.hip);
+                                   // an experiment that measured slower than the pair kernel - QRK_SPLIT=1 enables
     bool use_small_kernel = true;  // uniform tiles with at most 16 rows: 64/G tiles per wavefront (bdqr_small.hip); QRK_SMALL=0 disables
     // side streams for the size classes of a mixed batch (fork after / join into `stream`), created on first use
     hipStream_t side[3] = {nullptr, nullptr, nullptr};
@@ -72,6 +74,7 @@ struct qrk_bd_plan_s {
     int32_t* d_col_ids = nullptr;
     int64_t n_col = 0;
     double* d_col_workspace = nullptr;   // one part per class
+    double* d_split_ws = nullptr;        // uniform 32x32, two-kernel form: reflector vectors (1024) + scalars (64) per tile
 };
 
 struct qrk_bb_plan_s {
@@ -189,6 +192,11 @@ qrk_status enqueue_factorize(qrk_bd_plan_s* p, const double* tiles, double* q, d
             qrk::launch_bdqr_wg(nb, tiles, q, r, perm, hc, p->d_workspace, p->ws_stride, p->num_wg, p->max_dim, h->stream);
         else if (p->max_dim <= 16 && p->r >= p->c && h->use_small_kernel)   // 64/G tiles per wavefront (bdqr_small.hip)
             qrk::launch_bdqr_small(p->B, p->r, p->c, nb.pivoting, tiles, q, r, perm, hc, h->num_cus * 32, h->stream);
+        else if (full32 && h->use_split_kernel && nb.pivoting) {
+            if (!p->d_split_ws) QRK_HIP(h, hipMalloc((void**)&p->d_split_ws, (size_t)p->B * (1024 + 64) * sizeof(double)));
+            qrk::launch_bdqr_split32(p->B, nb.pivoting, tiles, p->d_split_ws, p->d_split_ws + (size_t)p->B * 1024, q, r, perm, hc,
+                                     h->num_cus, h->stream);
+        }
         else if (h->use_pair_kernel) qrk::launch_bdqr_pair(nb, full32, tiles, q, r, perm, hc, h->num_cus * h->pair_wgs_per_cu, h->stream);
         else qrk::launch_bdqr_wave(nb, full32, tiles, q, r, perm, hc, max_blocks, h->stream);
     } else {
@@ -261,6 +269,7 @@ qrk_status qrk_create(qrk_handle* out, int device, void* stream)
     h->stream = static_cast<hipStream_t>(stream);
     if (const char* k = std::getenv("QRK_KERNEL")) h->use_pair_kernel = std::strcmp(k, "wave") != 0;
     if (const char* k = std::getenv("QRK_SMALL")) h->use_small_kernel = k[0] != '0';
+    if (const char* k = std::getenv("QRK_SPLIT")) h->use_split_kernel = k[0] == '1';
     if (const char* k = std::getenv("QRK_PAIR_WGS_PER_CU")) { const int v = std::atoi(k); if (v > 0) h->pair_wgs_per_cu = v; }
     if (hipSetDevice(device) != hipSuccess) {
         delete h;
@@ -451,7 +460,7 @@ qrk_status qrk_bd_plan_destroy(qrk_bd_plan p)
     (void)hipFree(p->d_rows); (void)hipFree(p->d_cols); (void)hipFree(p->d_coff); (void)hipFree(p->d_rowoff);
     (void)hipFree(p->d_toff); (void)hipFree(p->d_qoff); (void)hipFree(p->d_roff); (void)hipFree(p->d_wave_ids);
     (void)hipFree(p->d_wg_ids); (void)hipFree(p->d_workspace);
-    (void)hipFree(p->d_col_ids); (void)hipFree(p->d_col_workspace);
+    (void)hipFree(p->d_col_ids); (void)hipFree(p->d_col_workspace); (void)hipFree(p->d_split_ws);
     delete p;
     return QRK_STATUS_OK;
 }

@@ -48,6 +48,10 @@ void launch_bdqr_wave(const WaveBatch& nb, bool full32, const double* tiles, dou
 void launch_bdqr_pair(const WaveBatch& nb, bool full32, const double* tiles, double* q_vals,
                       double* r_vals, int32_t* perm, double* hcoeffs, int max_blocks,
                       hipStream_t stream);
+// Uniform 32x32 batches in two kernels (bdqr_split.hip): factorisation of A with 10 waves per CU, then Q from the reflectors.
+// vbuf: 1024 doubles per tile, sbuf: 64 doubles per tile (device workspace of the plan).
+void launch_bdqr_split32(int64_t num_tiles, int pivoting, const double* tiles, double* vbuf, double* sbuf, double* q_vals,
+                         double* r_vals, int32_t* perm, double* hcoeffs, int num_cus, hipStream_t stream);
 // Uniform batches of small tiles (rows <= 16, cols <= rows): 64/G tiles per wavefront (bdqr_small.hip).
 void launch_bdqr_small(int64_t num_tiles, int r, int c, int pivoting, const double* tiles, double* q_vals, double* r_vals,
                        int32_t* perm, double* hcoeffs, int max_blocks, hipStream_t stream);
