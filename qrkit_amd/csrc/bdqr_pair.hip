@@ -45,6 +45,10 @@
 #ifndef QRK_ABL
 #define QRK_ABL 0
 #endif
+#ifndef QRK_EARLY_SCALARS
+#define QRK_EARLY_SCALARS 0    // 1: reflector scalars in the head of the step, from a DPP sum of the lanes' own pivot-column
+                               // entries (no ds_bpermute, rsq/rcp chains beside the broadcast + dots): measured 92.8 vs 89.5 us
+#endif
 #ifndef QRK_TAIL_LOCAL
 #define QRK_TAIL_LOCAL 0       // 1: |x_tail|^2 accumulated by every lane before the dots (rsq/rcp chains under the dot FMAs, no ds_bpermute): measured 90.0 vs 87.4 us, kept off
 #endif
@@ -159,6 +163,7 @@ struct LaneState {
     double nu2;      // m_colNormsUpdated^2
     double thr_nd2;  // sqrt(eps) * m_colNormsDirect^2
     double h[RB];    // entry j of the pivot columns of the last RB steps
+    double tailSq, nb, s, ng;   // QRK_EARLY_SCALARS: |x_tail|^2 and the reflector scalars of the step whose head ran last
 #ifdef QRK_STAMP
     unsigned long long tk[8];
 #endif
@@ -171,6 +176,27 @@ __device__ __forceinline__ double bpermute_f64(int byte_addr, double v)
     const int lo = __builtin_amdgcn_ds_bpermute(byte_addr, __double2loint(v));
     const int hi = __builtin_amdgcn_ds_bpermute(byte_addr, __double2hiint(v));
     return __hiloint2double(hi, lo);
+}
+
+// Sum over each half of the wave (lanes 0..31 / 32..63), the same bits in every lane of the half: four DPP stages inside
+// the rows of 16 lanes (partners add the same two numbers, so both get the same result), then the two rows of a half.
+__device__ __forceinline__ double half32_sum_f64(double v)
+{
+    v += dpp_f64<0xB1>(v);     // quad_perm [1,0,3,2]
+    v += dpp_f64<0x4E>(v);     // quad_perm [2,3,0,1]
+    v += dpp_f64<0x141>(v);    // row_half_mirror
+    v += dpp_f64<0x140>(v);    // row_mirror
+    const auto rl = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(v), (unsigned)__double2loint(v), false, false);
+    const auto rh = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(v), (unsigned)__double2hiint(v), false, false);
+    const double a = __hiloint2double((int)rh[0], (int)rl[0]), b = __hiloint2double((int)rh[1], (int)rl[1]);
+    return (a + b);            // (a, b) = (own row, other row) or the reverse: the sum is the same
+}
+// Entry of lane K of this lane's half.
+template <int K>
+__device__ __forceinline__ double half32_lane(double v, int half)
+{
+    const double lo = readlane_f64(v, K), hi = readlane_f64(v, 32 + K);
+    return half ? hi : lo;
 }
 
 // Rare path of the pivot search: several live columns share the high word of the largest squared
@@ -277,6 +303,21 @@ __device__ __forceinline__ void search_fetch(double* hl /* this half's LDS */, L
         st.h[K % RB] = xi;
         hl[L_XBUF + j] = xi;
         QRK_STAMP_IN(2);
+#if QRK_EARLY_SCALARS
+        // |x_tail|^2 = sum over the lanes below the diagonal of their own entry squared, and x_k from lane K: neither
+        // needs the broadcast, so the square root / reciprocal chains run beside the publish -> broadcast -> dots leg
+        // of the step (and, with the heads issued one step ahead, under the trailing update of the step before).
+        const double tsq = half32_sum_f64(j > K ? xi * xi : 0.0);
+        const double xk0 = half32_lane<K>(xi, st.half);
+        const double nrm = (QRK_ABL & 8) ? fma(xk0, xk0, tsq) : sqrt_pos(fma(xk0, xk0, tsq));
+        const double nb0 = __hiloint2double((__double2hiint(nrm) & 0x7fffffff) | (__double2hiint(xk0 + 0.0) & (int)0x80000000),
+                                            __double2loint(nrm));
+        const double s0 = nb0 + xk0;
+        st.tailSq = tsq; st.nb = nb0; st.s = s0;
+        st.ng = (QRK_ABL & 8) ? -(nb0 * s0) : -recip(nb0 * s0);
+        // (keep the chains HERE: without a use at this point hipcc sinks them to their consumers in the step)
+        asm volatile("" : "+v"(st.ng), "+v"(st.s), "+v"(st.nb));
+#endif
     }
 }
 
@@ -337,7 +378,11 @@ __device__ __forceinline__ void pair_step(double (&a)[WR], double (&q)[WR], doub
     //                                     c_i <- c_i - gamma x_i (= c_i - tau ess_i tmp),
     // which needs one square root and one reciprocal (of beta*w > 0) per step and no division.
     // Kept here: nb = -beta = copysign(norm, x0), s = -w = nb + x0, ng = -1/(beta w).
-#if !QRK_TAIL_LOCAL
+#if QRK_EARLY_SCALARS
+    const double tailSq = st.tailSq;
+    double nb = st.nb, s = st.s, ng = st.ng;
+    (void)xk;
+#elif !QRK_TAIL_LOCAL
     const double tailSq = (QRK_ABL & 2) ? dA : bpermute_f64((lbl << 2) + st.hb4, dA);
     const double nrm = (QRK_ABL & 8) ? fma(xk, xk, tailSq) : sqrt_pos(fma(xk, xk, tailSq));
     // Eigen: if (c0 >= 0) beta = -beta; -0.0 counts as >= 0, hence the + 0.0
@@ -346,7 +391,7 @@ __device__ __forceinline__ void pair_step(double (&a)[WR], double (&q)[WR], doub
     double s = nb + xk;
 #endif
     QRK_STAMP_IN(4);
-#if !QRK_TAIL_LOCAL
+#if !QRK_TAIL_LOCAL && !QRK_EARLY_SCALARS
     double ng = (QRK_ABL & 8) ? -(nb * s) : -recip(nb * s);
 #endif
     // Eigen: tailSqNorm <= min() gives tau = 0, beta = x0, H = I.  Rare, so a real branch (the empty
