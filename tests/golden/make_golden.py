@@ -105,6 +105,29 @@ def make_compositions():
     print("angular_64x7x2_24 ok")
 
 
+def make_small():
+    """Shapes of the small-tile kernel (bdqr_small.hip): one per lane-group size G = 4, 8, 16, the LM-damped 9x2 blocks
+    of the reference (rowpermADiagLambda, test/test-utils.cpp:145-180, on its own 7x2 input, lambda = 1e-3) and a
+    HouseholderQR (no pivoting) case."""
+    make_case("u11_4x4_colpiv", 24, 4, 4, orc.gen_uniform(11, -1.0, 1.0, 24 * 16))
+    make_case("u11_3x2_colpiv", 24, 3, 2, orc.gen_uniform(12, -1.0, 1.0, 24 * 6))
+    make_case("u11_8x8_colpiv", 12, 8, 8, orc.gen_uniform(13, -1.0, 1.0, 12 * 64))
+    make_case("u11_16x16_colpiv", 6, 16, 16, orc.gen_uniform(14, -1.0, 1.0, 6 * 256))
+    make_case("u11_12x7_colpiv", 8, 12, 7, orc.gen_uniform(15, -1.0, 1.0, 8 * 84))
+    make_case("u11_16x5_nopiv", 8, 16, 5, orc.gen_uniform(16, -1.0, 1.0, 8 * 80), solver=orc.NOPIV)
+    nv = 24
+    j7 = orc.gen_reference_7x2(nv).reshape(nv, 2, 7)
+    damped = np.zeros((nv, 2, 9))
+    damped[:, :, :7] = j7
+    damped[:, 0, 7] = np.sqrt(1e-3)
+    damped[:, 1, 8] = np.sqrt(1e-3)
+    make_case("ref_9x2_lm_damped_colpiv", nv, 9, 2, damped.ravel())
+
+
 if __name__ == "__main__":
-    main()
-    make_compositions()
+    if len(sys.argv) > 1 and sys.argv[1] == "small":
+        make_small()
+    else:
+        main()
+        make_compositions()
+        make_small()
