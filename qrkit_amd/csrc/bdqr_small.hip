@@ -24,6 +24,9 @@
 
 #include <float.h>
 
+#ifndef QRK_SMALL_WAVES8
+#define QRK_SMALL_WAVES8 4      // ... and the G = 4 / G = 8 instantiations
+#endif
 #ifndef QRK_SMALL_WAVES16
 #define QRK_SMALL_WAVES16 3     // waves per SIMD the G = 16 instantiation is compiled for
 #endif
@@ -100,7 +103,7 @@ __device__ __forceinline__ double bperm_f64(int byte_addr, double v)
 
 // One workgroup = 4 waves = TW = 4 * 64/G tiles.  PIVOT: ColPivHouseholderQR (else HouseholderQR).
 template <int G, bool PIVOT>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(G == 16 ? QRK_SMALL_WAVES16 : 4)))
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(G == 16 ? QRK_SMALL_WAVES16 : QRK_SMALL_WAVES8)))
 bdqr_small_kernel(int64_t num_tiles, int r, int c, const double* __restrict__ tiles, double* __restrict__ q_vals,
                   double* __restrict__ r_vals, int32_t* __restrict__ perm, double* __restrict__ hcoeffs)
 {
