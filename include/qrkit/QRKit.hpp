@@ -233,7 +233,7 @@ class BlockDiagonalSparseQR {
             throw std::runtime_error(std::string("qrkit: ") + qrk_last_error(0));
     }
     explicit BlockDiagonalSparseQR(const MatrixType& mat, int device = 0) : BlockDiagonalSparseQR(device) { compute(mat); }
-    ~BlockDiagonalSparseQR() { if (m_plan) qrk_bd_plan_destroy(m_plan); if (m_handle) qrk_destroy(m_handle); }
+    ~BlockDiagonalSparseQR() { releaseDevice(); if (m_plan) qrk_bd_plan_destroy(m_plan); if (m_handle) qrk_destroy(m_handle); }
     BlockDiagonalSparseQR(const BlockDiagonalSparseQR&) = delete;
     BlockDiagonalSparseQR& operator=(const BlockDiagonalSparseQR&) = delete;
 
@@ -266,25 +266,30 @@ class BlockDiagonalSparseQR {
         check(qrk_bd_plan_create(m_handle, &lay, (qrk_q_format)QFormat, (qrk_block_solver)BlockQRSolver::kSolver, &m_plan));
         m_analysisIsok = true;
     }
-    // :415-547
+    // :415-547.  The factors stay ON THE DEVICE (Q and R values, permutation); matrixQ() / matrixR() copy them to the host
+    // when they are asked for, and solve() / matrixQ() products run on the resident copies: an LM loop that only
+    // solves moves the tiles up and the solution down, nothing else.
     void factorize(const MatrixType& mat) {
         assert(m_analysisIsok && "analyzePattern() should be called first");
         int64_t tl, nq, nr;
         check(qrk_bd_plan_sizes(m_plan, &tl, &nq, &nr));
         const Index rows = mat.rows(), cols = mat.cols();
+        m_nq = nq; m_nr = nr;
         m_Q.resize(rows, rows);
         m_R.resize(rows, cols);
-        m_Q.values().assign((size_t)nq, 0.0); m_Q.innerIndex().assign((size_t)nq, 0);
-        m_R.values().assign((size_t)nr, 0.0); m_R.innerIndex().assign((size_t)nr, 0);
+        m_Qsynced = m_Rsynced = false;
         m_outputPerm_c.setIdentity(cols);
-        check(qrk_bd_factorize(m_plan, mat.tiles().data(), m_Q.values().data(), m_R.values().data(),
-                               m_outputPerm_c.indices().data(), 0, QRK_MEM_HOST));
+        reserve(m_dtiles, m_ctiles, tl * (int64_t)sizeof(double));
+        reserve(m_dq, m_cq, nq * (int64_t)sizeof(double));
+        reserve(m_dr, m_cr, nr * (int64_t)sizeof(double));
+        reserve(m_dperm, m_cperm, cols * (int64_t)sizeof(int32_t));
+        check(qrk_memcpy(m_handle, m_dtiles, mat.tiles().data(), tl * (int64_t)sizeof(double), 0));
+        check(qrk_bd_factorize(m_plan, (const double*)m_dtiles, (double*)m_dq, (double*)m_dr, (int32_t*)m_dperm, 0, QRK_MEM_DEVICE));
+        check(qrk_memcpy(m_handle, m_outputPerm_c.indices().data(), m_dperm, cols * (int64_t)sizeof(int32_t), 1));
         qrk_info info; int64_t rank;
         check(qrk_bd_info(m_plan, &info, &rank));
         m_info = (ComputationInfo)info;
         if (m_info != Success) return;   // :504-516: m_info = InvalidInput; return
-        check(qrk_bd_pattern(m_plan, m_Q.outerIndex().data(), m_Q.innerIndex().data(), m_R.outerIndex().data(),
-                             m_R.innerIndex().data(), QRK_MEM_HOST));
         m_nonzeropivots = rank;
         m_isInitialized = true;
         m_factorizationIsok = true;
@@ -292,8 +297,8 @@ class BlockDiagonalSparseQR {
 
     Index rows() const { return m_R.rows(); }
     Index cols() const { return m_R.cols(); }
-    const MatrixRType& matrixR() const { return m_R; }
-    MatrixQType matrixQ() const { return m_Q; }   // by value, as the reference (:235-237)
+    const MatrixRType& matrixR() const { syncR(); return m_R; }
+    MatrixQType matrixQ() const { syncQ(); return m_Q; }   // by value, as the reference (:235-237)
     const PermutationType& colsPermutation() const { assert(m_isInitialized && "Decomposition is not initialized."); return m_outputPerm_c; }
     const PermutationType& rowsPermutation() const { assert(m_isInitialized && "Decomposition is not initialized."); return m_rowPerm; }
     Index rank() const { assert(m_isInitialized && "The factorization should be called first, use compute()"); return m_nonzeropivots; }
@@ -305,8 +310,9 @@ class BlockDiagonalSparseQR {
         assert((Index)B.size() % rows() == 0 && "SparseQR::solve() : invalid number of rows in the right hand side matrix");
         const int64_t nrhs = (int64_t)B.size() / rows();
         dest.assign((size_t)(nrhs * cols()), 0.0);
-        check(qrk_bd_solve(m_plan, m_Q.values().data(), m_R.values().data(), m_outputPerm_c.indices().data(), B.data(), nrhs,
-                           dest.data(), QRK_MEM_HOST));
+        DeviceVec b(*this, B), x(*this, dest.size());
+        check(qrk_bd_solve(m_plan, (const double*)m_dq, (const double*)m_dr, (const int32_t*)m_dperm, b.ptr(), nrhs, x.ptr(), QRK_MEM_DEVICE));
+        x.download(dest);
         m_info = Success;
         return true;
     }
@@ -315,21 +321,27 @@ class BlockDiagonalSparseQR {
     Vector solveR(const Vector& y) const {
         assert(m_isInitialized && (Index)y.size() % cols() == 0);
         Vector z(y.size());
-        check(qrk_bd_solve_r(m_plan, m_R.values().data(), y.data(), (int64_t)y.size() / cols(), z.data(), QRK_MEM_HOST));
+        DeviceVec dy(*this, y), dz(*this, z.size());
+        check(qrk_bd_solve_r(m_plan, (const double*)m_dr, dy.ptr(), (int64_t)y.size() / cols(), dz.ptr(), QRK_MEM_DEVICE));
+        dz.download(z);
         return z;
     }
     // matrixQ().transpose() * B on the device (test/test-qrkit.cpp:187)
     Vector applyQt(const Vector& B) const {
         const int64_t nrhs = (int64_t)B.size() / rows();
         Vector y(B.size());
-        check(qrk_bd_apply_qt(m_plan, m_Q.values().data(), B.data(), nrhs, y.data(), QRK_MEM_HOST));
+        DeviceVec b(*this, B), dy(*this, y.size());
+        check(qrk_bd_apply_qt(m_plan, (const double*)m_dq, b.ptr(), nrhs, dy.ptr(), QRK_MEM_DEVICE));
+        dy.download(y);
         return y;
     }
     // matrixQ() * B on the device (the product with the explicit m_Q)
     Vector applyQ(const Vector& B) const {
         const int64_t nrhs = (int64_t)B.size() / rows();
         Vector y(B.size());
-        check(qrk_bd_apply_q(m_plan, m_Q.values().data(), B.data(), nrhs, y.data(), QRK_MEM_HOST));
+        DeviceVec b(*this, B), dy(*this, y.size());
+        check(qrk_bd_apply_q(m_plan, (const double*)m_dq, b.ptr(), nrhs, dy.ptr(), QRK_MEM_DEVICE));
+        dy.download(y);
         return y;
     }
 
@@ -337,9 +349,55 @@ class BlockDiagonalSparseQR {
     void check(qrk_status st) const {
         if (st != QRK_STATUS_OK) throw std::runtime_error(std::string("qrkit: ") + qrk_last_error(m_handle));
     }
+    // scoped device vector of doubles for a right-hand side / a result
+    struct DeviceVec {
+        const BlockDiagonalSparseQR& s; void* p; size_t n;
+        DeviceVec(const BlockDiagonalSparseQR& ss, size_t count) : s(ss), p(0), n(count) {
+            s.check(qrk_device_alloc(s.m_handle, (int64_t)(n * sizeof(double)), &p));
+        }
+        DeviceVec(const BlockDiagonalSparseQR& ss, const Vector& host) : DeviceVec(ss, host.size()) {
+            s.check(qrk_memcpy(s.m_handle, p, host.data(), (int64_t)(n * sizeof(double)), 0));
+        }
+        ~DeviceVec() { if (p) qrk_device_free(s.m_handle, p); }
+        double* ptr() const { return (double*)p; }
+        void download(Vector& host) const { s.check(qrk_memcpy(s.m_handle, host.data(), p, (int64_t)(n * sizeof(double)), 1)); }
+        DeviceVec(const DeviceVec&) = delete;
+        DeviceVec& operator=(const DeviceVec&) = delete;
+    };
+    void reserve(void*& buf, int64_t& cap, int64_t bytes) {
+        if (bytes <= cap) return;
+        if (buf) { qrk_device_free(m_handle, buf); buf = 0; cap = 0; }
+        check(qrk_device_alloc(m_handle, bytes, &buf));
+        cap = bytes;
+    }
+    void releaseDevice() {
+        void** bufs[4] = {&m_dtiles, &m_dq, &m_dr, &m_dperm};
+        for (void** b : bufs) { if (*b) qrk_device_free(m_handle, *b); *b = 0; }
+        m_ctiles = m_cq = m_cr = m_cperm = 0;
+    }
+    // host copies of the factors, made when first asked for (values from the device, structure from qrk_bd_pattern)
+    void syncQ() const {
+        if (m_Qsynced || !m_isInitialized) return;
+        m_Q.values().assign((size_t)m_nq, 0.0); m_Q.innerIndex().assign((size_t)m_nq, 0);
+        std::vector<int> rp((size_t)m_R.cols() + 1, 0), ri((size_t)m_nr, 0);
+        check(qrk_bd_pattern(m_plan, m_Q.outerIndex().data(), m_Q.innerIndex().data(), rp.data(), ri.data(), QRK_MEM_HOST));
+        check(qrk_memcpy(m_handle, m_Q.values().data(), m_dq, m_nq * (int64_t)sizeof(double), 1));
+        m_Qsynced = true;
+    }
+    void syncR() const {
+        if (m_Rsynced || !m_isInitialized) return;
+        m_R.values().assign((size_t)m_nr, 0.0); m_R.innerIndex().assign((size_t)m_nr, 0);
+        std::vector<int> qp((size_t)m_R.rows() + 1, 0), qi((size_t)m_nq, 0);
+        check(qrk_bd_pattern(m_plan, qp.data(), qi.data(), m_R.outerIndex().data(), m_R.innerIndex().data(), QRK_MEM_HOST));
+        check(qrk_memcpy(m_handle, m_R.values().data(), m_dr, m_nr * (int64_t)sizeof(double), 1));
+        m_Rsynced = true;
+    }
+    void* m_dtiles = 0; void* m_dq = 0; void* m_dr = 0; void* m_dperm = 0;     // device-resident tiles, factors, permutation
+    int64_t m_ctiles = 0, m_cq = 0, m_cr = 0, m_cperm = 0, m_nq = 0, m_nr = 0;
+    mutable bool m_Qsynced = false, m_Rsynced = false;
     mutable ComputationInfo m_info;
-    MatrixRType m_R;
-    MatrixQType m_Q;
+    mutable MatrixRType m_R;
+    mutable MatrixQType m_Q;
     PermutationType m_outputPerm_c;
     PermutationType m_rowPerm;
     Index m_nonzeropivots;

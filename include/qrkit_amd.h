@@ -86,6 +86,16 @@ qrk_status qrk_synchronize(qrk_handle h);
 /* Text of the last error on this handle (h may be NULL for creation errors). */
 const char* qrk_last_error(qrk_handle h);
 
+/* ------------------------------------------------------- device memory helpers */
+
+/* For callers without a HIP toolchain of their own (the C++ facade in include/qrkit/QRKit.hpp keeps the
+ * factors on the device between factorize() and solve() with these): plain device memory on the
+ * context's device, and copies ordered on the context's stream that return when the data has arrived.
+ * direction: 0 = host -> device, 1 = device -> host. */
+qrk_status qrk_device_alloc(qrk_handle h, int64_t bytes, void** out);
+qrk_status qrk_device_free(qrk_handle h, void* ptr);
+qrk_status qrk_memcpy(qrk_handle h, void* dst, const void* src, int64_t bytes, int direction);
+
 /* -------------------------------------------- block-diagonal: analyzePattern */
 
 /* The block structure of a QRKit::SparseBlockDiagonal (SparseBlockDiagonal.h:43-163):

@@ -357,7 +357,7 @@ bdqr_factor32_kernel(int64_t num_tiles, const double* __restrict__ tiles, double
 // Q_i = H_0 ... H_31 applied to the identity, row j of Q_i (= column j of Q^T) in lane j, with the operations and the
 // order of bdqr_pair.hip (d = x_tail . c_tail as a product followed by FMAs; gamma' = (s c_k + d) ng; c_k += s gamma';
 // c_i += gamma' x_i).  The reflectors of a tile are staged in LDS (coalesced read), the steps only do broadcast reads.
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
+__global__ void __launch_bounds__(64, 2)
 bdqr_formq32_kernel(int64_t num_tiles, const double* __restrict__ vbuf, const double* __restrict__ sbuf,
                     double* __restrict__ q_vals)
 {

@@ -318,6 +318,34 @@ qrk_status qrk_synchronize(qrk_handle h)
 
 const char* qrk_last_error(qrk_handle h) { return h ? h->error.c_str() : g_create_error.c_str(); }
 
+qrk_status qrk_device_alloc(qrk_handle h, int64_t bytes, void** out)
+{
+    if (!h || !out || bytes < 0) return fail(h, QRK_STATUS_INVALID_ARGUMENT, "qrk_device_alloc: bad argument");
+    *out = nullptr;
+    if (bytes == 0) return QRK_STATUS_OK;
+    QRK_HIP(h, hipSetDevice(h->device));
+    if (hipMalloc(out, (size_t)bytes) != hipSuccess) { *out = nullptr; return fail(h, QRK_STATUS_ALLOC_FAILED, "qrk_device_alloc: out of device memory"); }
+    return QRK_STATUS_OK;
+}
+
+qrk_status qrk_device_free(qrk_handle h, void* ptr)
+{
+    if (!h) return QRK_STATUS_INVALID_ARGUMENT;
+    if (ptr) { QRK_HIP(h, hipSetDevice(h->device)); QRK_HIP(h, hipStreamSynchronize(h->stream)); QRK_HIP(h, hipFree(ptr)); }
+    return QRK_STATUS_OK;
+}
+
+qrk_status qrk_memcpy(qrk_handle h, void* dst, const void* src, int64_t bytes, int direction)
+{
+    if (!h || bytes < 0 || (bytes > 0 && (!dst || !src)) || (direction != 0 && direction != 1))
+        return fail(h, QRK_STATUS_INVALID_ARGUMENT, "qrk_memcpy: bad argument");
+    if (bytes == 0) return QRK_STATUS_OK;
+    QRK_HIP(h, hipSetDevice(h->device));
+    QRK_HIP(h, hipMemcpyAsync(dst, src, (size_t)bytes, direction == 0 ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost, h->stream));
+    QRK_HIP(h, hipStreamSynchronize(h->stream));
+    return QRK_STATUS_OK;
+}
+
 qrk_status qrk_bd_plan_create(qrk_handle h, const qrk_bd_layout* L, qrk_q_format q_format,
                               qrk_block_solver solver, qrk_bd_plan* out)
 {

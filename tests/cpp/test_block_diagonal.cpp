@@ -3,6 +3,7 @@
 // :101-117: default_random_engine + uniform_real_distribution(0.5, 5.0), 7x2 blocks), with the
 // reference's three invariants at 1e-12 (its own bar is 1e-6, test/test.h:31).
 // Also a 32x32 case (BASELINE configs[0] shape) and the landscape -> InvalidInput rule.
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <random>
@@ -95,10 +96,49 @@ static int test_landscape() {
     return fails;
 }
 
+// An LM-style loop on the facade: the pattern is analysed once, factorize() + solve() run per iteration with the factors
+// resident on the device (only tiles go up and the solution comes down); times printed for DESIGN.md (PCIe-inclusive).
+static int test_resident_loop(int numBlocks) {
+    const int n = 32;
+    SparseBlockDiagonal m;
+    std::default_random_engine gen;
+    std::uniform_real_distribution<double> dist(0.5, 5.0);
+    Matrix a(n, n);
+    for (int i = 0; i < numBlocks; ++i) { for (int e = 0; e < n * n; ++e) a.data()[e] = dist(gen); m.insertBack(a); }
+    m.setDims(numBlocks * n, numBlocks * n);
+    BlockDiagonalSparseQR<> qr;
+    qr.analyzePattern(m);
+    Vector x((size_t)(numBlocks * n)), b((size_t)(numBlocks * n), 0.0);
+    for (double& v : x) v = dist(gen) - 2.5;
+    for (int i = 0; i < numBlocks; ++i) {
+        const Matrix blk = m[i];
+        for (int c = 0; c < n; ++c) for (int r = 0; r < n; ++r) b[(size_t)(i * n + r)] += blk(r, c) * x[(size_t)(i * n + c)];
+    }
+    double tf = 0, ts = 0;
+    Vector sol;
+    const int iters = 5;
+    for (int it = 0; it < iters; ++it) {
+        const auto t0 = std::chrono::steady_clock::now();
+        qr.factorize(m);
+        const auto t1 = std::chrono::steady_clock::now();
+        sol = qr.solve(b);
+        const auto t2 = std::chrono::steady_clock::now();
+        if (it) { tf += std::chrono::duration<double, std::milli>(t1 - t0).count(); ts += std::chrono::duration<double, std::milli>(t2 - t1).count(); }
+    }
+    double d = 0, nx = 0;
+    for (size_t i = 0; i < x.size(); ++i) { d += (sol[i] - x[i]) * (sol[i] - x[i]); nx += x[i] * x[i]; }
+    const int fails = std::sqrt(d) <= 1e-8 * std::sqrt(nx) ? 0 : 1;
+    std::printf("resident loop, %d blocks of 32x32: factorize %.2f ms, solve %.2f ms per iteration (host tiles in, x out): %s\n",
+                numBlocks, tf / (iters - 1), ts / (iters - 1), fails ? "Failed." : "Passed.");
+    return fails;
+}
+
 int main() {
     int fails = 0;
     fails += test_block_diagonal(256, 7, 2);     // the reference's main(): numVars = 256 (test-qrkit.cpp:369-377)
     fails += test_block_diagonal(40, 32, 32);
     fails += test_landscape();
+    fails += test_resident_loop(1000);       // BASELINE configs[0]
+    fails += test_resident_loop(10000);      // BASELINE configs[1]
     return fails ? 1 : 0;
 }

@@ -13,7 +13,7 @@ def test_cpp_facade_block_diagonal():
     out = subprocess.run([os.path.join(ROOT, "build", "test_block_diagonal")], capture_output=True, text=True, timeout=300)
     print(out.stdout, out.stderr)
     assert out.returncode == 0, out.stdout + out.stderr
-    assert "Failed." not in out.stdout and out.stdout.count("Passed.") == 3
+    assert "Failed." not in out.stdout and out.stdout.count("Passed.") == 5
 
 
 @pytest.mark.gpu
