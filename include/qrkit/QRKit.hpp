@@ -480,7 +480,7 @@ class BandedBlockedSparseQR {
         if (qrk_create(&m_handle, device, 0) != QRK_STATUS_OK)
             throw std::runtime_error(std::string("qrkit: ") + qrk_last_error(0));
     }
-    ~BandedBlockedSparseQR() { if (m_plan) qrk_bb_plan_destroy(m_plan); if (m_handle) qrk_destroy(m_handle); }
+    ~BandedBlockedSparseQR() { releaseDevice(); if (m_plan) qrk_bb_plan_destroy(m_plan); if (m_handle) qrk_destroy(m_handle); }
     BandedBlockedSparseQR(const BandedBlockedSparseQR&) = delete;
     BandedBlockedSparseQR& operator=(const BandedBlockedSparseQR&) = delete;
 
@@ -505,8 +505,7 @@ class BandedBlockedSparseQR {
         m_yty.assign((size_t)6 * nb, 0);
         m_rowPerm.setIdentity(m_rows);
         check(qrk_bb_plan_blocks(m_plan, m_blocks.data(), m_rowPerm.indices().data(), m_yty.data()));
-        m_y.assign((size_t)std::max<int64_t>(yl, 1), 0.0);
-        m_t.assign((size_t)std::max<int64_t>(tl, 1), 0.0);
+        m_yl = yl; m_tl = tl;
         m_outputPerm_c.setIdentity(m_cols);
         m_analysisIsok = true;
     }
@@ -518,9 +517,15 @@ class BandedBlockedSparseQR {
         toCsr(mat, rp, ci, vals);
         assert(ci.size() == m_colidx.size() && "the sparsity pattern differs from the analysed one");
         m_R.resize(m_rows, m_cols);
-        m_R.values().assign((size_t)m_nnzR, 0.0); m_R.innerIndex().assign((size_t)m_nnzR, 0);
-        check(qrk_bb_factorize(m_plan, vals.data(), (int64_t)vals.size(), m_R.values().data(), m_y.data(), m_t.data(), QRK_MEM_HOST));
-        check(qrk_bb_pattern(m_plan, m_R.outerIndex().data(), m_R.innerIndex().data(), QRK_MEM_HOST));
+        m_Rsynced = false;
+        // the implicit Q (Y, T of every block) and the values of R stay on the device; products and solve() run there
+        reserve(m_dvals, m_cvals, (int64_t)(vals.size() * sizeof(double)));
+        reserve(m_dr, m_cr, std::max<int64_t>(m_nnzR, 1) * (int64_t)sizeof(double));
+        reserve(m_dy, m_cy, std::max<int64_t>(m_yl, 1) * (int64_t)sizeof(double));
+        reserve(m_dt, m_ct, std::max<int64_t>(m_tl, 1) * (int64_t)sizeof(double));
+        check(qrk_memcpy(m_handle, m_dvals, vals.data(), (int64_t)(vals.size() * sizeof(double)), 0));
+        check(qrk_bb_factorize(m_plan, (const double*)m_dvals, (int64_t)vals.size(), (double*)m_dr, (double*)m_dy, (double*)m_dt, QRK_MEM_DEVICE));
+        check(qrk_synchronize(m_handle));
         m_nonzeropivots = m_cols;                 // :513 "assuming all cols are nonzero"
         m_isInitialized = true;
         m_info = Success;
@@ -530,7 +535,7 @@ class BandedBlockedSparseQR {
     Index cols() const { return m_cols; }
     Index rank() const { assert(m_isInitialized); return m_nonzeropivots; }
     ComputationInfo info() const { return m_info; }
-    const MatrixRType& matrixR() const { return m_R; }
+    const MatrixRType& matrixR() const { syncR(); return m_R; }
     MatrixQType matrixQ() const { return MatrixQType(*this, false); }
     const PermutationType& colsPermutation() const { return m_outputPerm_c; }     // identity (:253-257)
     const PermutationType& rowsPermutation() const { return m_rowPerm; }
@@ -548,9 +553,14 @@ class BandedBlockedSparseQR {
     Vector solve(const Vector& B) const {
         assert(m_isInitialized && "The factorization should be called first, use compute()");
         // y = Q^T B, then the back substitution with R, both on the device (qrk_bb_apply_q, qrk_bb_solve_r)
-        Vector y = applyQt(B);
         const int64_t nrhs = (int64_t)B.size() / m_rows;
-        check(qrk_bb_solve_r(m_plan, y.data(), (int64_t)m_rows, nrhs, QRK_MEM_HOST));
+        Vector y(B.size());
+        {
+            DeviceBuf d(*this, B);
+            check(qrk_bb_apply_q(m_plan, (const double*)m_dy, (const double*)m_dt, 1, d.ptr(), nrhs, QRK_MEM_DEVICE));
+            check(qrk_bb_solve_r(m_plan, d.ptr(), (int64_t)m_rows, nrhs, QRK_MEM_DEVICE));
+            d.download(y);
+        }
         Vector x((size_t)(m_cols * nrhs));
         for (int64_t c = 0; c < nrhs; ++c) std::copy(y.begin() + c * m_rows, y.begin() + c * m_rows + m_cols, x.begin() + c * m_cols);
         return x;
@@ -558,21 +568,58 @@ class BandedBlockedSparseQR {
     // the triangular step alone, on the device (qrk_bb_solve_r); y: cols x nrhs
     Vector solveR(const Vector& y) const {
         assert(m_isInitialized && (Index)y.size() % m_cols == 0);
-        Vector z(y);
-        check(qrk_bb_solve_r(m_plan, z.data(), (int64_t)m_cols, (int64_t)y.size() / m_cols, QRK_MEM_HOST));
+        Vector z(y.size());
+        DeviceBuf d(*this, y);
+        check(qrk_bb_solve_r(m_plan, d.ptr(), (int64_t)m_cols, (int64_t)y.size() / m_cols, QRK_MEM_DEVICE));
+        d.download(z);
         return z;
     }
 
   protected:
     Vector apply(const Vector& v, int transpose) const {
         assert(m_isInitialized && (Index)v.size() % m_rows == 0);
-        Vector out(v);
-        check(qrk_bb_apply_q(m_plan, m_y.data(), m_t.data(), transpose, out.data(), (int64_t)v.size() / m_rows, QRK_MEM_HOST));
+        Vector out(v.size());
+        DeviceBuf d(*this, v);
+        check(qrk_bb_apply_q(m_plan, (const double*)m_dy, (const double*)m_dt, transpose, d.ptr(), (int64_t)v.size() / m_rows, QRK_MEM_DEVICE));
+        d.download(out);
         return out;
     }
     void check(qrk_status st) const {
         if (st != QRK_STATUS_OK) throw std::runtime_error(std::string("qrkit: ") + qrk_last_error(m_handle));
     }
+    struct DeviceBuf {           // scoped device copy of a host vector
+        const BandedBlockedSparseQR& s; void* p; size_t n;
+        DeviceBuf(const BandedBlockedSparseQR& ss, const Vector& host) : s(ss), p(0), n(host.size()) {
+            s.check(qrk_device_alloc(s.m_handle, (int64_t)(n * sizeof(double)), &p));
+            s.check(qrk_memcpy(s.m_handle, p, host.data(), (int64_t)(n * sizeof(double)), 0));
+        }
+        ~DeviceBuf() { if (p) qrk_device_free(s.m_handle, p); }
+        double* ptr() const { return (double*)p; }
+        void download(Vector& host) const { s.check(qrk_memcpy(s.m_handle, host.data(), p, (int64_t)(n * sizeof(double)), 1)); }
+        DeviceBuf(const DeviceBuf&) = delete;
+        DeviceBuf& operator=(const DeviceBuf&) = delete;
+    };
+    void reserve(void*& buf, int64_t& cap, int64_t bytes) {
+        if (bytes <= cap) return;
+        if (buf) { qrk_device_free(m_handle, buf); buf = 0; cap = 0; }
+        check(qrk_device_alloc(m_handle, bytes, &buf));
+        cap = bytes;
+    }
+    void releaseDevice() {
+        void** bufs[4] = {&m_dvals, &m_dr, &m_dy, &m_dt};
+        for (void** b : bufs) { if (*b) qrk_device_free(m_handle, *b); *b = 0; }
+        m_cvals = m_cr = m_cy = m_ct = 0;
+    }
+    void syncR() const {         // host copy of R when it is asked for
+        if (m_Rsynced || !m_isInitialized) return;
+        m_R.values().assign((size_t)m_nnzR, 0.0); m_R.innerIndex().assign((size_t)m_nnzR, 0);
+        check(qrk_bb_pattern(m_plan, m_R.outerIndex().data(), m_R.innerIndex().data(), QRK_MEM_HOST));
+        check(qrk_memcpy(m_handle, m_R.values().data(), m_dr, m_nnzR * (int64_t)sizeof(double), 1));
+        m_Rsynced = true;
+    }
+    void* m_dvals = 0; void* m_dr = 0; void* m_dy = 0; void* m_dt = 0;
+    int64_t m_cvals = 0, m_cr = 0, m_cy = 0, m_ct = 0, m_yl = 0, m_tl = 0;
+    mutable bool m_Rsynced = false;
     ComputationInfo m_info;
     Index m_nonzeropivots;
     bool m_isInitialized, m_analysisIsok;
@@ -584,8 +631,7 @@ class BandedBlockedSparseQR {
     std::vector<int> m_rowptr, m_colidx;
     std::vector<int32_t> m_blocks;
     std::vector<int64_t> m_yty;
-    std::vector<double> m_y, m_t;
-    MatrixRType m_R;
+    mutable MatrixRType m_R;
     PermutationType m_rowPerm, m_outputPerm_c;
 };
 
