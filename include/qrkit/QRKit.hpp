@@ -635,6 +635,76 @@ class BandedBlockedSparseQR {
     PermutationType m_rowPerm, m_outputPerm_c;
 };
 
+// Dense Householder QR kept on the device (qrk_dense_*): the packed QR and tau stay resident after factorize(), products
+// with Q and the triangular solve move only their vectors.  Shared by the thin solvers and the angular right block.
+class DenseDeviceQR {
+  public:
+    DenseDeviceQR() : m_h(0), m_plan(0), m_dqr(0), m_dhc(0), m_rows(0), m_cols(0) {}
+    ~DenseDeviceQR() { release(); }
+    DenseDeviceQR(const DenseDeviceQR&) = delete;
+    DenseDeviceQR& operator=(const DenseDeviceQR&) = delete;
+    // a: in the matrix, out the packed QR (R above the diagonal, essential parts below); hc: tau; perm: column permutation
+    void factorize(qrk_handle h, Matrix& a, int solver, std::vector<double>& hc, std::vector<int32_t>& perm) {
+        release();
+        m_h = h; m_rows = a.rows(); m_cols = a.cols();
+        const Index k = std::min(m_rows, m_cols);
+        check(qrk_dense_plan_create(m_h, (int32_t)m_rows, (int32_t)m_cols, (qrk_block_solver)solver, &m_plan));
+        hc.assign((size_t)std::max<Index>(k, 1), 0.0);
+        perm.assign((size_t)std::max<Index>(m_cols, 1), 0);
+        void* dperm = 0;
+        const int64_t nb = (int64_t)m_rows * m_cols * (int64_t)sizeof(double);
+        check(qrk_device_alloc(m_h, std::max<int64_t>(nb, 8), &m_dqr));
+        check(qrk_device_alloc(m_h, (int64_t)(hc.size() * sizeof(double)), &m_dhc));
+        check(qrk_device_alloc(m_h, (int64_t)(perm.size() * sizeof(int32_t)), &dperm));
+        check(qrk_memcpy(m_h, m_dqr, a.data(), nb, 0));
+        qrk_status st = qrk_dense_factorize(m_plan, (double*)m_dqr, m_rows, (double*)m_dhc, (int32_t*)dperm, QRK_MEM_DEVICE);
+        if (st == QRK_STATUS_OK) st = qrk_memcpy(m_h, a.data(), m_dqr, nb, 1);
+        if (st == QRK_STATUS_OK) st = qrk_memcpy(m_h, hc.data(), m_dhc, (int64_t)(hc.size() * sizeof(double)), 1);
+        if (st == QRK_STATUS_OK) st = qrk_memcpy(m_h, perm.data(), dperm, (int64_t)(perm.size() * sizeof(int32_t)), 1);
+        qrk_device_free(m_h, dperm);
+        check(st);
+    }
+    // v (rows x nrhs, column-major) <- Q^T v or Q v
+    void applyQ(Vector& v, Index nrhs, bool transpose) const {
+        Scoped d(*this, v);
+        check(qrk_dense_apply_q(m_plan, (const double*)m_dqr, m_rows, (const double*)m_dhc, transpose ? 1 : 0, d.ptr(), m_rows, nrhs, QRK_MEM_DEVICE));
+        d.download(v);
+    }
+    // z (ldb x nrhs; the first cols rows of every column) <- R^-1 z
+    void solveR(Vector& z, Index ldb, Index nrhs) const {
+        Scoped d(*this, z);
+        check(qrk_dense_solve_r(m_plan, (const double*)m_dqr, m_rows, d.ptr(), ldb, nrhs, QRK_MEM_DEVICE));
+        d.download(z);
+    }
+    bool ready() const { return m_plan != 0; }
+    void release() {             // (before the handle it was created with is destroyed)
+        if (m_dqr) qrk_device_free(m_h, m_dqr);
+        if (m_dhc) qrk_device_free(m_h, m_dhc);
+        if (m_plan) qrk_dense_plan_destroy(m_plan);
+        m_dqr = m_dhc = 0; m_plan = 0;
+    }
+  private:
+    struct Scoped {
+        const DenseDeviceQR& s; void* p; size_t n;
+        Scoped(const DenseDeviceQR& ss, const Vector& host) : s(ss), p(0), n(host.size()) {
+            s.check(qrk_device_alloc(s.m_h, (int64_t)(std::max<size_t>(n, 1) * sizeof(double)), &p));
+            s.check(qrk_memcpy(s.m_h, p, host.data(), (int64_t)(n * sizeof(double)), 0));
+        }
+        ~Scoped() { if (p) qrk_device_free(s.m_h, p); }
+        double* ptr() const { return (double*)p; }
+        void download(Vector& host) const { s.check(qrk_memcpy(s.m_h, host.data(), p, (int64_t)(n * sizeof(double)), 1)); }
+        Scoped(const Scoped&) = delete;
+        Scoped& operator=(const Scoped&) = delete;
+    };
+    void check(qrk_status st) const {
+        if (st != QRK_STATUS_OK) throw std::runtime_error(std::string("qrkit: ") + qrk_last_error(m_h));
+    }
+    qrk_handle m_h;
+    qrk_dense_plan m_plan;
+    void* m_dqr; void* m_dhc;
+    Index m_rows, m_cols;
+};
+
 // ---------------------------------------------------------------------------------------------
 // QRKit::BlockedThinDenseQR<MatrixXd, HouseholderQR<MatrixXd>, SuggestedBlockCols> (BlockedThinDenseQR.h:53-176,
 // base BlockedThinQRBase.h:47-333) and QRKit::BlockedThinSparseQR (BlockedThinSparseQR.h:105-283 -- the same
@@ -654,12 +724,12 @@ class BlockedThinDenseQR {
     typedef QProduct<BlockedThinDenseQR> MatrixQType;
 
     explicit BlockedThinDenseQR(int device = 0)
-        : m_info(Success), m_nonzeroPivots(0), m_isInitialized(false), m_handle(0), m_plan(0) {
+        : m_info(Success), m_nonzeroPivots(0), m_isInitialized(false), m_handle(0) {
         if (qrk_create(&m_handle, device, 0) != QRK_STATUS_OK)
             throw std::runtime_error(std::string("qrkit: ") + qrk_last_error(0));
     }
     explicit BlockedThinDenseQR(const Matrix& mat, int device = 0) : BlockedThinDenseQR(device) { compute(mat); }
-    ~BlockedThinDenseQR() { if (m_plan) qrk_dense_plan_destroy(m_plan); if (m_handle) qrk_destroy(m_handle); }
+    ~BlockedThinDenseQR() { m_dev.release(); if (m_handle) qrk_destroy(m_handle); }
     BlockedThinDenseQR(const BlockedThinDenseQR&) = delete;
     BlockedThinDenseQR& operator=(const BlockedThinDenseQR&) = delete;
 
@@ -669,11 +739,8 @@ class BlockedThinDenseQR {
         analyzePattern(mat);
         m_qr = mat;
         const Index rows = mat.rows(), cols = mat.cols(), k = std::min(rows, cols);
-        if (m_plan) { qrk_dense_plan_destroy(m_plan); m_plan = 0; }
-        check(qrk_dense_plan_create(m_handle, (int32_t)rows, (int32_t)cols, QRK_HOUSEHOLDER, &m_plan));
-        m_hc.assign((size_t)std::max<Index>(k, 1), 0.0);
-        std::vector<int32_t> p((size_t)std::max<Index>(cols, 1), 0);
-        check(qrk_dense_factorize(m_plan, m_qr.data(), rows, m_hc.data(), p.data(), QRK_MEM_HOST));
+        std::vector<int32_t> p;
+        m_dev.factorize(m_handle, m_qr, QRK_HOUSEHOLDER, m_hc, p);      // packed QR and tau stay on the device
         m_R = Matrix(rows, cols);
         for (Index c = 0; c < cols; ++c) for (Index r = 0; r <= std::min(c, k - 1); ++r) m_R(r, c) = m_qr(r, c);
         m_nonzeroPivots = cols;     // (:132)
@@ -702,7 +769,7 @@ class BlockedThinDenseQR {
         assert(m_isInitialized && "The factorization should be called first, use compute()");
         Vector y = applyQt(b);
         Vector z(y.begin(), y.begin() + cols());
-        check(qrk_dense_solve_r(m_plan, m_qr.data(), (int64_t)rows(), z.data(), (int64_t)cols(), 1, QRK_MEM_HOST));
+        m_dev.solveR(z, cols(), 1);
         return z;
     }
 
@@ -711,7 +778,7 @@ class BlockedThinDenseQR {
         assert(m_isInitialized && "The factorization should be called first, use compute()");
         const Index r = rows(), nrhs = (Index)v.size() / r;
         Vector out(v);
-        check(qrk_dense_apply_q(m_plan, m_qr.data(), r, m_hc.data(), transpose ? 1 : 0, out.data(), r, nrhs, QRK_MEM_HOST));
+        m_dev.applyQ(out, nrhs, transpose);
         return out;
     }
     void check(qrk_status st) const {
@@ -721,7 +788,7 @@ class BlockedThinDenseQR {
     Index m_nonzeroPivots;
     bool m_isInitialized;
     qrk_handle m_handle;
-    qrk_dense_plan m_plan;
+    DenseDeviceQR m_dev;
     Matrix m_qr, m_R;
     std::vector<double> m_hc;
     PermutationType m_outputPerm_c, m_rowPerm;
@@ -770,12 +837,12 @@ class BlockAngularSparseQR {
     typedef QProduct<BlockAngularSparseQR> MatrixQType;
 
     explicit BlockAngularSparseQR(int device = 0)
-        : m_leftSolver(device), m_info(Success), m_nonzeropivots(0), m_isInitialized(false), m_handle(0), m_dense(0),
+        : m_leftSolver(device), m_info(Success), m_nonzeropivots(0), m_isInitialized(false), m_handle(0),
           m_rows(0), m_cols(0), m_m1(0), m_m2(0), m_n1(0), m_k2(0) {
         if (qrk_create(&m_handle, device, 0) != QRK_STATUS_OK)
             throw std::runtime_error(std::string("qrkit: ") + qrk_last_error(0));
     }
-    ~BlockAngularSparseQR() { if (m_dense) qrk_dense_plan_destroy(m_dense); if (m_handle) qrk_destroy(m_handle); }
+    ~BlockAngularSparseQR() { m_dense.release(); if (m_handle) qrk_destroy(m_handle); }
     BlockAngularSparseQR(const BlockAngularSparseQR&) = delete;
     BlockAngularSparseQR& operator=(const BlockAngularSparseQR&) = delete;
 
@@ -822,12 +889,9 @@ class BlockAngularSparseQR {
         const Index rb = m_rows - m_m1;
         m_bottom = Matrix(rb, m_m2);
         for (Index c = 0; c < m_m2; ++c) for (Index r = 0; r < rb; ++r) m_bottom(r, c) = m_J2(m_m1 + r, c);
-        if (m_dense) { qrk_dense_plan_destroy(m_dense); m_dense = 0; }
-        check(qrk_dense_plan_create(m_handle, (int32_t)rb, (int32_t)m_m2, (qrk_block_solver)RightSolverTag::kSolver, &m_dense));
         m_k2 = std::min(rb, m_m2);
-        m_hc.assign((size_t)std::max<Index>(m_k2, 1), 0.0);
-        std::vector<int32_t> p2((size_t)std::max<Index>(m_m2, 1), 0);
-        check(qrk_dense_factorize(m_dense, m_bottom.data(), rb, m_hc.data(), p2.data(), QRK_MEM_HOST));
+        std::vector<int32_t> p2;
+        m_dense.factorize(m_handle, m_bottom, RightSolverTag::kSolver, m_hc, p2);    // packed QR and tau stay on the device
         // column permutation (:498-503) and rank (:510)
         m_outputPerm_c.setIdentity(m_cols);
         for (Index j = 0; j < m_m1; ++j) m_outputPerm_c.indices()[(size_t)j] = m_leftSolver.colsPermutation().indices()[(size_t)j];
@@ -872,7 +936,7 @@ class BlockAngularSparseQR {
         // R = [R1 S; 0 R2], block by block: z2 = R2^-1 y2 (qrk_dense_solve_r) and z1 = R1^-1 (y1 - S z2) (the left
         // solver's triangular step) on the device; S = (Q1^T J2)(0:m1, P2) is applied here
         Vector z2(y.begin() + m_m1, y.begin() + m_m1 + m_m2);
-        check(qrk_dense_solve_r(m_dense, m_bottom.data(), (int64_t)m_bottom.rows(), z2.data(), (int64_t)m_m2, 1, QRK_MEM_HOST));
+        m_dense.solveR(z2, m_m2, 1);
         Vector rhs1(y.begin(), y.begin() + m_m1);
         for (Index c = 0; c < m_m2; ++c) {
             const double zc = z2[(size_t)c];
@@ -895,7 +959,7 @@ class BlockAngularSparseQR {
         const Index rb = m_rows - m_m1;
         Vector bot((size_t)(rb * nrhs));
         for (Index c = 0; c < nrhs; ++c) std::copy(v.begin() + c * m_rows + m_m1, v.begin() + (c + 1) * m_rows, bot.begin() + c * rb);
-        check(qrk_dense_apply_q(m_dense, m_bottom.data(), rb, m_hc.data(), transpose ? 1 : 0, bot.data(), rb, nrhs, QRK_MEM_HOST));
+        m_dense.applyQ(bot, nrhs, transpose);
         for (Index c = 0; c < nrhs; ++c) std::copy(bot.begin() + c * rb, bot.begin() + (c + 1) * rb, v.begin() + c * m_rows + m_m1);
     }
     // makeR (:285-335): R = [R1(0:m1,:), (Q1^T J2)(0:m1, P2); 0, R2; 0, 0]
@@ -920,7 +984,7 @@ class BlockAngularSparseQR {
     Index m_nonzeropivots;
     bool m_isInitialized;
     qrk_handle m_handle;
-    qrk_dense_plan m_dense;
+    DenseDeviceQR m_dense;
     Index m_rows, m_cols, m_m1, m_m2, m_n1, m_k2;
     Matrix m_J2, m_bottom;              // [Q1^T J2.top; J2.bottom] and the packed QR of its rows m1..
     std::vector<double> m_hc;
