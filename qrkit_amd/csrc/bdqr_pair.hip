@@ -45,6 +45,10 @@
 #ifndef QRK_ABL
 #define QRK_ABL 0
 #endif
+#ifndef QRK_SETPRIO
+#define QRK_SETPRIO 0          // 1: s_setprio 2 around the head of a step; 2: everything but the trailing update at priority 3.
+                               // Both measured within the noise of the default (86.0 - 87.6 us over three A/B rounds)
+#endif
 #ifndef QRK_EARLY_SCALARS
 #define QRK_EARLY_SCALARS 0    // 1: reflector scalars in the head of the step, from a DPP sum of the lanes' own pivot-column
                                // entries (no ds_bpermute, rsq/rcp chains beside the broadcast + dots): measured 92.8 vs 89.5 us
@@ -439,11 +443,23 @@ __device__ __forceinline__ void pair_step(double (&a)[WR], double (&q)[WR], doub
     }
 
     // ---- head of the next step, then the trailing update of this one
+#if QRK_SETPRIO == 1
+    __builtin_amdgcn_s_setprio(2);
+#endif
     if (K + 1 < WR) search_fetch<(K + 1 < WR ? K + 1 : K), FULL32, PIVOT>(hl, st);
+#if QRK_SETPRIO == 1
+    __builtin_amdgcn_s_setprio(0);
+#endif
+#if QRK_SETPRIO == 2
+    __builtin_amdgcn_s_setprio(0);      // only the trailing update runs at low priority
+#endif
     if (!(QRK_ABL & 16) && !updated) {
 #pragma unroll
         for (int i = K + 1; i < WR; ++i) { if (QRK_ABL & 2048) a[i] = fma(ngA, x[i], a[i]); else fmac2_shared_b(a[i], q[i], ngA, ngQ, x[i]); }
     }
+#if QRK_SETPRIO == 2
+    __builtin_amdgcn_s_setprio(3);
+#endif
     QRK_STAMP_IN(6);
 
     // ---- refresh the LDS image of the live columns after every RB-th step
