@@ -45,6 +45,10 @@
 #ifndef QRK_ABL
 #define QRK_ABL 0
 #endif
+#ifndef QRK_STAGGER
+#define QRK_STAGGER 0          // n > 0: waves in odd slots of their SIMD start 64 n cycles late (de-phases the two waves of a
+                               // SIMD); n = 6, 12, 24 measured: no effect (86.6 - 87.9 us against 87.0)
+#endif
 #ifndef QRK_SETPRIO
 #define QRK_SETPRIO 0          // 1: s_setprio 2 around the head of a step; 2: everything but the trailing update at priority 3.
                                // Both measured within the noise of the default (86.0 - 87.6 us over three A/B rounds)
@@ -738,6 +742,13 @@ bdqr_pair32_kernel(int64_t num_tiles, const double* __restrict__ tiles, double* 
     __shared__ __attribute__((aligned(16))) double lds[2 * L_HALF];
     const int64_t npairs = (num_tiles + 1) / 2;
     double a[WR], q[WR];
+#if QRK_STAGGER
+    {
+        unsigned hwid;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        if (hwid & 1u) __builtin_amdgcn_s_sleep(QRK_STAGGER);
+    }
+#endif
 
     int64_t pi = blockIdx.x;
     {
