@@ -23,7 +23,7 @@
 // pairs per microsecond with more waves (0.276 pairs/us at eight, 0.244 at ten), i.e. the steps are bound by a resource
 // the waves of a CU share - the LDS pipe that serves the image reads, the publish/broadcast pairs and the refreshes -
 // not by occupancy.  The reflector stores cost ~10 us (78 us without them at eight workgroups), the missing prefetch
-// another ~10 (the pair kernel with its Q work removed: 68 us).  The Q kernel as written takes 50 us (210 VGPRs, two
+// another ~13 (the pair kernel with its Q work removed: 65 us).  The Q kernel as written takes 50 us (210 VGPRs, two
 // waves per SIMD, one dependent FMA chain per dot).  Sum 133-143 us against 88-90: the split does not pay, and raising
 // the occupancy of the factorisation is not the lever.  Parity-green and bitwise equal to the pair kernel
 // (tests/test_split_gpu.py); kept opt-in as a record of the experiment.
