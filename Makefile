@@ -14,6 +14,9 @@ $(OBJDIR)/%.o: $(CSRC)/%.hip $(CSRC)/qrk_device.h include/qrkit_amd.h
 	@mkdir -p $(OBJDIR)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
+# the exact-arithmetic path must round like a scalar evaluation of Eigen's algorithm: never contract a*b+c into an FMA
+$(OBJDIR)/bdqr_exact.o: HIPFLAGS += -ffp-contract=off
+
 $(LIB): $(OBJS)
 	@mkdir -p qrkit_amd/lib
 	$(HIPCC) -shared -fPIC --offload-arch=$(ARCH) $(OBJS) -o $@

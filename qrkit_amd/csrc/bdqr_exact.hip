@@ -1,0 +1,303 @@
+// bdqr_exact.hip -- the exact-arithmetic path of the per-block QR (gfx950).
+//
+// The fast kernels (bdqr_pair / bdqr_small / bdqr_col / bdqr_wg) evaluate Eigen's ColPivHouseholderQR with FMA chains,
+// squared column norms and an un-normalised reflector: the same mathematics, other roundings.  That is invisible in Q and R
+// (1e-15) but NOT in the column permutation whenever two candidate columns are tied in exact arithmetic (sign / indicator /
+// repeated-structure Jacobians): Eigen then breaks the tie by the rounding noise of ITS operation order.  Each fast kernel
+// therefore checks every decision it takes (pivot choice, LAWN-176 recompute test, degenerate reflector, sign of beta) against
+// an error margin and appends the tile to a list when a decision is not clear-cut; this file redoes the listed tiles with the
+// reference's arithmetic itself:
+//
+//   * Eigen/src/QR/ColPivHouseholderQR.h  ColPivHouseholderQR::computeInPlace  (norm tables, first maximum by CURRENT
+//     position, column swaps as position bookkeeping, LAWN-176 downdate `normUpd *= sqrt((1+t)(1-t))` / recompute test),
+//   * Eigen/src/QR/HouseholderQR.h  householder_qr_inplace_unblocked,
+//   * Eigen/src/Householder/Householder.h  makeHouseholder / applyHouseholderOnTheLeft
+//     (tmp = essential^T bottom; tmp += row0; row0 -= tau tmp; bottom -= (tau essential) tmp),
+//   * Eigen/src/Householder/HouseholderSequence.h  evalTo (Q = I, reflectors applied last to first on the shrinking corner),
+//
+// one IEEE-754 double operation at a time in Eigen's scalar order (sequential sums over the rows, no FMA contraction,
+// correctly rounded division and square root) -- the evaluation order the CPU oracle (oracle/qrk_oracle.c) states, so the
+// results of this path are bit-identical to the oracle's: permutation, tau, R and Q.
+// Call site in the reference: blockSolver.compute(block) / matrixQ() / matrixR() / colsPermutation(),
+// src/QRKit/BlockDiagonalSparseQR.h:437-447,519-521.
+//
+// Shape: one workgroup of 256 threads per listed tile; a thread owns whole columns (j, j+256, ...), so every sum over the rows
+// is a sequential chain in one thread exactly as in the scalar reference, and the columns run in parallel.  The working copy
+// of the tile (row-major: consecutive threads, consecutive addresses) and Q live in LDS when they fit, else in a global
+// workspace / directly in the output.  This is the slow path by design (it trades the FMA chains and the register tile for
+// reproducibility); generic inputs never reach it.
+#include "qrk_device.h"
+
+#include <float.h>
+
+#pragma clang fp contract(off)
+
+namespace qrk {
+namespace exact {
+
+constexpr int T = 256;
+constexpr double SQRT_EPS = 1.4901161193847656e-08;   // sqrt(DBL_EPSILON): Eigen's norm_downdate_threshold
+
+// Inverse of e = p(p+1)/2 + i (0 <= i <= p): position in the packed upper triangle by columns.
+__device__ __forceinline__ void tri_unpack(int64_t e, int& p, int& i)
+{
+    int64_t q = (int64_t)((sqrt(8.0 * (double)e + 1.0) - 1.0) * 0.5);
+    while ((q + 1) * (q + 2) / 2 <= e) ++q;
+    while (q * (q + 1) / 2 > e) --q;
+    p = (int)q;
+    i = (int)(e - q * (q + 1) / 2);
+}
+
+// a is a better pivot than b: larger norm, or the same norm at a smaller current position (Eigen's "first maximum").
+__device__ __forceinline__ bool better(double va, int pa, double vb, int pb) { return va > vb || (va == vb && pa < pb); }
+
+struct Shared {
+    double* xbuf;     // [maxr] pivot column, then the essential part of the reflector
+    double* nu;       // [maxc] m_colNormsUpdated
+    double* nd;       // [maxc] m_colNormsDirect
+    double* hc;       // [maxc] m_hCoeffs
+    int* pos;         // [maxc] current position of original column j
+    int* col_at;      // [maxc] original column at position p
+    double* sval;     // [T] reduction scratch
+    int* spos;        // [T]
+};
+
+// One tile.  tile: r x c column-major input; W: r x c row-major working copy (LDS or global); q: r x r row-major Q
+// (LDS or the output itself).
+template <bool PIVOT>
+__device__ void tile_qr(int r, int c, const double* __restrict__ tile, double* W, double* q, const Shared& sh)
+{
+    const int t = threadIdx.x;
+    for (int e = t; e < r * c; e += T) {
+        const int j = e / r, i = e - j * r;
+        W[(size_t)i * c + j] = tile[e];
+    }
+    for (int j = t; j < c; j += T) { sh.pos[j] = j; sh.col_at[j] = j; }
+    __syncthreads();
+    if (PIVOT) {
+        for (int j = t; j < c; j += T) {
+            double s = 0.0;
+            for (int i = 0; i < r; ++i) { const double v = W[(size_t)i * c + j]; s += v * v; }
+            const double n = sqrt(s);
+            sh.nu[j] = n; sh.nd[j] = n;
+        }
+        __syncthreads();
+    }
+    for (int k = 0; k < c; ++k) {      // size = min(rows, cols) = cols (portrait tiles only)
+        int jb = k;
+        if (PIVOT) {
+            // biggest remaining column norm, first maximum over the CURRENT positions k..c-1
+            double bv = -1.0; int bp = 0x7fffffff;
+            for (int j = t; j < c; j += T) {
+                const int p = sh.pos[j];
+                if (p >= k && better(sh.nu[j], p, bv, bp)) { bv = sh.nu[j]; bp = p; }
+            }
+            sh.sval[t] = bv; sh.spos[t] = bp;
+            __syncthreads();
+            for (int s = T / 2; s > 0; s >>= 1) {
+                if (t < s && better(sh.sval[t + s], sh.spos[t + s], sh.sval[t], sh.spos[t])) {
+                    sh.sval[t] = sh.sval[t + s]; sh.spos[t] = sh.spos[t + s];
+                }
+                __syncthreads();
+            }
+            if (t == 0) {
+                // m_qr.col(k).swap(m_qr.col(biggest)) and the two norm tables: position bookkeeping only
+                const int b = sh.spos[0];
+                const int cb = sh.col_at[b], ck = sh.col_at[k];
+                sh.col_at[k] = cb; sh.col_at[b] = ck; sh.pos[cb] = k; sh.pos[ck] = b;
+            }
+            __syncthreads();
+            jb = sh.col_at[k];
+        }
+        for (int i = k + t; i < r; i += T) sh.xbuf[i] = W[(size_t)i * c + jb];
+        __syncthreads();
+        // makeHouseholder (every thread evaluates the same scalars in the same order)
+        const double c0 = sh.xbuf[k];
+        double tail = 0.0;
+        for (int i = k + 1; i < r; ++i) { const double v = sh.xbuf[i]; tail += v * v; }
+        double tau, beta, denom = 1.0;
+        const bool degen = tail <= DBL_MIN;
+        if (degen) { tau = 0.0; beta = c0; }
+        else {
+            beta = sqrt(c0 * c0 + tail);
+            if (c0 >= 0.0) beta = -beta;
+            denom = c0 - beta;
+            tau = (beta - c0) / beta;
+        }
+        __syncthreads();
+        for (int i = k + 1 + t; i < r; i += T) {
+            const double e = degen ? 0.0 : sh.xbuf[i] / denom;
+            sh.xbuf[i] = e;
+            W[(size_t)i * c + jb] = e;        // packed QR: essential part below the diagonal
+        }
+        if (t == 0) { W[(size_t)k * c + jb] = beta; sh.hc[k] = tau; }
+        __syncthreads();
+        // applyHouseholderOnTheLeft on the remaining columns + norm downdate
+        const int m = r - k;
+        for (int j = t; j < c; j += T) {
+            if (!(PIVOT ? sh.pos[j] > k : j > k)) continue;
+            double* colk = W + (size_t)k * c + j;
+            if (m == 1) *colk *= (1.0 - tau);
+            else if (tau != 0.0) {
+                double tmp = 0.0;
+                for (int i = k + 1; i < r; ++i) tmp += sh.xbuf[i] * W[(size_t)i * c + j];
+                tmp += *colk;
+                *colk -= tau * tmp;
+                for (int i = k + 1; i < r; ++i) W[(size_t)i * c + j] -= (tau * sh.xbuf[i]) * tmp;
+            }
+            if (PIVOT) {
+                const double nuj = sh.nu[j];
+                if (nuj != 0.0) {
+                    double temp = fabs(*colk) / nuj;
+                    temp = (1.0 + temp) * (1.0 - temp);
+                    temp = temp < 0.0 ? 0.0 : temp;
+                    const double ratio = nuj / sh.nd[j];
+                    const double temp2 = temp * (ratio * ratio);
+                    if (temp2 <= SQRT_EPS) {
+                        double s = 0.0;
+                        for (int i = k + 1; i < r; ++i) { const double v = W[(size_t)i * c + j]; s += v * v; }
+                        const double n = sqrt(s);
+                        sh.nd[j] = n; sh.nu[j] = n;
+                    } else sh.nu[j] = nuj * sqrt(temp);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    // HouseholderSequence::evalTo: Q = I, then H_k on the corner Q(k:, k:) for k = c-1 .. 0
+    for (int e = t; e < r * r; e += T) q[e] = (e / r == e % r) ? 1.0 : 0.0;
+    __syncthreads();
+    for (int k = c - 1; k >= 0; --k) {
+        const int jb = sh.col_at[k];
+        const double tau = sh.hc[k];
+        for (int i = k + 1 + t; i < r; i += T) sh.xbuf[i] = W[(size_t)i * c + jb];
+        __syncthreads();
+        const int m = r - k;
+        for (int j = k + t; j < r; j += T) {
+            double* qk = q + (size_t)k * r + j;
+            if (m == 1) *qk *= (1.0 - tau);
+            else if (tau != 0.0) {
+                double tmp = 0.0;
+                for (int i = k + 1; i < r; ++i) tmp += sh.xbuf[i] * q[(size_t)i * r + j];
+                tmp += *qk;
+                *qk -= tau * tmp;
+                for (int i = k + 1; i < r; ++i) q[(size_t)i * r + j] -= (tau * sh.xbuf[i]) * tmp;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace exact
+
+// LDS carve-up: [xbuf maxr][nu maxc][nd maxc][hc maxc][sval T] doubles, [pos maxc][col_at maxc][spos T] ints,
+// then `lds_tile_doubles` doubles for W and Q of tiles that fit.
+__host__ __device__ static size_t exact_fixed_lds_bytes(int maxr, int maxc)
+{
+    size_t b = ((size_t)maxr + 3 * (size_t)maxc + exact::T) * sizeof(double);
+    b += (2 * (size_t)maxc + exact::T) * sizeof(int);
+    return (b + 15) & ~(size_t)15;
+}
+
+// ids/count: the tiles to redo (count == nullptr: all nb.num_tiles tiles, ids == nullptr: 0..num_tiles-1).
+// The list counter of the NEXT factorisation (next_count) is reset by this kernel, so no memset sits on the stream.
+template <bool PIVOT>
+__global__ void __launch_bounds__(exact::T)
+bdqr_exact_kernel(WaveBatch nb, const int32_t* __restrict__ ids, const int32_t* __restrict__ count, int32_t* next_count,
+                  const double* __restrict__ tiles, double* __restrict__ q_vals, double* __restrict__ r_vals,
+                  int32_t* __restrict__ perm, double* __restrict__ hcoeffs, double* __restrict__ workspace,
+                  int64_t ws_stride, int maxr, int maxc, int lds_tile_doubles)
+{
+    using namespace exact;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    Shared sh;
+    double* d = reinterpret_cast<double*>(smem);
+    sh.xbuf = d; d += maxr;
+    sh.nu = d; d += maxc;
+    sh.nd = d; d += maxc;
+    sh.hc = d; d += maxc;
+    sh.sval = d; d += T;
+    int* ip = reinterpret_cast<int*>(d);
+    sh.pos = ip; ip += maxc;
+    sh.col_at = ip; ip += maxc;
+    sh.spos = ip;
+    double* lds_tile = reinterpret_cast<double*>(smem + exact_fixed_lds_bytes(maxr, maxc));
+
+    if (next_count && blockIdx.x == 0 && threadIdx.x == 0) *next_count = 0;
+    const int64_t n = count ? (int64_t)*count : nb.num_tiles;
+    for (int64_t li = blockIdx.x; li < n; li += gridDim.x) {
+        const int64_t t = ids ? (int64_t)ids[li] : li;
+        int r, c, cbase;
+        int64_t toff, qoff, roff;
+        if (nb.t_rows) {
+            r = nb.t_rows[t]; c = nb.t_cols[t];
+            toff = nb.t_off[t]; qoff = nb.q_off[t]; roff = nb.r_off[t]; cbase = nb.c_off[t];
+        } else {
+            r = nb.rows; c = nb.cols;
+            toff = t * (int64_t)r * c; qoff = t * (int64_t)r * r; roff = t * (int64_t)(c * (c + 1) / 2);
+            cbase = (int)(t * c);
+        }
+        const bool in_lds = (int64_t)r * c + (int64_t)r * r <= lds_tile_doubles;
+        double* W = in_lds ? lds_tile : workspace + (size_t)blockIdx.x * ws_stride;
+        double* q = in_lds ? lds_tile + (size_t)r * c : q_vals + qoff;
+        tile_qr<PIVOT>(r, c, tiles + toff, W, q, sh);
+        // outputs: permutation (m_outputPerm_c splice, BlockDiagonalSparseQR.h:519-521), packed upper triangle of R in CSC
+        // order (:475-479), tau, Q rows (:455-471 / :480-492)
+        const int tid = threadIdx.x;
+        for (int p = tid; p < c; p += T) {
+            perm[cbase + p] = cbase + sh.col_at[p];
+            if (hcoeffs) hcoeffs[cbase + p] = sh.hc[p];
+        }
+        const int64_t n_r = (int64_t)c * (c + 1) / 2;
+        for (int64_t e = tid; e < n_r; e += T) {
+            int p, i;
+            tri_unpack(e, p, i);
+            r_vals[roff + e] = W[(size_t)i * c + sh.col_at[p]];
+        }
+        if (in_lds)
+            for (int e = tid; e < r * r; e += T) q_vals[qoff + e] = q[e];
+        __syncthreads();
+    }
+}
+
+hipError_t launch_bdqr_exact(const WaveBatch& nb, const int32_t* ids, const int32_t* count, int32_t* next_count,
+                             const double* tiles, double* q_vals, double* r_vals, int32_t* perm, double* hcoeffs,
+                             double* workspace, int64_t ws_stride, int num_wg, int maxr, int maxc, hipStream_t stream)
+{
+    if (num_wg <= 0) return hipSuccess;
+    const size_t fixed = exact_fixed_lds_bytes(maxr, maxc);
+    // W and Q of a tile in LDS when both fit beside the fixed part in 64 KB (tiles up to ~60 x 60), else global memory
+    const size_t budget = 64 * 1024;
+    int64_t tile_doubles = fixed < budget ? (int64_t)((budget - fixed) / sizeof(double)) : 0;
+    const int64_t want = (int64_t)maxr * maxc + (int64_t)maxr * maxr;
+    if (tile_doubles > want) tile_doubles = want;
+    if (!workspace && want > tile_doubles) return hipErrorInvalidValue;   // (the plan sizes the workspace for its largest tile)
+    const size_t smem = fixed + (size_t)tile_doubles * sizeof(double);
+    const dim3 grid((unsigned)num_wg), block(exact::T);
+    if (smem > 64 * 1024) {    // (tiles with thousands of rows/columns: the fixed part alone passes the default limit)
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&bdqr_exact_kernel<true>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&bdqr_exact_kernel<false>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return e;
+    }
+    if (nb.pivoting)
+        hipLaunchKernelGGL(bdqr_exact_kernel<true>, grid, block, smem, stream, nb, ids, count, next_count, tiles, q_vals, r_vals,
+                           perm, hcoeffs, workspace, ws_stride, maxr, maxc, (int)tile_doubles);
+    else
+        hipLaunchKernelGGL(bdqr_exact_kernel<false>, grid, block, smem, stream, nb, ids, count, next_count, tiles, q_vals, r_vals,
+                           perm, hcoeffs, workspace, ws_stride, maxr, maxc, (int)tile_doubles);
+    return hipGetLastError();
+}
+
+// Whether launch_bdqr_exact needs a global workspace for tiles of up to maxr x maxc.
+bool bdqr_exact_needs_workspace(int maxr, int maxc)
+{
+    const size_t fixed = exact_fixed_lds_bytes(maxr, maxc);
+    const size_t budget = 64 * 1024;
+    const int64_t have = fixed < budget ? (int64_t)((budget - fixed) / sizeof(double)) : 0;
+    return (int64_t)maxr * maxc + (int64_t)maxr * maxr > have;
+}
+
+}  // namespace qrk

@@ -45,21 +45,6 @@
 #ifndef QRK_ABL
 #define QRK_ABL 0
 #endif
-#ifndef QRK_STAGGER
-#define QRK_STAGGER 0          // n > 0: waves in odd slots of their SIMD start 64 n cycles late (de-phases the two waves of a
-                               // SIMD); n = 6, 12, 24 measured: no effect (86.6 - 87.9 us against 87.0)
-#endif
-#ifndef QRK_SETPRIO
-#define QRK_SETPRIO 0          // 1: s_setprio 2 around the head of a step; 2: everything but the trailing update at priority 3.
-                               // Both measured within the noise of the default (86.0 - 87.6 us over three A/B rounds)
-#endif
-#ifndef QRK_EARLY_SCALARS
-#define QRK_EARLY_SCALARS 0    // 1: reflector scalars in the head of the step, from a DPP sum of the lanes' own pivot-column
-                               // entries (no ds_bpermute, rsq/rcp chains beside the broadcast + dots): measured 92.8 vs 89.5 us
-#endif
-#ifndef QRK_TAIL_LOCAL
-#define QRK_TAIL_LOCAL 0       // 1: |x_tail|^2 accumulated by every lane before the dots (rsq/rcp chains under the dot FMAs, no ds_bpermute): measured 90.0 vs 87.4 us, kept off
-#endif
 #ifndef QRK_RB
 #define QRK_RB 4               // steps between refreshes of the LDS image (measured on one box: 4 -> 87.1 us, 3 -> 87.4, 2 -> 91.0; 8 needs 22 KB of LDS per wave)
 #endif
@@ -100,6 +85,13 @@ constexpr int L_POS = L_WBUF + RB * WR;   // [32] int: lane_of_pos
 constexpr int L_HALF = L_POS + WR / 2;    // 1264 doubles = 10112 B per half, 20224 B per wave -> 8 waves per CU
 
 constexpr double SQRT_EPS = 1.4901161193847656e-08;   // sqrt(DBL_EPSILON), Eigen's norm_downdate_threshold
+// Decision margins (see "Decisions and the exact path" below): a squared column norm carried by this kernel and the square of
+// Eigen's m_colNormsUpdated differ by rounding only, at most ~1000 eps normDirect^2 after 32 downdates (each adds
+// <= 2 k eps normDirect^2 through the error of a_kj); decisions closer than MARGIN_M eps normDirect^2 = 2^14 eps normDirect^2
+// are not taken here.  thr_hi = sqrt(eps) normDirect^2 (1 + 2^-12) is kept per lane, so MARGIN_M eps normDirect^2 = MREL thr_hi.
+constexpr double MREL = 0.000244140625;               // 2^-12 = 2^14 eps / sqrt(eps)
+constexpr double THR_HI = SQRT_EPS * (1.0 + MREL);
+constexpr double X0_TINY2 = 8.271806125530277e-25;    // 2^-80: |x0| <= 2^-40 |x| leaves the sign of beta to rounding noise
 
 #define QRK_0_31(M)                                                                              \
     M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9) M(10) M(11) M(12) M(13) M(14) M(15) M(16)  \
@@ -169,9 +161,9 @@ struct LaneState {
     int kstep;       // step at which this column was chosen (= its final position), 64 = not yet
     int rows, cols;  // tile shape of this half (rows/cols beyond are zero padding)
     double nu2;      // m_colNormsUpdated^2
-    double thr_nd2;  // sqrt(eps) * m_colNormsDirect^2
+    double thr_nd2;  // sqrt(eps) (1 + 2^-12) * m_colNormsDirect^2: upper edge of the band around Eigen's recompute threshold
+    unsigned long long flagmask;   // lanes that met a decision inside its error margin: their tile goes to the exact path
     double h[RB];    // entry j of the pivot columns of the last RB steps
-    double tailSq, nb, s, ng;   // QRK_EARLY_SCALARS: |x_tail|^2 and the reflector scalars of the step whose head ran last
 #ifdef QRK_STAMP
     unsigned long long tk[8];
 #endif
@@ -186,50 +178,28 @@ __device__ __forceinline__ double bpermute_f64(int byte_addr, double v)
     return __hiloint2double(hi, lo);
 }
 
-// Sum over each half of the wave (lanes 0..31 / 32..63), the same bits in every lane of the half: four DPP stages inside
-// the rows of 16 lanes (partners add the same two numbers, so both get the same result), then the two rows of a half.
-__device__ __forceinline__ double half32_sum_f64(double v)
-{
-    v += dpp_f64<0xB1>(v);     // quad_perm [1,0,3,2]
-    v += dpp_f64<0x4E>(v);     // quad_perm [2,3,0,1]
-    v += dpp_f64<0x141>(v);    // row_half_mirror
-    v += dpp_f64<0x140>(v);    // row_mirror
-    const auto rl = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(v), (unsigned)__double2loint(v), false, false);
-    const auto rh = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(v), (unsigned)__double2hiint(v), false, false);
-    const double a = __hiloint2double((int)rh[0], (int)rl[0]), b = __hiloint2double((int)rh[1], (int)rl[1]);
-    return (a + b);            // (a, b) = (own row, other row) or the reverse: the sum is the same
-}
-// Entry of lane K of this lane's half.
-template <int K>
-__device__ __forceinline__ double half32_lane(double v, int half)
-{
-    const double lo = readlane_f64(v, K), hi = readlane_f64(v, 32 + K);
-    return half ? hi : lo;
-}
-
-// Rare path of the pivot search: several live columns share the high word of the largest squared
-// norm.  Compare the low words, then apply Eigen's first-maximum rule = smallest CURRENT position
-// among exact ties.  Positions are not tracked in the hot path (the final position of a column is
-// simply the step that chose it); here they are rebuilt by replaying the column transpositions of
-// steps 0..K-1 (ColPivHouseholderQR.h: m_qr.col(k).swap(m_qr.col(biggest_col_index))).
+// Rare path of the pivot search: more than one live column has the high word of its squared norm within one unit of the
+// largest.  Picks the largest (lowest lane among exact ties: any valid choice will do, see below) and checks the decision:
+// a live column within the error margin of the chosen one means that Eigen's recurrence, rounded Eigen's way, may order the
+// two differently (exact ties, which Eigen resolves by the CURRENT column positions of its swapped matrix, always land
+// here) -- the tile is flagged and redone by the exact path (bdqr_exact.hip), which owns the first-maximum rule.
 // Returns a one-hot (per half) pivot flag.
-__device__ __forceinline__ bool resolve_ties(int K, int lane, int kstep, unsigned klo, bool cand)
+__device__ __forceinline__ bool resolve_near(int lane, bool live, double nu2, double thr_hi, int khi, int mh, int hb4,
+                                             unsigned long long& flagmask)
 {
-    const int half = lane >> 5;
+    bool cand = live && khi == mh;
+    const unsigned klo = (unsigned)__double2loint(nu2);
     const unsigned ml = half32_max_u32(cand ? klo : 0u);
     cand = cand && klo == ml;
-    int p = lane & 31;
-#pragma unroll 1
-    for (int k = 0; k < K; ++k) {
-        const unsigned long long m = ballot64(kstep == k);
-        const unsigned mh = half ? (unsigned)(m >> 32) : (unsigned)m;
-        const int l = (mh ? __ffs((int)mh) - 1 : 0) + 32 * half;
-        const int pl = __builtin_amdgcn_ds_bpermute(l * 4, p);
-        if (mh) p = (lane == l) ? k : (p == k ? pl : p);
-    }
-    const int pc = cand ? p : 64;
-    const int pmin = half32_min_i32(pc);
-    return pc == pmin && pc != 64;
+    const unsigned long long pm = ballot64(cand);
+    const unsigned tlo = (unsigned)pm, thi = (unsigned)(pm >> 32);
+    const int lA = tlo ? __builtin_ctz(tlo) : 0, lB = thi ? __builtin_ctz(thi) : 0;
+    const int lbl = (lane >> 5) ? lB : lA;
+    const bool ispiv = cand && (lane & 31) == lbl;
+    const double best = bpermute_f64((lbl << 2) + hb4, nu2), thrb = bpermute_f64((lbl << 2) + hb4, thr_hi);
+    const bool near = live && !ispiv && nu2 >= best - MREL * (thr_hi + thrb);
+    flagmask |= ballot64(near);
+    return ispiv;
 }
 
 // One step of ColPivHouseholderQR::computeInPlace (Eigen/src/QR/ColPivHouseholderQR.h) on both
@@ -237,9 +207,16 @@ __device__ __forceinline__ bool resolve_ties(int K, int lane, int kstep, unsigne
 //
 // Column norms are tracked SQUARED: Eigen's  temp = (1+t)(1-t), t = |a_kj|/normUpd;
 // normUpd *= sqrt(temp)  is  nu2 <- max(nu2 - a_kj^2, 0), and its recompute test
-// temp (normUpd/normDir)^2 <= sqrt(eps)  is  nu2_new <= sqrt(eps) normDir^2: the same quantities
-// without two FP64 divisions and a square root per step; the first maximum is the same column
-// because squaring is monotone.
+// temp (normUpd/normDir)^2 <= sqrt(eps)  is  nu2_new <= sqrt(eps) normDir^2: the same quantities in exact arithmetic,
+// without two FP64 divisions and a square root per step -- but NOT the same roundings.
+//
+// Decisions and the exact path.  Every data-dependent decision of the reference algorithm is taken here only when it is
+// clear of rounding: (1) the pivot: no other live column within MREL (thr_hi_j + thr_hi_b) of the largest squared norm;
+// (2) the LAWN-176 recompute test: the downdated norm not within 2^-12 (relative) of the threshold; (3) Eigen's degenerate
+// reflector test tailSqNorm <= DBL_MIN: never true on a non-empty tail; (4) the sign of beta: |x0| > 2^-40 |x|.  A tile that
+// meets any of them is flagged (st.flagmask) and appended to the redo list at the end; bdqr_exact.hip then recomputes it with
+// Eigen's own operation order and rounding.  On generic data nothing is flagged (a pivot inside its margin has probability
+// ~1e-9 per tile); on sign / indicator / repeated-column data everything is, and the permutation is Eigen's either way.
 //
 // The kernel is bound by the number of VALU instructions a wave issues (two waves per SIMD), so the
 // step is written to keep everything that is uniform per half out of VGPR selects: the pivot lane is
@@ -269,18 +246,20 @@ __device__ __forceinline__ void search_fetch(double* hl /* this half's LDS */, L
         // columns carry a negative norm, see below) ...
         const int khi = __double2hiint(st.nu2);
         const int mh = half32_max_i32_fused(khi);
+        // ... and every lane within one unit of it is a candidate (a unit of the high word is 2^-20 relative: far outside the
+        // error margin, so a single candidate is a clear decision)
         unsigned long long pm;
         if (FULL32) {
-            pm = __builtin_amdgcn_uicmp(khi, mh, 32 /* ICMP_EQ */);   // a live column exists: mh >= 0
-            ispiv = khi == mh;
+            pm = __builtin_amdgcn_sicmp(khi, mh - 1, 39 /* ICMP_SGE */);   // a live column exists: mh >= 0, chosen ones are < -1
+            ispiv = khi >= mh - 1;
         } else {
-            ispiv = st.live && khi == mh;
+            ispiv = st.live && khi >= mh - 1;
             pm = ballot64(ispiv);
         }
         unsigned tlo = (unsigned)pm, thi = (unsigned)(pm >> 32);
         if (!(QRK_ABL & 1) && ((tlo & (tlo - 1u)) | (thi & (thi - 1u))) != 0u) {
-            // ... unless several columns share it
-            ispiv = resolve_ties(K, st.lane, st.kstep, (unsigned)__double2loint(st.nu2), ispiv);
+            // ... unless there are several
+            ispiv = resolve_near(st.lane, st.live, st.nu2, st.thr_nd2, khi, mh, st.hb4, st.flagmask);
             pm = ballot64(ispiv);
             tlo = (unsigned)pm; thi = (unsigned)(pm >> 32);
         }
@@ -311,21 +290,6 @@ __device__ __forceinline__ void search_fetch(double* hl /* this half's LDS */, L
         st.h[K % RB] = xi;
         hl[L_XBUF + j] = xi;
         QRK_STAMP_IN(2);
-#if QRK_EARLY_SCALARS
-        // |x_tail|^2 = sum over the lanes below the diagonal of their own entry squared, and x_k from lane K: neither
-        // needs the broadcast, so the square root / reciprocal chains run beside the publish -> broadcast -> dots leg
-        // of the step (and, with the heads issued one step ahead, under the trailing update of the step before).
-        const double tsq = half32_sum_f64(j > K ? xi * xi : 0.0);
-        const double xk0 = half32_lane<K>(xi, st.half);
-        const double nrm = (QRK_ABL & 8) ? fma(xk0, xk0, tsq) : sqrt_pos(fma(xk0, xk0, tsq));
-        const double nb0 = __hiloint2double((__double2hiint(nrm) & 0x7fffffff) | (__double2hiint(xk0 + 0.0) & (int)0x80000000),
-                                            __double2loint(nrm));
-        const double s0 = nb0 + xk0;
-        st.tailSq = tsq; st.nb = nb0; st.s = s0;
-        st.ng = (QRK_ABL & 8) ? -(nb0 * s0) : -recip(nb0 * s0);
-        // (keep the chains HERE: without a use at this point hipcc sinks them to their consumers in the step)
-        asm volatile("" : "+v"(st.ng), "+v"(st.s), "+v"(st.nb));
-#endif
     }
 }
 
@@ -344,25 +308,6 @@ __device__ __forceinline__ void pair_step(double (&a)[WR], double (&q)[WR], doub
     double x[WR];                    // rows K+1.. of the pivot column (broadcast reads)
 #pragma unroll
     for (int i = K + 1; i < WR; ++i) x[i] = hl[L_XBUF + i];
-#if QRK_TAIL_LOCAL
-    // |x_tail|^2 in every lane (two chains), so that the square-root / reciprocal refinements below -- a long dependent
-    // chain of few instructions -- run under the dot FMAs instead of after them and after a ds_bpermute round trip
-    double tailSq;
-    {
-        double t0 = 0.0, t1 = 0.0;
-#pragma unroll
-        for (int i = K + 1; i < WR; i += 2) {
-            t0 = fma(x[i], x[i], t0);
-            if (i + 1 < WR) t1 = fma(x[i + 1], x[i + 1], t1);
-        }
-        tailSq = t0 + t1;
-    }
-    const double nrm = (QRK_ABL & 8) ? fma(xk, xk, tailSq) : sqrt_pos(fma(xk, xk, tailSq));
-    double nb = __hiloint2double((__double2hiint(nrm) & 0x7fffffff) | (__double2hiint(xk + 0.0) & (int)0x80000000),
-                                 __double2loint(nrm));
-    double s = nb + xk;
-    double ng = (QRK_ABL & 8) ? -(nb * s) : -recip(nb * s);
-#endif
     double dA = 0.0, dQ = 0.0;
     if (QRK_ABL & 32) { dA = xk; dQ = xk; }
     else {
@@ -386,29 +331,26 @@ __device__ __forceinline__ void pair_step(double (&a)[WR], double (&q)[WR], doub
     //                                     c_i <- c_i - gamma x_i (= c_i - tau ess_i tmp),
     // which needs one square root and one reciprocal (of beta*w > 0) per step and no division.
     // Kept here: nb = -beta = copysign(norm, x0), s = -w = nb + x0, ng = -1/(beta w).
-#if QRK_EARLY_SCALARS
-    const double tailSq = st.tailSq;
-    double nb = st.nb, s = st.s, ng = st.ng;
-    (void)xk;
-#elif !QRK_TAIL_LOCAL
     const double tailSq = (QRK_ABL & 2) ? dA : bpermute_f64((lbl << 2) + st.hb4, dA);
-    const double nrm = (QRK_ABL & 8) ? fma(xk, xk, tailSq) : sqrt_pos(fma(xk, xk, tailSq));
+    const double nrm2 = fma(xk, xk, tailSq);
+    const double nrm = (QRK_ABL & 8) ? nrm2 : sqrt_pos(nrm2);
     // Eigen: if (c0 >= 0) beta = -beta; -0.0 counts as >= 0, hence the + 0.0
     double nb = __hiloint2double((__double2hiint(nrm) & 0x7fffffff) | (__double2hiint(xk + 0.0) & (int)0x80000000),
                                  __double2loint(nrm));
     double s = nb + xk;
-#endif
     QRK_STAMP_IN(4);
-#if !QRK_TAIL_LOCAL && !QRK_EARLY_SCALARS
     double ng = (QRK_ABL & 8) ? -(nb * s) : -recip(nb * s);
-#endif
     // Eigen: tailSqNorm <= min() gives tau = 0, beta = x0, H = I.  Rare, so a real branch (the empty
     // asm keeps hipcc from flattening it into selects); s = 0 leaves c_k = x0 in the pivot lane.
     const bool degen = !act || !(tailSq > DBL_MIN);
-    const unsigned long long dm = FULL32 ? __builtin_amdgcn_fcmp(tailSq, DBL_MIN, 13 /* FCMP_ULE */) : ballot64(degen);
+    // (x0^2 <= 2^-80 |x|^2: the sign of beta = -sign(x0) |x| is below the rounding noise of x0)
+    const unsigned long long dm = (FULL32 ? __builtin_amdgcn_fcmp(tailSq, DBL_MIN, 13 /* FCMP_ULE */) : ballot64(degen)) |
+                                  __builtin_amdgcn_fcmp(xk * xk, X0_TINY2 * nrm2, 13 /* FCMP_ULE */);
     bool setdiag = ispiv;
     if (!(QRK_ABL & 4) && __builtin_expect(dm != 0ull, 0)) {
         asm volatile("");
+        // decisions (3) and (4): a degenerate reflector on a non-empty tail, or a first entry too small to fix the sign of beta
+        if (act && K + 1 < (FULL32 ? WR : st.rows) && (degen || xk * xk <= X0_TINY2 * nrm2)) st.flagmask |= ballot64(true);
         if (degen) { ng = 0.0; s = 0.0; setdiag = false; }   // (nrm may be NaN here: rsq(0) = inf)
     }
     if (HC) {
@@ -435,6 +377,8 @@ __device__ __forceinline__ void pair_step(double (&a)[WR], double (&q)[WR], doub
         if (__builtin_expect(nm != 0ull, 0)) {
             // rare: a column norm has to be recomputed from the updated column before the next search
             asm volatile("");
+            // decision (2): inside the band [1 - 2^-12, 1 + 2^-12] around Eigen's threshold the test is rounding noise
+            st.flagmask |= ballot64(st.live && nn <= st.thr_nd2 && nn > st.thr_nd2 * (1.0 - 2.0 * MREL));
 #pragma unroll
             for (int i = K + 1; i < WR; ++i) { if (QRK_ABL & 2048) a[i] = fma(ngA, x[i], a[i]); else fmac2_shared_b(a[i], q[i], ngA, ngQ, x[i]); }
             updated = true;
@@ -442,28 +386,16 @@ __device__ __forceinline__ void pair_step(double (&a)[WR], double (&q)[WR], doub
             double sq = 0.0;
 #pragma unroll
             for (int i = K + 1; i < WR; ++i) sq = fma(a[i], a[i], sq);
-            if (need) { st.nu2 = sq; st.thr_nd2 = sq * SQRT_EPS; }
+            if (need) { st.nu2 = sq; st.thr_nd2 = sq * THR_HI; }
         }
     }
 
     // ---- head of the next step, then the trailing update of this one
-#if QRK_SETPRIO == 1
-    __builtin_amdgcn_s_setprio(2);
-#endif
     if (K + 1 < WR) search_fetch<(K + 1 < WR ? K + 1 : K), FULL32, PIVOT>(hl, st);
-#if QRK_SETPRIO == 1
-    __builtin_amdgcn_s_setprio(0);
-#endif
-#if QRK_SETPRIO == 2
-    __builtin_amdgcn_s_setprio(0);      // only the trailing update runs at low priority
-#endif
     if (!(QRK_ABL & 16) && !updated) {
 #pragma unroll
         for (int i = K + 1; i < WR; ++i) { if (QRK_ABL & 2048) a[i] = fma(ngA, x[i], a[i]); else fmac2_shared_b(a[i], q[i], ngA, ngQ, x[i]); }
     }
-#if QRK_SETPRIO == 2
-    __builtin_amdgcn_s_setprio(3);
-#endif
     QRK_STAMP_IN(6);
 
     // ---- refresh the LDS image of the live columns after every RB-th step
@@ -484,7 +416,7 @@ template <bool FULL32, bool PIVOT, bool HC>
 __global__ void __launch_bounds__(64, 2)
 bdqr_pair_kernel(WaveBatch nb, const double* __restrict__ tiles, double* __restrict__ q_vals,
                  double* __restrict__ r_vals, int32_t* __restrict__ perm,
-                 double* __restrict__ hcoeffs)
+                 double* __restrict__ hcoeffs, int32_t* __restrict__ redo_count, int32_t* __restrict__ redo_ids)
 {
     using namespace pair;
     __shared__ __attribute__((aligned(16))) double lds[2 * L_HALF];
@@ -500,11 +432,13 @@ bdqr_pair_kernel(WaveBatch nb, const double* __restrict__ tiles, double* __restr
         const bool valid = t < nb.num_tiles;
         int r, c, cbase;
         int64_t toff, qoff, roff;
+        int gid = (int)t;     // global tile index (what the redo list holds)
         if (FULL32) {
             r = 32; c = 32;
             toff = t * 1024; qoff = t * 1024; roff = t * 528; cbase = (int)(t * 32);
         } else if (nb.tile_ids) {
             const int gidx = nb.tile_ids[valid ? t : nb.num_tiles - 1];
+            gid = gidx;
             r = nb.t_rows[gidx]; c = nb.t_cols[gidx];
             toff = nb.t_off[gidx]; qoff = nb.q_off[gidx]; roff = nb.r_off[gidx]; cbase = nb.c_off[gidx];
         } else {
@@ -556,6 +490,7 @@ bdqr_pair_kernel(WaveBatch nb, const double* __restrict__ tiles, double* __restr
         st.sh8 = half * 8; st.hb4 = half * 128;
         st.live = FULL32 ? true : j < c;
         st.livemask = FULL32 ? ~0ull : __builtin_amdgcn_ballot_w64(j < c);
+        st.flagmask = 0ull;
 #pragma unroll
         for (int m = 0; m < RB; ++m) st.h[m] = 0.0;
         {
@@ -564,7 +499,7 @@ bdqr_pair_kernel(WaveBatch nb, const double* __restrict__ tiles, double* __restr
 #pragma unroll
             for (int i = 0; i < WR; ++i) s = fma(a[i], a[i], s);
             st.nu2 = s;
-            st.thr_nd2 = s * SQRT_EPS;
+            st.thr_nd2 = s * THR_HI;
         }
         double* hc_tile = (hcoeffs && valid) ? hcoeffs + cbase : nullptr;
         // number of steps = the larger column count of the two tiles
@@ -600,6 +535,9 @@ bdqr_pair_kernel(WaveBatch nb, const double* __restrict__ tiles, double* __restr
             lane_of_pos[st.kstep] = j;
             perm[cbase + st.kstep] = cbase + j;   // m_outputPerm_c.indices()(base_col+j) (:519-521)
         }
+        // a decision inside its error margin: the tile is redone by the exact path (bdqr_exact.hip)
+        if (redo_count && valid && j == 0 && (half ? (unsigned)(st.flagmask >> 32) : (unsigned)st.flagmask) != 0u)
+            redo_ids[atomicAdd(redo_count, 1)] = gid;
         __syncthreads();
         if (FULL32) {
             if (valid) {
@@ -671,7 +609,9 @@ namespace pair {
 // All per-lane addresses derive from an opaque lane id so that none of them is computed (and kept
 // alive) before the factorisation.
 __device__ __forceinline__ void epilogue32(int lane_in, int64_t pi, int64_t num_tiles, int kstep, double* lds,
-                                           double* __restrict__ r_vals, int32_t* __restrict__ perm)
+                                           double* __restrict__ r_vals, int32_t* __restrict__ perm,
+                                           unsigned long long flagmask, int32_t* __restrict__ redo_count,
+                                           int32_t* __restrict__ redo_ids)
 {
     int lane = lane_in;
     asm volatile("" : "+v"(lane));
@@ -686,6 +626,11 @@ __device__ __forceinline__ void epilogue32(int lane_in, int64_t pi, int64_t num_
     int* lane_of_pos = reinterpret_cast<int*>(&hl[L_POS]);
     lane_of_pos[kstep] = j;                            // the column chosen at step k ends at position k
     if (valid) perm[cbase + kstep] = cbase + j;        // m_outputPerm_c.indices()(base_col+j) (:519-521)
+    // a decision inside its error margin: the tile is redone by the exact path (bdqr_exact.hip)
+    if (flagmask != 0ull) {
+        if (redo_count && valid && j == 0 && (half ? (unsigned)(flagmask >> 32) : (unsigned)flagmask) != 0u)
+            redo_ids[atomicAdd(redo_count, 1)] = (int)t;
+    }
     __builtin_amdgcn_wave_barrier();   // one wave per workgroup: LDS is in order, no s_barrier (its fence would wait for the prefetch)
     if (valid) {
         double2* dst = reinterpret_cast<double2*>(r_vals + t * 528);
@@ -736,19 +681,13 @@ __device__ __forceinline__ void store_q_half(int lane_in, int64_t pi, int64_t nu
 template <bool PIVOT, bool HC>
 __global__ void __launch_bounds__(64, 2)
 bdqr_pair32_kernel(int64_t num_tiles, const double* __restrict__ tiles, double* __restrict__ q_vals,
-                   double* __restrict__ r_vals, int32_t* __restrict__ perm, double* __restrict__ hcoeffs)
+                   double* __restrict__ r_vals, int32_t* __restrict__ perm, double* __restrict__ hcoeffs,
+                   int32_t* __restrict__ redo_count, int32_t* __restrict__ redo_ids)
 {
     using namespace pair;
     __shared__ __attribute__((aligned(16))) double lds[2 * L_HALF];
     const int64_t npairs = (num_tiles + 1) / 2;
     double a[WR], q[WR];
-#if QRK_STAGGER
-    {
-        unsigned hwid;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-        if (hwid & 1u) __builtin_amdgcn_s_sleep(QRK_STAGGER);
-    }
-#endif
 
     int64_t pi = blockIdx.x;
     {
@@ -797,6 +736,7 @@ bdqr_pair32_kernel(int64_t num_tiles, const double* __restrict__ tiles, double* 
         st.sh8 = half * 8; st.hb4 = half * 128;
         st.live = true;
         st.livemask = ~0ull;
+        st.flagmask = 0ull;
 #pragma unroll
         for (int m = 0; m < RB; ++m) st.h[m] = 0.0;
         {
@@ -805,7 +745,7 @@ bdqr_pair32_kernel(int64_t num_tiles, const double* __restrict__ tiles, double* 
 #pragma unroll
             for (int i = 0; i < WR; ++i) s = fma(a[i], a[i], s);
             st.nu2 = s;
-            st.thr_nd2 = s * SQRT_EPS;
+            st.thr_nd2 = s * THR_HI;
         }
         double* hc_tile = (HC && hcoeffs && valid) ? hcoeffs + cbase : nullptr;
         QRK_STAMP_AT(1);
@@ -853,7 +793,7 @@ bdqr_pair32_kernel(int64_t num_tiles, const double* __restrict__ tiles, double* 
                 for (int m = 16; m < WR; ++m) a[m] = nsrc[32 * m];
             }
         }
-        epilogue32(threadIdx.x, pi, num_tiles, st.kstep, lds, r_vals, perm);
+        epilogue32(threadIdx.x, pi, num_tiles, st.kstep, lds, r_vals, perm, st.flagmask, redo_count, redo_ids);
         QRK_STAMP_AT(6);
 #ifdef QRK_STAMP
         if (threadIdx.x == 0 && hcoeffs) {
@@ -871,13 +811,13 @@ bdqr_pair32_kernel(int64_t num_tiles, const double* __restrict__ tiles, double* 
 }
 void launch_bdqr_pair(const WaveBatch& nb, bool full32, const double* tiles, double* q_vals,
                       double* r_vals, int32_t* perm, double* hcoeffs, int max_blocks,
-                      hipStream_t stream)
+                      int32_t* redo_count, int32_t* redo_ids, hipStream_t stream)
 {
     if (nb.num_tiles <= 0) return;
     const int64_t npairs = (nb.num_tiles + 1) / 2;
     const dim3 grid((unsigned)npairs), block(64);
 #define QRK_LAUNCH(F, P, H)                                                                        \
-    hipLaunchKernelGGL((bdqr_pair_kernel<F, P, H>), grid, block, 0, stream, nb, tiles, q_vals, r_vals, perm, hcoeffs)
+    hipLaunchKernelGGL((bdqr_pair_kernel<F, P, H>), grid, block, 0, stream, nb, tiles, q_vals, r_vals, perm, hcoeffs, redo_count, redo_ids)
     const bool piv = nb.pivoting != 0, hc = hcoeffs != nullptr;
     if (full32) {
         // persistent: one workgroup per resident wave slot (2 waves per SIMD, 20 KB of LDS each)
@@ -887,7 +827,7 @@ void launch_bdqr_pair(const WaveBatch& nb, bool full32, const double* tiles, dou
         const int64_t nwg = npairs < slots ? npairs : slots;
         const dim3 pgrid((unsigned)nwg);
 #define QRK_LAUNCH32(P, H)                                                                         \
-    hipLaunchKernelGGL((bdqr_pair32_kernel<P, H>), pgrid, block, 0, stream, nb.num_tiles, tiles, q_vals, r_vals, perm, hcoeffs)
+    hipLaunchKernelGGL((bdqr_pair32_kernel<P, H>), pgrid, block, 0, stream, nb.num_tiles, tiles, q_vals, r_vals, perm, hcoeffs, redo_count, redo_ids)
 #if QRK_ABL || defined(QRK_STAMP)
         // diagnostic builds: the bench variant only; QRK_PAIR_PERSIST=0 selects the one-pair-per-workgroup kernel
         if (const char* e = std::getenv("QRK_PAIR_PERSIST")) {

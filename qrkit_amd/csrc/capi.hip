@@ -30,9 +30,9 @@ struct qrk_context_s {
     hipStream_t stream = nullptr;
     int num_cus = 256;
     int pair_wgs_per_cu = 8;       // resident pair-kernel workgroups per CU: 2 waves per SIMD (232 VGPRs, 20 KB LDS each)
-    bool use_pair_kernel = true;   // two tiles per wavefront (bdqr_pair.hip); QRK_KERNEL=wave selects bdqr_wave.hip
-    bool use_split_kernel = false; // uniform 32x32, column pivoting: factorisation and Q formation as two kernels (bdqr_split.hip);
-                                   // an experiment that measured slower than the pair kernel - QRK_SPLIT=1 enables
+    bool force_exact = false;      // QRK_EXACT=1: every tile through the exact-arithmetic path (bdqr_exact.hip): results bit-identical
+                                   // to a scalar evaluation of Eigen's algorithm, ~30x slower; the fast kernels send only the tiles
+                                   // whose decisions are not clear of rounding there
     bool use_small_kernel = true;  // uniform tiles with at most 16 rows: 64/G tiles per wavefront (bdqr_small.hip); QRK_SMALL=0 disables
     // side streams for the size classes of a mixed batch (fork after / join into `stream`), created on first use
     hipStream_t side[3] = {nullptr, nullptr, nullptr};
@@ -74,7 +74,13 @@ struct qrk_bd_plan_s {
     int32_t* d_col_ids = nullptr;
     int64_t n_col = 0;
     double* d_col_workspace = nullptr;   // one part per class
-    double* d_split_ws = nullptr;        // uniform 32x32, two-kernel form: reflector vectors (1024) + scalars (64) per tile
+    // redo list of the exact path: [0], [1] = counters of this / the next factorisation (ping-pong: the exact kernel zeroes the
+    // other one, so no memset sits on the stream), [2..2+B) = global tile ids
+    int32_t* d_redo = nullptr;
+    int redo_parity = 0;
+    double* d_exact_ws = nullptr;        // working copies of tiles too large for the exact kernel's LDS
+    int64_t exact_ws_stride = 0;
+    int exact_num_wg = 0, exact_maxr = 0, exact_maxc = 0;
 };
 
 struct qrk_bb_plan_s {
@@ -178,7 +184,23 @@ qrk_status enqueue_factorize(qrk_bd_plan_s* p, const double* tiles, double* q, d
     qrk_handle h = p->h;
     qrk::WaveBatch nb{};
     nb.pivoting = p->solver == QRK_COLPIV_HOUSEHOLDER ? 1 : 0;
-    const int max_blocks = h->num_cus * 16 * 8;   // several tiles per resident wave slot at most
+    // every tile of the plan, as the exact path addresses them (global tile index)
+    qrk::WaveBatch all = nb;
+    all.num_tiles = p->B; all.rows = p->r; all.cols = p->c;
+    if (!p->uniform) {
+        all.t_rows = p->d_rows; all.t_cols = p->d_cols; all.t_off = p->d_toff;
+        all.q_off = p->d_qoff; all.r_off = p->d_roff; all.c_off = p->d_coff;
+    }
+    if (h->force_exact) {
+        QRK_HIP(h, qrk::launch_bdqr_exact(all, nullptr, nullptr, nullptr, tiles, q, r, perm, hc, p->d_exact_ws, p->exact_ws_stride,
+                                          p->exact_num_wg, p->exact_maxr, p->exact_maxc, h->stream));
+        qrk::launch_bd_q_tail_ones(q, p->nnz_q_tiles, p->nnz_q - p->nnz_q_tiles, h->stream);
+        QRK_HIP(h, hipGetLastError());
+        return QRK_STATUS_OK;
+    }
+    int32_t* const redo_cnt = p->d_redo + p->redo_parity;
+    int32_t* const redo_next = p->d_redo + (p->redo_parity ^ 1);
+    int32_t* const redo_ids = p->d_redo + 2;
     if (p->uniform) {
         nb.num_tiles = p->B; nb.rows = p->r; nb.cols = p->c;
         const bool full32 = p->r == 32 && p->c == 32 &&
@@ -192,19 +214,12 @@ qrk_status enqueue_factorize(qrk_bd_plan_s* p, const double* tiles, double* q, d
             qrk::launch_bdqr_wg(nb, tiles, q, r, perm, hc, p->d_workspace, p->ws_stride, p->num_wg, p->max_dim, h->stream);
         else if (p->max_dim <= 16 && p->r >= p->c && h->use_small_kernel)   // 64/G tiles per wavefront (bdqr_small.hip)
             qrk::launch_bdqr_small(p->B, p->r, p->c, nb.pivoting, tiles, q, r, perm, hc, h->num_cus * 32, h->stream);
-        else if (full32 && h->use_split_kernel && nb.pivoting) {
-            if (!p->d_split_ws) QRK_HIP(h, hipMalloc((void**)&p->d_split_ws, (size_t)p->B * (1024 + 64) * sizeof(double)));
-            qrk::launch_bdqr_split32(p->B, nb.pivoting, tiles, p->d_split_ws, p->d_split_ws + (size_t)p->B * 1024, q, r, perm, hc,
-                                     h->num_cus, h->stream);
-        }
-        else if (h->use_pair_kernel) qrk::launch_bdqr_pair(nb, full32, tiles, q, r, perm, hc, h->num_cus * h->pair_wgs_per_cu, h->stream);
-        else qrk::launch_bdqr_wave(nb, full32, tiles, q, r, perm, hc, max_blocks, h->stream);
+        else qrk::launch_bdqr_pair(nb, full32, tiles, q, r, perm, hc, h->num_cus * h->pair_wgs_per_cu, redo_cnt, redo_ids, h->stream);
     } else {
         nb.num_tiles = p->n_wave; nb.tile_ids = p->d_wave_ids;
         nb.t_rows = p->d_rows; nb.t_cols = p->d_cols; nb.t_off = p->d_toff;
         nb.q_off = p->d_qoff; nb.r_off = p->d_roff; nb.c_off = p->d_coff;
-        if (h->use_pair_kernel) qrk::launch_bdqr_pair(nb, false, tiles, q, r, perm, hc, h->num_cus * h->pair_wgs_per_cu, h->stream);
-        else qrk::launch_bdqr_wave(nb, false, tiles, q, r, perm, hc, max_blocks, h->stream);
+        qrk::launch_bdqr_pair(nb, false, tiles, q, r, perm, hc, h->num_cus * h->pair_wgs_per_cu, redo_cnt, redo_ids, h->stream);
         // the size classes are independent of each other and of the small tiles above: each on its own side stream
         // (forked after what is already queued on the caller's stream, joined back below), so that the tail of one
         // launch overlaps the others
@@ -235,6 +250,11 @@ qrk_status enqueue_factorize(qrk_bd_plan_s* p, const double* tiles, double* q, d
             qrk::launch_bdqr_wg(lb, tiles, q, r, perm, hc, p->d_workspace, p->ws_stride, p->num_wg, p->max_dim, h->stream);
         }
     }
+    // the tiles whose decisions were not clear of rounding, again, with the reference's own operation order (bdqr_exact.hip);
+    // the list is empty on generic data and the workgroups return at once
+    QRK_HIP(h, qrk::launch_bdqr_exact(all, redo_ids, redo_cnt, redo_next, tiles, q, r, perm, hc, p->d_exact_ws, p->exact_ws_stride,
+                                      p->exact_num_wg, p->exact_maxr, p->exact_maxc, h->stream));
+    p->redo_parity ^= 1;
     qrk::launch_bd_q_tail_ones(q, p->nnz_q_tiles, p->nnz_q - p->nnz_q_tiles, h->stream);
     QRK_HIP(h, hipGetLastError());
     return QRK_STATUS_OK;
@@ -267,9 +287,8 @@ qrk_status qrk_create(qrk_handle* out, int device, void* stream)
     if (!h) return fail(nullptr, QRK_STATUS_ALLOC_FAILED, "qrk_create: out of host memory");
     h->device = device;
     h->stream = static_cast<hipStream_t>(stream);
-    if (const char* k = std::getenv("QRK_KERNEL")) h->use_pair_kernel = std::strcmp(k, "wave") != 0;
+    if (const char* k = std::getenv("QRK_EXACT")) h->force_exact = k[0] == '1';
     if (const char* k = std::getenv("QRK_SMALL")) h->use_small_kernel = k[0] != '0';
-    if (const char* k = std::getenv("QRK_SPLIT")) h->use_split_kernel = k[0] == '1';
     if (const char* k = std::getenv("QRK_PAIR_WGS_PER_CU")) { const int v = std::atoi(k); if (v > 0) h->pair_wgs_per_cu = v; }
     if (hipSetDevice(device) != hipSuccess) {
         delete h;
@@ -463,6 +482,26 @@ qrk_status qrk_bd_plan_create(qrk_handle h, const qrk_bd_layout* L, qrk_q_format
             return fail(h, QRK_STATUS_ALLOC_FAILED, "qrk_bd_plan_create: cannot allocate the large-tile workspace");
         }
     }
+    if (!p->landscape && B > 0) {
+        // exact path: redo list + workspace for the tiles that do not fit its LDS
+        int32_t maxr = p->r, maxc = p->c;
+        if (!p->uniform) { maxr = 0; maxc = 0; for (int64_t i = 0; i < B; ++i) { maxr = std::max(maxr, L->rows[i]); maxc = std::max(maxc, L->cols[i]); } }
+        p->exact_maxr = maxr; p->exact_maxc = maxc;
+        int64_t wgs = 2 * (int64_t)h->num_cus;
+        if (qrk::bdqr_exact_needs_workspace(maxr, maxc)) {
+            p->exact_ws_stride = (int64_t)maxr * maxc;
+            const int64_t cap = ((int64_t)1 << 31) / (p->exact_ws_stride * (int64_t)sizeof(double));   // at most 2 GiB of workspace
+            wgs = std::max<int64_t>(1, std::min(wgs, cap));
+        }
+        p->exact_num_wg = (int)std::min<int64_t>(wgs, B);
+        if (hipMalloc((void**)&p->d_redo, (size_t)(B + 2) * sizeof(int32_t)) != hipSuccess ||
+            hipMemsetAsync(p->d_redo, 0, 2 * sizeof(int32_t), h->stream) != hipSuccess ||
+            (p->exact_ws_stride > 0 &&
+             hipMalloc((void**)&p->d_exact_ws, (size_t)p->exact_num_wg * (size_t)p->exact_ws_stride * sizeof(double)) != hipSuccess)) {
+            qrk_bd_plan_destroy(p);
+            return fail(h, QRK_STATUS_ALLOC_FAILED, "qrk_bd_plan_create: cannot allocate the redo list / workspace of the exact path");
+        }
+    }
     if (!p->uniform) {
         std::vector<int32_t> rows(L->rows, L->rows + B), cols(L->cols, L->cols + B);
         qrk_status st;
@@ -488,7 +527,7 @@ qrk_status qrk_bd_plan_destroy(qrk_bd_plan p)
     (void)hipFree(p->d_rows); (void)hipFree(p->d_cols); (void)hipFree(p->d_coff); (void)hipFree(p->d_rowoff);
     (void)hipFree(p->d_toff); (void)hipFree(p->d_qoff); (void)hipFree(p->d_roff); (void)hipFree(p->d_wave_ids);
     (void)hipFree(p->d_wg_ids); (void)hipFree(p->d_workspace);
-    (void)hipFree(p->d_col_ids); (void)hipFree(p->d_col_workspace); (void)hipFree(p->d_split_ws);
+    (void)hipFree(p->d_col_ids); (void)hipFree(p->d_col_workspace); (void)hipFree(p->d_redo); (void)hipFree(p->d_exact_ws);
     delete p;
     return QRK_STATUS_OK;
 }

@@ -42,16 +42,10 @@ struct TileGeom {
 };
 
 // ---- host-side launchers (defined next to their kernels)
-void launch_bdqr_wave(const WaveBatch& nb, bool full32, const double* tiles, double* q_vals,
-                      double* r_vals, int32_t* perm, double* hcoeffs, int max_blocks,
-                      hipStream_t stream);
+// redo_count / redo_ids: list of tiles whose decisions were not clear of rounding (redone by launch_bdqr_exact)
 void launch_bdqr_pair(const WaveBatch& nb, bool full32, const double* tiles, double* q_vals,
                       double* r_vals, int32_t* perm, double* hcoeffs, int max_blocks,
-                      hipStream_t stream);
-// Uniform 32x32 batches in two kernels (bdqr_split.hip): factorisation of A with 10 waves per CU, then Q from the reflectors.
-// vbuf: 1024 doubles per tile, sbuf: 64 doubles per tile (device workspace of the plan).
-void launch_bdqr_split32(int64_t num_tiles, int pivoting, const double* tiles, double* vbuf, double* sbuf, double* q_vals,
-                         double* r_vals, int32_t* perm, double* hcoeffs, int num_cus, hipStream_t stream);
+                      int32_t* redo_count, int32_t* redo_ids, hipStream_t stream);
 // Uniform batches of small tiles (rows <= 16, cols <= rows): 64/G tiles per wavefront (bdqr_small.hip).
 void launch_bdqr_small(int64_t num_tiles, int r, int c, int pivoting, const double* tiles, double* q_vals, double* r_vals,
                        int32_t* perm, double* hcoeffs, int max_blocks, hipStream_t stream);
@@ -66,6 +60,11 @@ constexpr int QRK_COL_W_LDS_MAX = 4352;     // doubles of LDS for A in the LDS-r
 void launch_bdqr_wg(const WaveBatch& nb, const double* tiles, double* q_vals, double* r_vals, int32_t* perm,
                     double* hcoeffs, double* workspace, int64_t ws_stride, int num_wg, int max_dim,
                     hipStream_t stream);
+// The exact-arithmetic path (bdqr_exact.hip): redoes the listed tiles with Eigen's operation order and rounding.
+hipError_t launch_bdqr_exact(const WaveBatch& nb, const int32_t* ids, const int32_t* count, int32_t* next_count,
+                             const double* tiles, double* q_vals, double* r_vals, int32_t* perm, double* hcoeffs,
+                             double* workspace, int64_t ws_stride, int num_wg, int maxr, int maxc, hipStream_t stream);
+bool bdqr_exact_needs_workspace(int maxr, int maxc);
 size_t dense_qr_smem_bytes(int r, int c);
 // Tall dense QR over all CUs (dense_qr_tall.hip): row slabs, one short kernel sequence per reflector.
 size_t dense_tall_workspace_bytes(int r, int c, int num_cus, int* G, int* cpad, int* rows_per);

@@ -217,9 +217,13 @@ class BlockDiagonalSparseQR:
     """
 
     def __init__(self, mat: Optional[SparseBlockDiagonal] = None, blockSolver: int = capi.COLPIV_HOUSEHOLDER,
-                 qFormat: int = capi.FULL_Q, context: Optional[Context] = None, device: int = 0):
+                 qFormat: int = capi.FULL_Q, context: Optional[Context] = None, device: int = 0, hCoeffs: bool = True):
         self._ctx = context or Context(device)
         self._solver, self._qformat = blockSolver, qFormat
+        # hCoeffs=False passes NULL for the optional tau output of qrk_bd_factorize: the reference never reads m_hcoeffs
+        # (BlockDiagonalSparseQR.h:320), the C++ facade and bench.py do not ask for it, and the kernels are instantiated
+        # without the store -- the parity tests run both instantiations
+        self._want_hc = bool(hCoeffs)
         self._plan = C.c_void_p()
         self._layout_key = None
         self.m_isInitialized = False
@@ -273,9 +277,10 @@ class BlockDiagonalSparseQR:
         self._q = torch.empty(max(self._nnz_q, 1), dtype=torch.float64, device=dev)
         self._r = torch.empty(max(self._nnz_r, 1), dtype=torch.float64, device=dev)
         self._perm = torch.empty(max(self._cols, 1), dtype=torch.int32, device=dev)
-        self._hc = torch.empty(max(self._cols, 1), dtype=torch.float64, device=dev)
+        self._hc = torch.empty(max(self._cols, 1), dtype=torch.float64, device=dev) if self._want_hc else None
         capi.check(capi.lib().qrk_bd_factorize(self._plan, tiles.data_ptr(), self._q.data_ptr(), self._r.data_ptr(),
-                                               self._perm.data_ptr(), self._hc.data_ptr(), capi.MEM_DEVICE),
+                                               self._perm.data_ptr(), self._hc.data_ptr() if self._want_hc else None,
+                                               capi.MEM_DEVICE),
                    self._ctx.handle)
         info, rank = C.c_int(), C.c_int64()
         capi.check(capi.lib().qrk_bd_info(self._plan, C.byref(info), C.byref(rank)), self._ctx.handle)
@@ -341,6 +346,7 @@ class BlockDiagonalSparseQR:
         return self._r[:self._nnz_r]
 
     def hCoeffs(self) -> torch.Tensor:
+        assert self._hc is not None, "constructed with hCoeffs=False"
         return self._hc[:self._cols]
 
     def applyQt(self, B):

@@ -26,3 +26,25 @@ def seeded_tiles(seed, lo, hi, n):
 def oracle_factorize(rows, cols, tiles, mat_rows=None, q_format=0, block_solver=0):
     prob = orc.BDProblem(rows, cols, tiles, matRows=mat_rows, q_format=q_format, block_solver=block_solver)
     return prob, prob.factorize()
+
+
+def per_tile_rel(got, want, sizes):
+    """Largest per-tile relative Frobenius error of a packed per-tile array (`sizes[i]` values for tile i):
+    one tile off by 1e-11 among 1000 good ones fails, which a single batch-wide ratio would hide."""
+    got = np.asarray(got, dtype=np.float64).ravel()
+    want = np.asarray(want, dtype=np.float64).ravel()
+    sizes = np.asarray(sizes, dtype=np.int64)
+    assert got.size == want.size == int(sizes.sum()), (got.size, want.size, int(sizes.sum()))
+    ends = np.cumsum(sizes)
+    starts = ends - sizes
+    d2 = np.add.reduceat((got - want) ** 2, starts)[sizes > 0] if got.size else np.zeros(0)
+    w2 = np.add.reduceat(want ** 2, starts)[sizes > 0] if got.size else np.zeros(0)
+    rel = np.sqrt(d2) / np.where(w2 > 0, np.sqrt(w2), 1.0)
+    return float(rel.max()) if rel.size else 0.0
+
+
+def tile_sizes(rows, cols):
+    """(values per tile of Q, of packed R, of tau) for per_tile_rel."""
+    r = np.asarray(rows, dtype=np.int64)
+    c = np.asarray(cols, dtype=np.int64)
+    return r * r, c * (c + 1) // 2, c
