@@ -16,8 +16,8 @@
 //   * Eigen/src/Householder/HouseholderSequence.h  evalTo (Q = I, reflectors applied last to first on the shrinking corner),
 //
 // one IEEE-754 double operation at a time in Eigen's scalar order (sequential sums over the rows, no FMA contraction,
-// correctly rounded division and square root) -- the evaluation order the CPU oracle (oracle/qrk_oracle.c) states, so the
-// results of this path are bit-identical to the oracle's: permutation, tau, R and Q.
+// correctly rounded division and square root): what a scalar build of Eigen without FMA contraction computes.  The results of
+// this path are therefore reproducible bit for bit on any IEEE machine: permutation, tau, R and Q.
 // Call site in the reference: blockSolver.compute(block) / matrixQ() / matrixR() / colsPermutation(),
 // src/QRKit/BlockDiagonalSparseQR.h:437-447,519-521.
 //
