@@ -40,6 +40,7 @@ namespace qrk {
 namespace col {
 
 constexpr double SQRT_EPS = 1.4901161193847656e-08;   // sqrt(DBL_EPSILON), Eigen's norm_downdate_threshold
+using namespace decide;   // decision margins of the fast kernels (qrk_device.h)
 constexpr int W_LDS_DOUBLES = 4352;                   // 34 KB of LDS for A when the tile fits (two workgroups of the fixed layout per CU)
 constexpr int NB = 16;                                // reflectors per block in the formation of Q
 constexpr int MAXR = 256;                             // largest tile dimension of this kernel
@@ -86,7 +87,8 @@ template <int CT, bool BLOCKED, bool DYN>
 __device__ __forceinline__ void factor_tile(double* __restrict__ W, double* smem, int r, int c, int cbase, int pivoting,
                                             const double* __restrict__ src, double* __restrict__ Q,
                                             double* __restrict__ rv, int32_t* __restrict__ perm,
-                                            double* __restrict__ hcoeffs, const int w_lds_dyn, const int max_r_dyn)
+                                            double* __restrict__ hcoeffs, const int w_lds_dyn, const int max_r_dyn,
+                                            int32_t* __restrict__ redo_count, int32_t* __restrict__ redo_ids, int gid)
 {
     // LDS carve-up.  DYN (launches of tiles with at most 64 columns): w_lds doubles for A of the tiles that fit and
     // vectors of max_r rows, the largest tile of the launch - small tiles then leave room for many workgroups per
@@ -105,8 +107,8 @@ __device__ __forceinline__ void factor_tile(double* __restrict__ W, double* smem
     double* cngam = cval + NW;                           // [NW]
     int* cpos = reinterpret_cast<int*>(cngam + NW);      // [NW]
     int* ctid = cpos + NW;                               // [NW]
-    int* flags = ctid + NW;                              // [2] any-need flags (double buffered)
-    int* col_of_pos = flags + 2;                         // [max_r] column chosen at step k
+    int* flags = ctid + NW;                              // [2] any-need flags (double buffered) + [1] redo flag (+ pad)
+    int* col_of_pos = flags + 4;                         // [max_r] column chosen at step k
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ld = c;                                    // A row-major: W(i, j) = W[i * ld + j]
     {
@@ -116,6 +118,7 @@ __device__ __forceinline__ void factor_tile(double* __restrict__ W, double* smem
             W[(int64_t)i * ld + j] = src[(int64_t)j * r + i];
         }
         if (tid < 2) flags[tid] = 0;
+        if (tid == 0) flags[2] = 0;          // some decision of this tile was not clear of rounding
         __syncthreads();
 
         // ================= phase 1: R, reflectors, permutation =================
@@ -124,11 +127,13 @@ __device__ __forceinline__ void factor_tile(double* __restrict__ W, double* smem
         bool live = isA;
         int pos = tid;                       // current position of the column
         double nu2 = -1.0, thr = 0.0;
+        double a2 = 0.0;                     // |A|^2: squared norm of the first pivot column
+        bool unclear = false;
         if (isA) {
             // squared column norms (ColPivHouseholderQR: m_colNormsUpdated^2, sqrt(eps) m_colNormsDirect^2)
             double s = 0.0;
             for (int i = 0; i < r; ++i) { const double v = wc[(int64_t)i * ld]; s = fma(v, v, s); }
-            nu2 = s; thr = s * SQRT_EPS;
+            nu2 = s; thr = s * THR_HI;
         }
 
         if (BLOCKED) {
@@ -160,6 +165,8 @@ __device__ __forceinline__ void factor_tile(double* __restrict__ W, double* smem
 #pragma unroll
                     for (int w = 1; w < NW; ++w) { Cand o{cval[w], cpos[w], ctid[w], 0.0}; if (better(o, bb)) bb = o; }
                     P = bb.tidx; ppos = bb.pos;
+                    if (k == 0) a2 = bb.val;
+                    if (live && tid != P && near_best(nu2, thr, bb.val, a2)) unclear = true;
                     if (isA) { if (tid == P) pos = k; else if (pos == k) pos = ppos; }
                 }
                 if (tid == P) {
@@ -185,6 +192,8 @@ __device__ __forceinline__ void factor_tile(double* __restrict__ W, double* smem
                 for (int w = 0; w < NW; ++w) tsq += red[w];
                 const double xk = xv[k];
                 double beta, tau, inv_s;
+                if (k == 0 && !pivoting) a2 = fma(xk, xk, tsq);
+                if (unclear_reflector(xk, tsq, k + 1 < r, pivoting != 0, a2)) unclear = true;
                 if (!(tsq > DBL_MIN)) { beta = xk; tau = 0.0; inv_s = 0.0; }     // makeHouseholder: H = I
                 else {
                     const double nrm = sqrt(fma(xk, xk, tsq));
@@ -239,6 +248,7 @@ __device__ __forceinline__ void factor_tile(double* __restrict__ W, double* smem
                         const double nn = fma(-an, an, nu2);
                         nu2 = nn;
                         if (nn <= thr) {
+                            if (nn > thr * (1.0 - 2.0 * MREL)) unclear = true;     // (2) inside the band around Eigen's threshold
                             double s2 = 0.0;
                             for (int i = k + 1; i < r; ++i) {
                                 double a = wc[(int64_t)i * ld];
@@ -246,7 +256,7 @@ __device__ __forceinline__ void factor_tile(double* __restrict__ W, double* smem
                                 for (int l = 0; l < NBP; ++l) if (l <= j) a = fma(-vp[(i - k0) * NBP + l], F[l], a);
                                 s2 = fma(a, a, s2);
                             }
-                            nu2 = s2; thr = s2 * SQRT_EPS;
+                            nu2 = s2; thr = s2 * THR_HI;
                         }
                     }
                 }
@@ -289,6 +299,8 @@ __device__ __forceinline__ void factor_tile(double* __restrict__ W, double* smem
                 for (int w = 1; w < NW; ++w) { Cand o{cval[w], cpos[w], ctid[w], 0.0}; if (better(o, b)) b = o; }
                 P = b.tidx;
                 const int ppos = b.pos;      // old position of the pivot column
+                a2 = b.val;
+                if (live && tid != P && near_best(nu2, thr, b.val, a2)) unclear = true;
                 if (isA) { if (tid == P) pos = 0; else if (pos == 0) pos = ppos; }
             } else {
                 P = 0;
@@ -312,6 +324,10 @@ __device__ __forceinline__ void factor_tile(double* __restrict__ W, double* smem
             const double xk = xc[k];
             double nb_, s, ng;
             const bool degen = !(tsq > DBL_MIN);
+            if (isA) {           // (every column thread accumulates the same |x_tail|^2)
+                if (k == 0 && !pivoting) a2 = fma(xk, xk, tsq);
+                if (unclear_reflector(xk, tsq, k + 1 < r, pivoting != 0, a2)) unclear = true;
+            }
             if (degen) { nb_ = -xk; s = 0.0; ng = 0.0; }
             else {
                 const double nrm = sqrt(fma(xk, xk, tsq));
@@ -342,6 +358,7 @@ __device__ __forceinline__ void factor_tile(double* __restrict__ W, double* smem
                     const double nn = fma(-an, an, nu2);
                     nu2 = nn;
                     need = nn <= thr;
+                    if (need && nn > thr * (1.0 - 2.0 * MREL)) unclear = true;     // (2) inside the band around Eigen's threshold
                 }
                 if (need) flags[k & 1] = 1;
                 Cand cd{live ? nu2 : -1.0, pos, tid, ngam};
@@ -361,6 +378,7 @@ __device__ __forceinline__ void factor_tile(double* __restrict__ W, double* smem
 #pragma unroll
                     for (int w = 1; w < NW; ++w) { Cand o{cval[w], cpos[w], ctid[w], cngam[w]}; if (better(o, b)) b = o; }
                     Pn = b.tidx; ppos = b.pos; ngP = b.ngam;
+                    if (live && tid != Pn && near_best(nu2, thr, b.val, a2)) unclear = true;
                 } else {
                     Pn = k + 1;
                     if (tid == Pn) cngam[0] = ngam;   // -gamma of column k+1 is only known to its thread
@@ -417,7 +435,7 @@ __device__ __forceinline__ void factor_tile(double* __restrict__ W, double* smem
                         s2 = fma(w0, w0, s2);
                     }
                 }
-                if (need) { nu2 = s2; thr = s2 * SQRT_EPS; }
+                if (need) { nu2 = s2; thr = s2 * THR_HI; }
                 __syncthreads();
                 Cand cd{live ? nu2 : -1.0, pos, tid, 0.0};
                 cd = wave_best(cd);
@@ -427,6 +445,7 @@ __device__ __forceinline__ void factor_tile(double* __restrict__ W, double* smem
 #pragma unroll
                 for (int w = 1; w < NW; ++w) { Cand o{cval[w], cpos[w], ctid[w], 0.0}; if (better(o, b)) b = o; }
                 Pn = b.tidx; ppos = b.pos;
+                if (live && tid != Pn && near_best(nu2, thr, b.val, a2)) unclear = true;
                 for (int i = k + 1 + tid; i < r; i += CT) xn[i] = W[(int64_t)i * ld + Pn];
                 __syncthreads();
                 d = 0.0; tsq = 0.0;
@@ -444,6 +463,10 @@ __device__ __forceinline__ void factor_tile(double* __restrict__ W, double* smem
         __syncthreads();
 
         }
+        // ---- a decision inside its error margin: the tile is redone by the exact path
+        if (unclear) flags[2] = 1;
+        __syncthreads();
+        if (tid == 0 && flags[2] != 0 && redo_count) redo_ids[atomicAdd(redo_count, 1)] = gid;
         // ---- R (packed upper triangle by columns = CSC value order of m_R) and the permutation splice:
         // row i of R is row i of W; the column at position p is col_of_pos[p].
         for (int p = tid; p < c; p += CT) perm[cbase + p] = cbase + col_of_pos[p];   // m_outputPerm_c.indices() (:519-521)
@@ -574,7 +597,8 @@ template <int CT, bool BIG>
 __global__ void __launch_bounds__(CT) __attribute__((amdgpu_waves_per_eu(BIG ? 2 : 3)))
 bdqr_col_kernel(WaveBatch nb, const double* __restrict__ tiles, double* __restrict__ q_vals,
                 double* __restrict__ r_vals, int32_t* __restrict__ perm, double* __restrict__ hcoeffs,
-                double* __restrict__ workspace, int64_t ws_stride, int w_lds, int max_r)
+                double* __restrict__ workspace, int64_t ws_stride, int w_lds, int max_r,
+                int32_t* __restrict__ redo_count, int32_t* __restrict__ redo_ids)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     for (int64_t t = blockIdx.x; t < nb.num_tiles; t += gridDim.x) {
@@ -592,10 +616,11 @@ bdqr_col_kernel(WaveBatch nb, const double* __restrict__ tiles, double* __restri
         constexpr bool DYN = !BIG;
         if (r * c <= (DYN ? w_lds : col::W_LDS_DOUBLES))
             factor_tile<CT, false, DYN>(smem, smem, r, c, cbase, nb.pivoting, tiles + toff, q_vals + qoff, r_vals + roff, perm, hcoeffs,
-                                        w_lds, max_r);
+                                        w_lds, max_r, redo_count, redo_ids, gidx);
         else
             factor_tile<CT, QRK_COL_BLOCKED != 0, DYN>(workspace + (int64_t)blockIdx.x * ws_stride, smem, r, c, cbase, nb.pivoting,
-                                                       tiles + toff, q_vals + qoff, r_vals + roff, perm, hcoeffs, w_lds, max_r);
+                                                       tiles + toff, q_vals + qoff, r_vals + roff, perm, hcoeffs, w_lds, max_r,
+                                                       redo_count, redo_ids, gidx);
     }
 }
 
@@ -606,7 +631,7 @@ size_t bdqr_col_smem_bytes(int threads, int w_lds, int max_r)
     const int nw = threads / 64;
     if (bdqr_col_big(max_r)) { w_lds = col::W_LDS_DOUBLES; max_r = col::MAXR; }   // fixed layout (see bdqr_col_kernel)
     return (size_t)(w_lds + max_r * (col::NB + 1) + 3 * max_r + 2 * col::NB * col::NB + 2 * nw) * sizeof(double) +
-           (size_t)(2 * nw + 2 + max_r) * sizeof(int) + 16;
+           (size_t)(2 * nw + 4 + max_r) * sizeof(int) + 16;
 }
 
 bool bdqr_col_big(int max_rows);
@@ -643,7 +668,7 @@ int bdqr_col_wgs_per_cu(int max_cols, int w_lds, int max_r)
 
 hipError_t launch_bdqr_col(const WaveBatch& nb, const double* tiles, double* q_vals, double* r_vals, int32_t* perm,
                            double* hcoeffs, double* workspace, int64_t ws_stride, int num_wg, int max_rows,
-                           int max_cols, int w_lds, hipStream_t stream)
+                           int max_cols, int w_lds, int32_t* redo_count, int32_t* redo_ids, hipStream_t stream)
 {
     if (nb.num_tiles <= 0) return hipSuccess;
     if (max_rows > col::MAXR || max_cols > max_rows || w_lds > col::W_LDS_DOUBLES) return hipErrorInvalidValue;
@@ -656,7 +681,7 @@ hipError_t launch_bdqr_col(const WaveBatch& nb, const double* tiles, double* q_v
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);          \
         if (e != hipSuccess) return e;                                                                      \
         hipLaunchKernelGGL((bdqr_col_kernel<T, G>), dim3((unsigned)want), dim3(T), smem, stream, nb, tiles, q_vals, \
-                           r_vals, perm, hcoeffs, workspace, ws_stride, w_lds, max_rows);                   \
+                           r_vals, perm, hcoeffs, workspace, ws_stride, w_lds, max_rows, redo_count, redo_ids); \
     } while (0)
     if (bdqr_col_big(max_rows)) QRK_COL_LAUNCH(256, true);      // (more than 160 rows >= cols: 256 threads unless the tiles are narrow)
     else if (threads == 64) QRK_COL_LAUNCH(64, false);

@@ -91,7 +91,13 @@ constexpr double SQRT_EPS = 1.4901161193847656e-08;   // sqrt(DBL_EPSILON), Eige
 // are not taken here.  thr_hi = sqrt(eps) normDirect^2 (1 + 2^-12) is kept per lane, so MARGIN_M eps normDirect^2 = MREL thr_hi.
 constexpr double MREL = 0.000244140625;               // 2^-12 = 2^14 eps / sqrt(eps)
 constexpr double THR_HI = SQRT_EPS * (1.0 + MREL);
-constexpr double X0_TINY2 = 8.271806125530277e-25;    // 2^-80: |x0| <= 2^-40 |x| leaves the sign of beta to rounding noise
+// The entries of a column carry an absolute error of ~k eps |A| (|A| = the largest column norm of the tile = the first pivot),
+// whatever the column has shrunk to.  So (4) an |x0| below 2^9 eps |A| leaves the sign of beta to rounding noise, (5) a pivot
+// column below 2^-20 |A| makes every later decision noise relative to what is left, and the squared norms of two candidate
+// columns are only known to 2^10 eps |A| (|c_b| + |c_j|).  The scale is kept per lane as ONE register: the high word of
+// 2^-40 |A|^2 (st.scale_hi); comparisons against it are integer comparisons of high words (2^-20 relative resolution).
+constexpr int SCALE_SHIFT = 40 << 20;                 // 2^-40 in the exponent field of a high word
+constexpr int X0_SHIFT = 46 << 20;                    // x0^2 <= 2^-86 |A|^2 = (2^9 eps |A|)^2
 
 #define QRK_0_31(M)                                                                              \
     M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9) M(10) M(11) M(12) M(13) M(14) M(15) M(16)  \
@@ -163,6 +169,7 @@ struct LaneState {
     double nu2;      // m_colNormsUpdated^2
     double thr_nd2;  // sqrt(eps) (1 + 2^-12) * m_colNormsDirect^2: upper edge of the band around Eigen's recompute threshold
     unsigned long long flagmask;   // lanes that met a decision inside its error margin: their tile goes to the exact path
+    int scale_hi;    // high word of 2^-40 |A|^2, |A|^2 = squared norm of the first pivot column of this half's tile
     double h[RB];    // entry j of the pivot columns of the last RB steps
 #ifdef QRK_STAMP
     unsigned long long tk[8];
@@ -185,7 +192,7 @@ __device__ __forceinline__ double bpermute_f64(int byte_addr, double v)
 // here) -- the tile is flagged and redone by the exact path (bdqr_exact.hip), which owns the first-maximum rule.
 // Returns a one-hot (per half) pivot flag.
 __device__ __forceinline__ bool resolve_near(int lane, bool live, double nu2, double thr_hi, int khi, int mh, int hb4,
-                                             unsigned long long& flagmask)
+                                             int scale_hi, bool have_scale, unsigned long long& flagmask)
 {
     bool cand = live && khi == mh;
     const unsigned klo = (unsigned)__double2loint(nu2);
@@ -197,7 +204,14 @@ __device__ __forceinline__ bool resolve_near(int lane, bool live, double nu2, do
     const int lbl = (lane >> 5) ? lB : lA;
     const bool ispiv = cand && (lane & 31) == lbl;
     const double best = bpermute_f64((lbl << 2) + hb4, nu2), thrb = bpermute_f64((lbl << 2) + hb4, thr_hi);
-    const bool near = live && !ispiv && nu2 >= best - MREL * (thr_hi + thrb);
+    // margin: the downdate chain (MREL (thr_j + thr_b) = 2^14 eps (normDirect_j^2 + normDirect_b^2)) plus the absolute error of
+    // the column entries, 2^10 eps |A| (|c_b| + |c_j|) <= 2^11 eps sqrt(|A|^2 best)
+    double margin = MREL * (thr_hi + thrb);
+    if (have_scale) {
+        const double a2 = __hiloint2double(scale_hi + SCALE_SHIFT, 0);      // ~|A|^2
+        margin += 4.547473508864641e-13 /* 2^-41 */ * __builtin_sqrt(a2 * (best > 0.0 ? best : 0.0));
+    }
+    const bool near = live && !ispiv && nu2 >= best - margin;
     flagmask |= ballot64(near);
     return ispiv;
 }
@@ -259,7 +273,7 @@ __device__ __forceinline__ void search_fetch(double* hl /* this half's LDS */, L
         unsigned tlo = (unsigned)pm, thi = (unsigned)(pm >> 32);
         if (!(QRK_ABL & 1) && ((tlo & (tlo - 1u)) | (thi & (thi - 1u))) != 0u) {
             // ... unless there are several
-            ispiv = resolve_near(st.lane, st.live, st.nu2, st.thr_nd2, khi, mh, st.hb4, st.flagmask);
+            ispiv = resolve_near(st.lane, st.live, st.nu2, st.thr_nd2, khi, mh, st.hb4, st.scale_hi, K > 0, st.flagmask);
             pm = ballot64(ispiv);
             tlo = (unsigned)pm; thi = (unsigned)(pm >> 32);
         }
@@ -343,14 +357,19 @@ __device__ __forceinline__ void pair_step(double (&a)[WR], double (&q)[WR], doub
     // Eigen: tailSqNorm <= min() gives tau = 0, beta = x0, H = I.  Rare, so a real branch (the empty
     // asm keeps hipcc from flattening it into selects); s = 0 leaves c_k = x0 in the pivot lane.
     const bool degen = !act || !(tailSq > DBL_MIN);
-    // (x0^2 <= 2^-80 |x|^2: the sign of beta = -sign(x0) |x| is below the rounding noise of x0)
+    // decisions (4) and (5) as one integer test against the scale of the tile: x0^2 <= 2^-86 |A|^2 or |x|^2 <= 2^-40 |A|^2
+    if (K == 0) st.scale_hi = __double2hiint(nrm2) - SCALE_SHIFT;
+    const int h_x0 = __double2hiint(xk * xk) + X0_SHIFT, h_x = __double2hiint(nrm2);
+    const int h_min = h_x0 < h_x ? h_x0 : h_x;
     const unsigned long long dm = (FULL32 ? __builtin_amdgcn_fcmp(tailSq, DBL_MIN, 13 /* FCMP_ULE */) : ballot64(degen)) |
-                                  __builtin_amdgcn_fcmp(xk * xk, X0_TINY2 * nrm2, 13 /* FCMP_ULE */);
+                                  __builtin_amdgcn_sicmp(h_min, st.scale_hi, 41 /* ICMP_SLE */);
     bool setdiag = ispiv;
     if (!(QRK_ABL & 4) && __builtin_expect(dm != 0ull, 0)) {
         asm volatile("");
-        // decisions (3) and (4): a degenerate reflector on a non-empty tail, or a first entry too small to fix the sign of beta
-        if (act && K + 1 < (FULL32 ? WR : st.rows) && (degen || xk * xk <= X0_TINY2 * nrm2)) st.flagmask |= ballot64(true);
+        // (3) a degenerate reflector on a non-empty tail, (4) a first entry too small to fix the sign of beta (non-empty tail),
+        // (5) a pivot column at the noise level of the tile
+        const bool tail = K + 1 < (FULL32 ? WR : st.rows);
+        if (act && ((tail && (degen || h_x0 <= st.scale_hi)) || (PIVOT && h_x <= st.scale_hi))) st.flagmask |= ballot64(true);
         if (degen) { ng = 0.0; s = 0.0; setdiag = false; }   // (nrm may be NaN here: rsq(0) = inf)
     }
     if (HC) {
@@ -490,7 +509,7 @@ bdqr_pair_kernel(WaveBatch nb, const double* __restrict__ tiles, double* __restr
         st.sh8 = half * 8; st.hb4 = half * 128;
         st.live = FULL32 ? true : j < c;
         st.livemask = FULL32 ? ~0ull : __builtin_amdgcn_ballot_w64(j < c);
-        st.flagmask = 0ull;
+        st.flagmask = 0ull; st.scale_hi = 0;
 #pragma unroll
         for (int m = 0; m < RB; ++m) st.h[m] = 0.0;
         {
@@ -736,7 +755,7 @@ bdqr_pair32_kernel(int64_t num_tiles, const double* __restrict__ tiles, double* 
         st.sh8 = half * 8; st.hb4 = half * 128;
         st.live = true;
         st.livemask = ~0ull;
-        st.flagmask = 0ull;
+        st.flagmask = 0ull; st.scale_hi = 0;
 #pragma unroll
         for (int m = 0; m < RB; ++m) st.h[m] = 0.0;
         {

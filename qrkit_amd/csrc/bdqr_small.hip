@@ -16,6 +16,9 @@
 // the pair kernel's (squared column norms with the LAWN-176 downdate and recompute rule, first maximum = smallest
 // CURRENT position among exact ties, un-normalised reflector with one rsq and one rcp per step, Eigen's degenerate case).
 // Column positions are tracked explicitly here (one integer per lane), so ties need no replay.
+// Like the pair kernel, it takes a data-dependent decision only when the decision is clear of rounding (bdqr_pair.hip,
+// "Decisions and the exact path": pivot margin, recompute band, degenerate reflector, sign of beta, pivot at the noise level)
+// and otherwise appends the tile to the redo list of the exact path (bdqr_exact.hip).
 //
 // I/O is staged through LDS per workgroup of 4 waves: the 4 * 64/G tiles of a workgroup are one contiguous run of the
 // tile array, of q_vals (row-major Q_i = CSR order of m_Q, :455-492) and of r_vals (packed upper triangle by columns =
@@ -36,6 +39,11 @@ namespace qrk {
 namespace small {
 
 constexpr double SQRT_EPS = 1.4901161193847656e-08;   // sqrt(DBL_EPSILON), Eigen's norm_downdate_threshold
+// decision margins: the same constants as bdqr_pair.hip
+constexpr double MREL = 0.000244140625;               // 2^-12 = 2^14 eps / sqrt(eps)
+constexpr double THR_HI = SQRT_EPS * (1.0 + MREL);
+constexpr int SCALE_SHIFT = 40 << 20;
+constexpr int X0_SHIFT = 46 << 20;
 
 // sqrt(x) for a positive normal x: v_rsq_f64 seed, one Goldschmidt iteration and one residual correction (<= 1 ulp)
 __device__ __forceinline__ double sqrt_pos(double x)
@@ -105,7 +113,8 @@ __device__ __forceinline__ double bperm_f64(int byte_addr, double v)
 template <int G, bool PIVOT>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(G == 16 ? QRK_SMALL_WAVES16 : QRK_SMALL_WAVES8)))
 bdqr_small_kernel(int64_t num_tiles, int r, int c, const double* __restrict__ tiles, double* __restrict__ q_vals,
-                  double* __restrict__ r_vals, int32_t* __restrict__ perm, double* __restrict__ hcoeffs)
+                  double* __restrict__ r_vals, int32_t* __restrict__ perm, double* __restrict__ hcoeffs,
+                  int32_t* __restrict__ redo_count, int32_t* __restrict__ redo_ids)
 {
     using namespace small;
     constexpr int TW = 256 / G;                 // tiles per workgroup
@@ -137,13 +146,15 @@ bdqr_small_kernel(int64_t num_tiles, int r, int c, const double* __restrict__ ti
         bool live = j < c;
         int pos = j;                    // current position of this column (Eigen swaps columns; here only the index moves)
         int kstep = 2 * G;              // step at which this column was chosen = its final position
-        double nu2, thr_nd2;            // m_colNormsUpdated^2 and sqrt(eps) * m_colNormsDirect^2
+        double nu2, thr_nd2;            // m_colNormsUpdated^2 and sqrt(eps) (1 + 2^-12) * m_colNormsDirect^2
+        bool flag = false;              // a decision of this lane's tile was not clear of rounding
+        int scale_hi = 0;               // high word of 2^-40 |A|^2 (|A|^2 = squared norm of the first pivot column)
         {
             double s = 0.0;
 #pragma unroll
             for (int i = 0; i < G; ++i) s = fma(a[i], a[i], s);
             nu2 = s;
-            thr_nd2 = s * SQRT_EPS;
+            thr_nd2 = s * THR_HI;
         }
 
 #pragma unroll
@@ -161,6 +172,18 @@ bdqr_small_kernel(int64_t num_tiles, int r, int c, const double* __restrict__ ti
                     const unsigned long long bm = __builtin_amdgcn_ballot_w64(ispiv);
                     const unsigned gm = (unsigned)(bm >> (lane & ~(G - 1))) & ((1u << G) - 1u);
                     pl = gm ? __builtin_ctz(gm) : 0;
+                    // decision (1): candidates = live columns whose high word is within one unit of the maximum; more than one
+                    // in some group of the wave (rare) -> check the margin there
+                    const bool cand2 = live && __double2hiint(key) >= __double2hiint(gmax) - 1;
+                    const unsigned long long bm2 = __builtin_amdgcn_ballot_w64(cand2);
+                    const unsigned gm2 = (unsigned)(bm2 >> (lane & ~(G - 1))) & ((1u << G) - 1u);
+                    if (__builtin_amdgcn_ballot_w64((gm2 & (gm2 - 1u)) != 0u) != 0ull) {
+                        const double thrb = bperm_f64(gaddr + (pl << 2), thr_nd2);
+                        double margin = MREL * (thr_nd2 + thrb);
+                        if (K > 0) margin += 4.547473508864641e-13 /* 2^-41 */ *
+                                             __builtin_sqrt(__hiloint2double(scale_hi + SCALE_SHIFT, 0) * (gmax > 0.0 ? gmax : 0.0));
+                        flag = flag || (live && !ispiv && nu2 >= gmax - margin);
+                    }
                     // the column at position K and the chosen one trade places (m_qr.col(k).swap(m_qr.col(biggest)))
                     if (ispiv) pos = K; else if (pos == K) pos = pmin;
                 } else {
@@ -192,6 +215,16 @@ bdqr_small_kernel(int64_t num_tiles, int r, int c, const double* __restrict__ ti
                 double s = nb + xk;
                 double ng = -recip(nb * s);
                 bool setdiag = ispiv;
+                {
+                    // decisions (3), (4), (5) (bdqr_pair.hip): degenerate reflector on a non-empty tail, first entry too small
+                    // to fix the sign of beta, pivot column at the noise level of the tile
+                    const double nrm2 = fma(xk, xk, tailSq);
+                    if (K == 0) scale_hi = __double2hiint(nrm2) - SCALE_SHIFT;
+                    const bool tail = K + 1 < r;
+                    const bool tiny_x0 = __double2hiint(xk * xk) + X0_SHIFT <= scale_hi;
+                    const bool tiny_x = PIVOT && __double2hiint(nrm2) <= scale_hi;
+                    flag = flag || (tail && (!(tailSq > DBL_MIN) || tiny_x0)) || tiny_x;
+                }
                 if (!(tailSq > DBL_MIN)) { ng = 0.0; s = 0.0; setdiag = false; }   // tau = 0, beta = x0, H = I
                 if (hcoeffs && ispiv && valid) hcoeffs[(t0 + tl) * c + K] = -(s * s) * ng;   // tau = w^2/(beta w)
                 const double ngA = fma(s, a[K], dA) * ng;
@@ -210,16 +243,23 @@ bdqr_small_kernel(int64_t num_tiles, int r, int c, const double* __restrict__ ti
                     const double nn = fma(-an, an, nu2);
                     nu2 = nn;
                     if (live && nn <= thr_nd2) {
+                        flag = flag || nn > thr_nd2 * (1.0 - 2.0 * MREL);   // decision (2): inside the band around the threshold
                         double sq = 0.0;
 #pragma unroll
                         for (int i = K + 1; i < G; ++i) sq = fma(a[i], a[i], sq);
                         nu2 = sq;
-                        thr_nd2 = sq * SQRT_EPS;
+                        thr_nd2 = sq * THR_HI;
                     }
                 }
             }
         }
 
+        // ---- a decision inside its error margin: the tile is redone by the exact path
+        {
+            const unsigned long long fm = __builtin_amdgcn_ballot_w64(flag && valid);
+            const unsigned gf = (unsigned)(fm >> (lane & ~(G - 1))) & ((1u << G) - 1u);
+            if (redo_count && gf != 0u && j == 0) redo_ids[atomicAdd(redo_count, 1)] = (int32_t)(t0 + tl);
+        }
         // ---- R (packed upper triangle by columns, in final column order) and the permutation
         if (valid && j < c) {
 #pragma unroll
@@ -250,7 +290,7 @@ bdqr_small_kernel(int64_t num_tiles, int r, int c, const double* __restrict__ ti
 
 // rows <= 16, cols <= rows, uniform batch.
 void launch_bdqr_small(int64_t num_tiles, int r, int c, int pivoting, const double* tiles, double* q_vals, double* r_vals,
-                       int32_t* perm, double* hcoeffs, int max_blocks, hipStream_t stream)
+                       int32_t* perm, double* hcoeffs, int max_blocks, int32_t* redo_count, int32_t* redo_ids, hipStream_t stream)
 {
     if (num_tiles <= 0) return;
     const int G = r <= 4 ? 4 : (r <= 8 ? 8 : 16);
@@ -259,7 +299,7 @@ void launch_bdqr_small(int64_t num_tiles, int r, int c, int pivoting, const doub
     if (max_blocks > 0 && nwg > max_blocks) nwg = max_blocks;
     const dim3 grid((unsigned)nwg), block(256);
 #define QRK_SMALL(GG, P) \
-    hipLaunchKernelGGL((bdqr_small_kernel<GG, P>), grid, block, 0, stream, num_tiles, r, c, tiles, q_vals, r_vals, perm, hcoeffs)
+    hipLaunchKernelGGL((bdqr_small_kernel<GG, P>), grid, block, 0, stream, num_tiles, r, c, tiles, q_vals, r_vals, perm, hcoeffs, redo_count, redo_ids)
     if (pivoting) {
         if (G == 4) QRK_SMALL(4, true); else if (G == 8) QRK_SMALL(8, true); else QRK_SMALL(16, true);
     } else {

@@ -50,15 +50,18 @@ __device__ __forceinline__ double block_sum(double v, double* red)
 __global__ void __launch_bounds__(WG_THREADS)
 bdqr_wg_kernel(WaveBatch nb, const double* __restrict__ tiles, double* __restrict__ q_vals,
                double* __restrict__ r_vals, int32_t* __restrict__ perm, double* __restrict__ hcoeffs,
-               double* __restrict__ workspace, int64_t ws_stride, int max_dim)
+               double* __restrict__ workspace, int64_t ws_stride, int max_dim,
+               int32_t* __restrict__ redo_count, int32_t* __restrict__ redo_ids)
 {
+    using namespace decide;   // decisions inside their error margin send the tile to the exact path (qrk_device.h)
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double* xv = smem;                       // [max_dim] pivot column (rows k..r-1 valid)
     double* nu2 = xv + max_dim;              // [max_dim] m_colNormsUpdated^2
     double* thr = nu2 + max_dim;             // [max_dim] sqrt(eps) * m_colNormsDirect^2
     double* red = thr + max_dim;             // [2*WG_WAVES] reduction scratch
     int* pidx = reinterpret_cast<int*>(red + 2 * WG_WAVES);   // [max_dim] permutation indices
-    int* ired = pidx + max_dim;              // [2*WG_WAVES]
+    int* ired = pidx + max_dim;              // [2*WG_WAVES], then [1] redo flag
+    int* unclear = ired + 2 * WG_WAVES;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     double* W = workspace + (int64_t)blockIdx.x * ws_stride;
@@ -81,12 +84,14 @@ bdqr_wg_kernel(WaveBatch nb, const double* __restrict__ tiles, double* __restric
         // ---- working copy, identity, squared column norms
         for (int64_t e = tid; e < (int64_t)r * c; e += WG_THREADS) W[e] = src[e];
         for (int64_t e = tid; e < (int64_t)r * r; e += WG_THREADS) QT[e] = (e / r == e % r) ? 1.0 : 0.0;
+        if (tid == 0) *unclear = 0;
+        double a2 = 0.0;                     // |A|^2: squared norm of the first pivot column
         __syncthreads();
         for (int jc = wave; jc < c; jc += WG_WAVES) {
             double s = 0.0;
             for (int i = lane; i < r; i += 64) { const double v = W[(int64_t)jc * r + i]; s = fma(v, v, s); }
             s = wave_sum(s);
-            if (lane == 0) { nu2[jc] = s; thr[jc] = s * WG_SQRT_EPS; pidx[jc] = jc; }
+            if (lane == 0) { nu2[jc] = s; thr[jc] = s * THR_HI; pidx[jc] = jc; }
         }
         __syncthreads();
 
@@ -113,6 +118,9 @@ bdqr_wg_kernel(WaveBatch nb, const double* __restrict__ tiles, double* __restric
                 for (int w = 1; w < WG_WAVES; ++w)
                     if (red[w] > best || (red[w] == best && ired[w] < bi)) { best = red[w]; bi = ired[w]; }
                 b = bi < c ? bi : k;
+                if (k == 0) a2 = best;
+                for (int jc = k + tid; jc < c; jc += WG_THREADS)
+                    if (jc != b && near_best(nu2[jc], thr[jc], best, a2)) *unclear = 1;      // decision (1)
                 __syncthreads();
                 // Eigen swaps columns k and b physically, and the norm tables with them
                 if (b != k) {
@@ -140,6 +148,8 @@ bdqr_wg_kernel(WaveBatch nb, const double* __restrict__ tiles, double* __restric
             const double tailSq = block_sum(part, red);
             const double xk = xv[k];
             double beta, w, g;
+            if (k == 0 && !nb.pivoting) a2 = fma(xk, xk, tailSq);
+            if (tid == 0 && unclear_reflector(xk, tailSq, k + 1 < r, nb.pivoting != 0, a2)) *unclear = 1;   // (3), (4), (5)
             if (tailSq <= DBL_MIN) {               // Eigen: tau = 0, beta = x0, H = I
                 beta = xk; w = 0.0; g = 0.0;
             } else {
@@ -178,7 +188,10 @@ bdqr_wg_kernel(WaveBatch nb, const double* __restrict__ tiles, double* __restric
                     nn = nn > 0.0 ? nn : 0.0;
                     if (nn <= thr[jc]) {
                         s2 = wave_sum(s2);
-                        if (lane == 0) { nu2[jc] = s2; thr[jc] = s2 * WG_SQRT_EPS; }
+                        if (lane == 0) {
+                            if (in_recompute_band(nn, thr[jc])) *unclear = 1;                 // decision (2)
+                            nu2[jc] = s2; thr[jc] = s2 * THR_HI;
+                        }
                     } else if (lane == 0) {
                         nu2[jc] = nn;
                     }
@@ -193,23 +206,24 @@ bdqr_wg_kernel(WaveBatch nb, const double* __restrict__ tiles, double* __restric
             for (int i = lane; i <= jc; i += 64) r_vals[roff + (int64_t)jc * (jc + 1) / 2 + i] = W[(int64_t)jc * r + i];
         (void)n_r;
         for (int jc = tid; jc < c; jc += WG_THREADS) perm[cbase + jc] = cbase + pidx[jc];
+        if (tid == 0 && *unclear != 0 && redo_count) redo_ids[atomicAdd(redo_count, 1)] = gidx;
         __syncthreads();
     }
 }
 
 size_t bdqr_wg_smem_bytes(int max_dim)
 {
-    return (size_t)(3 * max_dim + 2 * WG_WAVES) * sizeof(double) + (size_t)(max_dim + 2 * WG_WAVES) * sizeof(int);
+    return (size_t)(3 * max_dim + 2 * WG_WAVES) * sizeof(double) + (size_t)(max_dim + 2 * WG_WAVES + 2) * sizeof(int);
 }
 
 void launch_bdqr_wg(const WaveBatch& nb, const double* tiles, double* q_vals, double* r_vals, int32_t* perm,
                     double* hcoeffs, double* workspace, int64_t ws_stride, int num_wg, int max_dim,
-                    hipStream_t stream)
+                    int32_t* redo_count, int32_t* redo_ids, hipStream_t stream)
 {
     if (nb.num_tiles <= 0) return;
     const int64_t want = nb.num_tiles < (int64_t)num_wg ? nb.num_tiles : (int64_t)num_wg;
     hipLaunchKernelGGL(bdqr_wg_kernel, dim3((unsigned)want), dim3(WG_THREADS), bdqr_wg_smem_bytes(max_dim), stream, nb,
-                       tiles, q_vals, r_vals, perm, hcoeffs, workspace, ws_stride, max_dim);
+                       tiles, q_vals, r_vals, perm, hcoeffs, workspace, ws_stride, max_dim, redo_count, redo_ids);
 }
 
 }  // namespace qrk

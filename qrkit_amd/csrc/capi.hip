@@ -209,11 +209,11 @@ qrk_status enqueue_factorize(qrk_bd_plan_s* p, const double* tiles, double* q, d
         if (p->max_dim > 32 && p->max_dim <= QRK_COL_MAX_DIM) {
             const auto& k = p->col_cls[0];
             QRK_HIP(h, qrk::launch_bdqr_col(nb, tiles, q, r, perm, hc, p->d_col_workspace, k.ws_stride, k.num_wg, k.max_rows,
-                                            k.max_cols, k.w_lds, h->stream));
+                                            k.max_cols, k.w_lds, redo_cnt, redo_ids, h->stream));
         } else if (p->max_dim > 32)
-            qrk::launch_bdqr_wg(nb, tiles, q, r, perm, hc, p->d_workspace, p->ws_stride, p->num_wg, p->max_dim, h->stream);
+            qrk::launch_bdqr_wg(nb, tiles, q, r, perm, hc, p->d_workspace, p->ws_stride, p->num_wg, p->max_dim, redo_cnt, redo_ids, h->stream);
         else if (p->max_dim <= 16 && p->r >= p->c && h->use_small_kernel)   // 64/G tiles per wavefront (bdqr_small.hip)
-            qrk::launch_bdqr_small(p->B, p->r, p->c, nb.pivoting, tiles, q, r, perm, hc, h->num_cus * 32, h->stream);
+            qrk::launch_bdqr_small(p->B, p->r, p->c, nb.pivoting, tiles, q, r, perm, hc, h->num_cus * 32, redo_cnt, redo_ids, h->stream);
         else qrk::launch_bdqr_pair(nb, full32, tiles, q, r, perm, hc, h->num_cus * h->pair_wgs_per_cu, redo_cnt, redo_ids, h->stream);
     } else {
         nb.num_tiles = p->n_wave; nb.tile_ids = p->d_wave_ids;
@@ -239,7 +239,7 @@ qrk_status enqueue_factorize(qrk_bd_plan_s* p, const double* tiles, double* q, d
                 cb.num_tiles = k.n; cb.tile_ids = p->d_col_ids + k.off;
                 QRK_HIP(h, hipStreamWaitEvent(h->side[z], h->ev_fork, 0));
                 QRK_HIP(h, qrk::launch_bdqr_col(cb, tiles, q, r, perm, hc, p->d_col_workspace + k.ws_off, k.ws_stride, k.num_wg,
-                                                k.max_rows, k.max_cols, k.w_lds, h->side[z]));
+                                                k.max_rows, k.max_cols, k.w_lds, redo_cnt, redo_ids, h->side[z]));
                 QRK_HIP(h, hipEventRecord(h->ev_join[z], h->side[z]));
                 QRK_HIP(h, hipStreamWaitEvent(h->stream, h->ev_join[z], 0));
             }
@@ -247,7 +247,7 @@ qrk_status enqueue_factorize(qrk_bd_plan_s* p, const double* tiles, double* q, d
         if (p->n_wg > 0) {
             qrk::WaveBatch lb = nb;
             lb.num_tiles = p->n_wg; lb.tile_ids = p->d_wg_ids;
-            qrk::launch_bdqr_wg(lb, tiles, q, r, perm, hc, p->d_workspace, p->ws_stride, p->num_wg, p->max_dim, h->stream);
+            qrk::launch_bdqr_wg(lb, tiles, q, r, perm, hc, p->d_workspace, p->ws_stride, p->num_wg, p->max_dim, redo_cnt, redo_ids, h->stream);
         }
     }
     // the tiles whose decisions were not clear of rounding, again, with the reference's own operation order (bdqr_exact.hip);

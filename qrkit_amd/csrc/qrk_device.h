@@ -4,6 +4,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <float.h>
 
 namespace qrk {
 
@@ -48,18 +49,18 @@ void launch_bdqr_pair(const WaveBatch& nb, bool full32, const double* tiles, dou
                       int32_t* redo_count, int32_t* redo_ids, hipStream_t stream);
 // Uniform batches of small tiles (rows <= 16, cols <= rows): 64/G tiles per wavefront (bdqr_small.hip).
 void launch_bdqr_small(int64_t num_tiles, int r, int c, int pivoting, const double* tiles, double* q_vals, double* r_vals,
-                       int32_t* perm, double* hcoeffs, int max_blocks, hipStream_t stream);
+                       int32_t* perm, double* hcoeffs, int max_blocks, int32_t* redo_count, int32_t* redo_ids, hipStream_t stream);
 // Mid-size tiles (32 < max(rows, cols) <= 256, rows >= cols): one thread per column of A, blocked Q (bdqr_col.hip).
 // One launch serves one size class (columns <= 64, <= 128, <= 256): its LDS is carved for the largest tile of the class.
 hipError_t launch_bdqr_col(const WaveBatch& nb, const double* tiles, double* q_vals, double* r_vals, int32_t* perm,
                            double* hcoeffs, double* workspace, int64_t ws_stride, int num_wg, int max_rows,
-                           int max_cols, int w_lds, hipStream_t stream);
+                           int max_cols, int w_lds, int32_t* redo_count, int32_t* redo_ids, hipStream_t stream);
 int bdqr_col_w_lds(int64_t max_rc, int64_t max_rc_fitting);
 int bdqr_col_wgs_per_cu(int max_cols, int w_lds, int max_r);
 constexpr int QRK_COL_W_LDS_MAX = 4352;     // doubles of LDS for A in the LDS-resident form (bdqr_col.hip)
 void launch_bdqr_wg(const WaveBatch& nb, const double* tiles, double* q_vals, double* r_vals, int32_t* perm,
                     double* hcoeffs, double* workspace, int64_t ws_stride, int num_wg, int max_dim,
-                    hipStream_t stream);
+                    int32_t* redo_count, int32_t* redo_ids, hipStream_t stream);
 // The exact-arithmetic path (bdqr_exact.hip): redoes the listed tiles with Eigen's operation order and rounding.
 hipError_t launch_bdqr_exact(const WaveBatch& nb, const int32_t* ids, const int32_t* count, int32_t* next_count,
                              const double* tiles, double* q_vals, double* r_vals, int32_t* perm, double* hcoeffs,
@@ -102,6 +103,34 @@ void launch_bd_solve_r(const TileGeom& g, int max_cols, const double* r_vals, co
 void launch_bd_solve(const TileGeom& g, int max_cols, const double* q_vals, const double* r_vals,
                      const int32_t* perm, const double* b, int64_t nrhs, double* x,
                      hipStream_t stream);
+
+// ---- decision margins of the fast kernels ------------------------------------------------
+// A fast kernel (FMA chains, squared column norms, un-normalised reflector) takes a data-dependent decision of the reference
+// algorithm only when it is clear of rounding, and otherwise sends the tile to the exact path (bdqr_exact.hip), which repeats
+// it in Eigen's own operation order; see bdqr_pair.hip, "Decisions and the exact path", for the error model.  Here as plain
+// double arithmetic for the thread-per-column kernels (bdqr_col, bdqr_wg, dense_qr*): a2 = |A|^2 is the squared norm of the
+// first pivot column, which bounds every later column norm and scales the absolute error of the column entries.
+namespace decide {
+constexpr double MREL = 0.000244140625;               // 2^-12 = 2^14 eps / sqrt(eps)
+constexpr double THR_HI = 1.4901161193847656e-08 * (1.0 + MREL);   // thr = sqrt(eps) (1 + 2^-12) normDirect^2: upper edge of the recompute band
+constexpr double X0_TINY2 = 1.2924697071141057e-26;   // 2^-86: x0^2 <= (2^9 eps |A|)^2 leaves the sign of beta to rounding noise
+constexpr double PIV_TINY2 = 9.094947017729282e-13;   // 2^-40: a pivot column below 2^-20 |A| is at the noise level of the tile
+
+// (1) another live column within the error margin of the chosen one: nu2 of a column (thr its band edge) against the best
+__device__ __forceinline__ bool near_best(double nu2, double thr, double best, double a2)
+{
+    const double margin = MREL * (thr + THR_HI * a2) + 4.547473508864641e-13 /* 2^-41 */ * sqrt(a2 * (best > 0.0 ? best : 0.0));
+    return nu2 >= best - margin;
+}
+// (2) the downdated squared norm nn passed the recompute test (nn <= thr) inside the band around Eigen's threshold
+__device__ __forceinline__ bool in_recompute_band(double nn, double thr) { return nn > thr * (1.0 - 2.0 * MREL); }
+// (3) degenerate reflector on a non-empty tail, (4) |x0| too small to fix the sign of beta, (5) pivot at the noise level
+__device__ __forceinline__ bool unclear_reflector(double xk, double tsq, bool tail, bool pivoting, double a2)
+{
+    const double n2 = fma(xk, xk, tsq);
+    return (tail && (!(tsq > DBL_MIN) || xk * xk <= X0_TINY2 * a2)) || (pivoting && n2 <= PIV_TINY2 * a2);
+}
+}  // namespace decide
 
 // ---- cross-lane helpers (wave64) ---------------------------------------------------------
 
