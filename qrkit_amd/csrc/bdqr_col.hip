@@ -248,7 +248,7 @@ __device__ __forceinline__ void factor_tile(double* __restrict__ W, double* smem
                         const double nn = fma(-an, an, nu2);
                         nu2 = nn;
                         if (nn <= thr) {
-                            if (nn > thr * (1.0 - 2.0 * MREL)) unclear = true;     // (2) inside the band around Eigen's threshold
+                            if (in_recompute_band(nn, thr, a2)) unclear = true;    // (2) inside the band around Eigen's threshold
                             double s2 = 0.0;
                             for (int i = k + 1; i < r; ++i) {
                                 double a = wc[(int64_t)i * ld];
@@ -358,7 +358,7 @@ __device__ __forceinline__ void factor_tile(double* __restrict__ W, double* smem
                     const double nn = fma(-an, an, nu2);
                     nu2 = nn;
                     need = nn <= thr;
-                    if (need && nn > thr * (1.0 - 2.0 * MREL)) unclear = true;     // (2) inside the band around Eigen's threshold
+                    if (need && in_recompute_band(nn, thr, a2)) unclear = true;    // (2) inside the band around Eigen's threshold
                 }
                 if (need) flags[k & 1] = 1;
                 Cand cd{live ? nu2 : -1.0, pos, tid, ngam};

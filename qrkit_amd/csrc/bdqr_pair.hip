@@ -45,6 +45,10 @@
 #ifndef QRK_ABL
 #define QRK_ABL 0
 #endif
+#ifndef QRK_DECISIONS
+#define QRK_DECISIONS 31       // diagnostic only (tools/ab.py): bit mask of the decision checks compiled in, to measure what each
+                               // costs: 1 pivot margin, 2 |x0| test, 4 recompute band, 8 pivot at the noise level, 16 degenerate tail
+#endif
 #ifndef QRK_RB
 #define QRK_RB 4               // steps between refreshes of the LDS image (measured on one box: 4 -> 87.1 us, 3 -> 87.4, 2 -> 91.0; 8 needs 22 KB of LDS per wave)
 #endif
@@ -82,7 +86,9 @@ constexpr int L_IMG = 0;             // [32][LDP] column-major image of A / stag
 constexpr int L_XBUF = WR * LDP;     // [32] current pivot column
 constexpr int L_WBUF = L_XBUF + WR;  // [RB][32] update coefficients of the last RB steps, per A column
 constexpr int L_POS = L_WBUF + RB * WR;   // [32] int: lane_of_pos
-constexpr int L_HALF = L_POS + WR / 2;    // 1264 doubles = 10112 B per half, 20224 B per wave -> 8 waves per CU
+constexpr int L_A2 = L_POS + WR / 2;      // [1] |A|^2: squared norm of the first pivot column (scale of the decision margins)
+constexpr int L_FLAG = L_A2 + 1;          // [1] != 0: a decision of this tile was not clear of rounding -> exact path
+constexpr int L_HALF = L_FLAG + 1;        // 1266 doubles = 10128 B per half, 20256 B per wave -> 8 waves per CU (162 048 of 163 840 B)
 
 constexpr double SQRT_EPS = 1.4901161193847656e-08;   // sqrt(DBL_EPSILON), Eigen's norm_downdate_threshold
 // Decision margins (see "Decisions and the exact path" below): a squared column norm carried by this kernel and the square of
@@ -92,12 +98,19 @@ constexpr double SQRT_EPS = 1.4901161193847656e-08;   // sqrt(DBL_EPSILON), Eige
 constexpr double MREL = 0.000244140625;               // 2^-12 = 2^14 eps / sqrt(eps)
 constexpr double THR_HI = SQRT_EPS * (1.0 + MREL);
 // The entries of a column carry an absolute error of ~k eps |A| (|A| = the largest column norm of the tile = the first pivot),
-// whatever the column has shrunk to.  So (4) an |x0| below 2^9 eps |A| leaves the sign of beta to rounding noise, (5) a pivot
-// column below 2^-20 |A| makes every later decision noise relative to what is left, and the squared norms of two candidate
-// columns are only known to 2^10 eps |A| (|c_b| + |c_j|).  The scale is kept per lane as ONE register: the high word of
-// 2^-40 |A|^2 (st.scale_hi); comparisons against it are integer comparisons of high words (2^-20 relative resolution).
-constexpr int SCALE_SHIFT = 40 << 20;                 // 2^-40 in the exponent field of a high word
-constexpr int X0_SHIFT = 46 << 20;                    // x0^2 <= 2^-86 |A|^2 = (2^9 eps |A|)^2
+// whatever the column has shrunk to: the squared norms of two candidate columns are only known to 2^10 eps |A| (|c_b| + |c_j|),
+// i.e. to 2^-42 |A| / |c| relative.  The hot path only looks at the HIGH WORDS of the squared norms: every live column within
+// FILTER units (2^-12 relative) of the largest is a candidate, and a single candidate is a clear decision as long as
+// 2^-42 |A| / |c| < 2^-12, which (5) guarantees: a pivot column below 2^-30 |A| flags the tile (checked once, in the epilogue,
+// on the diagonal of R; generic tiles have |R_kk| > 1e-4 |A|).  (4): an |x0| below 2^9 eps |A| leaves the sign of beta to
+// rounding noise; the hot path filters with |x0| <= 2^-13 |x| and the rare branch compares with |A|.  |A|^2 and the flag live
+// in LDS (L_A2, L_FLAG): no register is spent on them.
+constexpr int FILTER = 256;                            // units of the high word (2^-20 each)
+constexpr double X0_FILTER2 = 1.4901161193847656e-08;  // 2^-26: x0^2 <= 2^-26 |x|^2 enters the rare branch ...
+constexpr double X0_TINY2 = 1.2924697071141057e-26;    // ... where 2^-86: x0^2 <= (2^9 eps |A|)^2 flags
+constexpr double PIV_TINY2 = 8.673617379884035e-19;    // 2^-60: |R_kk|^2 <= 2^-60 |A|^2
+constexpr double ND_TINY2 = 5.820766091346741e-11;     // 2^-34: a column whose direct norm is below 2^-17 |A| meets the recompute
+                                                       // test with an error that the 2^-12 band does not cover
 
 #define QRK_0_31(M)                                                                              \
     M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9) M(10) M(11) M(12) M(13) M(14) M(15) M(16)  \
@@ -168,8 +181,6 @@ struct LaneState {
     int rows, cols;  // tile shape of this half (rows/cols beyond are zero padding)
     double nu2;      // m_colNormsUpdated^2
     double thr_nd2;  // sqrt(eps) (1 + 2^-12) * m_colNormsDirect^2: upper edge of the band around Eigen's recompute threshold
-    unsigned long long flagmask;   // lanes that met a decision inside its error margin: their tile goes to the exact path
-    int scale_hi;    // high word of 2^-40 |A|^2, |A|^2 = squared norm of the first pivot column of this half's tile
     double h[RB];    // entry j of the pivot columns of the last RB steps
 #ifdef QRK_STAMP
     unsigned long long tk[8];
@@ -192,7 +203,7 @@ __device__ __forceinline__ double bpermute_f64(int byte_addr, double v)
 // here) -- the tile is flagged and redone by the exact path (bdqr_exact.hip), which owns the first-maximum rule.
 // Returns a one-hot (per half) pivot flag.
 __device__ __forceinline__ bool resolve_near(int lane, bool live, double nu2, double thr_hi, int khi, int mh, int hb4,
-                                             int scale_hi, bool have_scale, unsigned long long& flagmask)
+                                             double* hl, bool have_scale)
 {
     bool cand = live && khi == mh;
     const unsigned klo = (unsigned)__double2loint(nu2);
@@ -207,12 +218,8 @@ __device__ __forceinline__ bool resolve_near(int lane, bool live, double nu2, do
     // margin: the downdate chain (MREL (thr_j + thr_b) = 2^14 eps (normDirect_j^2 + normDirect_b^2)) plus the absolute error of
     // the column entries, 2^10 eps |A| (|c_b| + |c_j|) <= 2^11 eps sqrt(|A|^2 best)
     double margin = MREL * (thr_hi + thrb);
-    if (have_scale) {
-        const double a2 = __hiloint2double(scale_hi + SCALE_SHIFT, 0);      // ~|A|^2
-        margin += 4.547473508864641e-13 /* 2^-41 */ * __builtin_sqrt(a2 * (best > 0.0 ? best : 0.0));
-    }
-    const bool near = live && !ispiv && nu2 >= best - margin;
-    flagmask |= ballot64(near);
+    if (have_scale) margin += 4.547473508864641e-13 /* 2^-41 */ * __builtin_sqrt(hl[L_A2] * (best > 0.0 ? best : 0.0));
+    if ((QRK_DECISIONS & 1) && live && !ispiv && nu2 >= best - margin) hl[L_FLAG] = 1.0;
     return ispiv;
 }
 
@@ -227,8 +234,8 @@ __device__ __forceinline__ bool resolve_near(int lane, bool live, double nu2, do
 // Decisions and the exact path.  Every data-dependent decision of the reference algorithm is taken here only when it is
 // clear of rounding: (1) the pivot: no other live column within MREL (thr_hi_j + thr_hi_b) of the largest squared norm;
 // (2) the LAWN-176 recompute test: the downdated norm not within 2^-12 (relative) of the threshold; (3) Eigen's degenerate
-// reflector test tailSqNorm <= DBL_MIN: never true on a non-empty tail; (4) the sign of beta: |x0| > 2^-40 |x|.  A tile that
-// meets any of them is flagged (st.flagmask) and appended to the redo list at the end; bdqr_exact.hip then recomputes it with
+// reflector test tailSqNorm <= DBL_MIN: never true on a non-empty tail; (4) the sign of beta: |x0| > 2^9 eps |A|; (5) no pivot below 2^-30 |A|.  A tile that
+// meets any of them is flagged (L_FLAG in LDS) and appended to the redo list at the end; bdqr_exact.hip then recomputes it with
 // Eigen's own operation order and rounding.  On generic data nothing is flagged (a pivot inside its margin has probability
 // ~1e-9 per tile); on sign / indicator / repeated-column data everything is, and the permutation is Eigen's either way.
 //
@@ -264,16 +271,16 @@ __device__ __forceinline__ void search_fetch(double* hl /* this half's LDS */, L
         // error margin, so a single candidate is a clear decision)
         unsigned long long pm;
         if (FULL32) {
-            pm = __builtin_amdgcn_sicmp(khi, mh - 1, 39 /* ICMP_SGE */);   // a live column exists: mh >= 0, chosen ones are < -1
-            ispiv = khi >= mh - 1;
+            pm = __builtin_amdgcn_sicmp(khi, mh - ((QRK_DECISIONS & 1) ? FILTER : 0), 39 /* ICMP_SGE */);   // a live column exists: mh >= 0, chosen ones are < -1
+            ispiv = khi >= mh - ((QRK_DECISIONS & 1) ? FILTER : 0);
         } else {
-            ispiv = st.live && khi >= mh - 1;
+            ispiv = st.live && khi >= mh - FILTER;
             pm = ballot64(ispiv);
         }
         unsigned tlo = (unsigned)pm, thi = (unsigned)(pm >> 32);
         if (!(QRK_ABL & 1) && ((tlo & (tlo - 1u)) | (thi & (thi - 1u))) != 0u) {
             // ... unless there are several
-            ispiv = resolve_near(st.lane, st.live, st.nu2, st.thr_nd2, khi, mh, st.hb4, st.scale_hi, K > 0, st.flagmask);
+            ispiv = resolve_near(st.lane, st.live, st.nu2, st.thr_nd2, khi, mh, st.hb4, hl, K > 0);
             pm = ballot64(ispiv);
             tlo = (unsigned)pm; thi = (unsigned)(pm >> 32);
         }
@@ -357,19 +364,15 @@ __device__ __forceinline__ void pair_step(double (&a)[WR], double (&q)[WR], doub
     // Eigen: tailSqNorm <= min() gives tau = 0, beta = x0, H = I.  Rare, so a real branch (the empty
     // asm keeps hipcc from flattening it into selects); s = 0 leaves c_k = x0 in the pivot lane.
     const bool degen = !act || !(tailSq > DBL_MIN);
-    // decisions (4) and (5) as one integer test against the scale of the tile: x0^2 <= 2^-86 |A|^2 or |x|^2 <= 2^-40 |A|^2
-    if (K == 0) st.scale_hi = __double2hiint(nrm2) - SCALE_SHIFT;
-    const int h_x0 = __double2hiint(xk * xk) + X0_SHIFT, h_x = __double2hiint(nrm2);
-    const int h_min = h_x0 < h_x ? h_x0 : h_x;
+    // decision (4) (filter: x0^2 <= 2^-26 |x|^2, with a non-empty tail); the scale of the tile goes to LDS at the first step
+    if (K == 0 && ispiv) hl[L_A2] = nrm2;
     const unsigned long long dm = (FULL32 ? __builtin_amdgcn_fcmp(tailSq, DBL_MIN, 13 /* FCMP_ULE */) : ballot64(degen)) |
-                                  __builtin_amdgcn_sicmp(h_min, st.scale_hi, 41 /* ICMP_SLE */);
+                                  ((QRK_DECISIONS & 2) ? __builtin_amdgcn_fcmp(xk * xk, X0_FILTER2 * nrm2, 13 /* FCMP_ULE */) : 0ull);
     bool setdiag = ispiv;
     if (!(QRK_ABL & 4) && __builtin_expect(dm != 0ull, 0)) {
         asm volatile("");
-        // (3) a degenerate reflector on a non-empty tail, (4) a first entry too small to fix the sign of beta (non-empty tail),
-        // (5) a pivot column at the noise level of the tile
-        const bool tail = K + 1 < (FULL32 ? WR : st.rows);
-        if (act && ((tail && (degen || h_x0 <= st.scale_hi)) || (PIVOT && h_x <= st.scale_hi))) st.flagmask |= ballot64(true);
+        // (3) a degenerate reflector on a non-empty tail, (4) a first entry too small to fix the sign of beta
+        if ((QRK_DECISIONS & 18) && act && K + 1 < (FULL32 ? WR : st.rows) && (degen || xk * xk <= X0_TINY2 * hl[L_A2])) hl[L_FLAG] = 1.0;
         if (degen) { ng = 0.0; s = 0.0; setdiag = false; }   // (nrm may be NaN here: rsq(0) = inf)
     }
     if (HC) {
@@ -397,7 +400,8 @@ __device__ __forceinline__ void pair_step(double (&a)[WR], double (&q)[WR], doub
             // rare: a column norm has to be recomputed from the updated column before the next search
             asm volatile("");
             // decision (2): inside the band [1 - 2^-12, 1 + 2^-12] around Eigen's threshold the test is rounding noise
-            st.flagmask |= ballot64(st.live && nn <= st.thr_nd2 && nn > st.thr_nd2 * (1.0 - 2.0 * MREL));
+            if ((QRK_DECISIONS & 4) && st.live && nn <= st.thr_nd2 &&
+                (nn > st.thr_nd2 * (1.0 - 2.0 * MREL) || st.thr_nd2 <= (THR_HI * ND_TINY2) * hl[L_A2])) hl[L_FLAG] = 1.0;
 #pragma unroll
             for (int i = K + 1; i < WR; ++i) { if (QRK_ABL & 2048) a[i] = fma(ngA, x[i], a[i]); else fmac2_shared_b(a[i], q[i], ngA, ngQ, x[i]); }
             updated = true;
@@ -509,7 +513,7 @@ bdqr_pair_kernel(WaveBatch nb, const double* __restrict__ tiles, double* __restr
         st.sh8 = half * 8; st.hb4 = half * 128;
         st.live = FULL32 ? true : j < c;
         st.livemask = FULL32 ? ~0ull : __builtin_amdgcn_ballot_w64(j < c);
-        st.flagmask = 0ull; st.scale_hi = 0;
+        if (j == 0) { hl[L_FLAG] = 0.0; hl[L_A2] = 0.0; }
 #pragma unroll
         for (int m = 0; m < RB; ++m) st.h[m] = 0.0;
         {
@@ -554,9 +558,11 @@ bdqr_pair_kernel(WaveBatch nb, const double* __restrict__ tiles, double* __restr
             lane_of_pos[st.kstep] = j;
             perm[cbase + st.kstep] = cbase + j;   // m_outputPerm_c.indices()(base_col+j) (:519-521)
         }
+        // decision (5): a pivot at the noise level of the tile, |R_kk|^2 <= 2^-40 |A|^2 (R_kk sits in this lane's own slot)
+        if (PIVOT && j < c) { const double rkk = hl[L_IMG + j * LDP + j]; if (rkk * rkk <= PIV_TINY2 * hl[L_A2]) hl[L_FLAG] = 1.0; }
+        __syncthreads();
         // a decision inside its error margin: the tile is redone by the exact path (bdqr_exact.hip)
-        if (redo_count && valid && j == 0 && (half ? (unsigned)(st.flagmask >> 32) : (unsigned)st.flagmask) != 0u)
-            redo_ids[atomicAdd(redo_count, 1)] = gid;
+        if (redo_count && valid && j == 0 && hl[L_FLAG] != 0.0) redo_ids[atomicAdd(redo_count, 1)] = gid;
         __syncthreads();
         if (FULL32) {
             if (valid) {
@@ -628,9 +634,8 @@ namespace pair {
 // All per-lane addresses derive from an opaque lane id so that none of them is computed (and kept
 // alive) before the factorisation.
 __device__ __forceinline__ void epilogue32(int lane_in, int64_t pi, int64_t num_tiles, int kstep, double* lds,
-                                           double* __restrict__ r_vals, int32_t* __restrict__ perm,
-                                           unsigned long long flagmask, int32_t* __restrict__ redo_count,
-                                           int32_t* __restrict__ redo_ids)
+                                           double* __restrict__ r_vals, int32_t* __restrict__ perm, bool pivot,
+                                           int32_t* __restrict__ redo_count, int32_t* __restrict__ redo_ids)
 {
     int lane = lane_in;
     asm volatile("" : "+v"(lane));
@@ -645,11 +650,11 @@ __device__ __forceinline__ void epilogue32(int lane_in, int64_t pi, int64_t num_
     int* lane_of_pos = reinterpret_cast<int*>(&hl[L_POS]);
     lane_of_pos[kstep] = j;                            // the column chosen at step k ends at position k
     if (valid) perm[cbase + kstep] = cbase + j;        // m_outputPerm_c.indices()(base_col+j) (:519-521)
+    // decision (5): a pivot at the noise level of the tile, |R_kk|^2 <= 2^-40 |A|^2 (R_kk sits in this lane's own slot)
+    if (pivot && (QRK_DECISIONS & 8)) { const double rkk = hl[L_IMG + j * LDP + j]; if (rkk * rkk <= PIV_TINY2 * hl[L_A2]) hl[L_FLAG] = 1.0; }
+    __builtin_amdgcn_wave_barrier();
     // a decision inside its error margin: the tile is redone by the exact path (bdqr_exact.hip)
-    if (flagmask != 0ull) {
-        if (redo_count && valid && j == 0 && (half ? (unsigned)(flagmask >> 32) : (unsigned)flagmask) != 0u)
-            redo_ids[atomicAdd(redo_count, 1)] = (int)t;
-    }
+    if (redo_count && valid && j == 0 && hl[L_FLAG] != 0.0) redo_ids[atomicAdd(redo_count, 1)] = (int)t;
     __builtin_amdgcn_wave_barrier();   // one wave per workgroup: LDS is in order, no s_barrier (its fence would wait for the prefetch)
     if (valid) {
         double2* dst = reinterpret_cast<double2*>(r_vals + t * 528);
@@ -755,7 +760,7 @@ bdqr_pair32_kernel(int64_t num_tiles, const double* __restrict__ tiles, double* 
         st.sh8 = half * 8; st.hb4 = half * 128;
         st.live = true;
         st.livemask = ~0ull;
-        st.flagmask = 0ull; st.scale_hi = 0;
+        if (j == 0) { hl[L_FLAG] = 0.0; hl[L_A2] = 0.0; }
 #pragma unroll
         for (int m = 0; m < RB; ++m) st.h[m] = 0.0;
         {
@@ -812,7 +817,7 @@ bdqr_pair32_kernel(int64_t num_tiles, const double* __restrict__ tiles, double* 
                 for (int m = 16; m < WR; ++m) a[m] = nsrc[32 * m];
             }
         }
-        epilogue32(threadIdx.x, pi, num_tiles, st.kstep, lds, r_vals, perm, st.flagmask, redo_count, redo_ids);
+        epilogue32(threadIdx.x, pi, num_tiles, st.kstep, lds, r_vals, perm, PIVOT, redo_count, redo_ids);
         QRK_STAMP_AT(6);
 #ifdef QRK_STAMP
         if (threadIdx.x == 0 && hcoeffs) {

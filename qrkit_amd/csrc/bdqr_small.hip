@@ -42,8 +42,8 @@ constexpr double SQRT_EPS = 1.4901161193847656e-08;   // sqrt(DBL_EPSILON), Eige
 // decision margins: the same constants as bdqr_pair.hip
 constexpr double MREL = 0.000244140625;               // 2^-12 = 2^14 eps / sqrt(eps)
 constexpr double THR_HI = SQRT_EPS * (1.0 + MREL);
-constexpr int SCALE_SHIFT = 40 << 20;
-constexpr int X0_SHIFT = 46 << 20;
+constexpr int SCALE_SHIFT = 60 << 20;                 // scale_hi = high word of 2^-60 |A|^2: a pivot below 2^-30 |A| flags
+constexpr int X0_SHIFT = 26 << 20;                    // x0^2 <= 2^-86 |A|^2 = (2^9 eps |A|)^2
 
 // sqrt(x) for a positive normal x: v_rsq_f64 seed, one Goldschmidt iteration and one residual correction (<= 1 ulp)
 __device__ __forceinline__ double sqrt_pos(double x)
@@ -148,7 +148,7 @@ bdqr_small_kernel(int64_t num_tiles, int r, int c, const double* __restrict__ ti
         int kstep = 2 * G;              // step at which this column was chosen = its final position
         double nu2, thr_nd2;            // m_colNormsUpdated^2 and sqrt(eps) (1 + 2^-12) * m_colNormsDirect^2
         bool flag = false;              // a decision of this lane's tile was not clear of rounding
-        int scale_hi = 0;               // high word of 2^-40 |A|^2 (|A|^2 = squared norm of the first pivot column)
+        int scale_hi = 0;               // high word of 2^-60 |A|^2 (|A|^2 = squared norm of the first pivot column)
         {
             double s = 0.0;
 #pragma unroll
@@ -243,7 +243,8 @@ bdqr_small_kernel(int64_t num_tiles, int r, int c, const double* __restrict__ ti
                     const double nn = fma(-an, an, nu2);
                     nu2 = nn;
                     if (live && nn <= thr_nd2) {
-                        flag = flag || nn > thr_nd2 * (1.0 - 2.0 * MREL);   // decision (2): inside the band around the threshold
+                        flag = flag || nn > thr_nd2 * (1.0 - 2.0 * MREL) ||   // decision (2): inside the band around the threshold, or a
+                               __double2hiint(thr_nd2) <= scale_hi;   // column below 2^-17 |A| (thr = 2^-26 nd^2 <= 2^-60 |A|^2)
                         double sq = 0.0;
 #pragma unroll
                         for (int i = K + 1; i < G; ++i) sq = fma(a[i], a[i], sq);

@@ -189,7 +189,7 @@ bdqr_wg_kernel(WaveBatch nb, const double* __restrict__ tiles, double* __restric
                     if (nn <= thr[jc]) {
                         s2 = wave_sum(s2);
                         if (lane == 0) {
-                            if (in_recompute_band(nn, thr[jc])) *unclear = 1;                 // decision (2)
+                            if (in_recompute_band(nn, thr[jc], a2)) *unclear = 1;                 // decision (2)
                             nu2[jc] = s2; thr[jc] = s2 * THR_HI;
                         }
                     } else if (lane == 0) {

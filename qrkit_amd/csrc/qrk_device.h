@@ -114,7 +114,8 @@ namespace decide {
 constexpr double MREL = 0.000244140625;               // 2^-12 = 2^14 eps / sqrt(eps)
 constexpr double THR_HI = 1.4901161193847656e-08 * (1.0 + MREL);   // thr = sqrt(eps) (1 + 2^-12) normDirect^2: upper edge of the recompute band
 constexpr double X0_TINY2 = 1.2924697071141057e-26;   // 2^-86: x0^2 <= (2^9 eps |A|)^2 leaves the sign of beta to rounding noise
-constexpr double PIV_TINY2 = 9.094947017729282e-13;   // 2^-40: a pivot column below 2^-20 |A| is at the noise level of the tile
+constexpr double PIV_TINY2 = 8.673617379884035e-19;   // 2^-60: a pivot column below 2^-30 |A| is at the noise level of the tile
+constexpr double ND_TINY2 = 5.820766091346741e-11;    // 2^-34: below 2^-17 |A| the error of a column norm passes the 2^-12 band
 
 // (1) another live column within the error margin of the chosen one: nu2 of a column (thr its band edge) against the best
 __device__ __forceinline__ bool near_best(double nu2, double thr, double best, double a2)
@@ -122,8 +123,12 @@ __device__ __forceinline__ bool near_best(double nu2, double thr, double best, d
     const double margin = MREL * (thr + THR_HI * a2) + 4.547473508864641e-13 /* 2^-41 */ * sqrt(a2 * (best > 0.0 ? best : 0.0));
     return nu2 >= best - margin;
 }
-// (2) the downdated squared norm nn passed the recompute test (nn <= thr) inside the band around Eigen's threshold
-__device__ __forceinline__ bool in_recompute_band(double nn, double thr) { return nn > thr * (1.0 - 2.0 * MREL); }
+// (2) the downdated squared norm nn passed the recompute test (nn <= thr) inside the band around Eigen's threshold, or on a
+// column so small against |A| that the band does not cover the error of its norm
+__device__ __forceinline__ bool in_recompute_band(double nn, double thr, double a2)
+{
+    return nn > thr * (1.0 - 2.0 * MREL) || thr <= (THR_HI * ND_TINY2) * a2;
+}
 // (3) degenerate reflector on a non-empty tail, (4) |x0| too small to fix the sign of beta, (5) pivot at the noise level
 __device__ __forceinline__ bool unclear_reflector(double xk, double tsq, bool tail, bool pivoting, double a2)
 {
