@@ -291,6 +291,11 @@ qrk_status qrk_bd_time_factorize(qrk_bd_plan plan, const double* tiles, double* 
                                  double* r_vals, int32_t* perm, int nsets, int iters,
                                  float* avg_ms);
 
+/* Name of the factorisation kernel `plan` launches for its tiles (which = 0: the kernel of the largest size class present),
+ * taken from the same dispatch qrk_bd_factorize uses; for reports (bench.py's roofline.kernel).  The pointer is static. */
+const char* qrk_bd_kernel_name(qrk_bd_plan plan, int which);
+
+
 #ifdef __cplusplus
 }
 #endif

@@ -15,7 +15,9 @@ from dataclasses import dataclass
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libqrk_oracle.so")
+# QRK_ORACLE_LIB (bench.py's cpu_baseline children only): the -O3 -march=native timing copy of the same source, built by
+# bench.py on the machine it times
+_LIB_PATH = os.environ.get("QRK_ORACLE_LIB") or os.path.join(_HERE, "libqrk_oracle.so")
 
 SUCCESS, NUMERICAL_ISSUE, NO_CONVERGENCE, INVALID_INPUT = 0, 1, 2, 3
 FULL_Q, BLOCK_DIAGONAL_Q = 0, 1
@@ -24,6 +26,8 @@ COLPIV, NOPIV = 0, 1
 
 def build(force: bool = False) -> str:
     """Compile the oracle with gcc (no-op when up to date)."""
+    if os.environ.get("QRK_ORACLE_LIB"):
+        return _LIB_PATH
     src = os.path.join(_HERE, "qrk_oracle.c")
     hdr = os.path.join(_HERE, "qrk_oracle.h")
     stale = (not os.path.exists(_LIB_PATH)) or any(

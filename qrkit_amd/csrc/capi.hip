@@ -1116,4 +1116,20 @@ qrk_status qrk_bd_time_factorize(qrk_bd_plan p, const double* tiles, double* q_v
     return st;
 }
 
+const char* qrk_bd_kernel_name(qrk_bd_plan p, int which)
+{
+    (void)which;
+    if (!p) return "";
+    qrk_handle h = p->h;
+    const bool piv = p->solver == QRK_COLPIV_HOUSEHOLDER;
+    if (h->force_exact) return piv ? "qrk::bdqr_exact_kernel<true>" : "qrk::bdqr_exact_kernel<false>";
+    if (p->max_dim > QRK_COL_MAX_DIM) return "qrk::bdqr_wg_kernel";
+    if (p->max_dim > 32) return "qrk::bdqr_col_kernel";
+    if (p->uniform && p->max_dim <= 16 && p->r >= p->c && h->use_small_kernel)
+        return piv ? "qrk::bdqr_small_kernel<G, true>" : "qrk::bdqr_small_kernel<G, false>";
+    // (tau is not stored by the measurement entry point and by callers that pass hcoeffs = NULL: the <.., false> instantiation)
+    if (p->uniform && p->r == 32 && p->c == 32) return piv ? "qrk::bdqr_pair32_kernel<true, false>" : "qrk::bdqr_pair32_kernel<false, false>";
+    return piv ? "qrk::bdqr_pair_kernel<false, true, true>" : "qrk::bdqr_pair_kernel<false, false, true>";
+}
+
 }  // extern "C"

@@ -308,6 +308,11 @@ class BlockDiagonalSparseQR:
         assert self.m_isInitialized, "Decomposition is not initialized."
         return self._perm[:self._cols].cpu().numpy()
 
+    def colsPermutationDevice(self) -> torch.Tensor:
+        """The same indices as an int32 tensor on the device (no copy)."""
+        assert self.m_isInitialized, "Decomposition is not initialized."
+        return self._perm[:self._cols]
+
     def rowsPermutation(self) -> np.ndarray:
         assert self.m_isInitialized, "Decomposition is not initialized."
         return self._rowperm
