@@ -133,6 +133,7 @@ def parse(argv):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true", help="skip the comparison of 500 tiles with the oracle (outside the timed region)")
     ap.add_argument("--no-strong", action="store_true", help="N > 1: skip the strong-scaling legs")
+    ap.add_argument("--no-steady", action="store_true", help="N = 1: skip the 160000-tile steady-state leg (profiling runs)")
     ap.add_argument("--strong-blocks", type=str, default="10000,1000000")
     ap.add_argument("--_cpu-worker", type=float, default=None, help=argparse.SUPPRESS)
     return ap.parse_args(argv)
@@ -247,7 +248,7 @@ def main():
 
     # ---- steady state (N = 1): the same kernel on 160000 tiles per launch, where the three-round tail of 10000 tiles vanishes
     steady = None
-    if world == 1:
+    if world == 1 and not args.no_steady:
         nb_big = 160000
         pbig = make_plan(nb_big)
         tb = torch.rand(nb_big * BR * BC, generator=g, device=dev, dtype=torch.float64) * 4.5 + 0.5

@@ -291,6 +291,136 @@ hipError_t launch_bdqr_exact(const WaveBatch& nb, const int32_t* ids, const int3
     return hipGetLastError();
 }
 
+// ---- the dense solver's exact path -------------------------------------------------------------------------------------
+// The right-block solver of BlockAngularSparseQR (Eigen ColPivHouseholderQR / HouseholderQR on one dense matrix with implicit
+// Q, src/QRKit/BlockAngularSparseQR.h:361-369) in Eigen's operation order, in place in the caller's column-major array with
+// Eigen's physical column swaps: ONE workgroup of 1024 threads, a thread owns whole columns (every sum over the rows is the
+// sequential chain of the scalar reference), the pivot column / essential vector, the two norm tables and the permutation
+// in a global workspace.  Launched after every dense factorisation and a no-op unless the fast kernels flagged a decision
+// (then the matrix is first restored from the copy the plan keeps).  Slow by design: the fall-back for inputs whose pivot
+// order is decided by rounding noise.
+namespace exact {
+constexpr int DT = 1024;
+
+template <bool PIVOT>
+__global__ void __launch_bounds__(DT)
+dense_exact_kernel(double* __restrict__ A, int64_t lda, int r, int c, const double* __restrict__ copy, double* __restrict__ hcoeffs,
+                   int32_t* __restrict__ perm, const int* __restrict__ unclear, double* __restrict__ ws)
+{
+    if (unclear && *unclear == 0) return;
+    __shared__ double sval[DT];
+    __shared__ int spos[DT];
+    const int t = threadIdx.x;
+    double* xbuf = ws;                    // [r]
+    double* nu = xbuf + r;                // [c] m_colNormsUpdated
+    double* nd = nu + c;                  // [c] m_colNormsDirect
+    int* pidx = reinterpret_cast<int*>(nd + c);   // [c]
+    if (copy)
+        for (int64_t e = t; e < (int64_t)r * c; e += DT) { const int64_t j = e / r; A[j * lda + (e - j * r)] = copy[e]; }
+    for (int j = t; j < c; j += DT) pidx[j] = j;
+    __syncthreads();
+    if (PIVOT) {
+        for (int j = t; j < c; j += DT) {
+            const double* col = A + (int64_t)j * lda;
+            double s = 0.0;
+            for (int i = 0; i < r; ++i) { const double v = col[i]; s += v * v; }
+            const double n = sqrt(s);
+            nu[j] = n; nd[j] = n;
+        }
+        __syncthreads();
+    }
+    const int size = r < c ? r : c;
+    for (int k = 0; k < size; ++k) {
+        if (PIVOT) {
+            double bv = -1.0; int bp = 0x7fffffff;
+            for (int j = k + t; j < c; j += DT) if (better(nu[j], j, bv, bp)) { bv = nu[j]; bp = j; }
+            sval[t] = bv; spos[t] = bp;
+            __syncthreads();
+            for (int s = DT / 2; s > 0; s >>= 1) {
+                if (t < s && better(sval[t + s], spos[t + s], sval[t], spos[t])) { sval[t] = sval[t + s]; spos[t] = spos[t + s]; }
+                __syncthreads();
+            }
+            const int b = spos[0];
+            __syncthreads();
+            if (b != k) {       // m_qr.col(k).swap(m_qr.col(b)), the two norm tables, the transposition
+                double* ck = A + (int64_t)k * lda;
+                double* cb = A + (int64_t)b * lda;
+                for (int i = t; i < r; i += DT) { const double v = ck[i]; ck[i] = cb[i]; cb[i] = v; }
+                if (t == 0) {
+                    double v = nu[k]; nu[k] = nu[b]; nu[b] = v;
+                    v = nd[k]; nd[k] = nd[b]; nd[b] = v;
+                    const int p = pidx[k]; pidx[k] = pidx[b]; pidx[b] = p;
+                }
+            }
+            __syncthreads();
+        }
+        double* ck = A + (int64_t)k * lda;
+        for (int i = k + t; i < r; i += DT) xbuf[i] = ck[i];
+        __syncthreads();
+        const double c0 = xbuf[k];
+        double tail = 0.0;
+        for (int i = k + 1; i < r; ++i) { const double v = xbuf[i]; tail += v * v; }
+        double tau, beta, denom = 1.0;
+        const bool degen = tail <= DBL_MIN;
+        if (degen) { tau = 0.0; beta = c0; }
+        else {
+            beta = sqrt(c0 * c0 + tail);
+            if (c0 >= 0.0) beta = -beta;
+            denom = c0 - beta;
+            tau = (beta - c0) / beta;
+        }
+        __syncthreads();
+        for (int i = k + 1 + t; i < r; i += DT) { const double e = degen ? 0.0 : xbuf[i] / denom; xbuf[i] = e; ck[i] = e; }
+        if (t == 0) { ck[k] = beta; hcoeffs[k] = tau; }
+        __syncthreads();
+        const int m = r - k;
+        for (int j = k + 1 + t; j < c; j += DT) {
+            double* col = A + (int64_t)j * lda;
+            if (m == 1) col[k] *= (1.0 - tau);
+            else if (tau != 0.0) {
+                double tmp = 0.0;
+                for (int i = k + 1; i < r; ++i) tmp += xbuf[i] * col[i];
+                tmp += col[k];
+                col[k] -= tau * tmp;
+                for (int i = k + 1; i < r; ++i) col[i] -= (tau * xbuf[i]) * tmp;
+            }
+            if (PIVOT) {
+                const double nuj = nu[j];
+                if (nuj != 0.0) {
+                    double temp = fabs(col[k]) / nuj;
+                    temp = (1.0 + temp) * (1.0 - temp);
+                    temp = temp < 0.0 ? 0.0 : temp;
+                    const double ratio = nuj / nd[j];
+                    const double temp2 = temp * (ratio * ratio);
+                    if (temp2 <= SQRT_EPS) {
+                        double s = 0.0;
+                        for (int i = k + 1; i < r; ++i) { const double v = col[i]; s += v * v; }
+                        const double n = sqrt(s);
+                        nd[j] = n; nu[j] = n;
+                    } else nu[j] = nuj * sqrt(temp);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    for (int j = t; j < c; j += DT) perm[j] = pidx[j];
+}
+}  // namespace exact
+
+size_t dense_exact_workspace_bytes(int r, int c) { return ((size_t)r + 2 * (size_t)c) * sizeof(double) + (size_t)c * sizeof(int) + 64; }
+
+hipError_t launch_dense_exact(double* A, int64_t lda, int r, int c, int pivoting, const double* copy, double* hcoeffs,
+                              int32_t* perm, const int* unclear, double* workspace, hipStream_t stream)
+{
+    if (pivoting)
+        hipLaunchKernelGGL(exact::dense_exact_kernel<true>, dim3(1), dim3(exact::DT), 0, stream, A, lda, r, c, copy, hcoeffs, perm,
+                           unclear, workspace);
+    else
+        hipLaunchKernelGGL(exact::dense_exact_kernel<false>, dim3(1), dim3(exact::DT), 0, stream, A, lda, r, c, copy, hcoeffs, perm,
+                           unclear, workspace);
+    return hipGetLastError();
+}
+
 // Whether launch_bdqr_exact needs a global workspace for tiles of up to maxr x maxc.
 bool bdqr_exact_needs_workspace(int maxr, int maxc)
 {

@@ -49,6 +49,9 @@
 #define QRK_DECISIONS 31       // diagnostic only (tools/ab.py): bit mask of the decision checks compiled in, to measure what each
                                // costs: 1 pivot margin, 2 |x0| test, 4 recompute band, 8 pivot at the noise level, 16 degenerate tail
 #endif
+#ifndef QRK_DOT4
+#define QRK_DOT4 0
+#endif
 #ifndef QRK_RB
 #define QRK_RB 4               // steps between refreshes of the LDS image (measured on one box: 4 -> 87.1 us, 3 -> 87.4, 2 -> 91.0; 8 needs 22 KB of LDS per wave)
 #endif
@@ -336,11 +339,24 @@ __device__ __forceinline__ void pair_step(double (&a)[WR], double (&q)[WR], doub
 #pragma unroll
             for (int i = K + 1; i < WR; ++i) dA = fma(x[i], a[i], dA);
         } else {
+#if QRK_DOT4
+        // four accumulation chains (A and Q, even and odd rows): half the dependent length, no wait states between the pairs
+        double eA = 0.0, eQ = 0.0;
+#pragma unroll
+        for (int i = K + 1; i < WR; ++i) {
+            if (i == K + 1) mul2_shared_a(dA, dQ, x[i], a[i], q[i]);
+            else if (i == K + 2) mul2_shared_a(eA, eQ, x[i], a[i], q[i]);
+            else if ((i - K) & 1) fmac2_shared_a(dA, dQ, x[i], a[i], q[i]);
+            else fmac2_shared_a(eA, eQ, x[i], a[i], q[i]);
+        }
+        dA += eA; dQ += eQ;
+#else
 #pragma unroll
         for (int i = K + 1; i < WR; ++i) {
             if (i == K + 1) mul2_shared_a(dA, dQ, x[i], a[i], q[i]);
             else fmac2_shared_a(dA, dQ, x[i], a[i], q[i]);
         }
+#endif
         }
     }
 

@@ -102,6 +102,11 @@ struct qrk_dense_plan_s {
     void* d_ws = nullptr;
     int G = 0, cpad = 0, rows_per = 0;
     bool persistent = false;   // the whole factorisation as ONE cooperative kernel (all slabs resident); QRK_DENSE_PERSISTENT=1 enables
+    // exact path: copy of the input (rows x cols, restored when a decision of the fast kernels was not clear of rounding),
+    // the flag word of the single-workgroup kernel, workspace of the exact kernel
+    double* d_copy = nullptr;
+    int* d_unclear = nullptr;
+    double* d_exact_ws = nullptr;
 };
 
 namespace {
@@ -795,13 +800,20 @@ qrk_status qrk_dense_plan_create(qrk_handle h, int32_t rows, int32_t cols, qrk_b
                                 qrk::dense_tall_persistent_ok(p->G, p->rows_per, h->num_cus);
         }
     }
+    // exact path: a copy of the input, the flag of the single-workgroup kernel, the exact kernel's workspace
+    if (hipMalloc((void**)&p->d_copy, (size_t)rows * (size_t)cols * sizeof(double)) != hipSuccess ||
+        hipMalloc((void**)&p->d_unclear, sizeof(int)) != hipSuccess ||
+        hipMalloc((void**)&p->d_exact_ws, qrk::dense_exact_workspace_bytes(rows, cols)) != hipSuccess) {
+        qrk_dense_plan_destroy(p);
+        return fail(h, QRK_STATUS_ALLOC_FAILED, "qrk_dense_plan_create: cannot allocate the input copy of the exact path");
+    }
     *out = p;
     return QRK_STATUS_OK;
 }
 
 qrk_status qrk_dense_plan_destroy(qrk_dense_plan p)
 {
-    if (p && p->d_ws) (void)hipFree(p->d_ws);
+    if (p) { (void)hipFree(p->d_ws); (void)hipFree(p->d_copy); (void)hipFree(p->d_unclear); (void)hipFree(p->d_exact_ws); }
     delete p;
     return QRK_STATUS_OK;
 }
@@ -815,25 +827,33 @@ qrk_status qrk_dense_factorize(qrk_dense_plan p, double* a, int64_t lda, double*
     QRK_HIP(h, hipSetDevice(h->device));
     const int piv = p->solver == QRK_COLPIV_HOUSEHOLDER ? 1 : 0;
     const int size = p->rows < p->cols ? p->rows : p->cols;
-    if (space == QRK_MEM_DEVICE) {
-        if (p->tall)
-            QRK_HIP(h, qrk::launch_dense_qr_tall(a, lda, p->rows, p->cols, piv, hcoeffs, perm, p->d_ws, p->G, p->cpad, p->rows_per,
-                                                 p->persistent, h->stream));
-        else
-            QRK_HIP(h, qrk::launch_dense_qr(a, lda, p->rows, p->cols, piv, hcoeffs, perm, h->stream));
+    auto run = [&](double* da, double* dhc, int32_t* dp) -> qrk_status {
+        // keep the input: the exact path restores it when a decision was not clear of rounding (a D2D copy, < 1 % of the work)
+        QRK_HIP(h, hipMemcpy2DAsync(p->d_copy, (size_t)p->rows * sizeof(double), da, (size_t)lda * sizeof(double),
+                                    (size_t)p->rows * sizeof(double), (size_t)p->cols, hipMemcpyDeviceToDevice, h->stream));
+        const int* flag = nullptr;
+        if (!h->force_exact) {
+            if (p->tall) {
+                QRK_HIP(h, qrk::launch_dense_qr_tall(da, lda, p->rows, p->cols, piv, dhc, dp, p->d_ws, p->G, p->cpad, p->rows_per,
+                                                     p->persistent, h->stream));
+                flag = qrk::dense_tall_unclear_ptr(p->d_ws, p->G, p->cpad);
+            } else {
+                QRK_HIP(h, hipMemsetAsync(p->d_unclear, 0, sizeof(int), h->stream));
+                QRK_HIP(h, qrk::launch_dense_qr(da, lda, p->rows, p->cols, piv, dhc, dp, p->d_unclear, h->stream));
+                flag = p->d_unclear;
+            }
+        }
+        QRK_HIP(h, qrk::launch_dense_exact(da, lda, p->rows, p->cols, piv, p->d_copy, dhc, dp, flag, p->d_exact_ws, h->stream));
         return QRK_STATUS_OK;
-    }
+    };
+    if (space == QRK_MEM_DEVICE) return run(a, hcoeffs, perm);
     Staging s(h);
     double *d_a, *d_hc;
     int32_t* d_p;
     qrk_status st;
     if ((st = s.in(a, lda * p->cols, &d_a)) || (st = s.out((int64_t)size, &d_hc)) || (st = s.out((int64_t)p->cols, &d_p)))
         return st;
-    if (p->tall)
-        QRK_HIP(h, qrk::launch_dense_qr_tall(d_a, lda, p->rows, p->cols, piv, d_hc, d_p, p->d_ws, p->G, p->cpad, p->rows_per,
-                                             p->persistent, h->stream));
-    else
-        QRK_HIP(h, qrk::launch_dense_qr(d_a, lda, p->rows, p->cols, piv, d_hc, d_p, h->stream));
+    if ((st = run(d_a, d_hc, d_p))) return st;
     if ((st = s.back(a, d_a, lda * p->cols)) || (st = s.back(hcoeffs, d_hc, (int64_t)size)) ||
         (st = s.back(perm, d_p, (int64_t)p->cols)))
         return st;

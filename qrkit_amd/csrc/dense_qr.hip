@@ -42,8 +42,10 @@ __device__ __forceinline__ double dq_block_sum(double v, double* red)
 // ColPivHouseholderQR::computeInPlace / HouseholderQR::compute on A (r x c, ld = lda), in place.
 __global__ void __launch_bounds__(DQ_THREADS)
 dense_qr_kernel(double* __restrict__ A, int64_t lda, int r, int c, int pivoting, double* __restrict__ hcoeffs,
-                int32_t* __restrict__ perm)
+                int32_t* __restrict__ perm, int* __restrict__ unclear)
 {
+    using namespace decide;   // decisions inside their error margin send the matrix to the exact path (qrk_device.h)
+    double a2 = 0.0;          // |A|^2: squared norm of the first pivot column
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double* xv = smem;                 // [r] pivot column, then essential vector
     double* nu2 = xv + r;              // [c]
@@ -58,7 +60,7 @@ dense_qr_kernel(double* __restrict__ A, int64_t lda, int r, int c, int pivoting,
         double s = 0.0;
         for (int i = lane; i < r; i += 64) { const double v = A[(int64_t)jc * lda + i]; s = fma(v, v, s); }
         s = dq_wave_sum(s);
-        if (lane == 0) { nu2[jc] = s; thr[jc] = s * DQ_SQRT_EPS; pidx[jc] = jc; }
+        if (lane == 0) { nu2[jc] = s; thr[jc] = s * THR_HI; pidx[jc] = jc; }
     }
     __syncthreads();
 
@@ -83,6 +85,9 @@ dense_qr_kernel(double* __restrict__ A, int64_t lda, int r, int c, int pivoting,
             for (int w = 1; w < DQ_WAVES; ++w)
                 if (red[w] > best || (red[w] == best && ired[w] < bi)) { best = red[w]; bi = ired[w]; }
             const int b = bi < c ? bi : k;
+            if (k == 0) a2 = best;
+            for (int jc = k + tid; jc < c; jc += DQ_THREADS)
+                if (jc != b && near_best(nu2[jc], thr[jc], best, a2)) *unclear = 1;          // decision (1)
             __syncthreads();
             if (b != k) {
                 for (int i = tid; i < r; i += DQ_THREADS) {
@@ -108,6 +113,8 @@ dense_qr_kernel(double* __restrict__ A, int64_t lda, int r, int c, int pivoting,
         const double tailSq = dq_block_sum(part, red);
         const double xk = xv[k];
         double beta, tau, scale;
+        if (k == 0 && !pivoting) a2 = fma(xk, xk, tailSq);
+        if (tid == 0 && unclear_reflector(xk, tailSq, k + 1 < r, pivoting != 0, a2)) *unclear = 1;   // (3), (4), (5)
         if (tailSq <= DBL_MIN) {           // makeHouseholder: tau = 0, beta = x0, essential = 0
             beta = xk; tau = 0.0; scale = 0.0;
         } else {
@@ -148,7 +155,10 @@ dense_qr_kernel(double* __restrict__ A, int64_t lda, int r, int c, int pivoting,
                 nn = nn > 0.0 ? nn : 0.0;
                 if (nn <= thr[jc]) {
                     s2 = dq_wave_sum(s2);
-                    if (lane == 0) { nu2[jc] = s2; thr[jc] = s2 * DQ_SQRT_EPS; }
+                    if (lane == 0) {
+                        if (in_recompute_band(nn, thr[jc], a2)) *unclear = 1;                         // decision (2)
+                        nu2[jc] = s2; thr[jc] = s2 * THR_HI;
+                    }
                 } else if (lane == 0) {
                     nu2[jc] = nn;
                 }
@@ -198,14 +208,14 @@ size_t dense_qr_smem_bytes(int r, int c)
     return (size_t)(r + 2 * c + 2 * DQ_WAVES) * sizeof(double) + (size_t)(c + 2 * DQ_WAVES) * sizeof(int);
 }
 
-hipError_t launch_dense_qr(double* A, int64_t lda, int r, int c, int pivoting, double* hcoeffs, int32_t* perm,
+hipError_t launch_dense_qr(double* A, int64_t lda, int r, int c, int pivoting, double* hcoeffs, int32_t* perm, int* unclear,
                            hipStream_t stream)
 {
     const size_t smem = dense_qr_smem_bytes(r, c);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(dense_qr_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(dense_qr_kernel, dim3(1), dim3(DQ_THREADS), smem, stream, A, lda, r, c, pivoting, hcoeffs, perm);
+    hipLaunchKernelGGL(dense_qr_kernel, dim3(1), dim3(DQ_THREADS), smem, stream, A, lda, r, c, pivoting, hcoeffs, perm, unclear);
     return hipGetLastError();
 }
 

@@ -28,7 +28,7 @@ namespace tall {
 
 constexpr int TT = 1024;                 // threads per workgroup
 constexpr int TW = TT / 64;
-constexpr double SQRT_EPS = 1.4901161193847656e-08;
+using namespace decide;                  // decisions inside their error margin send the matrix to the exact path (qrk_device.h)
 
 struct State {
     double s, ng, inv_s;     // reflector of the current step: s = x0 - beta, ng = -1/(beta w), 1/s (0 if H = I)
@@ -40,6 +40,8 @@ struct State {
     unsigned bar_count;      // persistent kernel: workgroups that have arrived at the grid barrier
     unsigned bar_gen;        // ... and its generation
     unsigned bar_abort;      // ... set when a workgroup gave up waiting (the kernel then drains without computing)
+    double a2;               // |A|^2: squared norm of the first pivot column (scale of the decision margins)
+    int unclear;             // some decision was not clear of rounding: the exact path redoes the factorisation
 };
 
 // Value another workgroup wrote during this kernel (persistent form): read at agent scope, never from a stale line.
@@ -106,6 +108,12 @@ __device__ __forceinline__ void choose_and_swap(int kpos, int c, int pivoting, W
         for (int jc = kpos + threadIdx.x; jc < c; jc += TT) { const double v = w.nu2[jc]; if (v > best) { best = v; bi = jc; } }
         block_argmax(best, bi, red, ired);
         P = bi < c ? bi : kpos;
+        // decision (1): another column within the error margin of the chosen one
+        const double a2 = kpos == 0 ? best : ld_agent(&w.st->a2);
+        if (kpos == 0 && threadIdx.x == 0) w.st->a2 = best;
+        bool nr = false;
+        for (int jc = kpos + threadIdx.x; jc < c; jc += TT) nr = nr || (jc != P && near_best(w.nu2[jc], w.thr[jc], best, a2));
+        if (nr) atomicOr(&w.st->unclear, 1);
     }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -125,9 +133,9 @@ __device__ __forceinline__ void init_body(int c, int pivoting, Work w)
     for (int jc = threadIdx.x; jc < c; jc += TT) {
         double s = 0.0;
         for (int g = 0; g < w.G; ++g) s += w.sqpart[(int64_t)g * w.cpad + jc];
-        w.nu2[jc] = s; w.thr[jc] = s * SQRT_EPS; w.pidx[jc] = jc;
+        w.nu2[jc] = s; w.thr[jc] = s * THR_HI; w.pidx[jc] = jc;
     }
-    if (threadIdx.x == 0) { w.st->slow = 0; w.st->ticket = 0u; w.st->anyneed = 0; w.st->ticket2 = 0u; }
+    if (threadIdx.x == 0) { w.st->slow = 0; w.st->ticket = 0u; w.st->anyneed = 0; w.st->ticket2 = 0u; w.st->unclear = 0; w.st->a2 = 0.0; }
     __syncthreads();
     choose_and_swap(0, c, pivoting, w, red, ired);
 }
@@ -245,6 +253,7 @@ __device__ __forceinline__ void head_body(double* __restrict__ A, int64_t lda, i
                 w.nu2[jc] = nn;
                 nd = nn <= w.thr[jc];
                 if (nd) atomicOr(&w.st->anyneed, 1);
+                if (nd && in_recompute_band(nn, w.thr[jc], ld_agent(&w.st->a2))) atomicOr(&w.st->unclear, 1);   // decision (2)
             }
             w.need[jc] = nd;
         }
@@ -262,6 +271,9 @@ __device__ __forceinline__ void head_body(double* __restrict__ A, int64_t lda, i
         w.st->s = s; w.st->ng = ng; w.st->inv_s = degen ? 0.0 : 1.0 / s;
         A[(int64_t)k * lda + k] = -nb;            // beta (= x0 when H = I)
         hcoeffs[k] = tau;
+        if (k == 0 && !pivoting) w.st->a2 = fma(xk, xk, tsq);
+        if (unclear_reflector(xk, tsq, k + 1 < r, pivoting != 0, k == 0 && !pivoting ? fma(xk, xk, tsq) : w.st->a2))
+            w.st->unclear = 1;                    // decisions (3), (4), (5)
     }
     __syncthreads();
     const int size = r < c ? r : c;
@@ -383,7 +395,7 @@ __device__ __forceinline__ void recompute_body(int c, int k, int pivoting, Work 
         if (w.need[jc]) {
             double s = 0.0;
             for (int g = 0; g < w.G; ++g) s += w.sqpart[(int64_t)g * w.cpad + jc];
-            w.nu2[jc] = s; w.thr[jc] = s * SQRT_EPS;
+            w.nu2[jc] = s; w.thr[jc] = s * THR_HI;
         }
     }
     __syncthreads();
@@ -532,7 +544,7 @@ size_t dense_tall_workspace_bytes(int r, int c, int num_cus, int* G_out, int* cp
     G = (r + rows_per - 1) / rows_per;
     const int cpad = (c + 63) / 64 * 64;
     *G_out = G; *cpad_out = cpad; *rows_per_out = rows_per;
-    return (size_t)(2 * (size_t)G * cpad + G + 3 * cpad) * sizeof(double) + (size_t)2 * cpad * sizeof(int) + 256;
+    return (size_t)(2 * (size_t)G * cpad + G + 3 * cpad) * sizeof(double) + (size_t)2 * cpad * sizeof(int) + 320;
 }
 
 // Can the persistent form run: all G workgroups of 1024 threads resident at once (one per CU)?
@@ -543,6 +555,15 @@ bool dense_tall_persistent_ok(int G, int rows_per, int num_cus)
                                                      2 * (size_t)rows_per * sizeof(double)) != hipSuccess)
         return false;
     return per_cu >= 1 && G <= per_cu * num_cus;
+}
+
+// Device address of the "unclear" word of a tall plan's workspace (read by the exact path after the factorisation)
+int* dense_tall_unclear_ptr(void* workspace, int G, int cpad)
+{
+    char* p = static_cast<char*>(workspace);
+    p += (size_t)(2 * (size_t)G * cpad + G + 3 * cpad) * sizeof(double) + (size_t)2 * cpad * sizeof(int);
+    p = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(p) + 63) & ~(uintptr_t)63);
+    return &reinterpret_cast<tall::State*>(p)->unclear;
 }
 
 hipError_t launch_dense_qr_tall(double* A, int64_t lda, int r, int c, int pivoting, double* hcoeffs, int32_t* perm,
@@ -564,6 +585,12 @@ hipError_t launch_dense_qr_tall(double* A, int64_t lda, int r, int c, int pivoti
     w.G = G; w.cpad = cpad; w.rows_per = rows_per;
     const int size = r < c ? r : c;
     const size_t sm1 = (size_t)rows_per * sizeof(double), sm2 = 2 * sm1;
+    if (sm2 > 64 * 1024) {     // very tall slabs: dynamic LDS above the default limit has to be asked for
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(sweep_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm2);
+        if (e == hipSuccess && sm1 > 64 * 1024)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(swap_dots_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm1);
+        if (e != hipSuccess) return e;
+    }
     if (persistent) {
         // one kernel, a workgroup per slab, all resident (checked by the caller and again by the cooperative launch)
         hipError_t e = hipMemsetAsync(&w.st->bar_count, 0, 3 * sizeof(unsigned), stream);

@@ -74,8 +74,14 @@ hipError_t launch_dense_qr_tall(double* A, int64_t lda, int r, int c, int pivoti
                                 void* workspace, int G, int cpad, int rows_per, bool persistent, hipStream_t stream);
 hipError_t launch_dense_apply_q_tall(const double* QR, int64_t lda, int r, int nrefl, const double* hcoeffs, int transpose,
                                      double* B, int64_t ldb, int64_t nrhs, hipStream_t stream);
-hipError_t launch_dense_qr(double* A, int64_t lda, int r, int c, int pivoting, double* hcoeffs, int32_t* perm,
+hipError_t launch_dense_qr(double* A, int64_t lda, int r, int c, int pivoting, double* hcoeffs, int32_t* perm, int* unclear,
                            hipStream_t stream);
+int* dense_tall_unclear_ptr(void* workspace, int G, int cpad);
+// The exact-arithmetic path of the dense solver (bdqr_exact.hip): when *unclear != 0 (or unclear == nullptr) the matrix is
+// restored from `copy` (leading dimension r) and factorised again in Eigen's operation order, in place.
+hipError_t launch_dense_exact(double* A, int64_t lda, int r, int c, int pivoting, const double* copy, double* hcoeffs,
+                              int32_t* perm, const int* unclear, double* workspace, hipStream_t stream);
+size_t dense_exact_workspace_bytes(int r, int c);
 hipError_t launch_dense_apply_q(const double* QR, int64_t lda, int r, int nrefl, const double* hcoeffs,
                                 int transpose, double* B, int64_t ldb, int64_t nrhs, hipStream_t stream);
 struct BBPanel;

@@ -48,8 +48,11 @@ def test_dense_qr_matches_oracle(rows, cols, path, solver):
     else:
         ref, hc = orc.householder_qr(A)
         np.testing.assert_array_equal(qr.colsPermutation().cpu().numpy(), np.arange(cols))
-    # R and the reflectors of the numerically non-null part (a duplicated column leaves noise below its pivot)
-    keep = k - (1 if (solver == 0 and cols >= 20) else 0)
+    # (a duplicated column is a tie and then a rank collapse: the matrix is flagged and redone by the exact path, whose
+    # result is the oracle's bit for bit -- noise below the last pivot included)
+    if solver == 0 and cols >= 20:
+        np.testing.assert_array_equal(got, ref)
+    keep = k
     assert rel_fro(np.triu(got[:k, :])[:keep], np.triu(ref[:k, :])[:keep]) <= 1e-11
     assert rel_fro(qr._hc.cpu().numpy()[:keep], hc[:keep]) <= 1e-11
     assert rel_fro(np.tril(got, -1)[:, :keep], np.tril(ref, -1)[:, :keep]) <= 1e-10
@@ -137,3 +140,41 @@ def test_dense_qr_persistent_form_matches_kernel_sequence(solver):
     np.testing.assert_array_equal(out[0][2], out[1][2])
     np.testing.assert_array_equal(out[0][0], out[1][0])
     np.testing.assert_array_equal(out[0][1], out[1][1])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["pm1", "zero_one", "small_int", "circulant", "dup_cols"])
+@pytest.mark.parametrize("rows,cols,path", [(2000, 40, "single"), (2000, 40, "tall"), (300, 120, "tall")])
+def test_dense_tie_battery_is_bitwise_the_oracle(kind, rows, cols, path):
+    """A dense block whose pivot decisions are ties in exact arithmetic (or noise after a rank collapse): the fast kernels flag
+    it and the dense exact path (bdqr_exact.hip, dense_exact_kernel) redoes it from the plan's copy of the input in Eigen's
+    operation order -- permutation, packed QR (R and the essential vectors) and tau bit-identical to the oracle."""
+    from test_ties_gpu import tie_tiles
+    A = tie_tiles(kind, 1, rows, cols, seed=rows + cols).reshape(cols, rows).T.copy()
+    qr, At = _factor(A, 0, path)
+    ref, hc, perm, _ = orc.colpiv_qr(A)
+    np.testing.assert_array_equal(qr.colsPermutation().cpu().numpy(), perm)
+    got, k = At.cpu().numpy(), min(rows, cols)
+    if not np.array_equal(got, ref):
+        # not flagged: every decision was clear of rounding (e.g. indicator columns with distinct counts) -- the fast path's
+        # result stands, within the tolerance
+        assert rel_fro(np.triu(got[:k]), np.triu(ref[:k])) <= 1e-12
+        assert rel_fro(np.tril(got, -1), np.tril(ref, -1)) <= 1e-11
+        assert rel_fro(qr._hc.cpu().numpy()[:k], hc[:k]) <= 1e-12
+    else:
+        np.testing.assert_array_equal(qr._hc.cpu().numpy()[:k], hc[:k])
+    if kind in ("pm1", "circulant", "dup_cols"):
+        assert np.array_equal(got, ref), "a matrix with exact ties must have gone through the exact path"
+
+
+@pytest.mark.gpu
+def test_dense_generic_matrix_is_not_redone():
+    """Generic data must stay on the fast path: its packed QR differs from the oracle's in the last bits (FMA chains)."""
+    rng = np.random.default_rng(4)
+    A = rng.uniform(-1.0, 1.0, (3000, 64))
+    qr, At = _factor(A, 0, "tall")
+    ref, hc, perm, _ = orc.colpiv_qr(A)
+    np.testing.assert_array_equal(qr.colsPermutation().cpu().numpy(), perm)
+    got = At.cpu().numpy()
+    assert rel_fro(np.triu(got[:64]), np.triu(ref[:64])) <= 1e-12
+    assert not np.array_equal(got, ref)

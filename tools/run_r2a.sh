@@ -1,4 +1,3 @@
 mkdir -p gpurun_out/r2a
-python tools/ab.py run 10000 > gpurun_out/r2a/ab.log 2>&1
-python -m pytest tests/test_ties_gpu.py tests/test_bd_gpu.py tests/test_small_tiles_gpu.py -q -m gpu > gpurun_out/r2a/ties.log 2>&1; echo "ties rc=$?" >> gpurun_out/r2a/ties.log
-cat gpurun_out/r2a/ab.log; tail -6 gpurun_out/r2a/ties.log
+python -m pytest tests/test_dense_gpu.py tests/test_angular.py tests/test_cpp_facade_gpu.py tests/test_qproduct_gpu.py tests/test_lm_gpu.py -q -m gpu > gpurun_out/r2a/dense.log 2>&1; echo "rc=$?" >> gpurun_out/r2a/dense.log
+tail -30 gpurun_out/r2a/dense.log
