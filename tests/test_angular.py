@@ -77,3 +77,70 @@ def test_hip_angular_with_thin_right_solver(num_vars, m2):
     J = sp.hstack([J1, sp.csc_matrix(J2)], format="csc")
     x = np.random.default_rng(0).uniform(-1, 1, J.shape[1])
     assert rel_fro(ba.solve(J @ x), x) <= 1e-9
+
+
+@pytest.mark.gpu
+def test_configs3_composition_reduced_matches_oracle():
+    """BASELINE configs[3] shape (tiles 8x6 + dense right block, concretised in SURVEY 8(d)) at 2000 tiles x 200 dense columns
+    against the oracle's BlockAngularSparseQR::factorize (BlockAngularSparseQR.h:459-514): permutation bit-exact, R and Q^T b
+    within the tolerance."""
+    import qrkit_amd
+    nt, m2 = 2000, 200
+    vals = orc.gen_uniform(7, -1.0, 1.0, nt * 48 + 8 * nt * m2)
+    tiles, J2 = vals[:nt * 48], vals[nt * 48:].reshape(8 * nt, m2)
+    prob = orc.BDProblem.uniform(nt, 8, 6, tiles)
+    ref = orc.ba_factorize(prob, J2)
+    left = qrkit_amd.SparseBlockDiagonal.fromTiles(prob.rows, prob.cols, tiles)
+    ba = qrkit_amd.BlockAngularSparseQR()
+    ba.compute(qrkit_amd.BlockMatrix1x2(left, J2))
+    assert ba.info() == 0 and ba.rank() == ref.rank
+    np.testing.assert_array_equal(ba.colsPermutation(), ref.perm)                   # bit-exact
+    R, Rref = ba.matrixR().tocsc(), ref.R.tocsc()
+    assert abs(R - Rref).max() <= 1e-12 * abs(Rref).max()
+    b = np.random.default_rng(1).uniform(-1, 1, 8 * nt)
+    assert rel_fro(ba.applyQt(b), orc.ba_apply_qt(ref, b)) <= 1e-12
+
+
+@pytest.mark.gpu
+def test_configs3_composition_full_size_properties():
+    """BASELINE configs[3] at FULL size as a composition: 20000 diagonal tiles of 8x6 (J1: 160000 x 120000) + a dense right
+    block 160000 x 2000 (2.56 GB), one GPU.  Size-independent properties of BlockAngularSparseQR::factorize
+    (BlockAngularSparseQR.h:459-514): valid permutation P = [P1; m1 + P2], rank, Q^T [J1 | J2] P = R on sampled columns of both
+    parts, non-increasing |diag(R2)|, and the reference's own assertion -- least-squares recovery (test-qrkit.cpp:289)."""
+    import torch
+    import qrkit_amd
+    nt, m2 = 20000, 2000
+    n1, m1 = 8 * nt, 6 * nt
+    g = torch.Generator(device="cuda"); g.manual_seed(3)
+    tiles = torch.rand(nt * 48, generator=g, device="cuda", dtype=torch.float64) * 2 - 1
+    J2 = torch.rand(n1, m2, generator=g, device="cuda", dtype=torch.float64) * 2 - 1
+    left = qrkit_amd.SparseBlockDiagonal.fromTiles(np.full(nt, 8, np.int32), np.full(nt, 6, np.int32), tiles)
+    ba = qrkit_amd.BlockAngularSparseQR()
+    ba.compute(qrkit_amd.BlockMatrix1x2(left, J2))
+    assert ba.info() == 0 and ba.rank() == m1 + m2
+    P = torch.as_tensor(ba.colsPermutation().astype(np.int64), device="cuda")
+    assert bool((P.sort().values == torch.arange(m1 + m2, device="cuda")).all())
+    assert bool((P[:m1] < m1).all()) and bool((P[m1:] >= m1).all())
+    # sampled columns of J P through Q^T against the same columns of R
+    A = tiles.view(nt, 6, 8)                                   # tile t, column c, row r (column-major tiles)
+    cols = [0, 5, 77777, m1 - 1, m1, m1 + 1, m1 + 999, m1 + m2 - 1]
+    JP = torch.zeros(n1, len(cols), device="cuda", dtype=torch.float64)
+    for q, j in enumerate(cols):
+        pj = int(P[j])
+        if pj < m1:
+            t, c = divmod(pj, 6)
+            JP[8 * t:8 * t + 8, q] = A[t, c]
+        else:
+            JP[:, q] = J2[:, pj - m1]
+    QtJP = ba.applyQt(JP)
+    R = ba.matrixR().tocsc()
+    Rs = torch.as_tensor(R[:, cols].toarray(), device="cuda")
+    scale = float(Rs.abs().max())
+    assert float((QtJP - Rs).abs().max()) <= 1e-11 * scale
+    d2 = np.abs(R[m1:m1 + m2, m1:m1 + m2].diagonal())
+    assert np.all(d2[1:] <= d2[:-1] * (1 + 1e-12))             # column pivoting of the right block
+    # least-squares recovery
+    x = torch.rand(m1 + m2, generator=g, device="cuda", dtype=torch.float64) * 2 - 1
+    b = torch.bmm(A.transpose(1, 2), x[:m1].view(nt, 6, 1)).view(n1) + J2 @ x[m1:]
+    xs = ba.solve(b)
+    assert float((xs - x).norm() / x.norm()) <= 1e-9
