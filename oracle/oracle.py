@@ -428,3 +428,145 @@ def bb_apply_q(res: BBResult, v: np.ndarray, transpose: bool) -> np.ndarray:
         seg = seg + Y @ (TT @ (Y.T @ seg))
         out[idx, :] = seg
     return out if np.ndim(v) > 1 else out[:, 0]
+
+
+# ---------------------------------------------------------------- BlockedThinDenseQR / BlockedThinSparseQR
+
+class BTResult:
+    pass
+
+
+def column_density(J):
+    """SparseQROrdering::ColumnDensity (src/QRKit/SparseQROrdering.h:21-50): columns stable-sorted by their number of
+    nonzeros (ascending); returns the INDICES of the Eigen PermutationMatrix it builds, colpermIndices(origIdx) = sorted rank
+    (:43-46).  As everywhere in Eigen, (A * P)(:, j) = A(:, indices[j])."""
+    import scipy.sparse as sp
+    M = sp.csc_matrix(J)
+    nnz = np.diff(M.indptr)
+    order = np.argsort(nnz, kind="stable")           # order[rank] = original column
+    idx = np.empty(M.shape[1], dtype=np.int32)
+    idx[order] = np.arange(M.shape[1], dtype=np.int32)
+    return idx
+
+
+def _panel_yt(qr, hc, ncols):
+    """BlockedThinQRBase::computeBlockedRepresentation (BlockedThinQRBase.h:322-333): Y = unit-lower essential vectors,
+    T = -make_block_householder_triangular_factor(Y, hCoeffs)."""
+    nrows = qr.shape[0]
+    Y = np.zeros((nrows, ncols))
+    for bc in range(ncols):
+        if bc < nrows:
+            Y[bc, bc] = 1.0
+            Y[bc + 1:, bc] = qr[bc + 1:, bc]
+    T = -block_triangular_factor(Y, np.concatenate([hc, np.zeros(max(0, ncols - len(hc)))])[:ncols])
+    return Y, T
+
+
+def _update_mat(mat, r0, Y, T, c_from, c_to):
+    """BlockedThinQRBase::updateMat (BlockedThinQRBase.h:309-319): mat(rows of the block, j) += Y (T^T (Y^T mat(..., j)))."""
+    rows = slice(r0, r0 + Y.shape[0])
+    blk = mat[rows, c_from:c_to]
+    mat[rows, c_from:c_to] = blk + Y @ (T.T @ (Y.T @ blk))
+
+
+def bt_dense_qr(A, block_cols: int = 2) -> BTResult:
+    """BlockedThinDenseQR::compute (src/QRKit/BlockedThinDenseQR.h:104-176): panels of `block_cols` columns at
+    (solvedCols, solvedCols), HouseholderQR of the panel, Y/T, block-reflector update of columns solvedCols.. of m_R in place;
+    identity permutations (:139-142)."""
+    R = np.array(A, dtype=np.float64, order="F")
+    rows, cols = R.shape
+    res = BTResult()
+    res.blocks = []
+    solved = 0
+    while solved < cols:
+        new = block_cols
+        nrows = rows - solved
+        if solved + new >= cols:                      # updateBlockInfo (:145-156)
+            new = cols - solved
+        qr, hc = householder_qr(R[solved:solved + nrows, solved:solved + new])
+        Y, T = _panel_yt(qr, hc, new)
+        res.blocks.append((solved, Y, T))
+        _update_mat(R, solved, Y, T, solved, cols)
+        solved += new
+    res.R = R
+    res.perm = np.arange(cols, dtype=np.int32)
+    res.rowperm = np.arange(rows, dtype=np.int32)
+    res.rank = cols
+    res.rows, res.cols = rows, cols
+    return res
+
+
+def bt_sparse_qr(J, block_cols: int = 2) -> BTResult:
+    """BlockedThinSparseQR::compute (src/QRKit/BlockedThinSparseQR.h:105-283): ColumnDensity column ordering and
+    AsBandedAsPossible row ordering (:168-201), densify (:120), then per panel: rows from the sparsity of the panel's columns
+    (updateBlockInfo, :203-238), ColPivHouseholderQR of the panel (a copy), nonzero / zero pivot column bookkeeping (:250-256),
+    Y/T, update of columns idxCol.. of the dense matrix, R built column-wise from the rows above the diagonal position and the
+    panel's packed QR (:271-279); colsPermutation = ColumnDensity permutation * Householder column permutation (:151-159)."""
+    import scipy.sparse as sp
+    M = sp.csc_matrix(J)
+    rows, cols = M.shape
+    cperm = column_density(M)
+    pm = sp.csc_matrix(M[:, cperm])                   # m_pmat = mat * m_outputPerm_c
+    R0 = sp.csr_matrix(pm); R0.sort_indices()
+    has, rperm = as_banded_as_possible(rows, cols, R0.indptr, R0.indices)
+    if not has:
+        rperm = np.arange(rows, dtype=np.int32)
+    inv = np.empty_like(rperm); inv[rperm] = np.arange(rows, dtype=rperm.dtype)
+    pm = sp.csc_matrix(sp.csr_matrix(pm)[inv])        # m_pmat = m_rowPerm * m_pmat: row i moves to row rperm[i]
+    pm.sort_indices()
+    D = pm.toarray(order="F")                         # m_pmatDense
+    Rout = np.zeros((rows, cols))
+    res = BTResult()
+    res.blocks = []
+    nnz_idx, zero_idx = [], []
+    nzp = 0                                           # m_nonzeroPivots
+    solved, new_piv, prev_rows = 0, 0, 0
+    while solved < cols:
+        new = block_cols
+        if solved + new >= cols:
+            new = cols - solved
+            nrows = rows - nzp
+        else:
+            biggest = 0
+            for c in range(new):
+                col = pm.indices[pm.indptr[solved + c]:pm.indptr[solved + c + 1]]
+                end = int(col[-1]) if len(col) else 0
+                biggest = max(biggest, end)
+            nrows = biggest - nzp + 1
+            if nrows < prev_rows - new_piv:
+                nrows = prev_rows - new_piv
+        r0, c0 = nzp, solved
+        Ji = D[r0:r0 + nrows, c0:c0 + new].copy()
+        qr, hc, p, nz = colpiv_qr(Ji)
+        nnz_idx += [c0 + int(p[c]) for c in range(nz)]
+        zero_idx += [c0 + int(p[c]) for c in range(nz, new)]
+        Y, T = _panel_yt(qr, hc, new)
+        res.blocks.append((r0, Y, T))
+        _update_mat(D, r0, Y, T, c0, cols)
+        for bc in range(new):
+            Rout[:nzp, nzp + bc] = D[:nzp, c0 + int(p[bc])]
+            for br in range(bc + 1):
+                if br < qr.shape[0]:
+                    Rout[nzp + br, nzp + bc] = qr[br, bc]
+        new_piv = nz
+        nzp += nz
+        prev_rows = nrows
+        solved += new
+    house = np.array(nnz_idx + zero_idx, dtype=np.int32)
+    res.R = Rout
+    res.perm = cperm[house].astype(np.int32)          # (P1 * P2).indices[j] = P1.indices[P2.indices[j]]
+    res.rowperm = rperm.astype(np.int32)
+    res.rank = nzp
+    res.rows, res.cols = rows, cols
+    return res
+
+
+def bt_apply_q(res: BTResult, v: np.ndarray, transpose: bool) -> np.ndarray:
+    """SparseBlockYTY sequenceYTY (SparseBlockYTY.h:111-138) for the thin solvers: Q^T v applies the blocks in order with T^T,
+    Q v in reverse order with T (numZeros = 0: one row segment per block)."""
+    out = np.array(v, dtype=np.float64).reshape(res.rows, -1).copy()
+    seq = res.blocks if transpose else res.blocks[::-1]
+    for r0, Y, T in seq:
+        seg = out[r0:r0 + Y.shape[0], :]
+        out[r0:r0 + Y.shape[0], :] = seg + Y @ ((T.T if transpose else T) @ (Y.T @ seg))
+    return out if np.ndim(v) > 1 else out[:, 0]

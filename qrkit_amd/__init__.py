@@ -9,9 +9,9 @@ from . import _capi
 from ._capi import (BLOCK_DIAGONAL_Q, COLPIV_HOUSEHOLDER, FULL_Q, HOUSEHOLDER, INFO_INVALID_INPUT,
                     INFO_SUCCESS, QrkError)
 from .banded import BandedBlockedSparseQR
-from .angular import BlockAngularSparseQR, BlockMatrix1x2, BlockedThinDenseQR, DenseColPivQR
+from .angular import BlockAngularSparseQR, BlockMatrix1x2, BlockedThinDenseQR, BlockedThinSparseQR, DenseColPivQR
 from .qproduct import QProduct
 from .solvers import BlockDiagonalSparseQR, Context, SparseBlockDiagonal
 
-__all__ = ["_capi", "QrkError", "Context", "SparseBlockDiagonal", "BlockDiagonalSparseQR", "BlockMatrix1x2", "BlockAngularSparseQR", "DenseColPivQR", "BlockedThinDenseQR", "QProduct", "BandedBlockedSparseQR", "FULL_Q",
+__all__ = ["_capi", "QrkError", "Context", "SparseBlockDiagonal", "BlockDiagonalSparseQR", "BlockMatrix1x2", "BlockAngularSparseQR", "DenseColPivQR", "BlockedThinDenseQR", "BlockedThinSparseQR", "QProduct", "BandedBlockedSparseQR", "FULL_Q",
            "BLOCK_DIAGONAL_Q", "COLPIV_HOUSEHOLDER", "HOUSEHOLDER", "INFO_SUCCESS", "INFO_INVALID_INPUT"]

@@ -114,17 +114,21 @@ class DenseColPivQR:
 
 
 class BlockedThinDenseQR(DenseColPivQR):
-    """QRKit::BlockedThinDenseQR / BlockedThinSparseQR (BlockedThinDenseQR.h:53-176, BlockedThinSparseQR.h:105-283):
-    Householder QR of a thin dense matrix without column pivoting, Q implicit.  The reference walks panels of
-    SuggestedBlockCols columns (HouseholderQR of the panel, Y/T, block-reflector update of the columns to the right);
-    the reflectors of that chain are those of one HouseholderQR of the whole matrix, which the device computes."""
+    """QRKit::BlockedThinDenseQR (BlockedThinDenseQR.h:53-176): Householder QR of a thin dense matrix without column
+    pivoting, Q implicit, identity permutations (:139-142).  The reference walks panels of SuggestedBlockCols columns
+    (HouseholderQR of the panel at (solvedCols, solvedCols), Y/T, block-reflector update of the columns from the panel on,
+    BlockedThinQRBase.h:309-333).  The reflectors of that chain ARE the reflectors of one HouseholderQR of the whole matrix
+    (a panel's columns arrive updated by every earlier reflector, and inside the panel HouseholderQR is the same recurrence),
+    so the device computes that factorisation (qrk_dense_*, QRK_HOUSEHOLDER) and keeps Q as essential vectors + tau instead
+    of per-panel (Y, T): R and every product with Q agree with the panel chain to rounding (tests/test_thin_gpu.py compares
+    with the oracle's restatement of the chain); `suggestedBlockCols` therefore does not change the result."""
 
     def __init__(self, context: Context, suggestedBlockCols: int = 2):
         super().__init__(context, capi.HOUSEHOLDER)
         self.suggestedBlockCols = suggestedBlockCols
 
     def compute(self, A):
-        if hasattr(A, "toarray"):        # BlockedThinSparseQR: the same chain fed from a sparse matrix (:131)
+        if hasattr(A, "toarray"):
             A = A.toarray()
         if not isinstance(A, torch.Tensor):
             A = _colmajor(torch.from_numpy(np.ascontiguousarray(A, dtype=np.float64)).to(self._ctx.device))
@@ -165,6 +169,206 @@ class BlockedThinDenseQR(DenseColPivQR):
         self.applyQ(y, transpose=True)
         z = _colmajor(y[:cols, :].clone())
         return self.solveR(z)
+
+
+def column_density_indices(mat) -> np.ndarray:
+    """SparseQROrdering::ColumnDensity (SparseQROrdering.h:21-50): columns stable-sorted by their number of nonzeros, as the
+    indices of the Eigen permutation it builds (indices[original column] = sorted rank); (A * P)(:, j) = A(:, indices[j])."""
+    import scipy.sparse as sp
+    M = sp.csc_matrix(mat)
+    order = np.argsort(np.diff(M.indptr), kind="stable")
+    idx = np.empty(M.shape[1], dtype=np.int32)
+    idx[order] = np.arange(M.shape[1], dtype=np.int32)
+    return idx
+
+
+def as_banded_as_possible_indices(mat):
+    """SparseQROrdering::AsBandedAsPossible (SparseQROrdering.h:52-120): rows stable-sorted by the column of their first
+    nonzero (empty rows last); returns (indices, hasPermutation) with indices[original row] = new row."""
+    import scipy.sparse as sp
+    M = sp.csr_matrix(mat)
+    M.sort_indices()
+    rows, cols = M.shape
+    start = np.full(rows, cols, dtype=np.int64)
+    nz = np.diff(M.indptr) > 0
+    start[nz] = M.indices[M.indptr[:-1][nz]]
+    has = bool(np.any(start[1:] < start[:-1]))
+    order = np.argsort(start, kind="stable") if has else np.arange(rows)
+    idx = np.empty(rows, dtype=np.int32)
+    idx[order] = np.arange(rows, dtype=np.int32)
+    return idx, has
+
+
+class BlockedThinSparseQR:
+    """QRKit::BlockedThinSparseQR (src/QRKit/BlockedThinSparseQR.h:105-283) on the device.
+
+    analyzePattern (:168-201): ColumnDensity column ordering, AsBandedAsPossible row ordering (integer logic, host).
+    compute (:105-165): the permuted matrix is densified on the device and factorised panel by panel; a panel of
+    SuggestedBlockCols columns takes the rows its sparsity pattern says (updateBlockInfo, :203-238), is factorised by the
+    column-pivoted dense solver (qrk_dense_factorize on a copy, as the reference's Ji; its decisions go through the exact
+    path like every other pivoted factorisation), its reflectors are applied to the columns to the right
+    (qrk_dense_apply_q on the row range of the panel -- the block-reflector update of BlockedThinQRBase.h:309-319 in
+    reflector form), and its columns of R are the rows above the diagonal position plus the panel's upper triangle
+    (:271-279).  colsPermutation() = ColumnDensity permutation * Householder column permutation with the zero-pivot columns
+    last (:151-159, :250-256); rank() = nonzero pivots (Eigen's threshold on the panel's pivots)."""
+
+    def __init__(self, context: Context, suggestedBlockCols: int = 2):
+        self._ctx = context
+        self.suggestedBlockCols = int(suggestedBlockCols)
+        self._plans = {}
+        self.m_isInitialized = False
+
+    def _plan(self, rows, cols):
+        key = (rows, cols)
+        if key not in self._plans:
+            pl = C.c_void_p()
+            capi.check(capi.lib().qrk_dense_plan_create(self._ctx.handle, rows, cols, capi.COLPIV_HOUSEHOLDER, C.byref(pl)),
+                       self._ctx.handle)
+            self._plans[key] = pl
+        return self._plans[key]
+
+    def compute(self, mat):
+        import scipy.sparse as sp
+        dev = self._ctx.device
+        M = sp.csc_matrix(mat)
+        rows, cols = M.shape
+        cperm = column_density_indices(M)
+        pm = sp.csc_matrix(M[:, cperm])                               # m_pmat = mat * m_outputPerm_c
+        rperm, has = as_banded_as_possible_indices(pm)
+        if has:
+            inv = np.empty_like(rperm); inv[rperm] = np.arange(rows, dtype=rperm.dtype)
+            pm = sp.csc_matrix(sp.csr_matrix(pm)[inv])                # m_pmat = m_rowPerm * m_pmat
+        pm.sort_indices()
+        D = torch.from_numpy(np.asfortranarray(pm.toarray()).T.copy()).to(dev).t()   # m_pmatDense, column-major on the device
+        Rout = torch.zeros(rows, cols, dtype=torch.float64, device=dev)
+        lib = capi.lib()
+        self._ctx.use_current_stream()
+        self._panels = []                                             # (row0, nrows, ncols, packed QR, tau)
+        nnz_idx, zero_idx = [], []
+        nzp = solved = new_piv = prev_rows = 0
+        eps = np.finfo(np.float64).eps
+        while solved < cols:
+            new = self.suggestedBlockCols
+            if solved + new >= cols:
+                new = cols - solved
+                nrows = rows - nzp
+            else:
+                biggest = 0
+                for c in range(new):
+                    col = pm.indices[pm.indptr[solved + c]:pm.indptr[solved + c + 1]]
+                    biggest = max(biggest, int(col[-1]) if len(col) else 0)
+                nrows = biggest - nzp + 1
+                if nrows < prev_rows - new_piv:
+                    nrows = prev_rows - new_piv
+            r0, c0 = nzp, solved
+            Ji = _colmajor(D[r0:r0 + nrows, c0:c0 + new].clone())     # the reference factorises a copy of the block
+            k = min(nrows, new)
+            hc = torch.empty(max(k, 1), dtype=torch.float64, device=dev)
+            pp = torch.empty(new, dtype=torch.int32, device=dev)
+            pl = self._plan(nrows, new)
+            capi.check(lib.qrk_dense_factorize(pl, Ji.data_ptr(), nrows, hc.data_ptr(), pp.data_ptr(), capi.MEM_DEVICE),
+                       self._ctx.handle)
+            p = pp.cpu().numpy()
+            # nonzeroPivots(): Eigen's rule on the pivots, |R_kk|^2 < (eps max|col|)^2 (rows - k) / rows ends the count
+            diag = torch.diagonal(Ji)[:k].abs().cpu().numpy()
+            nz = k
+            for q in range(k):
+                if diag[q] ** 2 < (diag[0] * eps) ** 2 * (nrows - q) / nrows:
+                    nz = q
+                    break
+            nnz_idx += [c0 + int(p[c]) for c in range(nz)]
+            zero_idx += [c0 + int(p[c]) for c in range(nz, new)]
+            # update of the columns to the right of the panel (rows of the panel): Q_panel^T applied in reflector form
+            ntrail = cols - (c0 + new)
+            if ntrail > 0 and k > 0:
+                B = D[r0:, c0 + new:]                                 # view: element (0,0) of the trailing block
+                capi.check(lib.qrk_dense_apply_q(pl, Ji.data_ptr(), nrows, hc.data_ptr(), 1, B.data_ptr(), rows, ntrail,
+                                                 capi.MEM_DEVICE), self._ctx.handle)
+            for bc in range(new):
+                Rout[:nzp, nzp + bc] = D[:nzp, c0 + int(p[bc])]
+            Rout[nzp:nzp + k, nzp:nzp + new] = torch.triu(Ji[:k, :])
+            self._panels.append((r0, nrows, new, Ji, hc))
+            new_piv = nz
+            nzp += nz
+            prev_rows = nrows
+            solved += new
+        house = np.array(nnz_idx + zero_idx, dtype=np.int32)
+        self._R = Rout
+        self.m_outputPerm_c = torch.from_numpy(cperm[house].astype(np.int32)).to(dev)
+        self.m_rowPerm = torch.from_numpy(rperm.astype(np.int32)).to(dev)
+        self.m_nonzeroPivots = nzp
+        self._shape = (rows, cols)
+        self.m_isInitialized = True
+        return self
+
+    def rows(self):
+        return self._shape[0]
+
+    def cols(self):
+        return self._shape[1]
+
+    def rank(self):
+        return self.m_nonzeroPivots
+
+    def colsPermutation(self) -> torch.Tensor:
+        return self.m_outputPerm_c
+
+    def rowsPermutation(self) -> torch.Tensor:
+        return self.m_rowPerm
+
+    def matrixR(self) -> torch.Tensor:
+        """rows x cols, dense on the device (the reference keeps it sparse, column by column)."""
+        return self._R
+
+    def _applyAny(self, v, transpose: bool):
+        """SparseBlockYTY sequence (SparseBlockYTY.h:111-138): Q^T v = panels in order, Q v = in reverse; a panel acts on its
+        row range only."""
+        was_np = not isinstance(v, torch.Tensor)
+        t = torch.as_tensor(np.asarray(v, dtype=np.float64)) if was_np else v
+        rows = self._shape[0]
+        y = _colmajor(t.to(self._ctx.device, torch.float64).reshape(rows, -1).clone())
+        self._ctx.use_current_stream()
+        seq = self._panels if transpose else self._panels[::-1]
+        for r0, nrows, new, Ji, hc in seq:
+            if min(nrows, new) == 0:
+                continue
+            B = y[r0:, :]
+            capi.check(capi.lib().qrk_dense_apply_q(self._plan(nrows, new), Ji.data_ptr(), nrows, hc.data_ptr(),
+                                                    1 if transpose else 0, B.data_ptr(), rows, y.shape[1], capi.MEM_DEVICE),
+                       self._ctx.handle)
+        out = y if np.ndim(v) > 1 else y[:, 0]
+        return out.cpu().numpy() if was_np else out
+
+    def matrixQ(self):
+        from .qproduct import QProduct
+        slv = self
+
+        class _Ops:
+            def rows(self_inner): return slv.rows()
+            def applyQ(self_inner, v): return slv._applyAny(v, False)
+            def applyQt(self_inner, v): return slv._applyAny(v, True)
+        return QProduct(_Ops())
+
+    def solve(self, b):
+        """BlockedThinQRBase::_solve_impl (BlockedThinQRBase.h:223-247): y = Q^T b; x(0:rank) = R(0:rank,0:rank)^-1 y(0:rank),
+        the rest zero (the caller applies the permutations, as with the reference)."""
+        rows, cols = self._shape
+        was_np = not isinstance(b, torch.Tensor)
+        y = self._applyAny(torch.as_tensor(np.asarray(b, dtype=np.float64)) if was_np else b, True)
+        y = y.to(self._ctx.device).reshape(rows, -1)
+        rk = self.m_nonzeroPivots
+        x = torch.zeros(max(cols, 0), y.shape[1], dtype=torch.float64, device=y.device)
+        if rk > 0:
+            x[:rk] = torch.linalg.solve_triangular(self._R[:rk, :rk], y[:rk], upper=True)
+        x = x if np.ndim(b) > 1 else x[:, 0]
+        return x.cpu().numpy() if was_np else x
+
+    def __del__(self):
+        try:
+            for pl in self._plans.values():
+                capi.lib().qrk_dense_plan_destroy(pl)
+        except Exception:
+            pass
 
 
 def _colmajor(t: torch.Tensor) -> torch.Tensor:

@@ -1,0 +1,90 @@
+"""The "thin" right-block solvers: BlockedThinDenseQR (src/QRKit/BlockedThinDenseQR.h:104-176) and
+BlockedThinSparseQR (src/QRKit/BlockedThinSparseQR.h:105-283) -- the oracle's restatement of the reference's panel chains
+against their own invariants (CPU), and the device solvers against the oracle (GPU)."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from helpers import rel_fro
+from oracle import oracle as orc
+
+
+def thin_sparse_problem(rows, cols, seed, density=0.25):
+    """A thin sparse matrix with a staircase profile (what the ordering is for) plus random fill, rows shuffled."""
+    rng = np.random.default_rng(seed)
+    M = sp.random(rows, cols, density=density, random_state=seed, format="lil", data_rvs=lambda n: rng.uniform(0.5, 5.0, n))
+    for j in range(cols):
+        M[min(rows - 1, j * (rows // cols)), j] = rng.uniform(0.5, 5.0)
+    M = sp.csc_matrix(M)
+    return sp.csc_matrix(M[rng.permutation(rows)])
+
+
+def permuted(M, res_perm, res_rowperm):
+    rows = M.shape[0]
+    inv = np.empty(rows, dtype=np.int64); inv[np.asarray(res_rowperm)] = np.arange(rows)
+    return sp.csr_matrix(M)[inv][:, np.asarray(res_perm)].toarray()
+
+
+@pytest.mark.parametrize("rows,cols,bc", [(60, 13, 2), (200, 40, 3), (64, 64, 2)])
+def test_oracle_thin_dense_chain(rows, cols, bc):
+    A = np.random.default_rng(rows + cols).uniform(-1, 1, (rows, cols))
+    r = orc.bt_dense_qr(A, bc)
+    assert np.abs(np.tril(r.R, -1)).max() <= 1e-13
+    assert rel_fro(orc.bt_apply_q(r, A, True), r.R) <= 1e-13                        # Q^T A = R
+    assert rel_fro(orc.bt_apply_q(r, r.R, False), A) <= 1e-13                       # Q R = A
+    qr, hc = orc.householder_qr(A)                                                  # the chain's reflectors are HouseholderQR's
+    assert rel_fro(np.triu(r.R[:cols]), np.triu(qr[:cols])) <= 1e-13
+
+
+@pytest.mark.parametrize("rows,cols,bc,seed", [(120, 20, 2, 1), (300, 48, 2, 2), (90, 30, 4, 3)])
+def test_oracle_thin_sparse_chain(rows, cols, bc, seed):
+    M = thin_sparse_problem(rows, cols, seed)
+    s = orc.bt_sparse_qr(M, bc)
+    assert sorted(s.perm.tolist()) == list(range(cols)) and sorted(s.rowperm.tolist()) == list(range(rows))
+    PM = permuted(M, s.perm, s.rowperm)
+    assert rel_fro(orc.bt_apply_q(s, PM, True), s.R) <= 1e-12                      # Q^T (Pr M Pc) = R
+    assert np.abs(np.tril(s.R, -1)).max() == 0.0 and s.rank == cols
+    x = np.random.default_rng(0).uniform(-1, 1, cols)
+    y = orc.bt_apply_q(s, PM @ x, True)
+    assert rel_fro(np.linalg.solve(s.R[:cols, :cols], y[:cols]), x) <= 1e-9
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows,cols,bc", [(300, 40, 2), (5120, 384, 2), (64, 64, 3)])
+def test_hip_thin_dense_matches_oracle_chain(rows, cols, bc):
+    """The device factorisation (one HouseholderQR of the whole matrix, Q as essential vectors) against the oracle's
+    restatement of the reference's panel chain: same R, same Q^T b."""
+    import qrkit_amd
+    A = np.random.default_rng(rows * 3 + cols).uniform(-1, 1, (rows, cols))
+    ref = orc.bt_dense_qr(A, bc)
+    ctx = qrkit_amd.Context(0)
+    qr = qrkit_amd.BlockedThinDenseQR(ctx, bc)
+    qr.compute(A)
+    assert qr.rank() == ref.rank
+    np.testing.assert_array_equal(qr.colsPermutation().cpu().numpy(), ref.perm)
+    assert rel_fro(qr.matrixR().cpu().numpy(), np.triu(ref.R[:cols])) <= 1e-12
+    b = np.random.default_rng(1).uniform(-1, 1, rows)
+    assert rel_fro(qr._applyAny(b, True), orc.bt_apply_q(ref, b, True)) <= 1e-12
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows,cols,bc,seed", [(120, 20, 2, 1), (300, 48, 2, 2), (90, 30, 4, 3), (2000, 96, 2, 4)])
+def test_hip_thin_sparse_matches_oracle(rows, cols, bc, seed):
+    """BlockedThinSparseQR on the device against the oracle: both permutations bit-exact, R and Q^T b within the tolerance,
+    and the reference's use of it -- least-squares recovery through the permutations."""
+    import qrkit_amd
+    M = thin_sparse_problem(rows, cols, seed)
+    ref = orc.bt_sparse_qr(M, bc)
+    ctx = qrkit_amd.Context(0)
+    qr = qrkit_amd.BlockedThinSparseQR(ctx, bc)
+    qr.compute(M)
+    assert qr.rank() == ref.rank
+    np.testing.assert_array_equal(qr.colsPermutation().cpu().numpy(), ref.perm)        # bit-exact
+    np.testing.assert_array_equal(qr.rowsPermutation().cpu().numpy(), ref.rowperm)     # bit-exact
+    assert rel_fro(qr.matrixR().cpu().numpy(), ref.R) <= 1e-12
+    b = np.random.default_rng(1).uniform(-1, 1, rows)
+    assert rel_fro(qr._applyAny(b, True), orc.bt_apply_q(ref, b, True)) <= 1e-12
+    assert rel_fro(qr._applyAny(qr._applyAny(b, True), False), b) <= 1e-13
+    x = np.random.default_rng(0).uniform(-1, 1, cols)
+    PM = permuted(M, ref.perm, ref.rowperm)
+    assert rel_fro(qr.solve(PM @ x), x) <= 1e-9

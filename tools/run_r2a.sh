@@ -1,3 +1,3 @@
 mkdir -p gpurun_out/r2a
-python -m pytest tests/test_angular.py -q -m gpu -k configs3 > gpurun_out/r2a/cfg3.log 2>&1; echo "rc=$?" >> gpurun_out/r2a/cfg3.log
-tail -30 gpurun_out/r2a/cfg3.log
+python -m pytest tests/test_thin_gpu.py -q -m gpu > gpurun_out/r2a/thin.log 2>&1; echo "rc=$?" >> gpurun_out/r2a/thin.log
+tail -40 gpurun_out/r2a/thin.log
