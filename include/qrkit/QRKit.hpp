@@ -212,9 +212,14 @@ class SparseBlockDiagonal {
     StorageIndex nRows, nCols;
 };
 
-// tags standing in for the _BlockQRSolver template argument (BlockDiagonalSparseQR.h:37)
-struct ColPivHouseholderQR { static const int kSolver = QRK_COLPIV_HOUSEHOLDER; };
-struct HouseholderQR { static const int kSolver = QRK_HOUSEHOLDER; };
+// tags standing in for the _BlockQRSolver template argument (BlockDiagonalSparseQR.h:37).  Rows/ColsAtCompileTime are what
+// BandedBlockedSparseQR consults to choose its fixed-pattern analysis (BandedBlockedSparseQR.h:398): Dynamic (-1) for the
+// plain tags, the block shape for the *Fixed ones (the reference's ColPivHouseholderQR<Matrix<double, 7, 2>> etc.).
+const int Dynamic = -1;
+struct ColPivHouseholderQR { static const int kSolver = QRK_COLPIV_HOUSEHOLDER; enum { RowsAtCompileTime = Dynamic, ColsAtCompileTime = Dynamic }; };
+struct HouseholderQR { static const int kSolver = QRK_HOUSEHOLDER; enum { RowsAtCompileTime = Dynamic, ColsAtCompileTime = Dynamic }; };
+template <int R, int C> struct ColPivHouseholderQRFixed { static const int kSolver = QRK_COLPIV_HOUSEHOLDER; enum { RowsAtCompileTime = R, ColsAtCompileTime = C }; };
+template <int R, int C> struct HouseholderQRFixed { static const int kSolver = QRK_HOUSEHOLDER; enum { RowsAtCompileTime = R, ColsAtCompileTime = C }; };
 
 // QRKit::BlockDiagonalSparseQR<_BlockQRSolver,_QFormat> (BlockDiagonalSparseQR.h:37-335).
 template <typename BlockQRSolver = ColPivHouseholderQR, int QFormat = 0>
@@ -285,11 +290,11 @@ class BlockDiagonalSparseQR {
         reserve(m_dperm, m_cperm, cols * (int64_t)sizeof(int32_t));
         check(qrk_memcpy(m_handle, m_dtiles, mat.tiles().data(), tl * (int64_t)sizeof(double), 0));
         check(qrk_bd_factorize(m_plan, (const double*)m_dtiles, (double*)m_dq, (double*)m_dr, (int32_t*)m_dperm, 0, QRK_MEM_DEVICE));
-        check(qrk_memcpy(m_handle, m_outputPerm_c.indices().data(), m_dperm, cols * (int64_t)sizeof(int32_t), 1));
         qrk_info info; int64_t rank;
         check(qrk_bd_info(m_plan, &info, &rank));
         m_info = (ComputationInfo)info;
-        if (m_info != Success) return;   // :504-516: m_info = InvalidInput; return
+        if (m_info != Success) return;   // :504-516: m_info = InvalidInput; return (nothing was written: the permutation stays identity)
+        check(qrk_memcpy(m_handle, m_outputPerm_c.indices().data(), m_dperm, cols * (int64_t)sizeof(int32_t), 1));
         m_nonzeropivots = rank;
         m_isInitialized = true;
         m_factorizationIsok = true;
@@ -467,7 +472,10 @@ class QProduct {
 // QRKit::BandedBlockedSparseQR<SparseMatrix, HouseholderQR<MatrixXd>, Dynamic, SuggestedBlockCols>
 // (BandedBlockedSparseQR.h:122-366), generic-pattern path: as-banded-as-possible row ordering, band
 // detection + block merge, sequential chain of dense Householder panels with Q kept as (Y, T) blocks.
-template <int SuggestedBlockCols = 2>
+// BlockRows / BlockCols / BlockOverlap != Dynamic select the fixed-pattern analysis (:398-408: identity row permutation, block map
+// of fromBlockBandedPattern, SparseQRUtils.h:274-302) through qrk_bb_plan_create_fixed.  The reference's parameter list is
+// provided by QRKit::BandedBlockedSparseQR at the end of this header.
+template <int SuggestedBlockCols = 2, int BlockRows = Dynamic, int BlockCols = Dynamic, int BlockOverlap = Dynamic>
 class BandedBlockedSparseQR {
   public:
     typedef SparseMatrixColMajor MatrixRType;
@@ -497,7 +505,11 @@ class BandedBlockedSparseQR {
         toCsr(mat, m_rowptr, m_colidx, vals);
         m_rows = mat.rows(); m_cols = mat.cols();
         if (m_plan) { qrk_bb_plan_destroy(m_plan); m_plan = 0; }
-        check(qrk_bb_plan_create(m_handle, (int32_t)m_rows, (int32_t)m_cols, m_rowptr.data(), m_colidx.data(), SuggestedBlockCols, &m_plan));
+        if (BlockRows != Dynamic && BlockCols != Dynamic && BlockOverlap != Dynamic)
+            check(qrk_bb_plan_create_fixed(m_handle, (int32_t)m_rows, (int32_t)m_cols, m_rowptr.data(), m_colidx.data(), BlockRows, BlockCols,
+                                           BlockOverlap, SuggestedBlockCols, &m_plan));
+        else
+            check(qrk_bb_plan_create(m_handle, (int32_t)m_rows, (int32_t)m_cols, m_rowptr.data(), m_colidx.data(), SuggestedBlockCols, &m_plan));
         int32_t nb = 0, has = 0; int64_t yl = 0, tl = 0;
         check(qrk_bb_plan_info(m_plan, &nb, &m_nnzR, &yl, &tl, &has));
         m_hasRowPermutation = has != 0;
@@ -820,8 +832,8 @@ template <typename BS, int QF>
 inline Vector leftApplyQ(const BlockDiagonalSparseQR<BS, QF>& s, const Vector& v, bool transpose) {
     return transpose ? s.applyQt(v) : s.applyQ(v);
 }
-template <int SBC>
-inline Vector leftApplyQ(const BandedBlockedSparseQR<SBC>& s, const Vector& v, bool transpose) {
+template <int SBC, int BR, int BC, int BO>
+inline Vector leftApplyQ(const BandedBlockedSparseQR<SBC, BR, BC, BO>& s, const Vector& v, bool transpose) {
     return transpose ? s.applyQt(v) : s.applyQ(v);
 }
 
@@ -994,5 +1006,42 @@ class BlockAngularSparseQR {
 };
 
 }  // namespace qrkit
+
+// The reference's namespace and template parameter lists (src/QRKit/*.h), so that code written against QRKit compiles against
+// this header by changing the include: parameters the device engine does not need (_MatrixType, _StorageIndex) are accepted and
+// ignored; the _BlockQRSolver argument is one of the tags above (Eigen's solver classes are not available without Eigen).
+namespace QRKit {
+using qrkit::Index;
+using qrkit::Matrix;
+using qrkit::Vector;
+using qrkit::SparseMatrix;
+using qrkit::SparseMatrixRowMajor;
+using qrkit::SparseMatrixColMajor;
+using qrkit::PermutationMatrix;
+using qrkit::ComputationInfo;
+using qrkit::Success;
+using qrkit::InvalidInput;
+using qrkit::Dynamic;
+using qrkit::ColPivHouseholderQR;
+using qrkit::HouseholderQR;
+using qrkit::ColPivHouseholderQRFixed;
+using qrkit::HouseholderQRFixed;
+enum MatrixQFormat { FullQ = 0, BlockDiagonalQ = 1 };     // BlockDiagonalSparseQR.h:59-62
+// SparseBlockDiagonal<BlockMatrixType, _StorageIndex> (SparseBlockDiagonal.h:43-44)
+template <typename BlockMatrixType = Matrix, typename StorageIndex = int> using SparseBlockDiagonal = qrkit::SparseBlockDiagonal;
+// BlockDiagonalSparseQR<_BlockQRSolver, _QFormat> (BlockDiagonalSparseQR.h:37)
+template <typename BlockQRSolver = qrkit::ColPivHouseholderQR, int QFormat = 0>
+using BlockDiagonalSparseQR = qrkit::BlockDiagonalSparseQR<BlockQRSolver, QFormat>;
+// BandedBlockedSparseQR<_MatrixType, _BlockQRSolver, _BlockOverlap = Dynamic, _SuggestedBlockCols = 2> (BandedBlockedSparseQR.h:122)
+template <typename MatrixType, typename BlockQRSolver, int BlockOverlap = qrkit::Dynamic, int SuggestedBlockCols = 2>
+using BandedBlockedSparseQR =
+    qrkit::BandedBlockedSparseQR<SuggestedBlockCols, BlockQRSolver::RowsAtCompileTime, BlockQRSolver::ColsAtCompileTime, BlockOverlap>;
+// BlockedThinDenseQR / BlockedThinSparseQR<_MatrixType, _SuggestedBlockCols = 2> (BlockedThinDenseQR.h:61, BlockedThinSparseQR.h:58)
+template <typename MatrixType, int SuggestedBlockCols = 2> using BlockedThinDenseQR = qrkit::BlockedThinDenseQR<SuggestedBlockCols>;
+template <typename MatrixType, int SuggestedBlockCols = 2> using BlockedThinSparseQR = qrkit::BlockedThinSparseQR<SuggestedBlockCols>;
+// BlockMatrix1x2<LeftBlockMatrixType, RightBlockMatrixType> (BlockMatrix1x2.h:31), BlockAngularSparseQR<Left, Right> (BlockAngularSparseQR.h:79)
+template <typename L, typename R> using BlockMatrix1x2 = qrkit::BlockMatrix1x2<L, R>;
+template <typename L, typename R> using BlockAngularSparseQR = qrkit::BlockAngularSparseQR<L, R>;
+}  // namespace QRKit
 
 #endif  // QRKIT_FACADE_HPP

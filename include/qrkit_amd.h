@@ -240,6 +240,19 @@ qrk_status qrk_bb_plan_create(qrk_handle h, int32_t rows, int32_t cols, const in
                               const int32_t* csr_colidx, int32_t suggested_block_cols, qrk_bb_plan* out);
 qrk_status qrk_bb_plan_destroy(qrk_bb_plan plan);
 
+/* The fixed-pattern path of BandedBlockedSparseQR::analyzePattern (src/QRKit/BandedBlockedSparseQR.h:398-408, taken when the
+ * block type is fixed-size and _BlockOverlap != Dynamic): identity row permutation and the block map of
+ * BlockBandedMatrixInfo::fromBlockBandedPattern (src/QRKit/SparseQRUtils.h:274-302) + mergeBlocks (:308-385) instead of the
+ * row ordering and band detection of qrk_bb_plan_create.  csr_*: pattern of the matrix, as there. */
+qrk_status qrk_bb_plan_create_fixed(qrk_handle h, int32_t rows, int32_t cols, const int32_t* csr_rowptr,
+                                    const int32_t* csr_colidx, int32_t block_rows, int32_t block_cols, int32_t block_overlap,
+                                    int32_t suggested_block_cols, qrk_bb_plan* out);
+
+/* Host-only: the merged block map of that fixed pattern (blocks: 4 ints each, idxRow idxCol numRows numCols; at most cap).
+ * Reproduces the reference's known answer test/test-utils.cpp:228-241 (7x4 blocks, overlap 2 -> 255 blocks, the last 14x4). */
+qrk_status qrk_bb_blocks_from_pattern(int32_t rows, int32_t cols, int32_t block_rows, int32_t block_cols, int32_t block_overlap,
+                                      int32_t suggested_block_cols, int32_t cap, int32_t* num_blocks, int32_t* blocks);
+
 /* The same structure analysis without a device (pure host integer logic): writes up to `cap` blocks as
  * (idxRow, idxCol, numRows, numCols) and, when row_perm != NULL, the row permutation indices;
  * *num_blocks receives the block count.  Lets the reference's known answers

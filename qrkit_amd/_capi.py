@@ -24,7 +24,7 @@ EXPORTS = (
     "qrk_version", "qrk_device_count", "qrk_create", "qrk_destroy", "qrk_set_stream", "qrk_synchronize",
     "qrk_last_error", "qrk_device_alloc", "qrk_device_free", "qrk_memcpy", "qrk_bd_plan_create", "qrk_bd_plan_destroy", "qrk_bd_plan_sizes", "qrk_bd_pattern",
     "qrk_bd_tiles_from_sparse", "qrk_bd_factorize", "qrk_bd_info", "qrk_bd_apply_qt", "qrk_bd_apply_q", "qrk_bd_solve", "qrk_bd_solve_r", "qrk_dense_plan_create",
-    "qrk_dense_plan_destroy", "qrk_dense_factorize", "qrk_dense_apply_q", "qrk_bb_plan_create", "qrk_bb_plan_destroy", "qrk_bb_analyze_host",
+    "qrk_dense_plan_destroy", "qrk_dense_factorize", "qrk_dense_apply_q", "qrk_bb_plan_create", "qrk_bb_plan_destroy", "qrk_bb_plan_create_fixed", "qrk_bb_blocks_from_pattern", "qrk_bb_analyze_host",
     "qrk_bb_plan_info", "qrk_bb_plan_blocks", "qrk_bb_pattern", "qrk_bb_factorize", "qrk_bb_apply_q", "qrk_bb_solve_r", "qrk_dense_solve_r", "qrk_bd_time_factorize", "qrk_bd_kernel_name",
 )
 
@@ -102,6 +102,11 @@ def lib() -> C.CDLL:
     L.qrk_bb_plan_create.argtypes = [vp, C.c_int32, C.c_int32, ip, ip, C.c_int32, C.POINTER(vp)]
     L.qrk_bb_plan_destroy.restype = C.c_int
     L.qrk_bb_plan_destroy.argtypes = [vp]
+    L.qrk_bb_plan_create_fixed.restype = C.c_int
+    L.qrk_bb_plan_create_fixed.argtypes = [vp, C.c_int32, C.c_int32, ip, ip, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(vp)]
+    L.qrk_bb_blocks_from_pattern.restype = C.c_int
+    L.qrk_bb_blocks_from_pattern.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                             C.POINTER(C.c_int32), ip]
     L.qrk_bb_analyze_host.restype = C.c_int
     L.qrk_bb_analyze_host.argtypes = [C.c_int32, C.c_int32, ip, ip, C.c_int32, C.c_int32, C.POINTER(C.c_int32), ip, ip,
                                       C.POINTER(C.c_int32)]

@@ -121,7 +121,7 @@ class BlockedThinDenseQR(DenseColPivQR):
     (a panel's columns arrive updated by every earlier reflector, and inside the panel HouseholderQR is the same recurrence),
     so the device computes that factorisation (qrk_dense_*, QRK_HOUSEHOLDER) and keeps Q as essential vectors + tau instead
     of per-panel (Y, T): R and every product with Q agree with the panel chain to rounding (tests/test_thin_gpu.py compares
-    with the oracle's restatement of the chain); `suggestedBlockCols` therefore does not change the result."""
+    with a CPU restatement of the chain); `suggestedBlockCols` therefore does not change the result."""
 
     def __init__(self, context: Context, suggestedBlockCols: int = 2):
         super().__init__(context, capi.HOUSEHOLDER)

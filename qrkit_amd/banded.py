@@ -31,10 +31,27 @@ def analyze_host(J, suggestedBlockCols: int = 2):
     return perm, blocks[:4 * nb.value].reshape(-1, 4), bool(has.value)
 
 
+def blocks_from_pattern(rows: int, cols: int, blockRows: int, blockCols: int, blockOverlap: int, suggestedBlockCols: int = 2):
+    """BlockBandedMatrixInfo::fromBlockBandedPattern + mergeBlocks (SparseQRUtils.h:274-385) by the library's host logic
+    (qrk_bb_blocks_from_pattern, no device needed): merged blocks [n, 4] = (idxRow, idxCol, numRows, numCols)."""
+    nb = C.c_int32()
+    cap = max(1, cols)
+    blocks = np.zeros(4 * cap, np.int32)
+    capi.check(capi.lib().qrk_bb_blocks_from_pattern(rows, cols, blockRows, blockCols, blockOverlap, suggestedBlockCols, cap,
+                                                     C.byref(nb), blocks.ctypes.data))
+    return blocks[:4 * nb.value].reshape(-1, 4)
+
+
 class BandedBlockedSparseQR:
-    def __init__(self, suggestedBlockCols: int = 2, context: Optional[Context] = None, device: int = 0):
+    """QRKit::BandedBlockedSparseQR<_MatrixType, _BlockQRSolver, _BlockOverlap, _SuggestedBlockCols>
+    (BandedBlockedSparseQR.h:122-366).  fixedPattern=(blockRows, blockCols, blockOverlap) selects the reference's fixed-pattern
+    analysis (a fixed-size _BlockQRSolver matrix type and _BlockOverlap != Dynamic, :398-408): identity row permutation and the
+    block map of fromBlockBandedPattern; None (the default, = Dynamic) the generic analysis (:409-427)."""
+
+    def __init__(self, suggestedBlockCols: int = 2, context: Optional[Context] = None, device: int = 0, fixedPattern=None):
         self._ctx = context or Context(device)
         self._suggested = suggestedBlockCols
+        self._fixed = tuple(int(x) for x in fixedPattern) if fixedPattern is not None else None
         self._plan = C.c_void_p()
         self.m_isInitialized = False
         self.m_analysisIsok = False
@@ -55,8 +72,14 @@ class BandedBlockedSparseQR:
         if self._plan:
             capi.lib().qrk_bb_plan_destroy(self._plan)
             self._plan = C.c_void_p()
-        capi.check(capi.lib().qrk_bb_plan_create(self._ctx.handle, self._rows, self._cols, self._rp.ctypes.data,
-                                                 self._ci.ctypes.data, self._suggested, C.byref(self._plan)), self._ctx.handle)
+        if self._fixed is not None:
+            br, bc, ov = self._fixed
+            capi.check(capi.lib().qrk_bb_plan_create_fixed(self._ctx.handle, self._rows, self._cols, self._rp.ctypes.data,
+                                                           self._ci.ctypes.data, br, bc, ov, self._suggested,
+                                                           C.byref(self._plan)), self._ctx.handle)
+        else:
+            capi.check(capi.lib().qrk_bb_plan_create(self._ctx.handle, self._rows, self._cols, self._rp.ctypes.data,
+                                                     self._ci.ctypes.data, self._suggested, C.byref(self._plan)), self._ctx.handle)
         nb, has = C.c_int32(), C.c_int32()
         nr, yl, tl = C.c_int64(), C.c_int64(), C.c_int64()
         capi.check(capi.lib().qrk_bb_plan_info(self._plan, C.byref(nb), C.byref(nr), C.byref(yl), C.byref(tl), C.byref(has)),

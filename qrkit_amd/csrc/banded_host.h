@@ -53,8 +53,14 @@ struct BandedStructure {
 
 // Returns false and sets err when the reference itself would be outside its domain (e.g. mergeBlocks
 // calling back() on an empty vector, SparseQRUtils.h:375) or a panel is not portrait.
+// `fixed` (optional): the fixed-pattern path of BandedBlockedSparseQR::analyzePattern (BandedBlockedSparseQR.h:398-408): no row
+// ordering, block map from BlockBandedMatrixInfo::fromBlockBandedPattern (SparseQRUtils.h:274-302) instead of band detection.
+struct FixedBandedPattern { int32_t block_rows, block_cols, overlap; };
+bool banded_block_map_fixed(int32_t rows, int32_t cols, const FixedBandedPattern& fx, int32_t suggested_block_cols,
+                            std::vector<BlockInfo>& blocks, std::string& err);
 bool analyze_banded(int32_t rows, int32_t cols, const int32_t* rowptr, const int32_t* colidx,
-                    int32_t suggested_block_cols, BandedStructure& out, std::string& err);
+                    int32_t suggested_block_cols, BandedStructure& out, std::string& err,
+                    const FixedBandedPattern* fixed = nullptr);
 
 }  // namespace qrk
 #endif

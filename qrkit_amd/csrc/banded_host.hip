@@ -77,12 +77,57 @@ bool merge_blocks(std::vector<int32_t>& order, std::map<int32_t, BlockInfo>& bma
 
 }  // namespace
 
+// BlockBandedMatrixInfo::fromBlockBandedPattern (SparseQRUtils.h:274-302), before the merge: numBlocks = cols / (blockCols -
+// overlap) blocks (i blockRows, i step, blockRows, blockCols), the last one blockCols - overlap wide
+static bool fixed_block_map(int32_t cols, const FixedBandedPattern& fx, std::vector<int32_t>& order, std::map<int32_t, BlockInfo>& bmap,
+                            int32_t& maxColStep, std::string& err)
+{
+    maxColStep = fx.block_cols - fx.overlap;
+    if (fx.block_rows <= 0 || fx.block_cols <= 0 || fx.overlap < 0 || maxColStep <= 0) { err = "bad fixed banded pattern"; return false; }
+    const int32_t numBlocks = cols / maxColStep;
+    for (int32_t i = 0; i < numBlocks; ++i) {
+        BlockInfo b;
+        b.idxRow = i * fx.block_rows; b.idxCol = i * maxColStep; b.numRows = fx.block_rows;
+        b.numCols = i < numBlocks - 1 ? fx.block_cols : fx.block_cols - fx.overlap;
+        order.push_back(b.idxCol);
+        bmap.insert(std::make_pair(b.idxCol, b));
+    }
+    return true;
+}
+
+// The merged block map of the fixed pattern alone (fromBlockBandedPattern + mergeBlocks): what the reference's known answers
+// (test/test-utils.cpp:228-241) pin.
+bool banded_block_map_fixed(int32_t rows, int32_t cols, const FixedBandedPattern& fx, int32_t suggested, std::vector<BlockInfo>& blocks,
+                            std::string& err)
+{
+    (void)rows;
+    std::vector<int32_t> order;
+    std::map<int32_t, BlockInfo> bmap;
+    int32_t maxColStep = 0;
+    if (!fixed_block_map(cols, fx, order, bmap, maxColStep, err)) return false;
+    if (!merge_blocks(order, bmap, maxColStep, suggested, err)) return false;
+    blocks.clear();
+    for (int32_t key : order) blocks.push_back(bmap.at(key));
+    return true;
+}
+
 bool analyze_banded(int32_t rows, int32_t cols, const int32_t* rowptr, const int32_t* colidx, int32_t suggested,
-                    BandedStructure& out, std::string& err)
+                    BandedStructure& out, std::string& err, const FixedBandedPattern* fixed)
 {
     out = BandedStructure();
     out.rows = rows; out.cols = cols;
     if (rows <= 0 || cols <= 0) { err = "empty matrix"; return false; }
+    // The pattern comes straight from the public C ABI: a malformed CSR (row pointers out of order, column indices out of
+    // range or unsorted within a row) would otherwise yield blocks that overrun the matrix and out-of-bounds panel descriptors.
+    if (!rowptr || rowptr[0] < 0) { err = "invalid CSR pattern: rowptr[0] < 0"; return false; }
+    for (int32_t j = 0; j < rows; ++j) {
+        if (rowptr[j + 1] < rowptr[j]) { err = "invalid CSR pattern: row pointers decrease"; return false; }
+        if (rowptr[j + 1] > rowptr[j] && !colidx) { err = "invalid CSR pattern: colidx is NULL"; return false; }
+        for (int32_t e = rowptr[j]; e < rowptr[j + 1]; ++e) {
+            if (colidx[e] < 0 || colidx[e] >= cols) { err = "invalid CSR pattern: column index out of range"; return false; }
+            if (e > rowptr[j] && colidx[e] <= colidx[e - 1]) { err = "invalid CSR pattern: column indices of a row not strictly increasing"; return false; }
+        }
+    }
 
     // ---- AsBandedAsPossible (SparseQROrdering.h:66-119): stable sort of the rows by first nonzero column
     std::vector<RowRange> ranges((size_t)rows);
@@ -94,7 +139,8 @@ bool analyze_banded(int32_t rows, int32_t cols, const int32_t* rowptr, const int
         ranges[(size_t)j] = RowRange{j, s, e};
     }
     auto less = [](const RowRange& a, const RowRange& b) { return a.start < b.start; };
-    out.has_row_perm = !std::is_sorted(ranges.begin(), ranges.end(), less);
+    // (fixed pattern, BandedBlockedSparseQR.h:398-408: "rows are already sorted, no permutation needed")
+    out.has_row_perm = !fixed && !std::is_sorted(ranges.begin(), ranges.end(), less);
     if (out.has_row_perm) std::stable_sort(ranges.begin(), ranges.end(), less);
     out.row_perm.assign((size_t)rows, 0);
     for (int32_t r = 0; r < rows; ++r) out.row_perm[(size_t)ranges[(size_t)r].origIdx] = r;
@@ -114,6 +160,12 @@ bool analyze_banded(int32_t rows, int32_t cols, const int32_t* rowptr, const int
         for (int32_t e = rowptr[o]; e < rowptr[o + 1]; ++e, ++dst) { out.pcol[(size_t)dst] = colidx[e]; out.pmap[(size_t)dst] = e; }
     }
 
+    std::vector<int32_t> order;
+    std::map<int32_t, BlockInfo> bmap;
+    int32_t maxColStep = 0;
+    if (fixed) {
+        if (!fixed_block_map(cols, *fixed, order, bmap, maxColStep, err)) return false;
+    } else {
     // ---- BlockBandedMatrixInfo::operator() (SparseQRUtils.h:186-253) on the sorted rows
     std::map<int32_t, int32_t> bandWidths, bandHeights;
     for (const RowRange& rr : ranges) {
@@ -123,11 +175,8 @@ bool analyze_banded(int32_t rows, int32_t cols, const int32_t* rowptr, const int
         else if (it->second < bw) it->second = bw;
         bandHeights[rr.start] += 1;
     }
-    int32_t maxColStep = 0;
     for (size_t j = 0; j + 1 < ranges.size(); ++j)
         maxColStep = std::max(maxColStep, ranges[j + 1].start - ranges[j].start);
-    std::vector<int32_t> order;
-    std::map<int32_t, BlockInfo> bmap;
     int32_t rowIdx = 0;
     for (const RowRange& rr : ranges) {
         if (!std::binary_search(order.begin(), order.end(), rr.start) && rr.start < cols) {
@@ -138,9 +187,15 @@ bool analyze_banded(int32_t rows, int32_t cols, const int32_t* rowptr, const int
         }
         ++rowIdx;
     }
+    }
     if (!merge_blocks(order, bmap, maxColStep, suggested, err)) return false;
     for (int32_t key : order) out.blocks.push_back(bmap.at(key));
     if (out.blocks.empty()) { err = "no blocks found"; return false; }
+    for (const BlockInfo& b : out.blocks)
+        if (b.idxRow < 0 || b.idxCol < 0 || b.numRows <= 0 || b.numCols <= 0 || b.idxCol + b.numCols > cols || b.idxRow + b.numRows > rows) {
+            err = "block map overruns the matrix";
+            return false;
+        }
 
     // ---- the panel chain of factorize() (BandedBlockedSparseQR.h:457-508) as descriptors
     const size_t nb = out.blocks.size();

@@ -912,8 +912,9 @@ qrk_status qrk_dense_solve_r(qrk_dense_plan p, const double* qr, int64_t lda, do
     return QRK_STATUS_OK;
 }
 
-qrk_status qrk_bb_plan_create(qrk_handle h, int32_t rows, int32_t cols, const int32_t* csr_rowptr,
-                              const int32_t* csr_colidx, int32_t suggested_block_cols, qrk_bb_plan* out)
+static qrk_status bb_plan_create_impl(qrk_handle h, int32_t rows, int32_t cols, const int32_t* csr_rowptr,
+                                      const int32_t* csr_colidx, int32_t suggested_block_cols,
+                                      const qrk::FixedBandedPattern* fixed, qrk_bb_plan* out)
 {
     if (!h || !out || !csr_rowptr || !csr_colidx || rows <= 0 || cols <= 0 || suggested_block_cols <= 0)
         return fail(h, QRK_STATUS_INVALID_ARGUMENT, "qrk_bb_plan_create: bad argument");
@@ -923,7 +924,7 @@ qrk_status qrk_bb_plan_create(qrk_handle h, int32_t rows, int32_t cols, const in
     if (!p) return fail(h, QRK_STATUS_ALLOC_FAILED, "qrk_bb_plan_create: out of host memory");
     p->h = h;
     std::string err;
-    if (!qrk::analyze_banded(rows, cols, csr_rowptr, csr_colidx, suggested_block_cols, p->st, err)) {
+    if (!qrk::analyze_banded(rows, cols, csr_rowptr, csr_colidx, suggested_block_cols, p->st, err, fixed)) {
         delete p;
         return fail(h, QRK_STATUS_INVALID_ARGUMENT, "qrk_bb_plan_create: " + err);
     }
@@ -948,6 +949,42 @@ qrk_status qrk_bb_plan_create(qrk_handle h, int32_t rows, int32_t cols, const in
         return fail(h, QRK_STATUS_ALLOC_FAILED, "qrk_bb_plan_create: cannot allocate workspaces");
     }
     *out = p;
+    return QRK_STATUS_OK;
+}
+
+qrk_status qrk_bb_plan_create(qrk_handle h, int32_t rows, int32_t cols, const int32_t* csr_rowptr,
+                              const int32_t* csr_colidx, int32_t suggested_block_cols, qrk_bb_plan* out)
+{
+    return bb_plan_create_impl(h, rows, cols, csr_rowptr, csr_colidx, suggested_block_cols, nullptr, out);
+}
+
+qrk_status qrk_bb_plan_create_fixed(qrk_handle h, int32_t rows, int32_t cols, const int32_t* csr_rowptr,
+                                    const int32_t* csr_colidx, int32_t block_rows, int32_t block_cols, int32_t block_overlap,
+                                    int32_t suggested_block_cols, qrk_bb_plan* out)
+{
+    const qrk::FixedBandedPattern fx{block_rows, block_cols, block_overlap};
+    return bb_plan_create_impl(h, rows, cols, csr_rowptr, csr_colidx, suggested_block_cols, &fx, out);
+}
+
+qrk_status qrk_bb_blocks_from_pattern(int32_t rows, int32_t cols, int32_t block_rows, int32_t block_cols, int32_t block_overlap,
+                                      int32_t suggested_block_cols, int32_t cap, int32_t* num_blocks, int32_t* blocks)
+{
+    if (!num_blocks || rows <= 0 || cols <= 0 || suggested_block_cols <= 0)
+        return fail(nullptr, QRK_STATUS_INVALID_ARGUMENT, "qrk_bb_blocks_from_pattern: bad argument");
+    // the block map alone (no values, no chain): an empty pattern of the right shape is enough for analyze_banded's front half,
+    // but the chain descriptors need real rows; so the map is rebuilt here from the same two routines
+    std::vector<int32_t> rp((size_t)rows + 1, 0), ci;
+    qrk::BandedStructure st;
+    std::string err;
+    const qrk::FixedBandedPattern fx{block_rows, block_cols, block_overlap};
+    if (!qrk::banded_block_map_fixed(rows, cols, fx, suggested_block_cols, st.blocks, err))
+        return fail(nullptr, QRK_STATUS_INVALID_ARGUMENT, "qrk_bb_blocks_from_pattern: " + err);
+    *num_blocks = (int32_t)st.blocks.size();
+    if (blocks)
+        for (size_t i = 0; i < st.blocks.size() && (int32_t)i < cap; ++i) {
+            blocks[4 * i] = st.blocks[i].idxRow; blocks[4 * i + 1] = st.blocks[i].idxCol;
+            blocks[4 * i + 2] = st.blocks[i].numRows; blocks[4 * i + 3] = st.blocks[i].numCols;
+        }
     return QRK_STATUS_OK;
 }
 

@@ -223,5 +223,24 @@ int main() {
         fails += test_block_angular_as<BlockAngularSparseQR<BandedBlockedQRSolver, BlockedThinSparseQR<2> > >(left, left, right, rightSparse, "banded left, BlockedThinSparseQR right (sparse right block)");
         fails += test_blocked_thin(right);
     }
+    {   // the reference's own spelling: namespace QRKit, four template parameters, a fixed-size block type and a block overlap
+        // (typedef at test-qrkit.cpp:43-44 with <Matrix<double,7,4>> / overlap 2 would take the fixed-pattern analysis,
+        // BandedBlockedSparseQR.h:398-408).  On the un-shuffled overlapping matrix both analyses must give the same block map
+        // (the reference's known answers, test-utils.cpp:228-241) and therefore the same R.
+        const Index numVars = 256, numParams = numVars * 2, numResiduals = numVars * 3 + numVars + numVars * 3;
+        SparseMatrixColMajor spJ;
+        generate_banded(numParams, numResiduals, true, 0, spJ);
+        QRKit::BandedBlockedSparseQR<QRKit::SparseMatrixColMajor, QRKit::HouseholderQRFixed<7, 4>, 2, 8> fixedSlvr;
+        QRKit::BandedBlockedSparseQR<QRKit::SparseMatrixColMajor, QRKit::HouseholderQR, QRKit::Dynamic, 8> genericSlvr;
+        fixedSlvr.compute(spJ);
+        genericSlvr.compute(spJ);
+        const SparseMatrixColMajor &Rf = fixedSlvr.matrixR(), &Rg = genericSlvr.matrixR();
+        bool same = Rf.values().size() == Rg.values().size() && Rf.innerIndex() == Rg.innerIndex() && Rf.outerIndex() == Rg.outerIndex();
+        double md = 0.0;
+        if (same) for (size_t i = 0; i < Rf.values().size(); ++i) md = std::max(md, std::fabs(Rf.values()[i] - Rg.values()[i]));
+        const bool ok = same && md == 0.0 && fixedSlvr.rowsPermutation().indices() == genericSlvr.rowsPermutation().indices();
+        std::printf("fixed-pattern banded analysis (QRKit:: spelling, 7x4 blocks, overlap 2): %s\n", ok ? "Passed." : "Failed.");
+        fails += ok ? 0 : 1;
+    }
     return fails ? 1 : 0;
 }

@@ -207,3 +207,26 @@ def test_hip_banded_solve_r_on_device(case):
     X = rng.uniform(-1, 1, (cols, 2))
     inv = np.empty_like(qr.rowsPermutation()); inv[qr.rowsPermutation()] = np.arange(rows)
     assert rel_fro(qr.solve((J @ X)[inv]), X) <= 1e-9
+
+
+@pytest.mark.gpu
+def test_hip_banded_fixed_pattern_path():
+    """The fixed-pattern analysis (BandedBlockedSparseQR.h:398-408: fixed-size block type and _BlockOverlap != Dynamic ->
+    fromBlockBandedPattern, SparseQRUtils.h:274-302; qrk_bb_plan_create_fixed) on the reference's un-shuffled overlapping matrix:
+    the block map is the oracle's and the reference's known answer (test-utils.cpp:228-241), and the factorisation equals the
+    generic-analysis one bit for bit (same block map, identity row permutation)."""
+    import qrkit_amd
+    from qrkit_amd.banded import blocks_from_pattern
+    J = banded_matrix(256, True, None)
+    fixed = qrkit_amd.BandedBlockedSparseQR(suggestedBlockCols=8, fixedPattern=(7, 4, 2))
+    generic = qrkit_amd.BandedBlockedSparseQR(suggestedBlockCols=8)
+    fixed.compute(J)
+    generic.compute(J)
+    np.testing.assert_array_equal(fixed.blocks, orc.from_block_banded_pattern(J.shape[0], J.shape[1], 7, 4, 2, 8))
+    np.testing.assert_array_equal(fixed.blocks, blocks_from_pattern(J.shape[0], J.shape[1], 7, 4, 2, 8))
+    np.testing.assert_array_equal(fixed.blocks, generic.blocks)
+    assert not fixed.hasPermutation
+    Rf, Rg = fixed.matrixR(), generic.matrixR()
+    np.testing.assert_array_equal(Rf.indptr, Rg.indptr)
+    np.testing.assert_array_equal(Rf.indices, Rg.indices)
+    np.testing.assert_array_equal(Rf.data, Rg.data)

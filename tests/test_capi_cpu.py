@@ -92,3 +92,18 @@ def test_tiles_from_sparse_rejects_null_arguments():
     from qrkit_amd import _capi
     lib = _capi.lib()
     assert lib.qrk_bd_tiles_from_sparse(None, 0, None, None, None, 0, None, _capi.MEM_HOST) == _capi.STATUS_INVALID_ARGUMENT
+
+
+def test_blocks_from_pattern_matches_oracle_and_known_answers():
+    """qrk_bb_blocks_from_pattern (host logic of the fixed-pattern banded path: BlockBandedMatrixInfo::fromBlockBandedPattern +
+    mergeBlocks, src/QRKit/SparseQRUtils.h:274-385) against the oracle and the reference's known answer
+    (test/test-utils.cpp:228-241: 7x4 blocks, overlap 2 -> 255 blocks (7i, 2i, 7, 4), the last one 14x4)."""
+    from oracle import oracle as orc
+    from qrkit_amd.banded import blocks_from_pattern
+    b = blocks_from_pattern(7 * 256, 2 * 256, 7, 4, 2, 2)
+    assert len(b) == 255
+    assert all(tuple(b[i]) == (7 * i, 2 * i, 7, 4) for i in range(254)) and tuple(b[254]) == (7 * 254, 2 * 254, 14, 4)
+    for args in [(7 * 256, 2 * 256, 7, 4, 2, 2), (7 * 256, 2 * 256, 7, 4, 2, 8), (3300, 3200, 33, 32, 0, 2), (90, 40, 9, 4, 2, 3)]:
+        want = orc.from_block_banded_pattern(*args)
+        assert want is not None
+        np.testing.assert_array_equal(blocks_from_pattern(*args), want)
