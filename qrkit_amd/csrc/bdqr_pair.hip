@@ -55,6 +55,10 @@
 #ifndef QRK_RB
 #define QRK_RB 4               // steps between refreshes of the LDS image (measured on one box: 4 -> 87.1 us, 3 -> 87.4, 2 -> 91.0; 8 needs 22 KB of LDS per wave)
 #endif
+#ifndef QRK_DPPX
+#define QRK_DPPX 1             // 1: the pivot column reaches the lanes as the DPP operand of the FMAs (row_newbcast), no LDS publish / broadcast reads;
+                               // 0: the round-1 form (XBUF in LDS, ds_read_b128 broadcasts), kept for A/B measurements
+#endif
 #ifndef QRK_QSTORE_EVERY
 #define QRK_QSTORE_EVERY 8     // 4, 8 or 16
 #endif
@@ -161,6 +165,33 @@ __device__ __forceinline__ void fmac2_shared_b(double& c0, double& c1, double n0
     asm("v_fmac_f64_e32 %0, %2, %4\n\tv_fmac_f64_e32 %1, %3, %4" : "+v"(c0), "+v"(c1) : "v"(n0), "v"(n1), "v"(x));
 }
 
+// FP64 FMAs whose first factor is a DPP row_newbcast operand: X holds one element of the pivot column per lane (element
+// lane & 15 of its row of 16), and row_newbcast:N hands lane N's element to all 16 lanes of the row -- the broadcast rides on
+// the FMA itself (gfx90a+: the only DPP control the FP64 ALU accepts; measured at 5.25 cycles against 4.94 for the plain FMA,
+// tools/ubench6.hip).  d0 += X[N]*c0; d1 += X[N]*c1.  Same products and the same order as the register form: results are
+// bit-identical.
+template <int N>
+__device__ __forceinline__ void fmac2_bcast_a(double& d0, double& d1, double X, double c0, double c1)
+{
+    asm("v_fmac_f64_dpp %0, %2, %3 row_newbcast:%5 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %1, %2, %4 row_newbcast:%5 row_mask:0xf bank_mask:0xf"
+        : "+v"(d0), "+v"(d1) : "v"(X), "v"(c0), "v"(c1), "n"(N));
+}
+template <int N>
+__device__ __forceinline__ void fmac1_bcast_a(double& d0, double X, double c0)
+{
+    asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(d0) : "v"(X), "v"(c0), "n"(N));
+}
+// element N of the row's X in every lane of the row (the s_nop covers the VALU-write -> DPP-read hazard, which hipcc does not
+// see through an asm statement)
+template <int N>
+__device__ __forceinline__ double bcast_f64(double X)
+{
+    double r;
+    asm("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(X), "n"(N));
+    return r;
+}
+
 // Inverse of e = p(p+1)/2 + i (0 <= i <= p): position in the packed upper triangle by columns.
 __device__ __forceinline__ void tri_unpack(int e, int& p, int& i)
 {
@@ -185,6 +216,9 @@ struct LaneState {
     double nu2;      // m_colNormsUpdated^2
     double thr_nd2;  // sqrt(eps) (1 + 2^-12) * m_colNormsDirect^2: upper edge of the band around Eigen's recompute threshold
     double h[RB];    // entry j of the pivot columns of the last RB steps
+#if QRK_DPPX
+    double xa, xb;   // the pivot column fetched last, spread over the lanes: xa = element (lane & 15), xb = element 16 + (lane & 15)
+#endif
 #ifdef QRK_STAMP
     unsigned long long tk[8];
 #endif
@@ -312,7 +346,15 @@ __device__ __forceinline__ void search_fetch(double* hl /* this half's LDS */, L
         for (int m = (QRK_ABL & 256) ? K : KR; m < K; ++m) xi = fma(hl[L_WBUF + (m % RB) * WR + lbl], st.h[m % RB], xi);
         if (!FULL32) xi = (act && j < st.rows) ? xi : 0.0;
         st.h[K % RB] = xi;
+#if QRK_DPPX
+        // lane j holds element j: v_permlane16_swap gives every lane the element of its partner row as well
+        const auto rl = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(xi), (unsigned)__double2loint(xi), false, false);
+        const auto rh = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(xi), (unsigned)__double2hiint(xi), false, false);
+        st.xa = __hiloint2double((int)rh[0], (int)rl[0]);
+        st.xb = __hiloint2double((int)rh[1], (int)rl[1]);
+#else
         hl[L_XBUF + j] = xi;
+#endif
         QRK_STAMP_IN(2);
     }
 }
@@ -328,37 +370,39 @@ __device__ __forceinline__ void pair_step(double (&a)[WR], double (&q)[WR], doub
 
     // ---- d = x_tail^T c_tail for the A column and the Q^T column (pivot lane: dA = |x_tail|^2)
     const double ak = a[K], qk = q[K];
+    double dA = 0.0, dQ = 0.0;
+#if QRK_DPPX
+    // the pivot column of THIS step (search_fetch<K+1> below replaces st.xa / st.xb before the trailing update runs)
+    const double xa = st.xa, xb = st.xb;
+    const double xk = bcast_f64<(K & 15)>(K < 16 ? xa : xb);
+#define QRK_XROW(I) ((I) < 16 ? xa : xb)
+    if (QRK_ABL & 32) { dA = xk; dQ = xk; }
+    else {
+#define QRK_DOT(I) if ((I) > K) { if (QRK_ABL & 2048) fmac1_bcast_a<((I) & 15)>(dA, QRK_XROW(I), a[I]); else fmac2_bcast_a<((I) & 15)>(dA, dQ, QRK_XROW(I), a[I], q[I]); }
+        QRK_0_31(QRK_DOT)
+#undef QRK_DOT
+    }
+#define QRK_TRAIL(I) if ((I) > K) { if (QRK_ABL & 2048) fmac1_bcast_a<((I) & 15)>(a[I], QRK_XROW(I), ngA); else fmac2_bcast_a<((I) & 15)>(a[I], q[I], QRK_XROW(I), ngA, ngQ); }
+#else
     const double xk = hl[L_XBUF + K];
     double x[WR];                    // rows K+1.. of the pivot column (broadcast reads)
 #pragma unroll
     for (int i = K + 1; i < WR; ++i) x[i] = hl[L_XBUF + i];
-    double dA = 0.0, dQ = 0.0;
     if (QRK_ABL & 32) { dA = xk; dQ = xk; }
     else {
         if (QRK_ABL & 2048) {       // diagnostic: the A columns only
 #pragma unroll
             for (int i = K + 1; i < WR; ++i) dA = fma(x[i], a[i], dA);
         } else {
-#if QRK_DOT4
-        // four accumulation chains (A and Q, even and odd rows): half the dependent length, no wait states between the pairs
-        double eA = 0.0, eQ = 0.0;
-#pragma unroll
-        for (int i = K + 1; i < WR; ++i) {
-            if (i == K + 1) mul2_shared_a(dA, dQ, x[i], a[i], q[i]);
-            else if (i == K + 2) mul2_shared_a(eA, eQ, x[i], a[i], q[i]);
-            else if ((i - K) & 1) fmac2_shared_a(dA, dQ, x[i], a[i], q[i]);
-            else fmac2_shared_a(eA, eQ, x[i], a[i], q[i]);
-        }
-        dA += eA; dQ += eQ;
-#else
 #pragma unroll
         for (int i = K + 1; i < WR; ++i) {
             if (i == K + 1) mul2_shared_a(dA, dQ, x[i], a[i], q[i]);
             else fmac2_shared_a(dA, dQ, x[i], a[i], q[i]);
         }
-#endif
         }
     }
+#define QRK_TRAIL(I) if ((I) > K) { if (QRK_ABL & 2048) a[I] = fma(ngA, x[I], a[I]); else fmac2_shared_b(a[I], q[I], ngA, ngQ, x[I]); }
+#endif
 
     QRK_STAMP_IN(3);
     // ---- makeHouseholder + applyHouseholderOnTheLeft (Eigen/src/Householder/Householder.h) in the
@@ -418,8 +462,7 @@ __device__ __forceinline__ void pair_step(double (&a)[WR], double (&q)[WR], doub
             // decision (2): inside the band [1 - 2^-12, 1 + 2^-12] around Eigen's threshold the test is rounding noise
             if ((QRK_DECISIONS & 4) && st.live && nn <= st.thr_nd2 &&
                 (nn > st.thr_nd2 * (1.0 - 2.0 * MREL) || st.thr_nd2 <= (THR_HI * ND_TINY2) * hl[L_A2])) hl[L_FLAG] = 1.0;
-#pragma unroll
-            for (int i = K + 1; i < WR; ++i) { if (QRK_ABL & 2048) a[i] = fma(ngA, x[i], a[i]); else fmac2_shared_b(a[i], q[i], ngA, ngQ, x[i]); }
+            QRK_0_31(QRK_TRAIL)
             updated = true;
             const bool need = st.live && nn <= st.thr_nd2;
             double sq = 0.0;
@@ -431,10 +474,9 @@ __device__ __forceinline__ void pair_step(double (&a)[WR], double (&q)[WR], doub
 
     // ---- head of the next step, then the trailing update of this one
     if (K + 1 < WR) search_fetch<(K + 1 < WR ? K + 1 : K), FULL32, PIVOT>(hl, st);
-    if (!(QRK_ABL & 16) && !updated) {
-#pragma unroll
-        for (int i = K + 1; i < WR; ++i) { if (QRK_ABL & 2048) a[i] = fma(ngA, x[i], a[i]); else fmac2_shared_b(a[i], q[i], ngA, ngQ, x[i]); }
-    }
+    if (!(QRK_ABL & 16) && !updated) { QRK_0_31(QRK_TRAIL) }
+#undef QRK_TRAIL
+#undef QRK_XROW
     QRK_STAMP_IN(6);
 
     // ---- refresh the LDS image of the live columns after every RB-th step
