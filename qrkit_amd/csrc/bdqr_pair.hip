@@ -896,6 +896,9 @@ void launch_bdqr_pair(const WaveBatch& nb, bool full32, const double* tiles, dou
                       int32_t* redo_count, int32_t* redo_ids, hipStream_t stream)
 {
     if (nb.num_tiles <= 0) return;
+#if QRK_ABL
+    redo_count = nullptr;   // diagnostic builds compute garbage: never hand their tiles to the exact path
+#endif
     const int64_t npairs = (nb.num_tiles + 1) / 2;
     const dim3 grid((unsigned)npairs), block(64);
 #define QRK_LAUNCH(F, P, H)                                                                        \
