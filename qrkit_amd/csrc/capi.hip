@@ -107,6 +107,17 @@ struct qrk_dense_plan_s {
     double* d_copy = nullptr;
     int* d_unclear = nullptr;
     double* d_exact_ws = nullptr;
+    // two-stage form of the pivoted factorisation of a tall matrix (caqr.hip): A = Q0 R0 without pivoting on the matrix cores,
+    // then R0 P = Q1 R by the level-2 kernels on the n x n triangle.  d_r0 keeps the packed QR of the second stage, d_t the T
+    // factors of the first; the caller's array holds the reflectors of Q0 below / inside its top triangles and R above.
+    bool two_stage = false;
+    bool ts_active = false;    // the last factorisation ended in the two-stage format (false: Eigen's packed format, also after the exact path)
+    double* d_t = nullptr;
+    double* d_r0 = nullptr;    // R0 (n x n), scratch of the second stage
+    double* d_q1 = nullptr;    // packed QR of the second stage in Eigen's format (== d_r0 when the row-slab kernels factorise in place)
+    void* d_ws2 = nullptr;
+    int G2 = 0, cpad2 = 0, rows_per2 = 0;
+    bool tall2 = false, cols2 = false;
 };
 
 namespace {
@@ -800,6 +811,32 @@ qrk_status qrk_dense_plan_create(qrk_handle h, int32_t rows, int32_t cols, qrk_b
                                 qrk::dense_tall_persistent_ok(p->G, p->rows_per, h->num_cus);
         }
     }
+    // Two-stage form: pivoted, tall (rows >= 4 cols) and large enough that the level-2 sweeps over the whole matrix dominate.
+    // QRK_DENSE_TWO_STAGE=0/1 overrides (1 needs rows >= cols, pivoting).
+    p->two_stage = p->tall && solver == QRK_COLPIV_HOUSEHOLDER && cols >= 128 && (int64_t)rows >= 4 * (int64_t)cols &&
+                   (int64_t)rows * cols >= (int64_t)1 << 22;
+    if (const char* e = std::getenv("QRK_DENSE_TWO_STAGE")) {
+        if (e[0] == '0') p->two_stage = false;
+        else if (e[0] == '1' && solver == QRK_COLPIV_HOUSEHOLDER && rows >= cols) p->two_stage = true;
+    }
+    if (p->two_stage) {
+        // second stage: the column-parallel kernel (one launch per reflector) when a column fits LDS, else the row-slab kernels
+        const bool fits2 = qrk::dense_qr_smem_bytes(cols, cols) <= 150 * 1024;
+        p->cols2 = qrk::dense_cols_supported(cols, cols) && (int64_t)cols * cols >= 65536;
+        if (const char* e = std::getenv("QRK_DENSE_STAGE2")) p->cols2 = p->cols2 && std::strcmp(e, "slabs") != 0;
+        p->tall2 = !p->cols2 && (!fits2 || (int64_t)cols * cols >= 65536);
+        size_t bytes2 = 0;
+        if (p->cols2) bytes2 = qrk::dense_cols_workspace_bytes(cols, &p->cpad2);
+        else if (p->tall2) bytes2 = qrk::dense_tall_workspace_bytes(cols, cols, h->num_cus, &p->G2, &p->cpad2, &p->rows_per2);
+        if (hipMalloc((void**)&p->d_t, qrk::caqr_t_bytes(rows, cols)) != hipSuccess ||
+            hipMalloc((void**)&p->d_r0, (size_t)cols * (size_t)cols * sizeof(double)) != hipSuccess ||
+            (p->cols2 && hipMalloc((void**)&p->d_q1, (size_t)cols * (size_t)cols * sizeof(double)) != hipSuccess) ||
+            (bytes2 && hipMalloc(&p->d_ws2, bytes2) != hipSuccess)) {
+            qrk_dense_plan_destroy(p);
+            return fail(h, QRK_STATUS_ALLOC_FAILED, "qrk_dense_plan_create: cannot allocate the two-stage workspaces");
+        }
+        if (!p->cols2) p->d_q1 = p->d_r0;
+    }
     // exact path: a copy of the input, the flag of the single-workgroup kernel, the exact kernel's workspace
     if (hipMalloc((void**)&p->d_copy, (size_t)rows * (size_t)cols * sizeof(double)) != hipSuccess ||
         hipMalloc((void**)&p->d_unclear, sizeof(int)) != hipSuccess ||
@@ -813,7 +850,10 @@ qrk_status qrk_dense_plan_create(qrk_handle h, int32_t rows, int32_t cols, qrk_b
 
 qrk_status qrk_dense_plan_destroy(qrk_dense_plan p)
 {
-    if (p) { (void)hipFree(p->d_ws); (void)hipFree(p->d_copy); (void)hipFree(p->d_unclear); (void)hipFree(p->d_exact_ws); }
+    if (p) {
+        (void)hipFree(p->d_ws); (void)hipFree(p->d_copy); (void)hipFree(p->d_unclear); (void)hipFree(p->d_exact_ws);
+        (void)hipFree(p->d_t); if (p->d_q1 != p->d_r0) (void)hipFree(p->d_q1); (void)hipFree(p->d_r0); (void)hipFree(p->d_ws2);
+    }
     delete p;
     return QRK_STATUS_OK;
 }
@@ -832,6 +872,34 @@ qrk_status qrk_dense_factorize(qrk_dense_plan p, double* a, int64_t lda, double*
         QRK_HIP(h, hipMemcpy2DAsync(p->d_copy, (size_t)p->rows * sizeof(double), da, (size_t)lda * sizeof(double),
                                     (size_t)p->rows * sizeof(double), (size_t)p->cols, hipMemcpyDeviceToDevice, h->stream));
         const int* flag = nullptr;
+        p->ts_active = false;
+        if (!h->force_exact && p->two_stage) {
+            // stage 1: A = Q0 R0 (no pivoting, MFMA trailing updates); stage 2: R0 P = Q1 R on the n x n triangle
+            const int n = p->cols;
+            QRK_HIP(h, qrk::launch_caqr_factorize(da, lda, p->rows, n, p->d_t, h->stream));
+            QRK_HIP(h, qrk::launch_caqr_copy_upper(da, lda, p->d_r0, n, n, 1, h->stream));
+            if (p->cols2) {
+                QRK_HIP(h, qrk::launch_dense_qr_cols(p->d_r0, n, n, n, piv, dhc, dp, p->d_ws2, p->cpad2, p->d_q1, n, h->stream));
+                flag = qrk::dense_cols_unclear_ptr(p->d_ws2, p->cpad2);
+            } else if (p->tall2) {
+                QRK_HIP(h, qrk::launch_dense_qr_tall(p->d_r0, n, n, n, piv, dhc, dp, p->d_ws2, p->G2, p->cpad2, p->rows_per2, false, h->stream));
+                flag = qrk::dense_tall_unclear_ptr(p->d_ws2, p->G2, p->cpad2);
+            } else {
+                QRK_HIP(h, hipMemsetAsync(p->d_unclear, 0, sizeof(int), h->stream));
+                QRK_HIP(h, qrk::launch_dense_qr(p->d_r0, n, n, n, piv, dhc, dp, p->d_unclear, h->stream));
+                flag = p->d_unclear;
+            }
+            // R replaces R0 in the caller's array (consumers read R from its upper triangle, as in Eigen's packed format)
+            QRK_HIP(h, qrk::launch_caqr_copy_upper(p->d_q1, n, da, lda, n, 0, h->stream));
+            // a decision of the second stage inside rounding: the exact path redoes the whole matrix in Eigen's operation order
+            // and leaves Eigen's packed format; the host has to know which format the factors are in
+            QRK_HIP(h, qrk::launch_dense_exact(da, lda, p->rows, p->cols, piv, p->d_copy, dhc, dp, flag, p->d_exact_ws, h->stream));
+            int unclear = 0;
+            QRK_HIP(h, hipMemcpyAsync(&unclear, flag, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+            QRK_HIP(h, hipStreamSynchronize(h->stream));
+            p->ts_active = unclear == 0;
+            return QRK_STATUS_OK;
+        }
         if (!h->force_exact) {
             if (p->tall) {
                 QRK_HIP(h, qrk::launch_dense_qr_tall(da, lda, p->rows, p->cols, piv, dhc, dp, p->d_ws, p->G, p->cpad, p->rows_per,
@@ -869,11 +937,26 @@ qrk_status qrk_dense_apply_q(qrk_dense_plan p, const double* qr, int64_t lda, co
     qrk_handle h = p->h;
     QRK_HIP(h, hipSetDevice(h->device));
     const int size = p->rows < p->cols ? p->rows : p->cols;
+    // Q = Q0 diag(Q1, I) after a two-stage factorisation (the factors of Q1 and the T factors of Q0 live in the plan)
+    auto apply = [&](const double* dqr, const double* dhc, double* db) -> hipError_t {
+        auto eigen_form = [&](const double* packed, int64_t ld, int rows, int nrefl) -> hipError_t {
+            if ((size_t)(rows + 4) * sizeof(double) > 150 * 1024)
+                return qrk::launch_dense_apply_q_tall(packed, ld, rows, nrefl, dhc, transpose, db, ldb, nrhs, h->stream);
+            return qrk::launch_dense_apply_q(packed, ld, rows, nrefl, dhc, transpose, db, ldb, nrhs, h->stream);
+        };
+        if (!p->ts_active) return eigen_form(dqr, lda, p->rows, size);
+        hipError_t e = hipSuccess;
+        if (transpose) {
+            e = qrk::launch_caqr_apply(dqr, lda, p->rows, p->cols, p->d_t, 1, db, ldb, nrhs, h->stream);
+            if (e == hipSuccess) e = eigen_form(p->d_q1, p->cols, p->cols, p->cols);
+        } else {
+            e = eigen_form(p->d_q1, p->cols, p->cols, p->cols);
+            if (e == hipSuccess) e = qrk::launch_caqr_apply(dqr, lda, p->rows, p->cols, p->d_t, 0, db, ldb, nrhs, h->stream);
+        }
+        return e;
+    };
     if (space == QRK_MEM_DEVICE) {
-        if ((size_t)(p->rows + 4) * sizeof(double) > 150 * 1024)
-            QRK_HIP(h, qrk::launch_dense_apply_q_tall(qr, lda, p->rows, size, hcoeffs, transpose, b, ldb, nrhs, h->stream));
-        else
-            QRK_HIP(h, qrk::launch_dense_apply_q(qr, lda, p->rows, size, hcoeffs, transpose, b, ldb, nrhs, h->stream));
+        QRK_HIP(h, apply(qr, hcoeffs, b));
         return QRK_STATUS_OK;
     }
     Staging s(h);
@@ -882,10 +965,7 @@ qrk_status qrk_dense_apply_q(qrk_dense_plan p, const double* qr, int64_t lda, co
     if ((st = s.in(qr, lda * p->cols, &d_qr)) || (st = s.in(hcoeffs, (int64_t)size, &d_hc)) ||
         (st = s.in((const double*)b, ldb * nrhs, &d_b)))
         return st;
-    if ((size_t)(p->rows + 4) * sizeof(double) > 150 * 1024)
-        QRK_HIP(h, qrk::launch_dense_apply_q_tall(d_qr, lda, p->rows, size, d_hc, transpose, d_b, ldb, nrhs, h->stream));
-    else
-        QRK_HIP(h, qrk::launch_dense_apply_q(d_qr, lda, p->rows, size, d_hc, transpose, d_b, ldb, nrhs, h->stream));
+    QRK_HIP(h, apply(d_qr, d_hc, d_b));
     if ((st = s.back(b, d_b, ldb * nrhs))) return st;
     QRK_HIP(h, hipStreamSynchronize(h->stream));
     return QRK_STATUS_OK;

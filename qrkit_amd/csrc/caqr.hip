@@ -1,0 +1,455 @@
+// caqr.hip -- communication-avoiding blocked Householder QR (no pivoting) of a TALL dense column-major matrix on all
+// CUs of a gfx950, with the trailing update on the matrix cores (v_mfma_f64_16x16x4_f64).
+//
+// Where it sits.  QRKit::BlockAngularSparseQR::factorize hands the bottom rows of Q1^T J2 to the right solver,
+// rightSolver.compute(J2.bottomRows(...)) (src/QRKit/BlockAngularSparseQR.h:361-369); with the reference's default that is an
+// Eigen::ColPivHouseholderQR of ONE tall dense matrix (BASELINE configs[3]: 40 000 x 2 000).  Column pivoting makes that a
+// level-2 algorithm -- every reflector needs the whole trailing matrix -- and the device path of round 1 (dense_qr_tall.hip)
+// streams 1.3 TB through HBM for it.  For a tall matrix the pivoted factorisation only depends on the Gram structure of the
+// columns, which an un-pivoted QR preserves exactly:  A = Q0 R0  (this file, GEMM-shaped, each entry of A read and written once per
+// 32 columns)  and then  R0 P = Q1 R  (the pivoted level-2 kernels on the n x n triangle: 1/20 of the bytes)  give
+// A P = (Q0 Q1) R with the same pivots and the same R as the direct algorithm up to rounding and up to the sign of each row of R
+// (the sign of a Householder beta follows the pivot entry, which the orthogonal change of basis alters; SURVEY.md section 7
+// normalises diag(R) >= 0 when the elimination order differs).  Pivot decisions inside rounding reach the exact path as before.
+//
+// The algorithm is tall-skinny QR applied panel by panel (CAQR): the rows are cut into CHUNKS of 32, a SLAB is 8 chunks.
+//   level 0   every slab factorises its 256 x 32 piece of the panel on its own (one workgroup, Householder, no communication):
+//             R_s in the upper triangle of its top chunk, the reflectors below, their T factor to a side buffer;
+//   level l   the stack of the R_s of 8 slabs of level l-1 -- 8 triangles, 256 virtual rows -- is factorised the same way.  Column j
+//             of a stack of triangles only has entries in rows <= j of every triangle and the reflectors keep that shape, so the
+//             level-l reflectors are stored IN the upper triangles they annihilate (the strictly lower parts keep the level-0
+//             reflectors), and the top triangle receives the R of the level;
+//   ...       until one slab is left: its R is rows 32 p .. 32 p + 31 of R0.
+// Nothing but kernel boundaries synchronises: 2 launches per level and panel (factorise, apply to the trailing columns), 63 x 4
+// levels for 40 000 x 2 000, against one launch sequence per REFLECTOR in the level-2 path.  The same apply kernel forms Q0^T b / Q0 b.
+//
+// Block reflector of a slab: Q_s = I - Y T Y^T (T upper triangular, LAPACK larft forward/columnwise = Eigen's
+// make_block_householder_triangular_factor); Q_s^T C = C - Y T^T (Y^T C).  On the matrix cores, a wave per 16 columns of C:
+//   W  = Y^T C     D[refl][col]   A = Y^T from LDS, B = C straight from memory (4 rows x 16 columns per step)
+//   W' = -T^T W    the D registers of W are the B operand of this product, k-step by k-step (no data movement)
+//   C += Y W'      as C^T += W'^T Y^T: the D registers of W' are the A operand, B = Y^T from LDS, D = 16 rows x 16 columns of C
+//                  with the ROW on lane & 15 -- column-major C is read and written in 128-byte runs.
+#include "qrk_device.h"
+
+namespace qrk {
+namespace caqr {
+
+constexpr int NB = 32;          // panel width = rows of a chunk
+constexpr int FAN = 8;          // chunks per slab
+constexpr int SR = NB * FAN;    // virtual rows of a slab
+constexpr int LS = NB + 1;      // LDS row stride (doubles): conflict-free by rows and by columns
+constexpr size_t PANEL_LDS = (size_t)(SR * LS + 1 + 2 * FAN * NB + NB * LS + FAN + 2 * NB + 1) * sizeof(double);   // 81 KB
+constexpr size_t APPLY_LDS = (size_t)(SR * LS + NB * LS) * sizeof(double);                                            // 76 KB
+
+// Slab t of a level: chunk i of it is chunk  p + stride (FAN t + i)  of the matrix (rows 32 chunk .. 32 chunk + 31).
+struct Slab {
+    int p, stride, nchunks;     // first active chunk of the panel, chunk stride of the level (FAN^l), chunks of the level
+};
+
+__device__ __forceinline__ int64_t chunk_row0(const Slab& s, int t, int i)
+{
+    return (int64_t)NB * ((int64_t)s.p + (int64_t)s.stride * ((int64_t)FAN * t + i));
+}
+__device__ __forceinline__ int chunk_rows(int64_t row0, int m)
+{
+    const int64_t left = (int64_t)m - row0;
+    return left <= 0 ? 0 : (left < NB ? (int)left : NB);
+}
+
+struct PanelLds {
+    double (*vb)[NB];
+    double (*red)[NB];
+    double (*zz)[LS];
+    double* nrm;
+    double* prow;
+    double* taus;
+    double* x0s;
+};
+
+// Reflector J of the slab (every index into the register arrays is a compile-time constant: a rolled loop leaves them in scratch).
+template <int J>
+__device__ __forceinline__ void panel_step(double (&a)[NB], const PanelLds& L, int c, int i, int w)
+{
+    __syncthreads();                                         // (A) vb holds column J
+    double v[NB];
+#pragma unroll
+    for (int r2 = 0; r2 < NB; r2 += 2) {
+        const double2 t2 = *reinterpret_cast<const double2*>(&L.vb[i][r2]);
+        v[r2] = t2.x; v[r2 + 1] = t2.y;
+    }
+    const double xj = v[J];                                  // pivot entry (meaningful in chunk 0)
+#pragma unroll
+    for (int r2 = 0; r2 < NB; ++r2) if (r2 <= J) v[r2] = (i == 0) ? 0.0 : v[r2];   // rows above and at the pivot are not part of the tail
+    double d = 0.0, s = 0.0;
+#pragma unroll
+    for (int r2 = 0; r2 < NB; ++r2) { d = fma(v[r2], a[r2], d); s = fma(v[r2], v[r2], s); }
+    L.red[i][c] = d;
+    if (c == 0) L.nrm[i] = s;
+    if (i == 0) { L.prow[c] = a[J]; if (c == 0) *L.x0s = xj; }
+    __syncthreads();                                         // (B)
+    double D = 0.0, tailSq = 0.0;
+#pragma unroll
+    for (int ii = 0; ii < FAN; ++ii) { D += L.red[ii][c]; tailSq += L.nrm[ii]; }
+    const double x0 = *L.x0s, a0c = L.prow[c];
+    double tau, beta, inv;
+    if (tailSq <= DBL_MIN) { tau = 0.0; beta = x0; inv = 0.0; }
+    else {
+        beta = sqrt(fma(x0, x0, tailSq));
+        if (x0 >= 0.0) beta = -beta;
+        inv = 1.0 / (x0 - beta);
+        tau = (beta - x0) / beta;
+    }
+    const double tmp = fma(inv, D, a0c);                     // row0 + essential^T bottom
+    // columns right of J: c_J -= tau tmp, tail -= tau tmp essential; column J itself: the essential part in place, beta on the
+    // diagonal (coefficient and multiplier chosen per thread so that one FMA sweep serves both)
+    const double g = tau * tmp;
+    const double coef = c > J ? -(g * inv) : 0.0;
+    if (c > J) {
+        if (i == 0) a[J] -= g;
+#pragma unroll
+        for (int r2 = 0; r2 < NB; ++r2) a[r2] = fma(coef, v[r2], a[r2]);
+    } else if (c == J) {
+#pragma unroll
+        for (int r2 = 0; r2 < NB; ++r2) a[r2] = (r2 <= J && i == 0) ? a[r2] : v[r2] * inv;   // essential part, in place
+        if (i == 0) { a[J] = beta; L.taus[J] = tau; }
+    } else if (i == 0) {
+        L.zz[c][J] = tmp;                                    // y_c^T y_J = Y(J, c) + Y(tail, c)^T essential
+    }
+    if (J + 1 < w && c == J + 1) {
+#pragma unroll
+        for (int r2 = 0; r2 < NB; r2 += 2) *reinterpret_cast<double2*>(&L.vb[i][r2]) = make_double2(a[r2], a[r2 + 1]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Panel factorisation of one slab: Householder QR of 256 (virtual) rows x w <= 32 columns.  Thread (c, i) = (tid & 31, tid >> 5)
+// keeps column c of chunk i in 32 registers; the reflector column travels through 2 KB of LDS, the per-column dots are summed
+// over the 8 chunks through LDS: two barriers per reflector, no other traffic.  Eigen's makeHouseholder /
+// applyHouseholderOnTheLeft (Eigen/src/Householder/Householder.h), real square root and division.
+// TRI: the rows are a stack of upper triangles (entries below the diagonal of a chunk are not data and are left alone).
+template <bool TRI>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2)))   // column + reflector in registers: ~150 VGPRs; 81 KB of LDS allow one workgroup per CU anyway
+caqr_panel_kernel(double* __restrict__ A, int64_t lda, int m, int pc, int w, Slab sl, double* __restrict__ Tout)
+{
+    extern __shared__ __attribute__((aligned(16))) double caqr_lds[];
+    double* sm = caqr_lds;                                                        // [SR][LS] transposing buffer
+    double (*vb)[NB] = reinterpret_cast<double (*)[NB]>(sm + SR * LS + 1);        // [FAN][NB] reflector column (16-byte aligned: SR*LS is odd)
+    double (*red)[NB] = reinterpret_cast<double (*)[NB]>(&vb[FAN][0]);            // [FAN][NB] partial dots
+    double (*zz)[LS] = reinterpret_cast<double (*)[LS]>(&red[FAN][0]);            // [NB][LS] strictly upper part: y_c^T y_j, c < j
+    double* nrm = &zz[NB][0];                                                     // [FAN] partial squared tail norms
+    double* prow = nrm + FAN;                                                     // [NB] pivot row
+    double* taus = prow + NB;                                                     // [NB]
+    double& x0s = taus[NB];
+
+    const int t = blockIdx.x;
+    const int tid = threadIdx.x, c = tid & 31, i = tid >> 5;
+    int cnt = sl.nchunks - FAN * t;
+    cnt = cnt > FAN ? FAN : cnt;
+    const int64_t row0 = chunk_row0(sl, t, i);
+    const int nr = i < cnt ? chunk_rows(row0, m) : 0;
+
+    // ---- load: lane = row of the chunk (column-major A: 256-byte runs), transposed through LDS to lane = column
+    {
+        const int x = c;
+        const double* src = A + (int64_t)pc * lda + row0 + x;
+#pragma unroll 8
+        for (int cc = 0; cc < NB; ++cc) {
+            double v = 0.0;
+            if (cc < w && x < nr && (!TRI || x <= cc)) v = src[(int64_t)cc * lda];
+            sm[(i * NB + x) * LS + cc] = v;
+        }
+    }
+    for (int e = tid; e < NB * LS; e += 256) (&zz[0][0])[e] = 0.0;
+    __syncthreads();
+    double a[NB];
+#pragma unroll
+    for (int r2 = 0; r2 < NB; ++r2) a[r2] = sm[(i * NB + r2) * LS + c];
+
+    if (c == 0) {
+#pragma unroll
+        for (int r2 = 0; r2 < NB; ++r2) vb[i][r2] = a[r2];
+    }
+    PanelLds L{vb, red, zz, nrm, prow, taus, &x0s};
+#define QRK_CAQR_STEP(J) if ((J) < w) panel_step<J>(a, L, c, i, w);
+    QRK_CAQR_STEP(0) QRK_CAQR_STEP(1) QRK_CAQR_STEP(2) QRK_CAQR_STEP(3) QRK_CAQR_STEP(4) QRK_CAQR_STEP(5) QRK_CAQR_STEP(6) QRK_CAQR_STEP(7)
+    QRK_CAQR_STEP(8) QRK_CAQR_STEP(9) QRK_CAQR_STEP(10) QRK_CAQR_STEP(11) QRK_CAQR_STEP(12) QRK_CAQR_STEP(13) QRK_CAQR_STEP(14) QRK_CAQR_STEP(15)
+    QRK_CAQR_STEP(16) QRK_CAQR_STEP(17) QRK_CAQR_STEP(18) QRK_CAQR_STEP(19) QRK_CAQR_STEP(20) QRK_CAQR_STEP(21) QRK_CAQR_STEP(22) QRK_CAQR_STEP(23)
+    QRK_CAQR_STEP(24) QRK_CAQR_STEP(25) QRK_CAQR_STEP(26) QRK_CAQR_STEP(27) QRK_CAQR_STEP(28) QRK_CAQR_STEP(29) QRK_CAQR_STEP(30) QRK_CAQR_STEP(31)
+#undef QRK_CAQR_STEP
+    __syncthreads();
+    // ---- T (forward, columnwise: LAPACK larft / Eigen make_block_householder_triangular_factor):
+    // T(l,l) = tau_l, T(0:l,l) = -tau_l T(0:l,0:l) (Y(:,0:l)^T y_l).  Row a of T only depends on row a: one thread per row.
+    if (tid < NB) {
+        const int ar = tid;
+        double trow[NB];
+#pragma unroll
+        for (int l = 0; l < NB; ++l) {
+            double tv = 0.0;
+            if (l < w) {
+                const double tau = taus[l];
+                if (ar == l) tv = tau;
+                else if (ar < l) {
+                    double acc = 0.0;
+#pragma unroll
+                    for (int b = 0; b < NB; ++b) if (b < l) acc = fma((b >= ar) ? trow[b] : 0.0, zz[b][l], acc);
+                    tv = -tau * acc;
+                }
+            }
+            trow[l] = tv;
+        }
+        double* dst = Tout + (int64_t)t * (NB * NB) + ar * NB;
+#pragma unroll
+        for (int l = 0; l < NB; ++l) dst[l] = trow[l];
+    }
+    // ---- store: back through LDS to lane = row
+#pragma unroll
+    for (int r2 = 0; r2 < NB; ++r2) sm[(i * NB + r2) * LS + c] = a[r2];
+    __syncthreads();
+    {
+        const int x = c;
+        double* dst = A + (int64_t)pc * lda + row0 + x;
+#pragma unroll 8
+        for (int cc = 0; cc < NB; ++cc)
+            if (cc < w && x < nr && (!TRI || x <= cc)) dst[(int64_t)cc * lda] = sm[(i * NB + x) * LS + cc];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// C <- Q_s^T C (transpose != 0) or Q_s C for the block reflector of every slab of a level, C column-major with the row indexing
+// of A.  Grid (slabs, column groups); a wave takes 16 columns at a time.
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+template <bool TRI>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2)))
+caqr_apply_kernel(const double* __restrict__ A, int64_t lda, int m, int pc, int w, Slab sl, const double* __restrict__ Tin,
+                  int transpose, double* __restrict__ C, int64_t ldc, int ncols, int cols_per_wg)
+{
+    extern __shared__ __attribute__((aligned(16))) double caqr_lds[];
+    double* ys = caqr_lds;              // [SR][LS]
+    double* ts = ys + SR * LS;          // [NB][LS]
+    const int t = blockIdx.x;
+    const int tid = threadIdx.x;
+    int cnt = sl.nchunks - FAN * t;
+    cnt = cnt > FAN ? FAN : cnt;
+    // ---- Y of the slab as a dense 256 x 32 matrix (unit diagonal and structural zeros written out)
+    {
+        const int x = tid & 31, y = tid >> 5;
+        const int64_t row0 = chunk_row0(sl, t, y);
+        const int nr = y < cnt ? chunk_rows(row0, m) : 0;
+        const double* src = A + (int64_t)pc * lda + row0 + x;
+#pragma unroll 8
+        for (int cc = 0; cc < NB; ++cc) {
+            double v = 0.0;
+            if (cc < w && x < nr) {
+                if (y == 0) {
+                    if (x == cc) v = 1.0;
+                    else if (!TRI && x > cc) v = src[(int64_t)cc * lda];
+                } else if (!TRI || x <= cc) v = src[(int64_t)cc * lda];
+            }
+            ys[(y * NB + x) * LS + cc] = v;
+        }
+        for (int e = tid; e < NB * NB; e += 256) ts[(e >> 5) * LS + (e & 31)] = Tin[(int64_t)t * (NB * NB) + e];
+    }
+    __syncthreads();
+    const int wave = tid >> 6, lane = tid & 63, kq = lane >> 4, l15 = lane & 15;
+    const int col_base = blockIdx.y * cols_per_wg;
+    const int ntile = (cols_per_wg + 15) >> 4;
+    for (int tile = wave; tile < ntile; tile += 4) {
+        const int n0 = col_base + 16 * tile;
+        if (n0 >= ncols) break;
+        // ---- W = Y^T C
+        d4 acc0 = d4{0.0, 0.0, 0.0, 0.0}, acc1 = d4{0.0, 0.0, 0.0, 0.0};
+        {
+            const int col = n0 + l15;
+            const bool cok = col < ncols;
+            const double* cb = C + (int64_t)col * ldc;
+            for (int ci = 0; ci < cnt; ++ci) {
+                const int64_t row0 = chunk_row0(sl, t, ci);
+                const int nr = chunk_rows(row0, m);
+                double bv[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int rr = 4 * k + kq;
+                    bv[k] = (cok && rr < nr) ? cb[row0 + rr] : 0.0;
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int vrow = ci * NB + 4 * k + kq;
+                    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(ys[vrow * LS + l15], bv[k], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ys[vrow * LS + 16 + l15], bv[k], acc1, 0, 0, 0);
+                }
+            }
+        }
+        // ---- W' = -(T^T or T) W
+        d4 u0 = d4{0.0, 0.0, 0.0, 0.0}, u1 = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            const double bw = ks < 4 ? acc0[ks & 3] : acc1[ks & 3];
+            const int kk = 4 * ks + kq;
+            const double t0 = transpose ? ts[kk * LS + l15] : ts[l15 * LS + kk];
+            const double t1 = transpose ? ts[kk * LS + 16 + l15] : ts[(16 + l15) * LS + kk];
+            u0 = __builtin_amdgcn_mfma_f64_16x16x4f64(t0, bw, u0, 0, 0, 0);
+            u1 = __builtin_amdgcn_mfma_f64_16x16x4f64(t1, bw, u1, 0, 0, 0);
+        }
+        u0 = -u0; u1 = -u1;
+        // ---- C += Y W'  (as C^T += W'^T Y^T: D[column kq + 4 z][row l15])
+        for (int ci = 0; ci < cnt; ++ci) {
+            const int64_t row0 = chunk_row0(sl, t, ci);
+            const int nr = chunk_rows(row0, m);
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) {
+                const int rr = 16 * rt + l15;
+                const bool rok = rr < nr;
+                const int vrow = ci * NB + rr;
+                double* cp = C + row0 + rr;
+                d4 dv;
+#pragma unroll
+                for (int z = 0; z < 4; ++z) {
+                    const int colz = n0 + kq + 4 * z;
+                    dv[z] = (rok && colz < ncols) ? cp[(int64_t)colz * ldc] : 0.0;
+                }
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) {
+                    const double aw = ks < 4 ? u0[ks & 3] : u1[ks & 3];
+                    dv = __builtin_amdgcn_mfma_f64_16x16x4f64(aw, ys[vrow * LS + 4 * ks + kq], dv, 0, 0, 0);
+                }
+#pragma unroll
+                for (int z = 0; z < 4; ++z) {
+                    const int colz = n0 + kq + 4 * z;
+                    if (rok && colz < ncols) cp[(int64_t)colz * ldc] = dv[z];
+                }
+            }
+        }
+    }
+}
+
+// R0 (upper triangle of the first n rows of A) as a dense n x n column-major matrix with zeros below the diagonal, and back
+// (the final R of the pivoted second stage replaces R0 in the caller's array).
+__global__ void caqr_copy_upper_kernel(const double* __restrict__ src, int64_t lds_, double* __restrict__ dst, int64_t ldd, int n,
+                                       int zero_lower)
+{
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (int64_t)n * n) return;
+    const int col = (int)(e / n), row = (int)(e - (int64_t)col * n);
+    if (row <= col) dst[(int64_t)col * ldd + row] = src[(int64_t)col * lds_ + row];
+    else if (zero_lower) dst[(int64_t)col * ldd + row] = 0.0;
+}
+
+}  // namespace caqr
+
+// ---- host side ------------------------------------------------------------------------------------------------------------
+namespace {
+struct CaqrShape { int NC, NP, LMAX, S0; };
+CaqrShape caqr_shape(int m, int n)
+{
+    CaqrShape s;
+    s.NC = (m + caqr::NB - 1) / caqr::NB;
+    s.NP = (n + caqr::NB - 1) / caqr::NB;
+    s.S0 = (s.NC + caqr::FAN - 1) / caqr::FAN;
+    s.LMAX = 1;
+    for (int k = s.S0; k > 1; k = (k + caqr::FAN - 1) / caqr::FAN) ++s.LMAX;
+    return s;
+}
+}  // namespace
+
+size_t caqr_t_bytes(int m, int n)
+{
+    const CaqrShape s = caqr_shape(m, n);
+    return (size_t)s.NP * s.LMAX * s.S0 * caqr::NB * caqr::NB * sizeof(double);
+}
+
+// One panel: factorise level by level, then (ncols > 0) apply the block reflectors of every level to C.
+static hipError_t caqr_panel_levels(double* A, int64_t lda, int m, int p, int w, double* Tbuf, const CaqrShape& s, bool factorize,
+                                    int transpose, double* C, int64_t ldc, int ncols, bool reverse, hipStream_t stream)
+{
+    using namespace caqr;
+    {
+        // dynamic LDS above 64 KB has to be asked for, once per kernel
+        static hipError_t attr = [] {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(caqr_panel_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)PANEL_LDS);
+            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(caqr_panel_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)PANEL_LDS);
+            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(caqr_apply_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)APPLY_LDS);
+            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(caqr_apply_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)APPLY_LDS);
+            return e;
+        }();
+        if (attr != hipSuccess) return attr;
+    }
+    const int pc = p * NB;
+    int nlev = 0, Ks[16], strides[16];
+    for (int K = s.NC - p, stride = 1;; ) {
+        Ks[nlev] = K; strides[nlev] = stride; ++nlev;
+        const int S = (K + FAN - 1) / FAN;
+        if (S <= 1) break;
+        K = S; stride *= FAN;
+    }
+    auto tptr = [&](int l) { return Tbuf + ((size_t)p * s.LMAX + l) * (size_t)s.S0 * (NB * NB); };
+    if (factorize) {
+        for (int l = 0; l < nlev; ++l) {
+            const Slab sl{p, strides[l], Ks[l]};
+            const int S = (Ks[l] + FAN - 1) / FAN;
+            if (l == 0) hipLaunchKernelGGL((caqr_panel_kernel<false>), dim3(S), dim3(256), PANEL_LDS, stream, A, lda, m, pc, w, sl, tptr(l));
+            else hipLaunchKernelGGL((caqr_panel_kernel<true>), dim3(S), dim3(256), PANEL_LDS, stream, A, lda, m, pc, w, sl, tptr(l));
+        }
+    }
+    if (ncols > 0) {
+        for (int li = 0; li < nlev; ++li) {
+            const int l = reverse ? nlev - 1 - li : li;
+            const Slab sl{p, strides[l], Ks[l]};
+            const int S = (Ks[l] + FAN - 1) / FAN;
+            // columns per workgroup: up to 128 (the Y of the slab is loaded once per workgroup), fewer when the level has few slabs,
+            // so that the grid still covers the chip (>= ~512 workgroups)
+            int cg_want = 512 / S; if (cg_want < 1) cg_want = 1;
+            int cols_per_wg = ((ncols + cg_want - 1) / cg_want + 15) / 16 * 16;
+            if (cols_per_wg > 128) cols_per_wg = 128;
+            if (cols_per_wg < 16) cols_per_wg = 16;
+            const int cg = (ncols + cols_per_wg - 1) / cols_per_wg;
+            if (l == 0) hipLaunchKernelGGL((caqr_apply_kernel<false>), dim3(S, cg), dim3(256), APPLY_LDS, stream, A, lda, m, pc, w, sl,
+                                           tptr(l), transpose, C, ldc, ncols, cols_per_wg);
+            else hipLaunchKernelGGL((caqr_apply_kernel<true>), dim3(S, cg), dim3(256), APPLY_LDS, stream, A, lda, m, pc, w, sl,
+                                    tptr(l), transpose, C, ldc, ncols, cols_per_wg);
+        }
+    }
+    return hipGetLastError();
+}
+
+// A (m x n, m >= n, column-major) <- R0 in the upper triangle, the reflectors of all levels below / inside the triangles; Tbuf
+// (caqr_t_bytes) receives the T factors.
+hipError_t launch_caqr_factorize(double* A, int64_t lda, int m, int n, double* Tbuf, hipStream_t stream)
+{
+    const CaqrShape s = caqr_shape(m, n);
+    for (int p = 0; p < s.NP; ++p) {
+        const int pc = p * caqr::NB;
+        const int w = n - pc < caqr::NB ? n - pc : caqr::NB;
+        const int ntrail = n - (pc + w);
+        const hipError_t e = caqr_panel_levels(A, lda, m, p, w, Tbuf, s, true, 1, A + (int64_t)(pc + w) * lda, lda, ntrail, false, stream);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
+// B (m x nrhs, column-major) <- Q0^T B (transpose != 0) or Q0 B.
+hipError_t launch_caqr_apply(const double* A, int64_t lda, int m, int n, const double* Tbuf, int transpose, double* B,
+                             int64_t ldb, int64_t nrhs, hipStream_t stream)
+{
+    if (nrhs <= 0) return hipSuccess;
+    const CaqrShape s = caqr_shape(m, n);
+    for (int pi = 0; pi < s.NP; ++pi) {
+        const int p = transpose ? pi : s.NP - 1 - pi;
+        const int pc = p * caqr::NB;
+        const int w = n - pc < caqr::NB ? n - pc : caqr::NB;
+        const hipError_t e = caqr_panel_levels(const_cast<double*>(A), lda, m, p, w, const_cast<double*>(Tbuf), s, false,
+                                               transpose, B, ldb, (int)nrhs, !transpose, stream);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
+hipError_t launch_caqr_copy_upper(const double* src, int64_t lds_, double* dst, int64_t ldd, int n, int zero_lower, hipStream_t stream)
+{
+    const int64_t tot = (int64_t)n * n;
+    hipLaunchKernelGGL(caqr::caqr_copy_upper_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, stream, src, lds_, dst, ldd, n,
+                       zero_lower);
+    return hipGetLastError();
+}
+
+}  // namespace qrk

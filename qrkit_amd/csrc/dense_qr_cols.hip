@@ -1,0 +1,298 @@
+// dense_qr_cols.hip -- column-pivoted (or plain) Householder QR of a SQUARE-ISH dense matrix whose columns fit LDS
+// (rows <= 8000), one kernel per reflector, a wavefront per column.
+//
+// Where it sits: second stage of the two-stage factorisation of a tall dense right block (caqr.hip;
+// QRKit::BlockAngularSparseQR, rightSolver.compute(J2.bottomRows(...)), src/QRKit/BlockAngularSparseQR.h:361-369): the n x n
+// factor R0 of the un-pivoted first stage is factorised with Eigen's ColPivHouseholderQR rule, R0 P = Q1 R.  The row-slab
+// kernels of dense_qr_tall.hip are built for 40 000 rows: on 2 000 x 2 000 they occupy 16 of 256 CUs and need three kernels per
+// reflector (141 ms).  Here the parallel axis is the COLUMN:
+//   * every workgroup repeats the small serial part of the step itself -- first maximum of the bookkeeping norms, the pivot
+//     column into LDS, |x_tail|^2, the reflector scalars (same data, same order of operations: bitwise the same everywhere) --
+//     so there is no head kernel and no cross-workgroup reduction;
+//   * then one wavefront per remaining column: dot with x, row k of R, rank-1 update, LAWN-176 downdate of its squared norm, and
+//     when Eigen's recompute test fires the wave has the updated column at hand and recomputes the norm itself (no slow path);
+//   * columns are never moved: positions map to physical columns through a ping-pong table (step parity), the pivot column is
+//     read-only during its own step (its essential part and beta are written by the closing kernel, which also gathers the
+//     columns into pivoted order = Eigen's packed format).
+// Pivot bookkeeping, squared norms and the decision margins are those of dense_qr_tall.hip / bdqr_pair.hip: a decision inside
+// its rounding margin sets `unclear` and the exact path redoes the factorisation in Eigen's operation order.
+#include "qrk_device.h"
+
+#include <float.h>
+
+namespace qrk {
+namespace cols {
+
+constexpr int TT = 512;                  // 8 wavefronts: the register-resident column (64 VGPRs) needs more than the 128 VGPRs of a 1024-thread workgroup
+constexpr int TW = TT / 64;
+using namespace decide;
+
+struct State {
+    double a2;       // |A|^2: squared norm of the first pivot column (scale of the decision margins)
+    int unclear;
+};
+
+struct Work {
+    double* nu2[2];   // [cpad] m_colNormsUpdated^2 by POSITION, ping-pong on the parity of the step
+    double* thr[2];   // [cpad] sqrt(eps) (1 + 2^-12) m_colNormsDirect^2
+    int* cmap[2];     // [cpad] physical column at a position
+    double* beta;     // [cpad] per reflector: beta (the diagonal of R)
+    double* invs;     // [cpad] per reflector: 1 / (x0 - beta), 0 if H = I
+    State* st;
+};
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+__global__ void __launch_bounds__(TT)
+cols_init_kernel(const double* __restrict__ A, int64_t lda, int r, int c, Work w)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int jc = blockIdx.x * TW + wave;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { w.st->a2 = 0.0; w.st->unclear = 0; }
+    if (jc >= c) return;
+    double s = 0.0;
+    for (int i = lane; i < r; i += 64) { const double v = A[(int64_t)jc * lda + i]; s = fma(v, v, s); }
+    s = wave_sum(s);
+    if (lane == 0) { w.nu2[0][jc] = s; w.thr[0][jc] = s * THR_HI; w.cmap[0][jc] = jc; }
+}
+
+// Step k.  Grid: ceil((c - k - 1) / 16) workgroups (at least one); dynamic LDS: (r - k) doubles.
+__global__ void __launch_bounds__(TT)
+cols_step_kernel(double* __restrict__ A, int64_t lda, int r, int c, int k, int pivoting, double* __restrict__ hcoeffs,
+                 int32_t* __restrict__ perm, Work w)
+{
+    extern __shared__ double xs[];            // x = rows k .. r-1 of the pivot column
+    __shared__ double red[TW];
+    __shared__ int ired[TW];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = k & 1;
+    // ---- this wave's column, assuming its position is not the one the pivot is swapped with (true for all waves but one):
+    // the loads are issued before the serial part of the step, whose memory round trips they overlap
+    const int pos = k + 1 + blockIdx.x * TW + wave;
+    const int n = r - k - 1;                      // rows below the pivot row
+    const bool cached = n <= 2048;
+    double a[32];
+    double ak = 0.0;
+    int pc = 0;
+    if (pos < c && cached) {
+        pc = w.cmap[b][pos];
+        const double* col0 = A + (int64_t)pc * lda;
+#pragma unroll
+        for (int q = 0; q < 32; ++q) { const int i = q * 64 + lane; a[q] = i < n ? col0[k + 1 + i] : 0.0; }
+        ak = col0[k];
+    }
+    // ---- the pivot: first maximum of the bookkeeping norms over positions k .. c-1 (larger wins, ties -> smaller position)
+    int P = k;
+    double best = 0.0;
+    if (pivoting) {
+        best = -1.0; int bi = c;
+        for (int pos = k + tid; pos < c; pos += TT) { const double v = w.nu2[b][pos]; if (v > best) { best = v; bi = pos; } }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            const double ob = __shfl_xor(best, off);
+            const int oi = __shfl_xor(bi, off);
+            if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+        }
+        if (lane == 0) { red[wave] = best; ired[wave] = bi; }
+        __syncthreads();
+        best = red[0]; bi = ired[0];
+#pragma unroll
+        for (int q = 1; q < TW; ++q) if (red[q] > best || (red[q] == best && ired[q] < bi)) { best = red[q]; bi = ired[q]; }
+        P = bi < c ? bi : k;
+        __syncthreads();
+    }
+    const double a2_in = w.st->a2;            // written by step 0 (a kernel boundary ago)
+    const int pk = w.cmap[b][P];
+    // ---- x into LDS, |x_tail|^2
+    double t = 0.0;
+    for (int i = k + tid; i < r; i += TT) {
+        const double v = A[(int64_t)pk * lda + i];
+        xs[i - k] = v;
+        if (i > k) t = fma(v, v, t);
+    }
+    t = wave_sum(t);
+    if (lane == 0) red[wave] = t;
+    __syncthreads();
+    double tsq = 0.0;
+#pragma unroll
+    for (int q = 0; q < TW; ++q) tsq += red[q];
+    const double xk = xs[0];
+    // makeHouseholder in the un-normalised form of bdqr_pair.hip: nb = -beta, s = x0 - beta, ng = -1/(beta w)
+    double nb, s, ng, tau;
+    const bool degen = !(tsq > DBL_MIN);
+    if (degen) { nb = -xk; s = 0.0; ng = 0.0; tau = 0.0; }
+    else {
+        const double nrm = sqrt(fma(xk, xk, tsq));
+        nb = xk >= 0.0 ? nrm : -nrm;
+        s = nb + xk;
+        ng = -1.0 / (nb * s);
+        tau = -(s * s) * ng;
+    }
+    const double a2 = pivoting ? (k == 0 ? best : a2_in) : (k == 0 ? fma(xk, xk, tsq) : a2_in);
+    if (blockIdx.x == 0) {
+        if (pivoting) {
+            // decision (1): another live column within the error margin of the chosen one
+            bool nr = false;
+            for (int pos = k + tid; pos < c; pos += TT) nr = nr || (pos != P && near_best(w.nu2[b][pos], w.thr[b][pos], best, a2));
+            if (nr) atomicOr(&w.st->unclear, 1);
+        }
+        if (tid == 0) {
+            if (k == 0) w.st->a2 = a2;
+            w.beta[k] = -nb;
+            w.invs[k] = degen ? 0.0 : 1.0 / s;
+            hcoeffs[k] = tau;
+            perm[k] = pk;                                        // colsPermutation().indices()(k)
+            if (unclear_reflector(xk, tsq, k + 1 < r, pivoting != 0, a2)) w.st->unclear = 1;   // decisions (3), (4), (5)
+        }
+    }
+    // ---- one wavefront per remaining position
+    if (pos >= c) return;
+    const int sp = pos == P ? k : pos;            // the swap of positions k and P
+    if (sp != pos || !cached) pc = w.cmap[b][sp];
+    double* col = A + (int64_t)pc * lda;
+    double nn = 0.0, th = 0.0;
+    if (cached) {
+        // the column stays in registers between the dot and the update: one read, one write
+        if (sp != pos) {
+#pragma unroll
+            for (int q = 0; q < 32; ++q) { const int i = q * 64 + lane; a[q] = i < n ? col[k + 1 + i] : 0.0; }
+            ak = col[k];
+        }
+        double d0 = 0.0, d1 = 0.0;
+#pragma unroll
+        for (int q = 0; q < 32; q += 2) {
+            const int i = q * 64 + lane;
+            d0 = fma(i < n ? xs[1 + i] : 0.0, a[q], d0);
+            d1 = fma(i + 64 < n ? xs[1 + i + 64] : 0.0, a[q + 1], d1);
+        }
+        const double d = wave_sum(d0 + d1);
+        const double ngam = fma(s, ak, d) * ng;
+        const double an = fma(s, ngam, ak);
+        double q0 = 0.0, q1 = 0.0;
+#pragma unroll
+        for (int q = 0; q < 32; q += 2) {
+            const int i = q * 64 + lane;
+            if (i < n) { const double v = fma(ngam, xs[1 + i], a[q]); col[k + 1 + i] = v; q0 = fma(v, v, q0); }
+            if (i + 64 < n) { const double v = fma(ngam, xs[1 + i + 64], a[q + 1]); col[k + 1 + i + 64] = v; q1 = fma(v, v, q1); }
+        }
+        const double sq = wave_sum(q0 + q1);
+        if (lane == 0) {
+            col[k] = an;                                          // row k of R
+            if (pivoting) {
+                nn = fma(-an, an, w.nu2[b][sp]); th = w.thr[b][sp];
+                if (nn <= th) {                                   // LAWN-176: recompute from the updated column (which is right here)
+                    if (in_recompute_band(nn, th, a2)) atomicOr(&w.st->unclear, 1);    // decision (2)
+                    nn = sq; th = sq * THR_HI;
+                }
+            }
+        }
+    } else {
+        ak = col[k];
+        double dacc[4] = {0.0, 0.0, 0.0, 0.0};
+        for (int i0 = lane; i0 < n; i0 += 256) {
+            double av[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) av[u] = i0 + 64 * u < n ? col[k + 1 + i0 + 64 * u] : 0.0;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) dacc[u] = fma(i0 + 64 * u < n ? xs[1 + i0 + 64 * u] : 0.0, av[u], dacc[u]);
+        }
+        const double d = wave_sum((dacc[0] + dacc[1]) + (dacc[2] + dacc[3]));
+        const double ngam = fma(s, ak, d) * ng;
+        const double an = fma(s, ngam, ak);
+        double qacc[4] = {0.0, 0.0, 0.0, 0.0};
+        for (int i0 = lane; i0 < n; i0 += 256) {
+            double av[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) av[u] = i0 + 64 * u < n ? col[k + 1 + i0 + 64 * u] : 0.0;
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (i0 + 64 * u < n) { const double v = fma(ngam, xs[1 + i0 + 64 * u], av[u]); col[k + 1 + i0 + 64 * u] = v; qacc[u] = fma(v, v, qacc[u]); }
+        }
+        const double sq = wave_sum((qacc[0] + qacc[1]) + (qacc[2] + qacc[3]));
+        if (lane == 0) {
+            col[k] = an;
+            if (pivoting) {
+                nn = fma(-an, an, w.nu2[b][sp]); th = w.thr[b][sp];
+                if (nn <= th) {
+                    if (in_recompute_band(nn, th, a2)) atomicOr(&w.st->unclear, 1);
+                    nn = sq; th = sq * THR_HI;
+                }
+            }
+        }
+    }
+    if (lane == 0) { w.nu2[b ^ 1][pos] = nn; w.thr[b ^ 1][pos] = th; w.cmap[b ^ 1][pos] = pc; }
+}
+
+// Closing pass: Eigen's packed format in pivoted column order, out(:, pos) from the physical column perm[pos]: rows above the
+// diagonal as they are (rows of R), beta on the diagonal, the essential part x_tail / (x0 - beta) below.
+__global__ void __launch_bounds__(256)
+cols_finish_kernel(const double* __restrict__ A, int64_t lda, int r, int c, int size, const int32_t* __restrict__ perm, Work w,
+                   double* __restrict__ out, int64_t ldo)
+{
+    const int pos = blockIdx.x;
+    const int pk = perm[pos];
+    const bool refl = pos < size;
+    const double beta = refl ? w.beta[pos] : 0.0, inv = refl ? w.invs[pos] : 0.0;
+    for (int i = threadIdx.x; i < r; i += 256) {
+        double v = A[(int64_t)pk * lda + i];
+        if (refl) { if (i == pos) v = beta; else if (i > pos) v *= inv; }
+        out[(int64_t)pos * ldo + i] = v;
+    }
+}
+// positions size .. c-1 of a wide matrix keep their final bookkeeping order
+__global__ void cols_tail_perm_kernel(int c, int size, Work w, int32_t* __restrict__ perm)
+{
+    const int pos = size + blockIdx.x * blockDim.x + threadIdx.x;
+    if (pos < c) perm[pos] = w.cmap[size & 1][pos];
+}
+
+}  // namespace cols
+
+size_t dense_cols_workspace_bytes(int c, int* cpad_out)
+{
+    const int cpad = (c + 63) / 64 * 64;
+    *cpad_out = cpad;
+    return (size_t)cpad * (6 * sizeof(double) + 2 * sizeof(int)) + 256;
+}
+bool dense_cols_supported(int r, int c) { return r >= 1 && r <= 8000 && c >= 1; }
+int* dense_cols_unclear_ptr(void* workspace, int cpad)
+{
+    char* p = static_cast<char*>(workspace) + (size_t)cpad * (6 * sizeof(double) + 2 * sizeof(int));
+    p = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(p) + 63) & ~(uintptr_t)63);
+    return &reinterpret_cast<cols::State*>(p)->unclear;
+}
+
+// A (r x c, column-major, r <= 8000) is the input and the scratch of the factorisation; `out` (ldo >= r) receives Eigen's packed QR
+// in pivoted column order, hcoeffs the tau, perm the column permutation.
+hipError_t launch_dense_qr_cols(double* A, int64_t lda, int r, int c, int pivoting, double* hcoeffs, int32_t* perm, void* workspace,
+                                int cpad, double* out, int64_t ldo, hipStream_t stream)
+{
+    using namespace cols;
+    Work w;
+    char* p = static_cast<char*>(workspace);
+    for (int q = 0; q < 2; ++q) { w.nu2[q] = reinterpret_cast<double*>(p); p += (size_t)cpad * sizeof(double); }
+    for (int q = 0; q < 2; ++q) { w.thr[q] = reinterpret_cast<double*>(p); p += (size_t)cpad * sizeof(double); }
+    w.beta = reinterpret_cast<double*>(p); p += (size_t)cpad * sizeof(double);
+    w.invs = reinterpret_cast<double*>(p); p += (size_t)cpad * sizeof(double);
+    for (int q = 0; q < 2; ++q) { w.cmap[q] = reinterpret_cast<int*>(p); p += (size_t)cpad * sizeof(int); }
+    p = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(p) + 63) & ~(uintptr_t)63);
+    w.st = reinterpret_cast<State*>(p);
+    const int size = r < c ? r : c;
+    hipLaunchKernelGGL(cols_init_kernel, dim3((c + TW - 1) / TW), dim3(TT), 0, stream, A, lda, r, c, w);
+    for (int k = 0; k < size; ++k) {
+        int nwg = (c - k - 1 + TW - 1) / TW;
+        if (nwg < 1) nwg = 1;
+        hipLaunchKernelGGL(cols_step_kernel, dim3(nwg), dim3(TT), (size_t)(r - k) * sizeof(double), stream, A, lda, r, c, k, pivoting,
+                           hcoeffs, perm, w);
+    }
+    if (c > size) hipLaunchKernelGGL(cols_tail_perm_kernel, dim3((c - size + 255) / 256), dim3(256), 0, stream, c, size, w, perm);
+    hipLaunchKernelGGL(cols_finish_kernel, dim3(c), dim3(256), 0, stream, A, lda, r, c, size, perm, w, out, ldo);
+    return hipGetLastError();
+}
+
+}  // namespace qrk

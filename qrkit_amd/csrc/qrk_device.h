@@ -84,6 +84,20 @@ hipError_t launch_dense_exact(double* A, int64_t lda, int r, int c, int pivoting
 size_t dense_exact_workspace_bytes(int r, int c);
 hipError_t launch_dense_apply_q(const double* QR, int64_t lda, int r, int nrefl, const double* hcoeffs,
                                 int transpose, double* B, int64_t ldb, int64_t nrhs, hipStream_t stream);
+// Un-pivoted communication-avoiding QR of a tall matrix on all CUs, MFMA trailing update (caqr.hip): first stage of the pivoted
+// factorisation of tall dense right blocks.  Tbuf: caqr_t_bytes(m, n).
+size_t caqr_t_bytes(int m, int n);
+hipError_t launch_caqr_factorize(double* A, int64_t lda, int m, int n, double* Tbuf, hipStream_t stream);
+hipError_t launch_caqr_apply(const double* A, int64_t lda, int m, int n, const double* Tbuf, int transpose, double* B, int64_t ldb,
+                             int64_t nrhs, hipStream_t stream);
+hipError_t launch_caqr_copy_upper(const double* src, int64_t lds_, double* dst, int64_t ldd, int n, int zero_lower, hipStream_t stream);
+// Column-parallel pivoted Householder QR of a square-ish matrix whose columns fit LDS (dense_qr_cols.hip): one kernel per reflector,
+// a wavefront per column; second stage of the two-stage form.
+size_t dense_cols_workspace_bytes(int c, int* cpad);
+bool dense_cols_supported(int r, int c);
+int* dense_cols_unclear_ptr(void* workspace, int cpad);
+hipError_t launch_dense_qr_cols(double* A, int64_t lda, int r, int c, int pivoting, double* hcoeffs, int32_t* perm, void* workspace,
+                                int cpad, double* out, int64_t ldo, hipStream_t stream);
 struct BBPanel;
 hipError_t launch_bb_chain(const BBPanel* panels, int num_panels, const int32_t* prowptr, const int32_t* pcol,
                            const int64_t* pmap, const double* vals, double* W, double* lo, double* y_vals,

@@ -178,3 +178,43 @@ def test_dense_generic_matrix_is_not_redone():
     got = At.cpu().numpy()
     assert rel_fro(np.triu(got[:64]), np.triu(ref[:64])) <= 1e-12
     assert not np.array_equal(got, ref)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows,cols", [(2048, 96), (4100, 200), (6000, 300), (700, 64)])
+def test_two_stage_tall_colpiv_matches_oracle(rows, cols, monkeypatch):
+    """The two-stage form of the pivoted QR of a tall right block (caqr.hip: A = Q0 R0 without pivoting on the matrix cores,
+    then R0 P = Q1 R on the triangle) against Eigen's direct ColPivHouseholderQR as restated by the oracle
+    (BlockAngularSparseQR.h:361-369): permutation bit-exact, R equal after aligning the sign of each row (the sign of a
+    Householder beta follows the pivot entry, which the change of basis alters: SURVEY.md section 7), Q^T A P = R, Q Q^T b = b and
+    the least-squares solution through the implicit Q.  Shapes: whole chunks / ragged last chunk and last panel / one slab only."""
+    import torch
+    monkeypatch.setenv("QRK_DENSE_TWO_STAGE", "1")
+    rng = np.random.default_rng(rows + 3 * cols)
+    A = rng.uniform(-1.0, 1.0, (rows, cols)) * rng.uniform(0.5, 2.0, cols)[None, :]
+    qr, At = _factor(A, 0, None)
+    got = At.cpu().numpy()
+    ref, hc, perm, _ = orc.colpiv_qr(A)
+    P = qr.colsPermutation().cpu().numpy()
+    np.testing.assert_array_equal(P, perm)                                           # bit-exact
+    # (the reflectors below the diagonal are those of Q0, not Eigen's: evidence that the two-stage path is the one that ran)
+    assert rel_fro(np.tril(got, -1), np.tril(ref, -1)) > 1e-3
+    Rg, Rr = np.triu(got[:cols, :]), np.triu(ref[:cols, :])
+    sg = np.sign(np.diag(Rg)) * np.sign(np.diag(Rr))
+    assert np.all(sg != 0)
+    row_err = np.linalg.norm(Rg * sg[:, None] - Rr, axis=1) / np.linalg.norm(Rr, axis=1)
+    assert row_err.max() <= 1e-11, row_err.max()                                     # every row of R, not one batch ratio
+    B = torch.from_numpy(np.asfortranarray(A[:, P]).T.copy()).cuda().t()
+    qr.applyQ(B, transpose=True)
+    Rfull = np.zeros((rows, cols)); Rfull[:cols, :] = Rg
+    assert np.linalg.norm(B.cpu().numpy() - Rfull) <= 1e-12 * np.linalg.norm(A) * np.sqrt(cols)
+    qr.applyQ(B, transpose=False)
+    assert rel_fro(B.cpu().numpy(), A[:, P]) <= 1e-12 * np.sqrt(cols)
+    x = rng.uniform(-1, 1, cols)
+    b = torch.from_numpy((A @ x)[None, :].copy()).cuda().t()
+    qr.applyQ(b, transpose=True)
+    assert np.linalg.norm(b.cpu().numpy()[cols:, 0]) <= 1e-11 * np.linalg.norm(A @ x)  # b is in the range of A
+    z = b[:cols, :].t().contiguous().t()
+    qr.solveR(z)
+    xs = np.empty(cols); xs[P] = z.cpu().numpy()[:, 0]
+    assert rel_fro(xs, x) <= 1e-9
