@@ -116,8 +116,13 @@ struct qrk_dense_plan_s {
     double* d_r0 = nullptr;    // R0 (n x n), scratch of the second stage
     double* d_q1 = nullptr;    // packed QR of the second stage in Eigen's format (== d_r0 when the row-slab kernels factorise in place)
     void* d_ws2 = nullptr;
+    hipStream_t la_stream = nullptr;               // look-ahead of the first stage: the next panel is factorised beside the trailing update
+    hipEvent_t la_urgent = nullptr, la_factored = nullptr;
     int G2 = 0, cpad2 = 0, rows_per2 = 0;
     bool tall2 = false, cols2 = false;
+    // column-parallel kernel as the DIRECT algorithm (same reflectors, signs and format as Eigen) when a column fits LDS: d_q1 then
+    // receives the packed result (rows x cols), copied back into the caller's array
+    bool cols_direct = false;
 };
 
 namespace {
@@ -790,7 +795,8 @@ qrk_status qrk_dense_plan_create(qrk_handle h, int32_t rows, int32_t cols, qrk_b
     const bool fits = qrk::dense_qr_smem_bytes(rows, cols) <= 150 * 1024;
     p->tall = !fits || (int64_t)rows * cols >= 65536;
     if (const char* e = std::getenv("QRK_DENSE_PATH")) {
-        if (!std::strcmp(e, "tall")) p->tall = true;
+        if (!std::strcmp(e, "tall") || !std::strcmp(e, "slabs") || !std::strcmp(e, "cols")) p->tall = true;   // "tall": the multi-workgroup
+        // paths, whichever fits; "slabs" / "cols": the row-slab kernels (dense_qr_tall.hip) / the column-parallel kernel (dense_qr_cols.hip)
         else if (!std::strcmp(e, "single") && fits) p->tall = false;
     }
     if (p->tall) {
@@ -819,6 +825,15 @@ qrk_status qrk_dense_plan_create(qrk_handle h, int32_t rows, int32_t cols, qrk_b
         if (e[0] == '0') p->two_stage = false;
         else if (e[0] == '1' && solver == QRK_COLPIV_HOUSEHOLDER && rows >= cols) p->two_stage = true;
     }
+    p->cols_direct = p->tall && !p->two_stage && !p->persistent && qrk::dense_cols_supported(rows, cols);
+    if (const char* e = std::getenv("QRK_DENSE_PATH")) { if (!std::strcmp(e, "slabs")) p->cols_direct = false; }
+    if (p->cols_direct) {
+        const size_t bytes2 = qrk::dense_cols_workspace_bytes(cols, &p->cpad2);
+        if (hipMalloc((void**)&p->d_q1, (size_t)rows * (size_t)cols * sizeof(double)) != hipSuccess || hipMalloc(&p->d_ws2, bytes2) != hipSuccess) {
+            qrk_dense_plan_destroy(p);
+            return fail(h, QRK_STATUS_ALLOC_FAILED, "qrk_dense_plan_create: cannot allocate the workspaces of the column-parallel kernel");
+        }
+    }
     if (p->two_stage) {
         // second stage: the column-parallel kernel (one launch per reflector) when a column fits LDS, else the row-slab kernels
         const bool fits2 = qrk::dense_qr_smem_bytes(cols, cols) <= 150 * 1024;
@@ -836,6 +851,14 @@ qrk_status qrk_dense_plan_create(qrk_handle h, int32_t rows, int32_t cols, qrk_b
             return fail(h, QRK_STATUS_ALLOC_FAILED, "qrk_dense_plan_create: cannot allocate the two-stage workspaces");
         }
         if (!p->cols2) p->d_q1 = p->d_r0;
+        const char* la = std::getenv("QRK_CAQR_LOOKAHEAD");
+        if (!(la && la[0] == '0') &&
+            (hipStreamCreateWithFlags(&p->la_stream, hipStreamNonBlocking) != hipSuccess ||
+             hipEventCreateWithFlags(&p->la_urgent, hipEventDisableTiming) != hipSuccess ||
+             hipEventCreateWithFlags(&p->la_factored, hipEventDisableTiming) != hipSuccess)) {
+            qrk_dense_plan_destroy(p);
+            return fail(h, QRK_STATUS_ALLOC_FAILED, "qrk_dense_plan_create: cannot create the look-ahead stream");
+        }
     }
     // exact path: a copy of the input, the flag of the single-workgroup kernel, the exact kernel's workspace
     if (hipMalloc((void**)&p->d_copy, (size_t)rows * (size_t)cols * sizeof(double)) != hipSuccess ||
@@ -852,6 +875,9 @@ qrk_status qrk_dense_plan_destroy(qrk_dense_plan p)
 {
     if (p) {
         (void)hipFree(p->d_ws); (void)hipFree(p->d_copy); (void)hipFree(p->d_unclear); (void)hipFree(p->d_exact_ws);
+        if (p->la_stream) (void)hipStreamDestroy(p->la_stream);
+        if (p->la_urgent) (void)hipEventDestroy(p->la_urgent);
+        if (p->la_factored) (void)hipEventDestroy(p->la_factored);
         (void)hipFree(p->d_t); if (p->d_q1 != p->d_r0) (void)hipFree(p->d_q1); (void)hipFree(p->d_r0); (void)hipFree(p->d_ws2);
     }
     delete p;
@@ -876,7 +902,7 @@ qrk_status qrk_dense_factorize(qrk_dense_plan p, double* a, int64_t lda, double*
         if (!h->force_exact && p->two_stage) {
             // stage 1: A = Q0 R0 (no pivoting, MFMA trailing updates); stage 2: R0 P = Q1 R on the n x n triangle
             const int n = p->cols;
-            QRK_HIP(h, qrk::launch_caqr_factorize(da, lda, p->rows, n, p->d_t, h->stream));
+            QRK_HIP(h, qrk::launch_caqr_factorize(da, lda, p->rows, n, p->d_t, h->stream, p->la_stream, p->la_urgent, p->la_factored));
             QRK_HIP(h, qrk::launch_caqr_copy_upper(da, lda, p->d_r0, n, n, 1, h->stream));
             if (p->cols2) {
                 QRK_HIP(h, qrk::launch_dense_qr_cols(p->d_r0, n, n, n, piv, dhc, dp, p->d_ws2, p->cpad2, p->d_q1, n, h->stream));
@@ -901,7 +927,12 @@ qrk_status qrk_dense_factorize(qrk_dense_plan p, double* a, int64_t lda, double*
             return QRK_STATUS_OK;
         }
         if (!h->force_exact) {
-            if (p->tall) {
+            if (p->cols_direct) {
+                QRK_HIP(h, qrk::launch_dense_qr_cols(da, lda, p->rows, p->cols, piv, dhc, dp, p->d_ws2, p->cpad2, p->d_q1, p->rows, h->stream));
+                QRK_HIP(h, hipMemcpy2DAsync(da, (size_t)lda * sizeof(double), p->d_q1, (size_t)p->rows * sizeof(double),
+                                            (size_t)p->rows * sizeof(double), (size_t)p->cols, hipMemcpyDeviceToDevice, h->stream));
+                flag = qrk::dense_cols_unclear_ptr(p->d_ws2, p->cpad2);
+            } else if (p->tall) {
                 QRK_HIP(h, qrk::launch_dense_qr_tall(da, lda, p->rows, p->cols, piv, dhc, dp, p->d_ws, p->G, p->cpad, p->rows_per,
                                                      p->persistent, h->stream));
                 flag = qrk::dense_tall_unclear_ptr(p->d_ws, p->G, p->cpad);

@@ -38,7 +38,7 @@ constexpr int NB = 32;          // panel width = rows of a chunk
 constexpr int FAN = 8;          // chunks per slab
 constexpr int SR = NB * FAN;    // virtual rows of a slab
 constexpr int LS = NB + 1;      // LDS row stride (doubles): conflict-free by rows and by columns
-constexpr size_t PANEL_LDS = (size_t)(SR * LS + 1 + 2 * FAN * NB + NB * LS + FAN + 2 * NB + 1) * sizeof(double);   // 81 KB
+constexpr size_t PANEL_LDS = (size_t)(SR * LS + 2 * FAN * NB + NB * LS + FAN + 2 * NB + 1) * sizeof(double);   // 81 KB
 constexpr size_t APPLY_LDS = (size_t)(SR * LS + NB * LS) * sizeof(double);                                            // 76 KB
 
 // Slab t of a level: chunk i of it is chunk  p + stride (FAN t + i)  of the matrix (rows 32 chunk .. 32 chunk + 31).
@@ -56,6 +56,28 @@ __device__ __forceinline__ int chunk_rows(int64_t row0, int m)
     return left <= 0 ? 0 : (left < NB ? (int)left : NB);
 }
 
+// sqrt(x) of a positive normal x by v_rsq_f64 + one Goldschmidt iteration + one residual correction (<= 1 ulp), and 1/x by v_rcp_f64 +
+// two Newton steps (<= 1 ulp): the dependent chains of the IEEE sqrt / division sequences are three times as long, and with one
+// wave per SIMD nothing hides them (same forms as bdqr_pair.hip).
+__device__ __forceinline__ double fast_sqrt(double x)
+{
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = 0.5 * y;
+    const double e = fma(-h, g, 0.5);
+    g = fma(g, e, g);
+    h = fma(h, e, h);
+    const double d = fma(-g, g, x);
+    return fma(d, h, g);
+}
+__device__ __forceinline__ double fast_recip(double x)
+{
+    double y = __builtin_amdgcn_rcp(x);
+    double e = fma(-x, y, 1.0);
+    y = fma(y, e, y);
+    e = fma(-x, y, 1.0);
+    return fma(y, e, y);
+}
+
 struct PanelLds {
     double (*vb)[NB];
     double (*red)[NB];
@@ -64,13 +86,23 @@ struct PanelLds {
     double* prow;
     double* taus;
     double* x0s;
+#ifdef QRK_CAQR_STAMP
+    unsigned long long* fine;      // diagnostic: s_memtime inside step 16
+#endif
 };
 
 // Reflector J of the slab (every index into the register arrays is a compile-time constant: a rolled loop leaves them in scratch).
 template <int J>
 __device__ __forceinline__ void panel_step(double (&a)[NB], const PanelLds& L, int c, int i, int w)
 {
+#ifdef QRK_CAQR_STAMP
+#define QRK_FINE(n) do { if (J == 16 && c == 0 && i == 0) L.fine[n] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define QRK_FINE(n) do { } while (0)
+#endif
+    QRK_FINE(0);
     __syncthreads();                                         // (A) vb holds column J
+    QRK_FINE(1);
     double v[NB];
 #pragma unroll
     for (int r2 = 0; r2 < NB; r2 += 2) {
@@ -80,26 +112,37 @@ __device__ __forceinline__ void panel_step(double (&a)[NB], const PanelLds& L, i
     const double xj = v[J];                                  // pivot entry (meaningful in chunk 0)
 #pragma unroll
     for (int r2 = 0; r2 < NB; ++r2) if (r2 <= J) v[r2] = (i == 0) ? 0.0 : v[r2];   // rows above and at the pivot are not part of the tail
-    double d = 0.0, s = 0.0;
+    double d0 = 0.0, d1 = 0.0, d2 = 0.0, d3 = 0.0, s0 = 0.0, s1 = 0.0;    // partial sums: no FMA waits for its predecessor
 #pragma unroll
-    for (int r2 = 0; r2 < NB; ++r2) { d = fma(v[r2], a[r2], d); s = fma(v[r2], v[r2], s); }
-    L.red[i][c] = d;
-    if (c == 0) L.nrm[i] = s;
+    for (int r2 = 0; r2 < NB; r2 += 4) {
+        d0 = fma(v[r2], a[r2], d0); d1 = fma(v[r2 + 1], a[r2 + 1], d1); d2 = fma(v[r2 + 2], a[r2 + 2], d2); d3 = fma(v[r2 + 3], a[r2 + 3], d3);
+        s0 = fma(v[r2], v[r2], s0); s1 = fma(v[r2 + 1], v[r2 + 1], s1); s0 = fma(v[r2 + 2], v[r2 + 2], s0); s1 = fma(v[r2 + 3], v[r2 + 3], s1);
+    }
+    L.red[i][c] = (d0 + d1) + (d2 + d3);
+    if (c == 0) L.nrm[i] = s0 + s1;
     if (i == 0) { L.prow[c] = a[J]; if (c == 0) *L.x0s = xj; }
+    QRK_FINE(2);
     __syncthreads();                                         // (B)
-    double D = 0.0, tailSq = 0.0;
+    QRK_FINE(3);
+    double rr[FAN], nn[FAN];
 #pragma unroll
-    for (int ii = 0; ii < FAN; ++ii) { D += L.red[ii][c]; tailSq += L.nrm[ii]; }
+    for (int ii = 0; ii < FAN; ++ii) { rr[ii] = L.red[ii][c]; nn[ii] = L.nrm[ii]; }
+    const double D = ((rr[0] + rr[1]) + (rr[2] + rr[3])) + ((rr[4] + rr[5]) + (rr[6] + rr[7]));
+    const double tailSq = ((nn[0] + nn[1]) + (nn[2] + nn[3])) + ((nn[4] + nn[5]) + (nn[6] + nn[7]));
+    static_assert((SR * LS) % 2 == 0, "vb is read and written with 16-byte LDS accesses");
+    static_assert(FAN == 8, "the sums above are written for 8 chunks");
     const double x0 = *L.x0s, a0c = L.prow[c];
     double tau, beta, inv;
     if (tailSq <= DBL_MIN) { tau = 0.0; beta = x0; inv = 0.0; }
     else {
-        beta = sqrt(fma(x0, x0, tailSq));
+        beta = fast_sqrt(fma(x0, x0, tailSq));
         if (x0 >= 0.0) beta = -beta;
-        inv = 1.0 / (x0 - beta);
-        tau = (beta - x0) / beta;
+        const double wv = x0 - beta;                 // |w| >= |beta|: no cancellation (beta and x0 have opposite signs)
+        inv = fast_recip(wv);
+        tau = -wv * fast_recip(beta);                // (beta - x0) / beta
     }
     const double tmp = fma(inv, D, a0c);                     // row0 + essential^T bottom
+    QRK_FINE(4);
     // columns right of J: c_J -= tau tmp, tail -= tau tmp essential; column J itself: the essential part in place, beta on the
     // diagonal (coefficient and multiplier chosen per thread so that one FMA sweep serves both)
     const double g = tau * tmp;
@@ -110,15 +153,20 @@ __device__ __forceinline__ void panel_step(double (&a)[NB], const PanelLds& L, i
         for (int r2 = 0; r2 < NB; ++r2) a[r2] = fma(coef, v[r2], a[r2]);
     } else if (c == J) {
 #pragma unroll
-        for (int r2 = 0; r2 < NB; ++r2) a[r2] = (r2 <= J && i == 0) ? a[r2] : v[r2] * inv;   // essential part, in place
+        for (int r2 = 0; r2 < NB; ++r2) {                        // essential part, in place (chunk 0 keeps its rows of R above the pivot)
+            if (r2 > J) a[r2] = v[r2] * inv;
+            else a[r2] = (i == 0) ? a[r2] : v[r2] * inv;
+        }
         if (i == 0) { a[J] = beta; L.taus[J] = tau; }
     } else if (i == 0) {
         L.zz[c][J] = tmp;                                    // y_c^T y_J = Y(J, c) + Y(tail, c)^T essential
     }
+    QRK_FINE(5);
     if (J + 1 < w && c == J + 1) {
 #pragma unroll
         for (int r2 = 0; r2 < NB; r2 += 2) *reinterpret_cast<double2*>(&L.vb[i][r2]) = make_double2(a[r2], a[r2 + 1]);
     }
+    QRK_FINE(6);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -133,7 +181,7 @@ caqr_panel_kernel(double* __restrict__ A, int64_t lda, int m, int pc, int w, Sla
 {
     extern __shared__ __attribute__((aligned(16))) double caqr_lds[];
     double* sm = caqr_lds;                                                        // [SR][LS] transposing buffer
-    double (*vb)[NB] = reinterpret_cast<double (*)[NB]>(sm + SR * LS + 1);        // [FAN][NB] reflector column (16-byte aligned: SR*LS is odd)
+    double (*vb)[NB] = reinterpret_cast<double (*)[NB]>(sm + SR * LS);            // [FAN][NB] reflector column (16-byte aligned: SR * LS is even)
     double (*red)[NB] = reinterpret_cast<double (*)[NB]>(&vb[FAN][0]);            // [FAN][NB] partial dots
     double (*zz)[LS] = reinterpret_cast<double (*)[LS]>(&red[FAN][0]);            // [NB][LS] strictly upper part: y_c^T y_j, c < j
     double* nrm = &zz[NB][0];                                                     // [FAN] partial squared tail norms
@@ -152,12 +200,11 @@ caqr_panel_kernel(double* __restrict__ A, int64_t lda, int m, int pc, int w, Sla
     {
         const int x = c;
         const double* src = A + (int64_t)pc * lda + row0 + x;
-#pragma unroll 8
-        for (int cc = 0; cc < NB; ++cc) {
-            double v = 0.0;
-            if (cc < w && x < nr && (!TRI || x <= cc)) v = src[(int64_t)cc * lda];
-            sm[(i * NB + x) * LS + cc] = v;
-        }
+        double ld[NB];                   // all 32 loads in flight at once
+#pragma unroll
+        for (int cc = 0; cc < NB; ++cc) ld[cc] = (cc < w && x < nr && (!TRI || x <= cc)) ? src[(int64_t)cc * lda] : 0.0;
+#pragma unroll
+        for (int cc = 0; cc < NB; ++cc) sm[(i * NB + x) * LS + cc] = ld[cc];
     }
     for (int e = tid; e < NB * LS; e += 256) (&zz[0][0])[e] = 0.0;
     __syncthreads();
@@ -169,38 +216,82 @@ caqr_panel_kernel(double* __restrict__ A, int64_t lda, int m, int pc, int w, Sla
 #pragma unroll
         for (int r2 = 0; r2 < NB; ++r2) vb[i][r2] = a[r2];
     }
+#ifdef QRK_CAQR_STAMP   // diagnostic only (tools/caqr_bench.hip): s_memtime at phase boundaries, parked in the (zero) strictly lower part of T
+#define QRK_CAQR_STAMP_AT(n) do { if (tid == 0) stamps[n] = __builtin_amdgcn_s_memtime(); } while (0)
+    __shared__ unsigned long long stamps[8];
+#else
+#define QRK_CAQR_STAMP_AT(n) do { } while (0)
+#endif
+    QRK_CAQR_STAMP_AT(0);
+#ifdef QRK_CAQR_STAMP
+    __shared__ unsigned long long fine[8];
+    PanelLds L{vb, red, zz, nrm, prow, taus, &x0s, fine};
+#else
     PanelLds L{vb, red, zz, nrm, prow, taus, &x0s};
+#endif
 #define QRK_CAQR_STEP(J) if ((J) < w) panel_step<J>(a, L, c, i, w);
     QRK_CAQR_STEP(0) QRK_CAQR_STEP(1) QRK_CAQR_STEP(2) QRK_CAQR_STEP(3) QRK_CAQR_STEP(4) QRK_CAQR_STEP(5) QRK_CAQR_STEP(6) QRK_CAQR_STEP(7)
+    QRK_CAQR_STAMP_AT(1);
     QRK_CAQR_STEP(8) QRK_CAQR_STEP(9) QRK_CAQR_STEP(10) QRK_CAQR_STEP(11) QRK_CAQR_STEP(12) QRK_CAQR_STEP(13) QRK_CAQR_STEP(14) QRK_CAQR_STEP(15)
+    QRK_CAQR_STAMP_AT(2);
     QRK_CAQR_STEP(16) QRK_CAQR_STEP(17) QRK_CAQR_STEP(18) QRK_CAQR_STEP(19) QRK_CAQR_STEP(20) QRK_CAQR_STEP(21) QRK_CAQR_STEP(22) QRK_CAQR_STEP(23)
+    QRK_CAQR_STAMP_AT(3);
     QRK_CAQR_STEP(24) QRK_CAQR_STEP(25) QRK_CAQR_STEP(26) QRK_CAQR_STEP(27) QRK_CAQR_STEP(28) QRK_CAQR_STEP(29) QRK_CAQR_STEP(30) QRK_CAQR_STEP(31)
 #undef QRK_CAQR_STEP
+    QRK_CAQR_STAMP_AT(4);
     __syncthreads();
-    // ---- T (forward, columnwise: LAPACK larft / Eigen make_block_householder_triangular_factor):
-    // T(l,l) = tau_l, T(0:l,l) = -tau_l T(0:l,0:l) (Y(:,0:l)^T y_l).  Row a of T only depends on row a: one thread per row.
-    if (tid < NB) {
-        const int ar = tid;
-        double trow[NB];
-#pragma unroll
-        for (int l = 0; l < NB; ++l) {
-            double tv = 0.0;
-            if (l < w) {
-                const double tau = taus[l];
-                if (ar == l) tv = tau;
-                else if (ar < l) {
-                    double acc = 0.0;
-#pragma unroll
-                    for (int b = 0; b < NB; ++b) if (b < l) acc = fma((b >= ar) ? trow[b] : 0.0, zz[b][l], acc);
-                    tv = -tau * acc;
+    // ---- T (LAPACK larft forward/columnwise = Eigen make_block_householder_triangular_factor): T(l,l) = tau_l,
+    // T(0:l,l) = -tau_l T(0:l,0:l) U(0:l,l) with U = strictly upper part of Y^T Y (zz).  In the recursive form: the four 8 x 8 diagonal
+    // blocks by the column recurrence (a thread per row, the blocks side by side), then T01 = -T00 (U01 T11), T23 likewise, then the
+    // 16 x 16 corner T[01][23] = -T[01] (U[01][23] T[23]): 55 dependent FMAs instead of 496 (the serial form took 15 us of the kernel's 80).
+    {
+        double* tm = sm;                 // [NB][LS] T            (sm is free until the store below)
+        double* mm = sm + NB * LS;       // [NB][LS] U * T of the merge in flight
+        for (int e = tid; e < NB * LS; e += 256) tm[e] = 0.0;
+        __syncthreads();
+        if (tid < NB) {
+            const int ar = tid, l0 = ar & ~7;
+            for (int l = l0; l < l0 + 8; ++l) {
+                double tv = 0.0;
+                if (l < w) {
+                    const double tau = taus[l];
+                    if (ar == l) tv = tau;
+                    else if (ar < l) {
+                        double acc = 0.0;
+                        for (int bb = ar; bb < l; ++bb) acc = fma(tm[ar * LS + bb], zz[bb][l], acc);
+                        tv = -tau * acc;
+                    }
                 }
+                tm[ar * LS + l] = tv;    // (row ar only depends on row ar)
             }
-            trow[l] = tv;
         }
-        double* dst = Tout + (int64_t)t * (NB * NB) + ar * NB;
+        __syncthreads();
+        // merges: rows [r0, r0 + h) x columns [r0 + h, r0 + 2 h)
 #pragma unroll
-        for (int l = 0; l < NB; ++l) dst[l] = trow[l];
+        for (int h = 8; h <= 16; h *= 2) {
+            const int per = h * h, nmerge = NB / (2 * h);
+            if (tid < per * nmerge) {
+                const int mg = tid / per, e = tid - mg * per, ii = e / h, jj = e - ii * h;
+                const int r0 = mg * 2 * h, cb = r0 + h;
+                double acc = 0.0;                                    // (U12 T22)(ii, jj)
+                for (int q = 0; q <= jj; ++q) acc = fma(zz[r0 + ii][cb + q], tm[(cb + q) * LS + cb + jj], acc);
+                mm[(r0 + ii) * LS + cb + jj] = acc;
+            }
+            __syncthreads();
+            if (tid < per * nmerge) {
+                const int mg = tid / per, e = tid - mg * per, ii = e / h, jj = e - ii * h;
+                const int r0 = mg * 2 * h, cb = r0 + h;
+                double acc = 0.0;                                    // -(T11 (U12 T22))(ii, jj)
+                for (int q = ii; q < h; ++q) acc = fma(tm[(r0 + ii) * LS + r0 + q], mm[(r0 + q) * LS + cb + jj], acc);
+                tm[(r0 + ii) * LS + cb + jj] = -acc;
+            }
+            __syncthreads();
+        }
+        double* dst = Tout + (int64_t)t * (NB * NB);
+        for (int e = tid; e < NB * NB; e += 256) dst[e] = tm[(e >> 5) * LS + (e & 31)];
+        __syncthreads();
     }
+    QRK_CAQR_STAMP_AT(5);
     // ---- store: back through LDS to lane = row
 #pragma unroll
     for (int r2 = 0; r2 < NB; ++r2) sm[(i * NB + r2) * LS + c] = a[r2];
@@ -212,6 +303,14 @@ caqr_panel_kernel(double* __restrict__ A, int64_t lda, int m, int pc, int w, Sla
         for (int cc = 0; cc < NB; ++cc)
             if (cc < w && x < nr && (!TRI || x <= cc)) dst[(int64_t)cc * lda] = sm[(i * NB + x) * LS + cc];
     }
+#ifdef QRK_CAQR_STAMP
+    __syncthreads();
+    if (tid == 0) {
+        stamps[6] = __builtin_amdgcn_s_memtime();
+        for (int q = 0; q < 7; ++q) reinterpret_cast<unsigned long long*>(Tout + (int64_t)t * (NB * NB))[NB * (q + 1)] = stamps[q];
+        for (int q = 0; q < 7; ++q) reinterpret_cast<unsigned long long*>(Tout + (int64_t)t * (NB * NB))[NB * (q + 9)] = fine[q];
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -414,15 +513,37 @@ static hipError_t caqr_panel_levels(double* A, int64_t lda, int m, int p, int w,
 
 // A (m x n, m >= n, column-major) <- R0 in the upper triangle, the reflectors of all levels below / inside the triangles; Tbuf
 // (caqr_t_bytes) receives the T factors.
-hipError_t launch_caqr_factorize(double* A, int64_t lda, int m, int n, double* Tbuf, hipStream_t stream)
+// With a side stream and two events (look-ahead): the reflectors of panel p are applied to the columns of panel p + 1 first; panel
+// p + 1 is then factorised on the side stream (a few hundred workgroups at most, one wave per SIMD: latency-bound) WHILE the caller's
+// stream applies panel p to the rest of the trailing matrix (disjoint columns, the Y / T of panel p only read).
+hipError_t launch_caqr_factorize(double* A, int64_t lda, int m, int n, double* Tbuf, hipStream_t stream, hipStream_t side,
+                                 hipEvent_t ev_urgent, hipEvent_t ev_factored)
 {
     const CaqrShape s = caqr_shape(m, n);
+    auto width = [&](int p) { const int pc = p * caqr::NB; return n - pc < caqr::NB ? n - pc : caqr::NB; };
+    hipError_t e;
+    if (!side || !ev_urgent || !ev_factored) {
+        for (int p = 0; p < s.NP; ++p) {
+            const int pc = p * caqr::NB, w = width(p);
+            if ((e = caqr_panel_levels(A, lda, m, p, w, Tbuf, s, true, 1, A + (int64_t)(pc + w) * lda, lda, n - (pc + w), false, stream)) != hipSuccess)
+                return e;
+        }
+        return hipSuccess;
+    }
+    if ((e = caqr_panel_levels(A, lda, m, 0, width(0), Tbuf, s, true, 1, nullptr, lda, 0, false, stream)) != hipSuccess) return e;
     for (int p = 0; p < s.NP; ++p) {
-        const int pc = p * caqr::NB;
-        const int w = n - pc < caqr::NB ? n - pc : caqr::NB;
-        const int ntrail = n - (pc + w);
-        const hipError_t e = caqr_panel_levels(A, lda, m, p, w, Tbuf, s, true, 1, A + (int64_t)(pc + w) * lda, lda, ntrail, false, stream);
-        if (e != hipSuccess) return e;
+        const int pc = p * caqr::NB, w = width(p);
+        const int pc1 = pc + w, w1 = p + 1 < s.NP ? width(p + 1) : 0, nrest = n - (pc1 + w1);
+        if (w1 > 0) {
+            if ((e = caqr_panel_levels(A, lda, m, p, w, Tbuf, s, false, 1, A + (int64_t)pc1 * lda, lda, w1, false, stream)) != hipSuccess) return e;
+            if ((e = hipEventRecord(ev_urgent, stream)) != hipSuccess || (e = hipStreamWaitEvent(side, ev_urgent, 0)) != hipSuccess) return e;
+            if ((e = caqr_panel_levels(A, lda, m, p + 1, w1, Tbuf, s, true, 1, nullptr, lda, 0, false, side)) != hipSuccess) return e;
+            if ((e = hipEventRecord(ev_factored, side)) != hipSuccess) return e;
+        }
+        if (nrest > 0 &&
+            (e = caqr_panel_levels(A, lda, m, p, w, Tbuf, s, false, 1, A + (int64_t)(pc1 + w1) * lda, lda, nrest, false, stream)) != hipSuccess)
+            return e;
+        if (w1 > 0 && (e = hipStreamWaitEvent(stream, ev_factored, 0)) != hipSuccess) return e;
     }
     return hipSuccess;
 }

@@ -1,6 +1,7 @@
 """GPU: the dense right-block solver (qrk_dense_*: Eigen ColPivHouseholderQR / HouseholderQR with implicit Q, the
 _BlockQRSolverRight of BlockAngularSparseQR, src/QRKit/BlockAngularSparseQR.h:361-369) against the oracle, on both
-device paths: the single-workgroup kernel (dense_qr.hip) and the row-slab path over all CUs (dense_qr_tall.hip)."""
+device paths: the single-workgroup kernel (dense_qr.hip), the row-slab path over all CUs (dense_qr_tall.hip) and the
+column-parallel kernel (dense_qr_cols.hip: one launch per reflector, a wavefront per column)."""
 import os
 
 import numpy as np
@@ -31,8 +32,10 @@ def _factor(A, solver, path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("rows,cols,path", [(64, 20, "single"), (64, 20, "tall"), (300, 300, "tall"), (1000, 37, "single"),
-                                             (1000, 37, "tall"), (5000, 64, "tall"), (30000, 24, None), (40, 60, "tall")])
+@pytest.mark.parametrize("rows,cols,path", [(64, 20, "single"), (64, 20, "slabs"), (64, 20, "cols"), (300, 300, "slabs"),
+                                             (300, 300, "cols"), (1000, 37, "single"), (1000, 37, "slabs"), (1000, 37, "cols"),
+                                             (5000, 64, "slabs"), (5000, 64, "cols"), (2500, 130, "cols"), (30000, 24, None),
+                                             (40, 60, "slabs"), (40, 60, "cols")])
 @pytest.mark.parametrize("solver", [0, 1])
 def test_dense_qr_matches_oracle(rows, cols, path, solver):
     rng = np.random.default_rng(rows * 7 + cols)
@@ -133,7 +136,7 @@ def test_dense_qr_persistent_form_matches_kernel_sequence(solver):
         if flag:
             os.environ["QRK_DENSE_PERSISTENT"] = flag
         try:
-            qr, At = _factor(A, solver, "tall")
+            qr, At = _factor(A, solver, "slabs")
         finally:
             os.environ.pop("QRK_DENSE_PERSISTENT", None)
         out.append((At.cpu().numpy().copy(), qr._hc.cpu().numpy().copy(), qr.colsPermutation().cpu().numpy().copy()))
@@ -144,7 +147,8 @@ def test_dense_qr_persistent_form_matches_kernel_sequence(solver):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("kind", ["pm1", "zero_one", "small_int", "circulant", "dup_cols"])
-@pytest.mark.parametrize("rows,cols,path", [(2000, 40, "single"), (2000, 40, "tall"), (300, 120, "tall")])
+@pytest.mark.parametrize("rows,cols,path", [(2000, 40, "single"), (2000, 40, "slabs"), (300, 120, "slabs"), (2000, 40, "cols"),
+                                             (300, 120, "cols")])
 def test_dense_tie_battery_is_bitwise_the_oracle(kind, rows, cols, path):
     """A dense block whose pivot decisions are ties in exact arithmetic (or noise after a rank collapse): the fast kernels flag
     it and the dense exact path (bdqr_exact.hip, dense_exact_kernel) redoes it from the plan's copy of the input in Eigen's
@@ -168,11 +172,12 @@ def test_dense_tie_battery_is_bitwise_the_oracle(kind, rows, cols, path):
 
 
 @pytest.mark.gpu
-def test_dense_generic_matrix_is_not_redone():
+@pytest.mark.parametrize("path", ["slabs", "cols"])
+def test_dense_generic_matrix_is_not_redone(path):
     """Generic data must stay on the fast path: its packed QR differs from the oracle's in the last bits (FMA chains)."""
     rng = np.random.default_rng(4)
     A = rng.uniform(-1.0, 1.0, (3000, 64))
-    qr, At = _factor(A, 0, "tall")
+    qr, At = _factor(A, 0, path)
     ref, hc, perm, _ = orc.colpiv_qr(A)
     np.testing.assert_array_equal(qr.colsPermutation().cpu().numpy(), perm)
     got = At.cpu().numpy()
