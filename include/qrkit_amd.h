@@ -209,7 +209,16 @@ qrk_status qrk_dense_plan_destroy(qrk_dense_plan plan);
 
 /* compute(): a (rows x cols, column-major, leading dimension lda) is overwritten by the packed QR
  * (R in the upper triangle, essential Householder vectors below); hcoeffs[min(rows,cols)];
- * perm[cols] = colsPermutation().indices(). */
+ * perm[cols] = colsPermutation().indices().
+ *
+ * Large tall pivoted problems (rows >= 4 cols, cols >= 128, rows * cols >= 2^22; QRK_DENSE_TWO_STAGE=0/1 overrides) are
+ * factorised in two stages: A = Q0 R0 without pivoting on the matrix cores (communication-avoiding QR), then R0 P = Q1 R with
+ * Eigen's pivot rule on the n x n triangle.  Same permutation; R equal to Eigen's up to the sign of each ROW (the sign of a
+ * Householder beta follows the pivot entry, which the change of basis alters); Q = Q0 diag(Q1, I).  After such a factorisation the
+ * upper triangle of `a` holds R as always, but what lies below are the reflectors of Q0, not Eigen's essential vectors, and
+ * hcoeffs are those of Q1: use qrk_dense_apply_q / qrk_dense_solve_r with the same plan (the factors of Q1 stay in the plan),
+ * do not interpret the lower part yourself.  A pivot decision inside its rounding margin still sends the whole matrix through
+ * the exact path, which leaves Eigen's format. */
 qrk_status qrk_dense_factorize(qrk_dense_plan plan, double* a, int64_t lda, double* hcoeffs, int32_t* perm,
                                qrk_memspace space);
 

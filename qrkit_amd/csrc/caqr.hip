@@ -356,20 +356,28 @@ caqr_apply_kernel(const double* __restrict__ A, int64_t lda, int m, int pc, int 
     for (int tile = wave; tile < ntile; tile += 4) {
         const int n0 = col_base + 16 * tile;
         if (n0 >= ncols) break;
-        // ---- W = Y^T C
+        // ---- W = Y^T C  (the loads of the next chunk are in flight while the MFMAs of this one run)
         d4 acc0 = d4{0.0, 0.0, 0.0, 0.0}, acc1 = d4{0.0, 0.0, 0.0, 0.0};
         {
             const int col = n0 + l15;
             const bool cok = col < ncols;
             const double* cb = C + (int64_t)col * ldc;
-            for (int ci = 0; ci < cnt; ++ci) {
-                const int64_t row0 = chunk_row0(sl, t, ci);
+            double bn[8];
+            {
+                const int64_t row0 = chunk_row0(sl, t, 0);
                 const int nr = chunk_rows(row0, m);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { const int rr = 4 * k + kq; bn[k] = (cok && rr < nr) ? cb[row0 + rr] : 0.0; }
+            }
+            for (int ci = 0; ci < cnt; ++ci) {
                 double bv[8];
 #pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const int rr = 4 * k + kq;
-                    bv[k] = (cok && rr < nr) ? cb[row0 + rr] : 0.0;
+                for (int k = 0; k < 8; ++k) bv[k] = bn[k];
+                if (ci + 1 < cnt) {
+                    const int64_t row0 = chunk_row0(sl, t, ci + 1);
+                    const int nr = chunk_rows(row0, m);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) { const int rr = 4 * k + kq; bn[k] = (cok && rr < nr) ? cb[row0 + rr] : 0.0; }
                 }
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
@@ -391,27 +399,36 @@ caqr_apply_kernel(const double* __restrict__ A, int64_t lda, int m, int pc, int 
             u1 = __builtin_amdgcn_mfma_f64_16x16x4f64(t1, bw, u1, 0, 0, 0);
         }
         u0 = -u0; u1 = -u1;
-        // ---- C += Y W'  (as C^T += W'^T Y^T: D[column kq + 4 z][row l15])
-        for (int ci = 0; ci < cnt; ++ci) {
-            const int64_t row0 = chunk_row0(sl, t, ci);
-            const int nr = chunk_rows(row0, m);
-#pragma unroll
-            for (int rt = 0; rt < 2; ++rt) {
-                const int rr = 16 * rt + l15;
-                const bool rok = rr < nr;
-                const int vrow = ci * NB + rr;
-                double* cp = C + row0 + rr;
-                d4 dv;
+        // ---- C += Y W'  (as C^T += W'^T Y^T: D[column kq + 4 z][row l15]); the tile after the current one is being loaded
+        // while this one goes through the matrix cores
+        {
+            const int ntl = 2 * cnt;                 // 16-row tiles of the slab
+            auto load_tile = [&](int tl, d4& dv) {
+                const int ci = tl >> 1, rr = 16 * (tl & 1) + l15;
+                const int64_t row0 = chunk_row0(sl, t, ci);
+                const bool rok = rr < chunk_rows(row0, m);
+                const double* cp = C + row0 + rr;
 #pragma unroll
                 for (int z = 0; z < 4; ++z) {
                     const int colz = n0 + kq + 4 * z;
                     dv[z] = (rok && colz < ncols) ? cp[(int64_t)colz * ldc] : 0.0;
                 }
+            };
+            d4 dn;
+            load_tile(0, dn);
+            for (int tl = 0; tl < ntl; ++tl) {
+                d4 dv = dn;
+                if (tl + 1 < ntl) load_tile(tl + 1, dn);
+                const int ci = tl >> 1, rr = 16 * (tl & 1) + l15;
+                const int64_t row0 = chunk_row0(sl, t, ci);
+                const bool rok = rr < chunk_rows(row0, m);
+                const int vrow = ci * NB + rr;
 #pragma unroll
                 for (int ks = 0; ks < 8; ++ks) {
                     const double aw = ks < 4 ? u0[ks & 3] : u1[ks & 3];
                     dv = __builtin_amdgcn_mfma_f64_16x16x4f64(aw, ys[vrow * LS + 4 * ks + kq], dv, 0, 0, 0);
                 }
+                double* cp = C + row0 + rr;
 #pragma unroll
                 for (int z = 0; z < 4; ++z) {
                     const int colz = n0 + kq + 4 * z;
