@@ -1,0 +1,13 @@
+#!/bin/bash
+# End-of-round evidence on the GPU box: full GPU suite, bench line, rocprofv3 kernel stats of the same bench command, composition timings.
+OUT=gpurun_out/r2end
+mkdir -p $OUT
+ROOT=$(pwd)
+timeout -k 10 900 python -m pytest tests -q -m gpu > $OUT/gpu_tests.txt 2>&1; echo "rc=$?" >> $OUT/gpu_tests.txt
+tail -3 $OUT/gpu_tests.txt
+timeout -k 10 300 python bench.py > $OUT/bench.json 2> $OUT/bench.err; tail -c 1500 $OUT/bench.json
+cd /tmp && export TMPDIR=/tmp
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/$OUT/prof -o bench -- python3 $ROOT/bench.py --no-cpu-baseline > $ROOT/$OUT/prof.log 2>&1
+cd $ROOT
+f=$(find $OUT/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cut -c1-220 "$f" | head -12 > $OUT/kernel_stats.csv; cat $OUT/kernel_stats.csv
+QRK_BIG=1 timeout -k 10 300 python tools/angular_probe.py 2>&1 | grep compute > $OUT/angular_probe.txt; cat $OUT/angular_probe.txt
