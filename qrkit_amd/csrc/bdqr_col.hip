@@ -324,7 +324,8 @@ __device__ __forceinline__ void factor_tile(double* __restrict__ W, double* smem
             const double xk = xc[k];
             double nb_, s, ng;
             const bool degen = !(tsq > DBL_MIN);
-            if (isA) {           // (every column thread accumulates the same |x_tail|^2)
+            if (isA && active) { // (every column thread that took part in the last sweep accumulated the same |x_tail|^2; the threads
+                                 // of columns chosen earlier carry tsq = 0 and must not read it as a degenerate reflector)
                 if (k == 0 && !pivoting) a2 = fma(xk, xk, tsq);
                 if (unclear_reflector(xk, tsq, k + 1 < r, pivoting != 0, a2)) unclear = true;
             }

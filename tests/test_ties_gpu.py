@@ -175,3 +175,24 @@ def test_generic_tiles_are_not_flagged(qa, ctx):
     _, ref = oracle_factorize(rows, cols, tiles)
     n_same = check(qr, ref, rows, cols)
     assert n_same <= 2, f"{n_same} of {B} generic tiles took the exact path"
+
+
+@pytest.mark.parametrize("n", [16, 32, 33, 48, 64, 96, 160, 300])
+def test_generic_tiles_stay_on_the_fast_path(qa, ctx, n):
+    """The other half of the decision margins: on generic data NO tile may be flagged.  The exact path rounds like a scalar
+    evaluation of Eigen's algorithm and is bit-identical to the oracle; the fast kernels (FMA chains, squared norms) differ from it
+    in the last bits -- so a tile whose R is bitwise the oracle's went through the exact path.  (A false positive is invisible to
+    the parity tests, the exact result being right: round 2 had every tile of 33..64 columns redone, 5x slower, because threads
+    of already chosen columns read their stale |x_tail|^2 = 0 as a degenerate reflector.)  One kernel family per size class."""
+    B = 64 if n <= 160 else 8
+    rng = np.random.default_rng(n)
+    tiles = rng.uniform(0.5, 5.0, B * n * n)
+    rows = np.full(B, n, np.int32)
+    mat = qa.SparseBlockDiagonal.fromTiles(rows, rows, tiles)
+    qr = qa.BlockDiagonalSparseQR(mat, context=ctx)
+    _, ref = oracle_factorize(rows, rows, tiles)
+    np.testing.assert_array_equal(qr.colsPermutation(), ref.perm)
+    got = qr.rValues().cpu().numpy()
+    per = n * (n + 1) // 2
+    redone = sum(np.array_equal(got[i * per:(i + 1) * per], ref.R_vals[i * per:(i + 1) * per]) for i in range(B))
+    assert redone == 0, f"{redone} of {B} generic {n}x{n} tiles were sent to the exact path"
