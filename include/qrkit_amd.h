@@ -232,6 +232,22 @@ qrk_status qrk_dense_apply_q(qrk_dense_plan plan, const double* qr, int64_t lda,
 qrk_status qrk_dense_solve_r(qrk_dense_plan plan, const double* qr, int64_t lda, double* b, int64_t ldb, int64_t nrhs,
                              qrk_memspace space);
 
+/* ------------------------------------- right block sharded over GPUs: local TSQR stage */
+
+/* rightSolver.compute(J2.bottomRows(...)) (src/QRKit/BlockAngularSparseQR.h:361-369) when the rows of J2 live on several
+ * GPUs (BASELINE configs[3], "8 x MI355X sharded"): every rank reduces ITS rows to an n x n triangle without pivoting,
+ * A_rank = Q0 R0 (communication-avoiding QR on the matrix cores, the first stage of the two-stage form above), the root gathers
+ * the triangles (n^2 doubles per rank instead of rows_rank * n), stacks them and runs qrk_dense_factorize on the stack; Q^T b
+ * follows the same route with one n-vector per rank (qrkit_amd/sharding.py, ShardedBlockAngularQR).  Device memory only, rows >= cols.
+ * factorize: a (rows x cols, column-major) <- R0 in the upper triangle of its first cols rows, reflectors of Q0 elsewhere.
+ * apply_q:   b (rows x nrhs) <- Q0^T b (transpose != 0) or Q0 b. */
+typedef struct qrk_tsqr_plan_s* qrk_tsqr_plan;
+qrk_status qrk_tsqr_plan_create(qrk_handle h, int32_t rows, int32_t cols, qrk_tsqr_plan* out);
+qrk_status qrk_tsqr_plan_destroy(qrk_tsqr_plan plan);
+qrk_status qrk_tsqr_factorize(qrk_tsqr_plan plan, double* a, int64_t lda, qrk_memspace space);
+qrk_status qrk_tsqr_apply_q(qrk_tsqr_plan plan, const double* a, int64_t lda, int transpose, double* b, int64_t ldb,
+                            int64_t nrhs, qrk_memspace space);
+
 /* ------------------------------------------------------------ block-banded solver */
 
 /* QRKit::BandedBlockedSparseQR<SparseMatrix, HouseholderQR<MatrixXd>, Dynamic, SuggestedBlockCols>

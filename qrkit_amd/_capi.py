@@ -26,6 +26,7 @@ EXPORTS = (
     "qrk_bd_tiles_from_sparse", "qrk_bd_factorize", "qrk_bd_info", "qrk_bd_apply_qt", "qrk_bd_apply_q", "qrk_bd_solve", "qrk_bd_solve_r", "qrk_dense_plan_create",
     "qrk_dense_plan_destroy", "qrk_dense_factorize", "qrk_dense_apply_q", "qrk_bb_plan_create", "qrk_bb_plan_destroy", "qrk_bb_plan_create_fixed", "qrk_bb_blocks_from_pattern", "qrk_bb_analyze_host",
     "qrk_bb_plan_info", "qrk_bb_plan_blocks", "qrk_bb_pattern", "qrk_bb_factorize", "qrk_bb_apply_q", "qrk_bb_solve_r", "qrk_dense_solve_r", "qrk_bd_time_factorize", "qrk_bd_kernel_name",
+    "qrk_tsqr_plan_create", "qrk_tsqr_plan_destroy", "qrk_tsqr_factorize", "qrk_tsqr_apply_q",
 )
 
 
@@ -125,6 +126,14 @@ def lib() -> C.CDLL:
     L.qrk_dense_solve_r.argtypes = [vp, dp, C.c_int64, dp, C.c_int64, C.c_int64, C.c_int]
     L.qrk_bb_solve_r.restype = C.c_int
     L.qrk_bb_solve_r.argtypes = [vp, dp, C.c_int64, C.c_int64, C.c_int]
+    L.qrk_tsqr_plan_create.restype = C.c_int
+    L.qrk_tsqr_plan_create.argtypes = [vp, C.c_int32, C.c_int32, C.POINTER(vp)]
+    L.qrk_tsqr_plan_destroy.restype = C.c_int
+    L.qrk_tsqr_plan_destroy.argtypes = [vp]
+    L.qrk_tsqr_factorize.restype = C.c_int
+    L.qrk_tsqr_factorize.argtypes = [vp, dp, C.c_int64, C.c_int]
+    L.qrk_tsqr_apply_q.restype = C.c_int
+    L.qrk_tsqr_apply_q.argtypes = [vp, dp, C.c_int64, C.c_int, dp, C.c_int64, C.c_int64, C.c_int]
     L.qrk_bd_time_factorize.restype = C.c_int
     L.qrk_bd_time_factorize.argtypes = [vp, dp, dp, dp, ip, C.c_int, C.c_int, C.POINTER(C.c_float)]
     _lib = L

@@ -113,6 +113,50 @@ class DenseColPivQR:
             pass
 
 
+class DenseTSQR:
+    """Un-pivoted communication-avoiding QR of a tall dense block on this GPU (qrk_tsqr_*): the per-rank stage of the sharded
+    right solver (BlockAngularSparseQR.h:361-369 with the rows of J2 spread over GPUs)."""
+
+    def __init__(self, context: Context):
+        self._ctx = context
+        self._plan = C.c_void_p()
+        self._shape = None
+
+    def compute(self, A: torch.Tensor):
+        """A: (rows, cols), rows >= cols, float64, column-major on the device; factorised in place (R0 in the upper triangle of the
+        first cols rows)."""
+        rows, cols = A.shape
+        assert A.dtype == torch.float64 and A.t().is_contiguous() and rows >= cols
+        if self._shape != (rows, cols):
+            if self._plan:
+                capi.lib().qrk_tsqr_plan_destroy(self._plan)
+            self._plan = C.c_void_p()
+            capi.check(capi.lib().qrk_tsqr_plan_create(self._ctx.handle, rows, cols, C.byref(self._plan)), self._ctx.handle)
+            self._shape = (rows, cols)
+        self._qr = A
+        self._ctx.use_current_stream()
+        capi.check(capi.lib().qrk_tsqr_factorize(self._plan, A.data_ptr(), rows, capi.MEM_DEVICE), self._ctx.handle)
+        return self
+
+    def matrixR(self) -> torch.Tensor:
+        return torch.triu(self._qr[:self._shape[1], :])
+
+    def applyQ(self, B: torch.Tensor, transpose: bool) -> torch.Tensor:
+        rows = self._shape[0]
+        assert B.shape[0] == rows and B.t().is_contiguous()
+        self._ctx.use_current_stream()
+        capi.check(capi.lib().qrk_tsqr_apply_q(self._plan, self._qr.data_ptr(), rows, 1 if transpose else 0, B.data_ptr(), rows,
+                                               B.shape[1], capi.MEM_DEVICE), self._ctx.handle)
+        return B
+
+    def __del__(self):
+        try:
+            if self._plan:
+                capi.lib().qrk_tsqr_plan_destroy(self._plan)
+        except Exception:
+            pass
+
+
 class BlockedThinDenseQR(DenseColPivQR):
     """QRKit::BlockedThinDenseQR (BlockedThinDenseQR.h:53-176): Householder QR of a thin dense matrix without column
     pivoting, Q implicit, identity permutations (:139-142).  The reference walks panels of SuggestedBlockCols columns

@@ -1023,6 +1023,57 @@ qrk_status qrk_dense_solve_r(qrk_dense_plan p, const double* qr, int64_t lda, do
     return QRK_STATUS_OK;
 }
 
+struct qrk_tsqr_plan_s {
+    qrk_handle h = nullptr;
+    int32_t rows = 0, cols = 0;
+    double* d_t = nullptr;
+};
+
+qrk_status qrk_tsqr_plan_create(qrk_handle h, int32_t rows, int32_t cols, qrk_tsqr_plan* out)
+{
+    if (!h || !out || cols <= 0 || rows < cols) return fail(h, QRK_STATUS_INVALID_ARGUMENT, "qrk_tsqr_plan_create: bad argument (rows >= cols > 0)");
+    *out = nullptr;
+    QRK_HIP(h, hipSetDevice(h->device));
+    qrk_tsqr_plan_s* p = new (std::nothrow) qrk_tsqr_plan_s();
+    if (!p) return fail(h, QRK_STATUS_ALLOC_FAILED, "qrk_tsqr_plan_create: out of host memory");
+    p->h = h; p->rows = rows; p->cols = cols;
+    if (hipMalloc((void**)&p->d_t, qrk::caqr_t_bytes(rows, cols)) != hipSuccess) {
+        delete p;
+        return fail(h, QRK_STATUS_ALLOC_FAILED, "qrk_tsqr_plan_create: cannot allocate the T factors");
+    }
+    *out = p;
+    return QRK_STATUS_OK;
+}
+
+qrk_status qrk_tsqr_plan_destroy(qrk_tsqr_plan p)
+{
+    if (p) (void)hipFree(p->d_t);
+    delete p;
+    return QRK_STATUS_OK;
+}
+
+qrk_status qrk_tsqr_factorize(qrk_tsqr_plan p, double* a, int64_t lda, qrk_memspace space)
+{
+    if (!p || !a || lda < p->rows) return fail(p ? p->h : nullptr, QRK_STATUS_INVALID_ARGUMENT, "qrk_tsqr_factorize: bad argument");
+    if (space != QRK_MEM_DEVICE) return fail(p->h, QRK_STATUS_UNSUPPORTED, "qrk_tsqr_factorize: device memory only");
+    qrk_handle h = p->h;
+    QRK_HIP(h, hipSetDevice(h->device));
+    QRK_HIP(h, qrk::launch_caqr_factorize(a, lda, p->rows, p->cols, p->d_t, h->stream));
+    return QRK_STATUS_OK;
+}
+
+qrk_status qrk_tsqr_apply_q(qrk_tsqr_plan p, const double* a, int64_t lda, int transpose, double* b, int64_t ldb, int64_t nrhs,
+                            qrk_memspace space)
+{
+    if (!p || !a || !b || nrhs < 0 || lda < p->rows || ldb < p->rows)
+        return fail(p ? p->h : nullptr, QRK_STATUS_INVALID_ARGUMENT, "qrk_tsqr_apply_q: bad argument");
+    if (space != QRK_MEM_DEVICE) return fail(p->h, QRK_STATUS_UNSUPPORTED, "qrk_tsqr_apply_q: device memory only");
+    qrk_handle h = p->h;
+    QRK_HIP(h, hipSetDevice(h->device));
+    QRK_HIP(h, qrk::launch_caqr_apply(a, lda, p->rows, p->cols, p->d_t, transpose, b, ldb, nrhs, h->stream));
+    return QRK_STATUS_OK;
+}
+
 static qrk_status bb_plan_create_impl(qrk_handle h, int32_t rows, int32_t cols, const int32_t* csr_rowptr,
                                       const int32_t* csr_colidx, int32_t suggested_block_cols,
                                       const qrk::FixedBandedPattern* fixed, qrk_bb_plan* out)

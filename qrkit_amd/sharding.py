@@ -165,3 +165,118 @@ class ShardedBlockDiagonalQR:
         out = torch.empty(sum(sizes), dtype=torch.int32, device=p.device) if self.rank_id == root else None
         gather_ragged_to_root(p, sizes, out, root, self.rank_id, self.world, self.group)
         return out
+
+
+class ShardedBlockAngularQR:
+    """QRKit::BlockAngularSparseQR with the rows sharded over the GPUs of a node (BASELINE configs[3], "8 x MI355X sharded").
+
+    Rank g holds the tiles [start, end) of the block-diagonal left block J1 and the rows of the dense right block J2 that
+    belong to them (the last rank also any rows of J2 below J1).  factorize (BlockAngularSparseQR.h:459-514):
+      * J1_g = Q1_g R1_g and T = Q1_g^T J2_g on the rank (no exchange: :472-475, solveRightBlock :361-369);
+      * the strip S_g = T(0:m1_g, :) stays on the rank (it is only needed for z1 = R1^-1 (y1 - S z2));
+      * the bottom rows of T are reduced on the rank to ONE n x n triangle, bottom_g = Q0_g R0_g (qrk_tsqr_*: un-pivoted CAQR on
+        the matrix cores) -- tall-skinny QR across ranks: the root gathers world triangles (n^2 doubles each, against
+        rows_g * n for the rows themselves), stacks them and runs the pivoted right solver on the stack (the Gram structure of
+        the columns, hence Eigen's pivots, is that of the un-sharded bottom block);
+      * the permutation P2 of the right block goes back to every rank.
+    solve (_solve_impl :202-227) follows the same route with one n-vector per rank up and z2 down.
+    Collectives: torch.distributed on `group` (RCCL as "nccl"; with "gloo" -- the CPU/one-GPU rehearsal -- tensors are staged
+    through the host).  No reference site exists for the sharding itself."""
+
+    def __init__(self, block_rows, block_cols, m2: int, rank: int, world: int, context=None, group=None, root: int = 0):
+        from .angular import DenseColPivQR, DenseTSQR
+        from .solvers import BlockDiagonalSparseQR, Context
+        from . import _capi as capi
+        self.block_rows = np.asarray(block_rows, dtype=np.int32)
+        self.block_cols = np.asarray(block_cols, dtype=np.int32)
+        self.m2, self.rank_id, self.world, self.group, self.root = int(m2), rank, world, group, root
+        self.ranges = shard_ranges(self.block_rows, self.block_cols, world)
+        self.start, self.end = self.ranges[rank]
+        self._ctx = context or Context(0)
+        self.m_leftSolver = BlockDiagonalSparseQR(blockSolver=capi.COLPIV_HOUSEHOLDER, qFormat=capi.FULL_Q, context=self._ctx)
+        self._tsqr = DenseTSQR(self._ctx)
+        self.m_rightSolver = DenseColPivQR(self._ctx, capi.COLPIV_HOUSEHOLDER) if rank == root else None
+        self._host_comm = dist.get_backend(group) == "gloo"
+
+    def local_layout(self):
+        return self.block_rows[self.start:self.end], self.block_cols[self.start:self.end]
+
+    # -- exchange helpers (equal-sized pieces: one n x n triangle or one n-vector per rank)
+    def _gather(self, t: torch.Tensor):
+        dev = t.device
+        t = t.contiguous().cpu() if self._host_comm else t.contiguous()
+        lst = [torch.empty_like(t) for _ in range(self.world)] if self.rank_id == self.root else None
+        dist.gather(t, lst, dst=self.root, group=self.group)
+        return None if lst is None else [p.to(dev) for p in lst]
+
+    def _bcast(self, t: torch.Tensor):
+        dev = t.device
+        c = t.contiguous().cpu() if self._host_comm else t.contiguous()
+        dist.broadcast(c, src=self.root, group=self.group)
+        return c.to(dev)
+
+    @staticmethod
+    def _colmajor(t: torch.Tensor) -> torch.Tensor:
+        return t.t().contiguous().t()
+
+    def compute(self, local_left, local_J2: torch.Tensor):
+        dev = self._ctx.device
+        m2 = self.m2
+        self.m_leftSolver.compute(local_left)
+        n1, m1 = local_left.rows(), local_left.cols()
+        J2 = local_J2.to(dev, torch.float64)
+        assert J2.shape[0] >= n1 and J2.shape[1] == m2
+        T = self.m_leftSolver.applyQt(J2[:n1, :].contiguous())
+        self._S = T[:m1, :].clone()
+        bottom = self._colmajor(torch.cat([T[m1:, :], J2[n1:, :]], dim=0))
+        self._n1, self._m1, self._nb = n1, m1, bottom.shape[0]
+        if bottom.shape[0] >= m2:
+            self._tsqr.compute(bottom)                       # bottom_g = Q0_g R0_g on this GPU
+            tri = self._tsqr.matrixR()
+            self._reduced = True
+        else:                                                # fewer rows than columns: the rows themselves, padded
+            tri = torch.zeros((m2, m2), dtype=torch.float64, device=dev)
+            tri[:bottom.shape[0], :] = bottom
+            self._reduced = False
+        parts = self._gather(tri)
+        perm = torch.empty(m2, dtype=torch.int32, device=dev)
+        if self.rank_id == self.root:
+            stack = self._colmajor(torch.cat(parts, dim=0))  # (world n) x n
+            self.m_rightSolver.compute(stack)
+            perm = self.m_rightSolver.colsPermutation().clone()
+        self._P2 = self._bcast(perm).long()
+        return self
+
+    def colsPermutationRight(self) -> np.ndarray:
+        return self._P2.cpu().numpy()
+
+    def solve(self, b_local: torch.Tensor):
+        """Least-squares solution: returns (x1_local, x2): the entries of x that belong to this rank's tiles, and the m2 entries of
+        the right block (on every rank).  b_local: this rank's rows of the right-hand side."""
+        dev = self._ctx.device
+        m2, n1, m1 = self.m2, self._n1, self._m1
+        b = b_local.to(dev, torch.float64).reshape(-1, 1)
+        y = self.m_leftSolver.applyQt(b[:n1, :].contiguous())
+        y1 = y[:m1, :]
+        yb = self._colmajor(torch.cat([y[m1:, :], b[n1:, :]], dim=0))
+        if self._reduced:
+            self._tsqr.applyQ(yb, transpose=True)
+            t = yb[:m2, :].clone()
+        else:
+            t = torch.zeros((m2, 1), dtype=torch.float64, device=dev)
+            t[:yb.shape[0], :] = yb
+        parts = self._gather(t)
+        z2 = torch.empty((m2, 1), dtype=torch.float64, device=dev)
+        if self.rank_id == self.root:
+            ys = self._colmajor(torch.cat(parts, dim=0))
+            self.m_rightSolver.applyQ(ys, transpose=True)
+            z2 = self.m_rightSolver.solveR(self._colmajor(ys[:m2, :].clone()))
+        z2 = self._bcast(z2)
+        rhs1 = y1 - self._S[:, self._P2] @ z2
+        z1 = self.m_leftSolver.solveR(rhs1)
+        p1 = torch.as_tensor(self.m_leftSolver.colsPermutation(), device=dev).long()
+        x1 = torch.empty_like(z1)
+        x1[p1, :] = z1
+        x2 = torch.empty_like(z2)
+        x2[self._P2, :] = z2
+        return x1[:, 0], x2[:, 0]

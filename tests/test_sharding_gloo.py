@@ -101,3 +101,63 @@ def test_shard_and_gather(tmp_path, world):
 def test_shard_and_gather_world2_hip_solver(tmp_path):
     """The HIP solver under ShardedBlockDiagonalQR, two ranks on the box's one GPU, gloo for the exchange."""
     _run(tmp_path, 2, use_gpu=True, seed=5, B=61)
+
+
+def _angular_worker(rank, world, port, rows, cols, tiles, J2, b, extra, out):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import qrkit_amd
+    from qrkit_amd.sharding import ShardedBlockAngularQR
+    m2 = J2.shape[1]
+    sh = ShardedBlockAngularQR(rows, cols, m2, rank, world)
+    lr, lc = sh.local_layout()
+    sizes = rows.astype(np.int64) * cols
+    t0, t1 = int(sizes[:sh.start].sum()), int(sizes[:sh.end].sum())
+    r0, r1 = int(rows[:sh.start].sum()), int(rows[:sh.end].sum())
+    n1 = int(rows.sum())
+    rsel = np.arange(r0, r1) if rank < world - 1 else np.concatenate([np.arange(r0, r1), np.arange(n1, n1 + extra)])
+    left = qrkit_amd.SparseBlockDiagonal.fromTiles(lr, lc, tiles[t0:t1])
+    sh.compute(left, torch.from_numpy(J2[rsel, :]))
+    x1, x2 = sh.solve(torch.from_numpy(b[rsel]))
+    np.save(f"{out}_x1_{rank}.npy", x1.cpu().numpy())
+    np.save(f"{out}_x2_{rank}.npy", x2.cpu().numpy())
+    np.save(f"{out}_p2_{rank}.npy", sh.colsPermutationRight())
+    np.save(f"{out}_red_{rank}.npy", np.array([int(sh._reduced)]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,m2,extra,reduced", [(600, 160, 37, True), (40, 64, 5, False)])
+def test_sharded_block_angular_tsqr_world2(tmp_path, B, m2, extra, reduced):
+    """ShardedBlockAngularQR, two ranks on the box's one GPU (gloo): left tiles and the rows of J2 sharded, the bottom rows reduced
+    per rank to a triangle (qrk_tsqr_*), the triangles stacked and pivoted on the root; the least-squares solution and the
+    right-block permutation against the un-sharded BlockAngularSparseQR (BlockAngularSparseQR.h:459-514, :202-227) run by the
+    oracle.  Second shape: ranks with fewer bottom rows than right columns send the rows themselves."""
+    sys.path.insert(0, ROOT)
+    from oracle import oracle as orc
+    rng = np.random.default_rng(B + m2)
+    r, c = 8, 6
+    rows = np.full(B, r, np.int32); cols = np.full(B, c, np.int32)
+    tiles = rng.uniform(0.5, 5.0, B * r * c)
+    n1, m1 = B * r, B * c
+    J2 = rng.uniform(0.5, 5.0, (n1 + extra, m2))
+    x = rng.uniform(-1.0, 1.0, m1 + m2)
+    T = tiles.reshape(B, c, r)
+    b = J2 @ x[m1:]
+    b[:n1] += np.einsum("bcr,bc->br", T, x[:m1].reshape(B, c)).reshape(-1)
+    out = str(tmp_path / "a")
+    port = 31500 + (os.getpid() % 2000) + B % 7
+    mp.spawn(_angular_worker, args=(2, port, rows, cols, tiles, J2, b, extra, out), nprocs=2, join=True)
+    x1 = np.concatenate([np.load(f"{out}_x1_{k}.npy") for k in range(2)])
+    x2 = np.load(f"{out}_x2_0.npy")
+    np.testing.assert_array_equal(x2, np.load(f"{out}_x2_1.npy"))
+    xs = np.concatenate([x1, x2])
+    assert np.linalg.norm(xs - x) <= 1e-10 * np.linalg.norm(x)
+    assert bool(np.load(f"{out}_red_0.npy")[0]) == reduced
+    # the right-block permutation is the un-sharded one: the oracle's BlockAngularSparseQR on the whole matrix
+    ref = orc.ba_factorize(orc.BDProblem(rows, cols, tiles), J2)
+    np.testing.assert_array_equal(np.load(f"{out}_p2_0.npy") + m1, ref.perm[m1:])
+    np.testing.assert_array_equal(np.load(f"{out}_p2_0.npy"), np.load(f"{out}_p2_1.npy"))
