@@ -349,6 +349,17 @@ class BlockDiagonalSparseQR {
         dy.download(y);
         return y;
     }
+    // The same three steps on device pointers (rows x nrhs / cols x nrhs, contiguous columns; in and out must not alias); they
+    // return when the result is in memory.  BlockAngularSparseQR keeps Q1^T J2 on the device with them.
+    void applyQDevice(const double* d_in, int64_t nrhs, double* d_out, bool transpose) const {
+        check(transpose ? qrk_bd_apply_qt(m_plan, (const double*)m_dq, d_in, nrhs, d_out, QRK_MEM_DEVICE)
+                        : qrk_bd_apply_q(m_plan, (const double*)m_dq, d_in, nrhs, d_out, QRK_MEM_DEVICE));
+        check(qrk_synchronize(m_handle));
+    }
+    void solveRDevice(const double* d_y, int64_t nrhs, double* d_z) const {
+        check(qrk_bd_solve_r(m_plan, (const double*)m_dr, d_y, nrhs, d_z, QRK_MEM_DEVICE));
+        check(qrk_synchronize(m_handle));
+    }
 
   protected:
     void check(qrk_status st) const {
@@ -577,6 +588,19 @@ class BandedBlockedSparseQR {
         for (int64_t c = 0; c < nrhs; ++c) std::copy(y.begin() + c * m_rows, y.begin() + c * m_rows + m_cols, x.begin() + c * m_cols);
         return x;
     }
+    // Q^T v / Q v and the triangular step on device pointers (the ABI works in place: in is copied to out first)
+    void applyQDevice(const double* d_in, int64_t nrhs, double* d_out, bool transpose) const {
+        check(qrk_memcpy_2d(m_handle, d_out, m_rows * (int64_t)sizeof(double), d_in, m_rows * (int64_t)sizeof(double),
+                            m_rows * (int64_t)sizeof(double), nrhs, 2));
+        check(qrk_bb_apply_q(m_plan, (const double*)m_dy, (const double*)m_dt, transpose ? 1 : 0, d_out, nrhs, QRK_MEM_DEVICE));
+        check(qrk_synchronize(m_handle));
+    }
+    void solveRDevice(const double* d_y, int64_t nrhs, double* d_z) const {
+        check(qrk_memcpy_2d(m_handle, d_z, m_cols * (int64_t)sizeof(double), d_y, m_cols * (int64_t)sizeof(double),
+                            m_cols * (int64_t)sizeof(double), nrhs, 2));
+        check(qrk_bb_solve_r(m_plan, d_z, (int64_t)m_cols, nrhs, QRK_MEM_DEVICE));
+        check(qrk_synchronize(m_handle));
+    }
     // the triangular step alone, on the device (qrk_bb_solve_r); y: cols x nrhs
     Vector solveR(const Vector& y) const {
         assert(m_isInitialized && (Index)y.size() % m_cols == 0);
@@ -651,7 +675,7 @@ class BandedBlockedSparseQR {
 // with Q and the triangular solve move only their vectors.  Shared by the thin solvers and the angular right block.
 class DenseDeviceQR {
   public:
-    DenseDeviceQR() : m_h(0), m_plan(0), m_dqr(0), m_dhc(0), m_rows(0), m_cols(0) {}
+    DenseDeviceQR() : m_h(0), m_plan(0), m_dqr(0), m_dhc(0), m_dperm(0), m_rows(0), m_cols(0) {}
     ~DenseDeviceQR() { release(); }
     DenseDeviceQR(const DenseDeviceQR&) = delete;
     DenseDeviceQR& operator=(const DenseDeviceQR&) = delete;
@@ -676,6 +700,32 @@ class DenseDeviceQR {
         qrk_device_free(m_h, dperm);
         check(st);
     }
+    // the same for a matrix that is already on the device (rows x cols, leading dimension rows): the buffer becomes the solver's own
+    // (freed by release()); only tau and the permutation travel to the host
+    void factorizeDevice(qrk_handle h, void* d_a, Index rows, Index cols, int solver, std::vector<double>& hc, std::vector<int32_t>& perm) {
+        release();
+        m_h = h; m_rows = rows; m_cols = cols; m_dqr = d_a;
+        const Index k = std::min(m_rows, m_cols);
+        check(qrk_dense_plan_create(m_h, (int32_t)m_rows, (int32_t)m_cols, (qrk_block_solver)solver, &m_plan));
+        hc.assign((size_t)std::max<Index>(k, 1), 0.0);
+        perm.assign((size_t)std::max<Index>(m_cols, 1), 0);
+        check(qrk_device_alloc(m_h, (int64_t)(hc.size() * sizeof(double)), &m_dhc));
+        check(qrk_device_alloc(m_h, (int64_t)(perm.size() * sizeof(int32_t)), &m_dperm));
+        qrk_status st = qrk_dense_factorize(m_plan, (double*)m_dqr, m_rows, (double*)m_dhc, (int32_t*)m_dperm, QRK_MEM_DEVICE);
+        if (st == QRK_STATUS_OK) st = qrk_memcpy(m_h, hc.data(), m_dhc, (int64_t)(hc.size() * sizeof(double)), 1);
+        if (st == QRK_STATUS_OK) st = qrk_memcpy(m_h, perm.data(), m_dperm, (int64_t)(perm.size() * sizeof(int32_t)), 1);
+        check(st);
+    }
+    const double* packedDevice() const { return (const double*)m_dqr; }      // R in the upper triangle of its first cols rows
+    const int32_t* permDevice() const { return (const int32_t*)m_dperm; }     // (after factorizeDevice)
+    void applyQDevice(double* d_v, Index nrhs, bool transpose) const {
+        check(qrk_dense_apply_q(m_plan, (const double*)m_dqr, m_rows, (const double*)m_dhc, transpose ? 1 : 0, d_v, m_rows, nrhs, QRK_MEM_DEVICE));
+        check(qrk_synchronize(m_h));
+    }
+    void solveRDevice(double* d_z, Index ldb, Index nrhs) const {
+        check(qrk_dense_solve_r(m_plan, (const double*)m_dqr, m_rows, d_z, ldb, nrhs, QRK_MEM_DEVICE));
+        check(qrk_synchronize(m_h));
+    }
     // v (rows x nrhs, column-major) <- Q^T v or Q v
     void applyQ(Vector& v, Index nrhs, bool transpose) const {
         Scoped d(*this, v);
@@ -692,8 +742,9 @@ class DenseDeviceQR {
     void release() {             // (before the handle it was created with is destroyed)
         if (m_dqr) qrk_device_free(m_h, m_dqr);
         if (m_dhc) qrk_device_free(m_h, m_dhc);
+        if (m_dperm) qrk_device_free(m_h, m_dperm);
         if (m_plan) qrk_dense_plan_destroy(m_plan);
-        m_dqr = m_dhc = 0; m_plan = 0;
+        m_dqr = m_dhc = m_dperm = 0; m_plan = 0;
     }
   private:
     struct Scoped {
@@ -713,7 +764,7 @@ class DenseDeviceQR {
     }
     qrk_handle m_h;
     qrk_dense_plan m_plan;
-    void* m_dqr; void* m_dhc;
+    void* m_dqr; void* m_dhc; void* m_dperm;
     Index m_rows, m_cols;
 };
 
@@ -854,7 +905,7 @@ class BlockAngularSparseQR {
         if (qrk_create(&m_handle, device, 0) != QRK_STATUS_OK)
             throw std::runtime_error(std::string("qrkit: ") + qrk_last_error(0));
     }
-    ~BlockAngularSparseQR() { m_dense.release(); if (m_handle) qrk_destroy(m_handle); }
+    ~BlockAngularSparseQR() { m_dense.release(); if (m_dS) qrk_device_free(m_handle, m_dS); if (m_handle) qrk_destroy(m_handle); }
     BlockAngularSparseQR(const BlockAngularSparseQR&) = delete;
     BlockAngularSparseQR& operator=(const BlockAngularSparseQR&) = delete;
 
@@ -876,41 +927,56 @@ class BlockAngularSparseQR {
         m_rowPerm.setIdentity(m_rows);
     }
 
-    // :459-514
+    // :459-514.  J2 crosses PCIe once: Q1^T J2, the strip S = (Q1^T J2)(0:m1, :) and the packed QR of the bottom rows stay on the
+    // device (the host copy of R is assembled when matrixR() is first asked for).
     template <typename LeftMat>
     void factorize(const BlockMatrix1x2<LeftMat, Matrix>& mat) {
         const Matrix& J2in = mat.rightBlock();
         m_m1 = mat.leftBlock().cols(); m_n1 = mat.leftBlock().rows(); m_m2 = J2in.cols();
+        m_isInitialized = false; m_Rbuilt = false;
         // J1 = Q1 R1 (:472-475)
         m_leftSolver.compute(mat.leftBlock());
         m_info = m_leftSolver.info();
         if (m_info != Success) return;
-        // solveRightBlock (:361-369): J2.top(n1) <- Q1^T (rowPerm1 * J2.top(n1)); the rows below stay
-        m_J2 = J2in;
-        {
-            Vector top((size_t)(m_n1 * m_m2));
-            const std::vector<int>& rp = m_leftSolver.rowsPermutation().indices();
-            for (Index c = 0; c < m_m2; ++c)
-                for (Index r = 0; r < m_n1; ++r) top[(size_t)(c * m_n1 + rp[(size_t)r])] = J2in(r, c);
-            top = leftApplyQ(m_leftSolver, top, true);
-            for (Index c = 0; c < m_m2; ++c)
-                for (Index r = 0; r < m_n1; ++r) m_J2(r, c) = top[(size_t)(c * m_n1 + r)];
-            for (Index r = 0; r < m_n1; ++r) m_rowPerm.indices()[(size_t)r] = rp[(size_t)r];
-        }
-        // rightSolver.compute(J2.bottomRows(rows - m1))
+        const int64_t D = (int64_t)sizeof(double);
         const Index rb = m_rows - m_m1;
-        m_bottom = Matrix(rb, m_m2);
-        for (Index c = 0; c < m_m2; ++c) for (Index r = 0; r < rb; ++r) m_bottom(r, c) = m_J2(m_m1 + r, c);
+        // solveRightBlock (:361-369): J2.top(n1) <- Q1^T (rowPerm1 * J2.top(n1)); the rows below stay
+        const std::vector<int>& rp = m_leftSolver.rowsPermutation().indices();
+        bool identity = true;
+        for (Index r = 0; r < m_n1 && identity; ++r) identity = rp[(size_t)r] == (int)r;
+        for (Index r = 0; r < m_n1; ++r) m_rowPerm.indices()[(size_t)r] = rp[(size_t)r];
+        void* dBottom = 0;
+        {
+            DBuf dTop(*this, m_n1 * m_m2), dT(*this, m_n1 * m_m2);
+            if (identity) {
+                check(qrk_memcpy_2d(m_handle, dTop.p, m_n1 * D, J2in.data(), m_rows * D, m_n1 * D, m_m2, 0));
+            } else {
+                Vector top((size_t)(m_n1 * m_m2));
+                for (Index c = 0; c < m_m2; ++c)
+                    for (Index r = 0; r < m_n1; ++r) top[(size_t)(c * m_n1 + rp[(size_t)r])] = J2in(r, c);
+                check(qrk_memcpy(m_handle, dTop.p, top.data(), m_n1 * m_m2 * D, 0));
+            }
+            m_leftSolver.applyQDevice(dTop.ptr(), m_m2, dT.ptr(), true);
+            // rightSolver.compute(J2.bottomRows(rows - m1)): rows m1..n1 of Q1^T J2, then the rows of J2 below J1
+            check(qrk_device_alloc(m_handle, std::max<int64_t>(rb * m_m2 * D, 8), &dBottom));
+            qrk_status st = qrk_memcpy_2d(m_handle, dBottom, rb * D, dT.ptr() + m_m1, m_n1 * D, (m_n1 - m_m1) * D, m_m2, 2);
+            if (st == QRK_STATUS_OK && m_rows > m_n1)
+                st = qrk_memcpy_2d(m_handle, (double*)dBottom + (m_n1 - m_m1), rb * D, J2in.data() + m_n1, m_rows * D, (m_rows - m_n1) * D, m_m2, 0);
+            // the strip of R: S = (Q1^T J2)(0:m1, :)
+            if (m_dS) { qrk_device_free(m_handle, m_dS); m_dS = 0; }
+            if (st == QRK_STATUS_OK) st = qrk_device_alloc(m_handle, std::max<int64_t>(m_m1 * m_m2 * D, 8), &m_dS);
+            if (st == QRK_STATUS_OK) st = qrk_memcpy_2d(m_handle, m_dS, m_m1 * D, dT.ptr(), m_n1 * D, m_m1 * D, m_m2, 2);
+            if (st != QRK_STATUS_OK) { qrk_device_free(m_handle, dBottom); check(st); }
+        }
         m_k2 = std::min(rb, m_m2);
         std::vector<int32_t> p2;
-        m_dense.factorize(m_handle, m_bottom, RightSolverTag::kSolver, m_hc, p2);    // packed QR and tau stay on the device
+        m_dense.factorizeDevice(m_handle, dBottom, rb, m_m2, RightSolverTag::kSolver, m_hc, p2);   // (takes the buffer over)
         // column permutation (:498-503) and rank (:510)
         m_outputPerm_c.setIdentity(m_cols);
         for (Index j = 0; j < m_m1; ++j) m_outputPerm_c.indices()[(size_t)j] = m_leftSolver.colsPermutation().indices()[(size_t)j];
         for (Index j = 0; j < m_m2; ++j) m_outputPerm_c.indices()[(size_t)(m_m1 + j)] = (int)(m_m1 + p2[(size_t)j]);
         m_P2.assign(p2.begin(), p2.begin() + m_m2);
         m_nonzeropivots = m_leftSolver.rank() + m_k2;
-        makeR();
         m_isInitialized = true;
     }
 
@@ -918,75 +984,97 @@ class BlockAngularSparseQR {
     Index cols() const { return m_cols; }
     Index rank() const { assert(m_isInitialized); return m_nonzeropivots; }
     ComputationInfo info() const { return m_info; }
-    const MatrixRType& matrixR() const { return m_R; }
+    const MatrixRType& matrixR() const { if (!m_Rbuilt) makeR(); return m_R; }   // (host copy assembled on first use)
     MatrixQType matrixQ() const { return MatrixQType(*this, false); }
     const PermutationType& colsPermutation() const { return m_outputPerm_c; }
     const PermutationType& rowsPermutation() const { return m_rowPerm; }
     const LeftSolver& leftSolver() const { return m_leftSolver; }
 
-    // matrixQ().transpose() * v (:607-625): rows [0,n1) <- Q1^T, then rows [m1, rows) <- Q2^T
-    Vector applyQt(const Vector& v) const {
-        const Index nrhs = (Index)v.size() / m_rows;
-        Vector out(v);
-        leftPart(out, nrhs, true);
-        rightPart(out, nrhs, true);
-        return out;
-    }
+    // matrixQ().transpose() * v (:607-625): rows [0,n1) <- Q1^T, then rows [m1, rows) <- Q2^T; the vector crosses PCIe once each way
+    Vector applyQt(const Vector& v) const { return applyAny(v, true); }
     // matrixQ() * v (:627-645): the same two factors in the opposite order
-    Vector applyQ(const Vector& v) const {
-        const Index nrhs = (Index)v.size() / m_rows;
-        Vector out(v);
-        rightPart(out, nrhs, false);
-        leftPart(out, nrhs, false);
-        return out;
-    }
+    Vector applyQ(const Vector& v) const { return applyAny(v, false); }
     // _solve_impl (:202-227): x = P [R(0:rank,0:rank)^-1 (Q^T b)(0:rank)], b already row-permuted
     Vector solve(const Vector& b) const {
         assert(m_isInitialized && "The factorization should be called first, use compute()");
-        const Vector y = applyQt(b);
-        if (m_rows - m_m1 < m_m2) return m_outputPerm_c * solveUpperCsc(m_R, m_cols, y);   // (fewer bottom rows than right columns)
-        // R = [R1 S; 0 R2], block by block: z2 = R2^-1 y2 (qrk_dense_solve_r) and z1 = R1^-1 (y1 - S z2) (the left
-        // solver's triangular step) on the device; S = (Q1^T J2)(0:m1, P2) is applied here
-        Vector z2(y.begin() + m_m1, y.begin() + m_m1 + m_m2);
-        m_dense.solveR(z2, m_m2, 1);
-        Vector rhs1(y.begin(), y.begin() + m_m1);
-        for (Index c = 0; c < m_m2; ++c) {
-            const double zc = z2[(size_t)c];
-            const Index jc = m_P2[(size_t)c];
-            for (Index r = 0; r < m_m1; ++r) rhs1[(size_t)r] -= m_J2(r, jc) * zc;
-        }
-        Vector z = m_leftSolver.solveR(rhs1);
-        z.insert(z.end(), z2.begin(), z2.end());
+        if (m_rows - m_m1 < m_m2) return m_outputPerm_c * solveUpperCsc(matrixR(), m_cols, applyQt(b));   // (fewer bottom rows than right columns)
+        // R = [R1 S; 0 R2], block by block and on the device: y = Q^T b, z2 = R2^-1 y2 (qrk_dense_solve_r), y1 -= S(:, P2) z2
+        // (qrk_dense_gemv_sub), z1 = R1^-1 y1 (the left solver's triangular step); only b and x cross PCIe
+        const int64_t D = (int64_t)sizeof(double);
+        DBuf y(*this, m_rows), z2(*this, m_m2), z1(*this, m_m1);
+        check(qrk_memcpy(m_handle, y.p, b.data(), m_rows * D, 0));
+        applyDevice(y.ptr(), 1, true);
+        check(qrk_memcpy_2d(m_handle, z2.p, m_m2 * D, y.ptr() + m_m1, m_m2 * D, m_m2 * D, 1, 2));
+        m_dense.solveRDevice(z2.ptr(), m_m2, 1);
+        check(qrk_dense_gemv_sub(m_handle, (const double*)m_dS, m_m1, m_m1, m_m2, m_dense.permDevice(), z2.ptr(), y.ptr()));
+        check(qrk_synchronize(m_handle));
+        m_leftSolver.solveRDevice(y.ptr(), 1, z1.ptr());
+        Vector z((size_t)(m_m1 + m_m2));
+        check(qrk_memcpy(m_handle, z.data(), z1.p, m_m1 * D, 1));
+        check(qrk_memcpy(m_handle, z.data() + m_m1, z2.p, m_m2 * D, 1));
         return m_outputPerm_c * z;
     }
 
   protected:
-    void leftPart(Vector& v, Index nrhs, bool transpose) const {
-        Vector top((size_t)(m_n1 * nrhs));
-        for (Index c = 0; c < nrhs; ++c) std::copy(v.begin() + c * m_rows, v.begin() + c * m_rows + m_n1, top.begin() + c * m_n1);
-        top = leftApplyQ(m_leftSolver, top, transpose);
-        for (Index c = 0; c < nrhs; ++c) std::copy(top.begin() + c * m_n1, top.begin() + (c + 1) * m_n1, v.begin() + c * m_rows);
+    // scoped device buffer of doubles on this solver's handle
+    struct DBuf {
+        const BlockAngularSparseQR& s; void* p;
+        DBuf(const BlockAngularSparseQR& ss, int64_t count) : s(ss), p(0) {
+            s.check(qrk_device_alloc(s.m_handle, std::max<int64_t>(count, 1) * (int64_t)sizeof(double), &p));
+        }
+        ~DBuf() { if (p) qrk_device_free(s.m_handle, p); }
+        double* ptr() const { return (double*)p; }
+        DBuf(const DBuf&) = delete;
+        DBuf& operator=(const DBuf&) = delete;
+    };
+    Vector applyAny(const Vector& v, bool transpose) const {
+        const Index nrhs = (Index)v.size() / m_rows;
+        DBuf d(*this, m_rows * nrhs);
+        check(qrk_memcpy(m_handle, d.p, v.data(), m_rows * nrhs * (int64_t)sizeof(double), 0));
+        applyDevice(d.ptr(), nrhs, transpose);
+        Vector out(v.size());
+        check(qrk_memcpy(m_handle, out.data(), d.p, m_rows * nrhs * (int64_t)sizeof(double), 1));
+        return out;
     }
-    void rightPart(Vector& v, Index nrhs, bool transpose) const {
+    // d_v (rows x nrhs on the device, leading dimension rows) <- Q^T d_v or Q d_v
+    void applyDevice(double* d_v, Index nrhs, bool transpose) const {
+        if (transpose) { leftPart(d_v, nrhs, true); rightPart(d_v, nrhs, true); }
+        else { rightPart(d_v, nrhs, false); leftPart(d_v, nrhs, false); }
+    }
+    void leftPart(double* d_v, Index nrhs, bool transpose) const {
+        const int64_t D = (int64_t)sizeof(double);
+        DBuf a(*this, m_n1 * nrhs), b(*this, m_n1 * nrhs);
+        check(qrk_memcpy_2d(m_handle, a.p, m_n1 * D, d_v, m_rows * D, m_n1 * D, nrhs, 2));
+        m_leftSolver.applyQDevice(a.ptr(), nrhs, b.ptr(), transpose);
+        check(qrk_memcpy_2d(m_handle, d_v, m_rows * D, b.p, m_n1 * D, m_n1 * D, nrhs, 2));
+    }
+    void rightPart(double* d_v, Index nrhs, bool transpose) const {
+        const int64_t D = (int64_t)sizeof(double);
         const Index rb = m_rows - m_m1;
-        Vector bot((size_t)(rb * nrhs));
-        for (Index c = 0; c < nrhs; ++c) std::copy(v.begin() + c * m_rows + m_m1, v.begin() + (c + 1) * m_rows, bot.begin() + c * rb);
-        m_dense.applyQ(bot, nrhs, transpose);
-        for (Index c = 0; c < nrhs; ++c) std::copy(bot.begin() + c * rb, bot.begin() + (c + 1) * rb, v.begin() + c * m_rows + m_m1);
+        DBuf c(*this, rb * nrhs);
+        check(qrk_memcpy_2d(m_handle, c.p, rb * D, d_v + m_m1, m_rows * D, rb * D, nrhs, 2));
+        m_dense.applyQDevice(c.ptr(), nrhs, transpose);
+        check(qrk_memcpy_2d(m_handle, d_v + m_m1, m_rows * D, c.p, rb * D, rb * D, nrhs, 2));
     }
-    // makeR (:285-335): R = [R1(0:m1,:), (Q1^T J2)(0:m1, P2); 0, R2; 0, 0]
-    void makeR() {
+    // makeR (:285-335): R = [R1(0:m1,:), (Q1^T J2)(0:m1, P2); 0, R2; 0, 0] as a host sparse matrix: the strip and R2 come from the device
+    void makeR() const {
+        const int64_t D = (int64_t)sizeof(double);
+        const Index rb = m_rows - m_m1;
+        Vector S((size_t)(m_m1 * m_m2)), R2((size_t)(m_k2 * m_m2));
+        check(qrk_memcpy(m_handle, S.data(), m_dS, m_m1 * m_m2 * D, 1));
+        check(qrk_memcpy_2d(m_handle, R2.data(), m_k2 * D, m_dense.packedDevice(), rb * D, m_k2 * D, m_m2, 1));
         std::vector<Triplet> t;
         const SparseMatrixColMajor& R1 = m_leftSolver.matrixR();
         for (Index c = 0; c < m_m1; ++c)
             for (int p = R1.outerIndex()[(size_t)c]; p < R1.outerIndex()[(size_t)c + 1]; ++p)
                 if (R1.innerIndex()[(size_t)p] < m_m1) t.emplace_back(R1.innerIndex()[(size_t)p], (int)c, R1.values()[(size_t)p]);
         for (Index c = 0; c < m_m2; ++c)
-            for (Index r = 0; r < m_m1; ++r) t.emplace_back((int)r, (int)(m_m1 + c), m_J2(r, m_P2[(size_t)c]));
+            for (Index r = 0; r < m_m1; ++r) t.emplace_back((int)r, (int)(m_m1 + c), S[(size_t)(m_P2[(size_t)c] * m_m1 + r)]);
         for (Index c = 0; c < m_m2; ++c)
-            for (Index r = 0; r <= std::min(c, m_k2 - 1); ++r) t.emplace_back((int)(m_m1 + r), (int)(m_m1 + c), m_bottom(r, c));
+            for (Index r = 0; r <= std::min(c, m_k2 - 1); ++r) t.emplace_back((int)(m_m1 + r), (int)(m_m1 + c), R2[(size_t)(c * m_k2 + r)]);
         m_R.resize(m_rows, m_cols);
         m_R.setFromTriplets(t);
+        m_Rbuilt = true;
     }
     void check(qrk_status st) const {
         if (st != QRK_STATUS_OK) throw std::runtime_error(std::string("qrkit: ") + qrk_last_error(m_handle));
@@ -998,10 +1086,11 @@ class BlockAngularSparseQR {
     qrk_handle m_handle;
     DenseDeviceQR m_dense;
     Index m_rows, m_cols, m_m1, m_m2, m_n1, m_k2;
-    Matrix m_J2, m_bottom;              // [Q1^T J2.top; J2.bottom] and the packed QR of its rows m1..
+    void* m_dS = 0;                     // device: the strip S = (Q1^T J2)(0:m1, :), m1 x m2 (the packed QR of the rows below is m_dense's)
     std::vector<double> m_hc;
     std::vector<int> m_P2;
-    MatrixRType m_R;
+    mutable MatrixRType m_R;            // host copy of R, assembled by the first matrixR()
+    mutable bool m_Rbuilt = false;
     PermutationType m_outputPerm_c, m_rowPerm;
 };
 

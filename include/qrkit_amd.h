@@ -95,6 +95,11 @@ const char* qrk_last_error(qrk_handle h);
 qrk_status qrk_device_alloc(qrk_handle h, int64_t bytes, void** out);
 qrk_status qrk_device_free(qrk_handle h, void* ptr);
 qrk_status qrk_memcpy(qrk_handle h, void* dst, const void* src, int64_t bytes, int direction);
+/* `height` runs of `width_bytes` bytes, `dst_pitch` / `src_pitch` bytes apart (a block of columns of a column-major matrix, e.g.
+ * the top or bottom rows of the dense right block J2, BlockAngularSparseQR.h:361-369).  direction: 0 = host -> device,
+ * 1 = device -> host, 2 = device -> device. */
+qrk_status qrk_memcpy_2d(qrk_handle h, void* dst, int64_t dst_pitch, const void* src, int64_t src_pitch, int64_t width_bytes,
+                         int64_t height, int direction);
 
 /* -------------------------------------------- block-diagonal: analyzePattern */
 
@@ -231,6 +236,12 @@ qrk_status qrk_dense_apply_q(qrk_dense_plan plan, const double* qr, int64_t lda,
  * (src/QRKit/BlockAngularSparseQR.h:202-227); the column permutation is the caller's. */
 qrk_status qrk_dense_solve_r(qrk_dense_plan plan, const double* qr, int64_t lda, double* b, int64_t ldb, int64_t nrhs,
                              qrk_memspace space);
+
+/* y(0:rows) -= sum_c S(:, colidx[c]) z[c]  for c = 0..cols-1 (colidx == NULL: column c), all device pointers, S column-major with
+ * leading dimension lds: the strip term of the block back substitution of BlockAngularSparseQR::_solve_impl
+ * (src/QRKit/BlockAngularSparseQR.h:202-227), z1 = R1^-1 (y1 - S z2) with S = (Q1^T J2)(0:m1, P2) kept on the device. */
+qrk_status qrk_dense_gemv_sub(qrk_handle h, const double* S, int64_t lds, int64_t rows, int64_t cols, const int32_t* colidx,
+                              const double* z, double* y);
 
 /* ------------------------------------- right block sharded over GPUs: local TSQR stage */
 

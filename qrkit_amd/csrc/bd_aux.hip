@@ -427,4 +427,35 @@ void launch_bd_cut_tiles(const TileGeom& g, const int64_t* t_off, int row_major,
         hipLaunchKernelGGL(bd_cut_tiles_kernel<false>, dim3(grid), dim3(256), 0, stream, g, t_off, outer_ptr, inner_idx, vals, nnz, tiles);
 }
 
+// y -= S(:, colidx) z: a thread per row (column-major S: a wave reads 512 contiguous bytes per column), the z of 256 columns at a
+// time through LDS.  HBM-bound: the strip is read once.
+__global__ void __launch_bounds__(256)
+gemv_sub_kernel(const double* __restrict__ S, int64_t lds, int64_t rows, int64_t cols, const int32_t* __restrict__ colidx,
+                const double* __restrict__ z, double* __restrict__ y)
+{
+    __shared__ double zs[256];
+    __shared__ int cs[256];
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    double acc = 0.0;
+    for (int64_t c0 = 0; c0 < cols; c0 += 256) {
+        const int64_t c = c0 + threadIdx.x;
+        __syncthreads();
+        if (c < cols) { zs[threadIdx.x] = z[c]; cs[threadIdx.x] = colidx ? colidx[c] : (int)c; }
+        __syncthreads();
+        const int nc = (int)(cols - c0 < 256 ? cols - c0 : 256);
+        if (r < rows) {
+#pragma unroll 8
+            for (int q = 0; q < nc; ++q) acc = fma(S[(int64_t)cs[q] * lds + r], zs[q], acc);
+        }
+    }
+    if (r < rows) y[r] -= acc;
+}
+
+hipError_t launch_gemv_sub(const double* S, int64_t lds, int64_t rows, int64_t cols, const int32_t* colidx, const double* z, double* y,
+                           hipStream_t stream)
+{
+    hipLaunchKernelGGL(gemv_sub_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, stream, S, lds, rows, cols, colidx, z, y);
+    return hipGetLastError();
+}
+
 }  // namespace qrk

@@ -386,6 +386,31 @@ qrk_status qrk_memcpy(qrk_handle h, void* dst, const void* src, int64_t bytes, i
     return QRK_STATUS_OK;
 }
 
+qrk_status qrk_memcpy_2d(qrk_handle h, void* dst, int64_t dst_pitch, const void* src, int64_t src_pitch, int64_t width_bytes,
+                         int64_t height, int direction)
+{
+    if (!h || width_bytes < 0 || height < 0 || dst_pitch < width_bytes || src_pitch < width_bytes || direction < 0 || direction > 2 ||
+        (width_bytes > 0 && height > 0 && (!dst || !src)))
+        return fail(h, QRK_STATUS_INVALID_ARGUMENT, "qrk_memcpy_2d: bad argument");
+    if (width_bytes == 0 || height == 0) return QRK_STATUS_OK;
+    QRK_HIP(h, hipSetDevice(h->device));
+    const hipMemcpyKind kind = direction == 0 ? hipMemcpyHostToDevice : direction == 1 ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
+    QRK_HIP(h, hipMemcpy2DAsync(dst, (size_t)dst_pitch, src, (size_t)src_pitch, (size_t)width_bytes, (size_t)height, kind, h->stream));
+    QRK_HIP(h, hipStreamSynchronize(h->stream));
+    return QRK_STATUS_OK;
+}
+
+qrk_status qrk_dense_gemv_sub(qrk_handle h, const double* S, int64_t lds, int64_t rows, int64_t cols, const int32_t* colidx,
+                              const double* z, double* y)
+{
+    if (!h || rows < 0 || cols < 0 || lds < rows || (rows > 0 && cols > 0 && (!S || !z || !y)))
+        return fail(h, QRK_STATUS_INVALID_ARGUMENT, "qrk_dense_gemv_sub: bad argument");
+    if (rows == 0 || cols == 0) return QRK_STATUS_OK;
+    QRK_HIP(h, hipSetDevice(h->device));
+    QRK_HIP(h, qrk::launch_gemv_sub(S, lds, rows, cols, colidx, z, y, h->stream));
+    return QRK_STATUS_OK;
+}
+
 qrk_status qrk_bd_plan_create(qrk_handle h, const qrk_bd_layout* L, qrk_q_format q_format,
                               qrk_block_solver solver, qrk_bd_plan* out)
 {

@@ -99,6 +99,9 @@ bool dense_cols_supported(int r, int c);
 int* dense_cols_unclear_ptr(void* workspace, int cpad);
 hipError_t launch_dense_qr_cols(double* A, int64_t lda, int r, int c, int pivoting, double* hcoeffs, int32_t* perm, void* workspace,
                                 int cpad, double* out, int64_t ldo, hipStream_t stream);
+// y(0:rows) -= sum_c S(:, colidx[c]) z[c] (bd_aux.hip): the strip term of the angular back substitution
+hipError_t launch_gemv_sub(const double* S, int64_t lds, int64_t rows, int64_t cols, const int32_t* colidx, const double* z, double* y,
+                           hipStream_t stream);
 struct BBPanel;
 hipError_t launch_bb_chain(const BBPanel* panels, int num_panels, const int32_t* prowptr, const int32_t* pcol,
                            const int64_t* pmap, const double* vals, double* W, double* lo, double* y_vals,

@@ -5,8 +5,10 @@
 //                        left solver it uses (typedefs :43-48), and with a BlockDiagonalSparseQR left
 //                        solver on a block-diagonal left part (BASELINE configs[3] shape).
 // The reference checks at 1e-6 (test/test.h:31); the bars here are 1e-10 / 1e-8.
+#include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <numeric>
 #include <random>
 
@@ -222,6 +224,40 @@ int main() {
         rightSparse.setFromTriplets(rt);
         fails += test_block_angular_as<BlockAngularSparseQR<BandedBlockedQRSolver, BlockedThinSparseQR<2> > >(left, left, right, rightSparse, "banded left, BlockedThinSparseQR right (sparse right block)");
         fails += test_blocked_thin(right);
+    }
+    if (std::getenv("QRK_BIG")) {
+        // BASELINE configs[3] through the facade: 20000 tiles of 8x6 + 2000 dense columns, host matrices in, solution out.
+        // J2 (2.56 GB) crosses PCIe once; Q1^T J2, the strip of R and the packed right factor stay on the device.
+        const Index B = 20000, r = 8, c = 6, m2 = 2000, n1 = B * r, m1 = B * c;
+        std::mt19937_64 rng(3);
+        std::uniform_real_distribution<double> ud(0.5, 5.0);
+        SparseBlockDiagonal blk(n1, m1);
+        Matrix tile(r, c);
+        for (Index b = 0; b < B; ++b) { for (Index e = 0; e < r * c; ++e) tile.data()[e] = ud(rng); blk.insertBack(tile); }
+        Matrix right(n1, m2);
+        for (Index e = 0; e < n1 * m2; ++e) right.data()[e] = ud(rng);
+        Vector x((size_t)(m1 + m2));
+        for (double& v : x) v = ud(rng) - 2.75;
+        Vector bvec((size_t)n1, 0.0);
+        {   // b = [J1 | J2] x
+            size_t off = 0;
+            for (Index b = 0; b < B; ++b, off += (size_t)(r * c))
+                for (Index j = 0; j < c; ++j) for (Index i = 0; i < r; ++i) bvec[(size_t)(b * r + i)] += blk.tiles()[off + (size_t)(j * r + i)] * x[(size_t)(b * c + j)];
+            for (Index j = 0; j < m2; ++j) { const double xv = x[(size_t)(m1 + j)]; const double* col = right.data() + j * n1; for (Index i = 0; i < n1; ++i) bvec[(size_t)i] += col[i] * xv; }
+        }
+        BlockAngularSparseQR<BlockDiagonalSparseQR<ColPivHouseholderQR>, ColPivHouseholderQR> baqr;
+        BlockMatrix1x2<SparseBlockDiagonal, Matrix> mat(blk, right);
+        baqr.compute(mat);                               // (first call: plans, allocations)
+        const auto t0 = std::chrono::steady_clock::now();
+        baqr.compute(mat);
+        const auto t1 = std::chrono::steady_clock::now();
+        const Vector xs = baqr.solve(bvec);
+        const auto t2 = std::chrono::steady_clock::now();
+        const bool ok = approxVec(x, xs, 1e-8);
+        std::printf("configs[3] through the facade (%lld x (8x6) + %lld dense, host matrices in): compute %.1f ms, solve %.1f ms: %s\n",
+                    (long long)B, (long long)m2, std::chrono::duration<double, std::milli>(t1 - t0).count(),
+                    std::chrono::duration<double, std::milli>(t2 - t1).count(), ok ? "Passed." : "Failed.");
+        if (!ok) ++fails;
     }
     {   // the reference's own spelling: namespace QRKit, four template parameters, a fixed-size block type and a block overlap
         // (typedef at test-qrkit.cpp:43-44 with <Matrix<double,7,4>> / overlap 2 would take the fixed-pattern analysis,
