@@ -177,6 +177,23 @@ def test_generic_tiles_are_not_flagged(qa, ctx):
     assert n_same <= 2, f"{n_same} of {B} generic tiles took the exact path"
 
 
+@pytest.mark.parametrize("r,c", [(8, 8), (12, 7), (20, 17), (31, 31)])
+def test_generic_small_and_ragged_tiles_stay_on_the_fast_path(qa, ctx, r, c):
+    """The same for the small-tile kernel (G = 8, 16) and the ragged form of the pair kernel.  With so few operations a tile can
+    agree with the oracle bit for bit by chance, so the bar is that most tiles do not (a false-positive flag redoes ALL of them)."""
+    B = 256
+    rng = np.random.default_rng(100 * r + c)
+    tiles = rng.uniform(0.5, 5.0, B * r * c)
+    rows = np.full(B, r, np.int32); cols = np.full(B, c, np.int32)
+    qr = qa.BlockDiagonalSparseQR(qa.SparseBlockDiagonal.fromTiles(rows, cols, tiles), context=ctx)
+    _, ref = oracle_factorize(rows, cols, tiles)
+    np.testing.assert_array_equal(qr.colsPermutation(), ref.perm)
+    got = qr.qValues().cpu().numpy()
+    per = r * r
+    redone = sum(np.array_equal(got[i * per:(i + 1) * per], ref.Q_vals[i * per:(i + 1) * per]) for i in range(B))
+    assert redone < B // 2, f"{redone} of {B} generic {r}x{c} tiles are bitwise the exact path's result"
+
+
 @pytest.mark.parametrize("n", [16, 32, 33, 48, 64, 96, 160, 300])
 def test_generic_tiles_stay_on_the_fast_path(qa, ctx, n):
     """The other half of the decision margins: on generic data NO tile may be flagged.  The exact path rounds like a scalar
