@@ -318,8 +318,9 @@ caqr_panel_kernel(double* __restrict__ A, int64_t lda, int m, int pc, int w, Sla
 // of A.  Grid (slabs, column groups); a wave takes 16 columns at a time.
 typedef double d4 __attribute__((ext_vector_type(4)));
 
+constexpr int APPLY_T = 512;     // 8 waves share the Y of a slab: two workgroups per CU (LDS) = 4 waves per SIMD behind the loads of C
 template <bool TRI>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2)))
+__global__ void __launch_bounds__(APPLY_T)
 caqr_apply_kernel(const double* __restrict__ A, int64_t lda, int m, int pc, int w, Slab sl, const double* __restrict__ Tin,
                   int transpose, double* __restrict__ C, int64_t ldc, int ncols, int cols_per_wg)
 {
@@ -332,12 +333,12 @@ caqr_apply_kernel(const double* __restrict__ A, int64_t lda, int m, int pc, int 
     cnt = cnt > FAN ? FAN : cnt;
     // ---- Y of the slab as a dense 256 x 32 matrix (unit diagonal and structural zeros written out)
     {
-        const int x = tid & 31, y = tid >> 5;
+        const int x = tid & 31, y = (tid >> 5) & (FAN - 1), ch = tid >> 8;      // row of the chunk, chunk, half of the columns
         const int64_t row0 = chunk_row0(sl, t, y);
         const int nr = y < cnt ? chunk_rows(row0, m) : 0;
         const double* src = A + (int64_t)pc * lda + row0 + x;
 #pragma unroll 8
-        for (int cc = 0; cc < NB; ++cc) {
+        for (int cc = ch * (NB / 2); cc < (ch + 1) * (NB / 2); ++cc) {
             double v = 0.0;
             if (cc < w && x < nr) {
                 if (y == 0) {
@@ -347,13 +348,13 @@ caqr_apply_kernel(const double* __restrict__ A, int64_t lda, int m, int pc, int 
             }
             ys[(y * NB + x) * LS + cc] = v;
         }
-        for (int e = tid; e < NB * NB; e += 256) ts[(e >> 5) * LS + (e & 31)] = Tin[(int64_t)t * (NB * NB) + e];
+        for (int e = tid; e < NB * NB; e += APPLY_T) ts[(e >> 5) * LS + (e & 31)] = Tin[(int64_t)t * (NB * NB) + e];
     }
     __syncthreads();
     const int wave = tid >> 6, lane = tid & 63, kq = lane >> 4, l15 = lane & 15;
     const int col_base = blockIdx.y * cols_per_wg;
     const int ntile = (cols_per_wg + 15) >> 4;
-    for (int tile = wave; tile < ntile; tile += 4) {
+    for (int tile = wave; tile < ntile; tile += APPLY_T / 64) {
         const int n0 = col_base + 16 * tile;
         if (n0 >= ncols) break;
         // ---- W = Y^T C  (the loads of the next chunk are in flight while the MFMAs of this one run)
@@ -519,9 +520,9 @@ static hipError_t caqr_panel_levels(double* A, int64_t lda, int m, int p, int w,
             if (cols_per_wg > 128) cols_per_wg = 128;
             if (cols_per_wg < 16) cols_per_wg = 16;
             const int cg = (ncols + cols_per_wg - 1) / cols_per_wg;
-            if (l == 0) hipLaunchKernelGGL((caqr_apply_kernel<false>), dim3(S, cg), dim3(256), APPLY_LDS, stream, A, lda, m, pc, w, sl,
+            if (l == 0) hipLaunchKernelGGL((caqr_apply_kernel<false>), dim3(S, cg), dim3(APPLY_T), APPLY_LDS, stream, A, lda, m, pc, w, sl,
                                            tptr(l), transpose, C, ldc, ncols, cols_per_wg);
-            else hipLaunchKernelGGL((caqr_apply_kernel<true>), dim3(S, cg), dim3(256), APPLY_LDS, stream, A, lda, m, pc, w, sl,
+            else hipLaunchKernelGGL((caqr_apply_kernel<true>), dim3(S, cg), dim3(APPLY_T), APPLY_LDS, stream, A, lda, m, pc, w, sl,
                                     tptr(l), transpose, C, ldc, ncols, cols_per_wg);
         }
     }
