@@ -223,3 +223,28 @@ def test_two_stage_tall_colpiv_matches_oracle(rows, cols, monkeypatch):
     qr.solveR(z)
     xs = np.empty(cols); xs[P] = z.cpu().numpy()[:, 0]
     assert rel_fro(xs, x) <= 1e-9
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["pm1", "dup_cols"])
+def test_two_stage_tie_matrix_falls_back_to_the_exact_path(kind, monkeypatch):
+    """A tall block with exact ties under the two-stage form: the pivoted second stage flags its decisions, the exact path redoes the
+    WHOLE block from the plan's copy of the input in Eigen's operation order and leaves Eigen's packed format -- bitwise the oracle --
+    and the products that follow must read that format (not the two-stage one)."""
+    import torch
+    from test_ties_gpu import tie_tiles
+    monkeypatch.setenv("QRK_DENSE_TWO_STAGE", "1")
+    rows, cols = 1536, 64
+    A = tie_tiles(kind, 1, rows, cols, seed=7).reshape(cols, rows).T.copy()
+    qr, At = _factor(A, 0, None)
+    ref, hc, perm, _ = orc.colpiv_qr(A)
+    np.testing.assert_array_equal(qr.colsPermutation().cpu().numpy(), perm)
+    np.testing.assert_array_equal(At.cpu().numpy(), ref)
+    np.testing.assert_array_equal(qr._hc.cpu().numpy()[:cols], hc[:cols])
+    P = perm
+    B = torch.from_numpy(np.asfortranarray(A[:, P]).T.copy()).cuda().t()
+    qr.applyQ(B, transpose=True)
+    Rfull = np.zeros((rows, cols)); Rfull[:cols, :] = np.triu(ref[:cols, :])
+    assert np.linalg.norm(B.cpu().numpy() - Rfull) <= 1e-11 * np.linalg.norm(A)
+    qr.applyQ(B, transpose=False)
+    assert rel_fro(B.cpu().numpy(), A[:, P]) <= 1e-11
