@@ -274,3 +274,33 @@ def test_mixed_8_to_256_properties_and_determinism(qa, ctx):
     np.testing.assert_array_equal(qr2.colsPermutation(), perm)
     np.testing.assert_array_equal(qr2.qValues().cpu().numpy(), Qv)
     np.testing.assert_array_equal(qr2.rValues().cpu().numpy(), Rv)
+
+
+@pytest.mark.gpu
+def test_edge_shapes_match_oracle():
+    """Edge cases of the container and of the per-block solver: an empty matrix (no blocks), a single 1x1 tile, an all-zero tile
+    (rank 0: every reflector degenerate, Q = I), a tile with one row more than columns, and a 1-column tile next to a wide-ish one."""
+    import qrkit_amd
+    ctx = qrkit_amd.Context(0)
+    # no blocks at all: empty factors, empty permutation, Success
+    empty = qrkit_amd.SparseBlockDiagonal.fromTiles(np.zeros(0, np.int32), np.zeros(0, np.int32), np.zeros(0))
+    qr = qrkit_amd.BlockDiagonalSparseQR(empty, context=ctx)
+    assert qr.info() == 0 and qr.rank() == 0
+    assert len(qr.colsPermutation()) == 0 and qr.rValues().numel() == 0 and qr.qValues().numel() == 0
+    rng = np.random.default_rng(8)
+    for rows, cols, zero in (([1], [1], False), ([5], [3], True), ([4, 9, 2], [3, 1, 2], False), ([33, 7], [32, 7], False)):
+        rows = np.asarray(rows, np.int32); cols = np.asarray(cols, np.int32)
+        n = int((rows.astype(np.int64) * cols).sum())
+        tiles = np.zeros(n) if zero else rng.uniform(-1.0, 1.0, n)
+        mat = qrkit_amd.SparseBlockDiagonal.fromTiles(rows, cols, tiles)
+        qr = qrkit_amd.BlockDiagonalSparseQR(mat, context=ctx)
+        _, ref = oracle_factorize(rows, cols, tiles)
+        assert qr.info() == 0 and qr.rank() == ref.rank
+        np.testing.assert_array_equal(qr.colsPermutation(), ref.perm)
+        sq, sr, _ = tile_sizes(rows, cols)
+        if zero:
+            np.testing.assert_array_equal(qr.rValues().cpu().numpy(), ref.R_vals)
+            np.testing.assert_array_equal(qr.qValues().cpu().numpy(), ref.Q_vals)
+        else:
+            assert per_tile_rel(qr.qValues().cpu().numpy(), ref.Q_vals, sq) <= RTOL
+            assert per_tile_rel(qr.rValues().cpu().numpy(), ref.R_vals, sr) <= RTOL
