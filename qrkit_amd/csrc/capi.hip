@@ -877,8 +877,11 @@ qrk_status qrk_dense_plan_create(qrk_handle h, int32_t rows, int32_t cols, qrk_b
         }
         if (!p->cols2) p->d_q1 = p->d_r0;
         const char* la = std::getenv("QRK_CAQR_LOOKAHEAD");
+        // (highest priority: a panel workgroup needs the LDS of one apply workgroup and should get the next slot that frees up)
+        int prio_least = 0, prio_greatest = 0;
+        (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
         if (!(la && la[0] == '0') &&
-            (hipStreamCreateWithFlags(&p->la_stream, hipStreamNonBlocking) != hipSuccess ||
+            (hipStreamCreateWithPriority(&p->la_stream, hipStreamNonBlocking, prio_greatest) != hipSuccess ||
              hipEventCreateWithFlags(&p->la_urgent, hipEventDisableTiming) != hipSuccess ||
              hipEventCreateWithFlags(&p->la_factored, hipEventDisableTiming) != hipSuccess)) {
             qrk_dense_plan_destroy(p);

@@ -38,7 +38,7 @@ constexpr int NB = 32;          // panel width = rows of a chunk
 constexpr int FAN = 8;          // chunks per slab
 constexpr int SR = NB * FAN;    // virtual rows of a slab
 constexpr int LS = NB + 1;      // LDS row stride (doubles): conflict-free by rows and by columns
-constexpr size_t PANEL_LDS = (size_t)(SR * LS + 2 * FAN * NB + NB * LS + FAN + 2 * NB + 1) * sizeof(double);   // 81 KB
+constexpr size_t PANEL_LDS = (size_t)(SR * LS + 2 * FAN * NB + FAN + 2 * NB + 1) * sizeof(double);            // 72 KB: fits where an apply workgroup (76 KB) was
 constexpr size_t APPLY_LDS = (size_t)(SR * LS + NB * LS) * sizeof(double);                                            // 76 KB
 
 // Slab t of a level: chunk i of it is chunk  p + stride (FAN t + i)  of the matrix (rows 32 chunk .. 32 chunk + 31).
@@ -176,15 +176,17 @@ __device__ __forceinline__ void panel_step(double (&a)[NB], const PanelLds& L, i
 // applyHouseholderOnTheLeft (Eigen/src/Householder/Householder.h), real square root and division.
 // TRI: the rows are a stack of upper triangles (entries below the diagonal of a chunk are not data and are left alone).
 template <bool TRI>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2)))   // column + reflector in registers: ~150 VGPRs; 81 KB of LDS allow one workgroup per CU anyway
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2)))   // column + reflector in registers: ~150 VGPRs
 caqr_panel_kernel(double* __restrict__ A, int64_t lda, int m, int pc, int w, Slab sl, double* __restrict__ Tout)
 {
     extern __shared__ __attribute__((aligned(16))) double caqr_lds[];
     double* sm = caqr_lds;                                                        // [SR][LS] transposing buffer
     double (*vb)[NB] = reinterpret_cast<double (*)[NB]>(sm + SR * LS);            // [FAN][NB] reflector column (16-byte aligned: SR * LS is even)
     double (*red)[NB] = reinterpret_cast<double (*)[NB]>(&vb[FAN][0]);            // [FAN][NB] partial dots
-    double (*zz)[LS] = reinterpret_cast<double (*)[LS]>(&red[FAN][0]);            // [NB][LS] strictly upper part: y_c^T y_j, c < j
-    double* nrm = &zz[NB][0];                                                     // [FAN] partial squared tail norms
+    double (*zz)[LS] = reinterpret_cast<double (*)[LS]>(sm + 2 * NB * LS);        // [NB][LS] strictly upper part: y_c^T y_j, c < j.  Lives INSIDE the
+                                                                                  // transposing buffer, which is idle between the load and the store (behind
+                                                                                  // the two T scratch areas): 72 KB in all, the LDS slot of one apply workgroup
+    double* nrm = &red[FAN][0];                                                   // [FAN] partial squared tail norms
     double* prow = nrm + FAN;                                                     // [NB] pivot row
     double* taus = prow + NB;                                                     // [NB]
     double& x0s = taus[NB];
@@ -206,11 +208,12 @@ caqr_panel_kernel(double* __restrict__ A, int64_t lda, int m, int pc, int w, Sla
 #pragma unroll
         for (int cc = 0; cc < NB; ++cc) sm[(i * NB + x) * LS + cc] = ld[cc];
     }
-    for (int e = tid; e < NB * LS; e += 256) (&zz[0][0])[e] = 0.0;
     __syncthreads();
     double a[NB];
 #pragma unroll
     for (int r2 = 0; r2 < NB; ++r2) a[r2] = sm[(i * NB + r2) * LS + c];
+    __syncthreads();                     // (the buffer has been read: its space now serves zz)
+    for (int e = tid; e < NB * LS; e += 256) (&zz[0][0])[e] = 0.0;
 
     if (c == 0) {
 #pragma unroll
