@@ -61,7 +61,10 @@ cols_init_kernel(const double* __restrict__ A, int64_t lda, int r, int c, Work w
     if (lane == 0) { w.nu2[0][jc] = s; w.thr[0][jc] = s * THR_HI; w.cmap[0][jc] = jc; }
 }
 
-// Step k.  Grid: ceil((c - k - 1) / 16) workgroups (at least one); dynamic LDS: (r - k) doubles.
+// Step k.  Grid: ceil((c - k - 1) / 8) workgroups (at least one); dynamic LDS: (r - k) doubles.
+// RPL: a lane keeps up to RPL entries of its column in registers between the dot and the update (32: columns of <= 2048 rows below the
+// pivot, 64: <= 4096); longer columns are read twice.
+template <int RPL>
 __global__ void __launch_bounds__(TT)
 cols_step_kernel(double* __restrict__ A, int64_t lda, int r, int c, int k, int pivoting, double* __restrict__ hcoeffs,
                  int32_t* __restrict__ perm, Work w)
@@ -75,15 +78,15 @@ cols_step_kernel(double* __restrict__ A, int64_t lda, int r, int c, int k, int p
     // the loads are issued before the serial part of the step, whose memory round trips they overlap
     const int pos = k + 1 + blockIdx.x * TW + wave;
     const int n = r - k - 1;                      // rows below the pivot row
-    const bool cached = n <= 2048;
-    double a[32];
+    const bool cached = n <= 64 * RPL;
+    double a[RPL];
     double ak = 0.0;
     int pc = 0;
     if (pos < c && cached) {
         pc = w.cmap[b][pos];
         const double* col0 = A + (int64_t)pc * lda;
 #pragma unroll
-        for (int q = 0; q < 32; ++q) { const int i = q * 64 + lane; a[q] = i < n ? col0[k + 1 + i] : 0.0; }
+        for (int q = 0; q < RPL; ++q) { const int i = q * 64 + lane; a[q] = i < n ? col0[k + 1 + i] : 0.0; }
         ak = col0[k];
     }
     // ---- the pivot: first maximum of the bookkeeping norms over positions k .. c-1 (larger wins, ties -> smaller position)
@@ -160,12 +163,12 @@ cols_step_kernel(double* __restrict__ A, int64_t lda, int r, int c, int k, int p
         // the column stays in registers between the dot and the update: one read, one write
         if (sp != pos) {
 #pragma unroll
-            for (int q = 0; q < 32; ++q) { const int i = q * 64 + lane; a[q] = i < n ? col[k + 1 + i] : 0.0; }
+            for (int q = 0; q < RPL; ++q) { const int i = q * 64 + lane; a[q] = i < n ? col[k + 1 + i] : 0.0; }
             ak = col[k];
         }
         double d0 = 0.0, d1 = 0.0;
 #pragma unroll
-        for (int q = 0; q < 32; q += 2) {
+        for (int q = 0; q < RPL; q += 2) {
             const int i = q * 64 + lane;
             d0 = fma(i < n ? xs[1 + i] : 0.0, a[q], d0);
             d1 = fma(i + 64 < n ? xs[1 + i + 64] : 0.0, a[q + 1], d1);
@@ -175,7 +178,7 @@ cols_step_kernel(double* __restrict__ A, int64_t lda, int r, int c, int k, int p
         const double an = fma(s, ngam, ak);
         double q0 = 0.0, q1 = 0.0;
 #pragma unroll
-        for (int q = 0; q < 32; q += 2) {
+        for (int q = 0; q < RPL; q += 2) {
             const int i = q * 64 + lane;
             if (i < n) { const double v = fma(ngam, xs[1 + i], a[q]); col[k + 1 + i] = v; q0 = fma(v, v, q0); }
             if (i + 64 < n) { const double v = fma(ngam, xs[1 + i + 64], a[q + 1]); col[k + 1 + i + 64] = v; q1 = fma(v, v, q1); }
@@ -193,27 +196,32 @@ cols_step_kernel(double* __restrict__ A, int64_t lda, int r, int c, int k, int p
         }
     } else {
         ak = col[k];
-        double dacc[4] = {0.0, 0.0, 0.0, 0.0};
-        for (int i0 = lane; i0 < n; i0 += 256) {
-            double av[4];
+        constexpr int UW = 8;              // loads in flight per lane
+        double dacc[UW];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) av[u] = i0 + 64 * u < n ? col[k + 1 + i0 + 64 * u] : 0.0;
+        for (int u = 0; u < UW; ++u) dacc[u] = 0.0;
+        for (int i0 = lane; i0 < n; i0 += 64 * UW) {
+            double av[UW];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) dacc[u] = fma(i0 + 64 * u < n ? xs[1 + i0 + 64 * u] : 0.0, av[u], dacc[u]);
+            for (int u = 0; u < UW; ++u) av[u] = i0 + 64 * u < n ? col[k + 1 + i0 + 64 * u] : 0.0;
+#pragma unroll
+            for (int u = 0; u < UW; ++u) dacc[u] = fma(i0 + 64 * u < n ? xs[1 + i0 + 64 * u] : 0.0, av[u], dacc[u]);
         }
-        const double d = wave_sum((dacc[0] + dacc[1]) + (dacc[2] + dacc[3]));
+        const double d = wave_sum(((dacc[0] + dacc[1]) + (dacc[2] + dacc[3])) + ((dacc[4] + dacc[5]) + (dacc[6] + dacc[7])));
         const double ngam = fma(s, ak, d) * ng;
         const double an = fma(s, ngam, ak);
-        double qacc[4] = {0.0, 0.0, 0.0, 0.0};
-        for (int i0 = lane; i0 < n; i0 += 256) {
-            double av[4];
+        double qacc[UW];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) av[u] = i0 + 64 * u < n ? col[k + 1 + i0 + 64 * u] : 0.0;
+        for (int u = 0; u < UW; ++u) qacc[u] = 0.0;
+        for (int i0 = lane; i0 < n; i0 += 64 * UW) {
+            double av[UW];
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
+            for (int u = 0; u < UW; ++u) av[u] = i0 + 64 * u < n ? col[k + 1 + i0 + 64 * u] : 0.0;
+#pragma unroll
+            for (int u = 0; u < UW; ++u)
                 if (i0 + 64 * u < n) { const double v = fma(ngam, xs[1 + i0 + 64 * u], av[u]); col[k + 1 + i0 + 64 * u] = v; qacc[u] = fma(v, v, qacc[u]); }
         }
-        const double sq = wave_sum((qacc[0] + qacc[1]) + (qacc[2] + qacc[3]));
+        const double sq = wave_sum(((qacc[0] + qacc[1]) + (qacc[2] + qacc[3])) + ((qacc[4] + qacc[5]) + (qacc[6] + qacc[7])));
         if (lane == 0) {
             col[k] = an;
             if (pivoting) {
@@ -287,7 +295,8 @@ hipError_t launch_dense_qr_cols(double* A, int64_t lda, int r, int c, int pivoti
     for (int k = 0; k < size; ++k) {
         int nwg = (c - k - 1 + TW - 1) / TW;
         if (nwg < 1) nwg = 1;
-        hipLaunchKernelGGL(cols_step_kernel, dim3(nwg), dim3(TT), (size_t)(r - k) * sizeof(double), stream, A, lda, r, c, k, pivoting,
+        // (RPL = 64, columns of up to 4096 rows in registers, was measured slower: 256 VGPRs and spills: 3000 x 300 in 10.3 ms against 6)
+        hipLaunchKernelGGL(cols_step_kernel<32>, dim3(nwg), dim3(TT), (size_t)(r - k) * sizeof(double), stream, A, lda, r, c, k, pivoting,
                            hcoeffs, perm, w);
     }
     if (c > size) hipLaunchKernelGGL(cols_tail_perm_kernel, dim3((c - size + 255) / 256), dim3(256), 0, stream, c, size, w, perm);
