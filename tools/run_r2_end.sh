@@ -7,7 +7,9 @@ timeout -k 10 900 python -m pytest tests -q -m gpu > $OUT/gpu_tests.txt 2>&1; ec
 tail -3 $OUT/gpu_tests.txt
 timeout -k 10 300 python bench.py > $OUT/bench.json 2> $OUT/bench.err; tail -c 1500 $OUT/bench.json
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/$OUT/prof -o bench -- python3 $ROOT/bench.py --no-cpu-baseline > $ROOT/$OUT/prof.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/$OUT/prof -o bench -- python3 $ROOT/bench.py --no-cpu-baseline --no-steady > $ROOT/$OUT/prof.log 2>&1
 cd $ROOT
 f=$(find $OUT/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cut -c1-220 "$f" | head -12 > $OUT/kernel_stats.csv; cat $OUT/kernel_stats.csv
 QRK_BIG=1 timeout -k 10 300 python tools/angular_probe.py 2>&1 | grep compute > $OUT/angular_probe.txt; cat $OUT/angular_probe.txt
+timeout -k 10 200 python tools/caqr_probe.py 2>&1 | grep factorize > $OUT/caqr_probe.txt; cat $OUT/caqr_probe.txt
+timeout -k 10 200 python tools/mixed_probe.py 4000 2>&1 | grep tiles/s > $OUT/mixed_probe.txt; head -3 $OUT/mixed_probe.txt
