@@ -360,32 +360,41 @@ caqr_apply_kernel(const double* __restrict__ A, int64_t lda, int m, int pc, int 
     for (int tile = wave; tile < ntile; tile += APPLY_T / 64) {
         const int n0 = col_base + 16 * tile;
         if (n0 >= ncols) break;
-        // ---- W = Y^T C  (the loads of the next chunk are in flight while the MFMAs of this one run)
+        // ---- W = Y^T C  (the loads of the next chunk are in flight while the MFMAs of this one run).  A lane takes FOUR consecutive
+        // rows of its column (two 16-byte loads; the 16 lanes of a k-group cover 16 rows x 16 columns in whole 128-byte lines) and
+        // feeds them to four k-steps: slot k of a chunk is row 16 (k >> 2) + 4 kq + (k & 3) -- the order inside a k-step is free as
+        // long as the Y operand is read with the same rows.
         d4 acc0 = d4{0.0, 0.0, 0.0, 0.0}, acc1 = d4{0.0, 0.0, 0.0, 0.0};
         {
             const int col = n0 + l15;
             const bool cok = col < ncols;
             const double* cb = C + (int64_t)col * ldc;
-            double bn[8];
-            {
-                const int64_t row0 = chunk_row0(sl, t, 0);
+            auto load_chunk = [&](int ci, double (&bb)[8]) {
+                const int64_t row0 = chunk_row0(sl, t, ci);
                 const int nr = chunk_rows(row0, m);
 #pragma unroll
-                for (int k = 0; k < 8; ++k) { const int rr = 4 * k + kq; bn[k] = (cok && rr < nr) ? cb[row0 + rr] : 0.0; }
-            }
+                for (int blk = 0; blk < 2; ++blk) {
+                    const int base = 16 * blk + 4 * kq;
+                    const double* p = cb + row0 + base;
+                    if (cok && base + 3 < nr && (reinterpret_cast<uintptr_t>(p) & 15) == 0) {
+                        const double2 lo = *reinterpret_cast<const double2*>(p), hi = *reinterpret_cast<const double2*>(p + 2);
+                        bb[4 * blk] = lo.x; bb[4 * blk + 1] = lo.y; bb[4 * blk + 2] = hi.x; bb[4 * blk + 3] = hi.y;
+                    } else {
+#pragma unroll
+                        for (int jj = 0; jj < 4; ++jj) bb[4 * blk + jj] = (cok && base + jj < nr) ? p[jj] : 0.0;
+                    }
+                }
+            };
+            double bn[8];
+            load_chunk(0, bn);
             for (int ci = 0; ci < cnt; ++ci) {
                 double bv[8];
 #pragma unroll
                 for (int k = 0; k < 8; ++k) bv[k] = bn[k];
-                if (ci + 1 < cnt) {
-                    const int64_t row0 = chunk_row0(sl, t, ci + 1);
-                    const int nr = chunk_rows(row0, m);
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) { const int rr = 4 * k + kq; bn[k] = (cok && rr < nr) ? cb[row0 + rr] : 0.0; }
-                }
+                if (ci + 1 < cnt) load_chunk(ci + 1, bn);
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
-                    const int vrow = ci * NB + 4 * k + kq;
+                    const int vrow = ci * NB + 16 * (k >> 2) + 4 * kq + (k & 3);
                     acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(ys[vrow * LS + l15], bv[k], acc0, 0, 0, 0);
                     acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ys[vrow * LS + 16 + l15], bv[k], acc1, 0, 0, 0);
                 }
