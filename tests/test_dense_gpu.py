@@ -248,3 +248,37 @@ def test_two_stage_tie_matrix_falls_back_to_the_exact_path(kind, monkeypatch):
     assert np.linalg.norm(B.cpu().numpy() - Rfull) <= 1e-11 * np.linalg.norm(A)
     qr.applyQ(B, transpose=False)
     assert rel_fro(B.cpu().numpy(), A[:, P]) <= 1e-11
+
+
+@pytest.mark.gpu
+def test_two_stage_many_right_hand_sides_and_larger_block(monkeypatch):
+    """Two-stage form on a larger block (12 288 x 448: 48 slabs, three levels, a ragged last panel of 0 columns -- 14 whole panels)
+    with 70 right-hand sides (not a multiple of the 16-column MFMA tile): permutation and R against the oracle, Q^T B against
+    the oracle's own Q^T B on the rows that are determined (the first `cols`, up to the row signs of R), Q (Q^T B) = B."""
+    import torch
+    monkeypatch.setenv("QRK_DENSE_TWO_STAGE", "1")
+    rows, cols, nrhs = 12288, 448, 70
+    rng = np.random.default_rng(99)
+    A = rng.uniform(-1.0, 1.0, (rows, cols)) * rng.uniform(0.25, 4.0, cols)[None, :]
+    qr, At = _factor(A, 0, None)
+    ref, hc, perm, _ = orc.colpiv_qr(A)
+    np.testing.assert_array_equal(qr.colsPermutation().cpu().numpy(), perm)
+    Rg, Rr = np.triu(At.cpu().numpy()[:cols, :]), np.triu(ref[:cols, :])
+    sg = np.sign(np.diag(Rg)) * np.sign(np.diag(Rr))
+    row_err = np.linalg.norm(Rg * sg[:, None] - Rr, axis=1) / np.linalg.norm(Rr, axis=1)
+    assert row_err.max() <= 1e-11, row_err.max()
+    Bh = rng.uniform(-1.0, 1.0, (rows, nrhs))
+    B = torch.from_numpy(np.asfortranarray(Bh).T.copy()).cuda().t()
+    qr.applyQ(B, transpose=True)
+    got = B.cpu().numpy()
+    # the oracle's Q^T B through its own reflectors (rows 0..cols-1 are R^-T (A P)^T B: determined up to the sign of each row)
+    want = orc.apply_householder_qt(ref, hc, Bh) if hasattr(orc, "apply_householder_qt") else None
+    if want is None:
+        AP = A[:, perm]
+        want_top = np.linalg.solve(Rr.T, AP.T @ Bh)                     # = (Q^T B)(0:cols, :) for the oracle's R
+        assert np.linalg.norm(got[:cols] * sg[:, None] - want_top) <= 1e-9 * np.linalg.norm(want_top)
+    else:
+        assert np.linalg.norm(got[:cols] * sg[:, None] - want[:cols]) <= 1e-10 * np.linalg.norm(want[:cols])
+    assert abs(np.linalg.norm(got) - np.linalg.norm(Bh)) <= 1e-11 * np.linalg.norm(Bh)       # orthogonal
+    qr.applyQ(B, transpose=False)
+    assert rel_fro(B.cpu().numpy(), Bh) <= 1e-11

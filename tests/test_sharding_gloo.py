@@ -130,9 +130,9 @@ def _angular_worker(rank, world, port, rows, cols, tiles, J2, b, extra, out):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("B,m2,extra,reduced", [(600, 160, 37, True), (40, 64, 5, False)])
-def test_sharded_block_angular_tsqr_world2(tmp_path, B, m2, extra, reduced):
-    """ShardedBlockAngularQR, two ranks on the box's one GPU (gloo): left tiles and the rows of J2 sharded, the bottom rows reduced
+@pytest.mark.parametrize("B,m2,extra,reduced,world", [(600, 160, 37, True, 2), (40, 64, 5, False, 2), (900, 96, 0, True, 3)])
+def test_sharded_block_angular_tsqr_world2(tmp_path, B, m2, extra, reduced, world):
+    """ShardedBlockAngularQR, two or three ranks on the box's one GPU (gloo): left tiles and the rows of J2 sharded, the bottom rows reduced
     per rank to a triangle (qrk_tsqr_*), the triangles stacked and pivoted on the root; the least-squares solution and the
     right-block permutation against the un-sharded BlockAngularSparseQR (BlockAngularSparseQR.h:459-514, :202-227) run by the
     oracle.  Second shape: ranks with fewer bottom rows than right columns send the rows themselves."""
@@ -150,14 +150,16 @@ def test_sharded_block_angular_tsqr_world2(tmp_path, B, m2, extra, reduced):
     b[:n1] += np.einsum("bcr,bc->br", T, x[:m1].reshape(B, c)).reshape(-1)
     out = str(tmp_path / "a")
     port = 31500 + (os.getpid() % 2000) + B % 7
-    mp.spawn(_angular_worker, args=(2, port, rows, cols, tiles, J2, b, extra, out), nprocs=2, join=True)
-    x1 = np.concatenate([np.load(f"{out}_x1_{k}.npy") for k in range(2)])
+    mp.spawn(_angular_worker, args=(world, port, rows, cols, tiles, J2, b, extra, out), nprocs=world, join=True)
+    x1 = np.concatenate([np.load(f"{out}_x1_{k}.npy") for k in range(world)])
     x2 = np.load(f"{out}_x2_0.npy")
-    np.testing.assert_array_equal(x2, np.load(f"{out}_x2_1.npy"))
+    for k in range(1, world):
+        np.testing.assert_array_equal(x2, np.load(f"{out}_x2_{k}.npy"))
     xs = np.concatenate([x1, x2])
     assert np.linalg.norm(xs - x) <= 1e-10 * np.linalg.norm(x)
     assert bool(np.load(f"{out}_red_0.npy")[0]) == reduced
     # the right-block permutation is the un-sharded one: the oracle's BlockAngularSparseQR on the whole matrix
     ref = orc.ba_factorize(orc.BDProblem(rows, cols, tiles), J2)
     np.testing.assert_array_equal(np.load(f"{out}_p2_0.npy") + m1, ref.perm[m1:])
-    np.testing.assert_array_equal(np.load(f"{out}_p2_0.npy"), np.load(f"{out}_p2_1.npy"))
+    for k in range(1, world):
+        np.testing.assert_array_equal(np.load(f"{out}_p2_0.npy"), np.load(f"{out}_p2_{k}.npy"))
