@@ -91,26 +91,33 @@ cols_step_kernel(double* __restrict__ A, int64_t lda, int r, int c, int k, int p
     }
     // ---- the pivot: first maximum of the bookkeeping norms over positions k .. c-1 (larger wins, ties -> smaller position)
     int P = k;
+    int pk = -1;                              // physical column of the pivot: travels with the candidate through the reduction, so that
+                                              // no dependent look-up follows the search
     double best = 0.0;
     if (pivoting) {
-        best = -1.0; int bi = c;
-        for (int pos = k + tid; pos < c; pos += TT) { const double v = w.nu2[b][pos]; if (v > best) { best = v; bi = pos; } }
+        __shared__ int cred[TW];
+        best = -1.0; int bi = c, bc = -1;
+        for (int pos = k + tid; pos < c; pos += TT) {
+            const double v = w.nu2[b][pos];
+            const int cc = w.cmap[b][pos];
+            if (v > best) { best = v; bi = pos; bc = cc; }
+        }
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) {
             const double ob = __shfl_xor(best, off);
-            const int oi = __shfl_xor(bi, off);
-            if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+            const int oi = __shfl_xor(bi, off), oc = __shfl_xor(bc, off);
+            if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; bc = oc; }
         }
-        if (lane == 0) { red[wave] = best; ired[wave] = bi; }
+        if (lane == 0) { red[wave] = best; ired[wave] = bi; cred[wave] = bc; }
         __syncthreads();
-        best = red[0]; bi = ired[0];
+        best = red[0]; bi = ired[0]; bc = cred[0];
 #pragma unroll
-        for (int q = 1; q < TW; ++q) if (red[q] > best || (red[q] == best && ired[q] < bi)) { best = red[q]; bi = ired[q]; }
-        P = bi < c ? bi : k;
+        for (int q = 1; q < TW; ++q) if (red[q] > best || (red[q] == best && ired[q] < bi)) { best = red[q]; bi = ired[q]; bc = cred[q]; }
+        if (bi < c) { P = bi; pk = bc; }
         __syncthreads();
     }
     const double a2_in = w.st->a2;            // written by step 0 (a kernel boundary ago)
-    const int pk = w.cmap[b][P];
+    if (pk < 0) pk = w.cmap[b][P];
     // ---- x into LDS, |x_tail|^2
     double t = 0.0;
     for (int i = k + tid; i < r; i += TT) {
