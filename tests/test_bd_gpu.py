@@ -304,3 +304,45 @@ def test_edge_shapes_match_oracle():
         else:
             assert per_tile_rel(qr.qValues().cpu().numpy(), ref.Q_vals, sq) <= RTOL
             assert per_tile_rel(qr.rValues().cpu().numpy(), ref.R_vals, sr) <= RTOL
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(12))
+def test_random_mixed_batches_match_oracle(seed):
+    """Randomised sweep over what a caller can hand in: mixed batches of 1..150 tiles with columns 1..70 and 0..9 extra rows
+    (every kernel family and the bins between them in one matrix), values from one of four distributions (uniform, wide dynamic
+    range, small integers = ties, one dominant column), both block solvers, both Q formats, optional trailing identity rows."""
+    import qrkit_amd
+    from qrkit_amd import _capi as capi
+    rng = np.random.default_rng(1000 + seed)
+    B = int(rng.integers(1, 151))
+    cols = rng.integers(1, 71, B).astype(np.int32)
+    rows = (cols + rng.integers(0, 10, B)).astype(np.int32)
+    n = int((rows.astype(np.int64) * cols).sum())
+    kind = seed % 4
+    if kind == 0:
+        tiles = rng.uniform(-1.0, 1.0, n)
+    elif kind == 1:
+        tiles = rng.uniform(-1.0, 1.0, n) * np.exp2(rng.integers(-30, 31, n))
+    elif kind == 2:
+        tiles = rng.integers(-2, 3, n).astype(np.float64)
+    else:
+        tiles = rng.uniform(-1.0, 1.0, n) * 1e-3
+        off = 0
+        for r, c in zip(rows, cols):
+            tiles[off: off + r] += rng.uniform(1.0, 2.0, r)                                              # column 0 dominates
+            off += int(r) * int(c)
+    solver = capi.COLPIV_HOUSEHOLDER if seed % 3 else capi.HOUSEHOLDER
+    qformat = capi.FULL_Q if seed % 2 else capi.BLOCK_DIAGONAL_Q
+    extra = int(rng.integers(0, 4))
+    mat_rows = int(rows.sum()) + extra
+    mat = qrkit_amd.SparseBlockDiagonal.fromTiles(rows, cols, tiles, rows=mat_rows)
+    qr = qrkit_amd.BlockDiagonalSparseQR(mat, blockSolver=solver, qFormat=qformat)
+    _, ref = oracle_factorize(rows, cols, tiles, mat_rows=mat_rows, q_format=qformat, block_solver=solver)
+    assert qr.info() == 0 and qr.rank() == ref.rank
+    np.testing.assert_array_equal(qr.colsPermutation(), ref.perm)
+    sq, sr, _ = tile_sizes(rows, cols)
+    nq = int(sq.sum())
+    assert per_tile_rel(qr.qValues().cpu().numpy()[:nq], ref.Q_vals[:nq], sq) <= 10 * RTOL
+    assert per_tile_rel(qr.rValues().cpu().numpy(), ref.R_vals, sr) <= 10 * RTOL
+    np.testing.assert_array_equal(qr.qValues().cpu().numpy()[nq:], ref.Q_vals[nq:])      # trailing identity rows

@@ -282,3 +282,33 @@ def test_two_stage_many_right_hand_sides_and_larger_block(monkeypatch):
     assert abs(np.linalg.norm(got) - np.linalg.norm(Bh)) <= 1e-11 * np.linalg.norm(Bh)       # orthogonal
     qr.applyQ(B, transpose=False)
     assert rel_fro(B.cpu().numpy(), Bh) <= 1e-11
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(10))
+def test_random_dense_blocks_match_oracle(seed):
+    """Randomised sweep over dense right blocks: tall, square and wide shapes (1..700 rows, 1..160 columns), both solvers, whichever
+    device path the plan picks; generic values (fast path: <= 1e-11) or small integers (ties: exact path, bitwise)."""
+    rng = np.random.default_rng(500 + seed)
+    rows, cols = int(rng.integers(1, 701)), int(rng.integers(1, 161))
+    solver = seed % 2
+    ints = seed % 5 == 4
+    A = rng.integers(-2, 3, (rows, cols)).astype(np.float64) if ints else rng.uniform(-1.0, 1.0, (rows, cols))
+    qr, At = _factor(A, solver, None)
+    got, k = At.cpu().numpy(), min(rows, cols)
+    if solver == 0:
+        ref, hc, perm, _ = orc.colpiv_qr(A)
+    else:
+        ref, hc = orc.householder_qr(A)
+        perm = np.arange(cols)
+    np.testing.assert_array_equal(qr.colsPermutation().cpu().numpy(), perm)
+    if ints and solver == 0 and np.array_equal(got, ref):
+        np.testing.assert_array_equal(qr._hc.cpu().numpy()[:k], hc[:k])
+    else:
+        scale = np.linalg.norm(np.triu(ref[:k]))
+        assert np.linalg.norm(np.triu(got[:k]) - np.triu(ref[:k])) <= 1e-11 * max(scale, 1e-300)
+        live = np.abs(np.diag(ref[:k, :k])) > 1e-9 * np.abs(ref[0, 0]) if k > 0 else np.zeros(0, bool)
+        cols_live = np.where(live)[0]
+        if cols_live.size:
+            lo_g, lo_r = np.tril(got, -1)[:, cols_live], np.tril(ref, -1)[:, cols_live]
+            assert np.linalg.norm(lo_g - lo_r) <= 1e-9 * max(np.linalg.norm(lo_r), 1.0)
