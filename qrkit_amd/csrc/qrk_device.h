@@ -50,6 +50,9 @@ void launch_bdqr_pair(const WaveBatch& nb, bool full32, const double* tiles, dou
 // Uniform batches of small tiles (rows <= 16, cols <= rows): 64/G tiles per wavefront (bdqr_small.hip).
 void launch_bdqr_small(int64_t num_tiles, int r, int c, int pivoting, const double* tiles, double* q_vals, double* r_vals,
                        int32_t* perm, double* hcoeffs, int max_blocks, int32_t* redo_count, int32_t* redo_ids, hipStream_t stream);
+// Uniform batches of tall-thin small tiles (1 or 2 columns, rows <= 16): one tile per lane, no LDS (bdqr_thin.hip).
+void launch_bdqr_thin(int64_t num_tiles, int r, int c, int pivoting, const double* tiles, double* q_vals, double* r_vals,
+                      int32_t* perm, double* hcoeffs, int max_blocks, int32_t* redo_count, int32_t* redo_ids, hipStream_t stream);
 // Mid-size tiles (32 < max(rows, cols) <= 256, rows >= cols): one thread per column of A, blocked Q (bdqr_col.hip).
 // One launch serves one size class (columns <= 64, <= 128, <= 256): its LDS is carved for the largest tile of the class.
 hipError_t launch_bdqr_col(const WaveBatch& nb, const double* tiles, double* q_vals, double* r_vals, int32_t* perm,

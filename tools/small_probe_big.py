@@ -7,8 +7,11 @@ import numpy as np, torch
 import qrkit_amd as qa
 
 ctx = qa.Context(0)
-for (r, c, b) in ((7, 2, 2000000), (9, 2, 2000000), (6, 6, 1000000), (8, 6, 1000000), (4, 4, 2000000), (8, 8, 1000000),
-                  (12, 12, 400000), (16, 16, 400000)):
+SHAPES = ((7, 2, 2000000), (9, 2, 2000000), (6, 6, 1000000), (8, 6, 1000000), (4, 4, 2000000), (8, 8, 1000000),
+          (12, 12, 400000), (16, 16, 400000))
+if len(sys.argv) > 1:      # e.g. "9x2,12x2,16x1"
+    SHAPES = tuple((int(a.split("x")[0]), int(a.split("x")[1]), 1000000) for a in sys.argv[1].split(","))
+for (r, c, b) in SHAPES:
     rows, cols = np.full(b, r, np.int32), np.full(b, c, np.int32)
     tiles = torch.rand(b * r * c, device="cuda", dtype=torch.float64) * 2 - 1
     mat = qa.SparseBlockDiagonal.fromTiles(rows, cols, tiles)
