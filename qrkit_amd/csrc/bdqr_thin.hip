@@ -31,8 +31,9 @@ constexpr int RM = 16;      // rows of a tile at most
 // workgroup's contiguous run of `tiles` / `q_vals` (a lane reading or writing its own tile directly touches 64 different lines per
 // instruction: measured at 27 % of the roofline whatever the shape):
 //   in    the 256 r c doubles of the tiles, copied in index order to LDS (tile t at an odd stride: conflict-free pick-up by its lane);
-//   out   every lane leaves al = tau0 v0, be = tau1 v1, v1 and w of its tile in LDS (4 r doubles), and the workgroup then produces the
-//         256 r^2 entries of Q in OUTPUT order: entry e belongs to tile e / r^2, row (e % r^2) / r, column e % r.
+//   out   every lane leaves v0, v1, tau0, tau1 and tau1 (v0 . v1) of its tile in LDS (2 r + 3 doubles: 43 KB per workgroup at 9 rows, three
+//         workgroups per CU; with al = tau0 v0, be = tau1 v1, v1, w precomputed -- 4 r doubles, 76 KB -- the 9 x 2 batch ran 8 % slower), and
+//         the workgroup then produces the 256 r^2 entries of Q in OUTPUT order: entry e belongs to tile e / r^2, row (e % r^2) / r, column e % r.
 template <bool PIVOT, bool HC>
 __global__ void __launch_bounds__(256)
 bdqr_thin_kernel(int64_t num_tiles, int r, int c, const double* __restrict__ tiles, double* __restrict__ q_vals, double* __restrict__ r_vals,
@@ -42,7 +43,7 @@ bdqr_thin_kernel(int64_t num_tiles, int r, int c, const double* __restrict__ til
     const int tid = threadIdx.x;
     const int rc = r * c, rr = r * r;
     const int sin = rc | 1;              // LDS stride of a tile's input (odd)
-    const int sout = (4 * r) | 1;        // LDS stride of a tile's reflector data (odd)
+    const int sout = (2 * r + 3) | 1;    // LDS stride of a tile's reflector data (odd): v0, v1, tau0, tau1, tau1 (v0 . v1)
     const float inv_rr = 1.0f / (float)rr, inv_r = 1.0f / (float)r;
     for (int64_t t0 = (int64_t)blockIdx.x * 256; t0 < num_tiles; t0 += (int64_t)gridDim.x * 256) {
         const int nt = (int)(num_tiles - t0 < 256 ? num_tiles - t0 : 256);
@@ -141,12 +142,12 @@ bdqr_thin_kernel(int64_t num_tiles, int r, int c, const double* __restrict__ til
             perm[cbase] = cbase + P;
             if (c > 1) perm[cbase + 1] = cbase + 1 - P;
             if (HC && hcoeffs) { hcoeffs[cbase] = tau0; if (c > 1) hcoeffs[cbase + 1] = tau1; }
-            // ---- al = tau0 v0, be = tau1 v1, v1, w = v0 - tau1 (v0 . v1) v1 of this tile
-            const double ts = tau1 * s01;
+            // ---- the two reflectors and their scalars of this tile
             double* o = thin_lds + tid * sout;
 #pragma unroll
             for (int i = 0; i < RM; ++i)
-                if (i < r) { o[i] = tau0 * a0[i]; o[r + i] = tau1 * a1[i]; o[2 * r + i] = a1[i]; o[3 * r + i] = fma(-ts, a1[i], a0[i]); }
+                if (i < r) { o[i] = a0[i]; o[r + i] = a1[i]; }
+            o[2 * r] = tau0; o[2 * r + 1] = tau1; o[2 * r + 2] = tau1 * s01;
         }
         __syncthreads();
         // ---- Q in output order: Q(j,k) = delta_jk - be(j) v1(k) - al(j) w(k)
@@ -159,7 +160,9 @@ bdqr_thin_kernel(int64_t num_tiles, int r, int c, const double* __restrict__ til
                 const int j = (int)(((float)rem + 0.5f) * inv_r);
                 const int k = rem - j * r;
                 const double* o = thin_lds + tl * sout;
-                dst[e] = fma(-o[r + j], o[2 * r + k], fma(-o[j], o[3 * r + k], j == k ? 1.0 : 0.0));
+                const double v1k = o[r + k];
+                const double wk = fma(-o[2 * r + 2], v1k, o[k]);                    // w(k) = v0(k) - tau1 (v0 . v1) v1(k)
+                dst[e] = fma(-(o[2 * r + 1] * o[r + j]), v1k, fma(-(o[2 * r] * o[j]), wk, j == k ? 1.0 : 0.0));
             }
         }
         __syncthreads();
@@ -175,8 +178,8 @@ void launch_bdqr_thin(int64_t num_tiles, int r, int c, int pivoting, const doubl
     int64_t nwg = (num_tiles + 255) / 256;
     if (max_blocks > 0 && nwg > max_blocks) nwg = max_blocks;
     const dim3 grid((unsigned)nwg), block(256);
-    const int sin = (r * c) | 1, sout = (4 * r) | 1;
-    const size_t smem = (size_t)256 * (sin > sout ? sin : sout) * sizeof(double);      // <= 256 x 65 x 8 = 130 KB at 16 rows; 37 KB at 9 x 2
+    const int sin = (r * c) | 1, sout = (2 * r + 3) | 1;
+    const size_t smem = (size_t)256 * (sin > sout ? sin : sout) * sizeof(double);      // 43 KB at 9 x 2; <= 256 x 35 x 8 = 72 KB at 16 rows
     if (smem > 64 * 1024) {
         static hipError_t attr = [] {
             hipError_t e = hipSuccess;
