@@ -31,6 +31,12 @@
 #include <float.h>
 #include <cstdlib>
 
+#ifndef QRK_COL_UF
+#define QRK_COL_UF 16          // loads in flight per thread in the read-only pass of the panel-blocked phase 1
+#endif
+#ifndef QRK_COL_UT
+#define QRK_COL_UT 8           // ... in the trailing update of a panel
+#endif
 #ifndef QRK_COL_BLOCKED
 #define QRK_COL_BLOCKED 1      // tiles in global memory: panel-blocked phase 1 (0 = fused level-2 sweeps)
 #endif
@@ -39,7 +45,6 @@ namespace qrk {
 
 namespace col {
 
-constexpr double SQRT_EPS = 1.4901161193847656e-08;   // sqrt(DBL_EPSILON), Eigen's norm_downdate_threshold
 using namespace decide;   // decision margins of the fast kernels (qrk_device.h)
 constexpr int W_LDS_DOUBLES = 4352;                   // 34 KB of LDS for A when the tile fits (two workgroups of the fixed layout per CU)
 constexpr int NB = 16;                                // reflectors per block in the formation of Q
@@ -143,6 +148,12 @@ __device__ __forceinline__ void factor_tile(double* __restrict__ W, double* smem
         // date on demand from V (LDS) and F (registers); the trailing matrix is updated once per panel,
         // A -= V F^T.  Half the bytes of the fused level-2 sweeps, and mostly reads.
         constexpr int NBP = NB;
+#ifdef QRK_COL_PROF
+        unsigned long long pt[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, pt0 = __builtin_amdgcn_s_memtime();
+#define COL_TICK(z) do { const unsigned long long t1 = __builtin_amdgcn_s_memtime(); pt[z] += t1 - pt0; pt0 = t1; } while (0)
+#else
+#define COL_TICK(z) do { } while (0)
+#endif
         double* vp = vs;                      // [rows k0.. x NBP] V of the current panel, row-major
         double* xv = xv0;                     // [r] x, then v, of the current reflector
         double* fP = gm;                      // [NBP] F row of the pivot column
@@ -169,6 +180,7 @@ __device__ __forceinline__ void factor_tile(double* __restrict__ W, double* smem
                     if (live && tid != P && near_best(nu2, thr, bb.val, a2)) unclear = true;
                     if (isA) { if (tid == P) pos = k; else if (pos == k) pos = ppos; }
                 }
+                COL_TICK(0);
                 if (tid == P) {
                     live = false; col_of_pos[k] = tid;
 #pragma unroll
@@ -187,6 +199,7 @@ __device__ __forceinline__ void factor_tile(double* __restrict__ W, double* smem
                 part = wave_sum_d(part);
                 if (lane == 0) red[wave] = part;
                 __syncthreads();
+                COL_TICK(1);
                 double tsq = 0.0;
 #pragma unroll
                 for (int w = 0; w < NW; ++w) tsq += red[w];
@@ -210,6 +223,7 @@ __device__ __forceinline__ void factor_tile(double* __restrict__ W, double* smem
                 }
                 if (tid == 0) { taus[k] = tau; if (hcoeffs) hcoeffs[cbase + k] = tau; }
                 __syncthreads();
+                COL_TICK(2);
                 // c_l = V(:, l)^T v for the earlier reflectors of the panel (one wave per l)
                 for (int l = wave; l < j; l += NW) {
                     double cp = 0.0;
@@ -218,24 +232,29 @@ __device__ __forceinline__ void factor_tile(double* __restrict__ W, double* smem
                     if (lane == 0) cvec[l] = cp;
                 }
                 __syncthreads();
+                COL_TICK(3);
                 if (live) {
                     // F(t, j) = tau (A(k:, t)^T v - F(t, 0:j) c): read-only pass over this thread's column
                     double f = 0.0;
                     {
-                        constexpr int U = 16;
-                        int i = k;
-                        for (; i + U <= r; i += U) {
+                        // (U loads in flight, no scalar tail: rows past the end are clamped and meet a zero of v, so the sum
+                        //  is the same sequence of FMAs - the pass is bound by the round trips to L2 / Infinity Cache)
+                        constexpr int U = QRK_COL_UF;
+                        for (int i = k; i < r; i += U) {
                             double wv[U];
 #pragma unroll
-                            for (int u = 0; u < U; ++u) wv[u] = wc[(int64_t)(i + u) * ld];
+                            for (int u = 0; u < U; ++u) { int ii = i + u; ii = ii < r ? ii : r - 1; wv[u] = wc[(int64_t)ii * ld]; }
 #pragma unroll
-                            for (int u = 0; u < U; ++u) f = fma(wv[u], xv[i + u], f);
+                            for (int u = 0; u < U; ++u) { const int ii = i + u; f = fma(wv[u], ii < r ? xv[ii < r ? ii : r - 1] : 0.0, f); }
                         }
-                        for (; i < r; ++i) f = fma(wc[(int64_t)i * ld], xv[i], f);
                     }
 #pragma unroll
                     for (int l = 0; l < NBP; ++l) if (l < j) f = fma(-F[l], cvec[l], f);
                     f *= tau;
+#ifdef QRK_COL_PROF
+                    if (f == 1.2345e300) pt[9]++;      // (the loads have to land before the tick)
+                    COL_TICK(4);
+#endif
 #pragma unroll
                     for (int l = 0; l < NBP; ++l) if (l == j) F[l] = f;
                     // row k of R: A(k, t) - V(k, 0:j+1) F(t, 0:j+1)^T
@@ -261,30 +280,31 @@ __device__ __forceinline__ void factor_tile(double* __restrict__ W, double* smem
                     }
                 }
             }
+            COL_TICK(5);
             // trailing update of the live columns: A(k0+kb:, t) -= V(k0+kb:, :) F(t, :)^T
             if (live) {
-                constexpr int U = 8;
-                int i = k0 + kb;
-                for (; i + U <= r; i += U) {
+                constexpr int U = QRK_COL_UT;
+                for (int i = k0 + kb; i < r; i += U) {
                     double wv[U];
 #pragma unroll
-                    for (int u = 0; u < U; ++u) wv[u] = wc[(int64_t)(i + u) * ld];
+                    for (int u = 0; u < U; ++u) { int ii = i + u; ii = ii < r ? ii : r - 1; wv[u] = wc[(int64_t)ii * ld]; }
 #pragma unroll
                     for (int u = 0; u < U; ++u) {
+                        int ii = i + u; const bool in = ii < r; ii = in ? ii : r - 1;
 #pragma unroll
-                        for (int l = 0; l < NBP; ++l) wv[u] = fma(-vp[(i + u - k0) * NBP + l], F[l], wv[u]);
-                        wc[(int64_t)(i + u) * ld] = wv[u];
+                        for (int l = 0; l < NBP; ++l) wv[u] = fma(-vp[(ii - k0) * NBP + l], F[l], wv[u]);
+                        if (in) wc[(int64_t)ii * ld] = wv[u];
                     }
-                }
-                for (; i < r; ++i) {
-                    double a = wc[(int64_t)i * ld];
-#pragma unroll
-                    for (int l = 0; l < NBP; ++l) a = fma(-vp[(i - k0) * NBP + l], F[l], a);
-                    wc[(int64_t)i * ld] = a;
                 }
             }
             __syncthreads();
+            COL_TICK(6);
         }
+#ifdef QRK_COL_PROF
+        if (blockIdx.x == 0 && (tid == 0 || tid == c - 1 || tid == c / 2))
+            printf("col prof (last column's thread, 100 MHz ticks): pivot %llu  x %llu  v %llu  VtV %llu  Fpass %llu  downdate %llu  trailing %llu\n",
+                   pt[0], pt[1], pt[2], pt[3], pt[4], pt[5], pt[6]);
+#endif
         } else {
         // ---- head of step 0: pivot, its column to LDS, dot products
         int P;                               // pivot thread of the current step
