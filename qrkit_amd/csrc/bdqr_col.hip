@@ -619,10 +619,13 @@ __global__ void __launch_bounds__(CT) __attribute__((amdgpu_waves_per_eu(BIG ? 2
 bdqr_col_kernel(WaveBatch nb, const double* __restrict__ tiles, double* __restrict__ q_vals,
                 double* __restrict__ r_vals, int32_t* __restrict__ perm, double* __restrict__ hcoeffs,
                 double* __restrict__ workspace, int64_t ws_stride, int w_lds, int max_r,
-                int32_t* __restrict__ redo_count, int32_t* __restrict__ redo_ids)
+                int32_t* __restrict__ redo_count, int32_t* __restrict__ redo_ids, int32_t* __restrict__ queue)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    for (int64_t t = blockIdx.x; t < nb.num_tiles; t += gridDim.x) {
+    // Tiles are handed out through a counter (zeroed by the launcher): with the list sorted largest first that is the
+    // longest-processing-time rule.  (A grid-stride assignment gave workgroup 0 the largest tile of every round.)
+    __shared__ int next_tile;
+    for (int64_t t = blockIdx.x; t < nb.num_tiles;) {
         const int gidx = nb.tile_ids ? nb.tile_ids[t] : (int)t;
         int r, c, cbase;
         int64_t toff, qoff, roff;
@@ -642,6 +645,10 @@ bdqr_col_kernel(WaveBatch nb, const double* __restrict__ tiles, double* __restri
             factor_tile<CT, QRK_COL_BLOCKED != 0, DYN>(workspace + (int64_t)blockIdx.x * ws_stride, smem, r, c, cbase, nb.pivoting,
                                                        tiles + toff, q_vals + qoff, r_vals + roff, perm, hcoeffs, w_lds, max_r,
                                                        redo_count, redo_ids, gidx);
+        __syncthreads();
+        if (threadIdx.x == 0) next_tile = (int)gridDim.x + atomicAdd(queue, 1);
+        __syncthreads();
+        t = next_tile;
     }
 }
 
@@ -689,9 +696,10 @@ int bdqr_col_wgs_per_cu(int max_cols, int w_lds, int max_r)
 
 hipError_t launch_bdqr_col(const WaveBatch& nb, const double* tiles, double* q_vals, double* r_vals, int32_t* perm,
                            double* hcoeffs, double* workspace, int64_t ws_stride, int num_wg, int max_rows,
-                           int max_cols, int w_lds, int32_t* redo_count, int32_t* redo_ids, hipStream_t stream)
+                           int max_cols, int w_lds, int32_t* redo_count, int32_t* redo_ids, int32_t* queue, hipStream_t stream)
 {
     if (nb.num_tiles <= 0) return hipSuccess;
+    if (hipError_t e = hipMemsetAsync(queue, 0, sizeof(int32_t), stream)) return e;
     if (max_rows > col::MAXR || max_cols > max_rows || w_lds > col::W_LDS_DOUBLES) return hipErrorInvalidValue;
     const int64_t want = nb.num_tiles < (int64_t)num_wg ? nb.num_tiles : (int64_t)num_wg;
     const int threads = bdqr_col_threads(max_cols, max_rows);
@@ -702,7 +710,7 @@ hipError_t launch_bdqr_col(const WaveBatch& nb, const double* tiles, double* q_v
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);          \
         if (e != hipSuccess) return e;                                                                      \
         hipLaunchKernelGGL((bdqr_col_kernel<T, G>), dim3((unsigned)want), dim3(T), smem, stream, nb, tiles, q_vals, \
-                           r_vals, perm, hcoeffs, workspace, ws_stride, w_lds, max_rows, redo_count, redo_ids); \
+                           r_vals, perm, hcoeffs, workspace, ws_stride, w_lds, max_rows, redo_count, redo_ids, queue); \
     } while (0)
     if (bdqr_col_big(max_rows)) QRK_COL_LAUNCH(256, true);      // (more than 160 rows >= cols: 256 threads unless the tiles are narrow)
     else if (threads == 64) QRK_COL_LAUNCH(64, false);

@@ -25,7 +25,6 @@ namespace qrk {
 
 constexpr int WG_THREADS = 256;
 constexpr int WG_WAVES = WG_THREADS / 64;
-constexpr double WG_SQRT_EPS = 1.4901161193847656e-08;
 
 __device__ __forceinline__ double wave_sum(double v)
 {

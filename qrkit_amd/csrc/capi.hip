@@ -231,7 +231,7 @@ qrk_status enqueue_factorize(qrk_bd_plan_s* p, const double* tiles, double* q, d
         if (p->max_dim > 32 && p->max_dim <= QRK_COL_MAX_DIM) {
             const auto& k = p->col_cls[0];
             QRK_HIP(h, qrk::launch_bdqr_col(nb, tiles, q, r, perm, hc, p->d_col_workspace, k.ws_stride, k.num_wg, k.max_rows,
-                                            k.max_cols, k.w_lds, redo_cnt, redo_ids, h->stream));
+                                            k.max_cols, k.w_lds, redo_cnt, redo_ids, p->d_redo + 2 + p->B, h->stream));
         } else if (p->max_dim > 32)
             qrk::launch_bdqr_wg(nb, tiles, q, r, perm, hc, p->d_workspace, p->ws_stride, p->num_wg, p->max_dim, redo_cnt, redo_ids, h->stream);
         else if (p->max_dim <= 16 && p->r >= p->c && p->c <= 2 && h->use_small_kernel && h->use_thin_kernel)   // a tile per lane (bdqr_thin.hip)
@@ -250,8 +250,13 @@ qrk_status enqueue_factorize(qrk_bd_plan_s* p, const double* tiles, double* q, d
         if (p->n_col > 0) {
             if (!h->ev_fork) {
                 QRK_HIP(h, hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+                int prio_least = 0, prio_greatest = 0;
+                QRK_HIP(h, hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
+                const bool use_prio = !(std::getenv("QRK_COL_PRIO") && std::atoi(std::getenv("QRK_COL_PRIO")) == 0);
                 for (int z = 0; z < 3; ++z) {
-                    QRK_HIP(h, hipStreamCreateWithFlags(&h->side[z], hipStreamNonBlocking));
+                    // (the class of the largest tiles first in line for the CUs: its tiles are the critical path of a mixed batch)
+                    const int prio = !use_prio ? prio_least : (z == 2 ? prio_greatest : (z == 1 ? (prio_least + prio_greatest) / 2 : prio_least));
+                    QRK_HIP(h, hipStreamCreateWithPriority(&h->side[z], hipStreamNonBlocking, prio));
                     QRK_HIP(h, hipEventCreateWithFlags(&h->ev_join[z], hipEventDisableTiming));
                 }
             }
@@ -263,7 +268,7 @@ qrk_status enqueue_factorize(qrk_bd_plan_s* p, const double* tiles, double* q, d
                 cb.num_tiles = k.n; cb.tile_ids = p->d_col_ids + k.off;
                 QRK_HIP(h, hipStreamWaitEvent(h->side[z], h->ev_fork, 0));
                 QRK_HIP(h, qrk::launch_bdqr_col(cb, tiles, q, r, perm, hc, p->d_col_workspace + k.ws_off, k.ws_stride, k.num_wg,
-                                                k.max_rows, k.max_cols, k.w_lds, redo_cnt, redo_ids, h->side[z]));
+                                                k.max_rows, k.max_cols, k.w_lds, redo_cnt, redo_ids, p->d_redo + 2 + p->B + z, h->side[z]));
                 QRK_HIP(h, hipEventRecord(h->ev_join[z], h->side[z]));
                 QRK_HIP(h, hipStreamWaitEvent(h->stream, h->ev_join[z], 0));
             }
@@ -544,7 +549,7 @@ qrk_status qrk_bd_plan_create(qrk_handle h, const qrk_bd_layout* L, qrk_q_format
             wgs = std::max<int64_t>(1, std::min(wgs, cap));
         }
         p->exact_num_wg = (int)std::min<int64_t>(wgs, B);
-        if (hipMalloc((void**)&p->d_redo, (size_t)(B + 2) * sizeof(int32_t)) != hipSuccess ||
+        if (hipMalloc((void**)&p->d_redo, (size_t)(B + 2 + 3) * sizeof(int32_t)) != hipSuccess ||
             hipMemsetAsync(p->d_redo, 0, 2 * sizeof(int32_t), h->stream) != hipSuccess ||
             (p->exact_ws_stride > 0 &&
              hipMalloc((void**)&p->d_exact_ws, (size_t)p->exact_num_wg * (size_t)p->exact_ws_stride * sizeof(double)) != hipSuccess)) {

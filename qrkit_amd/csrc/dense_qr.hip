@@ -18,7 +18,6 @@ namespace qrk {
 
 constexpr int DQ_THREADS = 1024;
 constexpr int DQ_WAVES = DQ_THREADS / 64;
-constexpr double DQ_SQRT_EPS = 1.4901161193847656e-08;
 
 __device__ __forceinline__ double dq_wave_sum(double v)
 {
