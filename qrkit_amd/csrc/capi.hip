@@ -238,7 +238,11 @@ qrk_status enqueue_factorize(qrk_bd_plan_s* p, const double* tiles, double* q, d
             qrk::launch_bdqr_thin(p->B, p->r, p->c, nb.pivoting, tiles, q, r, perm, hc, h->num_cus * 32, redo_cnt, redo_ids, h->stream);
         else if (p->max_dim <= 16 && p->r >= p->c && h->use_small_kernel)   // 64/G tiles per wavefront (bdqr_small.hip)
             qrk::launch_bdqr_small(p->B, p->r, p->c, nb.pivoting, tiles, q, r, perm, hc, h->num_cus * 32, redo_cnt, redo_ids, h->stream);
-        else qrk::launch_bdqr_pair(nb, full32, tiles, q, r, perm, hc, h->num_cus * h->pair_wgs_per_cu, redo_cnt, redo_ids, h->stream);
+        else {
+            int wgs = h->num_cus * h->pair_wgs_per_cu;
+            if (const char* e = std::getenv("QRK_PAIR_WGS")) { const int v = std::atoi(e); if (v > 0) wgs = v; }   // (experiments)
+            qrk::launch_bdqr_pair(nb, full32, tiles, q, r, perm, hc, wgs, redo_cnt, redo_ids, h->stream);
+        }
     } else {
         nb.num_tiles = p->n_wave; nb.tile_ids = p->d_wave_ids;
         nb.t_rows = p->d_rows; nb.t_cols = p->d_cols; nb.t_off = p->d_toff;
