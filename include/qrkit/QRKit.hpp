@@ -914,14 +914,11 @@ class BlockAngularSparseQR {
     // sparse right block (BlockMatrix1x2<JacobianType, JacobianType>, test/test-qrkit.cpp:335): the right solver
     // works on dense columns either way (BlockedThinSparseQR.h:131: m_R = mat)
     template <typename LeftMat, bool RM>
-    void compute(const BlockMatrix1x2<LeftMat, SparseMatrix<RM> >& mat) {
-        const Matrix right = mat.rightBlock().toDense();
-        compute(BlockMatrix1x2<LeftMat, Matrix>(mat.leftBlock(), right));
-    }
+    void compute(const BlockMatrix1x2<LeftMat, SparseMatrix<RM> >& mat) { analyzePattern(mat); factorize(mat); }
 
     // :431-449
-    template <typename LeftMat>
-    void analyzePattern(const BlockMatrix1x2<LeftMat, Matrix>& mat) {
+    template <typename LeftMat, typename RightMat>
+    void analyzePattern(const BlockMatrix1x2<LeftMat, RightMat>& mat) {
         assert(mat.leftBlock().cols() > mat.rightBlock().cols() && "the left block should be the bigger one");
         m_rows = mat.rows(); m_cols = mat.cols();
         m_rowPerm.setIdentity(m_rows);
@@ -932,52 +929,55 @@ class BlockAngularSparseQR {
     template <typename LeftMat>
     void factorize(const BlockMatrix1x2<LeftMat, Matrix>& mat) {
         const Matrix& J2in = mat.rightBlock();
-        m_m1 = mat.leftBlock().cols(); m_n1 = mat.leftBlock().rows(); m_m2 = J2in.cols();
-        m_isInitialized = false; m_Rbuilt = false;
-        // J1 = Q1 R1 (:472-475)
-        m_leftSolver.compute(mat.leftBlock());
-        m_info = m_leftSolver.info();
-        if (m_info != Success) return;
         const int64_t D = (int64_t)sizeof(double);
-        const Index rb = m_rows - m_m1;
-        // solveRightBlock (:361-369): J2.top(n1) <- Q1^T (rowPerm1 * J2.top(n1)); the rows below stay
-        const std::vector<int>& rp = m_leftSolver.rowsPermutation().indices();
-        bool identity = true;
-        for (Index r = 0; r < m_n1 && identity; ++r) identity = rp[(size_t)r] == (int)r;
-        for (Index r = 0; r < m_n1; ++r) m_rowPerm.indices()[(size_t)r] = rp[(size_t)r];
-        void* dBottom = 0;
-        {
-            DBuf dTop(*this, m_n1 * m_m2), dT(*this, m_n1 * m_m2);
-            if (identity) {
-                check(qrk_memcpy_2d(m_handle, dTop.p, m_n1 * D, J2in.data(), m_rows * D, m_n1 * D, m_m2, 0));
-            } else {
-                Vector top((size_t)(m_n1 * m_m2));
-                for (Index c = 0; c < m_m2; ++c)
-                    for (Index r = 0; r < m_n1; ++r) top[(size_t)(c * m_n1 + rp[(size_t)r])] = J2in(r, c);
-                check(qrk_memcpy(m_handle, dTop.p, top.data(), m_n1 * m_m2 * D, 0));
+        factorizeWith(mat.leftBlock(), J2in.cols(),
+            [&](double* dTop, const std::vector<int>& rp, bool identity) {           // rows [0, n1) of J2, row r -> rp[r]
+                if (identity) {
+                    check(qrk_memcpy_2d(m_handle, dTop, m_n1 * D, J2in.data(), m_rows * D, m_n1 * D, m_m2, 0));
+                } else {
+                    Vector top((size_t)(m_n1 * m_m2));
+                    for (Index c = 0; c < m_m2; ++c)
+                        for (Index r = 0; r < m_n1; ++r) top[(size_t)(c * m_n1 + rp[(size_t)r])] = J2in(r, c);
+                    check(qrk_memcpy(m_handle, dTop, top.data(), m_n1 * m_m2 * D, 0));
+                }
+            },
+            [&](double* dst, int64_t ld) {                                            // rows [n1, rows) of J2
+                return qrk_memcpy_2d(m_handle, dst, ld * D, J2in.data() + m_n1, m_rows * D, (m_rows - m_n1) * D, m_m2, 0);
+            });
+    }
+    // sparse right block (BlockMatrix1x2<JacobianType, JacobianType>, test/test-qrkit.cpp:335): its nonzeros cross PCIe and the
+    // dense copy the right solver works on (BlockedThinSparseQR.h:131: m_R = mat) is written on the device
+    template <typename LeftMat, bool RM>
+    void factorize(const BlockMatrix1x2<LeftMat, SparseMatrix<RM> >& mat) {
+        const SparseMatrix<RM>& J2in = mat.rightBlock();
+        const int64_t nnz = J2in.nonZeros(), no = J2in.outerSize();
+        void *dOuter = 0, *dInner = 0, *dVal = 0, *dMap = 0;
+        auto release = [&]() { qrk_device_free(m_handle, dOuter); qrk_device_free(m_handle, dInner); qrk_device_free(m_handle, dVal); qrk_device_free(m_handle, dMap); };
+        try {
+            check(qrk_device_alloc(m_handle, (no + 1) * 4, &dOuter));
+            check(qrk_device_alloc(m_handle, std::max<int64_t>(nnz, 1) * 4, &dInner));
+            check(qrk_device_alloc(m_handle, std::max<int64_t>(nnz, 1) * 8, &dVal));
+            check(qrk_memcpy(m_handle, dOuter, J2in.outerIndex().data(), (no + 1) * 4, 0));
+            if (nnz > 0) {
+                check(qrk_memcpy(m_handle, dInner, J2in.innerIndex().data(), nnz * 4, 0));
+                check(qrk_memcpy(m_handle, dVal, J2in.values().data(), nnz * 8, 0));
             }
-            m_leftSolver.applyQDevice(dTop.ptr(), m_m2, dT.ptr(), true);
-            // rightSolver.compute(J2.bottomRows(rows - m1)): rows m1..n1 of Q1^T J2, then the rows of J2 below J1
-            check(qrk_device_alloc(m_handle, std::max<int64_t>(rb * m_m2 * D, 8), &dBottom));
-            qrk_status st = qrk_memcpy_2d(m_handle, dBottom, rb * D, dT.ptr() + m_m1, m_n1 * D, (m_n1 - m_m1) * D, m_m2, 2);
-            if (st == QRK_STATUS_OK && m_rows > m_n1)
-                st = qrk_memcpy_2d(m_handle, (double*)dBottom + (m_n1 - m_m1), rb * D, J2in.data() + m_n1, m_rows * D, (m_rows - m_n1) * D, m_m2, 0);
-            // the strip of R: S = (Q1^T J2)(0:m1, :)
-            if (m_dS) { qrk_device_free(m_handle, m_dS); m_dS = 0; }
-            if (st == QRK_STATUS_OK) st = qrk_device_alloc(m_handle, std::max<int64_t>(m_m1 * m_m2 * D, 8), &m_dS);
-            if (st == QRK_STATUS_OK) st = qrk_memcpy_2d(m_handle, m_dS, m_m1 * D, dT.ptr(), m_n1 * D, m_m1 * D, m_m2, 2);
-            if (st != QRK_STATUS_OK) { qrk_device_free(m_handle, dBottom); check(st); }
-        }
-        m_k2 = std::min(rb, m_m2);
-        std::vector<int32_t> p2;
-        m_dense.factorizeDevice(m_handle, dBottom, rb, m_m2, RightSolverTag::kSolver, m_hc, p2);   // (takes the buffer over)
-        // column permutation (:498-503) and rank (:510)
-        m_outputPerm_c.setIdentity(m_cols);
-        for (Index j = 0; j < m_m1; ++j) m_outputPerm_c.indices()[(size_t)j] = m_leftSolver.colsPermutation().indices()[(size_t)j];
-        for (Index j = 0; j < m_m2; ++j) m_outputPerm_c.indices()[(size_t)(m_m1 + j)] = (int)(m_m1 + p2[(size_t)j]);
-        m_P2.assign(p2.begin(), p2.begin() + m_m2);
-        m_nonzeropivots = m_leftSolver.rank() + m_k2;
-        m_isInitialized = true;
+            factorizeWith(mat.leftBlock(), J2in.cols(),
+                [&](double* dTop, const std::vector<int>& rp, bool identity) {
+                    if (!identity) {
+                        check(qrk_device_alloc(m_handle, std::max<int64_t>(m_n1, 1) * 4, &dMap));
+                        check(qrk_memcpy(m_handle, dMap, rp.data(), m_n1 * 4, 0));
+                    }
+                    check(qrk_sparse_window_to_dense(m_handle, RM ? 1 : 0, m_rows, m_m2, (const int32_t*)dOuter, (const int32_t*)dInner,
+                                                     (const double*)dVal, 0, m_n1, (const int32_t*)dMap, dTop, m_n1));
+                },
+                [&](double* dst, int64_t ld) {
+                    return qrk_sparse_window_to_dense(m_handle, RM ? 1 : 0, m_rows, m_m2, (const int32_t*)dOuter, (const int32_t*)dInner,
+                                                      (const double*)dVal, m_n1, m_rows - m_n1, 0, dst, ld);
+                });
+            check(qrk_synchronize(m_handle));
+        } catch (...) { release(); throw; }
+        release();
     }
 
     Index rows() const { return m_rows; }
@@ -1016,6 +1016,49 @@ class BlockAngularSparseQR {
     }
 
   protected:
+    // the factorisation proper: `top(dTop, rp, identity)` puts rows [0, n1) of J2 on the device (n1 x m2, column-major, source row
+    // r at row rp[r]), `bottom(dst, ld)` rows [n1, rows) at dst with leading dimension ld
+    template <typename LeftMat, typename TopFn, typename BottomFn>
+    void factorizeWith(const LeftMat& left, Index m2, TopFn top, BottomFn bottom) {
+        m_m1 = left.cols(); m_n1 = left.rows(); m_m2 = m2;
+        m_isInitialized = false; m_Rbuilt = false;
+        // J1 = Q1 R1 (:472-475)
+        m_leftSolver.compute(left);
+        m_info = m_leftSolver.info();
+        if (m_info != Success) return;
+        const int64_t D = (int64_t)sizeof(double);
+        const Index rb = m_rows - m_m1;
+        // solveRightBlock (:361-369): J2.top(n1) <- Q1^T (rowPerm1 * J2.top(n1)); the rows below stay
+        const std::vector<int>& rp = m_leftSolver.rowsPermutation().indices();
+        bool identity = true;
+        for (Index r = 0; r < m_n1 && identity; ++r) identity = rp[(size_t)r] == (int)r;
+        for (Index r = 0; r < m_n1; ++r) m_rowPerm.indices()[(size_t)r] = rp[(size_t)r];
+        void* dBottom = 0;
+        {
+            DBuf dTop(*this, m_n1 * m_m2), dT(*this, m_n1 * m_m2);
+            top(dTop.ptr(), rp, identity);
+            m_leftSolver.applyQDevice(dTop.ptr(), m_m2, dT.ptr(), true);
+            // rightSolver.compute(J2.bottomRows(rows - m1)): rows m1..n1 of Q1^T J2, then the rows of J2 below J1
+            check(qrk_device_alloc(m_handle, std::max<int64_t>(rb * m_m2 * D, 8), &dBottom));
+            qrk_status st = qrk_memcpy_2d(m_handle, dBottom, rb * D, dT.ptr() + m_m1, m_n1 * D, (m_n1 - m_m1) * D, m_m2, 2);
+            if (st == QRK_STATUS_OK && m_rows > m_n1) st = bottom((double*)dBottom + (m_n1 - m_m1), rb);
+            // the strip of R: S = (Q1^T J2)(0:m1, :)
+            if (m_dS) { qrk_device_free(m_handle, m_dS); m_dS = 0; }
+            if (st == QRK_STATUS_OK) st = qrk_device_alloc(m_handle, std::max<int64_t>(m_m1 * m_m2 * D, 8), &m_dS);
+            if (st == QRK_STATUS_OK) st = qrk_memcpy_2d(m_handle, m_dS, m_m1 * D, dT.ptr(), m_n1 * D, m_m1 * D, m_m2, 2);
+            if (st != QRK_STATUS_OK) { qrk_device_free(m_handle, dBottom); check(st); }
+        }
+        m_k2 = std::min(rb, m_m2);
+        std::vector<int32_t> p2;
+        m_dense.factorizeDevice(m_handle, dBottom, rb, m_m2, RightSolverTag::kSolver, m_hc, p2);   // (takes the buffer over)
+        // column permutation (:498-503) and rank (:510)
+        m_outputPerm_c.setIdentity(m_cols);
+        for (Index j = 0; j < m_m1; ++j) m_outputPerm_c.indices()[(size_t)j] = m_leftSolver.colsPermutation().indices()[(size_t)j];
+        for (Index j = 0; j < m_m2; ++j) m_outputPerm_c.indices()[(size_t)(m_m1 + j)] = (int)(m_m1 + p2[(size_t)j]);
+        m_P2.assign(p2.begin(), p2.begin() + m_m2);
+        m_nonzeropivots = m_leftSolver.rank() + m_k2;
+        m_isInitialized = true;
+    }
     // scoped device buffer of doubles on this solver's handle
     struct DBuf {
         const BlockAngularSparseQR& s; void* p;

@@ -101,6 +101,16 @@ qrk_status qrk_memcpy(qrk_handle h, void* dst, const void* src, int64_t bytes, i
 qrk_status qrk_memcpy_2d(qrk_handle h, void* dst, int64_t dst_pitch, const void* src, int64_t src_pitch, int64_t width_bytes,
                          int64_t height, int direction);
 
+/* Dense column-major copy of the row window [row0, row0 + nrows) of a compressed sparse matrix whose arrays are on the device
+ * (CSR when row_major != 0, else CSC; Eigen's outerIndexPtr / innerIndexPtr / valuePtr of a compressed matrix):
+ * d_out[c * ld + (d_row_map ? d_row_map[r - row0] : r - row0)] = value of entry (r, c); every other element of the nrows x cols
+ * window is zero.  d_row_map (device, nrows entries, a permutation of 0..nrows-1) or NULL.  Replaces the dense copy the
+ * reference makes of a sparse right block - BlockedThinSparseQR::compute, BlockedThinSparseQR.h:131 "m_R = mat", reached from
+ * BlockAngularSparseQR::solveRightBlock (BlockAngularSparseQR.h:361-369) - so that a sparse J2 crosses PCIe as its nonzeros. */
+qrk_status qrk_sparse_window_to_dense(qrk_handle h, int row_major, int64_t rows, int64_t cols, const int32_t* d_outer,
+                                      const int32_t* d_inner, const double* d_values, int64_t row0, int64_t nrows,
+                                      const int32_t* d_row_map, double* d_out, int64_t ld);
+
 /* -------------------------------------------- block-diagonal: analyzePattern */
 
 /* The block structure of a QRKit::SparseBlockDiagonal (SparseBlockDiagonal.h:43-163):
@@ -223,7 +233,8 @@ qrk_status qrk_dense_plan_destroy(qrk_dense_plan plan);
  * upper triangle of `a` holds R as always, but what lies below are the reflectors of Q0, not Eigen's essential vectors, and
  * hcoeffs are those of Q1: use qrk_dense_apply_q / qrk_dense_solve_r with the same plan (the factors of Q1 stay in the plan),
  * do not interpret the lower part yourself.  A pivot decision inside its rounding margin still sends the whole matrix through
- * the exact path, which leaves Eigen's format. */
+ * the exact path, which leaves Eigen's format; decisions that only fix the sign of a row of R (leading entry of a reflector at the
+ * noise level, zero tail) do not, since that sign is open in this form anyway. */
 qrk_status qrk_dense_factorize(qrk_dense_plan plan, double* a, int64_t lda, double* hcoeffs, int32_t* perm,
                                qrk_memspace space);
 

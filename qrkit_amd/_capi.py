@@ -27,6 +27,7 @@ EXPORTS = (
     "qrk_dense_plan_destroy", "qrk_dense_factorize", "qrk_dense_apply_q", "qrk_bb_plan_create", "qrk_bb_plan_destroy", "qrk_bb_plan_create_fixed", "qrk_bb_blocks_from_pattern", "qrk_bb_analyze_host",
     "qrk_bb_plan_info", "qrk_bb_plan_blocks", "qrk_bb_pattern", "qrk_bb_factorize", "qrk_bb_apply_q", "qrk_bb_solve_r", "qrk_dense_solve_r", "qrk_bd_time_factorize", "qrk_bd_kernel_name",
     "qrk_memcpy_2d", "qrk_dense_gemv_sub", "qrk_tsqr_plan_create", "qrk_tsqr_plan_destroy", "qrk_tsqr_factorize", "qrk_tsqr_apply_q",
+    "qrk_sparse_window_to_dense",
 )
 
 
@@ -127,6 +128,8 @@ def lib() -> C.CDLL:
     L.qrk_bb_solve_r.restype = C.c_int
     L.qrk_bb_solve_r.argtypes = [vp, dp, C.c_int64, C.c_int64, C.c_int]
     L.qrk_tsqr_plan_create.restype = C.c_int
+    L.qrk_sparse_window_to_dense.restype = C.c_int
+    L.qrk_sparse_window_to_dense.argtypes = [vp, C.c_int, C.c_int64, C.c_int64, ip, ip, dp, C.c_int64, C.c_int64, ip, dp, C.c_int64]
     L.qrk_tsqr_plan_create.argtypes = [vp, C.c_int32, C.c_int32, C.POINTER(vp)]
     L.qrk_tsqr_plan_destroy.restype = C.c_int
     L.qrk_tsqr_plan_destroy.argtypes = [vp]

@@ -39,6 +39,28 @@ class BlockMatrix1x2:
     def cols(self) -> int:
         return self._left.cols() + int(self._right.shape[1])
 
+def sparse_to_device_dense(context: Context, mat, row0: int = 0, nrows: Optional[int] = None, row_map=None) -> torch.Tensor:
+    """Rows [row0, row0 + nrows) of a scipy sparse matrix as a dense COLUMN-major float64 tensor on the device
+    (qrk_sparse_window_to_dense: the nonzeros cross PCIe, the dense copy the reference makes - BlockedThinSparseQR.h:131
+    "m_R = mat" - is written on the device).  row_map (nrows integers, a permutation) sends source row row0 + i to row_map[i]."""
+    import scipy.sparse as sp
+    M = mat if sp.isspmatrix_csr(mat) or sp.isspmatrix_csc(mat) else sp.csc_matrix(mat)
+    if not M.has_canonical_format:
+        M = M.copy(); M.sum_duplicates()
+    rows, cols = M.shape
+    nrows = rows - row0 if nrows is None else int(nrows)
+    dev = context.device
+    outer = torch.from_numpy(np.ascontiguousarray(M.indptr, dtype=np.int32)).to(dev)
+    inner = torch.from_numpy(np.ascontiguousarray(M.indices, dtype=np.int32)).to(dev)
+    vals = torch.from_numpy(np.ascontiguousarray(M.data, dtype=np.float64)).to(dev)
+    rmap = None if row_map is None else torch.as_tensor(np.asarray(row_map, dtype=np.int32)).to(dev)
+    out = torch.empty(cols, max(nrows, 1), dtype=torch.float64, device=dev)[:, :nrows].t()   # column-major (nrows, cols)
+    context.use_current_stream()
+    capi.check(capi.lib().qrk_sparse_window_to_dense(
+        context.handle, 1 if sp.isspmatrix_csr(M) else 0, rows, cols, outer.data_ptr(), inner.data_ptr(), vals.data_ptr(),
+        int(row0), nrows, rmap.data_ptr() if rmap is not None else None, out.data_ptr(), max(nrows, 1)), context.handle)
+    return out
+
 
 class DenseColPivQR:
     """Dense Householder QR with implicit Q (Eigen::ColPivHouseholderQR / HouseholderQR interface)."""
@@ -172,8 +194,8 @@ class BlockedThinDenseQR(DenseColPivQR):
         self.suggestedBlockCols = suggestedBlockCols
 
     def compute(self, A):
-        if hasattr(A, "toarray"):
-            A = A.toarray()
+        if hasattr(A, "tocsc"):
+            A = sparse_to_device_dense(self._ctx, A)              # (densified on the device: the nonzeros cross PCIe)
         if not isinstance(A, torch.Tensor):
             A = _colmajor(torch.from_numpy(np.ascontiguousarray(A, dtype=np.float64)).to(self._ctx.device))
         return super().compute(A)
@@ -283,7 +305,7 @@ class BlockedThinSparseQR:
             inv = np.empty_like(rperm); inv[rperm] = np.arange(rows, dtype=rperm.dtype)
             pm = sp.csc_matrix(sp.csr_matrix(pm)[inv])                # m_pmat = m_rowPerm * m_pmat
         pm.sort_indices()
-        D = torch.from_numpy(np.asfortranarray(pm.toarray()).T.copy()).to(dev).t()   # m_pmatDense, column-major on the device
+        D = sparse_to_device_dense(self._ctx, pm)                     # m_pmatDense, column-major, written on the device
         Rout = torch.zeros(rows, cols, dtype=torch.float64, device=dev)
         lib = capi.lib()
         self._ctx.use_current_stream()
@@ -454,8 +476,11 @@ class BlockAngularSparseQR:
         assert self.m_leftSolver.info() == capi.INFO_SUCCESS
         # solveRightBlock (:361-369): J2.top(n1) = Q1^T (rowPerm * J2.top(n1)); bottom n2 rows as they are;
         # rightSolver.compute(J2.bottomRows(n1 + n2 - m1)).  The left solver's row permutation is the identity.
-        J2 = torch.as_tensor(np.asarray(right, dtype=np.float64)) if not isinstance(right, torch.Tensor) else right
-        J2 = J2.to(dev, torch.float64)
+        if hasattr(right, "tocsc"):          # sparse right block (test/test-qrkit.cpp:335): only its nonzeros cross PCIe
+            J2 = sparse_to_device_dense(self._ctx, right)
+        else:
+            J2 = torch.as_tensor(np.asarray(right, dtype=np.float64)) if not isinstance(right, torch.Tensor) else right
+            J2 = J2.to(dev, torch.float64)
         top = self.m_leftSolver.applyQt(J2[:n1, :])                    # device, (n1, m2)
         self._J2 = torch.cat([top, J2[n1:, :]], dim=0) if n2 > 0 else top
         bottom = _colmajor(self._J2[m1:, :].clone())

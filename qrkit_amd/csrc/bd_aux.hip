@@ -458,4 +458,45 @@ hipError_t launch_gemv_sub(const double* S, int64_t lds, int64_t rows, int64_t c
     return hipGetLastError();
 }
 
+// Dense column-major copy of a row window of a compressed sparse matrix (the right block J2 of a block-angular matrix handed over
+// sparse: BlockedThinSparseQR.h:131 "m_R = mat" densifies it inside the right solver either way).  The window is zeroed by the
+// launcher; here one wave walks one outer vector (a row of a CSR matrix, a column of a CSC one), its entries over the lanes.
+template <bool CSR>
+__global__ void __launch_bounds__(256)
+sparse_window_kernel(int64_t outer_size, const int32_t* __restrict__ outer, const int32_t* __restrict__ inner,
+                     const double* __restrict__ vals, int64_t row0, int64_t nrows, const int32_t* __restrict__ row_map,
+                     double* __restrict__ out, int64_t ld)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6, nwaves = ((int64_t)gridDim.x * 256) >> 6;
+    const int64_t o_lo = CSR ? row0 : 0, o_hi = CSR ? row0 + nrows : outer_size;
+    for (int64_t o = o_lo + wave; o < o_hi; o += nwaves) {
+        const int e0 = outer[o], e1 = outer[o + 1];
+        for (int e = e0 + lane; e < e1; e += 64) {
+            const int64_t r = CSR ? o : inner[e], c = CSR ? inner[e] : o;
+            if (r < row0 || r >= row0 + nrows) continue;
+            const int64_t dr = row_map ? row_map[r - row0] : r - row0;
+            out[c * ld + dr] = vals[e];
+        }
+    }
+}
+
+hipError_t launch_sparse_window_to_dense(bool row_major, int64_t rows, int64_t cols, const int32_t* outer, const int32_t* inner,
+                                         const double* vals, int64_t row0, int64_t nrows, const int32_t* row_map, double* out,
+                                         int64_t ld, hipStream_t stream)
+{
+    if (nrows <= 0 || cols <= 0) return hipSuccess;
+    if (hipError_t e = hipMemset2DAsync(out, (size_t)ld * sizeof(double), 0, (size_t)nrows * sizeof(double), (size_t)cols, stream)) return e;
+    const int64_t work = row_major ? nrows : cols;          // outer vectors to walk, one wave each
+    int64_t grid = (work + 3) / 4;
+    if (grid > 65536) grid = 65536;
+    if (row_major)
+        hipLaunchKernelGGL(sparse_window_kernel<true>, dim3((unsigned)grid), dim3(256), 0, stream, rows, outer, inner, vals, row0, nrows,
+                           row_map, out, ld);
+    else
+        hipLaunchKernelGGL(sparse_window_kernel<false>, dim3((unsigned)grid), dim3(256), 0, stream, cols, outer, inner, vals, row0, nrows,
+                           row_map, out, ld);
+    return hipGetLastError();
+}
+
 }  // namespace qrk

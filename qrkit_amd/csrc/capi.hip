@@ -424,6 +424,20 @@ qrk_status qrk_dense_gemv_sub(qrk_handle h, const double* S, int64_t lds, int64_
     return QRK_STATUS_OK;
 }
 
+qrk_status qrk_sparse_window_to_dense(qrk_handle h, int row_major, int64_t rows, int64_t cols, const int32_t* d_outer,
+                                      const int32_t* d_inner, const double* d_values, int64_t row0, int64_t nrows,
+                                      const int32_t* d_row_map, double* d_out, int64_t ld)
+{
+    if (!h || rows < 0 || cols < 0 || row0 < 0 || nrows < 0 || row0 + nrows > rows || ld < nrows ||
+        (nrows > 0 && cols > 0 && (!d_outer || !d_out)))
+        return fail(h, QRK_STATUS_INVALID_ARGUMENT, "qrk_sparse_window_to_dense: bad argument");
+    if (nrows == 0 || cols == 0) return QRK_STATUS_OK;
+    QRK_HIP(h, hipSetDevice(h->device));
+    QRK_HIP(h, qrk::launch_sparse_window_to_dense(row_major != 0, rows, cols, d_outer, d_inner, d_values, row0, nrows, d_row_map, d_out,
+                                                  ld, h->stream));
+    return QRK_STATUS_OK;
+}
+
 qrk_status qrk_bd_plan_create(qrk_handle h, const qrk_bd_layout* L, qrk_q_format q_format,
                               qrk_block_solver solver, qrk_bd_plan* out)
 {
@@ -943,17 +957,18 @@ qrk_status qrk_dense_factorize(qrk_dense_plan p, double* a, int64_t lda, double*
         if (!h->force_exact && p->two_stage) {
             // stage 1: A = Q0 R0 (no pivoting, MFMA trailing updates); stage 2: R0 P = Q1 R on the n x n triangle
             const int n = p->cols;
+            const int piv2 = piv | qrk::decide::PIVOTING_SIGN_FREE;      // R is Eigen's up to the signs of its rows either way
             QRK_HIP(h, qrk::launch_caqr_factorize(da, lda, p->rows, n, p->d_t, h->stream, p->la_stream, p->la_urgent, p->la_factored));
             QRK_HIP(h, qrk::launch_caqr_copy_upper(da, lda, p->d_r0, n, n, 1, h->stream));
             if (p->cols2) {
-                QRK_HIP(h, qrk::launch_dense_qr_cols(p->d_r0, n, n, n, piv, dhc, dp, p->d_ws2, p->cpad2, p->d_q1, n, h->stream));
+                QRK_HIP(h, qrk::launch_dense_qr_cols(p->d_r0, n, n, n, piv2, dhc, dp, p->d_ws2, p->cpad2, p->d_q1, n, h->stream));
                 flag = qrk::dense_cols_unclear_ptr(p->d_ws2, p->cpad2);
             } else if (p->tall2) {
-                QRK_HIP(h, qrk::launch_dense_qr_tall(p->d_r0, n, n, n, piv, dhc, dp, p->d_ws2, p->G2, p->cpad2, p->rows_per2, false, h->stream));
+                QRK_HIP(h, qrk::launch_dense_qr_tall(p->d_r0, n, n, n, piv2, dhc, dp, p->d_ws2, p->G2, p->cpad2, p->rows_per2, false, h->stream));
                 flag = qrk::dense_tall_unclear_ptr(p->d_ws2, p->G2, p->cpad2);
             } else {
                 QRK_HIP(h, hipMemsetAsync(p->d_unclear, 0, sizeof(int), h->stream));
-                QRK_HIP(h, qrk::launch_dense_qr(p->d_r0, n, n, n, piv, dhc, dp, p->d_unclear, h->stream));
+                QRK_HIP(h, qrk::launch_dense_qr(p->d_r0, n, n, n, piv2, dhc, dp, p->d_unclear, h->stream));
                 flag = p->d_unclear;
             }
             // R replaces R0 in the caller's array (consumers read R from its upper triangle, as in Eigen's packed format)
@@ -965,6 +980,8 @@ qrk_status qrk_dense_factorize(qrk_dense_plan p, double* a, int64_t lda, double*
             QRK_HIP(h, hipMemcpyAsync(&unclear, flag, sizeof(int), hipMemcpyDeviceToHost, h->stream));
             QRK_HIP(h, hipStreamSynchronize(h->stream));
             p->ts_active = unclear == 0;
+            if (unclear && std::getenv("QRK_DEBUG_UNCLEAR"))
+                std::fprintf(stderr, "qrk_dense_factorize: second stage unclear, flags 0x%x (1 pivot margin, 2 recompute band, 4 reflector: 8 degenerate, 16 |x0| tiny, 32 pivot tiny)\n", unclear);
             return QRK_STATUS_OK;
         }
         if (!h->force_exact) {

@@ -113,7 +113,7 @@ dense_qr_kernel(double* __restrict__ A, int64_t lda, int r, int c, int pivoting,
         const double xk = xv[k];
         double beta, tau, scale;
         if (k == 0 && !pivoting) a2 = fma(xk, xk, tailSq);
-        if (tid == 0 && unclear_reflector(xk, tailSq, k + 1 < r, pivoting != 0, a2)) *unclear = 1;   // (3), (4), (5)
+        if (tid == 0 && unclear_reflector(xk, tailSq, k + 1 < r, pivoting != 0, a2, (pivoting & PIVOTING_SIGN_FREE) != 0)) *unclear = 1;   // (3), (4), (5)
         if (tailSq <= DBL_MIN) {           // makeHouseholder: tau = 0, beta = x0, essential = 0
             beta = xk; tau = 0.0; scale = 0.0;
         } else {

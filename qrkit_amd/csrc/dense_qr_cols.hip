@@ -157,7 +157,8 @@ cols_step_kernel(double* __restrict__ A, int64_t lda, int r, int c, int k, int p
             w.invs[k] = degen ? 0.0 : 1.0 / s;
             hcoeffs[k] = tau;
             perm[k] = pk;                                        // colsPermutation().indices()(k)
-            if (unclear_reflector(xk, tsq, k + 1 < r, pivoting != 0, a2)) w.st->unclear = 1;   // decisions (3), (4), (5)
+            if (unclear_reflector(xk, tsq, k + 1 < r, pivoting != 0, a2, (pivoting & PIVOTING_SIGN_FREE) != 0))    // decisions (3), (4), (5)
+                atomicOr(&w.st->unclear, 4 | (!(tsq > DBL_MIN) ? 8 : 0) | (xk * xk <= X0_TINY2 * a2 ? 16 : 0) | (fma(xk, xk, tsq) <= PIV_TINY2 * a2 ? 32 : 0));
         }
     }
     // ---- one wavefront per remaining position
@@ -196,7 +197,7 @@ cols_step_kernel(double* __restrict__ A, int64_t lda, int r, int c, int k, int p
             if (pivoting) {
                 nn = fma(-an, an, w.nu2[b][sp]); th = w.thr[b][sp];
                 if (nn <= th) {                                   // LAWN-176: recompute from the updated column (which is right here)
-                    if (in_recompute_band(nn, th, a2)) atomicOr(&w.st->unclear, 1);    // decision (2)
+                    if (in_recompute_band(nn, th, a2)) atomicOr(&w.st->unclear, 2);    // decision (2)
                     nn = sq; th = sq * THR_HI;
                 }
             }
@@ -234,7 +235,7 @@ cols_step_kernel(double* __restrict__ A, int64_t lda, int r, int c, int k, int p
             if (pivoting) {
                 nn = fma(-an, an, w.nu2[b][sp]); th = w.thr[b][sp];
                 if (nn <= th) {
-                    if (in_recompute_band(nn, th, a2)) atomicOr(&w.st->unclear, 1);
+                    if (in_recompute_band(nn, th, a2)) atomicOr(&w.st->unclear, 2);
                     nn = sq; th = sq * THR_HI;
                 }
             }

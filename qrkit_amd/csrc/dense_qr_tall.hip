@@ -272,7 +272,8 @@ __device__ __forceinline__ void head_body(double* __restrict__ A, int64_t lda, i
         A[(int64_t)k * lda + k] = -nb;            // beta (= x0 when H = I)
         hcoeffs[k] = tau;
         if (k == 0 && !pivoting) w.st->a2 = fma(xk, xk, tsq);
-        if (unclear_reflector(xk, tsq, k + 1 < r, pivoting != 0, k == 0 && !pivoting ? fma(xk, xk, tsq) : w.st->a2))
+        if (unclear_reflector(xk, tsq, k + 1 < r, pivoting != 0, k == 0 && !pivoting ? fma(xk, xk, tsq) : w.st->a2,
+                              (pivoting & PIVOTING_SIGN_FREE) != 0))
             w.st->unclear = 1;                    // decisions (3), (4), (5)
     }
     __syncthreads();

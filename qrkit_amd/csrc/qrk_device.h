@@ -105,6 +105,10 @@ hipError_t launch_dense_qr_cols(double* A, int64_t lda, int r, int c, int pivoti
 // y(0:rows) -= sum_c S(:, colidx[c]) z[c] (bd_aux.hip): the strip term of the angular back substitution
 hipError_t launch_gemv_sub(const double* S, int64_t lds, int64_t rows, int64_t cols, const int32_t* colidx, const double* z, double* y,
                            hipStream_t stream);
+// dense column-major copy of rows [row0, row0 + nrows) of a sparse matrix on the device (bd_aux.hip)
+hipError_t launch_sparse_window_to_dense(bool row_major, int64_t rows, int64_t cols, const int32_t* outer, const int32_t* inner,
+                                         const double* vals, int64_t row0, int64_t nrows, const int32_t* row_map, double* out,
+                                         int64_t ld, hipStream_t stream);
 struct BBPanel;
 hipError_t launch_bb_chain(const BBPanel* panels, int num_panels, const int32_t* prowptr, const int32_t* pcol,
                            const int64_t* pmap, const double* vals, double* W, double* lo, double* y_vals,
@@ -156,12 +160,17 @@ __device__ __forceinline__ bool in_recompute_band(double nn, double thr, double 
 {
     return nn > thr * (1.0 - 2.0 * MREL) || thr <= (THR_HI * ND_TINY2) * a2;
 }
-// (3) degenerate reflector on a non-empty tail, (4) |x0| too small to fix the sign of beta, (5) pivot at the noise level
-__device__ __forceinline__ bool unclear_reflector(double xk, double tsq, bool tail, bool pivoting, double a2)
+// (3) degenerate reflector on a non-empty tail, (4) |x0| too small to fix the sign of beta, (5) pivot at the noise level.
+// sign_free: the caller's R is compared with Eigen's up to the signs of its rows anyway (second stage of the two-stage dense
+// form, whose first stage changed the basis): (3) and (4) decide only the sign of beta - H = I against a reflector with the same
+// |R_kk| - and are no reason for the exact path.  They are common there: structurally orthogonal columns (cameras of a bundle
+// adjustment that share no point) leave entries at the noise level, or exact zeros, in the first stage's triangle.
+__device__ __forceinline__ bool unclear_reflector(double xk, double tsq, bool tail, bool pivoting, double a2, bool sign_free = false)
 {
     const double n2 = fma(xk, xk, tsq);
-    return (tail && (!(tsq > DBL_MIN) || xk * xk <= X0_TINY2 * a2)) || (pivoting && n2 <= PIV_TINY2 * a2);
+    return (!sign_free && tail && (!(tsq > DBL_MIN) || xk * xk <= X0_TINY2 * a2)) || (pivoting && n2 <= PIV_TINY2 * a2);
 }
+constexpr int PIVOTING_SIGN_FREE = 2;     // bit of the launchers' `pivoting` argument that sets sign_free
 }  // namespace decide
 
 // ---- cross-lane helpers (wave64) ---------------------------------------------------------

@@ -8,6 +8,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstring>
 #include <cstdlib>
 #include <numeric>
 #include <random>
@@ -223,12 +224,28 @@ int main() {
         SparseMatrixColMajor rightSparse(right.rows(), right.cols());
         rightSparse.setFromTriplets(rt);
         fails += test_block_angular_as<BlockAngularSparseQR<BandedBlockedQRSolver, BlockedThinSparseQR<2> > >(left, left, right, rightSparse, "banded left, BlockedThinSparseQR right (sparse right block)");
+        {   // the same right block row-major, and one with two thirds of its entries absent (the window kernel's zero fill)
+            SparseMatrixRowMajor rightRM(right.rows(), right.cols());
+            rightRM.setFromTriplets(rt);
+            fails += test_block_angular_as<BlockAngularSparseQR<BandedBlockedQRSolver, BlockedThinSparseQR<2> > >(left, left, right, rightRM, "banded left, row-major sparse right block");
+            Matrix thin(right.rows(), right.cols());
+            std::vector<Triplet> tt;
+            for (Index j = 0; j < right.cols(); ++j)
+                for (Index i = 0; i < right.rows(); ++i)
+                    if ((i + 2 * j) % 3 == 0) { thin(i, j) = right(i, j); tt.emplace_back((int)i, (int)j, right(i, j)); }
+            SparseMatrixColMajor thinCM(right.rows(), right.cols());
+            SparseMatrixRowMajor thinRM(right.rows(), right.cols());
+            thinCM.setFromTriplets(tt); thinRM.setFromTriplets(tt);
+            fails += test_block_angular_as<BlockAngularSparseQR<BandedBlockedQRSolver, BlockedThinSparseQR<2> > >(left, left, thin, thinCM, "banded left, right block with 1/3 of its entries (CSC)");
+            fails += test_block_angular_as<BlockAngularSparseQR<BandedBlockedQRSolver, BlockedThinSparseQR<2> > >(left, left, thin, thinRM, "banded left, right block with 1/3 of its entries (CSR)");
+        }
         fails += test_blocked_thin(right);
     }
     if (std::getenv("QRK_BIG")) {
         // BASELINE configs[3] through the facade: 20000 tiles of 8x6 + 2000 dense columns, host matrices in, solution out.
         // J2 (2.56 GB) crosses PCIe once; Q1^T J2, the strip of R and the packed right factor stay on the device.
-        const Index B = 20000, r = 8, c = 6, m2 = 2000, n1 = B * r, m1 = B * c;
+        const bool small = std::strcmp(std::getenv("QRK_BIG"), "small") == 0;        // (a quarter of the shape, for diagnostics)
+        const Index B = small ? 5000 : 20000, r = 8, c = 6, m2 = small ? 504 : 2000, n1 = B * r, m1 = B * c;
         std::mt19937_64 rng(3);
         std::uniform_real_distribution<double> ud(0.5, 5.0);
         SparseBlockDiagonal blk(n1, m1);
@@ -258,6 +275,39 @@ int main() {
                     (long long)B, (long long)m2, std::chrono::duration<double, std::milli>(t1 - t0).count(),
                     std::chrono::duration<double, std::milli>(t2 - t1).count(), ok ? "Passed." : "Failed.");
         if (!ok) ++fails;
+        // the same shape with a sparse right block, bundle-adjustment style: every row sees one of 222 cameras, 9 nonzeros in
+        // that camera's columns (1.44 M nonzeros instead of 320 M entries cross PCIe; the dense copy is written on the device)
+        {
+            std::vector<Triplet> tt;
+            tt.reserve((size_t)n1 * 9);
+            const Index ncam = m2 / 9;
+            for (Index i = 0; i < n1; ++i) {
+                const Index cam = (Index)((uint64_t)i * 2654435761ull % (uint64_t)ncam);
+                for (Index q = 0; q < 9; ++q) tt.emplace_back((int)i, (int)(9 * cam + q), ud(rng));
+            }
+            for (Index j = 9 * ncam; j < m2; ++j) for (Index i = j; i < n1; i += 997) tt.emplace_back((int)i, (int)j, ud(rng));
+            SparseMatrixRowMajor rs(n1, m2);
+            rs.setFromTriplets(tt);
+            Vector x2(x.begin() + m1, x.end());
+            Vector b2 = rs * x2;
+            {
+                size_t off = 0;
+                for (Index b = 0; b < B; ++b, off += (size_t)(r * c))
+                    for (Index j = 0; j < c; ++j) for (Index i = 0; i < r; ++i) b2[(size_t)(b * r + i)] += blk.tiles()[off + (size_t)(j * r + i)] * x[(size_t)(b * c + j)];
+            }
+            BlockMatrix1x2<SparseBlockDiagonal, SparseMatrixRowMajor> smat(blk, rs);
+            baqr.compute(smat);
+            const auto s0 = std::chrono::steady_clock::now();
+            baqr.compute(smat);
+            const auto s1 = std::chrono::steady_clock::now();
+            const Vector xs2 = baqr.solve(b2);
+            const auto s2 = std::chrono::steady_clock::now();
+            const bool ok2 = approxVec(x, xs2, 1e-7);
+            std::printf("configs[3] through the facade, sparse right block (%lld nonzeros): compute %.1f ms, solve %.1f ms: %s\n",
+                        (long long)rs.nonZeros(), std::chrono::duration<double, std::milli>(s1 - s0).count(),
+                        std::chrono::duration<double, std::milli>(s2 - s1).count(), ok2 ? "Passed." : "Failed.");
+            if (!ok2) ++fails;
+        }
     }
     {   // the reference's own spelling: namespace QRKit, four template parameters, a fixed-size block type and a block overlap
         // (typedef at test-qrkit.cpp:43-44 with <Matrix<double,7,4>> / overlap 2 would take the fixed-pattern analysis,

@@ -144,3 +144,49 @@ def test_configs3_composition_full_size_properties():
     b = torch.bmm(A.transpose(1, 2), x[:m1].view(nt, 6, 1)).view(n1) + J2 @ x[m1:]
     xs = ba.solve(b)
     assert float((xs - x).norm() / x.norm()) <= 1e-9
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fmt", ["csr", "csc"])
+def test_sparse_window_to_dense(fmt):
+    """qrk_sparse_window_to_dense (the dense copy of a sparse right block written on the device, BlockedThinSparseQR.h:131): whole
+    matrix, a row window, a window with a row map, an empty window, empty rows and columns - against scipy's toarray()."""
+    import torch
+    import qrkit_amd
+    from qrkit_amd.angular import sparse_to_device_dense
+    ctx = qrkit_amd.Context(0)
+    rng = np.random.default_rng(5)
+    for rows, cols, dens in ((300, 40, 0.2), (1000, 7, 0.5), (65, 130, 0.05), (5, 3, 1.0), (200, 16, 0.0)):
+        M = sp.random(rows, cols, density=dens, random_state=int(rng.integers(1 << 30)), format=fmt, dtype=np.float64)
+        D = M.toarray()
+        out = sparse_to_device_dense(ctx, M)
+        assert out.shape == (rows, cols) and out.t().is_contiguous()
+        np.testing.assert_array_equal(out.cpu().numpy(), D)
+        r0, nr = rows // 3, rows // 2
+        np.testing.assert_array_equal(sparse_to_device_dense(ctx, M, r0, nr).cpu().numpy(), D[r0:r0 + nr])
+        rmap = rng.permutation(nr).astype(np.int32)
+        want = np.zeros((nr, cols)); want[rmap] = D[r0:r0 + nr]
+        np.testing.assert_array_equal(sparse_to_device_dense(ctx, M, r0, nr, rmap).cpu().numpy(), want)
+        assert sparse_to_device_dense(ctx, M, rows, 0).shape == (0, cols)
+    torch.cuda.synchronize()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fmt", ["csr", "csc"])
+def test_hip_angular_sparse_right_block(fmt):
+    """A sparse right block (test-qrkit.cpp:335, BlockMatrix1x2<JacobianType, JacobianType>) gives bit for bit what its dense copy
+    gives: the same dense J2 reaches the same kernels, only the way it reaches the device differs."""
+    import qrkit_amd
+    prob, tiles, J1, J2 = angular_problem(200, 48, n2=9)
+    J2 = J2 * (np.random.default_rng(2).uniform(size=J2.shape) < 0.3)          # 70 % structural zeros
+    left = qrkit_amd.SparseBlockDiagonal.fromTiles(prob.rows, prob.cols, tiles)
+    dense, sparse = qrkit_amd.BlockAngularSparseQR(), qrkit_amd.BlockAngularSparseQR()
+    dense.compute(qrkit_amd.BlockMatrix1x2(left, J2))
+    sparse.compute(qrkit_amd.BlockMatrix1x2(left, sp.csr_matrix(J2) if fmt == "csr" else sp.csc_matrix(J2)))
+    ref = orc.ba_factorize(prob, J2)
+    assert sparse.rank() == dense.rank() == ref.rank
+    np.testing.assert_array_equal(sparse.colsPermutation(), ref.perm)
+    np.testing.assert_array_equal(sparse.matrixR().toarray(), dense.matrixR().toarray())
+    assert rel_fro(sparse.matrixR().toarray(), ref.R.toarray()) <= 1e-12
+    b = np.random.default_rng(1).uniform(-1, 1, J2.shape[0])
+    np.testing.assert_array_equal(sparse.applyQt(b), dense.applyQt(b))
