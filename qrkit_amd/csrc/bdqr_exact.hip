@@ -407,6 +407,211 @@ dense_exact_kernel(double* __restrict__ A, int64_t lda, int r, int c, const doub
 }
 }  // namespace exact
 
+// ---- the same, wide: for blocks where one workgroup would take minutes (40 000 x 2 000: 200 s).  The arithmetic of a column is
+// a sequential chain in one thread, as above - that is what makes the result Eigen's, bit for bit - but the columns are
+// independent, so they are spread over the chip: per reflector one `head` launch (one workgroup: pivot search, Eigen's
+// physical column swap, |x_tail|^2 as one chain, beta / tau, the essential vector) and one `apply` launch (a thread per
+// remaining column, 16 columns per workgroup so that a wave touches 16 cache lines per access, not 64; the LAWN-176 update of
+// its norms included).  Launched by the host only after it has read the `unclear` word (the sequence is 2 launches per
+// reflector: not something to queue as no-ops behind every factorisation).
+namespace exact {
+constexpr int WIDE_COLS = 16;
+constexpr int HT = 256;       // threads of the head kernel (256 VGPRs each: the two batches of the chain stay in registers)
+constexpr int WU = 32;        // loads issued together, two batches in flight; the sums stay ONE sequential chain in row order
+
+#define QRK_WU_LOAD(dst, src, at) _Pragma("unroll") for (int u = 0; u < WU; ++u) dst[u] = src[(at) + u]
+// Walks rows i0 .. r-1 of y in batches of WU with the next batch already in flight; BODY(buf, i) consumes batch `buf` whose first
+// row is i, TAIL(i) a single row.  (The columns of a 40 000 x 2 000 block come from HBM: without the second batch in flight the
+// chains run at the memory latency, 30 s per factorisation instead of a few.)
+#define QRK_WU_STREAM(y, i0, r, BODY, TAIL)                                          \
+    do {                                                                             \
+        int i_ = (i0);                                                               \
+        const int nb_ = ((r) - (i0)) > 0 ? ((r) - (i0)) / WU : 0;                    \
+        double b0_[WU], b1_[WU];                                                     \
+        if (nb_ > 0) { QRK_WU_LOAD(b0_, y, i_); }                                    \
+        int t_ = 0;                                                                  \
+        for (; t_ + 2 <= nb_; t_ += 2) {                                             \
+            QRK_WU_LOAD(b1_, y, i_ + WU);                                            \
+            BODY(b0_, i_);                                                           \
+            i_ += WU;                                                                \
+            if (t_ + 2 < nb_) { QRK_WU_LOAD(b0_, y, i_ + WU); }                      \
+            BODY(b1_, i_);                                                           \
+            i_ += WU;                                                                \
+        }                                                                            \
+        if (t_ < nb_) { BODY(b0_, i_); i_ += WU; }                                   \
+        for (; i_ < (r); ++i_) { TAIL(i_); }                                         \
+    } while (0)
+
+// s += v[i]^2, i = i0 .. r-1, in that order
+__device__ __forceinline__ double chain_sumsq(const double* v, int i0, int r, double s)
+{
+#define QRK_BODY(buf, i) _Pragma("unroll") for (int u = 0; u < WU; ++u) s += buf[u] * buf[u]
+#define QRK_TAIL(i) { const double a = v[i]; s += a * a; }
+    QRK_WU_STREAM(v, i0, r, QRK_BODY, QRK_TAIL);
+#undef QRK_BODY
+#undef QRK_TAIL
+    return s;
+}
+// s += x[i] * y[i], i = i0 .. r-1, in that order (y streamed from memory, x the shared reflector: cache hits)
+__device__ __forceinline__ double chain_dot(const double* x, const double* y, int i0, int r, double s)
+{
+#define QRK_BODY(buf, i) { double a[WU]; QRK_WU_LOAD(a, x, i); _Pragma("unroll") for (int u = 0; u < WU; ++u) s += a[u] * buf[u]; }
+#define QRK_TAIL(i) s += x[i] * y[i]
+    QRK_WU_STREAM(y, i0, r, QRK_BODY, QRK_TAIL);
+#undef QRK_BODY
+#undef QRK_TAIL
+    return s;
+}
+// y[i] -= (tau x[i]) tmp, i = i0 .. r-1
+__device__ __forceinline__ void chain_update(const double* x, double* y, int i0, int r, double tau, double tmp)
+{
+#define QRK_BODY(buf, i) { double a[WU]; QRK_WU_LOAD(a, x, i); _Pragma("unroll") for (int u = 0; u < WU; ++u) y[(i) + u] = buf[u] - (tau * a[u]) * tmp; }
+#define QRK_TAIL(i) y[i] -= (tau * x[i]) * tmp
+    QRK_WU_STREAM(y, i0, r, QRK_BODY, QRK_TAIL);
+#undef QRK_BODY
+#undef QRK_TAIL
+}
+
+struct WideWs { double* xbuf; double* nu; double* nd; int* pidx; };
+__host__ __device__ inline WideWs wide_ws(double* ws, int r, int c)
+{
+    WideWs w;
+    w.xbuf = ws; w.nu = ws + r; w.nd = w.nu + c; w.pidx = reinterpret_cast<int*>(w.nd + c);
+    return w;
+}
+
+template <bool PIVOT>
+__global__ void __launch_bounds__(64)
+dense_exact_wide_init_kernel(const double* __restrict__ A, int64_t lda, int r, int c, double* __restrict__ ws)
+{
+    const WideWs w = wide_ws(ws, r, c);
+    const int j = blockIdx.x * WIDE_COLS + threadIdx.x;
+    if (threadIdx.x >= WIDE_COLS || j >= c) return;
+    w.pidx[j] = j;
+    if (PIVOT) {
+        const double* col = A + (int64_t)j * lda;
+        const double n = sqrt(chain_sumsq(col, 0, r, 0.0));
+        w.nu[j] = n; w.nd[j] = n;
+    }
+}
+
+template <bool PIVOT>
+__global__ void __launch_bounds__(HT)
+dense_exact_wide_head_kernel(double* __restrict__ A, int64_t lda, int r, int c, int k, double* __restrict__ hcoeffs,
+                             int32_t* __restrict__ perm, double* __restrict__ ws)
+{
+    __shared__ double sval[HT];
+    __shared__ int spos[HT];
+    const int t = threadIdx.x;
+    const WideWs w = wide_ws(ws, r, c);
+    double* xbuf = w.xbuf; double* nu = w.nu; double* nd = w.nd; int* pidx = w.pidx;
+    if (PIVOT) {
+        double bv = -1.0; int bp = 0x7fffffff;
+        for (int j = k + t; j < c; j += HT) if (better(nu[j], j, bv, bp)) { bv = nu[j]; bp = j; }
+        sval[t] = bv; spos[t] = bp;
+        __syncthreads();
+        for (int s = HT / 2; s > 0; s >>= 1) {
+            if (t < s && better(sval[t + s], spos[t + s], sval[t], spos[t])) { sval[t] = sval[t + s]; spos[t] = spos[t + s]; }
+            __syncthreads();
+        }
+        const int b = spos[0];
+        __syncthreads();
+        if (b != k) {       // m_qr.col(k).swap(m_qr.col(b)), the two norm tables, the transposition
+            double* ck = A + (int64_t)k * lda;
+            double* cb = A + (int64_t)b * lda;
+            for (int i = t; i < r; i += HT) { const double v = ck[i]; ck[i] = cb[i]; cb[i] = v; }
+            if (t == 0) {
+                double v = nu[k]; nu[k] = nu[b]; nu[b] = v;
+                v = nd[k]; nd[k] = nd[b]; nd[b] = v;
+                const int p = pidx[k]; pidx[k] = pidx[b]; pidx[b] = p;
+            }
+        }
+        __syncthreads();
+    }
+    double* ck = A + (int64_t)k * lda;
+    for (int i = k + t; i < r; i += HT) xbuf[i] = ck[i];
+    __syncthreads();
+    const double c0 = xbuf[k];
+    // (every thread runs the same chain on the same data, as in the one-workgroup kernel: no broadcast needed)
+    const double tail = chain_sumsq(xbuf, k + 1, r, 0.0);
+    double tau, beta, denom = 1.0;
+    const bool degen = tail <= DBL_MIN;
+    if (degen) { tau = 0.0; beta = c0; }
+    else {
+        beta = sqrt(c0 * c0 + tail);
+        if (c0 >= 0.0) beta = -beta;
+        denom = c0 - beta;
+        tau = (beta - c0) / beta;
+    }
+    __syncthreads();
+    for (int i = k + 1 + t; i < r; i += HT) { const double e = degen ? 0.0 : xbuf[i] / denom; xbuf[i] = e; ck[i] = e; }
+    if (t == 0) { ck[k] = beta; hcoeffs[k] = tau; }
+    const int size = r < c ? r : c;
+    if (k == size - 1) {
+        __syncthreads();
+        for (int j = t; j < c; j += HT) perm[j] = pidx[j];
+    }
+}
+
+template <bool PIVOT>
+__global__ void __launch_bounds__(64)
+dense_exact_wide_apply_kernel(double* __restrict__ A, int64_t lda, int r, int c, int k, const double* __restrict__ hcoeffs,
+                              double* __restrict__ ws)
+{
+    const WideWs w = wide_ws(ws, r, c);
+    const double* xbuf = w.xbuf; double* nu = w.nu; double* nd = w.nd;
+    const int j = k + 1 + blockIdx.x * WIDE_COLS + threadIdx.x;
+    if (threadIdx.x >= WIDE_COLS || j >= c) return;
+    const double tau = hcoeffs[k];
+    const int m = r - k;
+    double* col = A + (int64_t)j * lda;
+    if (m == 1) col[k] *= (1.0 - tau);
+    else if (tau != 0.0) {
+        double tmp = chain_dot(xbuf, col, k + 1, r, 0.0);
+        tmp += col[k];
+        col[k] -= tau * tmp;
+        chain_update(xbuf, col, k + 1, r, tau, tmp);
+    }
+    if (PIVOT) {
+        const double nuj = nu[j];
+        if (nuj != 0.0) {
+            double temp = fabs(col[k]) / nuj;
+            temp = (1.0 + temp) * (1.0 - temp);
+            temp = temp < 0.0 ? 0.0 : temp;
+            const double ratio = nuj / nd[j];
+            const double temp2 = temp * (ratio * ratio);
+            if (temp2 <= SQRT_EPS) {
+                const double n = sqrt(chain_sumsq(col, k + 1, r, 0.0));
+                nd[j] = n; nu[j] = n;
+            } else nu[j] = nuj * sqrt(temp);
+        }
+    }
+}
+}  // namespace exact
+
+// A (restored by the caller) -> Eigen's packed QR, hcoeffs, perm; workspace as for launch_dense_exact
+hipError_t launch_dense_exact_wide(double* A, int64_t lda, int r, int c, int pivoting, double* hcoeffs, int32_t* perm,
+                                   double* workspace, hipStream_t stream)
+{
+    using namespace exact;
+    const int size = r < c ? r : c;
+    const unsigned gi = (unsigned)((c + WIDE_COLS - 1) / WIDE_COLS);
+#define QRK_WIDE(PV)                                                                                                         \
+    do {                                                                                                                     \
+        hipLaunchKernelGGL(dense_exact_wide_init_kernel<PV>, dim3(gi), dim3(64), 0, stream, A, lda, r, c, workspace);        \
+        for (int k = 0; k < size; ++k) {                                                                                     \
+            hipLaunchKernelGGL(dense_exact_wide_head_kernel<PV>, dim3(1), dim3(HT), 0, stream, A, lda, r, c, k, hcoeffs, perm, workspace); \
+            const int rest = c - k - 1;                                                                                      \
+            if (rest > 0)                                                                                                    \
+                hipLaunchKernelGGL(dense_exact_wide_apply_kernel<PV>, dim3((unsigned)((rest + WIDE_COLS - 1) / WIDE_COLS)), dim3(64), 0, \
+                                   stream, A, lda, r, c, k, hcoeffs, workspace);                                             \
+        }                                                                                                                    \
+    } while (0)
+    if (pivoting) QRK_WIDE(true); else QRK_WIDE(false);
+#undef QRK_WIDE
+    return hipGetLastError();
+}
+
 size_t dense_exact_workspace_bytes(int r, int c) { return ((size_t)r + 2 * (size_t)c) * sizeof(double) + (size_t)c * sizeof(int) + 64; }
 
 hipError_t launch_dense_exact(double* A, int64_t lda, int r, int c, int pivoting, const double* copy, double* hcoeffs,

@@ -121,6 +121,7 @@ struct qrk_dense_plan_s {
     hipEvent_t la_urgent = nullptr, la_factored = nullptr;
     int G2 = 0, cpad2 = 0, rows_per2 = 0;
     bool tall2 = false, cols2 = false;
+    bool exact_wide = false;   // large block: the exact path runs as a host-launched sequence over all CUs (the host reads the unclear word)
     // column-parallel kernel as the DIRECT algorithm (same reflectors, signs and format as Eigen) when a column fits LDS: d_q1 then
     // receives the packed result (rows x cols), copied back into the caller's array
     bool cols_direct = false;
@@ -877,6 +878,8 @@ qrk_status qrk_dense_plan_create(qrk_handle h, int32_t rows, int32_t cols, qrk_b
         if (e[0] == '0') p->two_stage = false;
         else if (e[0] == '1' && solver == QRK_COLPIV_HOUSEHOLDER && rows >= cols) p->two_stage = true;
     }
+    p->exact_wide = (int64_t)rows * cols >= (int64_t)1 << 18;
+    if (const char* e = std::getenv("QRK_EXACT_WIDE")) p->exact_wide = e[0] == '1' || (e[0] != '0' && p->exact_wide);
     p->cols_direct = p->tall && !p->two_stage && !p->persistent && qrk::dense_cols_supported(rows, cols);
     if (const char* e = std::getenv("QRK_DENSE_PATH")) { if (!std::strcmp(e, "slabs")) p->cols_direct = false; }
     if (p->cols_direct) {
@@ -948,6 +951,17 @@ qrk_status qrk_dense_factorize(qrk_dense_plan p, double* a, int64_t lda, double*
     QRK_HIP(h, hipSetDevice(h->device));
     const int piv = p->solver == QRK_COLPIV_HOUSEHOLDER ? 1 : 0;
     const int size = p->rows < p->cols ? p->rows : p->cols;
+    // the exact path of a large block: input restored from the plan's copy, then Eigen's operation order column by column, the
+    // columns spread over the chip (bdqr_exact.hip, launch_dense_exact_wide)
+    auto exact_wide = [&](double* da, double* dhc, int32_t* dp, int unclear) -> qrk_status {
+        if (std::getenv("QRK_DEBUG_UNCLEAR"))
+            std::fprintf(stderr, "qrk_dense_factorize: %d x %d to the exact path, flags 0x%x (1 pivot margin, 2 recompute band, 4 reflector: 8 degenerate, 16 |x0| tiny, 32 pivot tiny)\n",
+                         p->rows, p->cols, unclear);
+        QRK_HIP(h, hipMemcpy2DAsync(da, (size_t)lda * sizeof(double), p->d_copy, (size_t)p->rows * sizeof(double),
+                                    (size_t)p->rows * sizeof(double), (size_t)p->cols, hipMemcpyDeviceToDevice, h->stream));
+        QRK_HIP(h, qrk::launch_dense_exact_wide(da, lda, p->rows, p->cols, piv, dhc, dp, p->d_exact_ws, h->stream));
+        return QRK_STATUS_OK;
+    };
     auto run = [&](double* da, double* dhc, int32_t* dp) -> qrk_status {
         // keep the input: the exact path restores it when a decision was not clear of rounding (a D2D copy, < 1 % of the work)
         QRK_HIP(h, hipMemcpy2DAsync(p->d_copy, (size_t)p->rows * sizeof(double), da, (size_t)lda * sizeof(double),
@@ -975,13 +989,11 @@ qrk_status qrk_dense_factorize(qrk_dense_plan p, double* a, int64_t lda, double*
             QRK_HIP(h, qrk::launch_caqr_copy_upper(p->d_q1, n, da, lda, n, 0, h->stream));
             // a decision of the second stage inside rounding: the exact path redoes the whole matrix in Eigen's operation order
             // and leaves Eigen's packed format; the host has to know which format the factors are in
-            QRK_HIP(h, qrk::launch_dense_exact(da, lda, p->rows, p->cols, piv, p->d_copy, dhc, dp, flag, p->d_exact_ws, h->stream));
             int unclear = 0;
             QRK_HIP(h, hipMemcpyAsync(&unclear, flag, sizeof(int), hipMemcpyDeviceToHost, h->stream));
             QRK_HIP(h, hipStreamSynchronize(h->stream));
             p->ts_active = unclear == 0;
-            if (unclear && std::getenv("QRK_DEBUG_UNCLEAR"))
-                std::fprintf(stderr, "qrk_dense_factorize: second stage unclear, flags 0x%x (1 pivot margin, 2 recompute band, 4 reflector: 8 degenerate, 16 |x0| tiny, 32 pivot tiny)\n", unclear);
+            if (unclear) return exact_wide(da, dhc, dp, unclear);
             return QRK_STATUS_OK;
         }
         if (!h->force_exact) {
@@ -999,6 +1011,16 @@ qrk_status qrk_dense_factorize(qrk_dense_plan p, double* a, int64_t lda, double*
                 QRK_HIP(h, qrk::launch_dense_qr(da, lda, p->rows, p->cols, piv, dhc, dp, p->d_unclear, h->stream));
                 flag = p->d_unclear;
             }
+        }
+        if (p->exact_wide) {
+            // large blocks: one workgroup would take minutes, so the host reads the word and runs the exact path over the whole chip
+            int unclear = 1;                               // (no flag: the exact path was asked for)
+            if (flag) {
+                QRK_HIP(h, hipMemcpyAsync(&unclear, flag, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+                QRK_HIP(h, hipStreamSynchronize(h->stream));
+            }
+            if (unclear) return exact_wide(da, dhc, dp, unclear);
+            return QRK_STATUS_OK;
         }
         QRK_HIP(h, qrk::launch_dense_exact(da, lda, p->rows, p->cols, piv, p->d_copy, dhc, dp, flag, p->d_exact_ws, h->stream));
         return QRK_STATUS_OK;

@@ -85,6 +85,9 @@ int* dense_tall_unclear_ptr(void* workspace, int G, int cpad);
 hipError_t launch_dense_exact(double* A, int64_t lda, int r, int c, int pivoting, const double* copy, double* hcoeffs,
                               int32_t* perm, const int* unclear, double* workspace, hipStream_t stream);
 size_t dense_exact_workspace_bytes(int r, int c);
+// the exact path of a large dense block over the whole chip (A already restored; host-launched sequence, 2 launches per reflector)
+hipError_t launch_dense_exact_wide(double* A, int64_t lda, int r, int c, int pivoting, double* hcoeffs, int32_t* perm,
+                                   double* workspace, hipStream_t stream);
 hipError_t launch_dense_apply_q(const double* QR, int64_t lda, int r, int nrefl, const double* hcoeffs,
                                 int transpose, double* B, int64_t ldb, int64_t nrhs, hipStream_t stream);
 // Un-pivoted communication-avoiding QR of a tall matrix on all CUs, MFMA trailing update (caqr.hip): first stage of the pivoted

@@ -343,3 +343,33 @@ def test_two_stage_structurally_orthogonal_columns_stay_on_the_fast_path(monkeyp
     assert np.linalg.norm(B.cpu().numpy() - Rfull) <= 1e-12 * np.linalg.norm(A) * np.sqrt(cols)
     qr.applyQ(B, transpose=False)
     assert rel_fro(B.cpu().numpy(), A[:, P]) <= 1e-12 * np.sqrt(cols)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,rows,cols,two_stage,solver", [
+    ("pm1", 4096, 128, "1", 0), ("dup_cols", 4096, 128, "0", 0), ("circulant", 3000, 100, "0", 0), ("pm1", 300, 70, "0", 0),
+    ("pm1", 40, 60, "0", 0), ("small_int", 2111, 130, "0", 1)])
+def test_dense_exact_path_over_the_whole_chip_is_bitwise_the_oracle(kind, rows, cols, two_stage, solver, monkeypatch):
+    """Large dense blocks whose decisions are ties: the exact path as a host-launched sequence over all CUs (bdqr_exact.hip,
+    launch_dense_exact_wide: a thread per column runs Eigen's sequential chains, one head and one apply launch per reflector) instead
+    of one workgroup (200 s at 40 000 x 2 000): packed QR, tau and permutation bit-identical to the oracle, after the two-stage
+    form and after the direct kernels, tall and landscape, pivoted and not (QRK_EXACT_WIDE=1 forces it on the small shapes)."""
+    from test_ties_gpu import tie_tiles
+    monkeypatch.setenv("QRK_DENSE_TWO_STAGE", two_stage)
+    monkeypatch.setenv("QRK_EXACT_WIDE", "1")
+    A = tie_tiles(kind, 1, rows, cols, seed=rows + cols).reshape(cols, rows).T.copy()
+    qr, At = _factor(A, solver, None)
+    k = min(rows, cols)
+    if solver == 0:
+        ref, hc, perm, _ = orc.colpiv_qr(A)
+        np.testing.assert_array_equal(qr.colsPermutation().cpu().numpy(), perm)
+    else:
+        ref, hc = orc.householder_qr(A)[:2]
+    got = At.cpu().numpy()
+    if solver == 0:
+        np.testing.assert_array_equal(got, ref)
+        np.testing.assert_array_equal(qr._hc.cpu().numpy()[:k], hc[:k])
+    else:
+        # (un-pivoted: nothing but a degenerate reflector or a sign at the noise level flags the block; either it was redone - bitwise -
+        #  or the fast result stands)
+        assert np.array_equal(got, ref) or rel_fro(np.triu(got[:k]), np.triu(ref[:k])) <= 1e-12
