@@ -204,9 +204,9 @@ caqr_panel_kernel(double* __restrict__ A, int64_t lda, int m, int pc, int w, Sla
         const double* src = A + (int64_t)pc * lda + row0 + x;
         double ld[NB];                   // all 32 loads in flight at once
 #pragma unroll
-        for (int cc = 0; cc < NB; ++cc) ld[cc] = (cc < w && x < nr && (!TRI || x <= cc)) ? src[(int64_t)cc * lda] : 0.0;
+        for (int cc = 0; cc < NB; ++cc) ld[cc] = *((cc < w && x < nr && (!TRI || x <= cc)) ? src + (int64_t)cc * lda : A);   // (clamped address, not a load under a condition)
 #pragma unroll
-        for (int cc = 0; cc < NB; ++cc) sm[(i * NB + x) * LS + cc] = ld[cc];
+        for (int cc = 0; cc < NB; ++cc) sm[(i * NB + x) * LS + cc] = (cc < w && x < nr && (!TRI || x <= cc)) ? ld[cc] : 0.0;
     }
     __syncthreads();
     double a[NB];
@@ -340,15 +340,21 @@ caqr_apply_kernel(const double* __restrict__ A, int64_t lda, int m, int pc, int 
         const int64_t row0 = chunk_row0(sl, t, y);
         const int nr = y < cnt ? chunk_rows(row0, m) : 0;
         const double* src = A + (int64_t)pc * lda + row0 + x;
-#pragma unroll 8
-        for (int cc = ch * (NB / 2); cc < (ch + 1) * (NB / 2); ++cc) {
-            double v = 0.0;
-            if (cc < w && x < nr) {
-                if (y == 0) {
-                    if (x == cc) v = 1.0;
-                    else if (!TRI && x > cc) v = src[(int64_t)cc * lda];
-                } else if (!TRI || x <= cc) v = src[(int64_t)cc * lda];
-            }
+        // (every load is issued before the first is waited for: the address of an entry that is not read from memory is clamped
+        //  to a valid one and the value replaced afterwards -- loads under a condition each got their own wait, 16 round trips
+        //  to L2 before the first MFMA of the workgroup)
+        double raw[NB / 2];
+#pragma unroll
+        for (int q = 0; q < NB / 2; ++q) {
+            const int cc = ch * (NB / 2) + q;
+            const bool need = cc < w && x < nr && (y == 0 ? (!TRI && x > cc) : (!TRI || x <= cc));
+            raw[q] = *(need ? src + (int64_t)cc * lda : A);
+        }
+#pragma unroll
+        for (int q = 0; q < NB / 2; ++q) {
+            const int cc = ch * (NB / 2) + q;
+            const bool need = cc < w && x < nr && (y == 0 ? (!TRI && x > cc) : (!TRI || x <= cc));
+            const double v = need ? raw[q] : ((cc < w && x < nr && y == 0 && x == cc) ? 1.0 : 0.0);
             ys[(y * NB + x) * LS + cc] = v;
         }
         for (int e = tid; e < NB * NB; e += APPLY_T) ts[(e >> 5) * LS + (e & 31)] = Tin[(int64_t)t * (NB * NB) + e];
@@ -452,6 +458,81 @@ caqr_apply_kernel(const double* __restrict__ A, int64_t lda, int m, int pc, int 
     }
 }
 
+// The same block reflectors applied to a few vectors (the right-hand side of a solve: C has 1 ... VEC_MAX columns).  The MFMA kernel
+// above stages Y densely in LDS for tiles of 16 columns and takes 25-30 us per launch whatever the width; here thread (x, y) of the
+// 256 keeps row x of chunk y of Y in 32 registers and one entry of each vector: w = Y^T c through LDS (two passes of 16 columns,
+// fixed summation order), w' = -(T^T or T) w by 32 threads, c += Y w' from the registers.  252 launches of a solve with the
+// 40 000 x 2 000 block: 6.7 -> 2.5 ms.
+constexpr int VEC_MAX = 4;
+template <bool TRI>
+__global__ void __launch_bounds__(256)
+caqr_apply_vec_kernel(const double* __restrict__ A, int64_t lda, int m, int pc, int w, Slab sl, const double* __restrict__ Tin,
+                      int transpose, double* __restrict__ C, int64_t ldc, int ncols)
+{
+    __shared__ double prod[256 * 17];
+    __shared__ double part[8 * 16];
+    __shared__ double wv[NB], wp[NB];
+    const int t = blockIdx.x, tid = threadIdx.x;
+    int cnt = sl.nchunks - FAN * t;
+    cnt = cnt > FAN ? FAN : cnt;
+    const int x = tid & 31, y = tid >> 5;
+    const int64_t row0 = chunk_row0(sl, t, y);
+    const int nr = y < cnt ? chunk_rows(row0, m) : 0;
+    const bool rok = x < nr;
+    double yr[NB];
+    {
+        const double* src = A + (int64_t)pc * lda + row0 + x;
+#pragma unroll
+        for (int cc = 0; cc < NB; ++cc) {          // (all loads in flight at once: see caqr_apply_kernel)
+            const bool need = cc < w && rok && (y == 0 ? (!TRI && x > cc) : (!TRI || x <= cc));
+            yr[cc] = *(need ? src + (int64_t)cc * lda : A);
+        }
+#pragma unroll
+        for (int cc = 0; cc < NB; ++cc) {
+            const bool need = cc < w && rok && (y == 0 ? (!TRI && x > cc) : (!TRI || x <= cc));
+            yr[cc] = need ? yr[cc] : ((cc < w && rok && y == 0 && x == cc) ? 1.0 : 0.0);
+        }
+    }
+    const double* Tt = Tin + (int64_t)t * (NB * NB);
+    for (int v = 0; v < ncols; ++v) {
+        double* cp = C + (int64_t)v * ldc + row0 + x;
+        double c = rok ? *cp : 0.0;
+        // w = Y^T c
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) prod[tid * 17 + j] = yr[16 * h + j] * c;
+            __syncthreads();
+            if (tid < 128) {
+                const int j = tid & 15, pp = tid >> 4;
+                double sacc = 0.0;
+                for (int q = 0; q < 32; ++q) sacc += prod[(pp * 32 + q) * 17 + j];
+                part[pp * 16 + j] = sacc;
+            }
+            __syncthreads();
+            if (tid < 16) {
+                double sacc = 0.0;
+#pragma unroll
+                for (int pp = 0; pp < 8; ++pp) sacc += part[pp * 16 + tid];
+                wv[16 * h + tid] = sacc;
+            }
+            __syncthreads();
+        }
+        // w' = -(T^T or T) w
+        if (tid < NB) {
+            double sacc = 0.0;
+            for (int k = 0; k < NB; ++k) sacc = fma(transpose ? Tt[k * NB + tid] : Tt[tid * NB + k], wv[k], sacc);
+            wp[tid] = -sacc;
+        }
+        __syncthreads();
+        // c += Y w'
+#pragma unroll
+        for (int j = 0; j < NB; ++j) c = fma(yr[j], wp[j], c);
+        if (rok) *cp = c;
+        __syncthreads();
+    }
+}
+
 // R0 (upper triangle of the first n rows of A) as a dense n x n column-major matrix with zeros below the diagonal, and back
 // (the final R of the pivoted second stage replaces R0 in the caller's array).
 __global__ void caqr_copy_upper_kernel(const double* __restrict__ src, int64_t lds_, double* __restrict__ dst, int64_t ldd, int n,
@@ -532,6 +613,13 @@ static hipError_t caqr_panel_levels(double* A, int64_t lda, int m, int p, int w,
             if (cols_per_wg > 128) cols_per_wg = 128;
             if (cols_per_wg < 16) cols_per_wg = 16;
             const int cg = (ncols + cols_per_wg - 1) / cols_per_wg;
+            if (ncols <= VEC_MAX && !std::getenv("QRK_CAQR_NO_VEC")) {        // a few right-hand sides: the register kernel
+                if (l == 0) hipLaunchKernelGGL((caqr_apply_vec_kernel<false>), dim3(S), dim3(256), 0, stream, A, lda, m, pc, w, sl, tptr(l),
+                                               transpose, C, ldc, ncols);
+                else hipLaunchKernelGGL((caqr_apply_vec_kernel<true>), dim3(S), dim3(256), 0, stream, A, lda, m, pc, w, sl, tptr(l),
+                                        transpose, C, ldc, ncols);
+                continue;
+            }
             if (l == 0) hipLaunchKernelGGL((caqr_apply_kernel<false>), dim3(S, cg), dim3(APPLY_T), APPLY_LDS, stream, A, lda, m, pc, w, sl,
                                            tptr(l), transpose, C, ldc, ncols, cols_per_wg);
             else hipLaunchKernelGGL((caqr_apply_kernel<true>), dim3(S, cg), dim3(APPLY_T), APPLY_LDS, stream, A, lda, m, pc, w, sl,

@@ -168,6 +168,7 @@ dense_qr_kernel(double* __restrict__ A, int64_t lda, int r, int c, int pivoting,
     for (int jc = tid; jc < c; jc += DQ_THREADS) perm[jc] = pidx[jc];
 }
 
+constexpr int APQ_EPT = 8;     // entries of a reflector per thread in the register-prefetch form of dense_apply_q_kernel
 // B <- Q^T B (transpose != 0) or Q B, Q = H_0 ... H_{n-1} from the packed reflectors
 // (HouseholderSequence::applyThisOnTheLeft).  One workgroup per right-hand-side column.
 __global__ void __launch_bounds__(256)
@@ -181,6 +182,40 @@ dense_apply_q_kernel(const double* __restrict__ QR, int64_t lda, int r, int nref
         double* b = B + col * ldb;
         for (int i = tid; i < r; i += 256) bs[i] = b[i];
         __syncthreads();
+        if (r <= 256 * APQ_EPT + 1) {
+            // short columns (the n x n second-stage factor of the two-stage form, n <= 2049): the reflector of the NEXT step is
+            // loaded into registers while this one is applied, and is read once for dot and update -- a step was the latency of
+            // two dependent loads from L2 plus three barriers (2.5 us; 5.1 ms for the 2000 reflectors of a solve)
+            double vn[APQ_EPT];
+            auto load_v = [&](int k, double (&dst)[APQ_EPT]) {
+                const double* v = QR + (int64_t)k * lda;
+#pragma unroll
+                for (int e = 0; e < APQ_EPT; ++e) { const int i = k + 1 + tid + 256 * e; dst[e] = v[i < r ? i : r - 1]; }
+            };
+            int kn = transpose ? 0 : nrefl - 1;
+            double taun = nrefl > 0 ? hcoeffs[kn] : 0.0;
+            if (nrefl > 0) load_v(kn, vn);
+            for (int s = 0; s < nrefl; ++s) {
+                const int k = kn;
+                const double tau = taun;
+                double vc[APQ_EPT];
+#pragma unroll
+                for (int e = 0; e < APQ_EPT; ++e) vc[e] = (k + 1 + tid + 256 * e < r) ? vn[e] : 0.0;
+                if (s + 1 < nrefl) { kn = transpose ? s + 1 : nrefl - 2 - s; taun = hcoeffs[kn]; load_v(kn, vn); }
+                const double xk = bs[k];
+                double part = 0.0;
+#pragma unroll
+                for (int e = 0; e < APQ_EPT; ++e) { const int i = k + 1 + tid + 256 * e; part = fma(vc[e], bs[i < r ? i : r - 1], part); }
+                part = dq_wave_sum(part);
+                if ((tid & 63) == 0) red[tid >> 6] = part;
+                __syncthreads();
+                const double tt = tau * (red[0] + red[1] + red[2] + red[3] + xk);
+                if (tid == 0) bs[k] = xk - tt;
+#pragma unroll
+                for (int e = 0; e < APQ_EPT; ++e) { const int i = k + 1 + tid + 256 * e; if (i < r) bs[i] = fma(-tt, vc[e], bs[i]); }
+                __syncthreads();
+            }
+        } else
         for (int s = 0; s < nrefl; ++s) {
             const int k = transpose ? s : nrefl - 1 - s;
             const double tau = hcoeffs[k];
