@@ -41,11 +41,15 @@ struct Work {
     State* st;
 };
 
+// Sum over the 64 lanes, the same value in every lane: four DPP steps inside the rows of 16, then the four row sums through
+// SGPRs (a fixed order; no LDS round trips -- a step of this kernel is a chain of such reductions).
 __device__ __forceinline__ double wave_sum(double v)
 {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
-    return v;
+    v += dpp_f64<0xB1>(v);    // quad_perm [1,0,3,2]
+    v += dpp_f64<0x4E>(v);    // quad_perm [2,3,0,1]
+    v += dpp_f64<0x141>(v);   // row_half_mirror
+    v += dpp_f64<0x140>(v);   // row_mirror
+    return (readlane_f64(v, 0) + readlane_f64(v, 16)) + (readlane_f64(v, 32) + readlane_f64(v, 48));
 }
 
 __global__ void __launch_bounds__(TT)
@@ -102,11 +106,21 @@ cols_step_kernel(double* __restrict__ A, int64_t lda, int r, int c, int k, int p
             const int cc = w.cmap[b][pos];
             if (v > best) { best = v; bi = pos; bc = cc; }
         }
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) {
-            const double ob = __shfl_xor(best, off);
-            const int oi = __shfl_xor(bi, off), oc = __shfl_xor(bc, off);
-            if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; bc = oc; }
+        {   // the wave's first maximum without LDS round trips: the maximum by DPP steps and four readlanes, the smallest position among
+            // the lanes that hold it the same way, its physical column from the lane a ballot names
+            double m = row16_max(best);
+            m = fmax(fmax(readlane_f64(m, 0), readlane_f64(m, 16)), fmax(readlane_f64(m, 32), readlane_f64(m, 48)));
+            int p = best == m ? bi : 0x7fffffff;
+            p = min(p, dpp_i32<0xB1>(p));
+            p = min(p, dpp_i32<0x4E>(p));
+            p = min(p, dpp_i32<0x141>(p));
+            p = min(p, dpp_i32<0x140>(p));
+            p = min(min(__builtin_amdgcn_readlane(p, 0), __builtin_amdgcn_readlane(p, 16)),
+                    min(__builtin_amdgcn_readlane(p, 32), __builtin_amdgcn_readlane(p, 48)));
+            const unsigned long long who = __ballot(best == m && bi == p);
+            const int src = who ? (int)__builtin_ctzll(who) : 0;             // (no lane: NaN norms; any lane will do)
+            bc = __builtin_amdgcn_readlane(bc, src);
+            best = m; bi = p;
         }
         if (lane == 0) { red[wave] = best; ired[wave] = bi; cred[wave] = bc; }
         __syncthreads();
