@@ -159,12 +159,6 @@ cols_step_kernel(double* __restrict__ A, int64_t lda, int r, int c, int k, int p
     }
     const double a2 = pivoting ? (k == 0 ? best : a2_in) : (k == 0 ? fma(xk, xk, tsq) : a2_in);
     if (blockIdx.x == 0) {
-        if (pivoting) {
-            // decision (1): another live column within the error margin of the chosen one
-            bool nr = false;
-            for (int pos = k + tid; pos < c; pos += TT) nr = nr || (pos != P && near_best(w.nu2[b][pos], w.thr[b][pos], best, a2));
-            if (nr) atomicOr(&w.st->unclear, 1);
-        }
         if (tid == 0) {
             if (k == 0) w.st->a2 = a2;
             w.beta[k] = -nb;
@@ -209,7 +203,11 @@ cols_step_kernel(double* __restrict__ A, int64_t lda, int r, int c, int k, int p
         if (lane == 0) {
             col[k] = an;                                          // row k of R
             if (pivoting) {
-                nn = fma(-an, an, w.nu2[b][sp]); th = w.thr[b][sp];
+                const double nu_old = w.nu2[b][sp];
+                th = w.thr[b][sp];
+                // decision (1): this column within the error margin of the chosen one (every remaining column has its wave here)
+                if (near_best(nu_old, th, best, a2)) atomicOr(&w.st->unclear, 1);
+                nn = fma(-an, an, nu_old);
                 if (nn <= th) {                                   // LAWN-176: recompute from the updated column (which is right here)
                     if (in_recompute_band(nn, th, a2)) atomicOr(&w.st->unclear, 2);    // decision (2)
                     nn = sq; th = sq * THR_HI;
@@ -247,7 +245,10 @@ cols_step_kernel(double* __restrict__ A, int64_t lda, int r, int c, int k, int p
         if (lane == 0) {
             col[k] = an;
             if (pivoting) {
-                nn = fma(-an, an, w.nu2[b][sp]); th = w.thr[b][sp];
+                const double nu_old = w.nu2[b][sp];
+                th = w.thr[b][sp];
+                if (near_best(nu_old, th, best, a2)) atomicOr(&w.st->unclear, 1);      // decision (1)
+                nn = fma(-an, an, nu_old);
                 if (nn <= th) {
                     if (in_recompute_band(nn, th, a2)) atomicOr(&w.st->unclear, 2);
                     nn = sq; th = sq * THR_HI;
