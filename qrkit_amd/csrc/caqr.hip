@@ -40,6 +40,10 @@ constexpr int SR = NB * FAN;    // virtual rows of a slab
 constexpr int LS = NB + 1;      // LDS row stride (doubles): conflict-free by rows and by columns
 constexpr size_t PANEL_LDS = (size_t)(SR * LS + 2 * FAN * NB + FAN + 2 * NB + 1) * sizeof(double);            // 72 KB: fits where an apply workgroup (76 KB) was
 constexpr size_t APPLY_LDS = (size_t)(SR * LS + NB * LS) * sizeof(double);                                            // 76 KB
+// LDS asked for by the apply launch that runs BESIDE the factorisation of the next panel (look-ahead): more than half a CU's 160 KB,
+// so that one apply workgroup per CU is resident and a panel workgroup (72 KB, 240 VGPRs) finds room at once instead of waiting
+// for one of two apply workgroups to finish
+constexpr size_t APPLY_LDS_BESIDE = 86 * 1024;
 
 // Slab t of a level: chunk i of it is chunk  p + stride (FAN t + i)  of the matrix (rows 32 chunk .. 32 chunk + 31).
 struct Slab {
@@ -570,7 +574,8 @@ size_t caqr_t_bytes(int m, int n)
 
 // One panel: factorise level by level, then (ncols > 0) apply the block reflectors of every level to C.
 static hipError_t caqr_panel_levels(double* A, int64_t lda, int m, int p, int w, double* Tbuf, const CaqrShape& s, bool factorize,
-                                    int transpose, double* C, int64_t ldc, int ncols, bool reverse, hipStream_t stream)
+                                    int transpose, double* C, int64_t ldc, int ncols, bool reverse, hipStream_t stream,
+                                    size_t apply_lds = caqr::APPLY_LDS)
 {
     using namespace caqr;
     {
@@ -578,8 +583,8 @@ static hipError_t caqr_panel_levels(double* A, int64_t lda, int m, int p, int w,
         static hipError_t attr = [] {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(caqr_panel_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)PANEL_LDS);
             if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(caqr_panel_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)PANEL_LDS);
-            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(caqr_apply_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)APPLY_LDS);
-            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(caqr_apply_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)APPLY_LDS);
+            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(caqr_apply_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)APPLY_LDS_BESIDE);
+            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(caqr_apply_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)APPLY_LDS_BESIDE);
             return e;
         }();
         if (attr != hipSuccess) return attr;
@@ -620,9 +625,9 @@ static hipError_t caqr_panel_levels(double* A, int64_t lda, int m, int p, int w,
                                         transpose, C, ldc, ncols);
                 continue;
             }
-            if (l == 0) hipLaunchKernelGGL((caqr_apply_kernel<false>), dim3(S, cg), dim3(APPLY_T), APPLY_LDS, stream, A, lda, m, pc, w, sl,
+            if (l == 0) hipLaunchKernelGGL((caqr_apply_kernel<false>), dim3(S, cg), dim3(APPLY_T), apply_lds, stream, A, lda, m, pc, w, sl,
                                            tptr(l), transpose, C, ldc, ncols, cols_per_wg);
-            else hipLaunchKernelGGL((caqr_apply_kernel<true>), dim3(S, cg), dim3(APPLY_T), APPLY_LDS, stream, A, lda, m, pc, w, sl,
+            else hipLaunchKernelGGL((caqr_apply_kernel<true>), dim3(S, cg), dim3(APPLY_T), apply_lds, stream, A, lda, m, pc, w, sl,
                                     tptr(l), transpose, C, ldc, ncols, cols_per_wg);
         }
     }
@@ -658,8 +663,10 @@ hipError_t launch_caqr_factorize(double* A, int64_t lda, int m, int n, double* T
             if ((e = caqr_panel_levels(A, lda, m, p + 1, w1, Tbuf, s, true, 1, nullptr, lda, 0, false, side)) != hipSuccess) return e;
             if ((e = hipEventRecord(ev_factored, side)) != hipSuccess) return e;
         }
+        static const bool beside = !(std::getenv("QRK_CAQR_BESIDE") && std::getenv("QRK_CAQR_BESIDE")[0] == '0');
         if (nrest > 0 &&
-            (e = caqr_panel_levels(A, lda, m, p, w, Tbuf, s, false, 1, A + (int64_t)(pc1 + w1) * lda, lda, nrest, false, stream)) != hipSuccess)
+            (e = caqr_panel_levels(A, lda, m, p, w, Tbuf, s, false, 1, A + (int64_t)(pc1 + w1) * lda, lda, nrest, false, stream,
+                                   w1 > 0 && beside ? caqr::APPLY_LDS_BESIDE : caqr::APPLY_LDS)) != hipSuccess)
             return e;
         if (w1 > 0 && (e = hipStreamWaitEvent(stream, ev_factored, 0)) != hipSuccess) return e;
     }
