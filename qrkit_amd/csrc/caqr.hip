@@ -462,6 +462,144 @@ caqr_apply_kernel(const double* __restrict__ A, int64_t lda, int m, int pc, int 
     }
 }
 
+// The same for a NARROW C (5 ... 32 columns: the columns of the next panel, which the look-ahead needs before anything else -- this launch
+// sits on the loop-carried chain of the first stage, four of them per panel).  The kernel above gives a 16-column tile to ONE wave, which
+// then walks the 8 chunks of the slab with one load in flight: 25 us per launch whatever the level.  Here wave w takes chunk w: the
+// partial W of the chunks go through LDS and are added in a fixed order by every wave, and each wave updates the rows of its own chunk.
+constexpr size_t NARROW_LDS = APPLY_LDS + (size_t)FAN * 2 * 8 * 64 * sizeof(double);       // + 64 KB of partial sums
+template <bool TRI>
+__global__ void __launch_bounds__(APPLY_T)
+caqr_apply_narrow_kernel(const double* __restrict__ A, int64_t lda, int m, int pc, int w, Slab sl, const double* __restrict__ Tin,
+                         int transpose, double* __restrict__ C, int64_t ldc, int ncols)
+{
+    extern __shared__ __attribute__((aligned(16))) double caqr_lds[];
+    double* ys = caqr_lds;              // [SR][LS]
+    double* ts = ys + SR * LS;          // [NB][LS]
+    double* part = ts + NB * LS;        // [FAN][2][8][64]
+    const int t = blockIdx.x;
+    const int tid = threadIdx.x;
+    int cnt = sl.nchunks - FAN * t;
+    cnt = cnt > FAN ? FAN : cnt;
+    {
+        const int x = tid & 31, y = (tid >> 5) & (FAN - 1), ch = tid >> 8;
+        const int64_t row0 = chunk_row0(sl, t, y);
+        const int nr = y < cnt ? chunk_rows(row0, m) : 0;
+        const double* src = A + (int64_t)pc * lda + row0 + x;
+        double raw[NB / 2];
+#pragma unroll
+        for (int q = 0; q < NB / 2; ++q) {
+            const int cc = ch * (NB / 2) + q;
+            const bool need = cc < w && x < nr && (y == 0 ? (!TRI && x > cc) : (!TRI || x <= cc));
+            raw[q] = *(need ? src + (int64_t)cc * lda : A);
+        }
+#pragma unroll
+        for (int q = 0; q < NB / 2; ++q) {
+            const int cc = ch * (NB / 2) + q;
+            const bool need = cc < w && x < nr && (y == 0 ? (!TRI && x > cc) : (!TRI || x <= cc));
+            const double v = need ? raw[q] : ((cc < w && x < nr && y == 0 && x == cc) ? 1.0 : 0.0);
+            ys[(y * NB + x) * LS + cc] = v;
+        }
+        for (int e = tid; e < NB * NB; e += APPLY_T) ts[(e >> 5) * LS + (e & 31)] = Tin[(int64_t)t * (NB * NB) + e];
+    }
+    const int wave = tid >> 6, lane = tid & 63, kq = lane >> 4, l15 = lane & 15;
+    const int ci = wave;                                  // this wave's chunk
+    const bool active = ci < cnt;
+    const int ntile = (ncols + 15) >> 4;                  // 1 or 2
+    const int64_t crow0 = chunk_row0(sl, t, active ? ci : 0);
+    const int cnr = active ? chunk_rows(crow0, m) : 0;
+    // ---- the C entries of this chunk, for W (B-operand order: slot k = row 16 (k >> 2) + 4 kq + (k & 3)): in flight during the staging
+    double bv[2][8];
+#pragma unroll
+    for (int tile = 0; tile < 2; ++tile) {
+        const int col = 16 * tile + l15;
+        const bool cok = tile < ntile && col < ncols;
+        const double* cb = C + (int64_t)(cok ? col : 0) * ldc + crow0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int rr = 16 * (k >> 2) + 4 * kq + (k & 3);
+            const bool in = cok && rr < cnr;
+            const double v = *(in ? cb + rr : C);
+            bv[tile][k] = in ? v : 0.0;
+        }
+    }
+    __syncthreads();
+    // ---- partial W = Y_chunk^T C_chunk
+#pragma unroll
+    for (int tile = 0; tile < 2; ++tile) {
+        d4 acc0 = d4{0.0, 0.0, 0.0, 0.0}, acc1 = d4{0.0, 0.0, 0.0, 0.0};
+        if (active && tile < ntile) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int vrow = ci * NB + 16 * (k >> 2) + 4 * kq + (k & 3);
+                acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(ys[vrow * LS + l15], bv[tile][k], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ys[vrow * LS + 16 + l15], bv[tile][k], acc1, 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int z = 0; z < 4; ++z) {
+            part[((wave * 2 + tile) * 8 + z) * 64 + lane] = acc0[z];
+            part[((wave * 2 + tile) * 8 + 4 + z) * 64 + lane] = acc1[z];
+        }
+    }
+    __syncthreads();
+    // ---- W (the chunks added in a fixed order), W' = -(T^T or T) W: by every wave for itself
+    d4 u0[2], u1[2];
+#pragma unroll
+    for (int tile = 0; tile < 2; ++tile) {
+        d4 acc0 = d4{0.0, 0.0, 0.0, 0.0}, acc1 = d4{0.0, 0.0, 0.0, 0.0};
+        for (int cw = 0; cw < cnt; ++cw) {
+#pragma unroll
+            for (int z = 0; z < 4; ++z) {
+                acc0[z] += part[((cw * 2 + tile) * 8 + z) * 64 + lane];
+                acc1[z] += part[((cw * 2 + tile) * 8 + 4 + z) * 64 + lane];
+            }
+        }
+        d4 a0 = d4{0.0, 0.0, 0.0, 0.0}, a1 = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            const double bw = ks < 4 ? acc0[ks & 3] : acc1[ks & 3];
+            const int kk = 4 * ks + kq;
+            const double t0 = transpose ? ts[kk * LS + l15] : ts[l15 * LS + kk];
+            const double t1 = transpose ? ts[kk * LS + 16 + l15] : ts[(16 + l15) * LS + kk];
+            a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(t0, bw, a0, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(t1, bw, a1, 0, 0, 0);
+        }
+        u0[tile] = -a0; u1[tile] = -a1;
+    }
+    // ---- C_chunk += Y_chunk W' (as C^T += W'^T Y^T: D[column kq + 4 z][row l15]), the two 16-row tiles of this wave's chunk
+    if (active) {
+#pragma unroll
+        for (int tile = 0; tile < 2; ++tile) {
+            if (tile >= ntile) break;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int rr = 16 * h + l15;
+                const bool rok = rr < cnr;
+                double* cp = C + crow0 + rr;
+                d4 dv;
+#pragma unroll
+                for (int z = 0; z < 4; ++z) {
+                    const int colz = 16 * tile + kq + 4 * z;
+                    const bool in = rok && colz < ncols;
+                    const double v = *(in ? cp + (int64_t)colz * ldc : C);
+                    dv[z] = in ? v : 0.0;
+                }
+                const int vrow = ci * NB + rr;
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) {
+                    const double aw = ks < 4 ? u0[tile][ks & 3] : u1[tile][ks & 3];
+                    dv = __builtin_amdgcn_mfma_f64_16x16x4f64(aw, ys[vrow * LS + 4 * ks + kq], dv, 0, 0, 0);
+                }
+#pragma unroll
+                for (int z = 0; z < 4; ++z) {
+                    const int colz = 16 * tile + kq + 4 * z;
+                    if (rok && colz < ncols) cp[(int64_t)colz * ldc] = dv[z];
+                }
+            }
+        }
+    }
+}
+
 // The same block reflectors applied to a few vectors (the right-hand side of a solve: C has 1 ... VEC_MAX columns).  The MFMA kernel
 // above stages Y densely in LDS for tiles of 16 columns and takes 25-30 us per launch whatever the width; here thread (x, y) of the
 // 256 keeps row x of chunk y of Y in 32 registers and one entry of each vector: w = Y^T c through LDS (two passes of 16 columns,
@@ -585,6 +723,8 @@ static hipError_t caqr_panel_levels(double* A, int64_t lda, int m, int p, int w,
             if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(caqr_panel_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)PANEL_LDS);
             if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(caqr_apply_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)APPLY_LDS_BESIDE);
             if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(caqr_apply_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)APPLY_LDS_BESIDE);
+            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(caqr_apply_narrow_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)NARROW_LDS);
+            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(caqr_apply_narrow_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)NARROW_LDS);
             return e;
         }();
         if (attr != hipSuccess) return attr;
@@ -623,6 +763,13 @@ static hipError_t caqr_panel_levels(double* A, int64_t lda, int m, int p, int w,
                                                transpose, C, ldc, ncols);
                 else hipLaunchKernelGGL((caqr_apply_vec_kernel<true>), dim3(S), dim3(256), 0, stream, A, lda, m, pc, w, sl, tptr(l),
                                         transpose, C, ldc, ncols);
+                continue;
+            }
+            if (ncols <= 32 && !std::getenv("QRK_CAQR_NO_NARROW")) {       // the columns of the next panel: a wave per chunk
+                if (l == 0) hipLaunchKernelGGL((caqr_apply_narrow_kernel<false>), dim3(S), dim3(APPLY_T), NARROW_LDS, stream, A, lda, m, pc, w,
+                                               sl, tptr(l), transpose, C, ldc, ncols);
+                else hipLaunchKernelGGL((caqr_apply_narrow_kernel<true>), dim3(S), dim3(APPLY_T), NARROW_LDS, stream, A, lda, m, pc, w, sl,
+                                        tptr(l), transpose, C, ldc, ncols);
                 continue;
             }
             if (l == 0) hipLaunchKernelGGL((caqr_apply_kernel<false>), dim3(S, cg), dim3(APPLY_T), apply_lds, stream, A, lda, m, pc, w, sl,
