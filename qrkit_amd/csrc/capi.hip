@@ -119,6 +119,7 @@ struct qrk_dense_plan_s {
     void* d_ws2 = nullptr;
     hipStream_t la_stream = nullptr;               // look-ahead of the first stage: the next panel is factorised beside the trailing update
     hipEvent_t la_urgent = nullptr, la_factored = nullptr;
+    qrk::CaqrPipe la_pipe;                         // third stream + events of the look-ahead pipelined by levels (QRK_CAQR_PIPE=0: off)
     int G2 = 0, cpad2 = 0, rows_per2 = 0;
     bool tall2 = false, cols2 = false;
     bool exact_wide = false;   // large block: the exact path runs as a host-launched sequence over all CUs (the host reads the unclear word)
@@ -917,6 +918,17 @@ qrk_status qrk_dense_plan_create(qrk_handle h, int32_t rows, int32_t cols, qrk_b
             qrk_dense_plan_destroy(p);
             return fail(h, QRK_STATUS_ALLOC_FAILED, "qrk_dense_plan_create: cannot create the look-ahead stream");
         }
+        const char* pe = std::getenv("QRK_CAQR_PIPE");
+        if (p->la_stream && !(pe && pe[0] == '0')) {
+            bool ok = hipStreamCreateWithPriority(&p->la_pipe.urgent, hipStreamNonBlocking, prio_greatest) == hipSuccess &&
+                      hipEventCreateWithFlags(&p->la_pipe.ev_n2, hipEventDisableTiming) == hipSuccess &&
+                      hipEventCreateWithFlags(&p->la_pipe.ev_u, hipEventDisableTiming) == hipSuccess;
+            for (int l = 0; ok && l < qrk::CaqrPipe::MAXL; ++l) ok = hipEventCreateWithFlags(&p->la_pipe.ev_lvl[l], hipEventDisableTiming) == hipSuccess;
+            if (!ok) {
+                qrk_dense_plan_destroy(p);
+                return fail(h, QRK_STATUS_ALLOC_FAILED, "qrk_dense_plan_create: cannot create the streams of the pipelined look-ahead");
+            }
+        }
     }
     // exact path: a copy of the input, the flag of the single-workgroup kernel, the exact kernel's workspace
     if (hipMalloc((void**)&p->d_copy, (size_t)rows * (size_t)cols * sizeof(double)) != hipSuccess ||
@@ -936,6 +948,10 @@ qrk_status qrk_dense_plan_destroy(qrk_dense_plan p)
         if (p->la_stream) (void)hipStreamDestroy(p->la_stream);
         if (p->la_urgent) (void)hipEventDestroy(p->la_urgent);
         if (p->la_factored) (void)hipEventDestroy(p->la_factored);
+        if (p->la_pipe.urgent) (void)hipStreamDestroy(p->la_pipe.urgent);
+        if (p->la_pipe.ev_n2) (void)hipEventDestroy(p->la_pipe.ev_n2);
+        if (p->la_pipe.ev_u) (void)hipEventDestroy(p->la_pipe.ev_u);
+        for (int l = 0; l < qrk::CaqrPipe::MAXL; ++l) if (p->la_pipe.ev_lvl[l]) (void)hipEventDestroy(p->la_pipe.ev_lvl[l]);
         (void)hipFree(p->d_t); if (p->d_q1 != p->d_r0) (void)hipFree(p->d_q1); (void)hipFree(p->d_r0); (void)hipFree(p->d_ws2);
     }
     delete p;
@@ -972,7 +988,8 @@ qrk_status qrk_dense_factorize(qrk_dense_plan p, double* a, int64_t lda, double*
             // stage 1: A = Q0 R0 (no pivoting, MFMA trailing updates); stage 2: R0 P = Q1 R on the n x n triangle
             const int n = p->cols;
             const int piv2 = piv | qrk::decide::PIVOTING_SIGN_FREE;      // R is Eigen's up to the signs of its rows either way
-            QRK_HIP(h, qrk::launch_caqr_factorize(da, lda, p->rows, n, p->d_t, h->stream, p->la_stream, p->la_urgent, p->la_factored));
+            QRK_HIP(h, qrk::launch_caqr_factorize(da, lda, p->rows, n, p->d_t, h->stream, p->la_stream, p->la_urgent, p->la_factored,
+                                                  p->la_pipe.urgent ? &p->la_pipe : nullptr));
             QRK_HIP(h, qrk::launch_caqr_copy_upper(da, lda, p->d_r0, n, n, 1, h->stream));
             if (p->cols2) {
                 QRK_HIP(h, qrk::launch_dense_qr_cols(p->d_r0, n, n, n, piv2, dhc, dp, p->d_ws2, p->cpad2, p->d_q1, n, h->stream));

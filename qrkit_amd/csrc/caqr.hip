@@ -713,7 +713,7 @@ size_t caqr_t_bytes(int m, int n)
 // One panel: factorise level by level, then (ncols > 0) apply the block reflectors of every level to C.
 static hipError_t caqr_panel_levels(double* A, int64_t lda, int m, int p, int w, double* Tbuf, const CaqrShape& s, bool factorize,
                                     int transpose, double* C, int64_t ldc, int ncols, bool reverse, hipStream_t stream,
-                                    size_t apply_lds = caqr::APPLY_LDS)
+                                    size_t apply_lds = caqr::APPLY_LDS, int only_level = -1)
 {
     using namespace caqr;
     {
@@ -740,6 +740,7 @@ static hipError_t caqr_panel_levels(double* A, int64_t lda, int m, int p, int w,
     auto tptr = [&](int l) { return Tbuf + ((size_t)p * s.LMAX + l) * (size_t)s.S0 * (NB * NB); };
     if (factorize) {
         for (int l = 0; l < nlev; ++l) {
+            if (only_level >= 0 && l != only_level) continue;
             const Slab sl{p, strides[l], Ks[l]};
             const int S = (Ks[l] + FAN - 1) / FAN;
             if (l == 0) hipLaunchKernelGGL((caqr_panel_kernel<false>), dim3(S), dim3(256), PANEL_LDS, stream, A, lda, m, pc, w, sl, tptr(l));
@@ -749,6 +750,7 @@ static hipError_t caqr_panel_levels(double* A, int64_t lda, int m, int p, int w,
     if (ncols > 0) {
         for (int li = 0; li < nlev; ++li) {
             const int l = reverse ? nlev - 1 - li : li;
+            if (only_level >= 0 && l != only_level) continue;
             const Slab sl{p, strides[l], Ks[l]};
             const int S = (Ks[l] + FAN - 1) / FAN;
             // columns per workgroup: up to 128 (the Y of the slab is loaded once per workgroup), fewer when the level has few slabs,
@@ -786,12 +788,96 @@ static hipError_t caqr_panel_levels(double* A, int64_t lda, int m, int p, int w,
 // With a side stream and two events (look-ahead): the reflectors of panel p are applied to the columns of panel p + 1 first; panel
 // p + 1 is then factorised on the side stream (a few hundred workgroups at most, one wave per SIMD: latency-bound) WHILE the caller's
 // stream applies panel p to the rest of the trailing matrix (disjoint columns, the Y / T of panel p only read).
+// Levels of the reduction tree of panel p
+static int caqr_num_levels(const CaqrShape& s, int p)
+{
+    int nlev = 0;
+    for (int K = s.NC - p;;) {
+        ++nlev;
+        const int S = (K + caqr::FAN - 1) / caqr::FAN;
+        if (S <= 1) break;
+        K = S;
+    }
+    return nlev;
+}
+
+// The look-ahead pipelined by LEVELS (three streams).  The loop-carried chain of the plain look-ahead is: apply panel p to the columns
+// of panel p + 1 (all levels) -> factorise panel p + 1 (all levels).  But level l of the apply only needs level l of the
+// factorisation, so here:
+//   side   : factorise panel q level by level, an event after each level but the last; then apply the LAST level to the columns of
+//            panel q + 1 itself, so that the factorisation of panel q + 1 follows on the same stream;
+//   urgent : as each earlier level of panel q is done, apply it to the columns of panel q + 1 -- beside the factorisation of the
+//            next level (those columns must have seen panel q - 1 first: the caller's stream applies every panel to the columns
+//            of the panel after the next FIRST and records an event);
+//   stream : apply panel q - 1 to the columns of panel q + 1, then to the rest.
+// The chain becomes: factorise the levels of q -> apply the last level to the columns of q + 1 -> factorise q + 1, all on one stream.
+static hipError_t caqr_factorize_pipelined(double* A, int64_t lda, int m, int n, double* Tbuf, const CaqrShape& s, hipStream_t M,
+                                           hipStream_t S, const CaqrPipe& pp, hipEvent_t ev_urgent)
+{
+    using namespace caqr;
+    auto width = [&](int p) { const int pc = p * NB; return p < s.NP ? (n - pc < NB ? n - pc : NB) : 0; };
+    auto col = [&](int p) { return A + (int64_t)p * NB * lda; };
+    hipError_t e;
+    static const bool beside = !(std::getenv("QRK_CAQR_BESIDE") && std::getenv("QRK_CAQR_BESIDE")[0] == '0');
+#define QRK_E(x) do { if ((e = (x)) != hipSuccess) return e; } while (0)
+    // panel 0 on the caller's stream, and its reflectors on the columns of panel 1
+    QRK_E(caqr_panel_levels(A, lda, m, 0, width(0), Tbuf, s, true, 1, nullptr, lda, 0, false, M));
+    if (width(1) > 0) QRK_E(caqr_panel_levels(A, lda, m, 0, width(0), Tbuf, s, false, 1, col(1), lda, width(1), false, M));
+    QRK_E(hipEventRecord(ev_urgent, M));
+    for (int p = 0; p < s.NP; ++p) {
+        const int w = width(p), w1 = width(p + 1), w2 = width(p + 2);
+        const int nlev1 = w1 > 0 ? caqr_num_levels(s, p + 1) : 0;
+        // (1) panel p is complete (p >= 1: its last level was recorded on the side stream in the previous iteration)
+        if (p > 0) QRK_E(hipStreamWaitEvent(M, pp.ev_lvl[caqr_num_levels(s, p) - 1], 0));
+        // (3) caller's stream: panel p on the columns of panel p + 2, first
+        if (w2 > 0) QRK_E(caqr_panel_levels(A, lda, m, p, w, Tbuf, s, false, 1, col(p + 2), lda, w2, false, M));
+        QRK_E(hipEventRecord(pp.ev_n2, M));
+        if (w1 > 0) {
+            // (2a) side: panel p + 1, level by level (its columns have seen every level of panel p: the previous iteration of this
+            // stream, or the prologue); an event after every level but the last
+            if (p == 0) QRK_E(hipStreamWaitEvent(S, ev_urgent, 0));
+            for (int l = 0; l < nlev1; ++l) {
+                QRK_E(caqr_panel_levels(A, lda, m, p + 1, w1, Tbuf, s, true, 1, nullptr, lda, 0, false, S, APPLY_LDS, l));
+                if (l + 1 < nlev1) QRK_E(hipEventRecord(pp.ev_lvl[l], S));
+            }
+            if (w2 > 0) {
+                // (4) urgent: every level but the last on the columns of panel p + 2, as soon as it exists (beside the next level)
+                if (nlev1 > 1) {
+                    QRK_E(hipStreamWaitEvent(pp.urgent, pp.ev_n2, 0));
+                    for (int l = 0; l + 1 < nlev1; ++l) {
+                        QRK_E(hipStreamWaitEvent(pp.urgent, pp.ev_lvl[l], 0));
+                        QRK_E(caqr_panel_levels(A, lda, m, p + 1, w1, Tbuf, s, false, 1, col(p + 2), lda, w2, false, pp.urgent, APPLY_LDS, l));
+                    }
+                    QRK_E(hipEventRecord(pp.ev_u, pp.urgent));
+                    QRK_E(hipStreamWaitEvent(S, pp.ev_u, 0));
+                }
+                // (2b) the last level on the side stream itself: the next panel's factorisation follows it without a hop between
+                // streams (a hop costs 10-20 us, and this is the loop-carried chain)
+                QRK_E(hipStreamWaitEvent(S, pp.ev_n2, 0));
+                QRK_E(caqr_panel_levels(A, lda, m, p + 1, w1, Tbuf, s, false, 1, col(p + 2), lda, w2, false, S, APPLY_LDS, nlev1 - 1));
+            }
+            QRK_E(hipEventRecord(pp.ev_lvl[nlev1 - 1], S));       // panel p + 1 is complete (and applied to the next one)
+        }
+        // (5) caller's stream: panel p on the rest
+        const int c3 = (p + 3) * NB, nrest = n - c3;
+        if (nrest > 0)
+            QRK_E(caqr_panel_levels(A, lda, m, p, w, Tbuf, s, false, 1, A + (int64_t)c3 * lda, lda, nrest, false, M,
+                                    w1 > 0 && beside ? APPLY_LDS_BESIDE : APPLY_LDS));
+    }
+    // the caller's stream ends after everything: the last panel's levels (side) and the last urgent applies
+    if (s.NP > 1) QRK_E(hipStreamWaitEvent(M, pp.ev_lvl[caqr_num_levels(s, s.NP - 1) - 1], 0));
+#undef QRK_E
+    return hipSuccess;
+}
+
 hipError_t launch_caqr_factorize(double* A, int64_t lda, int m, int n, double* Tbuf, hipStream_t stream, hipStream_t side,
-                                 hipEvent_t ev_urgent, hipEvent_t ev_factored)
+                                 hipEvent_t ev_urgent, hipEvent_t ev_factored, const CaqrPipe* pipe)
 {
     const CaqrShape s = caqr_shape(m, n);
     auto width = [&](int p) { const int pc = p * caqr::NB; return n - pc < caqr::NB ? n - pc : caqr::NB; };
     hipError_t e;
+    if (side && ev_urgent && pipe && pipe->urgent && s.LMAX <= CaqrPipe::MAXL)
+        return caqr_factorize_pipelined(A, lda, m, n, Tbuf, s, stream, side, *pipe, ev_urgent);
     if (!side || !ev_urgent || !ev_factored) {
         for (int p = 0; p < s.NP; ++p) {
             const int pc = p * caqr::NB, w = width(p);

@@ -93,8 +93,16 @@ hipError_t launch_dense_apply_q(const double* QR, int64_t lda, int r, int nrefl,
 // Un-pivoted communication-avoiding QR of a tall matrix on all CUs, MFMA trailing update (caqr.hip): first stage of the pivoted
 // factorisation of tall dense right blocks.  Tbuf: caqr_t_bytes(m, n).
 size_t caqr_t_bytes(int m, int n);
+// third stream and events of the look-ahead pipelined by levels (caqr.hip, caqr_factorize_pipelined); all owned by the caller
+struct CaqrPipe {
+    static constexpr int MAXL = 8;
+    hipStream_t urgent = nullptr;
+    hipEvent_t ev_lvl[MAXL] = {};      // level l of the panel being factorised on the side stream is done
+    hipEvent_t ev_n2 = nullptr;        // the caller's stream has applied panel p to the columns of panel p + 2
+    hipEvent_t ev_u = nullptr;         // the urgent stream has applied every level of panel p + 1 to the columns of panel p + 2
+};
 hipError_t launch_caqr_factorize(double* A, int64_t lda, int m, int n, double* Tbuf, hipStream_t stream, hipStream_t side = nullptr,
-                                 hipEvent_t ev_urgent = nullptr, hipEvent_t ev_factored = nullptr);
+                                 hipEvent_t ev_urgent = nullptr, hipEvent_t ev_factored = nullptr, const CaqrPipe* pipe = nullptr);
 hipError_t launch_caqr_apply(const double* A, int64_t lda, int m, int n, const double* Tbuf, int transpose, double* B, int64_t ldb,
                              int64_t nrhs, hipStream_t stream);
 hipError_t launch_caqr_copy_upper(const double* src, int64_t lds_, double* dst, int64_t ldd, int n, int zero_lower, hipStream_t stream);
