@@ -40,9 +40,10 @@ constexpr int SR = NB * FAN;    // virtual rows of a slab
 constexpr int LS = NB + 1;      // LDS row stride (doubles): conflict-free by rows and by columns
 constexpr size_t PANEL_LDS = (size_t)(SR * LS + 2 * FAN * NB + FAN + 2 * NB + 1) * sizeof(double);            // 72 KB: fits where an apply workgroup (76 KB) was
 constexpr size_t APPLY_LDS = (size_t)(SR * LS + NB * LS) * sizeof(double);                                            // 76 KB
-// LDS asked for by the apply launch that runs BESIDE the factorisation of the next panel (look-ahead): more than half a CU's 160 KB,
-// so that one apply workgroup per CU is resident and a panel workgroup (72 KB, 240 VGPRs) finds room at once instead of waiting
-// for one of two apply workgroups to finish
+// LDS asked for by the apply launch that runs BESIDE the factorisation of the next panel when QRK_CAQR_BESIDE=1: more than half a CU's
+// 160 KB, so that one apply workgroup per CU is resident and a panel workgroup (72 KB, 240 VGPRs) finds room at once instead of waiting
+// for one of two apply workgroups to finish.  Helped the plain look-ahead (level-0 panel 133 -> 93 us, 49.75 -> 49.4 ms), costs the
+// pipelined one, where the caller's stream is on the critical path too (47.4 vs 45.9 ms): off by default
 constexpr size_t APPLY_LDS_BESIDE = 86 * 1024;
 
 // Slab t of a level: chunk i of it is chunk  p + stride (FAN t + i)  of the matrix (rows 32 chunk .. 32 chunk + 31).
@@ -818,7 +819,7 @@ static hipError_t caqr_factorize_pipelined(double* A, int64_t lda, int m, int n,
     auto width = [&](int p) { const int pc = p * NB; return p < s.NP ? (n - pc < NB ? n - pc : NB) : 0; };
     auto col = [&](int p) { return A + (int64_t)p * NB * lda; };
     hipError_t e;
-    static const bool beside = !(std::getenv("QRK_CAQR_BESIDE") && std::getenv("QRK_CAQR_BESIDE")[0] == '0');
+    static const bool beside = std::getenv("QRK_CAQR_BESIDE") && std::getenv("QRK_CAQR_BESIDE")[0] == '1';   // (off: see APPLY_LDS_BESIDE)
 #define QRK_E(x) do { if ((e = (x)) != hipSuccess) return e; } while (0)
     // panel 0 on the caller's stream, and its reflectors on the columns of panel 1
     QRK_E(caqr_panel_levels(A, lda, m, 0, width(0), Tbuf, s, true, 1, nullptr, lda, 0, false, M));
@@ -896,7 +897,7 @@ hipError_t launch_caqr_factorize(double* A, int64_t lda, int m, int n, double* T
             if ((e = caqr_panel_levels(A, lda, m, p + 1, w1, Tbuf, s, true, 1, nullptr, lda, 0, false, side)) != hipSuccess) return e;
             if ((e = hipEventRecord(ev_factored, side)) != hipSuccess) return e;
         }
-        static const bool beside = !(std::getenv("QRK_CAQR_BESIDE") && std::getenv("QRK_CAQR_BESIDE")[0] == '0');
+        static const bool beside = std::getenv("QRK_CAQR_BESIDE") && std::getenv("QRK_CAQR_BESIDE")[0] == '1';   // (off: see APPLY_LDS_BESIDE)
         if (nrest > 0 &&
             (e = caqr_panel_levels(A, lda, m, p, w, Tbuf, s, false, 1, A + (int64_t)(pc1 + w1) * lda, lda, nrest, false, stream,
                                    w1 > 0 && beside ? caqr::APPLY_LDS_BESIDE : caqr::APPLY_LDS)) != hipSuccess)
