@@ -675,14 +675,14 @@ class BandedBlockedSparseQR {
 // with Q and the triangular solve move only their vectors.  Shared by the thin solvers and the angular right block.
 class DenseDeviceQR {
   public:
-    DenseDeviceQR() : m_h(0), m_plan(0), m_dqr(0), m_dhc(0), m_dperm(0), m_rows(0), m_cols(0) {}
+    DenseDeviceQR() : m_h(0), m_plan(0), m_dqr(0), m_dhc(0), m_dperm(0), m_rows(0), m_cols(0), m_solver(-1) {}
     ~DenseDeviceQR() { release(); }
     DenseDeviceQR(const DenseDeviceQR&) = delete;
     DenseDeviceQR& operator=(const DenseDeviceQR&) = delete;
     // a: in the matrix, out the packed QR (R above the diagonal, essential parts below); hc: tau; perm: column permutation
     void factorize(qrk_handle h, Matrix& a, int solver, std::vector<double>& hc, std::vector<int32_t>& perm) {
         release();
-        m_h = h; m_rows = a.rows(); m_cols = a.cols();
+        m_h = h; m_rows = a.rows(); m_cols = a.cols(); m_solver = solver;
         const Index k = std::min(m_rows, m_cols);
         check(qrk_dense_plan_create(m_h, (int32_t)m_rows, (int32_t)m_cols, (qrk_block_solver)solver, &m_plan));
         hc.assign((size_t)std::max<Index>(k, 1), 0.0);
@@ -703,18 +703,32 @@ class DenseDeviceQR {
     // the same for a matrix that is already on the device (rows x cols, leading dimension rows): the buffer becomes the solver's own
     // (freed by release()); only tau and the permutation travel to the host
     void factorizeDevice(qrk_handle h, void* d_a, Index rows, Index cols, int solver, std::vector<double>& hc, std::vector<int32_t>& perm) {
-        release();
-        m_h = h; m_rows = rows; m_cols = cols; m_dqr = d_a;
+        // (the plan - workspaces of the size of the matrix, streams, events - and the small buffers are kept from one factorisation
+        //  to the next when the shape is the same: an LM loop calls compute() with one shape)
+        const bool same = m_plan && m_h == h && m_rows == rows && m_cols == cols && m_solver == solver;
+        if (same) { if (m_dqr) qrk_device_free(m_h, m_dqr); }
+        else release();
+        m_h = h; m_rows = rows; m_cols = cols; m_dqr = d_a; m_solver = solver;
         const Index k = std::min(m_rows, m_cols);
-        check(qrk_dense_plan_create(m_h, (int32_t)m_rows, (int32_t)m_cols, (qrk_block_solver)solver, &m_plan));
         hc.assign((size_t)std::max<Index>(k, 1), 0.0);
         perm.assign((size_t)std::max<Index>(m_cols, 1), 0);
-        check(qrk_device_alloc(m_h, (int64_t)(hc.size() * sizeof(double)), &m_dhc));
-        check(qrk_device_alloc(m_h, (int64_t)(perm.size() * sizeof(int32_t)), &m_dperm));
+        if (!same) {
+            check(qrk_dense_plan_create(m_h, (int32_t)m_rows, (int32_t)m_cols, (qrk_block_solver)solver, &m_plan));
+            check(qrk_device_alloc(m_h, (int64_t)(hc.size() * sizeof(double)), &m_dhc));
+            check(qrk_device_alloc(m_h, (int64_t)(perm.size() * sizeof(int32_t)), &m_dperm));
+        }
         qrk_status st = qrk_dense_factorize(m_plan, (double*)m_dqr, m_rows, (double*)m_dhc, (int32_t*)m_dperm, QRK_MEM_DEVICE);
         if (st == QRK_STATUS_OK) st = qrk_memcpy(m_h, hc.data(), m_dhc, (int64_t)(hc.size() * sizeof(double)), 1);
         if (st == QRK_STATUS_OK) st = qrk_memcpy(m_h, perm.data(), m_dperm, (int64_t)(perm.size() * sizeof(int32_t)), 1);
         check(st);
+    }
+    // a device buffer for a rows x cols matrix to hand to factorizeDevice: the one of the last factorisation when the shape is the same
+    void* acquireBuffer(qrk_handle h, Index rows, Index cols) {
+        if (m_dqr && m_h == h && m_rows == rows && m_cols == cols) { void* p = m_dqr; m_dqr = 0; return p; }
+        void* p = 0;
+        if (qrk_device_alloc(h, std::max<int64_t>((int64_t)rows * cols * (int64_t)sizeof(double), 8), &p) != QRK_STATUS_OK)
+            throw std::runtime_error(std::string("qrkit: ") + qrk_last_error(h));
+        return p;
     }
     const double* packedDevice() const { return (const double*)m_dqr; }      // R in the upper triangle of its first cols rows
     const int32_t* permDevice() const { return (const int32_t*)m_dperm; }     // (after factorizeDevice)
@@ -766,6 +780,7 @@ class DenseDeviceQR {
     qrk_dense_plan m_plan;
     void* m_dqr; void* m_dhc; void* m_dperm;
     Index m_rows, m_cols;
+    int m_solver;
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -905,7 +920,13 @@ class BlockAngularSparseQR {
         if (qrk_create(&m_handle, device, 0) != QRK_STATUS_OK)
             throw std::runtime_error(std::string("qrkit: ") + qrk_last_error(0));
     }
-    ~BlockAngularSparseQR() { m_dense.release(); if (m_dS) qrk_device_free(m_handle, m_dS); if (m_handle) qrk_destroy(m_handle); }
+    ~BlockAngularSparseQR() {
+        m_dense.release();
+        if (m_dS) qrk_device_free(m_handle, m_dS);
+        if (m_dTop.p) qrk_device_free(m_handle, m_dTop.p);
+        if (m_dT.p) qrk_device_free(m_handle, m_dT.p);
+        if (m_handle) qrk_destroy(m_handle);
+    }
     BlockAngularSparseQR(const BlockAngularSparseQR&) = delete;
     BlockAngularSparseQR& operator=(const BlockAngularSparseQR&) = delete;
 
@@ -1035,16 +1056,19 @@ class BlockAngularSparseQR {
         for (Index r = 0; r < m_n1; ++r) m_rowPerm.indices()[(size_t)r] = rp[(size_t)r];
         void* dBottom = 0;
         {
-            DBuf dTop(*this, m_n1 * m_m2), dT(*this, m_n1 * m_m2);
+            // (the two n1 x m2 work matrices are kept between calls: an LM loop calls compute() with one shape, and hipMalloc / hipFree
+            //  of gigabytes cost milliseconds)
+            Scratch &dTop = m_dTop, &dT = m_dT;
+            dTop.reserve(*this, m_n1 * m_m2); dT.reserve(*this, m_n1 * m_m2);
             top(dTop.ptr(), rp, identity);
             m_leftSolver.applyQDevice(dTop.ptr(), m_m2, dT.ptr(), true);
             // rightSolver.compute(J2.bottomRows(rows - m1)): rows m1..n1 of Q1^T J2, then the rows of J2 below J1
-            check(qrk_device_alloc(m_handle, std::max<int64_t>(rb * m_m2 * D, 8), &dBottom));
+            dBottom = m_dense.acquireBuffer(m_handle, rb, m_m2);
             qrk_status st = qrk_memcpy_2d(m_handle, dBottom, rb * D, dT.ptr() + m_m1, m_n1 * D, (m_n1 - m_m1) * D, m_m2, 2);
             if (st == QRK_STATUS_OK && m_rows > m_n1) st = bottom((double*)dBottom + (m_n1 - m_m1), rb);
             // the strip of R: S = (Q1^T J2)(0:m1, :)
-            if (m_dS) { qrk_device_free(m_handle, m_dS); m_dS = 0; }
-            if (st == QRK_STATUS_OK) st = qrk_device_alloc(m_handle, std::max<int64_t>(m_m1 * m_m2 * D, 8), &m_dS);
+            if (m_dS && m_dScount != m_m1 * m_m2) { qrk_device_free(m_handle, m_dS); m_dS = 0; }
+            if (st == QRK_STATUS_OK && !m_dS) { st = qrk_device_alloc(m_handle, std::max<int64_t>(m_m1 * m_m2 * D, 8), &m_dS); m_dScount = m_m1 * m_m2; }
             if (st == QRK_STATUS_OK) st = qrk_memcpy_2d(m_handle, m_dS, m_m1 * D, dT.ptr(), m_n1 * D, m_m1 * D, m_m2, 2);
             if (st != QRK_STATUS_OK) { qrk_device_free(m_handle, dBottom); check(st); }
         }
@@ -1059,6 +1083,18 @@ class BlockAngularSparseQR {
         m_nonzeropivots = m_leftSolver.rank() + m_k2;
         m_isInitialized = true;
     }
+    // grow-only device buffer of doubles on this solver's handle (freed with the solver)
+    struct Scratch {
+        void* p; int64_t cap;
+        Scratch() : p(0), cap(0) {}
+        void reserve(const BlockAngularSparseQR& s, int64_t count) {
+            if (count <= cap) return;
+            if (p) { qrk_device_free(s.m_handle, p); p = 0; cap = 0; }
+            s.check(qrk_device_alloc(s.m_handle, std::max<int64_t>(count, 1) * (int64_t)sizeof(double), &p));
+            cap = count;
+        }
+        double* ptr() const { return (double*)p; }
+    };
     // scoped device buffer of doubles on this solver's handle
     struct DBuf {
         const BlockAngularSparseQR& s; void* p;
@@ -1130,6 +1166,8 @@ class BlockAngularSparseQR {
     DenseDeviceQR m_dense;
     Index m_rows, m_cols, m_m1, m_m2, m_n1, m_k2;
     void* m_dS = 0;                     // device: the strip S = (Q1^T J2)(0:m1, :), m1 x m2 (the packed QR of the rows below is m_dense's)
+    int64_t m_dScount = 0;
+    Scratch m_dTop, m_dT;               // device: J2.top(n1) and Q1^T of it, kept between factorisations
     std::vector<double> m_hc;
     std::vector<int> m_P2;
     mutable MatrixRType m_R;            // host copy of R, assembled by the first matrixR()
