@@ -373,3 +373,34 @@ def test_dense_exact_path_over_the_whole_chip_is_bitwise_the_oracle(kind, rows, 
         # (un-pivoted: nothing but a degenerate reflector or a sign at the noise level flags the block; either it was redone - bitwise -
         #  or the fast result stands)
         assert np.array_equal(got, ref) or rel_fro(np.triu(got[:k]), np.triu(ref[:k])) <= 1e-12
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows,cols", [(6000, 300), (4100, 200), (16000, 520)])
+def test_caqr_schedules_agree_bitwise(rows, cols, monkeypatch):
+    """The first stage of the two-stage form runs on one, two (look-ahead) or three streams (look-ahead pipelined by levels,
+    caqr.hip: caqr_factorize_pipelined).  The arithmetic does not depend on the schedule, so with the same kernels on every column
+    (QRK_CAQR_NO_NARROW=1: the narrow apply kernel adds its partial sums in another order) the packed result, tau and the
+    permutation must be bitwise the same in all three, run after run: a missing dependency between the streams shows up here."""
+    import torch
+    import qrkit_amd
+    from qrkit_amd.angular import DenseColPivQR
+    monkeypatch.setenv("QRK_DENSE_TWO_STAGE", "1")
+    monkeypatch.setenv("QRK_CAQR_NO_NARROW", "1")
+    ctx = qrkit_amd.Context(0)
+    g = torch.Generator(device="cuda"); g.manual_seed(rows + cols)
+    A0 = torch.rand((cols, rows), device="cuda", dtype=torch.float64, generator=g) * 4.5 + 0.5
+    ref = None
+    for mode in ("pipe", "plain", "none"):
+        monkeypatch.setenv("QRK_CAQR_PIPE", "1" if mode == "pipe" else "0")
+        monkeypatch.setenv("QRK_CAQR_LOOKAHEAD", "0" if mode == "none" else "1")
+        qr = DenseColPivQR(ctx, 0)                      # (the switches are read when the plan is created)
+        for _ in range(3 if mode == "pipe" else 1):
+            At = A0.clone().t()
+            qr.compute(At)
+            torch.cuda.synchronize()
+            res = (At.clone(), qr._hc.clone(), qr.colsPermutation().clone())
+            if ref is None:
+                ref = res
+            for a, b in zip(res, ref):
+                assert torch.equal(a, b), f"{mode}: the result depends on the schedule"
