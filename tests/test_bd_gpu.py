@@ -346,3 +346,42 @@ def test_random_mixed_batches_match_oracle(seed):
     assert per_tile_rel(qr.qValues().cpu().numpy()[:nq], ref.Q_vals[:nq], sq) <= 10 * RTOL
     assert per_tile_rel(qr.rValues().cpu().numpy(), ref.R_vals, sr) <= 10 * RTOL
     np.testing.assert_array_equal(qr.qValues().cpu().numpy()[nq:], ref.Q_vals[nq:])      # trailing identity rows
+
+
+@pytest.mark.gpu
+def test_mixed_8_to_256_full_share_of_one_gpu(qa, ctx):
+    """BASELINE configs[4] at the count one of its 8 GPUs sees (100 000 / 8 = 12 500 square tiles, n ~ U{8..256}; three size
+    classes on their streams, tiles handed out through the queues over several rounds of resident workgroups): the size-independent
+    properties on every 25th tile, valid permutations everywhere, and a second factorisation that reproduces the first bit for bit."""
+    import torch
+    rng = np.random.default_rng(4)
+    B = 12500
+    n = rng.integers(8, 257, B).astype(np.int32)
+    n64 = n.astype(np.int64)
+    tiles = seeded_tiles(41, -1.0, 1.0, int((n64 ** 2).sum()))
+    _, qr = run_gpu(qa, ctx, n, n, tiles)
+    assert qr.info() == 0 and qr.rank() == int(n.sum())
+    perm = qr.colsPermutation().copy()
+    coff = np.concatenate([[0], np.cumsum(n64)]); toff = np.concatenate([[0], np.cumsum(n64 ** 2)])
+    roff = np.concatenate([[0], np.cumsum(n64 * (n64 + 1) // 2)])
+    # every permutation is a permutation of its own tile's columns
+    local = perm - np.repeat(coff[:-1], n)
+    assert local.min() >= 0 and np.all(local < np.repeat(n64, n))
+    seen = np.zeros(int(coff[-1]), np.int32); seen[perm] += 1
+    assert np.all(seen == 1)
+    Qd, Rd = qr.qValues(), qr.rValues()
+    worst_qr = worst_orth = 0.0
+    for i in range(0, B, 25):
+        c = int(n[i])
+        A = tiles[toff[i]:toff[i + 1]].reshape(c, c).T
+        Q = Qd[toff[i]:toff[i + 1]].cpu().numpy().reshape(c, c)
+        li = np.tril_indices(c)
+        R = np.zeros((c, c)); R[li[1], li[0]] = Rd[roff[i]:roff[i + 1]].cpu().numpy()
+        P = perm[coff[i]:coff[i + 1]] - coff[i]
+        worst_qr = max(worst_qr, np.linalg.norm(Q @ R - A[:, P]) / np.linalg.norm(A))
+        worst_orth = max(worst_orth, np.linalg.norm(Q.T @ Q - np.eye(c)))
+    assert worst_qr <= 1e-13 and worst_orth <= 1e-12, (worst_qr, worst_orth)
+    q1, r1 = Qd.clone(), Rd.clone()
+    _, qr2 = run_gpu(qa, ctx, n, n, tiles)
+    np.testing.assert_array_equal(qr2.colsPermutation(), perm)
+    assert torch.equal(qr2.qValues(), q1) and torch.equal(qr2.rValues(), r1)
