@@ -134,6 +134,53 @@ bd_apply_qt_small_kernel(TileGeom g, const double* __restrict__ q_vals, const do
     }
 }
 
+// The same for MANY right-hand sides (Q1^T J2 of the block-angular composition: 2000 columns): a lane keeps its column of Q_i in
+// registers and walks a chunk of right-hand sides - per output one coalesced load of b, the tile's b through LDS (one write, RP / 2
+// 16-byte reads), RP FMAs, one store.  The kernel above loads Q_i and b 2 RP times per output (1.4 TB/s on the 8 x 6 tiles).
+constexpr int APQT_CHUNK = 64;      // right-hand sides per wave
+template <int RP>
+__global__ void __launch_bounds__(64)
+bd_apply_qt_small_many_kernel(TileGeom g, const double* __restrict__ q_vals, const double* __restrict__ b, int64_t nrhs,
+                              double* __restrict__ y)
+{
+    constexpr int PER = 64 / RP;
+    __shared__ __attribute__((aligned(16))) double sb[2][64];
+    const int lane = threadIdx.x, sub = lane / RP, k = lane % RP;
+    const int r = g.rows, c = g.cols;
+    const int64_t tgroups = (g.num_tiles + PER - 1) / PER;
+    const int64_t tg = blockIdx.x % tgroups, chunk = blockIdx.x / tgroups;
+    const int64_t t = tg * PER + sub;
+    const bool on = t < g.num_tiles && k < r;
+    const int base_row = (int)(t * r), base_col = (int)(t * c);
+    double qk[RP];
+    {
+        const double* q = q_vals + (on ? t : 0) * (int64_t)r * r;
+#pragma unroll
+        for (int j = 0; j < RP; ++j) { const double v = q[(j < r ? j : 0) * r + (k < r ? k : 0)]; qk[j] = (on && j < r) ? v : 0.0; }
+    }
+    int idx;
+    if (g.q_format == 0) idx = k < c ? base_col + k : g.mat_cols + (base_row - base_col) + (k - c);
+    else idx = base_row + k;
+    const int64_t r0 = chunk * APQT_CHUNK, r1 = r0 + APQT_CHUNK < nrhs ? r0 + APQT_CHUNK : nrhs;
+    const double* bp = b + r0 * (int64_t)g.mat_rows + (on ? base_row + k : 0);
+    double bn = r0 < r1 ? *bp : 0.0;
+    for (int64_t rhs = r0; rhs < r1; ++rhs) {
+        const int par = (int)(rhs & 1);
+        sb[par][lane] = on ? bn : 0.0;
+        bp += g.mat_rows;
+        if (rhs + 1 < r1) bn = *bp;                          // next right-hand side in flight
+        __builtin_amdgcn_wave_barrier();
+        double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+        for (int j = 0; j < RP; j += 2) {
+            const double2 v2 = *reinterpret_cast<const double2*>(&sb[par][sub * RP + j]);
+            s0 = fma(qk[j], v2.x, s0); s1 = fma(qk[j + 1], v2.y, s1);
+        }
+        if (on) y[rhs * (int64_t)g.mat_rows + idx] = s0 + s1;
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 // y = Q b, the product matrixQ() * b of the explicit m_Q (BlockDiagonalSparseQR.h:235-237, row j of Q_i = [U_i(j,:), N_i(j,:)],
 // :455-492): one lane per row of a tile, the rows of Q_i are contiguous in q_vals.  FullQ reads b at base_col + k (k < c)
 // and at N + m1 + (k - c) for the N part; BlockDiagonalQ at base_row + k.  The trailing identity rows copy b.
@@ -363,6 +410,17 @@ void launch_bd_apply_qt(const TileGeom& g, const double* q_vals, const double* b
     if (total > 0) {
         if (g.t_rows == nullptr && g.rows <= 32) {
             const int rp = g.rows <= 4 ? 4 : (g.rows <= 8 ? 8 : (g.rows <= 16 ? 16 : 32));
+            if (nrhs >= 16) {                                  // many right-hand sides: Q_i in registers, a chunk of columns per wave
+                const int64_t tgroups = (g.num_tiles + 64 / rp - 1) / (64 / rp), chunks = (nrhs + APQT_CHUNK - 1) / APQT_CHUNK;
+                if (tgroups * chunks <= 0x7fffffff) {
+                    const unsigned grid = (unsigned)(tgroups * chunks);
+                    if (rp == 4) hipLaunchKernelGGL(bd_apply_qt_small_many_kernel<4>, dim3(grid), dim3(64), 0, stream, g, q_vals, b, nrhs, y);
+                    else if (rp == 8) hipLaunchKernelGGL(bd_apply_qt_small_many_kernel<8>, dim3(grid), dim3(64), 0, stream, g, q_vals, b, nrhs, y);
+                    else if (rp == 16) hipLaunchKernelGGL(bd_apply_qt_small_many_kernel<16>, dim3(grid), dim3(64), 0, stream, g, q_vals, b, nrhs, y);
+                    else hipLaunchKernelGGL(bd_apply_qt_small_many_kernel<32>, dim3(grid), dim3(64), 0, stream, g, q_vals, b, nrhs, y);
+                    goto tail;
+                }
+            }
             const int64_t waves = (total + 64 / rp - 1) / (64 / rp);
             const unsigned grid = (unsigned)(waves < 262144 ? waves : 262144);
             if (rp == 4) hipLaunchKernelGGL(bd_apply_qt_small_kernel<4>, dim3(grid), dim3(64), 0, stream, g, q_vals, b, nrhs, y);
@@ -374,6 +432,7 @@ void launch_bd_apply_qt(const TileGeom& g, const double* q_vals, const double* b
             hipLaunchKernelGGL(bd_apply_qt_kernel, dim3(grid), dim3(64), 0, stream, g, q_vals, b, nrhs, y);
         }
     }
+tail:
     const int64_t ntail = ((int64_t)g.mat_rows - g.sum_rows) * nrhs;
     if (ntail > 0)
         hipLaunchKernelGGL(bd_copy_tail_kernel, dim3((unsigned)((ntail + 255) / 256)), dim3(256), 0, stream, g,
