@@ -483,7 +483,8 @@ class BlockAngularSparseQR:
             J2 = J2.to(dev, torch.float64)
         top = self.m_leftSolver.applyQt(J2[:n1, :])                    # device, (n1, m2)
         self._J2 = torch.cat([top, J2[n1:, :]], dim=0) if n2 > 0 else top
-        bottom = _colmajor(self._J2[m1:, :].clone())
+        bottom = torch.empty((m2, self._J2.shape[0] - m1), dtype=torch.float64, device=dev).t()    # column-major, one strided copy
+        bottom.copy_(self._J2[m1:, :])
         self.m_rightSolver.compute(bottom)
         self._P2 = self.m_rightSolver.colsPermutation().long()
         self._m1, self._m2, self._n1, self._n2 = m1, m2, n1, n2

@@ -16,7 +16,7 @@ def run(B, r, c, m2, label):
     left = qa.SparseBlockDiagonal.fromTiles(np.full(B, r, np.int32), np.full(B, c, np.int32), tiles)
     J2 = rng.uniform(0.5, 5.0, (B * r, m2))
     ba = qa.BlockAngularSparseQR(context=ctx)
-    mat = qa.BlockMatrix1x2(left, torch.from_numpy(J2).cuda())
+    mat = qa.BlockMatrix1x2(left, torch.from_numpy(np.ascontiguousarray(J2.T)).cuda().t())   # column-major on the device, as Eigen's MatrixXd
     ba.compute(mat); torch.cuda.synchronize()
     t0 = time.perf_counter(); ba.compute(mat); torch.cuda.synchronize(); dt = time.perf_counter() - t0
     x = rng.uniform(-1, 1, B * c + m2)
