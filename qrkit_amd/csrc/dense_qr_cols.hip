@@ -19,6 +19,7 @@
 #include "qrk_device.h"
 
 #include <float.h>
+#include <cstdlib>
 
 namespace qrk {
 namespace cols {
@@ -68,19 +69,20 @@ cols_init_kernel(const double* __restrict__ A, int64_t lda, int r, int c, Work w
 // Step k.  Grid: ceil((c - k - 1) / 8) workgroups (at least one); dynamic LDS: (r - k) doubles.
 // RPL: a lane keeps up to RPL entries of its column in registers between the dot and the update (32: columns of <= 2048 rows below the
 // pivot, 64: <= 4096); longer columns are read twice.
-template <int RPL>
-__global__ void __launch_bounds__(TT)
+template <int RPL, int STT>
+__global__ void __launch_bounds__(STT) __attribute__((amdgpu_waves_per_eu(1, STT == 256 ? 1 : 2)))
 cols_step_kernel(double* __restrict__ A, int64_t lda, int r, int c, int k, int pivoting, double* __restrict__ hcoeffs,
                  int32_t* __restrict__ perm, Work w)
 {
+    constexpr int STW = STT / 64;
     extern __shared__ double xs[];            // x = rows k .. r-1 of the pivot column
-    __shared__ double red[TW];
-    __shared__ int ired[TW];
+    __shared__ double red[STW];
+    __shared__ int ired[STW];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = k & 1;
     // ---- this wave's column, assuming its position is not the one the pivot is swapped with (true for all waves but one):
     // the loads are issued before the serial part of the step, whose memory round trips they overlap
-    const int pos = k + 1 + blockIdx.x * TW + wave;
+    const int pos = k + 1 + blockIdx.x * STW + wave;
     const int n = r - k - 1;                      // rows below the pivot row
     const bool cached = n <= 64 * RPL;
     double a[RPL];
@@ -99,9 +101,9 @@ cols_step_kernel(double* __restrict__ A, int64_t lda, int r, int c, int k, int p
                                               // no dependent look-up follows the search
     double best = 0.0;
     if (pivoting) {
-        __shared__ int cred[TW];
+        __shared__ int cred[STW];
         best = -1.0; int bi = c, bc = -1;
-        for (int pos = k + tid; pos < c; pos += TT) {
+        for (int pos = k + tid; pos < c; pos += STT) {
             const double v = w.nu2[b][pos];
             const int cc = w.cmap[b][pos];
             if (v > best) { best = v; bi = pos; bc = cc; }
@@ -126,7 +128,7 @@ cols_step_kernel(double* __restrict__ A, int64_t lda, int r, int c, int k, int p
         __syncthreads();
         best = red[0]; bi = ired[0]; bc = cred[0];
 #pragma unroll
-        for (int q = 1; q < TW; ++q) if (red[q] > best || (red[q] == best && ired[q] < bi)) { best = red[q]; bi = ired[q]; bc = cred[q]; }
+        for (int q = 1; q < STW; ++q) if (red[q] > best || (red[q] == best && ired[q] < bi)) { best = red[q]; bi = ired[q]; bc = cred[q]; }
         if (bi < c) { P = bi; pk = bc; }
         __syncthreads();
     }
@@ -134,7 +136,7 @@ cols_step_kernel(double* __restrict__ A, int64_t lda, int r, int c, int k, int p
     if (pk < 0) pk = w.cmap[b][P];
     // ---- x into LDS, |x_tail|^2
     double t = 0.0;
-    for (int i = k + tid; i < r; i += TT) {
+    for (int i = k + tid; i < r; i += STT) {
         const double v = A[(int64_t)pk * lda + i];
         xs[i - k] = v;
         if (i > k) t = fma(v, v, t);
@@ -144,7 +146,7 @@ cols_step_kernel(double* __restrict__ A, int64_t lda, int r, int c, int k, int p
     __syncthreads();
     double tsq = 0.0;
 #pragma unroll
-    for (int q = 0; q < TW; ++q) tsq += red[q];
+    for (int q = 0; q < STW; ++q) tsq += red[q];
     const double xk = xs[0];
     // makeHouseholder in the un-normalised form of bdqr_pair.hip: nb = -beta, s = x0 - beta, ng = -1/(beta w)
     double nb, s, ng, tau;
@@ -316,11 +318,20 @@ hipError_t launch_dense_qr_cols(double* A, int64_t lda, int r, int c, int pivoti
     const int size = r < c ? r : c;
     hipLaunchKernelGGL(cols_init_kernel, dim3((c + TW - 1) / TW), dim3(TT), 0, stream, A, lda, r, c, w);
     for (int k = 0; k < size; ++k) {
-        int nwg = (c - k - 1 + TW - 1) / TW;
+        // rows below the pivot: up to 2048 -> 8 waves per workgroup with 32 entries of the column per lane in registers; 4097 ... 6144 ->
+        // 4 waves with 96 entries, rows up to 6144 (one wave per SIMD, 512 registers: the column is read once and written once instead of read twice; the
+        // reference's own block-angular test size, a 5120 x 384 bottom block, is such a matrix)
+        const bool longcol = r - k - 1 > 4096 && r - k - 1 <= 64 * 96 && !std::getenv("QRK_COLS_NO_LONG");
+        const int tw = longcol ? 4 : TW;
+        int nwg = (c - k - 1 + tw - 1) / tw;
         if (nwg < 1) nwg = 1;
         // (RPL = 64, columns of up to 4096 rows in registers, was measured slower: 256 VGPRs and spills: 3000 x 300 in 10.3 ms against 6)
-        hipLaunchKernelGGL(cols_step_kernel<32>, dim3(nwg), dim3(TT), (size_t)(r - k) * sizeof(double), stream, A, lda, r, c, k, pivoting,
-                           hcoeffs, perm, w);
+        if (longcol)
+            hipLaunchKernelGGL((cols_step_kernel<96, 256>), dim3(nwg), dim3(256), (size_t)(r - k) * sizeof(double), stream, A, lda, r, c, k,
+                               pivoting, hcoeffs, perm, w);
+        else
+            hipLaunchKernelGGL((cols_step_kernel<32, TT>), dim3(nwg), dim3(TT), (size_t)(r - k) * sizeof(double), stream, A, lda, r, c, k,
+                               pivoting, hcoeffs, perm, w);
     }
     if (c > size) hipLaunchKernelGGL(cols_tail_perm_kernel, dim3((c - size + 255) / 256), dim3(256), 0, stream, c, size, w, perm);
     hipLaunchKernelGGL(cols_finish_kernel, dim3(c), dim3(256), 0, stream, A, lda, r, c, size, perm, w, out, ldo);
