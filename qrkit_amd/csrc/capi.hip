@@ -253,7 +253,21 @@ qrk_status enqueue_factorize(qrk_bd_plan_s* p, const double* tiles, double* q, d
         // the size classes are independent of each other and of the small tiles above: each on its own side stream
         // (forked after what is already queued on the caller's stream, joined back below), so that the tail of one
         // launch overlaps the others
-        if (p->n_col > 0) {
+        static const bool col_serial = !(std::getenv("QRK_COL_CONCURRENT") && std::atoi(std::getenv("QRK_COL_CONCURRENT")) == 1);
+        if (p->n_col > 0 && col_serial) {
+            // one class after the other on the caller's stream, the largest tiles first.  Measured alone the classes of 4 000 mixed
+            // 8...256 tiles take 12.7 + 3.65 + 0.53 = 16.9 ms; launched side by side on three streams (QRK_COL_CONCURRENT=1) the
+            // batch takes 18 or 22 ms from run to run: what the classes cost each other in L2 / Infinity Cache is more than the
+            // tails they hide
+            for (int z = 2; z >= 0; --z) {
+                const auto& k = p->col_cls[z];
+                if (k.n <= 0) continue;
+                qrk::WaveBatch cb = nb;
+                cb.num_tiles = k.n; cb.tile_ids = p->d_col_ids + k.off;
+                QRK_HIP(h, qrk::launch_bdqr_col(cb, tiles, q, r, perm, hc, p->d_col_workspace + k.ws_off, k.ws_stride, k.num_wg,
+                                                k.max_rows, k.max_cols, k.w_lds, redo_cnt, redo_ids, p->d_redo + 2 + p->B + z, h->stream));
+            }
+        } else if (p->n_col > 0) {
             if (!h->ev_fork) {
                 QRK_HIP(h, hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
                 int prio_least = 0, prio_greatest = 0;
@@ -495,10 +509,13 @@ qrk_status qrk_bd_plan_create(qrk_handle h, const qrk_bd_layout* L, qrk_q_format
             if (md > p->max_dim) p->max_dim = md;
             if (md <= 32) wave_ids.push_back((int32_t)i);
             else if (md <= QRK_COL_MAX_DIM && r >= c) {
-                // three classes: up to 64 columns (one wave per tile, many workgroups per CU), up to 160 rows, and the rest
-                // (bdqr_col.hip: own instantiation and LDS layout each); concurrent on side streams, a mixed 8..256 batch
-                // takes 21.9 ms instead of 26.5 with the two upper classes in one launch
-                const int z = c <= 64 ? 0 : (r <= 160 ? 1 : 2);
+                // classes: up to 64 columns (one wave per tile, many workgroups per CU) and the rest (bdqr_col.hip: own instantiation
+                // and LDS layout each)
+                // (with the tiles of a launch handed out largest-first through a queue, one launch for everything wider than 64 columns
+                //  balances itself: 4 000 mixed 8...256 tiles 17.5 ms, against 19.1 with the tiles of up to 160 rows in a launch of
+                //  their own (QRK_COL_MERGE=0) -- the split dates from the grid-stride assignment)
+                static const bool merge12 = !(std::getenv("QRK_COL_MERGE") && std::atoi(std::getenv("QRK_COL_MERGE")) == 0);
+                const int z = c <= 64 ? 0 : ((r <= 160 && !merge12) ? 1 : 2);
                 auto& k = p->col_cls[z];
                 col_bin[z].push_back((int32_t)i);
                 const int64_t rc = (int64_t)r * c;
