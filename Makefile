@@ -10,7 +10,7 @@ OBJS      := $(patsubst $(CSRC)/%.hip,$(OBJDIR)/%.o,$(SRCS))
 
 all: $(LIB) oracle cpptest
 
-$(OBJDIR)/%.o: $(CSRC)/%.hip $(CSRC)/qrk_device.h include/qrkit_amd.h
+$(OBJDIR)/%.o: $(CSRC)/%.hip $(wildcard $(CSRC)/*.h) include/qrkit_amd.h
 	@mkdir -p $(OBJDIR)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 

@@ -32,163 +32,9 @@
 
 #pragma clang fp contract(off)
 
+#include "bdqr_exact_tile.h"
+
 namespace qrk {
-namespace exact {
-
-constexpr int T = 256;
-constexpr double SQRT_EPS = 1.4901161193847656e-08;   // sqrt(DBL_EPSILON): Eigen's norm_downdate_threshold
-
-// Inverse of e = p(p+1)/2 + i (0 <= i <= p): position in the packed upper triangle by columns.
-__device__ __forceinline__ void tri_unpack(int64_t e, int& p, int& i)
-{
-    int64_t q = (int64_t)((sqrt(8.0 * (double)e + 1.0) - 1.0) * 0.5);
-    while ((q + 1) * (q + 2) / 2 <= e) ++q;
-    while (q * (q + 1) / 2 > e) --q;
-    p = (int)q;
-    i = (int)(e - q * (q + 1) / 2);
-}
-
-// a is a better pivot than b: larger norm, or the same norm at a smaller current position (Eigen's "first maximum").
-__device__ __forceinline__ bool better(double va, int pa, double vb, int pb) { return va > vb || (va == vb && pa < pb); }
-
-struct Shared {
-    double* xbuf;     // [maxr] pivot column, then the essential part of the reflector
-    double* nu;       // [maxc] m_colNormsUpdated
-    double* nd;       // [maxc] m_colNormsDirect
-    double* hc;       // [maxc] m_hCoeffs
-    int* pos;         // [maxc] current position of original column j
-    int* col_at;      // [maxc] original column at position p
-    double* sval;     // [T] reduction scratch
-    int* spos;        // [T]
-};
-
-// One tile.  tile: r x c column-major input; W: r x c row-major working copy (LDS or global); q: r x r row-major Q
-// (LDS or the output itself).
-template <bool PIVOT>
-__device__ void tile_qr(int r, int c, const double* __restrict__ tile, double* W, double* q, const Shared& sh)
-{
-    const int t = threadIdx.x;
-    for (int e = t; e < r * c; e += T) {
-        const int j = e / r, i = e - j * r;
-        W[(size_t)i * c + j] = tile[e];
-    }
-    for (int j = t; j < c; j += T) { sh.pos[j] = j; sh.col_at[j] = j; }
-    __syncthreads();
-    if (PIVOT) {
-        for (int j = t; j < c; j += T) {
-            double s = 0.0;
-            for (int i = 0; i < r; ++i) { const double v = W[(size_t)i * c + j]; s += v * v; }
-            const double n = sqrt(s);
-            sh.nu[j] = n; sh.nd[j] = n;
-        }
-        __syncthreads();
-    }
-    for (int k = 0; k < c; ++k) {      // size = min(rows, cols) = cols (portrait tiles only)
-        int jb = k;
-        if (PIVOT) {
-            // biggest remaining column norm, first maximum over the CURRENT positions k..c-1
-            double bv = -1.0; int bp = 0x7fffffff;
-            for (int j = t; j < c; j += T) {
-                const int p = sh.pos[j];
-                if (p >= k && better(sh.nu[j], p, bv, bp)) { bv = sh.nu[j]; bp = p; }
-            }
-            sh.sval[t] = bv; sh.spos[t] = bp;
-            __syncthreads();
-            for (int s = T / 2; s > 0; s >>= 1) {
-                if (t < s && better(sh.sval[t + s], sh.spos[t + s], sh.sval[t], sh.spos[t])) {
-                    sh.sval[t] = sh.sval[t + s]; sh.spos[t] = sh.spos[t + s];
-                }
-                __syncthreads();
-            }
-            if (t == 0) {
-                // m_qr.col(k).swap(m_qr.col(biggest)) and the two norm tables: position bookkeeping only
-                const int b = sh.spos[0];
-                const int cb = sh.col_at[b], ck = sh.col_at[k];
-                sh.col_at[k] = cb; sh.col_at[b] = ck; sh.pos[cb] = k; sh.pos[ck] = b;
-            }
-            __syncthreads();
-            jb = sh.col_at[k];
-        }
-        for (int i = k + t; i < r; i += T) sh.xbuf[i] = W[(size_t)i * c + jb];
-        __syncthreads();
-        // makeHouseholder (every thread evaluates the same scalars in the same order)
-        const double c0 = sh.xbuf[k];
-        double tail = 0.0;
-        for (int i = k + 1; i < r; ++i) { const double v = sh.xbuf[i]; tail += v * v; }
-        double tau, beta, denom = 1.0;
-        const bool degen = tail <= DBL_MIN;
-        if (degen) { tau = 0.0; beta = c0; }
-        else {
-            beta = sqrt(c0 * c0 + tail);
-            if (c0 >= 0.0) beta = -beta;
-            denom = c0 - beta;
-            tau = (beta - c0) / beta;
-        }
-        __syncthreads();
-        for (int i = k + 1 + t; i < r; i += T) {
-            const double e = degen ? 0.0 : sh.xbuf[i] / denom;
-            sh.xbuf[i] = e;
-            W[(size_t)i * c + jb] = e;        // packed QR: essential part below the diagonal
-        }
-        if (t == 0) { W[(size_t)k * c + jb] = beta; sh.hc[k] = tau; }
-        __syncthreads();
-        // applyHouseholderOnTheLeft on the remaining columns + norm downdate
-        const int m = r - k;
-        for (int j = t; j < c; j += T) {
-            if (!(PIVOT ? sh.pos[j] > k : j > k)) continue;
-            double* colk = W + (size_t)k * c + j;
-            if (m == 1) *colk *= (1.0 - tau);
-            else if (tau != 0.0) {
-                double tmp = 0.0;
-                for (int i = k + 1; i < r; ++i) tmp += sh.xbuf[i] * W[(size_t)i * c + j];
-                tmp += *colk;
-                *colk -= tau * tmp;
-                for (int i = k + 1; i < r; ++i) W[(size_t)i * c + j] -= (tau * sh.xbuf[i]) * tmp;
-            }
-            if (PIVOT) {
-                const double nuj = sh.nu[j];
-                if (nuj != 0.0) {
-                    double temp = fabs(*colk) / nuj;
-                    temp = (1.0 + temp) * (1.0 - temp);
-                    temp = temp < 0.0 ? 0.0 : temp;
-                    const double ratio = nuj / sh.nd[j];
-                    const double temp2 = temp * (ratio * ratio);
-                    if (temp2 <= SQRT_EPS) {
-                        double s = 0.0;
-                        for (int i = k + 1; i < r; ++i) { const double v = W[(size_t)i * c + j]; s += v * v; }
-                        const double n = sqrt(s);
-                        sh.nd[j] = n; sh.nu[j] = n;
-                    } else sh.nu[j] = nuj * sqrt(temp);
-                }
-            }
-        }
-        __syncthreads();
-    }
-    // HouseholderSequence::evalTo: Q = I, then H_k on the corner Q(k:, k:) for k = c-1 .. 0
-    for (int e = t; e < r * r; e += T) q[e] = (e / r == e % r) ? 1.0 : 0.0;
-    __syncthreads();
-    for (int k = c - 1; k >= 0; --k) {
-        const int jb = sh.col_at[k];
-        const double tau = sh.hc[k];
-        for (int i = k + 1 + t; i < r; i += T) sh.xbuf[i] = W[(size_t)i * c + jb];
-        __syncthreads();
-        const int m = r - k;
-        for (int j = k + t; j < r; j += T) {
-            double* qk = q + (size_t)k * r + j;
-            if (m == 1) *qk *= (1.0 - tau);
-            else if (tau != 0.0) {
-                double tmp = 0.0;
-                for (int i = k + 1; i < r; ++i) tmp += sh.xbuf[i] * q[(size_t)i * r + j];
-                tmp += *qk;
-                *qk -= tau * tmp;
-                for (int i = k + 1; i < r; ++i) q[(size_t)i * r + j] -= (tau * sh.xbuf[i]) * tmp;
-            }
-        }
-        __syncthreads();
-    }
-}
-
-}  // namespace exact
 
 // LDS carve-up: [xbuf maxr][nu maxc][nd maxc][hc maxc][sval T] doubles, [pos maxc][col_at maxc][spos T] ints,
 // then `lds_tile_doubles` doubles for W and Q of tiles that fit.
@@ -211,16 +57,7 @@ bdqr_exact_kernel(WaveBatch nb, const int32_t* __restrict__ ids, const int32_t* 
     using namespace exact;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     Shared sh;
-    double* d = reinterpret_cast<double*>(smem);
-    sh.xbuf = d; d += maxr;
-    sh.nu = d; d += maxc;
-    sh.nd = d; d += maxc;
-    sh.hc = d; d += maxc;
-    sh.sval = d; d += T;
-    int* ip = reinterpret_cast<int*>(d);
-    sh.pos = ip; ip += maxc;
-    sh.col_at = ip; ip += maxc;
-    sh.spos = ip;
+    carve_shared<T>(smem, maxr, maxc, sh);
     double* lds_tile = reinterpret_cast<double*>(smem + exact_fixed_lds_bytes(maxr, maxc));
 
     if (next_count && blockIdx.x == 0 && threadIdx.x == 0) *next_count = 0;
@@ -240,22 +77,8 @@ bdqr_exact_kernel(WaveBatch nb, const int32_t* __restrict__ ids, const int32_t* 
         const bool in_lds = (int64_t)r * c + (int64_t)r * r <= lds_tile_doubles;
         double* W = in_lds ? lds_tile : workspace + (size_t)blockIdx.x * ws_stride;
         double* q = in_lds ? lds_tile + (size_t)r * c : q_vals + qoff;
-        tile_qr<PIVOT>(r, c, tiles + toff, W, q, sh);
-        // outputs: permutation (m_outputPerm_c splice, BlockDiagonalSparseQR.h:519-521), packed upper triangle of R in CSC
-        // order (:475-479), tau, Q rows (:455-471 / :480-492)
-        const int tid = threadIdx.x;
-        for (int p = tid; p < c; p += T) {
-            perm[cbase + p] = cbase + sh.col_at[p];
-            if (hcoeffs) hcoeffs[cbase + p] = sh.hc[p];
-        }
-        const int64_t n_r = (int64_t)c * (c + 1) / 2;
-        for (int64_t e = tid; e < n_r; e += T) {
-            int p, i;
-            tri_unpack(e, p, i);
-            r_vals[roff + e] = W[(size_t)i * c + sh.col_at[p]];
-        }
-        if (in_lds)
-            for (int e = tid; e < r * r; e += T) q_vals[qoff + e] = q[e];
+        tile_qr<PIVOT, T>(r, c, tiles + toff, W, q, sh);
+        tile_store<T>(r, c, cbase, W, in_lds ? q : nullptr, sh, perm, hcoeffs, r_vals + roff, q_vals + qoff);
         __syncthreads();
     }
 }

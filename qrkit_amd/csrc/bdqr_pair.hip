@@ -27,15 +27,17 @@
 //
 // Columns are never physically swapped.  The column chosen at step k ends at position k, which is
 // all the final permutation needs; the current positions that Eigen's "first maximum" tie rule
-// looks at (m_colsTranspositions bookkeeping) are rebuilt only when an exact tie occurs.  Row k of R
-// is final after step k and is parked in the LDS slot of the pivot column (dead from then on); the
-// epilogue gathers the packed upper triangle through the permutation.
+// looks at (m_colsTranspositions bookkeeping) are rebuilt only when an exact tie occurs.  Entry k of
+// a lane's column is final after step k (row k of R) and simply stays in its row register; the
+// column chosen at step p therefore ends as column p of R in rows 0..p of its lane, and the epilogue
+// packs the upper triangle with one unpredicated LDS store per row (see pack_r_column).
 //
 // Two kernels share the step: bdqr_pair_kernel (one pair per workgroup, any tile shape <= 32x32,
 // coalesced I/O staged through LDS) and bdqr_pair32_kernel (uniform 32x32 batches: persistent
 // workgroups that prefetch their next tile into dead registers and store Q rows straight from
 // registers).  Measured history and the per-phase cycle counts are in DESIGN.md.
 #include "qrk_device.h"
+#include "bdqr_exact_tile.h"
 
 #include <float.h>
 #include <cstdlib>
@@ -359,7 +361,10 @@ __device__ __forceinline__ void search_fetch(double* hl /* this half's LDS */, L
     }
 }
 
-template <int K, bool FULL32, bool PIVOT, bool HC>
+// RDUMP: the persistent kernel reuses the row registers of finished rows for the prefetch of its next tile, so every four steps
+// the four newest final entries of the lane's column (rows K-3..K of R) go to the lane's own image column, rows that no fetch
+// looks at any more (a fetch at step k' uses rows > k' only).
+template <int K, bool FULL32, bool PIVOT, bool HC, bool RDUMP>
 __device__ __forceinline__ void pair_step(double (&a)[WR], double (&q)[WR], double* hl /* this half's LDS */,
                                           LaneState& st, double* __restrict__ hcoeffs_tile)
 {
@@ -446,8 +451,8 @@ __device__ __forceinline__ void pair_step(double (&a)[WR], double (&q)[WR], doub
     if (!(QRK_ABL & 2048)) q[K] = fma(s, ngQ, qk);
     QRK_STAMP_IN(5);
     hl[L_WBUF + (K % RB) * WR + j] = ngA;
-    // Row K of R is final: park it in the LDS slot of the pivot column (never read as a column again).
-    if (!(QRK_ABL & 64) && (FULL32 || act)) hl[L_IMG + lbl * LDP + j] = an;
+    // Row K of R is final: it stays in the row register (never touched again: the steps that follow work on rows > K).
+    a[K] = an;
 
     // ---- LAWN-176 norm downdate for the remaining columns (squared form, see above).
     // No clamp at zero: a negative value is <= the threshold and is recomputed exactly.
@@ -479,6 +484,10 @@ __device__ __forceinline__ void pair_step(double (&a)[WR], double (&q)[WR], doub
 #undef QRK_XROW
     QRK_STAMP_IN(6);
 
+    if (RDUMP && K % 4 == 3) {
+        *reinterpret_cast<double2*>(&hl[L_IMG + j * LDP + K - 3]) = make_double2(a[K - 3], a[K - 2]);
+        *reinterpret_cast<double2*>(&hl[L_IMG + j * LDP + K - 1]) = make_double2(a[K - 1], a[K]);
+    }
     // ---- refresh the LDS image of the live columns after every RB-th step
     if (!(QRK_ABL & 64) && K % RB == RB - 1 && K + 1 < WR) {
         if (st.live) {   // (the column just chosen for step K+1 is skipped: it was fetched already)
@@ -489,6 +498,24 @@ __device__ __forceinline__ void pair_step(double (&a)[WR], double (&q)[WR], doub
     QRK_STAMP_IN(7);
 }
 
+
+// Packs the upper triangle of R of one half.  Lane j holds column p = kstep of R in c[0..p] (p = the step at which its column
+// was chosen); the packed CSC value order of m_R (BlockDiagonalSparseQR.h:475-479) puts entry (i, p) at slot p(p+1)/2 + i.
+// Every lane stores c[i] for i = 31 down to 0 WITHOUT a predicate: an entry with i > p lands in the slot of a later column,
+// (i', p') with p' > p and i' < i, which is stored by a later instruction of this same wave (LDS executes a wave's accesses in
+// order) and overwrites it; slots stay below 528 = 32 * 33 / 2.  32 stores per pair instead of a gather through the permutation
+// with an integer square root per entry.  pk: 528 doubles of this half's LDS that nothing else uses any more.
+__device__ __forceinline__ void pack_r_column(const double (&c)[WR], int kstep, double* pk)
+{
+    double* dst = pk + ((kstep * (kstep + 1)) >> 1);
+#pragma unroll
+    for (int i = WR - 1; i >= 0; --i) {
+        dst[i] = c[i];
+        // one store instruction per row, in this order: merged into ds_write2_b64 pairs, rows i and i + 1 would go out together
+        // and the entry (0, 1) would race with the left-over of column 0
+        asm volatile("" ::: "memory");
+    }
+}
 }  // namespace pair
 
 // FULL32: every tile is 32x32 and all arrays are 16-byte aligned (uniform batch).
@@ -590,7 +617,7 @@ bdqr_pair_kernel(WaveBatch nb, const double* __restrict__ tiles, double* __restr
         // The k loop is expanded by the preprocessor: every row-register index is a compile-time
         // constant.  (A rolled loop dispatching through a uniform switch makes hipcc's CFG
         // structurizer copy the whole register tile at every merge point.)
-#define QRK_STEP(K) if (!(QRK_ABL & 1024) && (FULL32 || K < cmax)) pair_step<K, FULL32, PIVOT, HC>(a, q, hl, st, hc_tile);
+#define QRK_STEP(K) if (!(QRK_ABL & 1024) && (FULL32 || K < cmax)) pair_step<K, FULL32, PIVOT, HC, false>(a, q, hl, st, hc_tile);
         search_fetch<0, FULL32, PIVOT>(hl, st);   // head of step 0; every step issues the head of the next one
 #ifdef QRK_STAMP
         QRK_STAMP_AT(1);
@@ -607,43 +634,34 @@ bdqr_pair_kernel(WaveBatch nb, const double* __restrict__ tiles, double* __restr
 #endif
 #undef QRK_STEP
 
-        // ---- R: row i of R sits in the LDS slot of the column chosen at step i, indexed by ORIGINAL
-        // column.  The packed upper triangle by columns is exactly the CSC value order of m_R
-        // (BlockDiagonalSparseQR.h:475-479): element e -> (column p, row i), gathered through lane_of_pos.
-        int* lane_of_pos = reinterpret_cast<int*>(&hl[L_POS]);
+        // ---- R: lane j holds column p = kstep of R in a[0..p]; the image is not needed any more and takes the packed triangle
+        // (CSC value order of m_R, BlockDiagonalSparseQR.h:475-479)
+        __syncthreads();
         if (j < c) {
-            // the column chosen at step k ends at position k
-            lane_of_pos[st.kstep] = j;
-            perm[cbase + st.kstep] = cbase + j;   // m_outputPerm_c.indices()(base_col+j) (:519-521)
+            pack_r_column(a, st.kstep, hl + L_IMG);
+            perm[cbase + st.kstep] = cbase + j;   // the column chosen at step k ends at position k: m_outputPerm_c.indices()(base_col+j) (:519-521)
         }
-        // decision (5): a pivot at the noise level of the tile, |R_kk|^2 <= 2^-40 |A|^2 (R_kk sits in this lane's own slot)
-        if (PIVOT && j < c) { const double rkk = hl[L_IMG + j * LDP + j]; if (rkk * rkk <= PIV_TINY2 * hl[L_A2]) hl[L_FLAG] = 1.0; }
+        __syncthreads();
+        // decision (5): a pivot at the noise level of the tile, |R_kk|^2 <= 2^-60 |A|^2
+        if (PIVOT && j < c) {
+            const double rkk = hl[L_IMG + ((st.kstep * (st.kstep + 3)) >> 1)];
+            if (rkk * rkk <= PIV_TINY2 * hl[L_A2]) hl[L_FLAG] = 1.0;
+        }
         __syncthreads();
         // a decision inside its error margin: the tile is redone by the exact path (bdqr_exact.hip)
         if (redo_count && valid && j == 0 && hl[L_FLAG] != 0.0) redo_ids[atomicAdd(redo_count, 1)] = gid;
-        __syncthreads();
         if (FULL32) {
             if (valid) {
                 double2* dst = reinterpret_cast<double2*>(r_vals + roff);
 #pragma unroll
                 for (int qq = 0; qq < 9; ++qq) {
                     const int e2 = j + 32 * qq;
-                    if (e2 < 264) {
-                        int p0, i0, p1, i1;
-                        tri_unpack(2 * e2, p0, i0);
-                        tri_unpack(2 * e2 + 1, p1, i1);
-                        dst[e2] = make_double2(hl[L_IMG + lane_of_pos[i0] * LDP + lane_of_pos[p0]],
-                                               hl[L_IMG + lane_of_pos[i1] * LDP + lane_of_pos[p1]]);
-                    }
+                    if (e2 < 264) dst[e2] = *reinterpret_cast<const double2*>(&hl[L_IMG + 2 * e2]);
                 }
             }
         } else {
             const int n_r = c * (c + 1) / 2;
-            for (int e = j; e < n_r; e += 32) {
-                int p0, i0;
-                tri_unpack(e, p0, i0);
-                r_vals[roff + e] = hl[L_IMG + lane_of_pos[i0] * LDP + lane_of_pos[p0]];
-            }
+            for (int e = j; e < n_r; e += 32) r_vals[roff + e] = hl[L_IMG + e];
         }
         __syncthreads();
 
@@ -688,12 +706,12 @@ bdqr_pair_kernel(WaveBatch nb, const double* __restrict__ tiles, double* __restr
 }
 
 namespace pair {
-// Epilogue of one 32x32 pair: R (packed upper triangle through the permutation) and perm.
-// All per-lane addresses derive from an opaque lane id so that none of them is computed (and kept
-// alive) before the factorisation.
-__device__ __forceinline__ void epilogue32(int lane_in, int64_t pi, int64_t num_tiles, int kstep, double* lds,
-                                           double* __restrict__ r_vals, int32_t* __restrict__ perm, bool pivot,
-                                           int32_t* __restrict__ redo_count, int32_t* __restrict__ redo_ids)
+// Epilogue of one 32x32 pair: R (packed upper triangle) and perm.  The lane's own image column holds its column of R (rows
+// 0..kstep; pair_step<..., RDUMP> put it there four rows at a time).  All per-lane addresses derive from an opaque lane id so
+// that none of them is computed (and kept alive) before the factorisation.  Returns (per half, in every lane of the half)
+// whether a decision of the tile was not clear of rounding.
+__device__ __forceinline__ bool epilogue32(int lane_in, int64_t pi, int64_t num_tiles, int kstep, double* lds,
+                                           double* __restrict__ r_vals, int32_t* __restrict__ perm, bool pivot)
 {
     int lane = lane_in;
     asm volatile("" : "+v"(lane));
@@ -702,33 +720,34 @@ __device__ __forceinline__ void epilogue32(int lane_in, int64_t pi, int64_t num_
     const int64_t t = 2 * pi + half;
     const bool valid = t < num_tiles;
     const int cbase = (int)(t * 32);
-    // ---- R: row i of R sits in the LDS slot of the column chosen at step i, indexed by ORIGINAL
-    // column.  The packed upper triangle by columns is exactly the CSC value order of m_R
-    // (BlockDiagonalSparseQR.h:475-479): element e -> (column p, row i), gathered through lane_of_pos.
-    int* lane_of_pos = reinterpret_cast<int*>(&hl[L_POS]);
-    lane_of_pos[kstep] = j;                            // the column chosen at step k ends at position k
-    if (valid) perm[cbase + kstep] = cbase + j;        // m_outputPerm_c.indices()(base_col+j) (:519-521)
-    // decision (5): a pivot at the noise level of the tile, |R_kk|^2 <= 2^-40 |A|^2 (R_kk sits in this lane's own slot)
-    if (pivot && (QRK_DECISIONS & 8)) { const double rkk = hl[L_IMG + j * LDP + j]; if (rkk * rkk <= PIV_TINY2 * hl[L_A2]) hl[L_FLAG] = 1.0; }
+    double c[WR];
+#pragma unroll
+    for (int i = 0; i < WR; i += 2) {
+        const double2 v = *reinterpret_cast<const double2*>(&hl[L_IMG + j * LDP + i]);
+        c[i] = v.x; c[i + 1] = v.y;
+    }
+    // (one wave per workgroup: LDS is in order, the loads above are served before the stores below; no s_barrier, whose fence
+    // would wait for the prefetch of the next tile)
+    pack_r_column(c, kstep, hl + L_IMG);
+    if (valid) perm[cbase + kstep] = cbase + j;        // the column chosen at step k ends at position k: m_outputPerm_c.indices()(base_col+j) (BlockDiagonalSparseQR.h:519-521)
     __builtin_amdgcn_wave_barrier();
-    // a decision inside its error margin: the tile is redone by the exact path (bdqr_exact.hip)
-    if (redo_count && valid && j == 0 && hl[L_FLAG] != 0.0) redo_ids[atomicAdd(redo_count, 1)] = (int)t;
-    __builtin_amdgcn_wave_barrier();   // one wave per workgroup: LDS is in order, no s_barrier (its fence would wait for the prefetch)
+    // decision (5): a pivot at the noise level of the tile, |R_kk|^2 <= 2^-60 |A|^2
+    if (pivot && (QRK_DECISIONS & 8)) {
+        const double rkk = hl[L_IMG + ((kstep * (kstep + 3)) >> 1)];
+        if (rkk * rkk <= PIV_TINY2 * hl[L_A2]) hl[L_FLAG] = 1.0;
+    }
+    __builtin_amdgcn_wave_barrier();
     if (valid) {
         double2* dst = reinterpret_cast<double2*>(r_vals + t * 528);
 #pragma unroll
         for (int qq = 0; qq < 9; ++qq) {
             const int e2 = j + 32 * qq;
-            if (e2 < 264) {
-                int p0, i0, p1, i1;
-                tri_unpack(2 * e2, p0, i0);
-                tri_unpack(2 * e2 + 1, p1, i1);
-                dst[e2] = make_double2(hl[L_IMG + lane_of_pos[i0] * LDP + lane_of_pos[p0]],
-                                       hl[L_IMG + lane_of_pos[i1] * LDP + lane_of_pos[p1]]);
-            }
+            if (e2 < 264) dst[e2] = *reinterpret_cast<const double2*>(&hl[L_IMG + 2 * e2]);
         }
     }
-    __builtin_amdgcn_wave_barrier();   // one wave per workgroup: LDS is in order, no s_barrier (its fence would wait for the prefetch)
+    const bool flagged = valid && hl[L_FLAG] != 0.0;
+    __builtin_amdgcn_wave_barrier();
+    return flagged;
 }
 
 // Half of the rows of Q straight from the registers: lane j holds row j of Q_i (row-major rows are the
@@ -750,28 +769,53 @@ __device__ __forceinline__ void store_q_half(int lane_in, int64_t pi, int64_t nu
         for (int m = 0; m < COUNT / 2; ++m) dst[m] = make_double2(q[FIRST + 2 * m], q[FIRST + 2 * m + 1]);
     }
 }
+
+// A tile whose decisions were not clear of rounding, again, by the wave that factorised it: Eigen's own operation order and
+// rounding (bdqr_exact_tile.h, 64 threads: lane = column, every sum over the rows a sequential chain), W and Q in the wave's
+// LDS.  Bitwise what bdqr_exact_kernel computes.  Rare by construction (generic tiles are never flagged), so it runs after the
+// persistent loop, where none of the loop's registers are live.
+template <bool PIVOT>
+__device__ __noinline__ void redo_exact32(int64_t t, double* lds, const double* __restrict__ tiles, double* __restrict__ q_vals,
+                                          double* __restrict__ r_vals, int32_t* __restrict__ perm, double* __restrict__ hcoeffs)
+{
+    exact::Shared sh;
+    double* W = exact::carve_shared<64>(reinterpret_cast<unsigned char*>(lds), 32, 32, sh);
+    double* q = W + 1024;
+    static_assert((32 + 3 * 32 + 64) * 8 + (2 * 32 + 64) * 4 + 16 + 2 * 1024 * 8 <= 2 * L_HALF * 8, "the exact path of a 32 x 32 tile must fit the wave's LDS");
+    __syncthreads();
+    exact::tile_qr<PIVOT, 64>(32, 32, tiles + t * 1024, W, q, sh);
+    exact::tile_store<64>(32, 32, (int)(t * 32), W, q, sh, perm, hcoeffs, r_vals + t * 528, q_vals + t * 1024);
+    __syncthreads();
+}
 }  // namespace pair
 
 // Uniform 32x32 batches (all arrays 16-byte aligned): persistent workgroups, software-pipelined
-// against HBM.  With two 232-register waves per SIMD nothing else can hide the tile loads, so each
+// against HBM.  With two 213-register waves per SIMD nothing else can hide the tile loads, so each
 // wave fetches its NEXT tile while it factorises the current one: row register a[k] is dead after
-// step k, so after step 15 columns 0..15 of the next tile are loaded into a[0..15] (coalesced: lane j
+// the R dump that follows step k, so after step 15 columns 0..15 of the next tile are loaded into a[0..15] (coalesced: lane j
 // takes ROW j, 8 bytes per column -- 8-byte loads because 16-byte register tuples that live across
 // the loop edge fragment the register file and spill), and after step 31 columns 16..31 into
 // a[16..31].  At the top of the next round the rows go to the LDS image (which transposes them to
 // lane = column) and the lane reads its column back.  Stores are fire-and-forget.
+//
+// Self-contained: a tile with a decision inside its error margin is redone by the wave itself with the exact-arithmetic
+// routine after its last round (no redo list, no second kernel behind the launch).  The rounds run in chunks of 64 so that one
+// 64-bit word per half remembers the flagged rounds.
 template <bool PIVOT, bool HC>
 __global__ void __launch_bounds__(64, 2)
 bdqr_pair32_kernel(int64_t num_tiles, const double* __restrict__ tiles, double* __restrict__ q_vals,
-                   double* __restrict__ r_vals, int32_t* __restrict__ perm, double* __restrict__ hcoeffs,
-                   int32_t* __restrict__ redo_count, int32_t* __restrict__ redo_ids)
+                   double* __restrict__ r_vals, int32_t* __restrict__ perm, double* __restrict__ hcoeffs)
 {
     using namespace pair;
     __shared__ __attribute__((aligned(16))) double lds[2 * L_HALF];
     const int64_t npairs = (num_tiles + 1) / 2;
-    double a[WR], q[WR];
+    constexpr int CHUNK = 64;
 
-    int64_t pi = blockIdx.x;
+    for (int64_t pi0 = blockIdx.x; pi0 < npairs; pi0 += (int64_t)CHUNK * gridDim.x) {
+    unsigned long long flagbits = 0ull;      // bit r: the tile of this half in round r of the chunk was flagged
+    {
+    double a[WR], q[WR];
+    int64_t pi = pi0;
     {
         const int j = threadIdx.x & 31;
         const int64_t t = 2 * pi + (threadIdx.x >> 5);
@@ -784,10 +828,10 @@ bdqr_pair32_kernel(int64_t num_tiles, const double* __restrict__ tiles, double* 
             for (int i = 0; i < WR; ++i) a[i] = 0.0;
         }
     }
-    for (; pi < npairs; pi += gridDim.x) {
+    for (int round = 0; round < CHUNK && pi < npairs; ++round, pi += gridDim.x) {
         // Everything per-lane is re-derived from an opaque lane id in every round: otherwise hipcc
-        // hoists the (loop-invariant) LDS addresses and packed-triangle indices of the epilogue out of
-        // the loop and keeps ~100 of them in scratch across the factorisation.
+        // hoists the (loop-invariant) LDS addresses of the epilogue out of
+        // the loop and keeps them in scratch across the factorisation.
         int lane = threadIdx.x;
         asm volatile("" : "+v"(lane));
         QRK_STAMP_AT(0);
@@ -796,6 +840,8 @@ bdqr_pair32_kernel(int64_t num_tiles, const double* __restrict__ tiles, double* 
         const int64_t t = 2 * pi + half;
         const bool valid = t < num_tiles;
         const int cbase = (int)(t * 32);
+        // the next pair of this wave (none after the last round of a chunk: the next chunk loads its own first pair)
+        const int64_t pn = round + 1 < CHUNK ? pi + gridDim.x : npairs;
 
         // ---- stage: chunk m of the lane -> its place in the padded column-major image
 #pragma unroll
@@ -832,7 +878,7 @@ bdqr_pair32_kernel(int64_t num_tiles, const double* __restrict__ tiles, double* 
         double* hc_tile = (HC && hcoeffs && valid) ? hcoeffs + cbase : nullptr;
         QRK_STAMP_AT(1);
 
-#define QRK_STEP(K) pair_step<K, true, PIVOT, HC>(a, q, hl, st, hc_tile);
+#define QRK_STEP(K) pair_step<K, true, PIVOT, HC, true>(a, q, hl, st, hc_tile);
         search_fetch<0, true, PIVOT>(hl, st);     // head of step 0; every step issues the head of the next one
         // q[0..k] are final after step k: every QRK_QSTORE_EVERY steps the finished entries of the lane's
         // Q row go out (16-byte stores; the pieces of a cache line meet again in L2) and free their registers
@@ -848,7 +894,7 @@ bdqr_pair32_kernel(int64_t num_tiles, const double* __restrict__ tiles, double* 
             // columns 0..15 of this half-wave's tile of the next round -> a[0..15] (dead by now)
             int ln = threadIdx.x;
             asm volatile("" : "+v"(ln));
-            const int64_t tn = 2 * (pi + gridDim.x) + (ln >> 5);
+            const int64_t tn = 2 * pn + (ln >> 5);
             if (tn < num_tiles) {
                 const double* nsrc = tiles + tn * 1024 + (ln & 31);
 #pragma unroll
@@ -868,14 +914,14 @@ bdqr_pair32_kernel(int64_t num_tiles, const double* __restrict__ tiles, double* 
             // columns 16..31 of the next tile -> a[16..31]
             int ln = threadIdx.x;
             asm volatile("" : "+v"(ln));
-            const int64_t tn = 2 * (pi + gridDim.x) + (ln >> 5);
+            const int64_t tn = 2 * pn + (ln >> 5);
             if (tn < num_tiles) {
                 const double* nsrc = tiles + tn * 1024 + (ln & 31);
 #pragma unroll
                 for (int m = 16; m < WR; ++m) a[m] = nsrc[32 * m];
             }
         }
-        epilogue32(threadIdx.x, pi, num_tiles, st.kstep, lds, r_vals, perm, PIVOT, redo_count, redo_ids);
+        if (epilogue32(threadIdx.x, pi, num_tiles, st.kstep, lds, r_vals, perm, PIVOT)) flagbits |= 1ull << round;
         QRK_STAMP_AT(6);
 #ifdef QRK_STAMP
         if (threadIdx.x == 0 && hcoeffs) {
@@ -888,6 +934,26 @@ bdqr_pair32_kernel(int64_t num_tiles, const double* __restrict__ tiles, double* 
             for (int n = 0; n < 8; ++n)
                 reinterpret_cast<unsigned long long*>(hcoeffs)[(size_t)npairs * 12 + (size_t)pi * 8 + n] = st.tk[n];
         }
+#endif
+    }
+    }
+#if !QRK_ABL
+    // ---- the flagged tiles of this chunk, again, with the reference's own operation order (rare: generic data never gets here)
+    {
+        const unsigned f0lo = __builtin_amdgcn_readlane((unsigned)flagbits, 0), f0hi = __builtin_amdgcn_readlane((unsigned)(flagbits >> 32), 0);
+        const unsigned f1lo = __builtin_amdgcn_readlane((unsigned)flagbits, 32), f1hi = __builtin_amdgcn_readlane((unsigned)(flagbits >> 32), 32);
+        unsigned long long f[2] = {((unsigned long long)f0hi << 32) | f0lo, ((unsigned long long)f1hi << 32) | f1lo};
+        if (__builtin_expect((f[0] | f[1]) != 0ull, 0)) {
+            for (int h2 = 0; h2 < 2; ++h2) {
+                unsigned long long m = f[h2];
+                while (m) {
+                    const int rnd = __builtin_ctzll(m);
+                    m &= m - 1;
+                    redo_exact32<PIVOT>(2 * (pi0 + (int64_t)rnd * gridDim.x) + h2, lds, tiles, q_vals, r_vals, perm, HC ? hcoeffs : nullptr);
+                }
+            }
+        }
+    }
 #endif
     }
 }
@@ -912,7 +978,7 @@ void launch_bdqr_pair(const WaveBatch& nb, bool full32, const double* tiles, dou
         const int64_t nwg = npairs < slots ? npairs : slots;
         const dim3 pgrid((unsigned)nwg);
 #define QRK_LAUNCH32(P, H)                                                                         \
-    hipLaunchKernelGGL((bdqr_pair32_kernel<P, H>), pgrid, block, 0, stream, nb.num_tiles, tiles, q_vals, r_vals, perm, hcoeffs, redo_count, redo_ids)
+    hipLaunchKernelGGL((bdqr_pair32_kernel<P, H>), pgrid, block, 0, stream, nb.num_tiles, tiles, q_vals, r_vals, perm, hcoeffs)
 #if QRK_ABL || defined(QRK_STAMP)
         // diagnostic builds: the bench variant only; QRK_PAIR_PERSIST=0 selects the one-pair-per-workgroup kernel
         if (const char* e = std::getenv("QRK_PAIR_PERSIST")) {

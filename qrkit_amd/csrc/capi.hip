@@ -225,6 +225,7 @@ qrk_status enqueue_factorize(qrk_bd_plan_s* p, const double* tiles, double* q, d
     int32_t* const redo_cnt = p->d_redo + p->redo_parity;
     int32_t* const redo_next = p->d_redo + (p->redo_parity ^ 1);
     int32_t* const redo_ids = p->d_redo + 2;
+    bool redo_pass = true;     // a launch of the exact kernel follows (it reads the redo list the fast kernels filled)
     if (p->uniform) {
         nb.num_tiles = p->B; nb.rows = p->r; nb.cols = p->c;
         const bool full32 = p->r == 32 && p->c == 32 &&
@@ -244,6 +245,8 @@ qrk_status enqueue_factorize(qrk_bd_plan_s* p, const double* tiles, double* q, d
             int wgs = h->num_cus * h->pair_wgs_per_cu;
             if (const char* e = std::getenv("QRK_PAIR_WGS")) { const int v = std::atoi(e); if (v > 0) wgs = v; }   // (experiments)
             qrk::launch_bdqr_pair(nb, full32, tiles, q, r, perm, hc, wgs, redo_cnt, redo_ids, h->stream);
+            // the persistent 32 x 32 kernel redoes its flagged tiles itself (bdqr_pair.hip, redo_exact32): nothing queued behind it
+            if (full32) redo_pass = false;
         }
     } else {
         nb.num_tiles = p->n_wave; nb.tile_ids = p->d_wave_ids;
@@ -301,9 +304,11 @@ qrk_status enqueue_factorize(qrk_bd_plan_s* p, const double* tiles, double* q, d
     }
     // the tiles whose decisions were not clear of rounding, again, with the reference's own operation order (bdqr_exact.hip);
     // the list is empty on generic data and the workgroups return at once
-    QRK_HIP(h, qrk::launch_bdqr_exact(all, redo_ids, redo_cnt, redo_next, tiles, q, r, perm, hc, p->d_exact_ws, p->exact_ws_stride,
-                                      p->exact_num_wg, p->exact_maxr, p->exact_maxc, h->stream));
-    p->redo_parity ^= 1;
+    if (redo_pass) {
+        QRK_HIP(h, qrk::launch_bdqr_exact(all, redo_ids, redo_cnt, redo_next, tiles, q, r, perm, hc, p->d_exact_ws, p->exact_ws_stride,
+                                          p->exact_num_wg, p->exact_maxr, p->exact_maxc, h->stream));
+        p->redo_parity ^= 1;
+    }
     qrk::launch_bd_q_tail_ones(q, p->nnz_q_tiles, p->nnz_q - p->nnz_q_tiles, h->stream);
     QRK_HIP(h, hipGetLastError());
     return QRK_STATUS_OK;

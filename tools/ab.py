@@ -66,6 +66,13 @@ def run_one(B):
                                                     S, it, C.byref(ms)))
         return ms.value
     run(30)
+    if os.environ.get("QRK_AB_HASH"):
+        # one factorisation of the first matrix through the product entry point; digest of perm / R / Q (bitwise comparison of builds)
+        import hashlib
+        capi.check(capi.lib().qrk_bd_factorize(plan, tiles.data_ptr(), qv.data_ptr(), rv.data_ptr(), pm.data_ptr(), None, capi.MEM_DEVICE))
+        torch.cuda.synchronize()
+        dig = [hashlib.sha1(x.cpu().numpy().tobytes()).hexdigest()[:10] for x in (pm[:B * 32], rv[:B * 528], qv[:B * 1024])]
+        print("HASH perm=%s R=%s Q=%s" % tuple(dig))
     print(f"{run(300) * 1e3:.2f}")
 
 
@@ -77,6 +84,9 @@ def run(B):
             env = dict(os.environ, QRKIT_AMD_LIB=lib)
             r = subprocess.run([sys.executable, os.path.abspath(__file__), "one", str(B)], env=env, capture_output=True, text=True)
             out = r.stdout.strip().splitlines()
+            for ln in out:
+                if ln.startswith("HASH"):
+                    print(os.path.basename(lib)[7:-3], ln, flush=True)
             res[lib].append(float(out[-1]) if out and out[-1].replace(".", "").isdigit() else float("nan"))
             if r.returncode != 0:
                 print(os.path.basename(lib), "FAILED", r.stderr[-400:], flush=True)
