@@ -61,6 +61,21 @@
 #define QRK_DPPX 1             // 1: the pivot column reaches the lanes as the DPP operand of the FMAs (row_newbcast), no LDS publish / broadcast reads;
                                // 0: the round-1 form (XBUF in LDS, ds_read_b128 broadcasts), kept for A/B measurements
 #endif
+// Diagnostic only (occupancy experiments; results are wrong): -DQRK_DIAG_LDS16 folds the LDS image onto 16 columns (11.8 KB of LDS
+// per wave instead of 20 KB), -DQRK_MINW=3 compiles the persistent kernel for three waves per SIMD.
+#ifdef QRK_DIAG_LDS16
+#define QRK_IC(x) ((x) & 15)
+#define QRK_IMG_COLS 16
+#else
+#define QRK_IC(x) (x)
+#define QRK_IMG_COLS 32
+#endif
+#ifndef QRK_MINW
+#define QRK_MINW 2
+#endif
+#ifndef QRK_DOT_SPLIT
+#define QRK_DOT_SPLIT 0
+#endif
 #ifndef QRK_QSTORE_EVERY
 #define QRK_QSTORE_EVERY 8     // 4, 8 or 16
 #endif
@@ -92,7 +107,7 @@ constexpr int LDP = WR + 2;          // LDS column stride in doubles: 272 B, con
 constexpr int RB = QRK_RB;           // the LDS image of A is refreshed every RB steps
 // LDS carve-up per HALF (doubles)
 constexpr int L_IMG = 0;             // [32][LDP] column-major image of A / staging for Q; R rows parked here
-constexpr int L_XBUF = WR * LDP;     // [32] current pivot column
+constexpr int L_XBUF = QRK_IMG_COLS * LDP;     // [32] current pivot column
 constexpr int L_WBUF = L_XBUF + WR;  // [RB][32] update coefficients of the last RB steps, per A column
 constexpr int L_POS = L_WBUF + RB * WR;   // [32] int: lane_of_pos
 constexpr int L_A2 = L_POS + WR / 2;      // [1] |A|^2: squared norm of the first pivot column (scale of the decision margins)
@@ -342,7 +357,7 @@ __device__ __forceinline__ void search_fetch(double* hl /* this half's LDS */, L
     // the update of every RB-th step, i.e. after the search_fetch of the following step has run.
     constexpr int KR = K == 0 ? 0 : ((K - 1) / RB) * RB;
     {
-        double xi = hl[L_IMG + lbl * LDP + j];
+        double xi = hl[L_IMG + QRK_IC(lbl) * LDP + j];
         QRK_STAMP_IN(1);
 #pragma unroll
         for (int m = (QRK_ABL & 256) ? K : KR; m < K; ++m) xi = fma(hl[L_WBUF + (m % RB) * WR + lbl], st.h[m % RB], xi);
@@ -383,7 +398,13 @@ __device__ __forceinline__ void pair_step(double (&a)[WR], double (&q)[WR], doub
 #define QRK_XROW(I) ((I) < 16 ? xa : xb)
     if (QRK_ABL & 32) { dA = xk; dQ = xk; }
     else {
+#if QRK_DOT_SPLIT
+    // one asm statement per FMA, the two chains alternating: gfx950's hazard recogniser pads an asm statement that reads a
+    // register written by the asm statement right before it (s_nop 0 between every two steps of a chain otherwise)
+#define QRK_DOT(I) if ((I) > K) { fmac1_bcast_a<((I) & 15)>(dA, QRK_XROW(I), a[I]); if (!(QRK_ABL & 2048)) fmac1_bcast_a<((I) & 15)>(dQ, QRK_XROW(I), q[I]); }
+#else
 #define QRK_DOT(I) if ((I) > K) { if (QRK_ABL & 2048) fmac1_bcast_a<((I) & 15)>(dA, QRK_XROW(I), a[I]); else fmac2_bcast_a<((I) & 15)>(dA, dQ, QRK_XROW(I), a[I], q[I]); }
+#endif
         QRK_0_31(QRK_DOT)
 #undef QRK_DOT
     }
@@ -485,14 +506,14 @@ __device__ __forceinline__ void pair_step(double (&a)[WR], double (&q)[WR], doub
     QRK_STAMP_IN(6);
 
     if (RDUMP && K % 4 == 3) {
-        *reinterpret_cast<double2*>(&hl[L_IMG + j * LDP + K - 3]) = make_double2(a[K - 3], a[K - 2]);
-        *reinterpret_cast<double2*>(&hl[L_IMG + j * LDP + K - 1]) = make_double2(a[K - 1], a[K]);
+        *reinterpret_cast<double2*>(&hl[L_IMG + QRK_IC(j) * LDP + K - 3]) = make_double2(a[K - 3], a[K - 2]);
+        *reinterpret_cast<double2*>(&hl[L_IMG + QRK_IC(j) * LDP + K - 1]) = make_double2(a[K - 1], a[K]);
     }
     // ---- refresh the LDS image of the live columns after every RB-th step
     if (!(QRK_ABL & 64) && K % RB == RB - 1 && K + 1 < WR) {
         if (st.live) {   // (the column just chosen for step K+1 is skipped: it was fetched already)
 #pragma unroll
-            for (int i = K + 1; i < WR; ++i) hl[L_IMG + j * LDP + i] = a[i];
+            for (int i = K + 1; i < WR; ++i) hl[L_IMG + QRK_IC(j) * LDP + i] = a[i];
         }
     }
     QRK_STAMP_IN(7);
@@ -723,7 +744,7 @@ __device__ __forceinline__ bool epilogue32(int lane_in, int64_t pi, int64_t num_
     double c[WR];
 #pragma unroll
     for (int i = 0; i < WR; i += 2) {
-        const double2 v = *reinterpret_cast<const double2*>(&hl[L_IMG + j * LDP + i]);
+        const double2 v = *reinterpret_cast<const double2*>(&hl[L_IMG + QRK_IC(j) * LDP + i]);
         c[i] = v.x; c[i + 1] = v.y;
     }
     // (one wave per workgroup: LDS is in order, the loads above are served before the stores below; no s_barrier, whose fence
@@ -781,7 +802,9 @@ __device__ __noinline__ void redo_exact32(int64_t t, double* lds, const double* 
     exact::Shared sh;
     double* W = exact::carve_shared<64>(reinterpret_cast<unsigned char*>(lds), 32, 32, sh);
     double* q = W + 1024;
+#ifndef QRK_DIAG_LDS16
     static_assert((32 + 3 * 32 + 64) * 8 + (2 * 32 + 64) * 4 + 16 + 2 * 1024 * 8 <= 2 * L_HALF * 8, "the exact path of a 32 x 32 tile must fit the wave's LDS");
+#endif
     __syncthreads();
     exact::tile_qr<PIVOT, 64>(32, 32, tiles + t * 1024, W, q, sh);
     exact::tile_store<64>(32, 32, (int)(t * 32), W, q, sh, perm, hcoeffs, r_vals + t * 528, q_vals + t * 1024);
@@ -802,7 +825,7 @@ __device__ __noinline__ void redo_exact32(int64_t t, double* lds, const double* 
 // routine after its last round (no redo list, no second kernel behind the launch).  The rounds run in chunks of 64 so that one
 // 64-bit word per half remembers the flagged rounds.
 template <bool PIVOT, bool HC>
-__global__ void __launch_bounds__(64, 2)
+__global__ void __launch_bounds__(64, QRK_MINW)
 bdqr_pair32_kernel(int64_t num_tiles, const double* __restrict__ tiles, double* __restrict__ q_vals,
                    double* __restrict__ r_vals, int32_t* __restrict__ perm, double* __restrict__ hcoeffs)
 {
@@ -845,17 +868,17 @@ bdqr_pair32_kernel(int64_t num_tiles, const double* __restrict__ tiles, double* 
 
         // ---- stage: chunk m of the lane -> its place in the padded column-major image
 #pragma unroll
-        for (int m = 0; m < WR; ++m) hl[L_IMG + m * LDP + j] = a[m];
+        for (int m = 0; m < WR; ++m) hl[L_IMG + QRK_IC(m) * LDP + j] = a[m];
         if (!valid) {
             // missing partner of an odd last tile: diag(64..33) -- distinct norms, no tie-breaking;
             // nothing of it is stored
 #pragma unroll 4
-            for (int i = 0; i < WR; ++i) hl[L_IMG + j * LDP + i] = (i == j) ? (double)(64 - j) : 0.0;
+            for (int i = 0; i < WR; ++i) hl[L_IMG + QRK_IC(j) * LDP + i] = (i == j) ? (double)(64 - j) : 0.0;
         }
         __builtin_amdgcn_wave_barrier();   // one wave per workgroup: LDS is in order, no s_barrier (its fence would wait for the prefetch)
 #pragma unroll
         for (int i = 0; i < WR; ++i) {
-            a[i] = hl[L_IMG + j * LDP + i];
+            a[i] = hl[L_IMG + QRK_IC(j) * LDP + i];
             q[i] = (i == j && valid) ? 1.0 : 0.0;
         }
 
