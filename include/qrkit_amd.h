@@ -238,6 +238,15 @@ qrk_status qrk_dense_plan_destroy(qrk_dense_plan plan);
 qrk_status qrk_dense_factorize(qrk_dense_plan plan, double* a, int64_t lda, double* hcoeffs, int32_t* perm,
                                qrk_memspace space);
 
+/* The two-stage format keeps part of Q (the T factors of Q0 and the packed Q1) IN THE PLAN, for the array factorised last:
+ * qrk_dense_apply_q with any other array fails with QRK_STATUS_INVALID_ARGUMENT while that state is live (it would otherwise
+ * apply the wrong Q without a sign of it).  A caller that factorises several matrices with one plan and applies their Qs later
+ * (the panel chain of BlockedThinSparseQR, src/QRKit/BlockedThinSparseQR.h:105-165) switches the format off: every
+ * factorisation then leaves Eigen's self-contained packed format in the caller's own arrays.  enable = 1 switches it back on
+ * for a plan whose shape qualified at creation.  qrk_dense_plan_two_stage returns the current setting. */
+qrk_status qrk_dense_plan_set_two_stage(qrk_dense_plan plan, int enable);
+int qrk_dense_plan_two_stage(qrk_dense_plan plan);
+
 /* b (rows x nrhs, leading dimension ldb) <- Q^T b (transpose != 0) or Q b. */
 qrk_status qrk_dense_apply_q(qrk_dense_plan plan, const double* qr, int64_t lda, const double* hcoeffs,
                              int transpose, double* b, int64_t ldb, int64_t nrhs, qrk_memspace space);

@@ -24,7 +24,7 @@ EXPORTS = (
     "qrk_version", "qrk_device_count", "qrk_create", "qrk_destroy", "qrk_set_stream", "qrk_synchronize",
     "qrk_last_error", "qrk_device_alloc", "qrk_device_free", "qrk_memcpy", "qrk_bd_plan_create", "qrk_bd_plan_destroy", "qrk_bd_plan_sizes", "qrk_bd_pattern",
     "qrk_bd_tiles_from_sparse", "qrk_bd_factorize", "qrk_bd_info", "qrk_bd_apply_qt", "qrk_bd_apply_q", "qrk_bd_solve", "qrk_bd_solve_r", "qrk_dense_plan_create",
-    "qrk_dense_plan_destroy", "qrk_dense_factorize", "qrk_dense_apply_q", "qrk_bb_plan_create", "qrk_bb_plan_destroy", "qrk_bb_plan_create_fixed", "qrk_bb_blocks_from_pattern", "qrk_bb_analyze_host",
+    "qrk_dense_plan_destroy", "qrk_dense_factorize", "qrk_dense_plan_set_two_stage", "qrk_dense_plan_two_stage", "qrk_dense_apply_q", "qrk_bb_plan_create", "qrk_bb_plan_destroy", "qrk_bb_plan_create_fixed", "qrk_bb_blocks_from_pattern", "qrk_bb_analyze_host",
     "qrk_bb_plan_info", "qrk_bb_plan_blocks", "qrk_bb_pattern", "qrk_bb_factorize", "qrk_bb_apply_q", "qrk_bb_solve_r", "qrk_dense_solve_r", "qrk_bd_time_factorize", "qrk_bd_kernel_name",
     "qrk_memcpy_2d", "qrk_dense_gemv_sub", "qrk_tsqr_plan_create", "qrk_tsqr_plan_destroy", "qrk_tsqr_factorize", "qrk_tsqr_apply_q",
     "qrk_sparse_window_to_dense",
@@ -98,6 +98,10 @@ def lib() -> C.CDLL:
     L.qrk_dense_plan_destroy.argtypes = [vp]
     L.qrk_dense_factorize.restype = C.c_int
     L.qrk_dense_factorize.argtypes = [vp, dp, C.c_int64, dp, ip, C.c_int]
+    L.qrk_dense_plan_set_two_stage.restype = C.c_int
+    L.qrk_dense_plan_set_two_stage.argtypes = [vp, C.c_int]
+    L.qrk_dense_plan_two_stage.restype = C.c_int
+    L.qrk_dense_plan_two_stage.argtypes = [vp]
     L.qrk_dense_apply_q.restype = C.c_int
     L.qrk_dense_apply_q.argtypes = [vp, dp, C.c_int64, dp, C.c_int, dp, C.c_int64, C.c_int64, C.c_int]
     L.qrk_bb_plan_create.restype = C.c_int

@@ -290,6 +290,9 @@ class BlockedThinSparseQR:
             pl = C.c_void_p()
             capi.check(capi.lib().qrk_dense_plan_create(self._ctx.handle, rows, cols, capi.COLPIV_HOUSEHOLDER, C.byref(pl)),
                        self._ctx.handle)
+            # one plan serves every panel of this shape and the panels are re-applied later (matrixQ, solve): each
+            # factorisation must leave its whole Q in the panel's own arrays, not in the plan (two-stage format)
+            capi.check(capi.lib().qrk_dense_plan_set_two_stage(pl, 0), self._ctx.handle)
             self._plans[key] = pl
         return self._plans[key]
 

@@ -58,12 +58,17 @@ bdqr_exact_kernel(WaveBatch nb, const int32_t* __restrict__ ids, const int32_t* 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     Shared sh;
     carve_shared<T>(smem, maxr, maxc, sh);
+    const int64_t total_tiles = nb.num_tiles;
     double* lds_tile = reinterpret_cast<double*>(smem + exact_fixed_lds_bytes(maxr, maxc));
 
     if (next_count && blockIdx.x == 0 && threadIdx.x == 0) *next_count = 0;
-    const int64_t n = count ? (int64_t)*count : nb.num_tiles;
+    // (a list can never be longer than the batch, nor name a tile outside it: a corrupted counter must not walk the workgroups
+    // out of the arrays)
+    int64_t n = count ? (int64_t)*count : nb.num_tiles;
+    if (n > total_tiles) n = total_tiles;
     for (int64_t li = blockIdx.x; li < n; li += gridDim.x) {
         const int64_t t = ids ? (int64_t)ids[li] : li;
+        if (t < 0 || t >= total_tiles) continue;
         int r, c, cbase;
         int64_t toff, qoff, roff;
         if (nb.t_rows) {

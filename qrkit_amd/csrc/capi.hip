@@ -113,6 +113,8 @@ struct qrk_dense_plan_s {
     // factors of the first; the caller's array holds the reflectors of Q0 below / inside its top triangles and R above.
     bool two_stage = false;
     bool ts_active = false;    // the last factorisation ended in the two-stage format (false: Eigen's packed format, also after the exact path)
+    const void* ts_owner = nullptr;   // ... and this is the caller's array it was computed in: the T factors and Q1 kept in the plan belong to
+                                      // that factorisation only (qrk_dense_apply_q refuses any other array while ts_active)
     double* d_t = nullptr;
     double* d_r0 = nullptr;    // R0 (n x n), scratch of the second stage
     double* d_q1 = nullptr;    // packed QR of the second stage in Eigen's format (== d_r0 when the row-slab kernels factorise in place)
@@ -592,7 +594,7 @@ qrk_status qrk_bd_plan_create(qrk_handle h, const qrk_bd_layout* L, qrk_q_format
         }
         p->exact_num_wg = (int)std::min<int64_t>(wgs, B);
         if (hipMalloc((void**)&p->d_redo, (size_t)(B + 2 + 3) * sizeof(int32_t)) != hipSuccess ||
-            hipMemsetAsync(p->d_redo, 0, 2 * sizeof(int32_t), h->stream) != hipSuccess ||
+            hipMemset(p->d_redo, 0, 2 * sizeof(int32_t)) != hipSuccess ||   /* synchronous: the first factorisation may run on another stream */
             (p->exact_ws_stride > 0 &&
              hipMalloc((void**)&p->d_exact_ws, (size_t)p->exact_num_wg * (size_t)p->exact_ws_stride * sizeof(double)) != hipSuccess)) {
             qrk_bd_plan_destroy(p);
@@ -980,6 +982,18 @@ qrk_status qrk_dense_plan_destroy(qrk_dense_plan p)
     return QRK_STATUS_OK;
 }
 
+qrk_status qrk_dense_plan_set_two_stage(qrk_dense_plan p, int enable)
+{
+    if (!p) return fail(nullptr, QRK_STATUS_INVALID_ARGUMENT, "qrk_dense_plan_set_two_stage: null plan");
+    if (enable && !p->d_t)
+        return fail(p->h, QRK_STATUS_UNSUPPORTED, "qrk_dense_plan_set_two_stage: this plan was created without the two-stage workspaces");
+    p->two_stage = enable != 0;
+    if (!p->two_stage) { p->ts_active = false; p->ts_owner = nullptr; }
+    return QRK_STATUS_OK;
+}
+
+int qrk_dense_plan_two_stage(qrk_dense_plan p) { return p && p->two_stage ? 1 : 0; }
+
 qrk_status qrk_dense_factorize(qrk_dense_plan p, double* a, int64_t lda, double* hcoeffs, int32_t* perm,
                                qrk_memspace space)
 {
@@ -1006,6 +1020,7 @@ qrk_status qrk_dense_factorize(qrk_dense_plan p, double* a, int64_t lda, double*
                                     (size_t)p->rows * sizeof(double), (size_t)p->cols, hipMemcpyDeviceToDevice, h->stream));
         const int* flag = nullptr;
         p->ts_active = false;
+        p->ts_owner = nullptr;
         if (!h->force_exact && p->two_stage) {
             // stage 1: A = Q0 R0 (no pivoting, MFMA trailing updates); stage 2: R0 P = Q1 R on the n x n triangle
             const int n = p->cols;
@@ -1032,6 +1047,7 @@ qrk_status qrk_dense_factorize(qrk_dense_plan p, double* a, int64_t lda, double*
             QRK_HIP(h, hipMemcpyAsync(&unclear, flag, sizeof(int), hipMemcpyDeviceToHost, h->stream));
             QRK_HIP(h, hipStreamSynchronize(h->stream));
             p->ts_active = unclear == 0;
+            p->ts_owner = p->ts_active ? static_cast<const void*>(a) : nullptr;
             if (unclear) return exact_wide(da, dhc, dp, unclear);
             return QRK_STATUS_OK;
         }
@@ -1087,6 +1103,12 @@ qrk_status qrk_dense_apply_q(qrk_dense_plan p, const double* qr, int64_t lda, co
     qrk_handle h = p->h;
     QRK_HIP(h, hipSetDevice(h->device));
     const int size = p->rows < p->cols ? p->rows : p->cols;
+    // the two-stage factors kept in the plan (T of Q0, packed Q1) are those of the LAST factorisation only: applying them to another
+    // array would silently compute with the wrong Q
+    if (p->ts_active && qr != p->ts_owner)
+        return fail(h, QRK_STATUS_INVALID_ARGUMENT,
+                    "qrk_dense_apply_q: this plan last factorised a different array in the two-stage format, whose Q lives in the plan; "
+                    "factorise with one plan per matrix, or switch the format off with qrk_dense_plan_set_two_stage(plan, 0)");
     // Q = Q0 diag(Q1, I) after a two-stage factorisation (the factors of Q1 and the T factors of Q0 live in the plan)
     auto apply = [&](const double* dqr, const double* dhc, double* db) -> hipError_t {
         auto eigen_form = [&](const double* packed, int64_t ld, int rows, int nrefl) -> hipError_t {

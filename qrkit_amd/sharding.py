@@ -192,7 +192,13 @@ class ShardedBlockAngularQR:
         self.m2, self.rank_id, self.world, self.group, self.root = int(m2), rank, world, group, root
         self.ranges = shard_ranges(self.block_rows, self.block_cols, world)
         self.start, self.end = self.ranges[rank]
-        self._ctx = context or Context(0)
+        if context is None:
+            # one process per GPU: the rank's own device (LOCAL_RANK under torch.distributed.run), never "device 0 on every rank"
+            # (RCCL rejects two ranks on one device; gloo would silently serialise them)
+            import os
+            ndev = max(torch.cuda.device_count(), 1)
+            context = Context(int(os.environ.get("LOCAL_RANK", rank)) % ndev)
+        self._ctx = context
         self.m_leftSolver = BlockDiagonalSparseQR(blockSolver=capi.COLPIV_HOUSEHOLDER, qFormat=capi.FULL_Q, context=self._ctx)
         self._tsqr = DenseTSQR(self._ctx)
         self.m_rightSolver = DenseColPivQR(self._ctx, capi.COLPIV_HOUSEHOLDER) if rank == root else None
@@ -204,6 +210,7 @@ class ShardedBlockAngularQR:
     # -- exchange helpers (equal-sized pieces: one n x n triangle or one n-vector per rank)
     def _gather(self, t: torch.Tensor):
         dev = t.device
+        assert self._host_comm or dev == self._ctx.device, "RCCL collectives need the tensor on the rank's own GPU"
         t = t.contiguous().cpu() if self._host_comm else t.contiguous()
         lst = [torch.empty_like(t) for _ in range(self.world)] if self.rank_id == self.root else None
         dist.gather(t, lst, dst=self.root, group=self.group)

@@ -404,3 +404,58 @@ def test_caqr_schedules_agree_bitwise(rows, cols, monkeypatch):
                 ref = res
             for a, b in zip(res, ref):
                 assert torch.equal(a, b), f"{mode}: the result depends on the schedule"
+
+
+@pytest.mark.gpu
+def test_two_stage_state_belongs_to_the_last_factorised_array(monkeypatch):
+    """The two-stage format keeps part of Q (T of Q0, packed Q1) in the PLAN.  Factorising A and then B with one plan and applying
+    Q_A afterwards must fail loudly instead of applying B's factors to A's reflectors; with the format switched off for the plan
+    (qrk_dense_plan_set_two_stage(plan, 0): what BlockedThinSparseQR does for its cached per-shape plans) both Qs stay usable."""
+    import ctypes as C
+    import torch
+    import qrkit_amd
+    from qrkit_amd import _capi as capi
+    monkeypatch.setenv("QRK_DENSE_TWO_STAGE", "1")
+    rows, cols = 1024, 64
+    rng = np.random.default_rng(5)
+    ctx = qrkit_amd.Context(0)
+    lib = capi.lib()
+    plan = C.c_void_p()
+    capi.check(lib.qrk_dense_plan_create(ctx.handle, rows, cols, capi.COLPIV_HOUSEHOLDER, C.byref(plan)), ctx.handle)
+    assert lib.qrk_dense_plan_two_stage(plan) == 1
+    mats, facs = [], []
+    for _ in range(2):
+        A = rng.uniform(-1.0, 1.0, (rows, cols))
+        At = torch.from_numpy(np.asfortranarray(A).T.copy()).cuda().t()
+        hc = torch.empty(cols, dtype=torch.float64, device="cuda")
+        pp = torch.empty(cols, dtype=torch.int32, device="cuda")
+        capi.check(lib.qrk_dense_factorize(plan, At.data_ptr(), rows, hc.data_ptr(), pp.data_ptr(), capi.MEM_DEVICE), ctx.handle)
+        mats.append(A); facs.append((At, hc, pp))
+    b = torch.from_numpy(rng.uniform(-1, 1, (1, rows))).cuda().t()
+    # the plan now holds B's factors: A's are gone, and the call says so
+    st = lib.qrk_dense_apply_q(plan, facs[0][0].data_ptr(), rows, facs[0][1].data_ptr(), 1, b.data_ptr(), rows, 1, capi.MEM_DEVICE)
+    assert st == capi.STATUS_INVALID_ARGUMENT
+    # ... while B's own product works
+    P = facs[1][2].cpu().numpy()
+    Bm = torch.from_numpy(np.asfortranarray(mats[1][:, P]).T.copy()).cuda().t()
+    capi.check(lib.qrk_dense_apply_q(plan, facs[1][0].data_ptr(), rows, facs[1][1].data_ptr(), 1, Bm.data_ptr(), rows, cols, capi.MEM_DEVICE), ctx.handle)
+    R = np.triu(facs[1][0].cpu().numpy()[:cols])
+    assert np.linalg.norm(Bm.cpu().numpy()[:cols] - R) <= 1e-12 * np.linalg.norm(mats[1]) * np.sqrt(cols)
+    # format off: self-contained factors, both usable afterwards
+    capi.check(lib.qrk_dense_plan_set_two_stage(plan, 0), ctx.handle)
+    facs = []
+    for A in mats:
+        At = torch.from_numpy(np.asfortranarray(A).T.copy()).cuda().t()
+        hc = torch.empty(cols, dtype=torch.float64, device="cuda")
+        pp = torch.empty(cols, dtype=torch.int32, device="cuda")
+        capi.check(lib.qrk_dense_factorize(plan, At.data_ptr(), rows, hc.data_ptr(), pp.data_ptr(), capi.MEM_DEVICE), ctx.handle)
+        facs.append((At, hc, pp))
+    for A, (At, hc, pp) in zip(mats, facs):
+        P = pp.cpu().numpy()
+        Bm = torch.from_numpy(np.asfortranarray(A[:, P]).T.copy()).cuda().t()
+        capi.check(lib.qrk_dense_apply_q(plan, At.data_ptr(), rows, hc.data_ptr(), 1, Bm.data_ptr(), rows, cols, capi.MEM_DEVICE), ctx.handle)
+        ref, _, perm, _ = orc.colpiv_qr(A)
+        np.testing.assert_array_equal(P, perm)
+        assert rel_fro(np.triu(At.cpu().numpy()[:cols]), np.triu(ref[:cols])) <= 1e-12      # Eigen's format: signs included
+        assert np.linalg.norm(Bm.cpu().numpy()[:cols] - np.triu(At.cpu().numpy()[:cols])) <= 1e-12 * np.linalg.norm(A) * np.sqrt(cols)
+    lib.qrk_dense_plan_destroy(plan)

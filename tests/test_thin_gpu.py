@@ -88,3 +88,31 @@ def test_hip_thin_sparse_matches_oracle(rows, cols, bc, seed):
     x = np.random.default_rng(0).uniform(-1, 1, cols)
     PM = permuted(M, ref.perm, ref.rowperm)
     assert rel_fro(qr.solve(PM @ x), x) <= 1e-9
+
+
+@pytest.mark.gpu
+def test_hip_thin_sparse_same_shape_panels_under_forced_two_stage(monkeypatch):
+    """Two panels of one shape share a dense plan and are re-applied later (matrixQ, solve).  With the two-stage format forced
+    on (QRK_DENSE_TWO_STAGE=1) the plan would keep only the LAST panel's T / Q1: the solver must switch the format off for its
+    plans (qrk_dense_plan_set_two_stage), or the earlier panels are applied with the wrong Q (round-2 advisor finding)."""
+    import qrkit_amd
+    monkeypatch.setenv("QRK_DENSE_TWO_STAGE", "1")
+    rows, cols, bc = 96, 12, 4
+    rng = np.random.default_rng(11)
+    A = rng.uniform(0.5, 5.0, (rows, cols))       # dense: every panel but the last one's successor has the same (rows - 4k, 4) shape family
+    M = sp.csc_matrix(A)
+    ref = orc.bt_sparse_qr(M, bc)
+    ctx = qrkit_amd.Context(0)
+    qr = qrkit_amd.BlockedThinSparseQR(ctx, bc)
+    qr.compute(M)
+    np.testing.assert_array_equal(qr.colsPermutation().cpu().numpy(), ref.perm)
+    assert rel_fro(qr.matrixR().cpu().numpy(), ref.R) <= 1e-12
+    b = rng.uniform(-1, 1, rows)
+    assert rel_fro(qr._applyAny(b, True), orc.bt_apply_q(ref, b, True)) <= 1e-12
+    # same shape twice: a second compute() re-uses the cached plans, the first object's panels must still apply
+    qr2 = qrkit_amd.BlockedThinSparseQR(ctx, bc)
+    qr2._plans = qr._plans
+    M2 = sp.csc_matrix(rng.uniform(0.5, 5.0, (rows, cols)))
+    qr2.compute(M2)
+    assert rel_fro(qr._applyAny(b, True), orc.bt_apply_q(ref, b, True)) <= 1e-12
+    qr2._plans = {}
