@@ -30,12 +30,22 @@
 
 #include <float.h>
 #include <cstdlib>
+#include <type_traits>
 
 #ifndef QRK_COL_UF
 #define QRK_COL_UF 16          // loads in flight per thread in the read-only pass of the panel-blocked phase 1
 #endif
 #ifndef QRK_COL_UT
 #define QRK_COL_UT 8           // ... in the trailing update of a panel
+#endif
+#ifndef QRK_COL_MFMA_TRAIL
+#define QRK_COL_MFMA_TRAIL 1     // large class: the trailing update of a panel on the matrix cores (0 = one thread per column, scalar FMAs)
+#endif
+#ifndef QRK_COL_BIGW
+#define QRK_COL_BIGW 2           // waves per SIMD the large-class instantiation is compiled for
+#endif
+#ifndef QRK_COL_REGROWS
+#define QRK_COL_REGROWS 48     // rows of its column that a thread of the large class keeps in registers (0 = none)
 #endif
 #ifndef QRK_COL_BLOCKED
 #define QRK_COL_BLOCKED 1      // tiles in global memory: panel-blocked phase 1 (0 = fused level-2 sweeps)
@@ -88,7 +98,11 @@ __device__ __forceinline__ Cand wave_best(Cand c)
 // Everything of one tile.  Called once with W in LDS and once with W in global memory, so that after
 // inlining hipcc knows the address space of every access: through one generic pointer it has to assume
 // that a store to W may alias the LDS vectors and serialises the sweeps on the store latency.
-template <int CT, bool BLOCKED, bool DYN>
+// REG (the large class, panel-blocked form): every column thread keeps the LAST RR rows of its column in registers for as long
+// as the panels stay above them.  The read-only pass of a step covers rows k.. of every live column, so rows near the bottom are
+// read in (almost) every step: with RR = 64 of 256 rows 37 % of the bytes of all passes never leave the registers (48 % at 192
+// rows).  The registers are written back once, when the first panel reaches them.
+template <int CT, bool BLOCKED, bool DYN, bool REG = false>
 __device__ __forceinline__ void factor_tile(double* __restrict__ W, double* smem, int r, int c, int cbase, int pivoting,
                                             const double* __restrict__ src, double* __restrict__ Q,
                                             double* __restrict__ rv, int32_t* __restrict__ perm,
@@ -160,8 +174,24 @@ __device__ __forceinline__ void factor_tile(double* __restrict__ W, double* smem
         double* cvec = gm + NBP;              // [NBP] V^T v
         double* red = tm;                     // [NW] block reduction
         double F[NBP];
-        for (int k0 = 0; k0 < c; k0 += NBP) {
+        constexpr int RR = REG ? QRK_COL_REGROWS : 1;
+        double ar[RR];                        // rows rbase.. of this thread's column while inreg
+        const int rbase = r - RR;
+        const bool use_reg = REG && rbase >= 2 * NBP;
+        double* xr = smem;                    // [RR] register rows of the pivot column, published by its thread (the LDS that holds
+                                              // A in the LDS-resident form is free here)
+        // panels [0, kflush) run with the register rows, the rest without: two instantiations of the panel loop, so that inside each
+        // the register array is read and written unconditionally (a register array defined under a run-time flag ends up in scratch)
+        int kflush = 0;
+        if (use_reg) { kflush = (rbase / NBP) * NBP; const int cend = ((c + NBP - 1) / NBP) * NBP; if (kflush > cend) kflush = cend; }
+#pragma unroll
+        for (int u = 0; u < RR; ++u) { const int ii = (use_reg && isA) ? rbase + u : 0; ar[u] = wc[(int64_t)ii * ld]; }
+        auto run_panels = [&](auto tag, const int k0_begin, const int k0_end) {
+        constexpr bool inreg = decltype(tag)::value;
+        constexpr bool MFMA_TRAIL = !DYN && CT == 256 && QRK_COL_MFMA_TRAIL != 0;
+        for (int k0 = k0_begin; k0 < k0_end && k0 < c; k0 += NBP) {
             const int kb = (c - k0) < NBP ? (c - k0) : NBP;
+            const int rm = inreg ? rbase : r;  // rows [k, rm) of the live columns are in memory
 #pragma unroll
             for (int l = 0; l < NBP; ++l) F[l] = 0.0;
             for (int j = 0; j < kb; ++j) {
@@ -185,16 +215,31 @@ __device__ __forceinline__ void factor_tile(double* __restrict__ W, double* smem
                     live = false; col_of_pos[k] = tid;
 #pragma unroll
                     for (int l = 0; l < NBP; ++l) fP[l] = F[l];
+                    if (inreg) {
+#pragma unroll
+                        for (int u = 0; u < RR; ++u) xr[u] = ar[u];
+                    }
                 }
                 __syncthreads();
                 // x = column P brought up to date (rows k..): A(k:, P) - V(k:, 0:j) F(P, 0:j)^T
                 double part = 0.0;
-                for (int i = k + tid; i < r; i += CT) {
+                for (int i = k + tid; i < rm; i += CT) {
                     double x = W[(int64_t)i * ld + P];
 #pragma unroll
                     for (int l = 0; l < NBP; ++l) if (l < j) x = fma(-vp[(i - k0) * NBP + l], fP[l], x);
                     xv[i] = x;
                     if (i > k) part = fma(x, x, part);
+                }
+                if (inreg) {
+                    // (the rows the pivot thread held in registers; separate loop: one loop with a pointer chosen per row makes hipcc
+                    //  emit a generic-address select that its own verifier rejects)
+                    for (int i = rbase + tid; i < r; i += CT) {
+                        double x = xr[i - rbase];
+#pragma unroll
+                        for (int l = 0; l < NBP; ++l) if (l < j) x = fma(-vp[(i - k0) * NBP + l], fP[l], x);
+                        xv[i] = x;
+                        part = fma(x, x, part);
+                    }
                 }
                 part = wave_sum_d(part);
                 if (lane == 0) red[wave] = part;
@@ -240,12 +285,20 @@ __device__ __forceinline__ void factor_tile(double* __restrict__ W, double* smem
                         // (U loads in flight, no scalar tail: rows past the end are clamped and meet a zero of v, so the sum
                         //  is the same sequence of FMAs - the pass is bound by the round trips to L2 / Infinity Cache)
                         constexpr int U = QRK_COL_UF;
-                        for (int i = k; i < r; i += U) {
+                        for (int i = k; i < rm; i += U) {
                             double wv[U];
 #pragma unroll
-                            for (int u = 0; u < U; ++u) { int ii = i + u; ii = ii < r ? ii : r - 1; wv[u] = wc[(int64_t)ii * ld]; }
+                            for (int u = 0; u < U; ++u) { int ii = i + u; ii = ii < rm ? ii : rm - 1; wv[u] = wc[(int64_t)ii * ld]; }
 #pragma unroll
-                            for (int u = 0; u < U; ++u) { const int ii = i + u; f = fma(wv[u], ii < r ? xv[ii < r ? ii : r - 1] : 0.0, f); }
+                            for (int u = 0; u < U; ++u) { const int ii = i + u; f = fma(wv[u], ii < rm ? xv[ii < rm ? ii : rm - 1] : 0.0, f); }
+                        }
+                        if (inreg) {
+                            // (eight rows at a time: left alone, the scheduler hoists all RR reads of v ahead of the FMAs and spills)
+#pragma unroll
+                            for (int u = 0; u < RR; ++u) {
+                                f = fma(ar[u], xv[rbase + u], f);
+                                if ((u & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+                            }
                         }
                     }
 #pragma unroll
@@ -269,11 +322,21 @@ __device__ __forceinline__ void factor_tile(double* __restrict__ W, double* smem
                         if (nn <= thr) {
                             if (in_recompute_band(nn, thr, a2)) unclear = true;    // (2) inside the band around Eigen's threshold
                             double s2 = 0.0;
-                            for (int i = k + 1; i < r; ++i) {
+                            for (int i = k + 1; i < rm; ++i) {
                                 double a = wc[(int64_t)i * ld];
 #pragma unroll
                                 for (int l = 0; l < NBP; ++l) if (l <= j) a = fma(-vp[(i - k0) * NBP + l], F[l], a);
                                 s2 = fma(a, a, s2);
+                            }
+                            if (inreg) {
+#pragma unroll
+                                for (int u = 0; u < RR; ++u) {
+                                    double a = ar[u];
+#pragma unroll
+                                    for (int l = 0; l < NBP; ++l) if (l <= j) a = fma(-vp[(rbase + u - k0) * NBP + l], F[l], a);
+                                    s2 = fma(a, a, s2);
+                                    if ((u & 1) == 1) __builtin_amdgcn_sched_barrier(0);
+                                }
                             }
                             nu2 = s2; thr = s2 * THR_HI;
                         }
@@ -282,24 +345,89 @@ __device__ __forceinline__ void factor_tile(double* __restrict__ W, double* smem
             }
             COL_TICK(5);
             // trailing update of the live columns: A(k0+kb:, t) -= V(k0+kb:, :) F(t, :)^T
-            if (live) {
+            if (MFMA_TRAIL) {
+                // The same update on the matrix cores (the large class: fixed LDS layout, whose A region is free here):
+                // A(row0:rm, :) += V(row0:rm, 0:16) (-F)^T as 16 x 16 tiles with v_mfma_f64_16x16x4_f64, a wave per strip of 16
+                // columns.  -F^T goes through LDS (the B operand wants F(col, 4 ks + lane / 16) of column lane % 16: other
+                // threads' registers); chosen columns carry zeros, so their places (reflectors) are rewritten unchanged.  The
+                // products of one entry are accumulated in the order l = 0..15 of the scalar form.
+                typedef double d4 __attribute__((ext_vector_type(4)));
+                double* fT = smem + 64;                     // [NBP][CT]
+#pragma unroll
+                for (int l = 0; l < NBP; ++l) fT[l * CT + tid] = live ? -F[l] : 0.0;
+                __syncthreads();
+                const int row0 = k0 + kb;
+                const int kq = lane >> 4, l15 = lane & 15;
+                const int nrt = (rm - row0 + 15) >> 4, nct = (c + 15) >> 4;
+                for (int st = wave; st < nct; st += NW) {
+                    const int col = 16 * st + l15;
+                    const bool cok = col < c;
+                    double bop[4];
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) bop[ks] = fT[(4 * ks + kq) * CT + (cok ? col : 0)];
+                    if (!cok) { bop[0] = 0.0; bop[1] = 0.0; bop[2] = 0.0; bop[3] = 0.0; }
+                    double* wcol = W + (cok ? col : 0);
+                    constexpr int UT = 2;
+                    for (int rt = 0; rt < nrt; rt += UT) {
+                        d4 dv[UT];
+#pragma unroll
+                        for (int u2 = 0; u2 < UT; ++u2)
+#pragma unroll
+                            for (int z = 0; z < 4; ++z) {
+                                int row = row0 + 16 * (rt + u2) + kq + 4 * z; row = row < rm ? row : rm - 1;
+                                dv[u2][z] = wcol[(int64_t)row * ld];
+                            }
+#pragma unroll
+                        for (int u2 = 0; u2 < UT; ++u2) {
+                            int arow = row0 + 16 * (rt + u2) + l15; arow = arow < rm ? arow : rm - 1;
+#pragma unroll
+                            for (int ks = 0; ks < 4; ++ks)
+                                dv[u2] = __builtin_amdgcn_mfma_f64_16x16x4f64(vp[(arow - k0) * NBP + 4 * ks + kq], bop[ks], dv[u2], 0, 0, 0);
+#pragma unroll
+                            for (int z = 0; z < 4; ++z) {
+                                const int row = row0 + 16 * (rt + u2) + kq + 4 * z;
+                                if (row < rm && cok) wcol[(int64_t)row * ld] = dv[u2][z];
+                            }
+                        }
+                    }
+                }
+            } else if (live) {
                 constexpr int U = QRK_COL_UT;
-                for (int i = k0 + kb; i < r; i += U) {
+                for (int i = k0 + kb; i < rm; i += U) {
                     double wv[U];
 #pragma unroll
-                    for (int u = 0; u < U; ++u) { int ii = i + u; ii = ii < r ? ii : r - 1; wv[u] = wc[(int64_t)ii * ld]; }
+                    for (int u = 0; u < U; ++u) { int ii = i + u; ii = ii < rm ? ii : rm - 1; wv[u] = wc[(int64_t)ii * ld]; }
 #pragma unroll
                     for (int u = 0; u < U; ++u) {
-                        int ii = i + u; const bool in = ii < r; ii = in ? ii : r - 1;
+                        int ii = i + u; const bool in = ii < rm; ii = in ? ii : rm - 1;
 #pragma unroll
                         for (int l = 0; l < NBP; ++l) wv[u] = fma(-vp[(ii - k0) * NBP + l], F[l], wv[u]);
                         if (in) wc[(int64_t)ii * ld] = wv[u];
                     }
                 }
             }
+            if (inreg && live) {
+#pragma unroll
+                for (int u = 0; u < RR; ++u) {
+#pragma unroll
+                    for (int l = 0; l < NBP; ++l) ar[u] = fma(-vp[(rbase + u - k0) * NBP + l], F[l], ar[u]);
+                    if ((u & 1) == 1) __builtin_amdgcn_sched_barrier(0);
+                }
+            }
             __syncthreads();
             COL_TICK(6);
         }
+        };
+        run_panels(std::integral_constant<bool, REG>(), 0, kflush);
+        if (REG && kflush > 0) {
+            // the next panel reaches the register rows: back to memory (live columns only: a chosen column's place holds its reflector)
+            if (live) {
+#pragma unroll
+                for (int u = 0; u < RR; ++u) wc[(int64_t)(rbase + u) * ld] = ar[u];
+            }
+            __syncthreads();
+        }
+        run_panels(std::integral_constant<bool, false>(), kflush, c);
 #ifdef QRK_COL_PROF
         if (blockIdx.x == 0 && (tid == 0 || tid == c - 1 || tid == c / 2))
             printf("col prof (last column's thread, 100 MHz ticks): pivot %llu  x %llu  v %llu  VtV %llu  Fpass %llu  downdate %llu  trailing %llu\n",
@@ -615,7 +743,7 @@ __device__ __forceinline__ void factor_tile(double* __restrict__ W, double* smem
 // spilled) and LDS carved for the largest tile of the launch: 96x96 533k -> 757k tiles/s, 128x128 326k -> 443k, while
 // the same settings cost the 192...256 tiles 3 % and a mixed 8...256 batch 6 %.
 template <int CT, bool BIG>
-__global__ void __launch_bounds__(CT) __attribute__((amdgpu_waves_per_eu(BIG ? 2 : 3)))
+__global__ void __launch_bounds__(CT) __attribute__((amdgpu_waves_per_eu(BIG ? QRK_COL_BIGW : 3)))
 bdqr_col_kernel(WaveBatch nb, const double* __restrict__ tiles, double* __restrict__ q_vals,
                 double* __restrict__ r_vals, int32_t* __restrict__ perm, double* __restrict__ hcoeffs,
                 double* __restrict__ workspace, int64_t ws_stride, int w_lds, int max_r,
@@ -642,7 +770,7 @@ bdqr_col_kernel(WaveBatch nb, const double* __restrict__ tiles, double* __restri
             factor_tile<CT, false, DYN>(smem, smem, r, c, cbase, nb.pivoting, tiles + toff, q_vals + qoff, r_vals + roff, perm, hcoeffs,
                                         w_lds, max_r, redo_count, redo_ids, gidx);
         else
-            factor_tile<CT, QRK_COL_BLOCKED != 0, DYN>(workspace + (int64_t)blockIdx.x * ws_stride, smem, r, c, cbase, nb.pivoting,
+            factor_tile<CT, QRK_COL_BLOCKED != 0, DYN, (BIG && QRK_COL_BLOCKED != 0 && QRK_COL_REGROWS > 0)>(workspace + (int64_t)blockIdx.x * ws_stride, smem, r, c, cbase, nb.pivoting,
                                                        tiles + toff, q_vals + qoff, r_vals + roff, perm, hcoeffs, w_lds, max_r,
                                                        redo_count, redo_ids, gidx);
         __syncthreads();

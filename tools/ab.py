@@ -19,11 +19,12 @@ def build(specs):
     os.makedirs(OUT, exist_ok=True)
     for f in glob.glob(os.path.join(OUT, "*.so")):
         os.remove(f)
-    objs = [o for o in glob.glob(os.path.join(ROOT, "build", "obj", "*.o")) if not o.endswith("bdqr_pair.o")]
+    base = os.environ.get("QRK_AB_SRC", "bdqr_pair.hip")      # which kernel source the variants are builds of
+    objs = [o for o in glob.glob(os.path.join(ROOT, "build", "obj", "*.o")) if not o.endswith(base.replace(".hip", ".o"))]
     procs = []
     for spec in specs:
         name, _, flags = spec.partition(":")
-        src = os.path.join(ROOT, "qrkit_amd", "csrc", "bdqr_pair.hip")
+        src = os.path.join(ROOT, "qrkit_amd", "csrc", base)
         if flags.startswith("@"):            # name:@path -> another source file
             src, flags = flags[1:], ""
         o = os.path.join(OUT, f"pair_{name}.o")
