@@ -263,6 +263,43 @@ qrk_status qrk_dense_solve_r(qrk_dense_plan plan, const double* qr, int64_t lda,
 qrk_status qrk_dense_gemv_sub(qrk_handle h, const double* S, int64_t lds, int64_t rows, int64_t cols, const int32_t* colidx,
                               const double* z, double* y);
 
+/* --------------------------------- banded matrix given as dense strips: two-stage factorisation */
+
+/* BandedBlockedSparseQR::factorize (src/QRKit/BandedBlockedSparseQR.h:463-508) for a block-banded matrix whose block rows are
+ * handed over as DENSE STRIPS: strip i is strip_rows x strip_cols and covers the rows [i strip_rows, (i+1) strip_rows) and the
+ * columns [i col_step, i col_step + strip_cols) (BASELINE configs[2]: 50 000 strips of 256 x 192, step 64 -- 2.46e9 stored
+ * entries, more than the int32 StorageIndex of the reference's SparseMatrix, and of qrk_bb_plan_create's CSR, can index; here
+ * every offset is 64-bit).  The factorisation runs in two stages:
+ *   A  every strip is triangularised on its own, A_i = Q_i [R_i; 0]: one workgroup per strip over all CUs (the block-diagonal
+ *      solver's kernels, HouseholderQR);
+ *   B  a chain over the strips merges the carried triangle (the strip_cols - col_step columns the next strip shares) with R_i:
+ *      the two triangles are stacked with their rows interleaved, which makes the stack a staircase whose zeros the
+ *      Householder sweep never visits; col_step rows of R leave per step, the rest is carried on.
+ * The reference re-factorises (leftover + strip_rows) x strip_cols per step (:503-506).  R is the reference's up to the sign of
+ * each ROW (R is unique up to row signs for a fixed column order; the signs follow the elimination order);
+ * Q is kept as the two sequences of reflectors, not as the reference's Y / T blocks.  All pointers are device pointers.
+ *
+ * Layout of Q^T b / of the argument of Q (rows = num_strips strip_rows entries): first the cols = (num_strips - 1) col_step +
+ * strip_cols entries that belong to the rows of R, then per strip i the components orthogonal to the columns: (strip_cols -
+ * col_step) of the chain (strips 1..), then strip_rows - strip_cols of stage A. */
+typedef struct qrk_bbs_plan_s* qrk_bbs_plan;
+qrk_status qrk_bbs_plan_create(qrk_handle h, int64_t num_strips, int32_t strip_rows, int32_t strip_cols, int32_t col_step,
+                               qrk_bbs_plan* out);
+qrk_status qrk_bbs_plan_destroy(qrk_bbs_plan plan);
+/* rows, cols of the matrix; r_len = doubles of R kept by the plan (col_step x strip_cols per strip, strip_cols^2 for the last) */
+qrk_status qrk_bbs_plan_sizes(qrk_bbs_plan plan, int64_t* rows, int64_t* cols, int64_t* r_len);
+/* strips: strip i column-major (leading dimension strip_rows) at strips + i strip_rows strip_cols.  Enqueue only. */
+qrk_status qrk_bbs_factorize(qrk_bbs_plan plan, const double* strips);
+/* the rows of R emitted by strip i: rows [i col_step, ..) x columns [i col_step, i col_step + strip_cols), column-major with
+ * leading dimension = the number of rows (col_step; strip_cols for the last strip), upper trapezoidal */
+qrk_status qrk_bbs_r_rows(qrk_bbs_plan plan, int64_t strip, double* r_rows);
+/* out = Q^T v (transpose != 0) or Q v; v, out: rows x nrhs (ld = rows), distinct; work: rows x nrhs doubles.  v is not modified
+ * logically (the Q v direction reads it only). */
+qrk_status qrk_bbs_apply_q(qrk_bbs_plan plan, int transpose, const double* v, double* out, int64_t nrhs, double* work);
+/* least squares: x (cols x nrhs, ld = cols) = R^-1 (Q^T b)(0:cols) (BandedBlockedSparseQR::_solve_impl, :290-311);
+ * b: rows x nrhs; work: 2 rows nrhs doubles */
+qrk_status qrk_bbs_solve(qrk_bbs_plan plan, const double* b, double* x, int64_t nrhs, double* work);
+
 /* ------------------------------------- right block sharded over GPUs: local TSQR stage */
 
 /* rightSolver.compute(J2.bottomRows(...)) (src/QRKit/BlockAngularSparseQR.h:361-369) when the rows of J2 live on several

@@ -28,6 +28,7 @@ EXPORTS = (
     "qrk_bb_plan_info", "qrk_bb_plan_blocks", "qrk_bb_pattern", "qrk_bb_factorize", "qrk_bb_apply_q", "qrk_bb_solve_r", "qrk_dense_solve_r", "qrk_bd_time_factorize", "qrk_bd_kernel_name",
     "qrk_memcpy_2d", "qrk_dense_gemv_sub", "qrk_tsqr_plan_create", "qrk_tsqr_plan_destroy", "qrk_tsqr_factorize", "qrk_tsqr_apply_q",
     "qrk_sparse_window_to_dense",
+    "qrk_bbs_plan_create", "qrk_bbs_plan_destroy", "qrk_bbs_plan_sizes", "qrk_bbs_factorize", "qrk_bbs_r_rows", "qrk_bbs_apply_q", "qrk_bbs_solve",
 )
 
 
@@ -104,6 +105,20 @@ def lib() -> C.CDLL:
     L.qrk_dense_plan_two_stage.argtypes = [vp]
     L.qrk_dense_apply_q.restype = C.c_int
     L.qrk_dense_apply_q.argtypes = [vp, dp, C.c_int64, dp, C.c_int, dp, C.c_int64, C.c_int64, C.c_int]
+    L.qrk_bbs_plan_create.restype = C.c_int
+    L.qrk_bbs_plan_create.argtypes = [vp, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]
+    L.qrk_bbs_plan_destroy.restype = C.c_int
+    L.qrk_bbs_plan_destroy.argtypes = [vp]
+    L.qrk_bbs_plan_sizes.restype = C.c_int
+    L.qrk_bbs_plan_sizes.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    L.qrk_bbs_factorize.restype = C.c_int
+    L.qrk_bbs_factorize.argtypes = [vp, dp]
+    L.qrk_bbs_r_rows.restype = C.c_int
+    L.qrk_bbs_r_rows.argtypes = [vp, C.c_int64, dp]
+    L.qrk_bbs_apply_q.restype = C.c_int
+    L.qrk_bbs_apply_q.argtypes = [vp, C.c_int, dp, dp, C.c_int64, dp]
+    L.qrk_bbs_solve.restype = C.c_int
+    L.qrk_bbs_solve.argtypes = [vp, dp, dp, C.c_int64, dp]
     L.qrk_bb_plan_create.restype = C.c_int
     L.qrk_bb_plan_create.argtypes = [vp, C.c_int32, C.c_int32, ip, ip, C.c_int32, C.POINTER(vp)]
     L.qrk_bb_plan_destroy.restype = C.c_int

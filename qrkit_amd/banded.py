@@ -191,3 +191,86 @@ class BandedBlockedSparseQR:
                 capi.lib().qrk_bb_plan_destroy(self._plan)
         except Exception:
             pass
+
+
+class BandedStripsQR:
+    """BandedBlockedSparseQR::factorize / matrixQ / solve (src/QRKit/BandedBlockedSparseQR.h:463-508, :290-311) for a block-banded
+    matrix handed over as dense strips (qrk_bbs_*, include/qrkit_amd.h): strip i is strip_rows x strip_cols, rows
+    [i strip_rows, ..), columns [i col_step, i col_step + strip_cols).  Two stages on the device: every strip triangularised on
+    all CUs, then a chain that merges the carried triangle with the strip's (the reference re-factorises the whole stacked panel
+    per step).  R is the reference's up to row signs; 64-bit offsets throughout (BASELINE configs[2] does not fit int32)."""
+
+    def __init__(self, num_strips: int, strip_rows: int, strip_cols: int, col_step: int, context: Optional[Context] = None, device: int = 0):
+        self._ctx = context or Context(device)
+        self.num_strips, self.strip_rows, self.strip_cols, self.col_step = int(num_strips), int(strip_rows), int(strip_cols), int(col_step)
+        self._plan = C.c_void_p()
+        capi.check(capi.lib().qrk_bbs_plan_create(self._ctx.handle, self.num_strips, self.strip_rows, self.strip_cols, self.col_step,
+                                                  C.byref(self._plan)), self._ctx.handle)
+        r, c, rl = C.c_int64(), C.c_int64(), C.c_int64()
+        capi.check(capi.lib().qrk_bbs_plan_sizes(self._plan, C.byref(r), C.byref(c), C.byref(rl)))
+        self._rows, self._cols, self._rlen = r.value, c.value, rl.value
+        self.m_isInitialized = False
+
+    def rows(self):
+        return self._rows
+
+    def cols(self):
+        return self._cols
+
+    def factorize(self, strips: torch.Tensor):
+        """strips: device tensor of num_strips * strip_rows * strip_cols doubles, strip i column-major."""
+        assert strips.dtype == torch.float64 and strips.is_cuda and strips.numel() == self.num_strips * self.strip_rows * self.strip_cols
+        self._ctx.use_current_stream()
+        capi.check(capi.lib().qrk_bbs_factorize(self._plan, strips.data_ptr()), self._ctx.handle)
+        self.m_isInitialized = True
+        return self
+
+    compute = factorize
+
+    def rRows(self, strip: int) -> torch.Tensor:
+        """The rows of R emitted by strip i as a (solved x strip_cols) tensor: rows [i col_step, ..), columns [i col_step, ..)."""
+        solved = self.col_step if strip + 1 < self.num_strips else self.strip_cols
+        out = torch.empty(self.strip_cols, solved, dtype=torch.float64, device=self._ctx.device)
+        capi.check(capi.lib().qrk_bbs_r_rows(self._plan, strip, out.data_ptr()), self._ctx.handle)
+        return out.t()
+
+    def matrixR_dense(self) -> np.ndarray:
+        """Dense cols x cols upper triangle (small problems / tests only)."""
+        R = np.zeros((self._cols, self._cols))
+        for i in range(self.num_strips):
+            blk = self.rRows(i).cpu().numpy()
+            R[i * self.col_step:i * self.col_step + blk.shape[0], i * self.col_step:i * self.col_step + self.strip_cols] = blk
+        return R
+
+    def applyQ(self, v: torch.Tensor, transpose: bool) -> torch.Tensor:
+        """v: (rows,) or (rows, nrhs) column-major device tensor; returns Q^T v or Q v in the layout of include/qrkit_amd.h
+        (first cols entries: the rows of R)."""
+        one = v.dim() == 1
+        V = v.reshape(self._rows, -1)
+        V = V.t().contiguous().t() if not V.t().is_contiguous() else V
+        nrhs = V.shape[1]
+        out = torch.empty_like(V)
+        work = torch.empty(self._rows * nrhs, dtype=torch.float64, device=V.device)
+        src = V.clone() if not transpose else V          # (the Q v direction reads its argument through a non-const pointer)
+        self._ctx.use_current_stream()
+        capi.check(capi.lib().qrk_bbs_apply_q(self._plan, 1 if transpose else 0, src.data_ptr(), out.data_ptr(), nrhs, work.data_ptr()),
+                   self._ctx.handle)
+        return out[:, 0] if one else out
+
+    def solve(self, b: torch.Tensor) -> torch.Tensor:
+        one = b.dim() == 1
+        B = b.reshape(self._rows, -1)
+        B = B.t().contiguous().t() if not B.t().is_contiguous() else B
+        nrhs = B.shape[1]
+        x = torch.empty(nrhs, self._cols, dtype=torch.float64, device=B.device).t()
+        work = torch.empty(2 * self._rows * nrhs, dtype=torch.float64, device=B.device)
+        self._ctx.use_current_stream()
+        capi.check(capi.lib().qrk_bbs_solve(self._plan, B.data_ptr(), x.data_ptr(), nrhs, work.data_ptr()), self._ctx.handle)
+        return x[:, 0] if one else x
+
+    def __del__(self):
+        try:
+            if self._plan:
+                capi.lib().qrk_bbs_plan_destroy(self._plan)
+        except Exception:
+            pass

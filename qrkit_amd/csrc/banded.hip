@@ -236,8 +236,13 @@ __host__ __device__ constexpr int bb_qr_aux_doubles(int OB) { return OB * OB + 8
 //    W -= V u.  W crosses this CU's L2 port twice per OB reflectors; with one reflector, or eight, at a time that
 //    port was the bound (0.55 ms of a 1.6 ms panel).
 // uni: [OB * ld] block (column-major, ld = m | 1), then bb_qr_aux_doubles(OB).
-template <int OB>
-__device__ __attribute__((noinline)) void bb_panel_qr(double* __restrict__ W, const int m, const int n
+// rlim (or null): rlim[g] = rows of the panel that can be nonzero in the columns [16 g, 16 g + 16) before this factorisation
+// (a staircase profile, non-decreasing in g): the block of columns that ends with group g then works on the rows below its
+// first one and above rlim[g] only -- the rows beyond are zero in these columns and no reflector of the block touches them.
+// NR: 64-row registers per lane that hold a column of the block (a block never works on more than 64 NR rows: the caller picks
+// the smallest instantiation that covers its tallest block -- every reflector costs NR FMAs per column and NR LDS reads)
+template <int OB, int NR = 256 / OB>
+__device__ __attribute__((noinline)) void bb_panel_qr(double* __restrict__ W, const int m, const int n, const int* __restrict__ rlim
 #ifdef QRK_BB_PROF
                                             , unsigned long long* qt
 #endif
@@ -251,7 +256,6 @@ __device__ __attribute__((noinline)) void bb_panel_qr(double* __restrict__ W, co
     double* uni = sc + 8;
     const int tid = threadIdx.x;
     constexpr int CPW = OB / 16;               // columns of the block per wave
-    constexpr int NR = 256 / OB;               // rows per lane: 512 rows with OB = 32, 1024 with OB = 16
     constexpr int MT = OB / 16;                // 16-row tiles of reflectors
     const int wv = tid >> 6, ln = tid & 63;
     const int ld = m | 1;
@@ -269,7 +273,9 @@ __device__ __attribute__((noinline)) void bb_panel_qr(double* __restrict__ W, co
 
     for (int jb = 0; jb < n; jb += OB) {
         const int ob = (n - jb) < OB ? (n - jb) : OB;
-        const int mr = m - jb;                 // rows jb.. of the panel take part (local row i = panel row jb + i)
+        int mtop = m;
+        if (rlim) { const int lim = rlim[(jb + ob - 1) >> 4]; mtop = lim < m ? lim : m; }
+        const int mr = mtop - jb;              // rows jb.. of the panel take part (local row i = panel row jb + i)
         // 1. block to LDS (coalesced rows of W), then to the registers of the owning waves
         for (int e = tid; e < mr * OB; e += BC_THREADS) {
             const int i = e / OB, l = e - i * OB;
@@ -583,7 +589,7 @@ bb_chain2_kernel(const BBPanel* __restrict__ panels, int num_panels, const int32
                  const int32_t* __restrict__ pcol, const int64_t* __restrict__ pmap, const double* __restrict__ vals,
                  double* __restrict__ lo, double* __restrict__ y_vals,
                  double* __restrict__ t_vals, double* __restrict__ r_stage, int max_act_rows, int max_ncols,
-                 int uni_doubles)
+                 int uni_doubles, const int* __restrict__ rlim_first, const int* __restrict__ rlim_rest)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double* hc = smem;                         // [BC_CW] hCoeffs of the panel
@@ -609,24 +615,35 @@ bb_chain2_kernel(const BBPanel* __restrict__ panels, int num_panels, const int32
         // ... with its top-left corner replaced by the leftover block of the previous panel (:504-506)
         for (int e = tid; e < p.lo_rows * p.lo_cols; e += BC_THREADS) {
             const int i = e / p.lo_cols, j = e - i * p.lo_cols;
-            W[(int64_t)i * n + j] = lo[e];
+            W[(int64_t)(i * p.lo_stride) * n + j] = lo[e];
         }
         __syncthreads();
+        const int* rlim = pi == 0 ? rlim_first : rlim_rest;
 
         BB_TICK(0);
         // ---- Eigen::HouseholderQR of the panel (:459-470): blocks of 32 columns when the block fits the LDS
         // next to its T and the partial sums (m <= ~470), else of 16
+        // tallest block of this panel: all of it without a staircase, else the largest rlim[g] - (first row of its block)
+        int tall = m;
+        if (rlim) {
+            tall = 0;
+            for (int jb = 0; jb < n; jb += 32) {
+                const int ob = (n - jb) < 32 ? (n - jb) : 32;
+                int lim = rlim[(jb + ob - 1) >> 4]; lim = lim < m ? lim : m;
+                tall = (lim - jb) > tall ? (lim - jb) : tall;
+            }
+        }
         if ((int64_t)32 * (m | 1) + bb_qr_aux_doubles(32) <= (int64_t)uni_doubles) {
 #ifdef QRK_BB_PROF
-            bb_panel_qr<32>(W, m, n, qt);
+            if (tall <= 192) bb_panel_qr<32, 3>(W, m, n, rlim, qt); else if (tall <= 256) bb_panel_qr<32, 4>(W, m, n, rlim, qt); else bb_panel_qr<32>(W, m, n, rlim, qt);
 #else
-            bb_panel_qr<32>(W, m, n);
+            if (tall <= 192) bb_panel_qr<32, 3>(W, m, n, rlim); else if (tall <= 256) bb_panel_qr<32, 4>(W, m, n, rlim); else bb_panel_qr<32>(W, m, n, rlim);
 #endif
         } else {
 #ifdef QRK_BB_PROF
-            bb_panel_qr<16>(W, m, n, qt);
+            bb_panel_qr<16>(W, m, n, rlim, qt);
 #else
-            bb_panel_qr<16>(W, m, n);
+            bb_panel_qr<16>(W, m, n, rlim);
 #endif
         }
         __syncthreads();
@@ -991,26 +1008,69 @@ bb_gather_r_kernel(const double* __restrict__ r_stage, const int64_t* __restrict
 // ahead of time (0.093: vmcnt retires in order, so the first real load waits for the prefetches).
 constexpr int BA_THREADS = 1024;
 constexpr int BA_WAVES = BA_THREADS / 64;
+// Strips form (BBStrips, launch_bbs_apply): the chain of stage B of the two-stage banded factorisation.  Panel i works on the
+// stack [carry of panel i-1 interleaved with the first lo rows of R_i; the other rows of R_i]; its vector is gathered from the
+// carry (LDS) and from the strip's stage-A vector ya_i, and leaves as: solved rows of the R part, the carry of the next panel
+// and lo residual components.  Layout of the full vector (rows = N m_s): [R part, cols] then per strip [lo chain residuals
+// (strips 1..) | m_s - n stage-A residuals].
+struct BBStrips {
+    double* ya;          // [nrhs][N][ms]: stage-A vectors Q_i^T b_i (transpose: in; else: out)
+    double* full;        // [nrhs][rows]: the vector in the layout above (transpose: out; else: in)
+    int64_t ya_ld, full_ld;
+    int ms, n, s, lo, cols;
+};
+__device__ __forceinline__ int64_t bbs_res_off(const BBStrips& S, int i)
+{
+    return (int64_t)S.cols + (int64_t)i * (S.ms - S.n) + (i >= 1 ? (int64_t)(i - 1) * S.lo : 0);
+}
+
 __global__ void __launch_bounds__(BA_THREADS)
 bb_apply_q_kernel(const BBPanel* __restrict__ panels, int num_panels, const double* __restrict__ y_vals,
                   const double* __restrict__ t_vals, int transpose, double* __restrict__ v, int64_t ldv, int64_t nrhs,
-                  int max_act_rows, int max_ncols)
+                  int max_act_rows, int max_ncols, const BBStrips S)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double* seg = smem;                      // [max_act_rows]
     double* w1 = seg + max_act_rows;         // [max_ncols]
     double* w2 = w1 + max_ncols;             // [max_ncols]
     double* part = w2 + max_ncols;           // [BA_THREADS]
+    double* carry = part + BA_THREADS;       // [lo] (strips form)
+    const bool strips = S.ya != nullptr;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int64_t col = blockIdx.x; col < nrhs; col += gridDim.x) {
-        double* x = v + col * ldv;
+        double* x = strips ? nullptr : v + col * ldv;
+        double* ya = strips ? S.ya + col * S.ya_ld : nullptr;
+        double* full = strips ? S.full + col * S.full_ld : nullptr;
         for (int s = 0; s < num_panels; ++s) {
-            const BBPanel p = panels[transpose ? s : num_panels - 1 - s];
+            const int pidx = transpose ? s : num_panels - 1 - s;
+            const BBPanel p = panels[pidx];
             const int m = p.act_rows, n = p.ncols;
             const int seg2 = p.yrow + n + p.num_zeros;     // start of the second row segment
             const double* Y = y_vals + p.y_off;
             const double* T = t_vals + p.t_off;
-            for (int i = tid; i < m; i += BA_THREADS) seg[i] = x[i < n ? p.yrow + i : seg2 + (i - n)];
+            if (!strips) {
+                for (int i = tid; i < m; i += BA_THREADS) seg[i] = x[i < n ? p.yrow + i : seg2 + (i - n)];
+            } else if (transpose) {
+                // stack rows in: panel 0 = the strip's own vector; else even rows 2t = carry, odd rows 2t+1 and the tail = ya_i
+                const double* yi = ya + (int64_t)pidx * S.ms;
+                for (int i = tid; i < m; i += BA_THREADS) {
+                    double val;
+                    if (pidx == 0) val = yi[i];
+                    else if (i < 2 * S.lo) val = (i & 1) ? yi[i >> 1] : carry[i >> 1];
+                    else val = yi[i - S.lo];
+                    seg[i] = val;
+                }
+            } else {
+                // stack rows out (the input of Q): solved rows of the R part, the carry handed back by panel i+1, residuals
+                const int64_t ro = bbs_res_off(S, pidx);
+                for (int i = tid; i < m; i += BA_THREADS) {
+                    double val;
+                    if (i < p.solved) val = full[(int64_t)S.s * pidx + i];
+                    else if (i < n) val = carry[i - p.solved];
+                    else val = full[ro + (i - n)];
+                    seg[i] = val;
+                }
+            }
             __syncthreads();
             // ---- w1 = Y^T seg
             for (int j0 = 0; j0 < n; j0 += BA_THREADS) {
@@ -1069,7 +1129,26 @@ bb_apply_q_kernel(const BBPanel* __restrict__ panels, int num_panels, const doub
                 double d = 0.0;
                 for (int j = lane; j < je; j += 64) d = fma(Y[(int64_t)i * n + j], w2[j], d);
                 d = bb_wave_sum_dpp(d);
-                if (lane == 0) x[i < n ? p.yrow + i : seg2 + (i - n)] = seg[i] + d + (i < n ? w2[i] : 0.0);
+                if (lane == 0) {
+                    const double val = seg[i] + d + (i < n ? w2[i] : 0.0);
+                    if (!strips) x[i < n ? p.yrow + i : seg2 + (i - n)] = val;
+                    else if (transpose) {
+                        if (i < p.solved) full[(int64_t)S.s * pidx + i] = val;
+                        else if (i < n) carry[i - p.solved] = val;
+                        else full[bbs_res_off(S, pidx) + (i - n)] = val;
+                    } else {
+                        double* yi = ya + (int64_t)pidx * S.ms;
+                        if (pidx == 0) yi[i] = val;
+                        else if (i < 2 * S.lo) { if (i & 1) yi[i >> 1] = val; else carry[i >> 1] = val; }
+                        else yi[i - S.lo] = val;
+                    }
+                }
+            }
+            if (strips) {
+                // the components stage A left out of the chain (rows n.. of the strip's vector) pass through
+                const int64_t ro = bbs_res_off(S, pidx) + (pidx >= 1 ? S.lo : 0);
+                double* yi = ya + (int64_t)pidx * S.ms;
+                for (int q = tid; q < S.ms - S.n; q += BA_THREADS) { if (transpose) full[ro + q] = yi[S.n + q]; else yi[S.n + q] = full[ro + q]; }
             }
             __syncthreads();
         }
@@ -1077,7 +1156,7 @@ bb_apply_q_kernel(const BBPanel* __restrict__ panels, int num_panels, const doub
 }
 
 size_t bb_chain_smem(int max_act_rows, int max_ncols) { return (size_t)(max_act_rows + 2 * max_ncols + BB_WAVES) * sizeof(double); }
-size_t bb_apply_smem(int max_act_rows, int max_ncols) { return (size_t)(max_act_rows + 2 * max_ncols + BA_THREADS) * sizeof(double); }
+size_t bb_apply_smem(int max_act_rows, int max_ncols) { return (size_t)(max_act_rows + 2 * max_ncols + BA_THREADS + max_ncols) * sizeof(double); }
 
 hipError_t launch_bb_chain(const BBPanel* panels, int num_panels, const int32_t* prowptr, const int32_t* pcol,
                            const int64_t* pmap, const double* vals, double* W, double* lo, double* y_vals, double* t_vals,
@@ -1093,7 +1172,7 @@ hipError_t launch_bb_chain(const BBPanel* panels, int num_panels, const int32_t*
         hipLaunchKernelGGL(bb_scatter_kernel, dim3((unsigned)num_panels), dim3(BC_THREADS),
                            (size_t)(max_act_rows + 2) * sizeof(int), stream, panels, prowptr, pcol, pmap, vals, y_vals);
         hipLaunchKernelGGL(bb_chain2_kernel, dim3(1), dim3(BC_THREADS), smem2, stream, panels, num_panels, prowptr, pcol, pmap,
-                           vals, lo, y_vals, t_vals, r_stage, max_act_rows, max_ncols, uni_doubles);
+                           vals, lo, y_vals, t_vals, r_stage, max_act_rows, max_ncols, uni_doubles, (const int*)nullptr, (const int*)nullptr);
         const size_t smem_t = bb_t_smem(max_ncols, &t_in_lds);
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(bb_t_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)smem_t);
@@ -1125,7 +1204,68 @@ hipError_t launch_bb_apply_q(const BBPanel* panels, int num_panels, const double
     if (e != hipSuccess) return e;
     const unsigned grid = (unsigned)(nrhs < 1024 ? nrhs : 1024);
     hipLaunchKernelGGL(bb_apply_q_kernel, dim3(grid), dim3(BA_THREADS), smem, stream, panels, num_panels, y_vals, t_vals,
-                       transpose, v, ldv, nrhs, max_act_rows, max_ncols);
+                       transpose, v, ldv, nrhs, max_act_rows, max_ncols, BBStrips{});
+    return hipGetLastError();
+}
+
+// ---- the strips form: stage B of the two-stage banded factorisation ---------------------------------------------------------
+// Stage A (the caller: the block-diagonal solver on the strips, HouseholderQR) left R_i (n x n upper triangle, packed by columns)
+// of every strip.  bbs_scatter_kernel writes the stack of panel i into the panel's own storage (row-major act x n): panel 0 is
+// R_0 itself; panel i >= 1 holds R_i's first lo rows on the ODD rows 1, 3, .. 2 lo - 1 (the even rows receive the carry inside
+// the chain) and its other rows from row 2 lo on.  Interleaved like this, row r of the stack has its first nonzero in column
+// r / 2 (r < 2 lo) or r - lo: a staircase, so that a plain Householder QR in the natural row order only ever touches the rows
+// [j, 2 j + 2) (j < lo) or [j, lo + j + 1) of column j -- the two triangles are merged without ever visiting their zeros
+// (4.5 instead of 18.9 Mflop for lo = 128, n = 192).
+__global__ void __launch_bounds__(256)
+bbs_scatter_kernel(const BBPanel* __restrict__ panels, const double* __restrict__ r_packed, int64_t r_stride, int n, int lo,
+                   double* __restrict__ y_vals)
+{
+    const int pi = blockIdx.x;
+    const BBPanel p = panels[pi];
+    const double* R = r_packed + (int64_t)pi * r_stride;      // R(r, c) = R[c (c + 1) / 2 + r], r <= c
+    double* W = y_vals + p.y_off;
+    for (int e = threadIdx.x; e < p.act_rows * n; e += 256) {
+        const int i = e / n, c = e - i * n;
+        int r;                                                // row of R_i that lives on stack row i (-1: a carry row)
+        if (pi == 0) r = i;
+        else if (i < 2 * lo) r = (i & 1) ? (i >> 1) : -1;
+        else r = i - lo;
+        W[e] = (r >= 0 && r <= c) ? R[(int64_t)c * (c + 1) / 2 + r] : 0.0;
+    }
+}
+
+hipError_t launch_bbs_chain(const BBPanel* panels, int num_panels, const double* r_packed, int64_t r_stride, int n, int lo,
+                            int max_act_rows, double* lo_buf, double* y_vals, double* t_vals, double* r_stage,
+                            const int* rlim_first, const int* rlim_rest, hipStream_t stream)
+{
+    int t_in_lds = 0, uni_doubles = 0;
+    const size_t smem2 = bb_chain2_smem(max_act_rows, &uni_doubles);
+    if (n > BC_CW || smem2 == 0) return hipErrorInvalidValue;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(bb_chain2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem2);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(bbs_scatter_kernel, dim3((unsigned)num_panels), dim3(256), 0, stream, panels, r_packed, r_stride, n, lo, y_vals);
+    hipLaunchKernelGGL(bb_chain2_kernel, dim3(1), dim3(BC_THREADS), smem2, stream, panels, num_panels, (const int32_t*)nullptr,
+                       (const int32_t*)nullptr, (const int64_t*)nullptr, (const double*)nullptr, lo_buf, y_vals, t_vals, r_stage,
+                       max_act_rows, n, uni_doubles, rlim_first, rlim_rest);
+    const size_t smem_t = bb_t_smem(n, &t_in_lds);
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(bb_t_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_t);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(bb_t_kernel, dim3((unsigned)num_panels), dim3(BC_THREADS), smem_t, stream, panels, num_panels, y_vals, t_vals, t_in_lds);
+    return hipGetLastError();
+}
+
+hipError_t launch_bbs_apply(const BBPanel* panels, int num_panels, const double* y_vals, const double* t_vals, int transpose,
+                            double* ya, int64_t ya_ld, double* full, int64_t full_ld, int64_t nrhs, int ms, int n, int s, int lo,
+                            int cols, int max_act_rows, hipStream_t stream)
+{
+    if (nrhs <= 0) return hipSuccess;
+    const size_t smem = bb_apply_smem(max_act_rows, n);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(bb_apply_q_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return e;
+    BBStrips S{ya, full, ya_ld, full_ld, ms, n, s, lo, cols};
+    const unsigned grid = (unsigned)(nrhs < 1024 ? nrhs : 1024);
+    hipLaunchKernelGGL(bb_apply_q_kernel, dim3(grid), dim3(BA_THREADS), smem, stream, panels, num_panels, y_vals, t_vals, transpose,
+                       (double*)nullptr, (int64_t)0, nrhs, max_act_rows, n, S);
     return hipGetLastError();
 }
 

@@ -28,6 +28,7 @@ struct BBPanel {
     int32_t lo_rows;    // leftover block taken from the previous panel: rows ...
     int32_t lo_cols;    // ... and columns (0 for the first panel)
     int32_t lo_from;    // V.block(lo_from, lo_from, lo_rows, lo_cols) of the previous panel
+    int32_t lo_stride = 1;   // leftover row i goes to panel row lo_stride * i (2: interleaved with the new rows, the strips form)
     int32_t yrow;       // BlockYTY row index (= idxCol)
     int32_t num_zeros;  // BlockYTY zero gap between its two row segments
     int64_t y_off;      // offset of the panel (act_rows x ncols, row-major; Y = its unit-lower view) in y_vals

@@ -94,6 +94,24 @@ struct qrk_bb_plan_s {
     bool factorized = false;       // d_stage holds the rows of R of the last factorize
 };
 
+// Banded matrix given as dense strips (include/qrkit_amd.h, qrk_bbs_*): two-stage factorisation, see banded.hip (strips form).
+struct qrk_bbs_plan_s {
+    qrk_handle h = nullptr;
+    int64_t N = 0;                      // strips
+    int32_t ms = 0, n = 0, s = 0, lo = 0;   // strip rows / columns, column step, carry size n - s
+    int64_t rows = 0, cols = 0;
+    qrk_bd_plan bd = nullptr;           // stage A: the strips as a block-diagonal matrix (HouseholderQR, BlockDiagonalQ)
+    std::vector<qrk::BBPanel> panels;
+    qrk::BBPanel* d_panels = nullptr;
+    int32_t* d_rlim = nullptr;          // [2][n / 16]: staircase row limits of panel 0 / of the other panels
+    double *d_q = nullptr, *d_ra = nullptr;     // stage A: explicit Q_i (ms x ms each), packed R_i
+    int32_t* d_perm = nullptr;
+    double *d_y = nullptr, *d_t = nullptr, *d_stage = nullptr, *d_lo = nullptr;   // stage B: panels (Y below the diagonal), T, rows of R, carry
+    int64_t y_len = 0, t_len = 0, stage_len = 0;
+    int32_t max_act = 0;
+    bool factorized = false;
+};
+
 struct qrk_dense_plan_s {
     qrk_handle h = nullptr;
     int32_t rows = 0, cols = 0;
@@ -1319,6 +1337,164 @@ qrk_status qrk_bb_plan_destroy(qrk_bb_plan p)
     (void)hipFree(p->d_rsrc); (void)hipFree(p->d_rcolptr); (void)hipFree(p->d_rrowidx);
     (void)hipFree(p->d_W); (void)hipFree(p->d_lo); (void)hipFree(p->d_stage);
     delete p;
+    return QRK_STATUS_OK;
+}
+
+/* ---- banded matrix as dense strips: two-stage factorisation (strips form, banded.hip) ------------------------------------ */
+
+qrk_status qrk_bbs_plan_create(qrk_handle h, int64_t num_strips, int32_t strip_rows, int32_t strip_cols, int32_t col_step,
+                               qrk_bbs_plan* out)
+{
+    if (!h || !out) return QRK_STATUS_INVALID_ARGUMENT;
+    *out = nullptr;
+    const int lo = strip_cols - col_step;
+    if (num_strips < 1 || strip_cols < 16 || strip_cols > 256 || strip_cols % 16 || col_step < 16 || col_step % 16 || lo < 0 ||
+        strip_rows < strip_cols || strip_rows > 256 || num_strips * (int64_t)strip_rows > INT32_MAX)
+        return fail(h, QRK_STATUS_INVALID_ARGUMENT,
+                    "qrk_bbs_plan_create: strips of rows >= cols, cols and col_step multiples of 16, cols <= 256, rows <= 256, "
+                    "col_step <= cols");
+    QRK_HIP(h, hipSetDevice(h->device));
+    qrk_bbs_plan_s* p = new (std::nothrow) qrk_bbs_plan_s();
+    if (!p) return fail(h, QRK_STATUS_ALLOC_FAILED, "qrk_bbs_plan_create: out of host memory");
+    p->h = h; p->N = num_strips; p->ms = strip_rows; p->n = strip_cols; p->s = col_step; p->lo = lo;
+    p->rows = num_strips * (int64_t)strip_rows;
+    p->cols = (num_strips - 1) * (int64_t)col_step + strip_cols;
+    const int n = p->n, s = p->s;
+    // stage A: N tiles of ms x n, un-pivoted Householder QR, Q_i explicit and block diagonal (Q^T b of strip i = rows i ms .. of the product)
+    qrk_bd_layout lay{};
+    lay.num_blocks = num_strips; lay.block_rows = strip_rows; lay.block_cols = strip_cols;
+    lay.mat_rows = (int32_t)p->rows; lay.mat_cols = (int32_t)(num_strips * (int64_t)strip_cols);
+    if (num_strips * (int64_t)strip_cols > INT32_MAX) { delete p; return fail(h, QRK_STATUS_INVALID_ARGUMENT, "qrk_bbs_plan_create: too many columns"); }
+    qrk_status st = qrk_bd_plan_create(h, &lay, QRK_BLOCK_DIAGONAL_Q, QRK_HOUSEHOLDER, &p->bd);
+    if (st != QRK_STATUS_OK) { delete p; return st; }
+    // stage B: one panel per strip.  Panel 0 is R_0 itself (n rows); panel i >= 1 stacks the carry (lo rows, interleaved) and R_i
+    p->panels.resize((size_t)num_strips);
+    for (int64_t i = 0; i < num_strips; ++i) {
+        qrk::BBPanel& q = p->panels[(size_t)i];
+        q = qrk::BBPanel{};
+        q.row0 = 0; q.col0 = (int32_t)(i * s);
+        q.act_rows = i == 0 ? n : lo + n;
+        q.ncols = n;
+        q.solved = i + 1 < num_strips ? s : n;
+        q.lo_rows = i == 0 ? 0 : lo; q.lo_cols = q.lo_rows; q.lo_from = s; q.lo_stride = 2;
+        q.yrow = q.col0; q.num_zeros = 0;
+        q.y_off = p->y_len; q.t_off = p->t_len; q.r_off = p->stage_len;
+        p->y_len += (int64_t)q.act_rows * n; p->t_len += (int64_t)n * n; p->stage_len += (int64_t)q.solved * n;
+        if (q.act_rows > p->max_act) p->max_act = q.act_rows;
+    }
+    // staircase limits at 16-column granularity: panel 0 is upper triangular; in the interleaved stack row r starts in column r / 2
+    // (r < 2 lo) or r - lo
+    std::vector<int32_t> rlim((size_t)2 * (n / 16));
+    for (int g = 0; g < n / 16; ++g) {
+        const int last = 16 * g + 15;
+        rlim[(size_t)g] = last + 1;
+        rlim[(size_t)(n / 16 + g)] = last < lo ? 2 * last + 2 : lo + last + 1;
+    }
+    const int64_t ntri = (int64_t)n * (n + 1) / 2;
+    if ((st = upload(h, p->panels, &p->d_panels)) || (st = upload(h, rlim, &p->d_rlim))) { qrk_bbs_plan_destroy(p); return st; }
+    if (hipMalloc((void**)&p->d_q, (size_t)num_strips * strip_rows * strip_rows * sizeof(double)) != hipSuccess ||
+        hipMalloc((void**)&p->d_ra, (size_t)num_strips * ntri * sizeof(double)) != hipSuccess ||
+        hipMalloc((void**)&p->d_perm, (size_t)num_strips * n * sizeof(int32_t)) != hipSuccess ||
+        hipMalloc((void**)&p->d_y, (size_t)p->y_len * sizeof(double)) != hipSuccess ||
+        hipMalloc((void**)&p->d_t, (size_t)p->t_len * sizeof(double)) != hipSuccess ||
+        hipMalloc((void**)&p->d_stage, (size_t)p->stage_len * sizeof(double)) != hipSuccess ||
+        hipMalloc((void**)&p->d_lo, (size_t)(lo > 0 ? lo * lo : 1) * sizeof(double)) != hipSuccess) {
+        qrk_bbs_plan_destroy(p);
+        return fail(h, QRK_STATUS_ALLOC_FAILED, "qrk_bbs_plan_create: cannot allocate the factors (Q of stage A, panels and T of stage B)");
+    }
+    *out = p;
+    return QRK_STATUS_OK;
+}
+
+qrk_status qrk_bbs_plan_destroy(qrk_bbs_plan p)
+{
+    if (!p) return QRK_STATUS_OK;
+    if (p->bd) (void)qrk_bd_plan_destroy(p->bd);
+    (void)hipFree(p->d_panels); (void)hipFree(p->d_rlim); (void)hipFree(p->d_q); (void)hipFree(p->d_ra); (void)hipFree(p->d_perm);
+    (void)hipFree(p->d_y); (void)hipFree(p->d_t); (void)hipFree(p->d_stage); (void)hipFree(p->d_lo);
+    delete p;
+    return QRK_STATUS_OK;
+}
+
+qrk_status qrk_bbs_plan_sizes(qrk_bbs_plan p, int64_t* rows, int64_t* cols, int64_t* r_len)
+{
+    if (!p) return QRK_STATUS_INVALID_ARGUMENT;
+    if (rows) *rows = p->rows;
+    if (cols) *cols = p->cols;
+    if (r_len) *r_len = p->stage_len;
+    return QRK_STATUS_OK;
+}
+
+qrk_status qrk_bbs_factorize(qrk_bbs_plan p, const double* strips)
+{
+    if (!p || !strips) return fail(p ? p->h : nullptr, QRK_STATUS_INVALID_ARGUMENT, "qrk_bbs_factorize: bad argument");
+    qrk_handle h = p->h;
+    QRK_HIP(h, hipSetDevice(h->device));
+    p->factorized = false;
+    // stage A on all CUs: every strip triangularised on its own
+    qrk_status st = qrk_bd_factorize(p->bd, strips, p->d_q, p->d_ra, p->d_perm, nullptr, QRK_MEM_DEVICE);
+    if (st != QRK_STATUS_OK) return st;
+    // stage B: the chain merges the carried triangle with the strip's
+    const int ng = p->n / 16;
+    QRK_HIP(h, qrk::launch_bbs_chain(p->d_panels, (int)p->N, p->d_ra, (int64_t)p->n * (p->n + 1) / 2, p->n, p->lo, p->max_act, p->d_lo,
+                                     p->d_y, p->d_t, p->d_stage, p->d_rlim, p->d_rlim + ng, h->stream));
+    p->factorized = true;
+    if (std::getenv("QRK_BBS_PROF_DUMP")) {
+        // diagnostic builds of banded.hip (-DQRK_BB_PROF) leave the chain's tick counts in the T of the last panel
+        double t[14];
+        QRK_HIP(h, hipStreamSynchronize(h->stream));
+        QRK_HIP(h, hipMemcpy(t, p->d_t + p->panels.back().t_off, sizeof(t), hipMemcpyDeviceToHost));
+        std::fprintf(stderr, "bb_chain2 ticks: carry-in %.0f  panel QR %.0f  R rows + carry out %.0f  hc %.0f | block->regs %.0f  reflectors %.0f  pack+G+T %.0f  "
+                             "update %.0f (V^T W %.0f  partial sums %.0f  T^T w %.0f  W -= V u %.0f)\n",
+                     t[0], t[1], t[2], t[3], t[6], t[7], t[8], t[9], t[10], t[11], t[12], t[13]);
+    }
+    return QRK_STATUS_OK;
+}
+
+qrk_status qrk_bbs_r_rows(qrk_bbs_plan p, int64_t strip, double* r_rows)
+{
+    if (!p || !r_rows || strip < 0 || strip >= p->N) return fail(p ? p->h : nullptr, QRK_STATUS_INVALID_ARGUMENT, "qrk_bbs_r_rows: bad argument");
+    if (!p->factorized) return fail(p->h, QRK_STATUS_NOT_FACTORIZED, "qrk_bbs_r_rows: qrk_bbs_factorize has not run on this plan");
+    qrk_handle h = p->h;
+    const qrk::BBPanel& q = p->panels[(size_t)strip];
+    QRK_HIP(h, hipMemcpyAsync(r_rows, p->d_stage + q.r_off, (size_t)q.solved * q.ncols * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    return QRK_STATUS_OK;
+}
+
+qrk_status qrk_bbs_apply_q(qrk_bbs_plan p, int transpose, const double* v, double* out, int64_t nrhs, double* work)
+{
+    if (!p || !v || !out || !work || nrhs < 0 || v == out)
+        return fail(p ? p->h : nullptr, QRK_STATUS_INVALID_ARGUMENT, "qrk_bbs_apply_q: bad argument");
+    if (!p->factorized) return fail(p->h, QRK_STATUS_NOT_FACTORIZED, "qrk_bbs_apply_q: qrk_bbs_factorize has not run on this plan");
+    qrk_handle h = p->h;
+    QRK_HIP(h, hipSetDevice(h->device));
+    qrk_status st;
+    if (transpose) {
+        // work = per strip Q_i^T v_i, then the chain: out = Q^T v in the layout of the header
+        if ((st = qrk_bd_apply_qt(p->bd, p->d_q, v, nrhs, work, QRK_MEM_DEVICE)) != QRK_STATUS_OK) return st;
+        QRK_HIP(h, qrk::launch_bbs_apply(p->d_panels, (int)p->N, p->d_y, p->d_t, 1, work, p->rows, out, p->rows, nrhs, p->ms, p->n, p->s,
+                                         p->lo, (int)p->cols, p->max_act, h->stream));
+    } else {
+        QRK_HIP(h, qrk::launch_bbs_apply(p->d_panels, (int)p->N, p->d_y, p->d_t, 0, work, p->rows, const_cast<double*>(v), p->rows, nrhs,
+                                         p->ms, p->n, p->s, p->lo, (int)p->cols, p->max_act, h->stream));
+        if ((st = qrk_bd_apply_q(p->bd, p->d_q, work, nrhs, out, QRK_MEM_DEVICE)) != QRK_STATUS_OK) return st;
+    }
+    return QRK_STATUS_OK;
+}
+
+qrk_status qrk_bbs_solve(qrk_bbs_plan p, const double* b, double* x, int64_t nrhs, double* work)
+{
+    if (!p || !b || !x || !work || nrhs < 0)
+        return fail(p ? p->h : nullptr, QRK_STATUS_INVALID_ARGUMENT, "qrk_bbs_solve: bad argument");
+    if (!p->factorized) return fail(p->h, QRK_STATUS_NOT_FACTORIZED, "qrk_bbs_solve: qrk_bbs_factorize has not run on this plan");
+    qrk_handle h = p->h;
+    // work: 2 * rows * nrhs doubles: [Q_i^T b_i of stage A | Q^T b]; x(0:cols) = R^-1 (Q^T b)(0:cols)
+    double* qtb = work + p->rows * nrhs;
+    qrk_status st = qrk_bbs_apply_q(p, 1, b, qtb, nrhs, work);
+    if (st != QRK_STATUS_OK) return st;
+    QRK_HIP(h, qrk::launch_bb_solve_r(p->d_panels, (int)p->N, p->d_stage, (int)p->cols, qtb, p->rows, nrhs, h->stream));
+    QRK_HIP(h, hipMemcpy2DAsync(x, (size_t)p->cols * sizeof(double), qtb, (size_t)p->rows * sizeof(double), (size_t)p->cols * sizeof(double),
+                                (size_t)nrhs, hipMemcpyDeviceToDevice, h->stream));
     return QRK_STATUS_OK;
 }
 

@@ -132,6 +132,14 @@ hipError_t launch_dense_solve_r(const double* qr, int64_t lda, int n, double* b,
 hipError_t launch_bb_solve_r(const BBPanel* panels, int num_panels, const double* r_stage, int cols, double* v, int64_t ldv,
                              int64_t nrhs, hipStream_t stream);
 size_t bb_chain_smem(int max_act_rows, int max_ncols);
+size_t bb_apply_smem(int max_act_rows, int max_ncols);
+// strips form of the banded factorisation (banded.hip): stage B on the triangles stage A left
+hipError_t launch_bbs_chain(const BBPanel* panels, int num_panels, const double* r_packed, int64_t r_stride, int n, int lo,
+                            int max_act_rows, double* lo_buf, double* y_vals, double* t_vals, double* r_stage,
+                            const int* rlim_first, const int* rlim_rest, hipStream_t stream);
+hipError_t launch_bbs_apply(const BBPanel* panels, int num_panels, const double* y_vals, const double* t_vals, int transpose,
+                            double* ya, int64_t ya_ld, double* full, int64_t full_ld, int64_t nrhs, int ms, int n, int s, int lo,
+                            int cols, int max_act_rows, hipStream_t stream);
 void launch_bd_pattern(const TileGeom& g, int64_t nnz_r, int32_t* q_rowptr, int32_t* q_colidx,
                        int32_t* r_colptr, int32_t* r_rowidx, hipStream_t stream);
 void launch_bd_cut_tiles(const TileGeom& g, const int64_t* t_off, int row_major, const int32_t* outer_ptr,

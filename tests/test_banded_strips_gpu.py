@@ -1,0 +1,143 @@
+"""GPU: the strips form of the banded factorisation (qrk_bbs_*: BandedBlockedSparseQR::factorize, src/QRKit/BandedBlockedSparseQR.h:
+463-508, on a block-banded matrix handed over as dense strips; stage A = every strip triangularised on all CUs, stage B = a chain
+that merges two triangles per step).  R is unique up to the signs of its rows for a fixed column order, so the
+checks are: R against LAPACK's QR of the assembled matrix after aligning row signs, against the oracle's restatement of the reference's
+chain the same way, Q^T J = R, Q Q^T b = b, and the least-squares solution."""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import rel_fro
+
+
+def assemble(strips, N, ms, n, s):
+    J = np.zeros((N * ms, (N - 1) * s + n))
+    for i in range(N):
+        J[i * ms:(i + 1) * ms, i * s:i * s + n] = strips[i]
+    return J
+
+
+def make(N, ms, n, s, seed):
+    rng = np.random.default_rng(seed)
+    return rng.uniform(-1.0, 1.0, (N, ms, n)) + 0.25 * np.sign(rng.uniform(-1, 1, (N, ms, n)))
+
+
+def to_device(strips):
+    import torch
+    # strip i column-major
+    return torch.from_numpy(np.ascontiguousarray(strips.transpose(0, 2, 1)).reshape(-1)).cuda()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,ms,n,s", [(1, 64, 48, 16), (2, 64, 48, 16), (5, 96, 64, 32), (6, 256, 192, 64), (9, 40, 32, 16),
+                                      (4, 128, 96, 96), (3, 256, 256, 64)])
+def test_strips_r_matches_lapack_and_products(N, ms, n, s):
+    import torch
+    import qrkit_amd
+    from qrkit_amd.banded import BandedStripsQR
+    strips = make(N, ms, n, s, seed=N * 7 + n)
+    J = assemble(strips, N, ms, n, s)
+    rows, cols = J.shape
+    qr = BandedStripsQR(N, ms, n, s, context=qrkit_amd.Context(0))
+    qr.factorize(to_device(strips))
+    R = qr.matrixR_dense()
+    assert np.abs(np.tril(R, -1)).max() == 0.0
+    # band structure: row r of R has nothing right of its window
+    for i in range(N - 1):
+        assert np.abs(R[i * s:(i + 1) * s, i * s + n:]).max(initial=0.0) == 0.0
+    Rl = np.linalg.qr(J, mode="r")
+    sg = np.sign(np.diag(R)) * np.sign(np.diag(Rl))
+    assert np.all(sg != 0)
+    row_err = np.linalg.norm(R * sg[:, None] - Rl, axis=1) / np.linalg.norm(Rl, axis=1)
+    assert row_err.max() <= 1e-11, row_err.max()
+    # Q^T J = [R; 0] in the documented layout (the rows of R first)
+    Jd = torch.from_numpy(np.asfortranarray(J).T.copy()).cuda().t()
+    QtJ = qr.applyQ(Jd, transpose=True).cpu().numpy()
+    assert np.linalg.norm(QtJ[:cols] - R) <= 1e-12 * np.linalg.norm(J) * np.sqrt(cols)
+    assert np.linalg.norm(QtJ[cols:]) <= 1e-12 * np.linalg.norm(J) * np.sqrt(cols)
+    # Q Q^T b = b, |Q^T b| = |b|
+    b = torch.from_numpy(np.random.default_rng(1).uniform(-1, 1, rows)).cuda()
+    qtb = qr.applyQ(b, transpose=True)
+    assert abs(float(qtb.norm()) - float(b.norm())) <= 1e-12 * float(b.norm())
+    assert rel_fro(qr.applyQ(qtb, transpose=False).cpu().numpy(), b.cpu().numpy()) <= 1e-12
+    # least squares through the implicit Q
+    x = np.random.default_rng(2).uniform(-1, 1, cols)
+    xs = qr.solve(torch.from_numpy(J @ x).cuda()).cpu().numpy()
+    assert rel_fro(xs, x) <= 1e-9
+    bb = np.random.default_rng(3).uniform(-1, 1, (rows, 3))
+    xls = qr.solve(torch.from_numpy(np.asfortranarray(bb).T.copy()).cuda().t()).cpu().numpy()
+    ref = np.linalg.lstsq(J, bb, rcond=None)[0]
+    assert rel_fro(xls, ref) <= 1e-9
+
+
+@pytest.mark.gpu
+def test_strips_r_matches_the_reference_chain_up_to_row_signs():
+    """The same matrix through the reference's own elimination order (the oracle's restatement of BandedBlockedSparseQR, and the CSR
+    entry qrk_bb_* that follows it): R agrees after aligning the sign of each row."""
+    import scipy.sparse as sp
+    import torch
+    import qrkit_amd
+    from qrkit_amd.banded import BandedStripsQR
+    from oracle import oracle as orc
+    N, ms, n, s = 6, 64, 48, 16
+    strips = make(N, ms, n, s, seed=3)
+    J = assemble(strips, N, ms, n, s)
+    qr = BandedStripsQR(N, ms, n, s, context=qrkit_amd.Context(0))
+    qr.factorize(to_device(strips))
+    R = qr.matrixR_dense()
+    res = orc.bb_factorize(sp.csr_matrix(J), suggested=s)
+    assert not np.any(res.row_perm != np.arange(J.shape[0]))
+    Ro = res.R.toarray()[:J.shape[1]]
+    sg = np.sign(np.diag(R)) * np.sign(np.diag(Ro))
+    row_err = np.linalg.norm(R * sg[:, None] - Ro, axis=1) / np.linalg.norm(Ro, axis=1)
+    assert row_err.max() <= 1e-11, row_err.max()
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.environ.get("QRK_BIG"), reason="BASELINE configs[2] at full size: 50 000 strips of 256 x 192 (set QRK_BIG=1)")
+def test_strips_configs2_full_size():
+    """BASELINE configs[2]: 50 000 strips of 256 x 192, column step 64 (12.8 M x 3.2 M, 2.46e9 stored entries).  Properties at full
+    size: Q^T J = R on sampled strips (columns of J are sparse: one strip wide), |Q^T b| = |b|, LS recovery."""
+    import time
+    import torch
+    import qrkit_amd
+    from qrkit_amd.banded import BandedStripsQR
+    N, ms, n, s = int(os.environ.get("QRK_BIG_STRIPS", "50000")), 256, 192, 64
+    g = torch.Generator(device="cuda").manual_seed(5)
+    strips = torch.rand(N * ms * n, device="cuda", dtype=torch.float64, generator=g) * 2 - 1
+    qr = BandedStripsQR(N, ms, n, s, context=qrkit_amd.Context(0))
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    qr.factorize(strips)
+    torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    print(f"configs[2] strips form: {N} strips in {dt:.3f} s = {dt / N * 1e3:.4f} ms per strip")
+    rows, cols = qr.rows(), qr.cols()
+    x = torch.rand(cols, device="cuda", dtype=torch.float64, generator=g) * 2 - 1
+    # b = J x, strip by strip
+    S3 = strips.view(N, n, ms)
+    b = torch.empty(rows, device="cuda", dtype=torch.float64)
+    for i0 in range(0, N, 2000):
+        i1 = min(N, i0 + 2000)
+        idx = (torch.arange(i0, i1, device="cuda") * s)[:, None] + torch.arange(n, device="cuda")[None, :]
+        b.view(N, ms)[i0:i1] = torch.einsum("inm,in->im", S3[i0:i1], x[idx])
+    xs = qr.solve(b)
+    err = float((xs - x).norm() / x.norm())
+    print(f"configs[2] LS recovery: {err:.2e}")
+    assert err <= 1e-8
+    qtb = qr.applyQ(b, transpose=True)
+    assert abs(float(qtb.norm()) - float(b.norm())) <= 1e-11 * float(b.norm())
+    assert float(qtb[cols:].norm()) <= 1e-9 * float(b.norm())       # b is in the range of J
+    # Q^T (column c of J) = column c of R, on sampled columns
+    for c in (0, 63, 64, 1000, cols // 2, cols - 193, cols - 1):
+        e = torch.zeros(rows, device="cuda", dtype=torch.float64)
+        for i in range(max(0, (c - n) // s), min(N, c // s + 1)):
+            if i * s <= c < i * s + n:
+                e[i * ms:(i + 1) * ms] = S3[i, c - i * s]
+        q = qr.applyQ(e, transpose=True)
+        col = torch.zeros(cols, device="cuda", dtype=torch.float64)
+        for i in range(max(0, (c - n) // s), min(N, c // s + 1)):
+            blk = qr.rRows(i)
+            if i * s <= c < i * s + n:
+                col[i * s:i * s + blk.shape[0]] = blk[:, c - i * s]
+        assert float((q[:cols] - col).norm()) <= 1e-11 * float(e.norm()), c
+        assert float(q[cols:].norm()) <= 1e-11 * float(e.norm()), c
