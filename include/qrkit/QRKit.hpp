@@ -871,11 +871,130 @@ class BlockedThinDenseQR {
     std::vector<double> m_hc;
     PermutationType m_outputPerm_c, m_rowPerm;
 };
+// ---------------------------------------------------------------------------------------------
+// QRKit::BlockedThinSparseQR<MatrixType, SuggestedBlockCols> (BlockedThinSparseQR.h:105-283): column-pivoted QR of a thin SPARSE
+// matrix, panel by panel, with the ColumnDensity column ordering and the as-banded-as-possible row ordering (analyzePattern,
+// :168-201), per-panel ColPivHouseholderQR and the nonzero / zero pivot column bookkeeping (:250-256).  compute() hands the CSC
+// arrays to qrk_thin_sparse_factorize (include/qrkit_amd.h), which runs that chain on the device; Q stays implicit.
+// As the RightSolver tag of BlockAngularSparseQR (test/test-qrkit.cpp:335-362) it selects the un-pivoted dense solver for the
+// bottom block, whose input there is the dense product Q1^T J2 (kSolver).
 template <int SuggestedBlockCols = 2>
-class BlockedThinSparseQR : public BlockedThinDenseQR<SuggestedBlockCols> {
+class BlockedThinSparseQR {
   public:
+    static const int kSolver = QRK_HOUSEHOLDER;
     typedef SparseMatrixColMajor MatrixType;
-    explicit BlockedThinSparseQR(int device = 0) : BlockedThinDenseQR<SuggestedBlockCols>(device) {}
+    typedef Matrix MatrixRType;
+    typedef PermutationMatrix PermutationType;
+    typedef QProduct<BlockedThinSparseQR> MatrixQType;
+
+    explicit BlockedThinSparseQR(int device = 0)
+        : m_info(Success), m_nonzeroPivots(0), m_isInitialized(false), m_handle(0), m_plan(0), m_rows(0), m_cols(0), m_Rbuilt(false) {
+        if (qrk_create(&m_handle, device, 0) != QRK_STATUS_OK)
+            throw std::runtime_error(std::string("qrkit: ") + qrk_last_error(0));
+    }
+    template <bool RM>
+    explicit BlockedThinSparseQR(const SparseMatrix<RM>& mat, int device = 0) : BlockedThinSparseQR(device) { compute(mat); }
+    ~BlockedThinSparseQR() { if (m_plan) qrk_thin_destroy(m_plan); if (m_handle) qrk_destroy(m_handle); }
+    BlockedThinSparseQR(const BlockedThinSparseQR&) = delete;
+    BlockedThinSparseQR& operator=(const BlockedThinSparseQR&) = delete;
+
+    // :105-165 (analyzePattern + factorize)
+    void compute(const SparseMatrixColMajor& mat) {
+        m_isInitialized = false; m_Rbuilt = false;
+        if (m_plan) { qrk_thin_destroy(m_plan); m_plan = 0; }
+        m_rows = mat.rows(); m_cols = mat.cols();
+        check(qrk_thin_sparse_factorize(m_handle, (int32_t)m_rows, (int32_t)m_cols, SuggestedBlockCols, mat.outerIndex().data(),
+                                        mat.innerIndex().data(), mat.values().data(), &m_plan));
+        int32_t rk = 0;
+        std::vector<int32_t> cp((size_t)m_cols), rp((size_t)m_rows);
+        check(qrk_thin_info(m_plan, &rk, cp.data(), rp.data()));
+        m_outputPerm_c.setIdentity(m_cols); m_rowPerm.setIdentity(m_rows);
+        for (Index j = 0; j < m_cols; ++j) m_outputPerm_c.indices()[(size_t)j] = cp[(size_t)j];
+        for (Index i = 0; i < m_rows; ++i) m_rowPerm.indices()[(size_t)i] = rp[(size_t)i];
+        m_nonzeroPivots = rk;
+        m_info = Success;
+        m_isInitialized = true;
+    }
+    void compute(const SparseMatrixRowMajor& mat) {
+        // (the reference's MatrixType is column-major; a row-major input is converted, as Eigen's assignment would)
+        std::vector<Triplet> t;
+        for (Index r = 0; r < mat.rows(); ++r)
+            for (int e = mat.outerIndex()[(size_t)r]; e < mat.outerIndex()[(size_t)r + 1]; ++e) t.push_back(Triplet((int)r, mat.innerIndex()[(size_t)e], mat.values()[(size_t)e]));
+        SparseMatrixColMajor cm(mat.rows(), mat.cols());
+        cm.setFromTriplets(t);
+        compute(cm);
+    }
+
+    Index rows() const { return m_rows; }
+    Index cols() const { return m_cols; }
+    Index rank() const { assert(m_isInitialized && "The factorization should be called first, use compute()"); return m_nonzeroPivots; }
+    ComputationInfo info() const { return m_info; }
+    // rows x cols with the upper triangle in its first cols rows (the reference keeps it sparse, column by column)
+    const MatrixRType& matrixR() const {
+        if (!m_Rbuilt) {
+            std::vector<double> top((size_t)(m_cols * m_cols));
+            check(qrk_thin_matrix_r(m_plan, top.data(), m_cols, QRK_MEM_HOST));
+            m_R = Matrix(m_rows, m_cols);
+            for (Index c = 0; c < m_cols; ++c) for (Index r = 0; r < m_cols && r < m_rows; ++r) m_R(r, c) = top[(size_t)(c * m_cols + r)];
+            m_Rbuilt = true;
+        }
+        return m_R;
+    }
+    MatrixQType matrixQ() const { return MatrixQType(*this, false); }
+    const PermutationType& colsPermutation() const { return m_outputPerm_c; }
+    const PermutationType& rowsPermutation() const { return m_rowPerm; }
+
+    Vector applyQt(const Vector& v) const { return applyAny(v, true); }
+    Vector applyQ(const Vector& v) const { return applyAny(v, false); }
+    // BlockedThinQRBase::_solve_impl (BlockedThinQRBase.h:223-247): x(0:rank) = R(0:rank,0:rank)^-1 (Q^T b)(0:rank), the rest zero
+    Vector solve(const Vector& b) const {
+        assert(m_isInitialized && "The factorization should be called first, use compute()");
+        Padded d(*this, b, 1);
+        check(qrk_thin_solve(m_plan, d.ptr(), 2 * m_rows, 1));
+        Vector x((size_t)m_cols);
+        check(qrk_memcpy(m_handle, x.data(), d.p, (int64_t)(m_cols * (Index)sizeof(double)), 1));
+        return x;
+    }
+
+  protected:
+    // device copy of nrhs columns with the zero rows the panels are applied with (leading dimension 2 rows)
+    struct Padded {
+        const BlockedThinSparseQR& s; void* p; Index nrhs;
+        Padded(const BlockedThinSparseQR& ss, const Vector& host, Index n) : s(ss), p(0), nrhs(n) {
+            const int64_t D = (int64_t)sizeof(double);
+            Vector pad((size_t)(2 * s.m_rows * nrhs), 0.0);
+            for (Index c = 0; c < nrhs; ++c) std::copy(host.begin() + c * s.m_rows, host.begin() + (c + 1) * s.m_rows, pad.begin() + c * 2 * s.m_rows);
+            s.check(qrk_device_alloc(s.m_handle, 2 * s.m_rows * nrhs * D, &p));
+            s.check(qrk_memcpy(s.m_handle, p, pad.data(), 2 * s.m_rows * nrhs * D, 0));
+        }
+        ~Padded() { if (p) qrk_device_free(s.m_handle, p); }
+        double* ptr() const { return (double*)p; }
+        Padded(const Padded&) = delete;
+        Padded& operator=(const Padded&) = delete;
+    };
+    Vector applyAny(const Vector& v, bool transpose) const {
+        assert(m_isInitialized && "The factorization should be called first, use compute()");
+        const Index nrhs = (Index)v.size() / m_rows;
+        Padded d(*this, v, nrhs);
+        check(qrk_thin_apply_q(m_plan, transpose ? 1 : 0, d.ptr(), 2 * m_rows, nrhs));
+        Vector pad((size_t)(2 * m_rows * nrhs));
+        check(qrk_memcpy(m_handle, pad.data(), d.p, (int64_t)(pad.size() * sizeof(double)), 1));
+        Vector out((size_t)(m_rows * nrhs));
+        for (Index c = 0; c < nrhs; ++c) std::copy(pad.begin() + c * 2 * m_rows, pad.begin() + c * 2 * m_rows + m_rows, out.begin() + c * m_rows);
+        return out;
+    }
+    void check(qrk_status st) const {
+        if (st != QRK_STATUS_OK) throw std::runtime_error(std::string("qrkit: ") + qrk_last_error(m_handle));
+    }
+    ComputationInfo m_info;
+    Index m_nonzeroPivots;
+    bool m_isInitialized;
+    qrk_handle m_handle;
+    qrk_thin_plan m_plan;
+    Index m_rows, m_cols;
+    mutable Matrix m_R;
+    mutable bool m_Rbuilt;
+    PermutationType m_outputPerm_c, m_rowPerm;
 };
 
 // ---------------------------------------------------------------------------------------------

@@ -263,6 +263,32 @@ qrk_status qrk_dense_solve_r(qrk_dense_plan plan, const double* qr, int64_t lda,
 qrk_status qrk_dense_gemv_sub(qrk_handle h, const double* S, int64_t lds, int64_t rows, int64_t cols, const int32_t* colidx,
                               const double* z, double* y);
 
+/* ------------------------------------------------ thin sparse right solver (BlockedThinSparseQR) */
+
+/* QRKit::BlockedThinSparseQR (src/QRKit/BlockedThinSparseQR.h:105-283): analyzePattern (:168-201: ColumnDensity column ordering,
+ * SparseQROrdering.h:21-50, and as-banded-as-possible row ordering, :52-120) and compute (:105-165) of a thin sparse matrix given
+ * in CSC on the host (colptr[cols + 1], rowidx / vals[nnz], row indices strictly increasing inside a column).  The permuted matrix
+ * is made dense on the device (its nonzeros cross PCIe) and factorised panel by panel: a panel of block_cols columns takes the rows
+ * its sparsity pattern says (updateBlockInfo, :203-238), is factorised by the column-pivoted dense solver (qrk_dense_factorize:
+ * decisions inside rounding go through the exact path as everywhere), its reflectors are applied to the columns on the right, and
+ * its columns of R are written (:271-279).  The number of nonzero pivots of a panel (Eigen's threshold) decides the rows of the next
+ * one, so one word per panel travels to the host.  Both language mirrors (include/qrkit/QRKit.hpp, qrkit_amd/angular.py) call this. */
+typedef struct qrk_thin_plan_s* qrk_thin_plan;
+qrk_status qrk_thin_sparse_factorize(qrk_handle h, int32_t rows, int32_t cols, int32_t block_cols, const int32_t* colptr,
+                                     const int32_t* rowidx, const double* vals, qrk_thin_plan* out);
+qrk_status qrk_thin_destroy(qrk_thin_plan plan);
+/* rank() = nonzero pivots; col_perm[cols] = colsPermutation().indices() (ColumnDensity permutation * Householder column
+ * permutations, zero-pivot columns last, :151-159, :250-256); row_perm[rows] = rowsPermutation().indices().  Any pointer may be NULL. */
+qrk_status qrk_thin_info(qrk_thin_plan plan, int32_t* rank, int32_t* col_perm, int32_t* row_perm);
+/* matrixR(): the cols x cols upper triangle (rows rank.. are zero), column-major with leading dimension ldr */
+qrk_status qrk_thin_matrix_r(qrk_thin_plan plan, double* r, int64_t ldr, qrk_memspace space);
+/* v <- Q^T v (transpose != 0) or Q v, device pointer, nrhs columns of `rows` entries with leading dimension ldv >= 2 rows
+ * (the panels are applied with zero rows appended; the entries rows..2 rows of a column must be zero and stay zero) */
+qrk_status qrk_thin_apply_q(qrk_thin_plan plan, int transpose, double* v, int64_t ldv, int64_t nrhs);
+/* BlockedThinQRBase::_solve_impl (BlockedThinQRBase.h:223-247) in place: v holds b (rows entries per column, ldv as above) and on
+ * return x(0:cols) = [R(0:rank,0:rank)^-1 (Q^T b)(0:rank); 0] (the caller applies the permutations, as with the reference) */
+qrk_status qrk_thin_solve(qrk_thin_plan plan, double* v, int64_t ldv, int64_t nrhs);
+
 /* --------------------------------- banded matrix given as dense strips: two-stage factorisation */
 
 /* BandedBlockedSparseQR::factorize (src/QRKit/BandedBlockedSparseQR.h:463-508) for a block-banded matrix whose block rows are

@@ -28,6 +28,7 @@ EXPORTS = (
     "qrk_bb_plan_info", "qrk_bb_plan_blocks", "qrk_bb_pattern", "qrk_bb_factorize", "qrk_bb_apply_q", "qrk_bb_solve_r", "qrk_dense_solve_r", "qrk_bd_time_factorize", "qrk_bd_kernel_name",
     "qrk_memcpy_2d", "qrk_dense_gemv_sub", "qrk_tsqr_plan_create", "qrk_tsqr_plan_destroy", "qrk_tsqr_factorize", "qrk_tsqr_apply_q",
     "qrk_sparse_window_to_dense",
+    "qrk_thin_sparse_factorize", "qrk_thin_destroy", "qrk_thin_info", "qrk_thin_matrix_r", "qrk_thin_apply_q", "qrk_thin_solve",
     "qrk_bbs_plan_create", "qrk_bbs_plan_destroy", "qrk_bbs_plan_sizes", "qrk_bbs_factorize", "qrk_bbs_r_rows", "qrk_bbs_apply_q", "qrk_bbs_solve",
 )
 
@@ -105,6 +106,18 @@ def lib() -> C.CDLL:
     L.qrk_dense_plan_two_stage.argtypes = [vp]
     L.qrk_dense_apply_q.restype = C.c_int
     L.qrk_dense_apply_q.argtypes = [vp, dp, C.c_int64, dp, C.c_int, dp, C.c_int64, C.c_int64, C.c_int]
+    L.qrk_thin_sparse_factorize.restype = C.c_int
+    L.qrk_thin_sparse_factorize.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, ip, ip, dp, C.POINTER(C.c_void_p)]
+    L.qrk_thin_destroy.restype = C.c_int
+    L.qrk_thin_destroy.argtypes = [vp]
+    L.qrk_thin_info.restype = C.c_int
+    L.qrk_thin_info.argtypes = [vp, C.POINTER(C.c_int32), ip, ip]
+    L.qrk_thin_matrix_r.restype = C.c_int
+    L.qrk_thin_matrix_r.argtypes = [vp, dp, C.c_int64, C.c_int]
+    L.qrk_thin_apply_q.restype = C.c_int
+    L.qrk_thin_apply_q.argtypes = [vp, C.c_int, dp, C.c_int64, C.c_int64]
+    L.qrk_thin_solve.restype = C.c_int
+    L.qrk_thin_solve.argtypes = [vp, dp, C.c_int64, C.c_int64]
     L.qrk_bbs_plan_create.restype = C.c_int
     L.qrk_bbs_plan_create.argtypes = [vp, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]
     L.qrk_bbs_plan_destroy.restype = C.c_int

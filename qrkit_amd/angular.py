@@ -266,107 +266,49 @@ def as_banded_as_possible_indices(mat):
 
 
 class BlockedThinSparseQR:
-    """QRKit::BlockedThinSparseQR (src/QRKit/BlockedThinSparseQR.h:105-283) on the device.
-
-    analyzePattern (:168-201): ColumnDensity column ordering, AsBandedAsPossible row ordering (integer logic, host).
-    compute (:105-165): the permuted matrix is densified on the device and factorised panel by panel; a panel of
-    SuggestedBlockCols columns takes the rows its sparsity pattern says (updateBlockInfo, :203-238), is factorised by the
-    column-pivoted dense solver (qrk_dense_factorize on a copy, as the reference's Ji; its decisions go through the exact
-    path like every other pivoted factorisation), its reflectors are applied to the columns to the right
-    (qrk_dense_apply_q on the row range of the panel -- the block-reflector update of BlockedThinQRBase.h:309-319 in
-    reflector form), and its columns of R are the rows above the diagonal position plus the panel's upper triangle
-    (:271-279).  colsPermutation() = ColumnDensity permutation * Householder column permutation with the zero-pivot columns
-    last (:151-159, :250-256); rank() = nonzero pivots (Eigen's threshold on the panel's pivots)."""
+    """QRKit::BlockedThinSparseQR (src/QRKit/BlockedThinSparseQR.h:105-283) on the device, through the C entry both language
+    mirrors share (qrk_thin_sparse_factorize, include/qrkit_amd.h): analyzePattern (:168-201: ColumnDensity column ordering,
+    AsBandedAsPossible row ordering), compute (:105-165: the permuted matrix made dense on the device and factorised panel by
+    panel -- a panel of SuggestedBlockCols columns takes the rows its sparsity pattern says, updateBlockInfo :203-238, is
+    factorised by the column-pivoted dense solver, its reflectors are applied to the columns to the right, and its columns of R
+    are the rows above the diagonal position plus the panel's upper triangle, :271-279).  colsPermutation() = ColumnDensity
+    permutation * Householder column permutation with the zero-pivot columns last (:151-159, :250-256); rank() = nonzero pivots
+    (Eigen's threshold on the panel's pivots)."""
 
     def __init__(self, context: Context, suggestedBlockCols: int = 2):
         self._ctx = context
         self.suggestedBlockCols = int(suggestedBlockCols)
-        self._plans = {}
+        self._plan = C.c_void_p()
         self.m_isInitialized = False
 
-    def _plan(self, rows, cols):
-        key = (rows, cols)
-        if key not in self._plans:
-            pl = C.c_void_p()
-            capi.check(capi.lib().qrk_dense_plan_create(self._ctx.handle, rows, cols, capi.COLPIV_HOUSEHOLDER, C.byref(pl)),
-                       self._ctx.handle)
-            # one plan serves every panel of this shape and the panels are re-applied later (matrixQ, solve): each
-            # factorisation must leave its whole Q in the panel's own arrays, not in the plan (two-stage format)
-            capi.check(capi.lib().qrk_dense_plan_set_two_stage(pl, 0), self._ctx.handle)
-            self._plans[key] = pl
-        return self._plans[key]
+    def _release(self):
+        if self._plan:
+            capi.lib().qrk_thin_destroy(self._plan)
+            self._plan = C.c_void_p()
 
     def compute(self, mat):
         import scipy.sparse as sp
-        dev = self._ctx.device
         M = sp.csc_matrix(mat)
+        if not M.has_canonical_format:
+            M = M.copy(); M.sum_duplicates()
+        M.sort_indices()
         rows, cols = M.shape
-        cperm = column_density_indices(M)
-        pm = sp.csc_matrix(M[:, cperm])                               # m_pmat = mat * m_outputPerm_c
-        rperm, has = as_banded_as_possible_indices(pm)
-        if has:
-            inv = np.empty_like(rperm); inv[rperm] = np.arange(rows, dtype=rperm.dtype)
-            pm = sp.csc_matrix(sp.csr_matrix(pm)[inv])                # m_pmat = m_rowPerm * m_pmat
-        pm.sort_indices()
-        D = sparse_to_device_dense(self._ctx, pm)                     # m_pmatDense, column-major, written on the device
-        Rout = torch.zeros(rows, cols, dtype=torch.float64, device=dev)
-        lib = capi.lib()
+        self._release()
+        cp = np.ascontiguousarray(M.indptr, dtype=np.int32)
+        ri = np.ascontiguousarray(M.indices, dtype=np.int32)
+        vv = np.ascontiguousarray(M.data, dtype=np.float64)
         self._ctx.use_current_stream()
-        self._panels = []                                             # (row0, nrows, ncols, packed QR, tau)
-        nnz_idx, zero_idx = [], []
-        nzp = solved = new_piv = prev_rows = 0
-        eps = np.finfo(np.float64).eps
-        while solved < cols:
-            new = self.suggestedBlockCols
-            if solved + new >= cols:
-                new = cols - solved
-                nrows = rows - nzp
-            else:
-                biggest = 0
-                for c in range(new):
-                    col = pm.indices[pm.indptr[solved + c]:pm.indptr[solved + c + 1]]
-                    biggest = max(biggest, int(col[-1]) if len(col) else 0)
-                nrows = biggest - nzp + 1
-                if nrows < prev_rows - new_piv:
-                    nrows = prev_rows - new_piv
-            r0, c0 = nzp, solved
-            Ji = _colmajor(D[r0:r0 + nrows, c0:c0 + new].clone())     # the reference factorises a copy of the block
-            k = min(nrows, new)
-            hc = torch.empty(max(k, 1), dtype=torch.float64, device=dev)
-            pp = torch.empty(new, dtype=torch.int32, device=dev)
-            pl = self._plan(nrows, new)
-            capi.check(lib.qrk_dense_factorize(pl, Ji.data_ptr(), nrows, hc.data_ptr(), pp.data_ptr(), capi.MEM_DEVICE),
-                       self._ctx.handle)
-            p = pp.cpu().numpy()
-            # nonzeroPivots(): Eigen's rule on the pivots, |R_kk|^2 < (eps max|col|)^2 (rows - k) / rows ends the count
-            diag = torch.diagonal(Ji)[:k].abs().cpu().numpy()
-            nz = k
-            for q in range(k):
-                if diag[q] ** 2 < (diag[0] * eps) ** 2 * (nrows - q) / nrows:
-                    nz = q
-                    break
-            nnz_idx += [c0 + int(p[c]) for c in range(nz)]
-            zero_idx += [c0 + int(p[c]) for c in range(nz, new)]
-            # update of the columns to the right of the panel (rows of the panel): Q_panel^T applied in reflector form
-            ntrail = cols - (c0 + new)
-            if ntrail > 0 and k > 0:
-                B = D[r0:, c0 + new:]                                 # view: element (0,0) of the trailing block
-                capi.check(lib.qrk_dense_apply_q(pl, Ji.data_ptr(), nrows, hc.data_ptr(), 1, B.data_ptr(), rows, ntrail,
-                                                 capi.MEM_DEVICE), self._ctx.handle)
-            for bc in range(new):
-                Rout[:nzp, nzp + bc] = D[:nzp, c0 + int(p[bc])]
-            Rout[nzp:nzp + k, nzp:nzp + new] = torch.triu(Ji[:k, :])
-            self._panels.append((r0, nrows, new, Ji, hc))
-            new_piv = nz
-            nzp += nz
-            prev_rows = nrows
-            solved += new
-        house = np.array(nnz_idx + zero_idx, dtype=np.int32)
-        self._R = Rout
-        self.m_outputPerm_c = torch.from_numpy(cperm[house].astype(np.int32)).to(dev)
-        self.m_rowPerm = torch.from_numpy(rperm.astype(np.int32)).to(dev)
-        self.m_nonzeroPivots = nzp
+        capi.check(capi.lib().qrk_thin_sparse_factorize(self._ctx.handle, rows, cols, self.suggestedBlockCols, cp.ctypes.data,
+                                                        ri.ctypes.data, vv.ctypes.data, C.byref(self._plan)), self._ctx.handle)
+        rk = C.c_int32()
+        cperm = np.empty(cols, np.int32); rperm = np.empty(rows, np.int32)
+        capi.check(capi.lib().qrk_thin_info(self._plan, C.byref(rk), cperm.ctypes.data, rperm.ctypes.data), self._ctx.handle)
+        dev = self._ctx.device
+        self.m_outputPerm_c = torch.from_numpy(cperm).to(dev)
+        self.m_rowPerm = torch.from_numpy(rperm).to(dev)
+        self.m_nonzeroPivots = int(rk.value)
         self._shape = (rows, cols)
+        self._R = None
         self.m_isInitialized = True
         return self
 
@@ -387,25 +329,34 @@ class BlockedThinSparseQR:
 
     def matrixR(self) -> torch.Tensor:
         """rows x cols, dense on the device (the reference keeps it sparse, column by column)."""
+        if self._R is None:
+            rows, cols = self._shape
+            top = torch.empty(cols, cols, dtype=torch.float64, device=self._ctx.device)      # column-major cols x cols
+            capi.check(capi.lib().qrk_thin_matrix_r(self._plan, top.data_ptr(), cols, capi.MEM_DEVICE), self._ctx.handle)
+            R = torch.zeros(rows, cols, dtype=torch.float64, device=self._ctx.device)
+            R[:cols] = top.t()
+            self._R = R
         return self._R
+
+    def _padded(self, v):
+        """(2 rows, nrhs) column-major work copy of v with zero rows appended (the panels are applied with zero rows below them)."""
+        rows = self._shape[0]
+        t = v if isinstance(v, torch.Tensor) else torch.as_tensor(np.asarray(v, dtype=np.float64))
+        t = t.to(self._ctx.device, torch.float64).reshape(rows, -1)
+        y = torch.zeros(t.shape[1], 2 * rows, dtype=torch.float64, device=self._ctx.device)
+        y[:, :rows] = t.t()
+        return y                                                     # y.t() is the column-major (2 rows, nrhs) matrix
 
     def _applyAny(self, v, transpose: bool):
         """SparseBlockYTY sequence (SparseBlockYTY.h:111-138): Q^T v = panels in order, Q v = in reverse; a panel acts on its
         row range only."""
         was_np = not isinstance(v, torch.Tensor)
-        t = torch.as_tensor(np.asarray(v, dtype=np.float64)) if was_np else v
         rows = self._shape[0]
-        y = _colmajor(t.to(self._ctx.device, torch.float64).reshape(rows, -1).clone())
+        y = self._padded(v)
         self._ctx.use_current_stream()
-        seq = self._panels if transpose else self._panels[::-1]
-        for r0, nrows, new, Ji, hc in seq:
-            if min(nrows, new) == 0:
-                continue
-            B = y[r0:, :]
-            capi.check(capi.lib().qrk_dense_apply_q(self._plan(nrows, new), Ji.data_ptr(), nrows, hc.data_ptr(),
-                                                    1 if transpose else 0, B.data_ptr(), rows, y.shape[1], capi.MEM_DEVICE),
-                       self._ctx.handle)
-        out = y if np.ndim(v) > 1 else y[:, 0]
+        capi.check(capi.lib().qrk_thin_apply_q(self._plan, 1 if transpose else 0, y.data_ptr(), 2 * rows, y.shape[0]), self._ctx.handle)
+        out = y[:, :rows].t()
+        out = out if np.ndim(v) > 1 else out[:, 0]
         return out.cpu().numpy() if was_np else out
 
     def matrixQ(self):
@@ -423,19 +374,16 @@ class BlockedThinSparseQR:
         the rest zero (the caller applies the permutations, as with the reference)."""
         rows, cols = self._shape
         was_np = not isinstance(b, torch.Tensor)
-        y = self._applyAny(torch.as_tensor(np.asarray(b, dtype=np.float64)) if was_np else b, True)
-        y = y.to(self._ctx.device).reshape(rows, -1)
-        rk = self.m_nonzeroPivots
-        x = torch.zeros(max(cols, 0), y.shape[1], dtype=torch.float64, device=y.device)
-        if rk > 0:
-            x[:rk] = torch.linalg.solve_triangular(self._R[:rk, :rk], y[:rk], upper=True)
+        y = self._padded(b)
+        self._ctx.use_current_stream()
+        capi.check(capi.lib().qrk_thin_solve(self._plan, y.data_ptr(), 2 * rows, y.shape[0]), self._ctx.handle)
+        x = y[:, :cols].t()
         x = x if np.ndim(b) > 1 else x[:, 0]
-        return x.cpu().numpy() if was_np else x
+        return x.cpu().numpy() if was_np else x.clone()
 
     def __del__(self):
         try:
-            for pl in self._plans.values():
-                capi.lib().qrk_dense_plan_destroy(pl)
+            self._release()
         except Exception:
             pass
 

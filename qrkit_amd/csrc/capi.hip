@@ -112,6 +112,42 @@ struct qrk_bbs_plan_s {
     bool factorized = false;
 };
 
+// ---- QRKit::BlockedThinSparseQR on the device (include/qrkit_amd.h, qrk_thin_*) -----------------------------------------------
+namespace qrk {
+// columns of R that a panel finishes (BlockedThinSparseQR.h:271-279): column nzp + bc of R takes the rows above the panel from
+// column c0 + p[bc] of the working matrix and the panel's own upper triangle below them
+__global__ void __launch_bounds__(256)
+thin_r_columns_kernel(const double* __restrict__ D, int64_t ldd, const double* __restrict__ Ji, int64_t ldj, const int32_t* __restrict__ pp,
+                      int nzp, int c0, int k, int nnew, double* __restrict__ R, int64_t ldr)
+{
+    const int bc = blockIdx.x;
+    if (bc >= nnew) return;
+    const double* src = D + (int64_t)(c0 + pp[bc]) * ldd;
+    double* dst = R + (int64_t)(nzp + bc) * ldr;
+    for (int i = threadIdx.x; i < nzp; i += 256) dst[i] = src[i];
+    for (int i = threadIdx.x; i < k; i += 256) dst[nzp + i] = i <= bc ? Ji[(int64_t)bc * ldj + i] : 0.0;
+}
+// [diag(Ji)(0:k) | perm as doubles (0:nnew)] in one buffer: one small copy to the host per panel
+__global__ void thin_pack_kernel(const double* __restrict__ Ji, int64_t ldj, const int32_t* __restrict__ pp, int k, int nnew, double* __restrict__ out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < k) out[i] = Ji[(int64_t)i * ldj + i];
+    if (i < nnew) out[k + i] = (double)pp[i];
+}
+}  // namespace qrk
+
+struct qrk_thin_plan_s {
+    qrk_handle h = nullptr;
+    int32_t rows = 0, cols = 0, block_cols = 0;
+    int32_t rank = 0, maxrows = 0;
+    std::vector<int32_t> col_perm, row_perm;       // m_outputPerm_c.indices(), m_rowPerm.indices()
+    struct Panel { int32_t r0, nrows, nnew; double* d_ji; double* d_hc; };
+    std::vector<Panel> panels;                     // packed QR + tau of every panel (maxrows x nnew, leading dimension maxrows)
+    qrk_dense_plan dplan = nullptr, dplan_last = nullptr;   // (maxrows x block_cols) and the last panel's width
+    double* d_R = nullptr;                         // cols x cols, column-major: R(0:rank, :) upper trapezoidal
+    int64_t ldd = 0;
+};
+
 struct qrk_dense_plan_s {
     qrk_handle h = nullptr;
     int32_t rows = 0, cols = 0;
@@ -1337,6 +1373,210 @@ qrk_status qrk_bb_plan_destroy(qrk_bb_plan p)
     (void)hipFree(p->d_rsrc); (void)hipFree(p->d_rcolptr); (void)hipFree(p->d_rrowidx);
     (void)hipFree(p->d_W); (void)hipFree(p->d_lo); (void)hipFree(p->d_stage);
     delete p;
+    return QRK_STATUS_OK;
+}
+
+/* ---- BlockedThinSparseQR (src/QRKit/BlockedThinSparseQR.h:105-283) ---------------------------------------------------------- */
+
+qrk_status qrk_thin_destroy(qrk_thin_plan p)
+{
+    if (!p) return QRK_STATUS_OK;
+    for (auto& q : p->panels) { (void)hipFree(q.d_ji); (void)hipFree(q.d_hc); }
+    if (p->dplan) (void)qrk_dense_plan_destroy(p->dplan);
+    if (p->dplan_last) (void)qrk_dense_plan_destroy(p->dplan_last);
+    (void)hipFree(p->d_R);
+    delete p;
+    return QRK_STATUS_OK;
+}
+
+qrk_status qrk_thin_sparse_factorize(qrk_handle h, int32_t rows, int32_t cols, int32_t block_cols, const int32_t* colptr,
+                                     const int32_t* rowidx, const double* vals, qrk_thin_plan* out)
+{
+    if (!h || !out || rows <= 0 || cols <= 0 || block_cols <= 0 || !colptr || rows < cols)
+        return fail(h, QRK_STATUS_INVALID_ARGUMENT, "qrk_thin_sparse_factorize: bad argument (a thin matrix, rows >= cols, in CSC)");
+    *out = nullptr;
+    const int64_t nnz = colptr[cols];
+    if (nnz < 0 || (nnz > 0 && (!rowidx || !vals))) return fail(h, QRK_STATUS_INVALID_ARGUMENT, "qrk_thin_sparse_factorize: bad CSC arrays");
+    for (int32_t j = 0; j < cols; ++j) {
+        if (colptr[j + 1] < colptr[j]) return fail(h, QRK_STATUS_INVALID_ARGUMENT, "qrk_thin_sparse_factorize: column pointers decrease");
+        for (int32_t e = colptr[j]; e < colptr[j + 1]; ++e)
+            if (rowidx[e] < 0 || rowidx[e] >= rows || (e > colptr[j] && rowidx[e] <= rowidx[e - 1]))
+                return fail(h, QRK_STATUS_INVALID_ARGUMENT, "qrk_thin_sparse_factorize: row indices out of range or not strictly increasing in a column");
+    }
+    QRK_HIP(h, hipSetDevice(h->device));
+    qrk_thin_plan_s* p = new (std::nothrow) qrk_thin_plan_s();
+    if (!p) return fail(h, QRK_STATUS_ALLOC_FAILED, "qrk_thin_sparse_factorize: out of host memory");
+    p->h = h; p->rows = rows; p->cols = cols; p->block_cols = block_cols;
+
+    // ---- analyzePattern (:168-201).  ColumnDensity (SparseQROrdering.h:21-50): columns stable-sorted by their number of nonzeros;
+    // cperm[original column] = sorted rank, and (A P)(:, j) = A(:, cperm[j]) as the reference applies it
+    std::vector<int32_t> order((size_t)cols), cperm((size_t)cols);
+    for (int32_t j = 0; j < cols; ++j) order[(size_t)j] = j;
+    std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return colptr[a + 1] - colptr[a] < colptr[b + 1] - colptr[b]; });
+    for (int32_t k = 0; k < cols; ++k) cperm[(size_t)order[(size_t)k]] = k;
+    // permuted CSC, then AsBandedAsPossible (SparseQROrdering.h:52-120): rows stable-sorted by the column of their first nonzero
+    std::vector<int32_t> pcp((size_t)cols + 1, 0), pri((size_t)nnz);
+    std::vector<double> pv((size_t)nnz);
+    for (int32_t j = 0; j < cols; ++j) pcp[(size_t)j + 1] = pcp[(size_t)j] + (colptr[cperm[(size_t)j] + 1] - colptr[cperm[(size_t)j]]);
+    std::vector<int32_t> start((size_t)rows, cols);
+    for (int32_t j = 0; j < cols; ++j) {
+        const int32_t src = cperm[(size_t)j];
+        int32_t w = pcp[(size_t)j];
+        for (int32_t e = colptr[src]; e < colptr[src + 1]; ++e, ++w) {
+            pri[(size_t)w] = rowidx[e]; pv[(size_t)w] = vals[e];
+            if (start[(size_t)rowidx[e]] == cols) start[(size_t)rowidx[e]] = j;      // (columns ascend: the first hit is the smallest)
+        }
+    }
+    bool has = false;
+    for (int32_t r = 1; r < rows && !has; ++r) has = start[(size_t)r] < start[(size_t)r - 1];
+    std::vector<int32_t> rorder((size_t)rows), rperm((size_t)rows);
+    for (int32_t r = 0; r < rows; ++r) rorder[(size_t)r] = r;
+    if (has) std::stable_sort(rorder.begin(), rorder.end(), [&](int32_t a, int32_t b) { return start[(size_t)a] < start[(size_t)b]; });
+    for (int32_t k = 0; k < rows; ++k) rperm[(size_t)rorder[(size_t)k]] = k;              // old row r -> new row rperm[r]
+    // last (new) row of every permuted column: the height of a panel (updateBlockInfo, :203-238)
+    std::vector<int32_t> lastrow((size_t)cols, 0);
+    for (int32_t j = 0; j < cols; ++j)
+        for (int32_t e = pcp[(size_t)j]; e < pcp[(size_t)j + 1]; ++e) lastrow[(size_t)j] = std::max(lastrow[(size_t)j], rperm[(size_t)pri[(size_t)e]]);
+
+    // ---- the working matrix m_pmatDense on the device: the nonzeros cross PCIe, zero rows are appended so that every panel can be
+    // handed to ONE dense plan of `maxrows` rows (appended zero rows change neither the reflectors nor Eigen's sums)
+    // upper bound of a panel's height: rows (the last panel takes everything that is left)
+    p->maxrows = rows;
+    const int64_t ldd = (int64_t)rows + p->maxrows;
+    p->ldd = ldd;
+    int32_t *d_cp = nullptr, *d_ri = nullptr, *d_map = nullptr, *d_pp = nullptr;
+    double *d_pv = nullptr, *d_D = nullptr, *d_pack = nullptr;
+    auto cleanup = [&]() { (void)hipFree(d_cp); (void)hipFree(d_ri); (void)hipFree(d_map); (void)hipFree(d_pv); (void)hipFree(d_D); (void)hipFree(d_pp); (void)hipFree(d_pack); };
+    qrk_status st;
+    if ((st = upload(h, pcp, &d_cp)) || (st = upload(h, pri, &d_ri)) || (st = upload(h, pv, &d_pv)) || (st = upload(h, rperm, &d_map))) { cleanup(); qrk_thin_destroy(p); return st; }
+    if (hipMalloc((void**)&d_D, (size_t)ldd * cols * sizeof(double)) != hipSuccess ||
+        hipMalloc((void**)&p->d_R, (size_t)cols * cols * sizeof(double)) != hipSuccess ||
+        hipMalloc((void**)&d_pp, (size_t)block_cols * sizeof(int32_t)) != hipSuccess ||
+        hipMalloc((void**)&d_pack, (size_t)2 * block_cols * sizeof(double)) != hipSuccess) {
+        cleanup(); qrk_thin_destroy(p);
+        return fail(h, QRK_STATUS_ALLOC_FAILED, "qrk_thin_sparse_factorize: cannot allocate the dense working matrix");
+    }
+    auto bail = [&](qrk_status code) { cleanup(); qrk_thin_destroy(p); return code; };
+#define QRK_THIN_HIP(expr) do { if ((expr) != hipSuccess) { (void)fail(h, QRK_STATUS_HIP_ERROR, std::string("qrk_thin_sparse_factorize: ") + hipGetErrorString(hipGetLastError())); return bail(QRK_STATUS_HIP_ERROR); } } while (0)
+    QRK_THIN_HIP(hipMemsetAsync(d_D, 0, (size_t)ldd * cols * sizeof(double), h->stream));
+    QRK_THIN_HIP(hipMemsetAsync(p->d_R, 0, (size_t)cols * cols * sizeof(double), h->stream));
+    if (nnz > 0)
+        QRK_THIN_HIP(qrk::launch_sparse_window_to_dense(false, rows, cols, d_cp, d_ri, d_pv, 0, rows, d_map, d_D, ldd, h->stream));
+
+    // ---- compute (:105-165): panel by panel
+    const double eps = DBL_EPSILON;
+    std::vector<int32_t> nnz_idx, zero_idx;
+    std::vector<double> pack((size_t)2 * block_cols);
+    int32_t nzp = 0, solved = 0, new_piv = 0, prev_rows = 0;
+    while (solved < cols) {
+        int32_t nnew = block_cols, nrows;
+        if (solved + nnew >= cols) { nnew = cols - solved; nrows = rows - nzp; }
+        else {
+            int32_t biggest = 0;
+            for (int32_t c = 0; c < nnew; ++c) if (pcp[(size_t)solved + c + 1] > pcp[(size_t)solved + c]) biggest = std::max(biggest, lastrow[(size_t)solved + c]);
+            nrows = biggest - nzp + 1;
+            if (nrows < prev_rows - new_piv) nrows = prev_rows - new_piv;
+        }
+        if (nrows < 0) nrows = 0;
+        const int32_t r0 = nzp, c0 = solved, k = std::min(nrows, nnew);
+        qrk_dense_plan& dp = nnew == block_cols ? p->dplan : p->dplan_last;
+        if (!dp) {
+            if ((st = qrk_dense_plan_create(h, p->maxrows, nnew, QRK_COLPIV_HOUSEHOLDER, &dp)) != QRK_STATUS_OK) return bail(st);
+            (void)qrk_dense_plan_set_two_stage(dp, 0);      // one plan, many panels that are re-applied later: every Q in the panel's own arrays
+        }
+        qrk_thin_plan_s::Panel pn{r0, nrows, nnew, nullptr, nullptr};
+        if (hipMalloc((void**)&pn.d_ji, (size_t)p->maxrows * nnew * sizeof(double)) != hipSuccess ||
+            hipMalloc((void**)&pn.d_hc, (size_t)std::max(nnew, 1) * sizeof(double)) != hipSuccess) {
+            (void)hipFree(pn.d_ji); (void)hipFree(pn.d_hc);
+            (void)fail(h, QRK_STATUS_ALLOC_FAILED, "qrk_thin_sparse_factorize: cannot allocate a panel");
+            return bail(QRK_STATUS_ALLOC_FAILED);
+        }
+        p->panels.push_back(pn);
+        // Ji = copy of the block (the reference factorises a copy), zero rows below it
+        QRK_THIN_HIP(hipMemsetAsync(pn.d_ji, 0, (size_t)p->maxrows * nnew * sizeof(double), h->stream));
+        if (nrows > 0)
+            QRK_THIN_HIP(hipMemcpy2DAsync(pn.d_ji, (size_t)p->maxrows * sizeof(double), d_D + (int64_t)c0 * ldd + r0, (size_t)ldd * sizeof(double),
+                                          (size_t)nrows * sizeof(double), (size_t)nnew, hipMemcpyDeviceToDevice, h->stream));
+        if ((st = qrk_dense_factorize(dp, pn.d_ji, p->maxrows, pn.d_hc, d_pp, QRK_MEM_DEVICE)) != QRK_STATUS_OK) return bail(st);
+        // pivots and permutation of the panel to the host: nonzeroPivots() decides the geometry of the next panel
+        hipLaunchKernelGGL(qrk::thin_pack_kernel, dim3(1), dim3(256), 0, h->stream, pn.d_ji, (int64_t)p->maxrows, d_pp, k, nnew, d_pack);
+        QRK_THIN_HIP(hipMemcpyAsync(pack.data(), d_pack, (size_t)(k + nnew) * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        QRK_THIN_HIP(hipStreamSynchronize(h->stream));
+        // Eigen's rule: |R_qq|^2 < (eps |R_00|)^2 (nrows - q) / nrows ends the count
+        int32_t nz = k;
+        for (int32_t q = 0; q < k; ++q) {
+            const double dq = std::fabs(pack[(size_t)q]), d0 = std::fabs(pack[0]);
+            if (dq * dq < (d0 * eps) * (d0 * eps) * (double)(nrows - q) / (double)nrows) { nz = q; break; }
+        }
+        for (int32_t c = 0; c < nz; ++c) nnz_idx.push_back(c0 + (int32_t)pack[(size_t)(k + c)]);
+        for (int32_t c = nz; c < nnew; ++c) zero_idx.push_back(c0 + (int32_t)pack[(size_t)(k + c)]);
+        // update of the columns to the right (the rows of the panel and the zero rows below them): Q_panel^T in reflector form
+        const int32_t ntrail = cols - (c0 + nnew);
+        if (ntrail > 0 && k > 0)
+            if ((st = qrk_dense_apply_q(dp, pn.d_ji, p->maxrows, pn.d_hc, 1, d_D + (int64_t)(c0 + nnew) * ldd + r0, ldd, ntrail, QRK_MEM_DEVICE)) != QRK_STATUS_OK) return bail(st);
+        hipLaunchKernelGGL(qrk::thin_r_columns_kernel, dim3((unsigned)nnew), dim3(256), 0, h->stream, d_D, ldd, pn.d_ji, (int64_t)p->maxrows, d_pp,
+                           nzp, c0, k, nnew, p->d_R, (int64_t)cols);
+        QRK_THIN_HIP(hipGetLastError());
+        new_piv = nz; nzp += nz; prev_rows = nrows; solved += nnew;
+    }
+#undef QRK_THIN_HIP
+    if (hipStreamSynchronize(h->stream) != hipSuccess) return bail(fail(h, QRK_STATUS_HIP_ERROR, "qrk_thin_sparse_factorize: device error"));
+    p->rank = nzp;
+    p->col_perm.resize((size_t)cols);
+    size_t w = 0;
+    for (int32_t c : nnz_idx) p->col_perm[w++] = cperm[(size_t)c];
+    for (int32_t c : zero_idx) p->col_perm[w++] = cperm[(size_t)c];
+    p->row_perm = rperm;
+    cleanup();
+    *out = p;
+    return QRK_STATUS_OK;
+}
+
+qrk_status qrk_thin_info(qrk_thin_plan p, int32_t* rank, int32_t* col_perm, int32_t* row_perm)
+{
+    if (!p) return QRK_STATUS_INVALID_ARGUMENT;
+    if (rank) *rank = p->rank;
+    if (col_perm) std::copy(p->col_perm.begin(), p->col_perm.end(), col_perm);
+    if (row_perm) std::copy(p->row_perm.begin(), p->row_perm.end(), row_perm);
+    return QRK_STATUS_OK;
+}
+
+qrk_status qrk_thin_matrix_r(qrk_thin_plan p, double* r, int64_t ldr, qrk_memspace space)
+{
+    if (!p || !r || ldr < p->cols) return fail(p ? p->h : nullptr, QRK_STATUS_INVALID_ARGUMENT, "qrk_thin_matrix_r: bad argument");
+    qrk_handle h = p->h;
+    QRK_HIP(h, hipMemcpy2DAsync(r, (size_t)ldr * sizeof(double), p->d_R, (size_t)p->cols * sizeof(double), (size_t)p->cols * sizeof(double),
+                                (size_t)p->cols, space == QRK_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, h->stream));
+    if (space != QRK_MEM_DEVICE) QRK_HIP(h, hipStreamSynchronize(h->stream));
+    return QRK_STATUS_OK;
+}
+
+qrk_status qrk_thin_apply_q(qrk_thin_plan p, int transpose, double* v, int64_t ldv, int64_t nrhs)
+{
+    if (!p || !v || nrhs < 0 || ldv < (int64_t)p->rows + p->maxrows)
+        return fail(p ? p->h : nullptr, QRK_STATUS_INVALID_ARGUMENT, "qrk_thin_apply_q: v needs a leading dimension of at least 2 rows (the panels are applied with zero rows appended)");
+    // SparseBlockYTY sequence (SparseBlockYTY.h:111-138): Q^T v = the panels in order, Q v = in reverse; a panel acts on its row range
+    const size_t np = p->panels.size();
+    for (size_t s = 0; s < np; ++s) {
+        const auto& q = p->panels[transpose ? s : np - 1 - s];
+        if (std::min(q.nrows, q.nnew) == 0) continue;
+        qrk_dense_plan dp = q.nnew == p->block_cols ? p->dplan : p->dplan_last;
+        qrk_status st = qrk_dense_apply_q(dp, q.d_ji, p->maxrows, q.d_hc, transpose ? 1 : 0, v + q.r0, ldv, nrhs, QRK_MEM_DEVICE);
+        if (st != QRK_STATUS_OK) return st;
+    }
+    return QRK_STATUS_OK;
+}
+
+qrk_status qrk_thin_solve(qrk_thin_plan p, double* v, int64_t ldv, int64_t nrhs)
+{
+    // BlockedThinQRBase::_solve_impl (BlockedThinQRBase.h:223-247): y = Q^T b; x(0:rank) = R(0:rank,0:rank)^-1 y(0:rank), the rest zero;
+    // in place in v (the first cols entries of every column on return)
+    qrk_status st = qrk_thin_apply_q(p, 1, v, ldv, nrhs);
+    if (st != QRK_STATUS_OK) return st;
+    qrk_handle h = p->h;
+    if (p->rank > 0) QRK_HIP(h, qrk::launch_dense_solve_r(p->d_R, p->cols, p->rank, v, ldv, nrhs, h->stream));
+    if (p->rank < p->cols)
+        QRK_HIP(h, hipMemset2DAsync(v + p->rank, (size_t)ldv * sizeof(double), 0, (size_t)(p->cols - p->rank) * sizeof(double), (size_t)nrhs, h->stream));
     return QRK_STATUS_OK;
 }
 

@@ -14,6 +14,7 @@
 #include <random>
 
 #include "qrkit/QRKit.hpp"
+#include "thin_sparse_fixture.h"
 
 using namespace qrkit;
 
@@ -191,6 +192,51 @@ static int test_blocked_thin(const Matrix& A) {
     return fails;
 }
 
+// BlockedThinSparseQR on its own (BlockedThinSparseQR.h:105-283): ColumnDensity / as-banded-as-possible orderings, per-panel
+// column pivoting, rank.  Invariants on any input: Q^T (Pr A Pc) = R upper triangular, Q (Q^T b) = b; with full rank also the
+// least-squares solution through both permutations; with the committed rank-deficient fixture the oracle's permutations and rank.
+static int test_blocked_thin_sparse(const SparseMatrixColMajor& A, const int* wantColPerm, const int* wantRowPerm, int wantRank, const char* name) {
+    int fails = 0;
+    BlockedThinSparseQR<2> slvr;
+    slvr.compute(A);
+    const Index rows = A.rows(), cols = A.cols();
+    if (slvr.info() != Success) { std::printf("  info wrong\n"); ++fails; }
+    if (wantRank >= 0 && slvr.rank() != wantRank) { std::printf("  rank %lld, want %d\n", (long long)slvr.rank(), wantRank); ++fails; }
+    if (wantColPerm) for (Index j = 0; j < cols; ++j) if (slvr.colsPermutation().indices()[(size_t)j] != wantColPerm[j]) { std::printf("  column permutation differs from the oracle's at %lld\n", (long long)j); ++fails; break; }
+    if (wantRowPerm) for (Index i = 0; i < rows; ++i) if (slvr.rowsPermutation().indices()[(size_t)i] != wantRowPerm[i]) { std::printf("  row permutation differs from the oracle's at %lld\n", (long long)i); ++fails; break; }
+    // Pr A Pc, dense: row i of A goes to row rowPerm[i]; column j of the product is column colPerm[j] of A
+    Matrix PAP(rows, cols);
+    for (Index j = 0; j < cols; ++j) {
+        const int src = slvr.colsPermutation().indices()[(size_t)j];
+        for (int e = A.outerIndex()[(size_t)src]; e < A.outerIndex()[(size_t)src + 1]; ++e)
+            PAP(slvr.rowsPermutation().indices()[(size_t)A.innerIndex()[(size_t)e]], j) = A.values()[(size_t)e];
+    }
+    const Matrix& R = slvr.matrixR();
+    for (Index j = 0; j < cols && !fails; ++j) for (Index i = j + 1; i < rows; ++i) if (R(i, j) != 0.0) { std::printf("  R is not upper triangular\n"); ++fails; break; }
+    // (the zero-pivot columns come last and carry no column of R: the leading rank() columns are the factorisation)
+    const Index rk = slvr.rank();
+    Matrix PAPr(rows, rk), Rr(rows, rk);
+    for (Index j = 0; j < rk; ++j) for (Index i = 0; i < rows; ++i) { PAPr(i, j) = PAP(i, j); Rr(i, j) = R(i, j); }
+    const Matrix QtA = slvr.matrixQ().transpose() * PAPr;
+    if (!approx(QtA, Rr, 1e-12)) { std::printf("  Q^T*(Pr A Pc) != R\n"); ++fails; }
+    const Matrix QR = slvr.matrixQ() * Rr;
+    if (!approx(QR, PAPr, 1e-12)) { std::printf("  Q*R != Pr A Pc\n"); ++fails; }
+    if (slvr.rank() == cols) {
+        std::mt19937_64 rng(9);
+        std::uniform_real_distribution<double> ud(-1.0, 1.0);
+        Vector x((size_t)cols);
+        for (double& v : x) v = ud(rng);
+        Vector b = A * x, pb((size_t)rows);
+        for (Index i = 0; i < rows; ++i) pb[(size_t)slvr.rowsPermutation().indices()[(size_t)i]] = b[(size_t)i];
+        const Vector z = slvr.solve(pb);                  // solves (Pr A Pc) z = Pr b
+        Vector xs((size_t)cols);
+        for (Index j = 0; j < cols; ++j) xs[(size_t)slvr.colsPermutation().indices()[(size_t)j]] = z[(size_t)j];
+        if (!approxVec(x, xs, 1e-8)) { std::printf("  LS recovery failed\n"); ++fails; }
+    }
+    std::printf("test_blocked_thin_sparse [%s] %lld x %lld, rank %lld: %s\n", name, (long long)rows, (long long)cols, (long long)slvr.rank(), fails ? "Failed." : "Passed.");
+    return fails;
+}
+
 int main() {
     int fails = 0;
     {   // main(), test-qrkit.cpp:363-384
@@ -240,6 +286,22 @@ int main() {
             fails += test_block_angular_as<BlockAngularSparseQR<BandedBlockedQRSolver, BlockedThinSparseQR<2> > >(left, left, thin, thinRM, "banded left, right block with 1/3 of its entries (CSR)");
         }
         fails += test_blocked_thin(right);
+        // the sparse thin solver as the reference defines it: full rank (a third of the right block's entries), then the committed
+        // rank-deficient fixture with the oracle's permutations and rank
+        {
+            std::vector<Triplet> tt;
+            for (Index j = 0; j < right.cols(); ++j)
+                for (Index i = 0; i < right.rows(); ++i)
+                    if ((i + 2 * j) % 3 == 0) tt.emplace_back((int)i, (int)j, right(i, j));
+            SparseMatrixColMajor thinCM(right.rows(), right.cols());
+            thinCM.setFromTriplets(tt);
+            fails += test_blocked_thin_sparse(thinCM, 0, 0, (int)right.cols(), "a third of the right block");
+            SparseMatrixColMajor fx(kThinRows, kThinCols);
+            fx.outerIndex().assign(kThinColPtr, kThinColPtr + kThinCols + 1);
+            fx.innerIndex().assign(kThinRowIdx, kThinRowIdx + kThinColPtr[kThinCols]);
+            fx.values().assign(kThinVals, kThinVals + kThinColPtr[kThinCols]);
+            fails += test_blocked_thin_sparse(fx, kThinColPerm, kThinRowPerm, kThinRank, "rank-deficient fixture (oracle.bt_sparse_qr)");
+        }
     }
     if (std::getenv("QRK_BIG")) {
         // BASELINE configs[3] through the facade: 20000 tiles of 8x6 + 2000 dense columns, host matrices in, solution out.

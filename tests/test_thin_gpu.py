@@ -92,15 +92,14 @@ def test_hip_thin_sparse_matches_oracle(rows, cols, bc, seed):
 
 @pytest.mark.gpu
 def test_hip_thin_sparse_same_shape_panels_under_forced_two_stage(monkeypatch):
-    """Two panels of one shape share a dense plan and are re-applied later (matrixQ, solve).  With the two-stage format forced
-    on (QRK_DENSE_TWO_STAGE=1) the plan would keep only the LAST panel's T / Q1: the solver must switch the format off for its
-    plans (qrk_dense_plan_set_two_stage), or the earlier panels are applied with the wrong Q (round-2 advisor finding)."""
+    """All panels of the chain share one dense plan and are re-applied later (matrixQ, solve).  With the two-stage format forced on
+    (QRK_DENSE_TWO_STAGE=1) the plan would keep only the LAST panel's T / Q1: the chain switches the format off for its plan
+    (qrk_dense_plan_set_two_stage), or the earlier panels would be applied with the wrong Q (round-2 advisor finding)."""
     import qrkit_amd
     monkeypatch.setenv("QRK_DENSE_TWO_STAGE", "1")
     rows, cols, bc = 96, 12, 4
     rng = np.random.default_rng(11)
-    A = rng.uniform(0.5, 5.0, (rows, cols))       # dense: every panel but the last one's successor has the same (rows - 4k, 4) shape family
-    M = sp.csc_matrix(A)
+    M = sp.csc_matrix(rng.uniform(0.5, 5.0, (rows, cols)))
     ref = orc.bt_sparse_qr(M, bc)
     ctx = qrkit_amd.Context(0)
     qr = qrkit_amd.BlockedThinSparseQR(ctx, bc)
@@ -109,10 +108,33 @@ def test_hip_thin_sparse_same_shape_panels_under_forced_two_stage(monkeypatch):
     assert rel_fro(qr.matrixR().cpu().numpy(), ref.R) <= 1e-12
     b = rng.uniform(-1, 1, rows)
     assert rel_fro(qr._applyAny(b, True), orc.bt_apply_q(ref, b, True)) <= 1e-12
-    # same shape twice: a second compute() re-uses the cached plans, the first object's panels must still apply
-    qr2 = qrkit_amd.BlockedThinSparseQR(ctx, bc)
-    qr2._plans = qr._plans
-    M2 = sp.csc_matrix(rng.uniform(0.5, 5.0, (rows, cols)))
-    qr2.compute(M2)
-    assert rel_fro(qr._applyAny(b, True), orc.bt_apply_q(ref, b, True)) <= 1e-12
-    qr2._plans = {}
+    assert rel_fro(qr._applyAny(qr._applyAny(b, True), False), b) <= 1e-13
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows,cols,bc,seed", [(150, 24, 2, 5), (200, 30, 3, 6)])
+def test_hip_thin_sparse_rank_deficient_matches_oracle(rows, cols, bc, seed):
+    """A rank-deficient sparse right block: an EMPTY column (an exact zero pivot: a column that is only numerically dependent leaves a
+    pivot of rounding noise, whose size -- and with it Eigen's nonzero-pivot count -- is not reproducible between two correct
+    implementations).  Rank, both permutations (zero-pivot columns last, BlockedThinSparseQR.h:151-159) and R against the oracle."""
+    import qrkit_amd
+    M = sp.lil_matrix(thin_sparse_problem(rows, cols, seed))
+    M[:, 11] = 0.0
+    M = sp.csc_matrix(M)
+    M.eliminate_zeros()
+    ref = orc.bt_sparse_qr(M, bc)
+    assert ref.rank == cols - 1
+    ctx = qrkit_amd.Context(0)
+    qr = qrkit_amd.BlockedThinSparseQR(ctx, bc)
+    qr.compute(M)
+    assert qr.rank() == ref.rank
+    np.testing.assert_array_equal(qr.colsPermutation().cpu().numpy(), ref.perm)
+    np.testing.assert_array_equal(qr.rowsPermutation().cpu().numpy(), ref.rowperm)
+    R = qr.matrixR().cpu().numpy()
+    assert rel_fro(R, ref.R) <= 1e-12
+    # the leading rank columns are a QR of the nonzero columns: Q^T (Pr M Pc)(:, 0:rank) = R(:, 0:rank)
+    rk = ref.rank
+    PM = permuted(M, ref.perm, ref.rowperm)
+    QtPM = qr._applyAny(PM[:, :rk], True)
+    assert np.linalg.norm(QtPM[:cols] - R[:cols, :rk]) <= 1e-12 * np.linalg.norm(PM) * np.sqrt(cols)
+    assert np.linalg.norm(QtPM[cols:]) <= 1e-12 * np.linalg.norm(PM) * np.sqrt(cols)
