@@ -44,16 +44,19 @@ HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # CPU baseline: the oracle (CPU restatement of the reference path, kind = "port"), in child processes that never touch a GPU
 # ---------------------------------------------------------------------------------------------------------------------
 def _cpu_worker(seconds: float):
-    """Child process: times orc_bd_factorize on 1000 blocks of 32x32 (BASELINE configs[0]) for `seconds`."""
+    """Child process: times orc_bd_factorize on 1000 blocks of 32x32 (BASELINE configs[0]) for `seconds`.
+    QRK_BENCH_FAITHFUL=1: the "faithful assembly" variant, which also reproduces the reference's per-element sparse insertion and
+    triplet sort (BlockDiagonalSparseQR.h:424,457-479,536-541)."""
     from oracle import oracle as orc           # (QRK_ORACLE_LIB, set by cpu_baseline, selects the -O3 -march=native timing copy)
     nb = 1000
+    faithful = os.environ.get("QRK_BENCH_FAITHFUL") == "1"
     tiles = orc.gen_uniform(1, 0.5, 5.0, nb * BR * BC)
     prob = orc.BDProblem.uniform(nb, BR, BC, tiles)
-    prob.factorize()
+    prob.factorize(faithful)
     t0 = time.perf_counter()
     reps = 0
     while time.perf_counter() - t0 < seconds:
-        prob.factorize()
+        prob.factorize(faithful)
         reps += 1
     dt = time.perf_counter() - t0
     print(json.dumps({"reps": reps, "seconds": dt, "tiles_per_s": reps * nb / dt}), flush=True)
@@ -86,6 +89,9 @@ def cpu_baseline(seconds: float):
         return json.loads(out.strip().splitlines()[-1])
 
     one = result(spawn(seconds))
+    pf = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--_cpu-worker", str(max(seconds / 3, 2.0))],
+                          stdout=subprocess.PIPE, text=True, cwd=ROOT, env=dict(env, QRK_BENCH_FAITHFUL="1"))
+    faithful = result(pf)
     try:
         ncores = len(os.sched_getaffinity(0))
     except AttributeError:
@@ -103,6 +109,9 @@ def cpu_baseline(seconds: float):
                       "(the reference's hot loop is single-threaded, BlockDiagonalSparseQR.h:432)",
             "block_factorizations_per_s": one["tiles_per_s"],
             "cpu_model": _cpu_model(),
+            "faithful_assembly": {"cores": 1, "value": faithful["tiles_per_s"] / BLOCKS, "block_factorizations_per_s": faithful["tiles_per_s"],
+                                  "sample": f"{faithful['reps']} x (1000 blocks of 32x32) in {faithful['seconds']:.1f} s, with the reference's per-element "
+                                            "sparse insertion and triplet sort of Q and R (BlockDiagonalSparseQR.h:424,457-479,536-541)"},
             "allcores": {"cores": ncores, "value": rate_all / BLOCKS, "block_factorizations_per_s": rate_all,
                          "sample": f"{ncores} independent processes, {allc[0]['seconds']:.1f} s each, same workload"}}
 
@@ -135,6 +144,9 @@ def parse(argv):
     ap.add_argument("--no-strong", action="store_true", help="N > 1: skip the strong-scaling legs")
     ap.add_argument("--no-steady", action="store_true", help="N = 1: skip the 160000-tile steady-state leg (profiling runs)")
     ap.add_argument("--strong-blocks", type=str, default="10000,1000000")
+    ap.add_argument("--mixed-blocks", type=int, default=100000, help="N > 1: tiles of the configs[4] strong leg (mixed 8..256; 0 = skip)")
+    ap.add_argument("--angular-blocks", type=int, default=20000, help="N > 1: tiles of the configs[3] strong leg (8x6 + 2000 dense columns; 0 = skip)")
+    ap.add_argument("--no-e2e", action="store_true", help="N = 1: skip the host-buffer (PCIe-inclusive) figure")
     ap.add_argument("--_cpu-worker", type=float, default=None, help=argparse.SUPPRESS)
     return ap.parse_args(argv)
 
@@ -145,7 +157,20 @@ def main():
     if args._cpu_worker is not None:
         return _cpu_worker(args._cpu_worker)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        sys.exit(spawn_ranks(args, argv))
+        # the CPU leg in the parent, before any rank (or GPU call) exists; rank 0 picks the result up from a file
+        if not args.no_cpu_baseline:
+            import tempfile
+            fd, path = tempfile.mkstemp(prefix="qrk_bench_cpu_", suffix=".json")
+            with os.fdopen(fd, "w") as f:
+                json.dump(cpu_baseline(args.cpu_seconds), f)
+            os.environ["QRK_BENCH_CPU_JSON"] = path
+        rc = spawn_ranks(args, argv)
+        if os.environ.get("QRK_BENCH_CPU_JSON"):
+            try:
+                os.remove(os.environ["QRK_BENCH_CPU_JSON"])
+            except OSError:
+                pass
+        sys.exit(rc)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -157,6 +182,12 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args.cpu_seconds)
+    elif rank == 0 and os.environ.get("QRK_BENCH_CPU_JSON"):
+        try:
+            with open(os.environ["QRK_BENCH_CPU_JSON"]) as f:
+                cpu = json.load(f)                       # measured by the parent before it started the ranks
+        except (OSError, ValueError):
+            cpu = None
 
     import numpy as np
     import torch
@@ -267,6 +298,26 @@ def main():
     strong = None
     if dist is not None and world > 1 and not args.no_strong:
         strong = strong_scaling(args, ctx, dev, dist, backend, rank, world, torch, np)
+        if args.mixed_blocks > 0:
+            strong["configs4_mixed"] = strong_mixed(args, ctx, dev, dist, backend, rank, world, torch, np)
+        if args.angular_blocks > 0:
+            strong["configs3_angular"] = strong_angular(args, ctx, dev, dist, backend, rank, world, torch, np)
+
+    # ---- end to end with host buffers (N = 1): tiles over PCIe in, Q / R / perm back (never the headline value)
+    e2e = None
+    if world == 1 and not args.no_e2e:
+        ht = tiles[:tl].cpu().numpy()
+        hq = np.empty(nq); hr = np.empty(nr); hp = np.empty(ncol, np.int32)
+        lib = capi.lib()
+        for _ in range(2):
+            capi.check(lib.qrk_bd_factorize(plan, ht.ctypes.data, hq.ctypes.data, hr.ctypes.data, hp.ctypes.data, None, capi.MEM_HOST), ctx.handle)
+        t0e = time.perf_counter()
+        for _ in range(5):
+            capi.check(lib.qrk_bd_factorize(plan, ht.ctypes.data, hq.ctypes.data, hr.ctypes.data, hp.ctypes.data, None, capi.MEM_HOST), ctx.handle)
+        dte = (time.perf_counter() - t0e) / 5
+        e2e = {"ms_per_factorization": dte * 1e3, "factorizations_per_s": 1.0 / dte,
+               "what": "qrk_bd_factorize with QRK_MEM_HOST: pageable host tiles in (82 MB), Q / R / perm out (125 MB) over PCIe + the kernel; "
+                       "not the headline value (inputs there are resident in HBM)"}
 
     if rank == 0:
         fact_per_s = world * args.steps / wall
@@ -295,6 +346,7 @@ def main():
                        "blocks": BLOCKS, "block_rows": BR, "block_cols": BC, "matrices_rotated": S,
                        "parallelism": f"{world} rank(s), one per GPU; ranks seen by the process group: "
                                       f"{dist.get_world_size() if dist is not None else 1} ({backend if dist is not None else 'no collective'}); "
+                                      f"GPUs visible to this rank: {ndev}; "
                                       "each rank factorises its own stream of matrices, no data-path collective"},
             "block_factorizations_per_s": fact_per_s * BLOCKS,
             "gflops": fact_per_s * BLOCKS * FLOPS_PER_TILE / 1e9,
@@ -308,6 +360,8 @@ def main():
             out["steady_state"] = steady
         if strong is not None:
             out["strong_scaling"] = strong
+        if e2e is not None:
+            out["end_to_end_host_buffers"] = e2e
         if cpu is not None:
             out["cpu_baseline"] = cpu
         print(json.dumps(out), flush=True)
@@ -378,6 +432,102 @@ def strong_scaling(args, ctx, dev, dist, backend, rank, world, torch, np):
         del t, q, r, p, R_all, P_all
     return {"scaling": "strong", "collective": "grouped send/recv of R (f64) and perm (i32) shards to rank 0, true byte counts, "
                                                "inside the timed region", "backend": backend, "runs": res}
+
+
+def _timed(dist, torch, dev, backend, fn, iters):
+    dist.barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        fn()
+    torch.cuda.synchronize(); dist.barrier()
+    dt = time.perf_counter() - t0
+    tt = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    return tt.item() / iters
+
+
+def strong_mixed(args, ctx, dev, dist, backend, rank, world, torch, np):
+    """BASELINE configs[4]: B mixed square tiles, n ~ U{8..256} (seed 12345), cut into contiguous ranges balanced by r c^2
+    (sharding.shard_ranges); every rank factorises its range; the packed R (about 9 GB at B = 100000) and the permutation are gathered
+    on rank 0 with their true byte counts (grouped send/recv) inside the timed region."""
+    from qrkit_amd import _capi as capi
+    from qrkit_amd.sharding import gather_ragged_to_root, shard_ranges
+    B = args.mixed_blocks
+    n = np.random.default_rng(12345).integers(8, 257, B).astype(np.int32)
+    ranges = shard_ranges(n, n, world)
+    lo, hi = ranges[rank]
+    nl = np.ascontiguousarray(n[lo:hi])
+    n64 = n.astype(np.int64)
+    lay = capi.BDLayout()
+    lay.num_blocks, lay.block_rows, lay.block_cols = len(nl), 0, 0
+    lay.rows = nl.ctypes.data_as(C.POINTER(C.c_int32)); lay.cols = nl.ctypes.data_as(C.POINTER(C.c_int32))
+    lay.mat_rows = lay.mat_cols = int(nl.sum())
+    plan = C.c_void_p()
+    capi.check(capi.lib().qrk_bd_plan_create(ctx.handle, C.byref(lay), capi.FULL_Q, capi.COLPIV_HOUSEHOLDER, C.byref(plan)), ctx.handle)
+    l64 = nl.astype(np.int64)
+    n_in, n_q, n_r, n_c = int((l64 * l64).sum()), int((l64 * l64).sum()), int((l64 * (l64 + 1) // 2).sum()), int(l64.sum())
+    g = torch.Generator(device=dev); g.manual_seed(4242 + rank)
+    t = torch.rand(n_in, generator=g, device=dev, dtype=torch.float64) * 2 - 1
+    q = torch.empty(n_q, device=dev, dtype=torch.float64)
+    r = torch.empty(n_r, device=dev, dtype=torch.float64)
+    p = torch.empty(n_c, device=dev, dtype=torch.int32)
+    r_sizes = [int((n64[a:b] * (n64[a:b] + 1) // 2).sum()) for a, b in ranges]
+    p_sizes = [int(n64[a:b].sum()) for a, b in ranges]
+    xdev = dev if backend == "nccl" else "cpu"
+    R_all = torch.empty(sum(r_sizes), device=xdev, dtype=torch.float64) if rank == 0 else None
+    P_all = torch.empty(sum(p_sizes), device=xdev, dtype=torch.int32) if rank == 0 else None
+    base_col = int(n64[:lo].sum())
+
+    def step(gather):
+        capi.check(capi.lib().qrk_bd_factorize(plan, t.data_ptr(), q.data_ptr(), r.data_ptr(), p.data_ptr(), None, capi.MEM_DEVICE), ctx.handle)
+        if gather:
+            gather_ragged_to_root(r.to(xdev), r_sizes, R_all, 0, rank, world)
+            gather_ragged_to_root((p + base_col).to(xdev), p_sizes, P_all, 0, rank, world)
+
+    step(True)
+    with_g = _timed(dist, torch, dev, backend, lambda: step(True), 3)
+    without = _timed(dist, torch, dev, backend, lambda: step(False), 3)
+    byts = float((8 * n64 * n64 + 8 * n64 * n64 + 4 * n64 * (n64 + 1) + 4 * n64).sum())
+    flops = float((2 * n64 ** 3 - 2 * n64 ** 3 / 3 + 4 * (n64 ** 3 / 3)).sum())
+    capi.lib().qrk_bd_plan_destroy(plan)
+    return {"workload": f"{B} square tiles, n ~ U{{8..256}}, seed 12345 (BASELINE configs[4]); shards balanced by r c^2",
+            "tiles_per_rank": [b - a for a, b in ranges], "ms_with_gather": with_g * 1e3, "ms_factorize_only": without * 1e3,
+            "gather_ms": (with_g - without) * 1e3, "tiles_per_s": B / with_g, "gathered_bytes_on_root": 8 * sum(r_sizes) + 4 * sum(p_sizes),
+            "roofline": {"bound": "hbm below n ~ 75, fp64 above", "algorithmic_GBs": byts / without / 1e9, "hbm_peak_GBs": HBM_PEAK_GBS * world,
+                         "TFLOPs": flops / without / 1e12, "fp64_peak_TFLOPs": 78.6 * world,
+                         "frac_of_fp64_peak": flops / without / 1e12 / (78.6 * world)}}
+
+
+def strong_angular(args, ctx, dev, dist, backend, rank, world, torch, np):
+    """BASELINE configs[3]: B tiles of 8 x 6 on the diagonal + a dense right block of (8 B) x 2000, rows sharded with the tiles
+    (qrkit_amd.sharding.ShardedBlockAngularQR: left factor and Q1^T J2 on the rank, the bottom rows reduced to one n x n triangle per
+    rank by the un-pivoted CAQR, triangles gathered on the root, pivoted right solver there, P2 broadcast); compute() and solve()."""
+    import qrkit_amd
+    from qrkit_amd.sharding import ShardedBlockAngularQR
+    B, r, c, m2 = args.angular_blocks, 8, 6, 2000
+    if B * r < 4 * m2:
+        m2 = max(16, (B * r // 4) // 16 * 16)
+    rows = np.full(B, r, np.int32); cols = np.full(B, c, np.int32)
+    slv = ShardedBlockAngularQR(rows, cols, m2, rank, world, context=ctx)
+    lo, hi = slv.start, slv.end
+    nb = hi - lo
+    g = torch.Generator(device=dev); g.manual_seed(777 + rank)
+    tl = torch.rand(nb * r * c, generator=g, device=dev, dtype=torch.float64) * 4.5 + 0.5
+    left = qrkit_amd.SparseBlockDiagonal.fromTiles(rows[lo:hi], cols[lo:hi], tl)
+    J2 = (torch.rand(m2, nb * r, generator=g, device=dev, dtype=torch.float64) * 4.5 + 0.5).t()      # column-major (nb r) x m2
+    b = torch.rand(nb * r, generator=g, device=dev, dtype=torch.float64)
+    slv.compute(left, J2); slv.solve(b)
+    t_compute = _timed(dist, torch, dev, backend, lambda: slv.compute(left, J2), 3)
+    t_solve = _timed(dist, torch, dev, backend, lambda: slv.solve(b), 3)
+    n1 = B * r
+    flops = 4.0 * n1 * c * m2 + (2.0 * (n1 - B * c) * m2 * m2 - 2.0 * m2 ** 3 / 3)          # Q1^T J2 + the right block's QR
+    return {"workload": f"{B} tiles of {r}x{c} + dense {n1} x {m2} right block, rows sharded with the tiles (BASELINE configs[3])",
+            "tiles_per_rank": [b2 - a for a, b2 in slv.ranges], "compute_ms": t_compute * 1e3, "solve_ms": t_solve * 1e3,
+            "factorizations_per_s": 1.0 / t_compute,
+            "exchange": f"{world} triangles of {m2} x {m2} doubles gathered on rank 0 ({8 * m2 * m2 * world} bytes), P2 ({4 * m2} bytes) broadcast; solve: one {m2}-vector per rank up, z2 down",
+            "roofline": {"bound": "mfma (right block), hbm (Q1^T J2)", "TFLOPs": flops / t_compute / 1e12, "fp64_peak_TFLOPs": 78.6 * world,
+                         "frac_of_fp64_peak": flops / t_compute / 1e12 / (78.6 * world), "J2_bytes": 8.0 * n1 * m2,
+                         "J2_GBs_if_read_once": 8.0 * n1 * m2 / t_compute / 1e9}}
 
 
 def _traffic():
