@@ -32,8 +32,18 @@ cpptest: $(LIB)
 	g++ -O2 -std=c++14 -Wall -Iinclude tests/cpp/test_compositions.cpp -Lqrkit_amd/lib -lqrkit_amd \
 	    -Wl,-rpath,'$$ORIGIN/../qrkit_amd/lib' -o build/test_compositions
 
+# CPU sanitizer targets (the GPU side has no sanitizer on this pool): the oracle as an ASan + UBSan library for
+# the oracle's own tests, and the host-side integer logic of the banded solver (banded_host.hip is plain C++) with a driver on the
+# reference's known answers.  tests/test_sanitizers.py runs both.
+SAN := -fsanitize=address,undefined -fno-omit-frame-pointer -g
+san:
+	@mkdir -p build/san
+	gcc -O1 -std=c99 -fPIC -ffp-contract=off -Wall -Wextra $(SAN) -shared -o build/san/libqrk_oracle_san.so oracle/qrk_oracle.c -lm
+	g++ -O1 -std=c++17 -Wall $(SAN) -x c++ $(CSRC)/banded_host.hip -x c++ tests/san/banded_host_san.cpp -o build/san/banded_host_san
+	ASAN_OPTIONS=detect_leaks=1 UBSAN_OPTIONS=halt_on_error=1 build/san/banded_host_san
+
 clean:
 	rm -rf build $(LIB)
 	$(MAKE) -C oracle clean
 
-.PHONY: all oracle clean cpptest
+.PHONY: all oracle clean cpptest san

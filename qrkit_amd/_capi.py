@@ -106,6 +106,8 @@ def lib() -> C.CDLL:
     L.qrk_dense_plan_two_stage.argtypes = [vp]
     L.qrk_dense_apply_q.restype = C.c_int
     L.qrk_dense_apply_q.argtypes = [vp, dp, C.c_int64, dp, C.c_int, dp, C.c_int64, C.c_int64, C.c_int]
+    L.qrk_dense_gemv_sub.restype = C.c_int
+    L.qrk_dense_gemv_sub.argtypes = [vp, dp, C.c_int64, C.c_int64, C.c_int64, ip, dp, dp]
     L.qrk_thin_sparse_factorize.restype = C.c_int
     L.qrk_thin_sparse_factorize.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, ip, ip, dp, C.POINTER(C.c_void_p)]
     L.qrk_thin_destroy.restype = C.c_int

@@ -518,8 +518,17 @@ class BlockAngularSparseQR:
         y = y.reshape(self._rows, -1)
         m1, m2 = self._m1, self._m2
         y2 = self.m_rightSolver.solveR(_colmajor(y[m1:m1 + m2, :].clone()))       # R2^-1 y2 on the device (qrk_dense_solve_r)
-        strip = self._J2[:m1, :][:, self._P2]
-        rhs1 = y[:m1, :] - strip @ y2
+        # y1 -= S(:, P2) z2 with the strip S = (Q1^T J2)(0:m1, :) as it lies on the device (qrk_dense_gemv_sub, one column at a time:
+        # the kernel reads the strip once per right-hand side), not a library GEMM on a permuted copy
+        rhs1 = _colmajor(y[:m1, :].clone())
+        strip = self._J2[:m1, :]
+        if not strip.t().is_contiguous():
+            strip = _colmajor(strip)
+        p2 = self._P2.to(torch.int32).contiguous()
+        self._ctx.use_current_stream()
+        for k in range(rhs1.shape[1]):
+            capi.check(capi.lib().qrk_dense_gemv_sub(self._ctx.handle, strip.data_ptr(), strip.stride(1), m1, m2, p2.data_ptr(),
+                                                     y2[:, k].contiguous().data_ptr(), rhs1[:, k].data_ptr()), self._ctx.handle)
         # R1 is block upper triangular: solve it tile by tile with the left solver's packed R
         y1 = self.m_leftSolver.solveR(rhs1)
         yy = torch.cat([y1, y2], dim=0)

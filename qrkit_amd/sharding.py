@@ -279,7 +279,15 @@ class ShardedBlockAngularQR:
             self.m_rightSolver.applyQ(ys, transpose=True)
             z2 = self.m_rightSolver.solveR(self._colmajor(ys[:m2, :].clone()))
         z2 = self._bcast(z2)
-        rhs1 = y1 - self._S[:, self._P2] @ z2
+        # y1 -= S(:, P2) z2 on the device with the strip as it lies there (qrk_dense_gemv_sub), not a library GEMM on a permuted copy
+        from . import _capi as capi
+        S = self._S if self._S.t().is_contiguous() else self._colmajor(self._S)
+        rhs1 = self._colmajor(y1.clone())
+        p2 = self._P2.to(torch.int32).contiguous()
+        zc = z2[:, 0].contiguous()
+        self._ctx.use_current_stream()
+        capi.check(capi.lib().qrk_dense_gemv_sub(self._ctx.handle, S.data_ptr(), S.stride(1), m1, m2, p2.data_ptr(), zc.data_ptr(),
+                                                 rhs1[:, 0].data_ptr()), self._ctx.handle)
         z1 = self.m_leftSolver.solveR(rhs1)
         p1 = torch.as_tensor(self.m_leftSolver.colsPermutation(), device=dev).long()
         x1 = torch.empty_like(z1)
