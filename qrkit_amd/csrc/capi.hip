@@ -166,6 +166,9 @@ struct qrk_dense_plan_s {
     // then R0 P = Q1 R by the level-2 kernels on the n x n triangle.  d_r0 keeps the packed QR of the second stage, d_t the T
     // factors of the first; the caller's array holds the reflectors of Q0 below / inside its top triangles and R above.
     bool two_stage = false;
+    bool caqr_only = false;    // un-pivoted solver (HouseholderQR) on a tall matrix: the first stage IS the factorisation, A = Q0 R0 on the matrix
+                               // cores (the block-reflector update of BlockedThinQRBase::updateMat, BlockedThinQRBase.h:309-333, as MFMA tiles)
+    int fmt_capable = 0;       // 0: Eigen's format only; 1: two-stage workspaces exist; 2: CAQR-only workspaces exist
     bool ts_active = false;    // the last factorisation ended in the two-stage format (false: Eigen's packed format, also after the exact path)
     const void* ts_owner = nullptr;   // ... and this is the caller's array it was computed in: the T factors and Q1 kept in the plan belong to
                                       // that factorisation only (qrk_dense_apply_q refuses any other array while ts_active)
@@ -951,15 +954,17 @@ qrk_status qrk_dense_plan_create(qrk_handle h, int32_t rows, int32_t cols, qrk_b
     }
     // Two-stage form: pivoted, tall (rows >= 4 cols) and large enough that the level-2 sweeps over the whole matrix dominate.
     // QRK_DENSE_TWO_STAGE=0/1 overrides (1 needs rows >= cols, pivoting).
-    p->two_stage = p->tall && solver == QRK_COLPIV_HOUSEHOLDER && cols >= 128 && (int64_t)rows >= 4 * (int64_t)cols &&
-                   (int64_t)rows * cols >= (int64_t)1 << 22;
+    const bool big_tall = p->tall && cols >= 128 && (int64_t)rows >= 4 * (int64_t)cols && (int64_t)rows * cols >= (int64_t)1 << 22;
+    p->two_stage = big_tall && solver == QRK_COLPIV_HOUSEHOLDER;
+    p->caqr_only = big_tall && solver == QRK_HOUSEHOLDER;
     if (const char* e = std::getenv("QRK_DENSE_TWO_STAGE")) {
-        if (e[0] == '0') p->two_stage = false;
-        else if (e[0] == '1' && solver == QRK_COLPIV_HOUSEHOLDER && rows >= cols) p->two_stage = true;
+        if (e[0] == '0') { p->two_stage = false; p->caqr_only = false; }
+        else if (e[0] == '1' && rows >= cols) { p->two_stage = solver == QRK_COLPIV_HOUSEHOLDER; p->caqr_only = solver == QRK_HOUSEHOLDER; }
     }
+    p->fmt_capable = p->two_stage ? 1 : (p->caqr_only ? 2 : 0);
     p->exact_wide = (int64_t)rows * cols >= (int64_t)1 << 18;
     if (const char* e = std::getenv("QRK_EXACT_WIDE")) p->exact_wide = e[0] == '1' || (e[0] != '0' && p->exact_wide);
-    p->cols_direct = p->tall && !p->two_stage && !p->persistent && qrk::dense_cols_supported(rows, cols);
+    p->cols_direct = p->tall && !p->two_stage && !p->caqr_only && !p->persistent && qrk::dense_cols_supported(rows, cols);
     if (const char* e = std::getenv("QRK_DENSE_PATH")) { if (!std::strcmp(e, "slabs")) p->cols_direct = false; }
     if (p->cols_direct) {
         const size_t bytes2 = qrk::dense_cols_workspace_bytes(cols, &p->cpad2);
@@ -967,6 +972,10 @@ qrk_status qrk_dense_plan_create(qrk_handle h, int32_t rows, int32_t cols, qrk_b
             qrk_dense_plan_destroy(p);
             return fail(h, QRK_STATUS_ALLOC_FAILED, "qrk_dense_plan_create: cannot allocate the workspaces of the column-parallel kernel");
         }
+    }
+    if (p->caqr_only && hipMalloc((void**)&p->d_t, qrk::caqr_t_bytes(rows, cols)) != hipSuccess) {
+        qrk_dense_plan_destroy(p);
+        return fail(h, QRK_STATUS_ALLOC_FAILED, "qrk_dense_plan_create: cannot allocate the T factors of the communication-avoiding QR");
     }
     if (p->two_stage) {
         // second stage: the column-parallel kernel (one launch per reflector) when a column fits LDS, else the row-slab kernels
@@ -985,6 +994,8 @@ qrk_status qrk_dense_plan_create(qrk_handle h, int32_t rows, int32_t cols, qrk_b
             return fail(h, QRK_STATUS_ALLOC_FAILED, "qrk_dense_plan_create: cannot allocate the two-stage workspaces");
         }
         if (!p->cols2) p->d_q1 = p->d_r0;
+    }
+    if (p->two_stage || p->caqr_only) {
         const char* la = std::getenv("QRK_CAQR_LOOKAHEAD");
         // (highest priority: a panel workgroup needs the LDS of one apply workgroup and should get the next slot that frees up)
         int prio_least = 0, prio_greatest = 0;
@@ -1039,14 +1050,15 @@ qrk_status qrk_dense_plan_destroy(qrk_dense_plan p)
 qrk_status qrk_dense_plan_set_two_stage(qrk_dense_plan p, int enable)
 {
     if (!p) return fail(nullptr, QRK_STATUS_INVALID_ARGUMENT, "qrk_dense_plan_set_two_stage: null plan");
-    if (enable && !p->d_t)
+    if (enable && p->fmt_capable == 0)
         return fail(p->h, QRK_STATUS_UNSUPPORTED, "qrk_dense_plan_set_two_stage: this plan was created without the two-stage workspaces");
-    p->two_stage = enable != 0;
-    if (!p->two_stage) { p->ts_active = false; p->ts_owner = nullptr; }
+    p->two_stage = enable != 0 && p->fmt_capable == 1;
+    p->caqr_only = enable != 0 && p->fmt_capable == 2;
+    if (!enable) { p->ts_active = false; p->ts_owner = nullptr; }
     return QRK_STATUS_OK;
 }
 
-int qrk_dense_plan_two_stage(qrk_dense_plan p) { return p && p->two_stage ? 1 : 0; }
+int qrk_dense_plan_two_stage(qrk_dense_plan p) { return p && (p->two_stage || p->caqr_only) ? 1 : 0; }
 
 qrk_status qrk_dense_factorize(qrk_dense_plan p, double* a, int64_t lda, double* hcoeffs, int32_t* perm,
                                qrk_memspace space)
@@ -1075,6 +1087,20 @@ qrk_status qrk_dense_factorize(qrk_dense_plan p, double* a, int64_t lda, double*
         const int* flag = nullptr;
         p->ts_active = false;
         p->ts_owner = nullptr;
+        if (!h->force_exact && p->caqr_only) {
+            // HouseholderQR of a tall matrix as communication-avoiding QR: R0 in the upper triangle of the first cols rows, the reflectors
+            // of the tree and their T factors elsewhere / in the plan; nothing is decided by the data, so nothing goes to the exact path
+            QRK_HIP(h, qrk::launch_caqr_factorize(da, lda, p->rows, p->cols, p->d_t, h->stream, p->la_stream, p->la_urgent, p->la_factored,
+                                                  p->la_pipe.urgent ? &p->la_pipe : nullptr));
+            QRK_HIP(h, hipMemsetAsync(dhc, 0, (size_t)size * sizeof(double), h->stream));        // (no Householder coefficients in this format)
+            std::vector<int32_t> ident((size_t)p->cols);
+            for (int32_t j = 0; j < p->cols; ++j) ident[(size_t)j] = j;
+            QRK_HIP(h, hipMemcpyAsync(dp, ident.data(), (size_t)p->cols * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+            QRK_HIP(h, hipStreamSynchronize(h->stream));                                         // (the host vector goes out of scope)
+            p->ts_active = true;
+            p->ts_owner = static_cast<const void*>(a);
+            return QRK_STATUS_OK;
+        }
         if (!h->force_exact && p->two_stage) {
             // stage 1: A = Q0 R0 (no pivoting, MFMA trailing updates); stage 2: R0 P = Q1 R on the n x n triangle
             const int n = p->cols;
@@ -1172,11 +1198,12 @@ qrk_status qrk_dense_apply_q(qrk_dense_plan p, const double* qr, int64_t lda, co
         };
         if (!p->ts_active) return eigen_form(dqr, lda, p->rows, size);
         hipError_t e = hipSuccess;
+        const bool q1 = !p->caqr_only;        // (two-stage: Q = Q0 diag(Q1, I); CAQR alone: Q = Q0)
         if (transpose) {
             e = qrk::launch_caqr_apply(dqr, lda, p->rows, p->cols, p->d_t, 1, db, ldb, nrhs, h->stream);
-            if (e == hipSuccess) e = eigen_form(p->d_q1, p->cols, p->cols, p->cols);
+            if (e == hipSuccess && q1) e = eigen_form(p->d_q1, p->cols, p->cols, p->cols);
         } else {
-            e = eigen_form(p->d_q1, p->cols, p->cols, p->cols);
+            if (q1) e = eigen_form(p->d_q1, p->cols, p->cols, p->cols);
             if (e == hipSuccess) e = qrk::launch_caqr_apply(dqr, lda, p->rows, p->cols, p->d_t, 0, db, ldb, nrhs, h->stream);
         }
         return e;

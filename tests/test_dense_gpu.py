@@ -459,3 +459,40 @@ def test_two_stage_state_belongs_to_the_last_factorised_array(monkeypatch):
         assert rel_fro(np.triu(At.cpu().numpy()[:cols]), np.triu(ref[:cols])) <= 1e-12      # Eigen's format: signs included
         assert np.linalg.norm(Bm.cpu().numpy()[:cols] - np.triu(At.cpu().numpy()[:cols])) <= 1e-12 * np.linalg.norm(A) * np.sqrt(cols)
     lib.qrk_dense_plan_destroy(plan)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows,cols,force", [(2048, 96, True), (4100, 200, True), (20000, 256, False)])
+def test_unpivoted_tall_block_runs_as_caqr(rows, cols, force, monkeypatch):
+    """HouseholderQR of a tall dense block (the BlockedThinDenseQR chain, BlockedThinDenseQR.h:104-176, whose panel update is the
+    block reflector of BlockedThinQRBase::updateMat, BlockedThinQRBase.h:309-333) as communication-avoiding QR on the matrix cores:
+    R is the reference's up to the sign of each row (the elimination order differs), Q stays implicit.  The
+    last shape takes the path by itself (rows >= 4 cols, cols >= 128, rows cols >= 2^22)."""
+    import torch
+    if force:
+        monkeypatch.setenv("QRK_DENSE_TWO_STAGE", "1")
+    rng = np.random.default_rng(rows + cols)
+    A = rng.uniform(-1.0, 1.0, (rows, cols))
+    qr, At = _factor(A, 1, None)
+    got = At.cpu().numpy()
+    ref, hc = orc.householder_qr(A)
+    np.testing.assert_array_equal(qr.colsPermutation().cpu().numpy(), np.arange(cols))
+    # (the reflectors below the diagonal are the tree's, not Eigen's: evidence that the CAQR path is the one that ran)
+    assert rel_fro(np.tril(got, -1), np.tril(ref, -1)) > 1e-3
+    Rg, Rr = np.triu(got[:cols, :]), np.triu(ref[:cols, :])
+    sg = np.sign(np.diag(Rg)) * np.sign(np.diag(Rr))
+    assert np.all(sg != 0)
+    row_err = np.linalg.norm(Rg * sg[:, None] - Rr, axis=1) / np.linalg.norm(Rr, axis=1)
+    assert row_err.max() <= 1e-11, row_err.max()
+    B = torch.from_numpy(np.asfortranarray(A).T.copy()).cuda().t()
+    qr.applyQ(B, transpose=True)
+    Rfull = np.zeros((rows, cols)); Rfull[:cols, :] = Rg
+    assert np.linalg.norm(B.cpu().numpy() - Rfull) <= 1e-12 * np.linalg.norm(A) * np.sqrt(cols)
+    qr.applyQ(B, transpose=False)
+    assert rel_fro(B.cpu().numpy(), A) <= 1e-12 * np.sqrt(cols)
+    x = rng.uniform(-1, 1, cols)
+    b = torch.from_numpy((A @ x)[None, :].copy()).cuda().t()
+    qr.applyQ(b, transpose=True)
+    z = b[:cols, :].t().contiguous().t()
+    qr.solveR(z)
+    assert rel_fro(z.cpu().numpy()[:, 0], x) <= 1e-9
