@@ -1,0 +1,415 @@
+// bdqr_reg.hip -- the large tiles of a block-diagonal matrix (more than 64 columns, up to 256 x 256, rows >= cols) factorised ON CHIP:
+// A_i P_i = Q_i R_i with explicit Q_i, one workgroup of 512 threads per tile, one workgroup per CU, for gfx950.
+//
+// Same reference seam as bdqr_col.hip (the hot loop of BlockDiagonalSparseQR::factorize, src/QRKit/BlockDiagonalSparseQR.h:432-526,
+// Eigen ColPivHouseholderQR / HouseholderQR behind blockSolver.compute), for the tiles whose working copy bdqr_col.hip keeps in a
+// global workspace.  There every step of the column-pivoted factorisation reads the live part of the tile once (the norm downdate
+// needs row k of the UPDATED matrix, i.e. v^T A over the whole trailing matrix): n^3/3 * 8 bytes = 45 MB for a 256 x 256 tile, 60 MB
+// with the rest, served by the Infinity Cache at 6 TB/s over the chip (profiles/r03_k2_pmc.txt) -- 50x the bytes of the tile.
+// A 256 x 256 tile is 512 KB, exactly the vector register file of a CU; here 384 KB of it live in registers and 128 KB in LDS:
+//
+//   * The tile is aligned to the BOTTOM of a padded 256-row frame (padded row = row + 256 - rows): the rows that die first -- the
+//     top ones -- are the ones in LDS, and a shorter tile simply starts with its top register rows dead.
+//   * Padded rows 0..63 are in LDS (row-major, stride 257: conflict-free by column thread and by row).
+//   * Padded rows 64..255 are in registers: two threads per column (lanes l and l + 32 of a wave, 32 columns per wave), thread
+//     (j, h) holds the six 16-row chunks 64 + 32 m + 16 h .. + 15 (m = 0..5) of column j: 96 doubles.  Register rows need static
+//     indices, so the step is instantiated six times, for m >= V live chunks; a dead chunk costs nothing.
+//   * A step is the level-2 Householder step in the un-normalised form of bdqr_pair.hip: the pivot column is published to LDS by
+//     its two threads, every thread takes the elements of ITS rows into six registers (lane l holds element l % 16 of each chunk)
+//     and the dot product / rank-1 update read them through the DPP row_newbcast operand of v_fmac_f64 -- no LDS operand per FMA.
+//     The two halves of a column meet through v_permlane32_swap.
+//   * Two barriers per step: after the pivot candidates of the eight waves are written, after the pivot column is published.
+//
+// Phase 1 ends with the packed factorisation written once to the workgroup's workspace; R, the permutation and Q (blocked backward
+// accumulation on the matrix cores) are bdqr_col_finish.h, shared with bdqr_col.hip.  Decisions inside their error margin flag the
+// tile for the exact path exactly as in bdqr_col.hip (same tests, qrk_device.h decide::).
+#include "qrk_device.h"
+#include "bdqr_col_finish.h"
+
+#include <float.h>
+#include <cstdlib>
+#include <type_traits>
+
+namespace qrk {
+
+namespace reg {
+
+using namespace decide;
+constexpr int CT = 512, NW = CT / 64;
+constexpr int PR = 256;            // rows of the padded frame
+constexpr int LR = 64;             // padded rows [0, LR) live in LDS
+constexpr int CS = 257;            // stride of an LDS row (doubles)
+constexpr int NCH = 6;             // register chunks of 16 rows per thread
+constexpr int NB = colfin::NB;
+
+struct Cand { double val; int pos; int col; };
+__device__ __forceinline__ bool better(const Cand& a, const Cand& b) { return a.val > b.val || (a.val == b.val && a.pos < b.pos); }
+
+// DPP butterflies (qrk_device.h: dpp_f64 / dpp_i32): quad xor 1, quad xor 2, half-row mirror, row mirror, then the rows through
+// v_permlane16_swap -- no LDS round trips.  Both halves of the wave hold the same candidates (two threads per column): 32 lanes.
+__device__ __forceinline__ double swap16_f64(double v)
+{
+    const unsigned vl = (unsigned)__double2loint(v), vh = (unsigned)__double2hiint(v);
+    const auto rl = __builtin_amdgcn_permlane16_swap(vl, vl, false, false);
+    const auto rh = __builtin_amdgcn_permlane16_swap(vh, vh, false, false);
+    // [0] / [1]: the lane's own value and that of the lane 16 away, in an order that depends on the row; callers are symmetric
+    return __hiloint2double((int)(rh[0] ^ rh[1] ^ vh), (int)(rl[0] ^ rl[1] ^ vl));
+}
+__device__ __forceinline__ int swap16_i32(int v)
+{
+    const auto r = __builtin_amdgcn_permlane16_swap((unsigned)v, (unsigned)v, false, false);
+    return (int)(r[0] ^ r[1] ^ (unsigned)v);
+}
+template <int CTRL>
+__device__ __forceinline__ Cand cand_dpp(const Cand& c) { return Cand{dpp_f64<CTRL>(c.val), dpp_i32<CTRL>(c.pos), dpp_i32<CTRL>(c.col)}; }
+__device__ __forceinline__ Cand half_best(Cand c)
+{
+    Cand o;
+    o = cand_dpp<0xB1>(c); if (better(o, c)) c = o;
+    o = cand_dpp<0x4E>(c); if (better(o, c)) c = o;
+    o = cand_dpp<0x141>(c); if (better(o, c)) c = o;
+    o = cand_dpp<0x140>(c); if (better(o, c)) c = o;
+    o = Cand{swap16_f64(c.val), swap16_i32(c.pos), swap16_i32(c.col)}; if (better(o, c)) c = o;
+    return c;
+}
+
+// sum over the 64 lanes, the same bits in every lane (each stage adds the same two partial sums in either order)
+__device__ __forceinline__ double wave_sum_d(double v)
+{
+    v += dpp_f64<0xB1>(v);
+    v += dpp_f64<0x4E>(v);
+    v += dpp_f64<0x141>(v);
+    v += dpp_f64<0x140>(v);
+    v += swap16_f64(v);
+    double lo, hi;
+    {
+        const unsigned vl = (unsigned)__double2loint(v), vh = (unsigned)__double2hiint(v);
+        const auto rl = __builtin_amdgcn_permlane32_swap(vl, vl, false, false);
+        const auto rh = __builtin_amdgcn_permlane32_swap(vh, vh, false, false);
+        lo = __hiloint2double((int)rh[0], (int)rl[0]);
+        hi = __hiloint2double((int)rh[1], (int)rl[1]);
+    }
+    return lo + hi;
+}
+
+__device__ __forceinline__ double uniform_f64(double v)      // a wave-uniform value into scalar registers
+{
+    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
+
+// lo / hi: the value of lane (l & 31) / (l & 31) + 32, in both lanes
+__device__ __forceinline__ void halves(double v, double& lo, double& hi)
+{
+    const unsigned vl = (unsigned)__double2loint(v), vh = (unsigned)__double2hiint(v);
+    const auto rl = __builtin_amdgcn_permlane32_swap(vl, vl, false, false);
+    const auto rh = __builtin_amdgcn_permlane32_swap(vh, vh, false, false);
+    lo = __hiloint2double((int)rh[0], (int)rl[0]);
+    hi = __hiloint2double((int)rh[1], (int)rl[1]);
+}
+__device__ __forceinline__ double halves_sum(double v) { double lo, hi; halves(v, lo, hi); return lo + hi; }
+
+// d += X[N] * c with X read through DPP row_newbcast (element N of the lane's row of 16), see bdqr_pair.hip
+template <int N>
+__device__ __forceinline__ void fmac_bcast(double& d, double X, double c)
+{
+    asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(d) : "v"(X), "v"(c), "n"(N));
+}
+
+#define QRK_REG_16(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9) M(10) M(11) M(12) M(13) M(14) M(15)
+
+__device__ __forceinline__ double sqrt_pos(double x)      // <= 1 ulp for positive normal x (bdqr_pair.hip)
+{
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = 0.5 * y;
+    const double e = fma(-h, g, 0.5);
+    g = fma(g, e, g);
+    h = fma(h, e, h);
+    const double d = fma(-g, g, x);
+    return fma(d, h, g);
+}
+__device__ __forceinline__ double recip(double x)
+{
+    double y = __builtin_amdgcn_rcp(x);
+    double e = fma(-x, y, 1.0);
+    y = fma(y, e, y);
+    e = fma(-x, y, 1.0);
+    y = fma(y, e, y);
+    return y;
+}
+
+constexpr size_t lds_bytes()
+{
+    return (size_t)(LR * CS + PR /* xv */ + PR /* taus */ + NW /* cval */) * sizeof(double) + (size_t)(2 * NW + 4 + PR) * sizeof(int) + 16;
+}
+static_assert((size_t)(PR * (NB + 1) + 2 * NB * NB) <= (size_t)LR * CS, "the scratch of the Q accumulation reuses the LDS rows");
+
+}  // namespace reg
+
+__global__ void __launch_bounds__(reg::CT) __attribute__((amdgpu_waves_per_eu(2, 2)))
+bdqr_reg_kernel(WaveBatch nb, const double* __restrict__ tiles, double* __restrict__ q_vals, double* __restrict__ r_vals,
+                int32_t* __restrict__ perm, double* __restrict__ hcoeffs, double* __restrict__ workspace, int64_t ws_stride,
+                int32_t* __restrict__ redo_count, int32_t* __restrict__ redo_ids, int32_t* __restrict__ queue)
+{
+    using namespace reg;
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    __shared__ int next_tile;
+    double* ldsA = smem;                                   // [LR][CS] padded rows 0..63
+    double* xv = ldsA + LR * CS;                           // [PR] pivot column of the step, by padded row
+    double* taus = xv + PR;                                // [PR]
+    double* cval = taus + PR;                              // [NW]
+    int* cpos = reinterpret_cast<int*>(cval + NW);         // [NW]
+    int* ccol = cpos + NW;                                 // [NW]
+    int* flags = ccol + NW;                                // [4]
+    int* col_of_pos = flags + 4;                           // [PR]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = lane >> 5, j = wave * 32 + (lane & 31), l16 = lane & 15;
+
+    for (int64_t t = blockIdx.x; t < nb.num_tiles;) {
+        const int gidx = nb.tile_ids ? nb.tile_ids[t] : (int)t;
+        int r, c, cbase;
+        int64_t toff, qoff, roff;
+        if (nb.t_rows) {
+            r = nb.t_rows[gidx]; c = nb.t_cols[gidx];
+            toff = nb.t_off[gidx]; qoff = nb.q_off[gidx]; roff = nb.r_off[gidx]; cbase = nb.c_off[gidx];
+        } else {
+            r = nb.rows; c = nb.cols;
+            toff = t * (int64_t)r * c; qoff = t * (int64_t)r * r; roff = t * (int64_t)(c * (c + 1) / 2);
+            cbase = (int)(t * c);
+        }
+        const int pivoting = nb.pivoting;
+        double* W = workspace + (int64_t)blockIdx.x * ws_stride;
+        const double* src = tiles + toff;                  // column-major: A(i, jj) = src[jj * r + i]
+        const int off = PR - r;                            // padded row of row 0
+        const bool isA = j < c;
+        const int nl = off < LR ? LR - off : 0;            // rows of the tile that live in LDS
+        const int lim = isA ? LR : 0;                      // end of this thread's loops over LDS rows
+
+        // ---- load: register chunks (16 consecutive rows of one column: one cache line), LDS rows
+        double a[NCH][16];
+        {
+            // (unconditional loads from clamped addresses, then a select: a branch per element otherwise)
+            const double* colp = src + (int64_t)(isA ? j : 0) * r;
+#pragma unroll
+            for (int m = 0; m < NCH; ++m)
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    const int i = LR + 32 * m + 16 * h + u - off;
+                    const double v = colp[i > 0 ? i : 0];
+                    a[m][u] = (isA && i >= 0) ? v : 0.0;
+                }
+        }
+        for (int e = tid; e < nl * c; e += CT) {
+            const int jj = e / nl, i = e - jj * nl;
+            ldsA[(off + i) * CS + jj] = src[(int64_t)jj * r + i];
+        }
+        if (tid < 4) flags[tid] = 0;
+        __syncthreads();
+
+        bool live = isA, unclear = false;
+        int pos = j;
+        double nu2 = -1.0, thr = 0.0, a2 = 0.0;
+        {
+            double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+            for (int m = 0; m < NCH; ++m)
+#pragma unroll
+                for (int u = 0; u < 16; u += 2) { s0 = fma(a[m][u], a[m][u], s0); s1 = fma(a[m][u + 1], a[m][u + 1], s1); }
+            for (int i = off + ((off ^ h) & 1); i < lim; i += 2) { const double v = ldsA[i * CS + j]; s0 = fma(v, v, s0); }
+            const double s = halves_sum(s0 + s1);
+            if (isA) { nu2 = s; thr = s * THR_HI; }
+        }
+
+        auto step = [&](auto tag, const int k) {
+            constexpr int V = decltype(tag)::value;        // register chunks [V, NCH) are live
+            const int kp = k + off;                        // padded row of the diagonal
+            const bool in_lds = kp < LR;
+            // Everything per-lane is re-derived from an opaque thread id in every step: otherwise hipcc hoists the (loop-invariant)
+            // LDS addresses out of the step loop and keeps them in scratch across the factorisation.
+            int tid = threadIdx.x;
+            asm volatile("" : "+v"(tid));
+            const int lane = tid & 63, wave = tid >> 6;
+            const int h = lane >> 5, j = wave * 32 + (lane & 31), l16 = lane & 15;
+            // ---- 1. pivot
+            int P = k, ppos = k;
+            if (pivoting) {
+                Cand cd{live ? nu2 : -1.0, pos, j};
+                cd = half_best(cd);
+                if (lane == 0) { cval[wave] = cd.val; cpos[wave] = cd.pos; ccol[wave] = cd.col; }
+            }
+            __syncthreads();      // (also: every read of xv of the step before is done)
+            if (pivoting) {
+                Cand bb{cval[0], cpos[0], ccol[0]};
+#pragma unroll
+                for (int w = 1; w < NW; ++w) { Cand o{cval[w], cpos[w], ccol[w]}; if (better(o, bb)) bb = o; }
+                P = bb.col; ppos = bb.pos;
+                if (k == 0) a2 = bb.val;
+                if (live && j != P && near_best(nu2, thr, bb.val, a2)) unclear = true;
+                if (isA) { if (j == P) pos = k; else if (pos == k) pos = ppos; }
+            }
+            // ---- 2. publish the pivot column: its two threads their register rows, 64 threads the LDS rows
+            if (j == P) {
+                live = false;
+                if (h == 0) col_of_pos[k] = j;
+#pragma unroll
+                for (int m = V; m < NCH; ++m) {
+                    double2* dst = reinterpret_cast<double2*>(&xv[LR + 32 * m + 16 * h]);
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) dst[u] = make_double2(a[m][2 * u], a[m][2 * u + 1]);
+                }
+            }
+            if (in_lds && tid < LR) xv[tid] = ldsA[tid * CS + P];
+            __syncthreads();
+            // ---- 3. |x_tail|^2 (every wave the same sum in the same order), the reflector
+            double tsq;
+            {
+                double p = 0.0;
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) { const int row = 64 * q4 + lane; double x = xv[row]; x = row > kp ? x : 0.0; p = fma(x, x, p); }
+                tsq = uniform_f64(wave_sum_d(p));
+            }
+            const double xk = uniform_f64(xv[kp]);
+            if (k == 0 && !pivoting) a2 = fma(xk, xk, tsq);
+            if (unclear_reflector(xk, tsq, k + 1 < r, pivoting != 0, a2)) unclear = true;
+            const bool degen = !(tsq > DBL_MIN);
+            double beta, s, ng, tau, inv_s;
+            if (degen) { beta = xk; s = 0.0; ng = 0.0; tau = 0.0; inv_s = 0.0; }    // makeHouseholder: H = I
+            else {
+                const double nrm = sqrt_pos(fma(xk, xk, tsq));
+                const double nbv = xk >= 0.0 ? nrm : -nrm;   // -beta (Eigen: if (c0 >= 0) beta = -beta; -0.0 counts as >= 0)
+                beta = uniform_f64(-nbv);
+                s = uniform_f64(nbv + xk);                   // x0 - beta
+                ng = uniform_f64(-recip(nbv * s));           // -1 / (beta w)
+                tau = -(s * s) * ng;                         // w / beta
+                inv_s = uniform_f64(recip(s));               // essential part = x_tail / (x0 - beta)
+            }
+            if (tid == 0) { taus[k] = tau; if (hcoeffs) hcoeffs[cbase + k] = tau; }
+            // the elements of this thread's register rows: x' = (0 .. 0, s, x_tail)
+            double xc[NCH];
+#pragma unroll
+            for (int m = V; m < NCH; ++m) {
+                const int row = LR + 32 * m + 16 * h + l16;
+                const double x = xv[row];
+                xc[m] = row > kp ? x : (row == kp ? s : 0.0);
+            }
+            // ---- 4. row kp of this column before the step
+            double ak;
+            if (in_lds) ak = isA ? ldsA[kp * CS + j] : 0.0;
+            else {
+                // element kp & 15 of chunk V, without a dynamic register index (a chain of selects is folded by hipcc into exactly that,
+                // and the whole array moves to scratch): the dot product with a one-hot vector, on the DPP broadcast
+                double onehot = l16 == (kp & 15) ? 1.0 : 0.0;
+                asm volatile("s_nop 1" : "+v"(onehot));
+                double sel = 0.0;
+#define QRK_REG_SEL(U) fmac_bcast<U>(sel, onehot, a[V][U]);
+                QRK_REG_16(QRK_REG_SEL)
+#undef QRK_REG_SEL
+                double lo, hi;
+                halves(sel, lo, hi);
+                ak = ((kp >> 4) & 1) ? hi : lo;
+            }
+            // ---- 5. d = x'^T a  (the s_nop covers the VALU write -> DPP read hazard of xc, which hipcc does not see through asm)
+            double d0 = 0.0, d1 = 0.0;
+#pragma unroll
+            for (int m = V; m < NCH; ++m) asm volatile("s_nop 1" : "+v"(xc[m]));
+#pragma unroll
+            for (int m = V; m < NCH; ++m) {
+#define QRK_REG_DOT(U) fmac_bcast<U>((U & 1) ? d1 : d0, xc[m], a[m][U]);
+                QRK_REG_16(QRK_REG_DOT)
+#undef QRK_REG_DOT
+            }
+            if (in_lds) {
+                for (int i = kp + 1 + ((kp + 1 + h) & 1); i < lim; i += 2) d0 = fma(xv[i], ldsA[i * CS + j], d0);
+            }
+            double d = halves_sum(d0 + d1);
+            if (in_lds) d = fma(s, ak, d);
+            const double ngam = live ? d * ng : 0.0;         // -gamma of this column
+            const double an = fma(s, ngam, ak);              // row kp of the updated column
+            // ---- 6. update a += (-gamma) x'
+#pragma unroll
+            for (int m = V; m < NCH; ++m) {
+#define QRK_REG_UPD(U) fmac_bcast<U>(a[m][U], xc[m], ngam);
+                QRK_REG_16(QRK_REG_UPD)
+#undef QRK_REG_UPD
+            }
+            if (in_lds && live) {
+                if (((kp ^ h) & 1) == 0) ldsA[kp * CS + j] = an;
+                for (int i = kp + 1 + ((kp + 1 + h) & 1); i < lim; i += 2) ldsA[i * CS + j] = fma(xv[i], ngam, ldsA[i * CS + j]);
+            }
+            // row k of R and reflector k leave for the workspace now (fire and forget): nothing of a chosen column, and no row above
+            // the diagonal, is needed on chip again -- dead register rows are simply garbage
+            if (h == 0 && (live || j == P)) W[(int64_t)k * c + j] = j == P ? beta : an;
+            { const int row = kp + 1 + tid; if (row < PR) W[(int64_t)(row - off) * c + P] = xv[row] * inv_s; }
+            // ---- 7. LAWN-176 norm downdate (squared form); Eigen's recompute uses the up-to-date column
+            if (pivoting) {
+                bool need = false;
+                if (live) {
+                    const double nn = fma(-an, an, nu2);
+                    nu2 = nn;
+                    need = nn <= thr;
+                    if (need && in_recompute_band(nn, thr, a2)) unclear = true;
+                }
+                if (__builtin_amdgcn_ballot_w64(need) != 0ull) {
+                    double s0 = 0.0;
+                    if (need) {
+#pragma unroll
+                        for (int m = V; m < NCH; ++m)
+#pragma unroll
+                            for (int u = 0; u < 16; ++u) {
+                                const int row = LR + 32 * m + 16 * h + u;
+                                s0 = row > kp ? fma(a[m][u], a[m][u], s0) : s0;
+                            }
+                        if (in_lds)
+                            for (int i = kp + 1 + ((kp + 1 + h) & 1); i < lim; i += 2) { const double v = ldsA[i * CS + j]; s0 = fma(v, v, s0); }
+                    }
+                    const double s2 = halves_sum(s0);
+                    if (need) { nu2 = s2; thr = s2 * THR_HI; }
+                }
+            }
+        };
+
+        // One loop per number of live register chunks (chunk m dies when the diagonal passes padded row LR + 32 (m + 1)): after
+        // its loop a chunk is dead for the register allocator too.
+        {
+            int k = 0;
+#define QRK_REG_LOOP(VV) for (; k < c && k + off < LR + 32 * (VV + 1); ++k) step(std::integral_constant<int, VV>(), k);
+            QRK_REG_LOOP(0) QRK_REG_LOOP(1) QRK_REG_LOOP(2) QRK_REG_LOOP(3) QRK_REG_LOOP(4) QRK_REG_LOOP(5)
+#undef QRK_REG_LOOP
+        }
+
+        // ---- a decision inside its error margin: the tile is redone by the exact path
+        if (unclear) flags[2] = 1;
+        __syncthreads();
+        if (tid == 0 && flags[2] != 0 && redo_count) redo_ids[atomicAdd(redo_count, 1)] = gidx;
+        __syncthreads();
+        // ---- R, the permutation, Q (scratch in the LDS rows, which are dead now)
+        double* vs = ldsA;
+        double* gm = vs + PR * (NB + 1);
+        double* tm = gm + NB * NB;
+        colfin::finish_tile<CT>(W, c, r, c, cbase, col_of_pos, taus, vs, gm, tm, q_vals + qoff, r_vals + roff, perm);
+        __syncthreads();
+        if (threadIdx.x == 0) next_tile = (int)gridDim.x + atomicAdd(queue, 1);
+        __syncthreads();
+        t = next_tile;
+    }
+}
+
+size_t bdqr_reg_smem_bytes() { return reg::lds_bytes(); }
+
+// Tiles with more than 64 columns, rows >= cols, rows <= 256.  workspace: num_wg * ws_stride doubles (ws_stride >= rows * cols of
+// the largest tile); queue: one int32 (zeroed here) through which the workgroups take their next tile.
+hipError_t launch_bdqr_reg(const WaveBatch& nb, const double* tiles, double* q_vals, double* r_vals, int32_t* perm, double* hcoeffs,
+                           double* workspace, int64_t ws_stride, int num_wg, int max_rows, int max_cols, int32_t* redo_count,
+                           int32_t* redo_ids, int32_t* queue, hipStream_t stream)
+{
+    if (nb.num_tiles <= 0) return hipSuccess;
+    if (max_rows > reg::PR || max_cols > max_rows || ws_stride <= 0) return hipErrorInvalidValue;
+    if (hipError_t e = hipMemsetAsync(queue, 0, sizeof(int32_t), stream)) return e;
+    const int64_t want = nb.num_tiles < (int64_t)num_wg ? nb.num_tiles : (int64_t)num_wg;
+    const size_t smem = reg::lds_bytes();
+    if (hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(bdqr_reg_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)) return e;
+    hipLaunchKernelGGL(bdqr_reg_kernel, dim3((unsigned)want), dim3(reg::CT), smem, stream, nb, tiles, q_vals, r_vals, perm, hcoeffs,
+                       workspace, ws_stride, redo_count, redo_ids, queue);
+    return hipGetLastError();
+}
+
+}  // namespace qrk

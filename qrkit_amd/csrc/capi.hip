@@ -71,6 +71,7 @@ struct qrk_bd_plan_s {
         int64_t ws_off = 0;              // this class's part of d_col_workspace (the classes run concurrently)
         int64_t max_rc_fitting = 0;      // largest rows * cols that fits the LDS-resident form
         int max_rows = 0, max_cols = 0, w_lds = 0, num_wg = 0;
+        bool onchip = false;             // every tile of the class has more than 64 columns: bdqr_reg.hip (registers + LDS) instead
     } col_cls[3];
     int32_t* d_col_ids = nullptr;
     int64_t n_col = 0;
@@ -83,6 +84,18 @@ struct qrk_bd_plan_s {
     int64_t exact_ws_stride = 0;
     int exact_num_wg = 0, exact_maxr = 0, exact_maxc = 0;
 };
+
+// One size class of the mid-size tiles: on chip (bdqr_reg.hip) when all of its tiles are wider than 64 columns, else bdqr_col.hip
+static hipError_t launch_col_class(const qrk_bd_plan_s::ColClass& k, const qrk::WaveBatch& cb, const double* tiles, double* q, double* r,
+                                   int32_t* perm, double* hc, double* workspace, int32_t* redo_cnt, int32_t* redo_ids, int32_t* queue,
+                                   hipStream_t stream)
+{
+    if (k.onchip)
+        return qrk::launch_bdqr_reg(cb, tiles, q, r, perm, hc, workspace, k.ws_stride, k.num_wg, k.max_rows, k.max_cols, redo_cnt, redo_ids,
+                                    queue, stream);
+    return qrk::launch_bdqr_col(cb, tiles, q, r, perm, hc, workspace, k.ws_stride, k.num_wg, k.max_rows, k.max_cols, k.w_lds, redo_cnt,
+                                redo_ids, queue, stream);
+}
 
 struct qrk_bb_plan_s {
     qrk_handle h = nullptr;
@@ -292,8 +305,7 @@ qrk_status enqueue_factorize(qrk_bd_plan_s* p, const double* tiles, double* q, d
                               reinterpret_cast<uintptr_t>(r)) & 15u) == 0;
         if (p->max_dim > 32 && p->max_dim <= QRK_COL_MAX_DIM) {
             const auto& k = p->col_cls[0];
-            QRK_HIP(h, qrk::launch_bdqr_col(nb, tiles, q, r, perm, hc, p->d_col_workspace, k.ws_stride, k.num_wg, k.max_rows,
-                                            k.max_cols, k.w_lds, redo_cnt, redo_ids, p->d_redo + 2 + p->B, h->stream));
+            QRK_HIP(h, launch_col_class(k, nb, tiles, q, r, perm, hc, p->d_col_workspace, redo_cnt, redo_ids, p->d_redo + 2 + p->B, h->stream));
         } else if (p->max_dim > 32)
             qrk::launch_bdqr_wg(nb, tiles, q, r, perm, hc, p->d_workspace, p->ws_stride, p->num_wg, p->max_dim, redo_cnt, redo_ids, h->stream);
         else if (p->max_dim <= 16 && p->r >= p->c && p->c <= 2 && h->use_small_kernel && h->use_thin_kernel)   // a tile per lane (bdqr_thin.hip)
@@ -326,8 +338,7 @@ qrk_status enqueue_factorize(qrk_bd_plan_s* p, const double* tiles, double* q, d
                 if (k.n <= 0) continue;
                 qrk::WaveBatch cb = nb;
                 cb.num_tiles = k.n; cb.tile_ids = p->d_col_ids + k.off;
-                QRK_HIP(h, qrk::launch_bdqr_col(cb, tiles, q, r, perm, hc, p->d_col_workspace + k.ws_off, k.ws_stride, k.num_wg,
-                                                k.max_rows, k.max_cols, k.w_lds, redo_cnt, redo_ids, p->d_redo + 2 + p->B + z, h->stream));
+                QRK_HIP(h, launch_col_class(k, cb, tiles, q, r, perm, hc, p->d_col_workspace + k.ws_off, redo_cnt, redo_ids, p->d_redo + 2 + p->B + z, h->stream));
             }
         } else if (p->n_col > 0) {
             if (!h->ev_fork) {
@@ -349,8 +360,7 @@ qrk_status enqueue_factorize(qrk_bd_plan_s* p, const double* tiles, double* q, d
                 qrk::WaveBatch cb = nb;
                 cb.num_tiles = k.n; cb.tile_ids = p->d_col_ids + k.off;
                 QRK_HIP(h, hipStreamWaitEvent(h->side[z], h->ev_fork, 0));
-                QRK_HIP(h, qrk::launch_bdqr_col(cb, tiles, q, r, perm, hc, p->d_col_workspace + k.ws_off, k.ws_stride, k.num_wg,
-                                                k.max_rows, k.max_cols, k.w_lds, redo_cnt, redo_ids, p->d_redo + 2 + p->B + z, h->side[z]));
+                QRK_HIP(h, launch_col_class(k, cb, tiles, q, r, perm, hc, p->d_col_workspace + k.ws_off, redo_cnt, redo_ids, p->d_redo + 2 + p->B + z, h->side[z]));
                 QRK_HIP(h, hipEventRecord(h->ev_join[z], h->side[z]));
                 QRK_HIP(h, hipStreamWaitEvent(h->stream, h->ev_join[z], 0));
             }
@@ -617,9 +627,14 @@ qrk_status qrk_bd_plan_create(qrk_handle h, const qrk_bd_layout* L, qrk_q_format
             if (k.n <= 0 || k.ws_stride <= 0) { k.n = p->uniform ? k.n : 0; continue; }
             k.w_lds = qrk::bdqr_col_w_lds(k.ws_stride, k.max_rc_fitting);
             int64_t wgs = (int64_t)h->num_cus * qrk::bdqr_col_wgs_per_cu(k.max_cols, k.w_lds, k.max_rows);
+            // tiles wider than 64 columns: factorised on chip, one workgroup of 512 threads per CU (QRK_COL_ONCHIP=0: bdqr_col.hip's
+            // global-workspace form, for comparison)
+            static const bool use_onchip = !(std::getenv("QRK_COL_ONCHIP") && std::atoi(std::getenv("QRK_COL_ONCHIP")) == 0);
+            k.onchip = use_onchip && (p->uniform ? p->c > 64 : z >= 1);
+            if (k.onchip) { wgs = h->num_cus; k.w_lds = 0; }
             if (const char* e = std::getenv("QRK_COL_WGS")) { const long v = std::atol(e); if (v > 0) wgs = v; }
             k.num_wg = (int)(k.n < wgs ? k.n : wgs);
-            if (k.ws_stride > k.w_lds) {       // some tile of the class works in global memory
+            if (k.ws_stride > k.w_lds) {       // some tile of the class works in (or, on chip, is dumped to) global memory
                 k.ws_off = (int64_t)ws_doubles;
                 ws_doubles += (size_t)k.num_wg * (size_t)k.ws_stride;
             }
