@@ -140,5 +140,192 @@ __device__ __forceinline__ void finish_tile(const double* __restrict__ W, const 
         }
     }
 }
+
+// The same for the on-chip kernel (bdqr_reg.hip: rows <= 256, 512 threads, no other register load at this point).  The round trips to
+// memory are what the accumulation above spends its time on (eight Q loads in flight, twice per strip and panel: 0.85 ms of a
+// 256 x 256 tile), and guards per element are what hipcc turns into one branch (and one wait) per load, so here
+//   * Q is accumulated in a PADDED 256 x 256 frame of the workgroup's workspace (row stride 256: every address is a scalar base plus
+//     one lane offset, no guard anywhere; rows and columns past the tile only ever hold identity) and copied out once at the end;
+//   * a strip of 16 columns of Q(kp:, kp:) stays in REGISTERS from its first use to its store (<= 64 doubles per lane, in the
+//     accumulator layout of v_mfma_f64_16x16x4_f64, which is also the B-operand layout of w = V^T q): one batch of loads per strip
+//     and panel, no second read;
+//   * the frame is never initialised: the part of Q(kp:, kp:) that no later panel has written yet is the identity, generated in the
+//     registers (first panel: everything; then the leading 16 rows / columns) -- the last panel (kp = 0) writes every entry;
+//   * V^T V comes from the matrix cores too (A and B operand are the same register: V(4 k' + lane / 16, lane % 16)), the k-steps
+//     dealt over the waves and summed through LDS; T with its row in registers.
+// Inputs, as bdqr_reg.hip leaves them in the workspace: Rw[k * 256 + j] = row k of R in ORIGINAL column order; Vb[k * 256 + i] =
+// essential part of reflector k at row i of the tile (i > k; anything elsewhere).  Qp: the frame.
+// vs [256 * (NB + 1)], gm [NB * NB], tm [NB * NB], gp [CT / 64][NB * NB]: LDS scratch.
+template <int CT>
+__device__ __forceinline__ void finish_tile_strips(const double* __restrict__ Rw, const double* __restrict__ Vb, double* __restrict__ Qp,
+                                                   const int r, const int c, const int cbase, const int* col_of_pos, const double* taus,
+                                                   double* vs, double* gm, double* tm, double* gp, double* __restrict__ Q,
+                                                   double* __restrict__ rv, int32_t* __restrict__ perm)
+{
+    typedef double d4 __attribute__((ext_vector_type(4)));
+    constexpr int NW = CT / 64, VS = NB + 1, MAXT = 16, LD = 256;
+    const int tid0 = threadIdx.x, wave = tid0 >> 6;
+    // (per-lane values are re-derived from an opaque thread id inside every loop body: hipcc otherwise hoists the loop-invariant
+    //  address arithmetic of all unrolled accesses out of the loops -- and of the tile loop around this call -- and spills it)
+#define QRK_FIN_LANE() int tid = threadIdx.x; asm volatile("" : "+v"(tid)); const int lane = tid & 63, kq = lane >> 4, l15 = lane & 15; (void)lane; (void)kq; (void)l15
+#ifdef QRK_REG_PROF
+    unsigned long long ft[6] = {0, 0, 0, 0, 0, 0}, ft0 = __builtin_amdgcn_s_memtime();
+#define FIN_TICK(z) do { const unsigned long long t1 = __builtin_amdgcn_s_memtime(); ft[z] += t1 - ft0; ft0 = t1; } while (0)
+#else
+#define FIN_TICK(z) do { } while (0)
+#endif
+    for (int p = tid0; p < c; p += CT) perm[cbase + p] = cbase + col_of_pos[p];   // m_outputPerm_c.indices() (:519-521)
+    // R: column p of the packed triangle is column col_of_pos[p] of Rw, rows 0..p.  Read by rows (coalesced), sixteen rows at a time
+    // through LDS (vs: [256][17]), written by columns in runs of sixteen (a column of Rw straight from memory is one cache line --
+    // and, at a stride of 2 KB, one L2 channel -- per element: 0.1 ms of a 256 x 256 tile)
+    for (int ib = 0; 16 * ib < c; ++ib) {
+        QRK_FIN_LANE();
+        double rowv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int e = tid + CT * u, ii = e >> 8, jj = e & 255; rowv[u] = Rw[(16 * ib + ii) * LD + jj]; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int e = tid + CT * u, ii = e >> 8, jj = e & 255; vs[jj * VS + ii] = rowv[u]; }
+        __syncthreads();
+        {
+            const int pp = tid >> 4, ii = tid & 15, i = 16 * ib + ii;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int p = 16 * ib + pp + 32 * u;
+                if (p < c && i <= p) rv[(int64_t)p * (p + 1) / 2 + i] = vs[col_of_pos[p] * VS + ii];
+            }
+        }
+        __syncthreads();
+    }
+    FIN_TICK(0);
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);      // (uniform for the compiler too: scalar bases below)
+    bool first = true;
+    for (int kp = ((c - 1) / NB) * NB; kp >= 0; kp -= NB) {
+        const int kb = (c - kp) < NB ? (c - kp) : NB;
+        const int m = r - kp;
+        const int mt = (m + 15) >> 4;          // row tiles of a strip; V is zero-filled up to 16 mt rows
+        QRK_FIN_LANE();
+        {
+            // thread -> reflector l = tid / 32, rows i = tid % 32 + 32 u: eight independent loads (a loop with one load per trip is a
+            // chain of memory latencies)
+            const int l = tid >> 5, i0 = tid & 31;
+            double vv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = i0 + 32 * u;
+                vv[u] = (l < kb && i > l && i < m) ? Vb[(kp + l) * LD + kp + i] : (i == l && l < kb ? 1.0 : 0.0);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int i = i0 + 32 * u; if (i < 16 * mt) vs[i * VS + l] = vv[u]; }
+        }
+        __syncthreads();
+        FIN_TICK(1);
+        {
+            d4 g = d4{0.0, 0.0, 0.0, 0.0};
+            for (int k = wave_u; k < 4 * mt; k += NW) {
+                const double v = vs[(4 * k + kq) * VS + l15];
+                g = __builtin_amdgcn_mfma_f64_16x16x4f64(v, v, g, 0, 0, 0);
+            }
+#pragma unroll
+            for (int z = 0; z < 4; ++z) gp[wave * NB * NB + (kq + 4 * z) * NB + l15] = g[z];   // G(row = kq + 4 z, col = l15)
+        }
+        __syncthreads();
+        if (tid < NB * NB) {
+            double g = 0.0;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) g += gp[w * NB * NB + tid];
+            gm[tid] = g;
+        }
+        __syncthreads();
+        FIN_TICK(2);
+        // T (forward, columnwise -- LAPACK larft): T(l,l) = tau_l, T(0:l,l) = -tau_l T(0:l,0:l) (V(:,0:l)^T v_l).  Lane (a, b) of the
+        // first four waves holds T(a, b) in a register; column l is sixteen products T(a, b) G(b, l) summed over b inside the row of
+        // 16 lanes by DPP: no LDS inside the recurrence (one thread per row, reading T and G from LDS, spent 12 000 cycles per panel)
+        if (tid < NB * NB) {
+            const int ta = tid >> 4, tb = tid & 15;
+            double g[NB];
+#pragma unroll
+            for (int l = 0; l < NB; ++l) g[l] = gm[tb * NB + l];
+            double tval = 0.0;
+#pragma unroll
+            for (int l = 0; l < NB; ++l) {
+                const double tau = l < kb ? taus[kp + l] : 0.0;
+                double sum = tb < l ? tval * g[l] : 0.0;
+                sum += dpp_f64<0xB1>(sum);
+                sum += dpp_f64<0x4E>(sum);
+                sum += dpp_f64<0x141>(sum);
+                sum += dpp_f64<0x140>(sum);
+                if (tb == l) tval = ta == l ? tau : (ta < l ? -tau * sum : 0.0);
+            }
+            tm[ta * NB + tb] = tval;
+        }
+        __syncthreads();
+        FIN_TICK(3);
+        for (int sidx = wave_u; sidx < mt; sidx += NW) {
+            QRK_FIN_LANE();
+            double* qs = Qp + (kp * LD + kp + 16 * sidx);          // uniform: Q(kp + i, kp + 16 sidx + l15) = qs[i * LD + l15]
+            const int loff = kq * LD + l15;
+            d4 dv[MAXT];
+            // rows kp..kp+15 and columns kp..kp+15 (everything, for the first panel) have not been written yet: identity
+            if (!first && sidx >= 1) {
+#pragma unroll
+                for (int z = 0; z < 4; ++z) dv[0][z] = 0.0;
+#pragma unroll
+                for (int rt = 1; rt < MAXT; ++rt)
+                    if (rt < mt) {
+#pragma unroll
+                        for (int z = 0; z < 4; ++z) dv[rt][z] = (qs + (16 * rt + 4 * z) * LD)[loff];
+                    }
+            } else {
+#pragma unroll
+                for (int rt = 0; rt < MAXT; ++rt)
+#pragma unroll
+                    for (int z = 0; z < 4; ++z) dv[rt][z] = (16 * rt + kq + 4 * z == 16 * sidx + l15) ? 1.0 : 0.0;
+            }
+            d4 acc = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int rt = 0; rt < MAXT; ++rt)
+                if (rt < mt) {
+#pragma unroll
+                    for (int z = 0; z < 4; ++z)
+                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(vs[(16 * rt + 4 * z + kq) * VS + l15], dv[rt][z], acc, 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);     // (left alone, the scheduler hoists all 64 operand reads ahead of the MFMAs and spills)
+                }
+            d4 uu = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+                uu = __builtin_amdgcn_mfma_f64_16x16x4f64(tm[l15 * NB + 4 * ks + kq], acc[ks], uu, 0, 0, 0);
+            uu = -uu;
+#pragma unroll
+            for (int rt = 0; rt < MAXT; ++rt)
+                if (rt < mt) {
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks)
+                        dv[rt] = __builtin_amdgcn_mfma_f64_16x16x4f64(vs[(16 * rt + l15) * VS + 4 * ks + kq], uu[ks], dv[rt], 0, 0, 0);
+                    if (kp > 0) {
+#pragma unroll
+                        for (int z = 0; z < 4; ++z) (qs + (16 * rt + 4 * z) * LD)[loff] = dv[rt][z];
+                    } else {
+                        // the last panel writes every entry of Q: straight to m_Q's values (row-major Q_i; guarded stores cost no wait)
+#pragma unroll
+                        for (int z = 0; z < 4; ++z) {
+                            const int row = 16 * rt + 4 * z + kq, col = 16 * sidx + l15;
+                            if (row < r && col < r) Q[(int64_t)row * r + col] = dv[rt][z];
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+        }
+        first = false;
+        __syncthreads();
+        FIN_TICK(4);
+    }
+    FIN_TICK(5);
+#ifdef QRK_REG_PROF
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        printf("   finish: R + perm %llu  V panels %llu  V^T V %llu  T %llu  apply %llu  copy %llu\n", ft[0], ft[1], ft[2], ft[3], ft[4], ft[5]);
+#endif
+#undef FIN_TICK
+#undef QRK_FIN_LANE
+}
 }  // namespace colfin
 }  // namespace qrk

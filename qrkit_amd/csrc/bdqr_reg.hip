@@ -115,6 +115,11 @@ __device__ __forceinline__ void fmac_bcast(double& d, double X, double c)
     asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(d) : "v"(X), "v"(c), "n"(N));
 }
 
+// Barrier of the step loop: orders LDS only.  __syncthreads() also waits for the global stores of the step before (row k of R and
+// the reflector, fire-and-forget: ~1.5 us of write latency per step); nothing on chip depends on them until the Q accumulation,
+// which is behind a full __syncthreads().
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 #define QRK_REG_16(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9) M(10) M(11) M(12) M(13) M(14) M(15)
 
 __device__ __forceinline__ double sqrt_pos(double x)      // <= 1 ulp for positive normal x (bdqr_pair.hip)
@@ -141,7 +146,7 @@ constexpr size_t lds_bytes()
 {
     return (size_t)(LR * CS + PR /* xv */ + PR /* taus */ + NW /* cval */) * sizeof(double) + (size_t)(2 * NW + 4 + PR) * sizeof(int) + 16;
 }
-static_assert((size_t)(PR * (NB + 1) + 2 * NB * NB) <= (size_t)LR * CS, "the scratch of the Q accumulation reuses the LDS rows");
+static_assert((size_t)(PR * (NB + 1) + (2 + NW) * NB * NB) <= (size_t)LR * CS, "the scratch of the Q accumulation reuses the LDS rows");
 
 }  // namespace reg
 
@@ -177,13 +182,22 @@ bdqr_reg_kernel(WaveBatch nb, const double* __restrict__ tiles, double* __restri
             cbase = (int)(t * c);
         }
         const int pivoting = nb.pivoting;
-        double* W = workspace + (int64_t)blockIdx.x * ws_stride;
+        // the workgroup's workspace: rows of R by original column, the reflectors by step, the padded frame of Q (bdqr_col_finish.h)
+        double* Rw = workspace + (int64_t)blockIdx.x * ws_stride;
+        double* Vb = Rw + PR * PR;
+        double* Qp = Vb + PR * PR;
         const double* src = tiles + toff;                  // column-major: A(i, jj) = src[jj * r + i]
         const int off = PR - r;                            // padded row of row 0
         const bool isA = j < c;
         const int nl = off < LR ? LR - off : 0;            // rows of the tile that live in LDS
         const int lim = isA ? LR : 0;                      // end of this thread's loops over LDS rows
 
+#ifdef QRK_REG_PROF
+        unsigned long long pt[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, pt0 = __builtin_amdgcn_s_memtime();
+#define REG_TICK(z) do { const unsigned long long t1 = __builtin_amdgcn_s_memtime(); pt[z] += t1 - pt0; pt0 = t1; } while (0)
+#else
+#define REG_TICK(z) do { } while (0)
+#endif
         // ---- load: register chunks (16 consecutive rows of one column: one cache line), LDS rows
         double a[NCH][16];
         {
@@ -219,6 +233,7 @@ bdqr_reg_kernel(WaveBatch nb, const double* __restrict__ tiles, double* __restri
             if (isA) { nu2 = s; thr = s * THR_HI; }
         }
 
+        REG_TICK(0);
         auto step = [&](auto tag, const int k) {
             constexpr int V = decltype(tag)::value;        // register chunks [V, NCH) are live
             const int kp = k + off;                        // padded row of the diagonal
@@ -236,7 +251,9 @@ bdqr_reg_kernel(WaveBatch nb, const double* __restrict__ tiles, double* __restri
                 cd = half_best(cd);
                 if (lane == 0) { cval[wave] = cd.val; cpos[wave] = cd.pos; ccol[wave] = cd.col; }
             }
-            __syncthreads();      // (also: every read of xv of the step before is done)
+            REG_TICK(1);
+            lds_barrier();      // (also: every read of xv of the step before is done)
+            REG_TICK(11);
             if (pivoting) {
                 Cand bb{cval[0], cpos[0], ccol[0]};
 #pragma unroll
@@ -246,6 +263,7 @@ bdqr_reg_kernel(WaveBatch nb, const double* __restrict__ tiles, double* __restri
                 if (live && j != P && near_best(nu2, thr, bb.val, a2)) unclear = true;
                 if (isA) { if (j == P) pos = k; else if (pos == k) pos = ppos; }
             }
+            REG_TICK(3);
             // ---- 2. publish the pivot column: its two threads their register rows, 64 threads the LDS rows
             if (j == P) {
                 live = false;
@@ -258,7 +276,8 @@ bdqr_reg_kernel(WaveBatch nb, const double* __restrict__ tiles, double* __restri
                 }
             }
             if (in_lds && tid < LR) xv[tid] = ldsA[tid * CS + P];
-            __syncthreads();
+            lds_barrier();
+            REG_TICK(4);
             // ---- 3. |x_tail|^2 (every wave the same sum in the same order), the reflector
             double tsq;
             {
@@ -283,6 +302,7 @@ bdqr_reg_kernel(WaveBatch nb, const double* __restrict__ tiles, double* __restri
                 inv_s = uniform_f64(recip(s));               // essential part = x_tail / (x0 - beta)
             }
             if (tid == 0) { taus[k] = tau; if (hcoeffs) hcoeffs[cbase + k] = tau; }
+            REG_TICK(5);
             // the elements of this thread's register rows: x' = (0 .. 0, s, x_tail)
             double xc[NCH];
 #pragma unroll
@@ -307,6 +327,7 @@ bdqr_reg_kernel(WaveBatch nb, const double* __restrict__ tiles, double* __restri
                 halves(sel, lo, hi);
                 ak = ((kp >> 4) & 1) ? hi : lo;
             }
+            REG_TICK(6);
             // ---- 5. d = x'^T a  (the s_nop covers the VALU write -> DPP read hazard of xc, which hipcc does not see through asm)
             double d0 = 0.0, d1 = 0.0;
 #pragma unroll
@@ -324,6 +345,7 @@ bdqr_reg_kernel(WaveBatch nb, const double* __restrict__ tiles, double* __restri
             if (in_lds) d = fma(s, ak, d);
             const double ngam = live ? d * ng : 0.0;         // -gamma of this column
             const double an = fma(s, ngam, ak);              // row kp of the updated column
+            REG_TICK(7);
             // ---- 6. update a += (-gamma) x'
 #pragma unroll
             for (int m = V; m < NCH; ++m) {
@@ -335,10 +357,12 @@ bdqr_reg_kernel(WaveBatch nb, const double* __restrict__ tiles, double* __restri
                 if (((kp ^ h) & 1) == 0) ldsA[kp * CS + j] = an;
                 for (int i = kp + 1 + ((kp + 1 + h) & 1); i < lim; i += 2) ldsA[i * CS + j] = fma(xv[i], ngam, ldsA[i * CS + j]);
             }
+            REG_TICK(8);
             // row k of R and reflector k leave for the workspace now (fire and forget): nothing of a chosen column, and no row above
             // the diagonal, is needed on chip again -- dead register rows are simply garbage
-            if (h == 0 && (live || j == P)) W[(int64_t)k * c + j] = j == P ? beta : an;
-            { const int row = kp + 1 + tid; if (row < PR) W[(int64_t)(row - off) * c + P] = xv[row] * inv_s; }
+            if (h == 0 && (live || j == P)) Rw[k * PR + j] = j == P ? beta : an;
+            { const int row = kp + 1 + tid; if (row < PR) Vb[k * PR + row - off] = xv[row] * inv_s; }
+            REG_TICK(9);
             // ---- 7. LAWN-176 norm downdate (squared form); Eigen's recompute uses the up-to-date column
             if (pivoting) {
                 bool need = false;
@@ -365,6 +389,7 @@ bdqr_reg_kernel(WaveBatch nb, const double* __restrict__ tiles, double* __restri
                     if (need) { nu2 = s2; thr = s2 * THR_HI; }
                 }
             }
+            REG_TICK(10);
         };
 
         // One loop per number of live register chunks (chunk m dies when the diagonal passes padded row LR + 32 (m + 1)): after
@@ -376,6 +401,7 @@ bdqr_reg_kernel(WaveBatch nb, const double* __restrict__ tiles, double* __restri
 #undef QRK_REG_LOOP
         }
 
+        REG_TICK(1);
         // ---- a decision inside its error margin: the tile is redone by the exact path
         if (unclear) flags[2] = 1;
         __syncthreads();
@@ -385,8 +411,17 @@ bdqr_reg_kernel(WaveBatch nb, const double* __restrict__ tiles, double* __restri
         double* vs = ldsA;
         double* gm = vs + PR * (NB + 1);
         double* tm = gm + NB * NB;
-        colfin::finish_tile<CT>(W, c, r, c, cbase, col_of_pos, taus, vs, gm, tm, q_vals + qoff, r_vals + roff, perm);
+        double* gp = tm + NB * NB;
+        colfin::finish_tile_strips<CT>(Rw, Vb, Qp, r, c, cbase, col_of_pos, taus, vs, gm, tm, gp, q_vals + qoff, r_vals + roff, perm);
         __syncthreads();
+        REG_TICK(2);
+#ifdef QRK_REG_PROF
+        if (blockIdx.x == 0 && threadIdx.x == 0)
+            printf("reg prof %d x %d (s_memtime ticks): load + norms %llu  R / perm / Q %llu  steps: search %llu  publish %llu  reflector %llu  "
+                   "x chunks + a_k %llu  dot %llu  update %llu  stores %llu  downdate %llu\n", r, c, pt[0], pt[2], pt[3], pt[4], pt[5], pt[6],
+                   pt[7], pt[8], pt[9], pt[10]);
+        if (blockIdx.x == 0 && threadIdx.x == 0) printf("   search: candidates of the wave %llu  barrier %llu  best of 8 + margins %llu\n", pt[1], pt[11], pt[3]);
+#endif
         if (threadIdx.x == 0) next_tile = (int)gridDim.x + atomicAdd(queue, 1);
         __syncthreads();
         t = next_tile;
@@ -394,15 +429,16 @@ bdqr_reg_kernel(WaveBatch nb, const double* __restrict__ tiles, double* __restri
 }
 
 size_t bdqr_reg_smem_bytes() { return reg::lds_bytes(); }
+int64_t bdqr_reg_ws_doubles() { return 3 * (int64_t)reg::PR * reg::PR; }
 
-// Tiles with more than 64 columns, rows >= cols, rows <= 256.  workspace: num_wg * ws_stride doubles (ws_stride >= rows * cols of
-// the largest tile); queue: one int32 (zeroed here) through which the workgroups take their next tile.
+// Tiles with more than 64 columns, rows >= cols, rows <= 256.  workspace: num_wg * ws_stride doubles, ws_stride >=
+// bdqr_reg_ws_doubles() (R rows, reflectors, frame of Q: 3 x 256 x 256); queue: one int32 (zeroed here) through which the workgroups take their next tile.
 hipError_t launch_bdqr_reg(const WaveBatch& nb, const double* tiles, double* q_vals, double* r_vals, int32_t* perm, double* hcoeffs,
                            double* workspace, int64_t ws_stride, int num_wg, int max_rows, int max_cols, int32_t* redo_count,
                            int32_t* redo_ids, int32_t* queue, hipStream_t stream)
 {
     if (nb.num_tiles <= 0) return hipSuccess;
-    if (max_rows > reg::PR || max_cols > max_rows || ws_stride <= 0) return hipErrorInvalidValue;
+    if (max_rows > reg::PR || max_cols > max_rows || ws_stride < bdqr_reg_ws_doubles()) return hipErrorInvalidValue;
     if (hipError_t e = hipMemsetAsync(queue, 0, sizeof(int32_t), stream)) return e;
     const int64_t want = nb.num_tiles < (int64_t)num_wg ? nb.num_tiles : (int64_t)num_wg;
     const size_t smem = reg::lds_bytes();

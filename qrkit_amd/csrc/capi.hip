@@ -631,7 +631,7 @@ qrk_status qrk_bd_plan_create(qrk_handle h, const qrk_bd_layout* L, qrk_q_format
             // global-workspace form, for comparison)
             static const bool use_onchip = !(std::getenv("QRK_COL_ONCHIP") && std::atoi(std::getenv("QRK_COL_ONCHIP")) == 0);
             k.onchip = use_onchip && (p->uniform ? p->c > 64 : z >= 1);
-            if (k.onchip) { wgs = h->num_cus; k.w_lds = 0; }
+            if (k.onchip) { wgs = h->num_cus; k.w_lds = 0; k.ws_stride = qrk::bdqr_reg_ws_doubles(); }
             if (const char* e = std::getenv("QRK_COL_WGS")) { const long v = std::atol(e); if (v > 0) wgs = v; }
             k.num_wg = (int)(k.n < wgs ? k.n : wgs);
             if (k.ws_stride > k.w_lds) {       // some tile of the class works in (or, on chip, is dumped to) global memory
