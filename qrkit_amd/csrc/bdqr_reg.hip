@@ -42,8 +42,10 @@ constexpr int CS = 257;            // stride of an LDS row (doubles)
 constexpr int NCH = 6;             // register chunks of 16 rows per thread
 constexpr int NB = colfin::NB;
 
-struct Cand { double val; int pos; int col; };
-__device__ __forceinline__ bool better(const Cand& a, const Cand& b) { return a.val > b.val || (a.val == b.val && a.pos < b.pos); }
+// Candidate of the pivot search: squared updated norm (< 0: none) and (current position << 8 | column): the first maximum in
+// Eigen's order is the largest norm, then the smallest position (positions are distinct, the column rides along).
+struct Cand { double val; int key; };
+__device__ __forceinline__ bool better(const Cand& a, const Cand& b) { return a.val > b.val || (a.val == b.val && a.key < b.key); }
 
 // DPP butterflies (qrk_device.h: dpp_f64 / dpp_i32): quad xor 1, quad xor 2, half-row mirror, row mirror, then the rows through
 // v_permlane16_swap -- no LDS round trips.  Both halves of the wave hold the same candidates (two threads per column): 32 lanes.
@@ -52,7 +54,7 @@ __device__ __forceinline__ double swap16_f64(double v)
     const unsigned vl = (unsigned)__double2loint(v), vh = (unsigned)__double2hiint(v);
     const auto rl = __builtin_amdgcn_permlane16_swap(vl, vl, false, false);
     const auto rh = __builtin_amdgcn_permlane16_swap(vh, vh, false, false);
-    // [0] / [1]: the lane's own value and that of the lane 16 away, in an order that depends on the row; callers are symmetric
+    // [0] / [1]: the value of the even and of the odd row, in every lane: own ^ both = the partner's
     return __hiloint2double((int)(rh[0] ^ rh[1] ^ vh), (int)(rl[0] ^ rl[1] ^ vl));
 }
 __device__ __forceinline__ int swap16_i32(int v)
@@ -61,15 +63,21 @@ __device__ __forceinline__ int swap16_i32(int v)
     return (int)(r[0] ^ r[1] ^ (unsigned)v);
 }
 template <int CTRL>
-__device__ __forceinline__ Cand cand_dpp(const Cand& c) { return Cand{dpp_f64<CTRL>(c.val), dpp_i32<CTRL>(c.pos), dpp_i32<CTRL>(c.col)}; }
-__device__ __forceinline__ Cand half_best(Cand c)
+__device__ __forceinline__ Cand cand_dpp(const Cand& c) { return Cand{dpp_f64<CTRL>(c.val), dpp_i32<CTRL>(c.key)}; }
+__device__ __forceinline__ Cand best8(Cand c)          // over every group of 8 lanes
 {
     Cand o;
     o = cand_dpp<0xB1>(c); if (better(o, c)) c = o;
     o = cand_dpp<0x4E>(c); if (better(o, c)) c = o;
     o = cand_dpp<0x141>(c); if (better(o, c)) c = o;
+    return c;
+}
+__device__ __forceinline__ Cand half_best(Cand c)
+{
+    c = best8(c);
+    Cand o;
     o = cand_dpp<0x140>(c); if (better(o, c)) c = o;
-    o = Cand{swap16_f64(c.val), swap16_i32(c.pos), swap16_i32(c.col)}; if (better(o, c)) c = o;
+    o = Cand{swap16_f64(c.val), swap16_i32(c.key)}; if (better(o, c)) c = o;
     return c;
 }
 
@@ -144,7 +152,7 @@ __device__ __forceinline__ double recip(double x)
 
 constexpr size_t lds_bytes()
 {
-    return (size_t)(LR * CS + PR /* xv */ + PR /* taus */ + NW /* cval */) * sizeof(double) + (size_t)(2 * NW + 4 + PR) * sizeof(int) + 16;
+    return (size_t)(LR * CS + PR /* xv */ + PR /* taus */ + 2 * NW /* cands */) * sizeof(double) + (size_t)(4 + PR) * sizeof(int) + 16;
 }
 static_assert((size_t)(PR * (NB + 1) + (2 + NW) * NB * NB) <= (size_t)LR * CS, "the scratch of the Q accumulation reuses the LDS rows");
 
@@ -161,10 +169,8 @@ bdqr_reg_kernel(WaveBatch nb, const double* __restrict__ tiles, double* __restri
     double* ldsA = smem;                                   // [LR][CS] padded rows 0..63
     double* xv = ldsA + LR * CS;                           // [PR] pivot column of the step, by padded row
     double* taus = xv + PR;                                // [PR]
-    double* cval = taus + PR;                              // [NW]
-    int* cpos = reinterpret_cast<int*>(cval + NW);         // [NW]
-    int* ccol = cpos + NW;                                 // [NW]
-    int* flags = ccol + NW;                                // [4]
+    double2* cands = reinterpret_cast<double2*>(taus + PR);   // [NW] candidates of the waves: {norm, key in the low word of .y}
+    int* flags = reinterpret_cast<int*>(cands + NW);       // [4]
     int* col_of_pos = flags + 4;                           // [PR]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h = lane >> 5, j = wave * 32 + (lane & 31), l16 = lane & 15;
@@ -247,20 +253,25 @@ bdqr_reg_kernel(WaveBatch nb, const double* __restrict__ tiles, double* __restri
             // ---- 1. pivot
             int P = k, ppos = k;
             if (pivoting) {
-                Cand cd{live ? nu2 : -1.0, pos, j};
+                Cand cd{live ? nu2 : -1.0, (pos << 8) | j};
                 cd = half_best(cd);
-                if (lane == 0) { cval[wave] = cd.val; cpos[wave] = cd.pos; ccol[wave] = cd.col; }
+                if (lane == 0) cands[wave] = make_double2(cd.val, __hiloint2double(0, cd.key));
             }
             REG_TICK(1);
             lds_barrier();      // (also: every read of xv of the step before is done)
             REG_TICK(11);
             if (pivoting) {
-                Cand bb{cval[0], cpos[0], ccol[0]};
-#pragma unroll
-                for (int w = 1; w < NW; ++w) { Cand o{cval[w], cpos[w], ccol[w]}; if (better(o, bb)) bb = o; }
-                P = bb.col; ppos = bb.pos;
-                if (k == 0) a2 = bb.val;
-                if (live && j != P && near_best(nu2, thr, bb.val, a2)) unclear = true;
+                // lane l takes the candidate of wave l % 8: one LDS read, three DPP stages
+                const double2 cw = cands[lane & 7];
+                const Cand bb = best8(Cand{cw.x, __double2loint(cw.y)});
+                P = bb.key & 255; ppos = bb.key >> 8;
+                if (k == 0) a2 = uniform_f64(bb.val);
+                if (live && j != P) {
+                    // decision (1), qrk_device.h near_best: its margin is at most MREL (thr + THR_HI a2) + 2^-41 max(a2, best), which
+                    // rules the test out for (almost) every column without the square root
+                    const double mub = MREL * (thr + THR_HI * a2) + 4.547473508864641e-13 * fmax(a2, bb.val);
+                    if (nu2 >= bb.val - mub && near_best(nu2, thr, bb.val, a2)) unclear = true;
+                }
                 if (isA) { if (j == P) pos = k; else if (pos == k) pos = ppos; }
             }
             REG_TICK(3);

@@ -59,7 +59,7 @@ FAMILIES = [
     ("K5 small 16x16", 16, 16, [0, 4, 8]),
     ("thin 9x2", 9, 2, [0]),
     ("K2 LDS-resident 48x48", 48, 48, [0, 8, 24]),
-    ("K2 panel-blocked 200x200", 200, 200, [0, 8, 24]),
+    ("K2 on-chip 200x200", 200, 200, [0, 8, 24]),
 ]
 
 
