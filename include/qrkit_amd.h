@@ -234,7 +234,12 @@ qrk_status qrk_dense_plan_destroy(qrk_dense_plan plan);
  * hcoeffs are those of Q1: use qrk_dense_apply_q / qrk_dense_solve_r with the same plan (the factors of Q1 stay in the plan),
  * do not interpret the lower part yourself.  A pivot decision inside its rounding margin still sends the whole matrix through
  * the exact path, which leaves Eigen's format; decisions that only fix the sign of a row of R (leading entry of a reflector at the
- * noise level, zero tail) do not, since that sign is open in this form anyway. */
+ * noise level, zero tail) do not, since that sign is open in this form anyway.
+ *
+ * Synchronisation: plans of at most 2^18 entries only enqueue (the exact path is queued behind the fast one and decides on the
+ * device).  Two-stage plans and plans with rows * cols >= 2^18 SYNCHRONISE the handle's stream before they return: the host reads
+ * one flag word (into a pinned buffer of the plan) to know which format the factors are in / whether the exact path has to be
+ * launched over the whole chip.  Such a call cannot be captured into a hipGraph. */
 qrk_status qrk_dense_factorize(qrk_dense_plan plan, double* a, int64_t lda, double* hcoeffs, int32_t* perm,
                                qrk_memspace space);
 

@@ -209,18 +209,28 @@ bdqr_reg_kernel(WaveBatch nb, const double* __restrict__ tiles, double* __restri
         {
             // (unconditional loads from clamped addresses, then a select: a branch per element otherwise)
             const double* colp = src + (int64_t)(isA ? j : 0) * r;
+            // 16 bytes per load (the hardware takes 8-byte alignment; a lane reads 16 consecutive rows of its column, one or two lines)
+            typedef double d2u __attribute__((ext_vector_type(2), aligned(8)));
 #pragma unroll
             for (int m = 0; m < NCH; ++m)
 #pragma unroll
-                for (int u = 0; u < 16; ++u) {
-                    const int i = LR + 32 * m + 16 * h + u - off;
-                    const double v = colp[i > 0 ? i : 0];
-                    a[m][u] = (isA && i >= 0) ? v : 0.0;
+                for (int u = 0; u < 16; u += 2) {
+                    const int i = LR + 32 * m + 16 * h + u - off;      // rows i, i + 1 of the tile; i = -1: only the second one exists
+                    const d2u v = *reinterpret_cast<const d2u*>(colp + (i > 0 ? i : 0));
+                    a[m][u] = (isA && i >= 0) ? v.x : 0.0;
+                    a[m][u + 1] = (isA && i >= 0) ? v.y : ((isA && i == -1) ? v.x : 0.0);
                 }
         }
-        for (int e = tid; e < nl * c; e += CT) {
-            const int jj = e / nl, i = e - jj * nl;
-            ldsA[(off + i) * CS + jj] = src[(int64_t)jj * r + i];
+        if (nl > 0) {
+            // lane = row (the top nl <= 64 rows of a column are consecutive in memory), a wave per column, eight loads in flight
+            const int i = lane < nl ? lane : nl - 1;
+            for (int j0 = wave; j0 < c; j0 += 8 * NW) {
+                double v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { const int jj = j0 + NW * u; v[u] = src[(int64_t)(jj < c ? jj : c - 1) * r + i]; }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { const int jj = j0 + NW * u; if (jj < c && lane < nl) ldsA[(off + lane) * CS + jj] = v[u]; }
+            }
         }
         if (tid < 4) flags[tid] = 0;
         __syncthreads();

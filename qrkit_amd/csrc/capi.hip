@@ -174,6 +174,7 @@ struct qrk_dense_plan_s {
     // the flag word of the single-workgroup kernel, workspace of the exact kernel
     double* d_copy = nullptr;
     int* d_unclear = nullptr;
+    int* h_unclear = nullptr;      // pinned: where the host reads the flag word (two-stage and exact_wide plans synchronise the stream)
     double* d_exact_ws = nullptr;
     // two-stage form of the pivoted factorisation of a tall matrix (caqr.hip): A = Q0 R0 without pivoting on the matrix cores,
     // then R0 P = Q1 R by the level-2 kernels on the n x n triangle.  d_r0 keeps the packed QR of the second stage, d_t the T
@@ -1037,6 +1038,7 @@ qrk_status qrk_dense_plan_create(qrk_handle h, int32_t rows, int32_t cols, qrk_b
     // exact path: a copy of the input, the flag of the single-workgroup kernel, the exact kernel's workspace
     if (hipMalloc((void**)&p->d_copy, (size_t)rows * (size_t)cols * sizeof(double)) != hipSuccess ||
         hipMalloc((void**)&p->d_unclear, sizeof(int)) != hipSuccess ||
+        hipHostMalloc((void**)&p->h_unclear, sizeof(int), hipHostMallocDefault) != hipSuccess ||
         hipMalloc((void**)&p->d_exact_ws, qrk::dense_exact_workspace_bytes(rows, cols)) != hipSuccess) {
         qrk_dense_plan_destroy(p);
         return fail(h, QRK_STATUS_ALLOC_FAILED, "qrk_dense_plan_create: cannot allocate the input copy of the exact path");
@@ -1049,6 +1051,7 @@ qrk_status qrk_dense_plan_destroy(qrk_dense_plan p)
 {
     if (p) {
         (void)hipFree(p->d_ws); (void)hipFree(p->d_copy); (void)hipFree(p->d_unclear); (void)hipFree(p->d_exact_ws);
+        if (p->h_unclear) (void)hipHostFree(p->h_unclear);
         if (p->la_stream) (void)hipStreamDestroy(p->la_stream);
         if (p->la_urgent) (void)hipEventDestroy(p->la_urgent);
         if (p->la_factored) (void)hipEventDestroy(p->la_factored);
@@ -1138,9 +1141,9 @@ qrk_status qrk_dense_factorize(qrk_dense_plan p, double* a, int64_t lda, double*
             QRK_HIP(h, qrk::launch_caqr_copy_upper(p->d_q1, n, da, lda, n, 0, h->stream));
             // a decision of the second stage inside rounding: the exact path redoes the whole matrix in Eigen's operation order
             // and leaves Eigen's packed format; the host has to know which format the factors are in
-            int unclear = 0;
-            QRK_HIP(h, hipMemcpyAsync(&unclear, flag, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+            QRK_HIP(h, hipMemcpyAsync(p->h_unclear, flag, sizeof(int), hipMemcpyDeviceToHost, h->stream));
             QRK_HIP(h, hipStreamSynchronize(h->stream));
+            const int unclear = *p->h_unclear;
             p->ts_active = unclear == 0;
             p->ts_owner = p->ts_active ? static_cast<const void*>(a) : nullptr;
             if (unclear) return exact_wide(da, dhc, dp, unclear);
@@ -1166,8 +1169,9 @@ qrk_status qrk_dense_factorize(qrk_dense_plan p, double* a, int64_t lda, double*
             // large blocks: one workgroup would take minutes, so the host reads the word and runs the exact path over the whole chip
             int unclear = 1;                               // (no flag: the exact path was asked for)
             if (flag) {
-                QRK_HIP(h, hipMemcpyAsync(&unclear, flag, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+                QRK_HIP(h, hipMemcpyAsync(p->h_unclear, flag, sizeof(int), hipMemcpyDeviceToHost, h->stream));
                 QRK_HIP(h, hipStreamSynchronize(h->stream));
+                unclear = *p->h_unclear;
             }
             if (unclear) return exact_wide(da, dhc, dp, unclear);
             return QRK_STATUS_OK;
