@@ -180,17 +180,18 @@ __device__ __forceinline__ void finish_tile_strips(const double* __restrict__ Rw
     // and, at a stride of 2 KB, one L2 channel -- per element: 0.1 ms of a 256 x 256 tile)
     for (int ib = 0; 16 * ib < c; ++ib) {
         QRK_FIN_LANE();
-        double rowv[8];
+        constexpr int PT = 16 * LD / CT;            // elements per thread of a block of 16 rows
+        double rowv[PT];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) { const int e = tid + CT * u, ii = e >> 8, jj = e & 255; rowv[u] = Rw[(16 * ib + ii) * LD + jj]; }
+        for (int u = 0; u < PT; ++u) { const int e = tid + CT * u, ii = e >> 8, jj = e & 255; rowv[u] = Rw[(16 * ib + ii) * LD + jj]; }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) { const int e = tid + CT * u, ii = e >> 8, jj = e & 255; vs[jj * VS + ii] = rowv[u]; }
+        for (int u = 0; u < PT; ++u) { const int e = tid + CT * u, ii = e >> 8, jj = e & 255; vs[jj * VS + ii] = rowv[u]; }
         __syncthreads();
         {
             const int pp = tid >> 4, ii = tid & 15, i = 16 * ib + ii;
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int p = 16 * ib + pp + 32 * u;
+            for (int u = 0; u < PT; ++u) {
+                const int p = 16 * ib + pp + (CT / 16) * u;
                 if (p < c && i <= p) rv[(int64_t)p * (p + 1) / 2 + i] = vs[col_of_pos[p] * VS + ii];
             }
         }
@@ -205,17 +206,18 @@ __device__ __forceinline__ void finish_tile_strips(const double* __restrict__ Rw
         const int mt = (m + 15) >> 4;          // row tiles of a strip; V is zero-filled up to 16 mt rows
         QRK_FIN_LANE();
         {
-            // thread -> reflector l = tid / 32, rows i = tid % 32 + 32 u: eight independent loads (a loop with one load per trip is a
+            // thread -> reflector l = tid / RPT, rows i = tid % RPT + RPT u: independent loads (a loop with one load per trip is a
             // chain of memory latencies)
-            const int l = tid >> 5, i0 = tid & 31;
-            double vv[8];
+            constexpr int RPT = CT / NB, NU = LD / RPT;
+            const int l = tid / RPT, i0 = tid % RPT;
+            double vv[NU];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int i = i0 + 32 * u;
+            for (int u = 0; u < NU; ++u) {
+                const int i = i0 + RPT * u;
                 vv[u] = (l < kb && i > l && i < m) ? Vb[(kp + l) * LD + kp + i] : (i == l && l < kb ? 1.0 : 0.0);
             }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) { const int i = i0 + 32 * u; if (i < 16 * mt) vs[i * VS + l] = vv[u]; }
+            for (int u = 0; u < NU; ++u) { const int i = i0 + RPT * u; if (i < 16 * mt) vs[i * VS + l] = vv[u]; }
         }
         __syncthreads();
         FIN_TICK(1);

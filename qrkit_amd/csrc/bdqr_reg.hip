@@ -35,7 +35,9 @@ namespace qrk {
 namespace reg {
 
 using namespace decide;
-constexpr int CT = 512, NW = CT / 64;
+// Two instantiations: NWV = 8 waves (512 threads, up to 256 columns, one workgroup per CU: the LDS rows) and NWV = 4 waves (256
+// threads, tiles of at most 128 columns and 192 rows: no LDS rows, TWO workgroups per CU -- the steps are a latency chain, a second
+// tile in flight on the CU hides half of it).
 constexpr int PR = 256;            // rows of the padded frame
 constexpr int LR = 64;             // padded rows [0, LR) live in LDS
 constexpr int CS = 257;            // stride of an LDS row (doubles)
@@ -150,24 +152,30 @@ __device__ __forceinline__ double recip(double x)
     return y;
 }
 
-constexpr size_t lds_bytes()
+// doubles of the first LDS region: the LDS rows (8 waves) and, after phase 1, the scratch of the Q accumulation
+constexpr int scratch_doubles(int nw) { return PR * (NB + 1) + (2 + nw) * NB * NB; }
+constexpr int region_doubles(int nw) { return nw == 8 ? LR * CS : scratch_doubles(nw); }
+constexpr size_t lds_bytes(int nw)
 {
-    return (size_t)(LR * CS + PR /* xv */ + PR /* taus */ + 2 * NW /* cands */) * sizeof(double) + (size_t)(4 + PR) * sizeof(int) + 16;
+    return (size_t)(region_doubles(nw) + PR /* xv */ + PR /* taus */ + 2 * nw /* cands */) * sizeof(double) + (size_t)(4 + PR) * sizeof(int) + 16;
 }
-static_assert((size_t)(PR * (NB + 1) + (2 + NW) * NB * NB) <= (size_t)LR * CS, "the scratch of the Q accumulation reuses the LDS rows");
+static_assert(scratch_doubles(8) <= LR * CS, "the scratch of the Q accumulation reuses the LDS rows");
+static_assert(region_doubles(4) % 2 == 0 && (LR * CS) % 2 == 0, "16-byte alignment of what follows");
 
 }  // namespace reg
 
-__global__ void __launch_bounds__(reg::CT) __attribute__((amdgpu_waves_per_eu(2, 2)))
+template <int NWV>
+__global__ void __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(2, 2)))
 bdqr_reg_kernel(WaveBatch nb, const double* __restrict__ tiles, double* __restrict__ q_vals, double* __restrict__ r_vals,
                 int32_t* __restrict__ perm, double* __restrict__ hcoeffs, double* __restrict__ workspace, int64_t ws_stride,
                 int32_t* __restrict__ redo_count, int32_t* __restrict__ redo_ids, int32_t* __restrict__ queue)
 {
     using namespace reg;
+    constexpr int CT = 64 * NWV, NW = NWV;
     extern __shared__ __attribute__((aligned(16))) double smem[];
     __shared__ int next_tile;
-    double* ldsA = smem;                                   // [LR][CS] padded rows 0..63
-    double* xv = ldsA + LR * CS;                           // [PR] pivot column of the step, by padded row
+    double* ldsA = smem;                                   // [LR][CS] padded rows 0..63 (8 waves; 4 waves: tiles have no such rows)
+    double* xv = ldsA + region_doubles(NW);                // [PR] pivot column of the step, by padded row
     double* taus = xv + PR;                                // [PR]
     double2* cands = reinterpret_cast<double2*>(taus + PR);   // [NW] candidates of the waves: {norm, key in the low word of .y}
     int* flags = reinterpret_cast<int*>(cands + NW);       // [4]
@@ -272,7 +280,7 @@ bdqr_reg_kernel(WaveBatch nb, const double* __restrict__ tiles, double* __restri
             REG_TICK(11);
             if (pivoting) {
                 // lane l takes the candidate of wave l % 8: one LDS read, three DPP stages
-                const double2 cw = cands[lane & 7];
+                const double2 cw = cands[lane & (NW - 1)];
                 const Cand bb = best8(Cand{cw.x, __double2loint(cw.y)});
                 P = bb.key & 255; ppos = bb.key >> 8;
                 if (k == 0) a2 = uniform_f64(bb.val);
@@ -449,7 +457,9 @@ bdqr_reg_kernel(WaveBatch nb, const double* __restrict__ tiles, double* __restri
     }
 }
 
-size_t bdqr_reg_smem_bytes() { return reg::lds_bytes(); }
+size_t bdqr_reg_smem_bytes(int small) { return reg::lds_bytes(small ? 4 : 8); }
+// the 4-wave instantiation takes tiles of at most this size
+bool bdqr_reg_small(int max_rows, int max_cols) { return max_cols <= 128 && max_rows <= 192; }
 int64_t bdqr_reg_ws_doubles() { return 3 * (int64_t)reg::PR * reg::PR; }
 
 // Tiles with more than 64 columns, rows >= cols, rows <= 256.  workspace: num_wg * ws_stride doubles, ws_stride >=
@@ -462,10 +472,17 @@ hipError_t launch_bdqr_reg(const WaveBatch& nb, const double* tiles, double* q_v
     if (max_rows > reg::PR || max_cols > max_rows || ws_stride < bdqr_reg_ws_doubles()) return hipErrorInvalidValue;
     if (hipError_t e = hipMemsetAsync(queue, 0, sizeof(int32_t), stream)) return e;
     const int64_t want = nb.num_tiles < (int64_t)num_wg ? nb.num_tiles : (int64_t)num_wg;
-    const size_t smem = reg::lds_bytes();
-    if (hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(bdqr_reg_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)) return e;
-    hipLaunchKernelGGL(bdqr_reg_kernel, dim3((unsigned)want), dim3(reg::CT), smem, stream, nb, tiles, q_vals, r_vals, perm, hcoeffs,
-                       workspace, ws_stride, redo_count, redo_ids, queue);
+    if (bdqr_reg_small(max_rows, max_cols)) {
+        const size_t smem = reg::lds_bytes(4);
+        if (hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(bdqr_reg_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)) return e;
+        hipLaunchKernelGGL(bdqr_reg_kernel<4>, dim3((unsigned)want), dim3(256), smem, stream, nb, tiles, q_vals, r_vals, perm, hcoeffs,
+                           workspace, ws_stride, redo_count, redo_ids, queue);
+    } else {
+        const size_t smem = reg::lds_bytes(8);
+        if (hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(bdqr_reg_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)) return e;
+        hipLaunchKernelGGL(bdqr_reg_kernel<8>, dim3((unsigned)want), dim3(512), smem, stream, nb, tiles, q_vals, r_vals, perm, hcoeffs,
+                           workspace, ws_stride, redo_count, redo_ids, queue);
+    }
     return hipGetLastError();
 }
 

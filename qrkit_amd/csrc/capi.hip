@@ -590,7 +590,10 @@ qrk_status qrk_bd_plan_create(qrk_handle h, const qrk_bd_layout* L, qrk_q_format
                 //  balances itself: 4 000 mixed 8...256 tiles 17.5 ms, against 19.1 with the tiles of up to 160 rows in a launch of
                 //  their own (QRK_COL_MERGE=0) -- the split dates from the grid-stride assignment)
                 static const bool merge12 = !(std::getenv("QRK_COL_MERGE") && std::atoi(std::getenv("QRK_COL_MERGE")) == 0);
-                const int z = c <= 64 ? 0 : ((r <= 160 && !merge12) ? 1 : 2);
+                // on chip (bdqr_reg.hip) the tiles of at most 128 columns and 192 rows form a class of their own: two workgroups of 256
+                // threads per CU instead of one of 512
+                static const bool onchip_classes = !(std::getenv("QRK_COL_ONCHIP") && std::atoi(std::getenv("QRK_COL_ONCHIP")) == 0);
+                const int z = c <= 64 ? 0 : (onchip_classes ? (qrk::bdqr_reg_small(r, c) ? 1 : 2) : ((r <= 160 && !merge12) ? 1 : 2));
                 auto& k = p->col_cls[z];
                 col_bin[z].push_back((int32_t)i);
                 const int64_t rc = (int64_t)r * c;
@@ -632,7 +635,10 @@ qrk_status qrk_bd_plan_create(qrk_handle h, const qrk_bd_layout* L, qrk_q_format
             // global-workspace form, for comparison)
             static const bool use_onchip = !(std::getenv("QRK_COL_ONCHIP") && std::atoi(std::getenv("QRK_COL_ONCHIP")) == 0);
             k.onchip = use_onchip && (p->uniform ? p->c > 64 : z >= 1);
-            if (k.onchip) { wgs = h->num_cus; k.w_lds = 0; k.ws_stride = qrk::bdqr_reg_ws_doubles(); }
+            if (k.onchip) {
+                wgs = (int64_t)h->num_cus * (qrk::bdqr_reg_small(k.max_rows, k.max_cols) ? 2 : 1);
+                k.w_lds = 0; k.ws_stride = qrk::bdqr_reg_ws_doubles();
+            }
             if (const char* e = std::getenv("QRK_COL_WGS")) { const long v = std::atol(e); if (v > 0) wgs = v; }
             k.num_wg = (int)(k.n < wgs ? k.n : wgs);
             if (k.ws_stride > k.w_lds) {       // some tile of the class works in (or, on chip, is dumped to) global memory

@@ -63,6 +63,7 @@ hipError_t launch_bdqr_reg(const WaveBatch& nb, const double* tiles, double* q_v
                            double* workspace, int64_t ws_stride, int num_wg, int max_rows, int max_cols, int32_t* redo_count,
                            int32_t* redo_ids, int32_t* queue, hipStream_t stream);
 int64_t bdqr_reg_ws_doubles();      // workspace of one workgroup of launch_bdqr_reg
+bool bdqr_reg_small(int max_rows, int max_cols);   // the launch runs the 4-wave instantiation: two workgroups per CU
 int bdqr_col_w_lds(int64_t max_rc, int64_t max_rc_fitting);
 int bdqr_col_wgs_per_cu(int max_cols, int w_lds, int max_r);
 constexpr int QRK_COL_W_LDS_MAX = 4352;     // doubles of LDS for A in the LDS-resident form (bdqr_col.hip)

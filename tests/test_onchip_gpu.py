@@ -1,7 +1,8 @@
 """The on-chip kernel for tiles wider than 64 columns (qrkit_amd/csrc/bdqr_reg.hip: registers + LDS, 512 threads per tile) against
 the CPU oracle, through the C ABI: every boundary of its layout -- the padded frame (rows = 256), the LDS rows (tiles taller than
 192 rows), each of the six register-chunk levels (a level dies every 32 rows), the 16-row panels of the Q accumulation (cols and
-rows that are not multiples of 16 / 4), the narrowest tile of the class (65 columns) -- with both block solvers, uniform and mixed
+rows that are not multiples of 16 / 4), the narrowest tile of the class (65 columns), the boundary between the 4-wave (at most 128 columns and 192 rows, two workgroups per
+CU) and the 8-wave instantiation -- with both block solvers, uniform and mixed
 launches, tiles that must go through the exact path, and the old global-workspace form (QRK_COL_ONCHIP=0) as a cross-check."""
 import os
 import subprocess
@@ -34,6 +35,10 @@ SHAPES = [
     (3, 66, 65),
     (2, 97, 96),      # rows not a multiple of 4
     (2, 128, 100),
+    (3, 128, 128),    # the widest tile of the 4-wave instantiation (two workgroups per CU)
+    (2, 192, 128),    # ... and its tallest
+    (2, 193, 128),    # one row more: the 8-wave instantiation
+    (2, 140, 129),    # one column more
     (2, 160, 160),    # exactly three live levels
     (2, 161, 70),
     (2, 191, 191),
