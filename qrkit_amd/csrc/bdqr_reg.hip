@@ -64,23 +64,36 @@ __device__ __forceinline__ int swap16_i32(int v)
     const auto r = __builtin_amdgcn_permlane16_swap((unsigned)v, (unsigned)v, false, false);
     return (int)(r[0] ^ r[1] ^ (unsigned)v);
 }
-template <int CTRL>
-__device__ __forceinline__ Cand cand_dpp(const Cand& c) { return Cand{dpp_f64<CTRL>(c.val), dpp_i32<CTRL>(c.key)}; }
+// arg-max in two passes: the largest norm (three instructions per stage: two DPP moves and v_max_f64), then the smallest key among the
+// lanes that hold it (one v_min_i32 with a DPP operand per stage) -- the same first maximum as comparing (norm, key) pairs stage by
+// stage, in half the instructions
 __device__ __forceinline__ Cand best8(Cand c)          // over every group of 8 lanes
 {
-    Cand o;
-    o = cand_dpp<0xB1>(c); if (better(o, c)) c = o;
-    o = cand_dpp<0x4E>(c); if (better(o, c)) c = o;
-    o = cand_dpp<0x141>(c); if (better(o, c)) c = o;
-    return c;
+    double m = c.val;
+    m = fmax(m, dpp_f64<0xB1>(m));
+    m = fmax(m, dpp_f64<0x4E>(m));
+    m = fmax(m, dpp_f64<0x141>(m));
+    int kk = c.val == m ? c.key : 0x7fffffff;
+    kk = min(kk, dpp_i32<0xB1>(kk));
+    kk = min(kk, dpp_i32<0x4E>(kk));
+    kk = min(kk, dpp_i32<0x141>(kk));
+    return Cand{m, kk};
 }
-__device__ __forceinline__ Cand half_best(Cand c)
+__device__ __forceinline__ Cand half_best(Cand c)      // over the 32 lanes of a half (both halves hold the same candidates)
 {
-    c = best8(c);
-    Cand o;
-    o = cand_dpp<0x140>(c); if (better(o, c)) c = o;
-    o = Cand{swap16_f64(c.val), swap16_i32(c.key)}; if (better(o, c)) c = o;
-    return c;
+    double m = c.val;
+    m = fmax(m, dpp_f64<0xB1>(m));
+    m = fmax(m, dpp_f64<0x4E>(m));
+    m = fmax(m, dpp_f64<0x141>(m));
+    m = fmax(m, dpp_f64<0x140>(m));
+    m = fmax(m, swap16_f64(m));
+    int kk = c.val == m ? c.key : 0x7fffffff;
+    kk = min(kk, dpp_i32<0xB1>(kk));
+    kk = min(kk, dpp_i32<0x4E>(kk));
+    kk = min(kk, dpp_i32<0x141>(kk));
+    kk = min(kk, dpp_i32<0x140>(kk));
+    kk = min(kk, swap16_i32(kk));
+    return Cand{m, kk};
 }
 
 // sum over the 64 lanes, the same bits in every lane (each stage adds the same two partial sums in either order)
@@ -311,8 +324,14 @@ bdqr_reg_kernel(WaveBatch nb, const double* __restrict__ tiles, double* __restri
             double tsq;
             {
                 double p = 0.0;
+                // (a group of 64 rows is skipped when the level says at compile time that all of it lies above the diagonal: from level 1
+                //  on kp >= LR + 32 V; level 0 also holds the steps whose diagonal is in an LDS row)
 #pragma unroll
-                for (int q4 = 0; q4 < 4; ++q4) { const int row = 64 * q4 + lane; double x = xv[row]; x = row > kp ? x : 0.0; p = fma(x, x, p); }
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    if (V == 0 || 64 * q4 + 63 >= LR + 32 * V) {        // otherwise every row of the group is <= kp
+                        const int row = 64 * q4 + lane; double x = xv[row]; x = row > kp ? x : 0.0; p = fma(x, x, p);
+                    }
+                }
                 tsq = uniform_f64(wave_sum_d(p));
             }
             const double xk = uniform_f64(xv[kp]);
@@ -328,7 +347,7 @@ bdqr_reg_kernel(WaveBatch nb, const double* __restrict__ tiles, double* __restri
                 s = uniform_f64(nbv + xk);                   // x0 - beta
                 ng = uniform_f64(-recip(nbv * s));           // -1 / (beta w)
                 tau = -(s * s) * ng;                         // w / beta
-                inv_s = uniform_f64(recip(s));               // essential part = x_tail / (x0 - beta)
+                inv_s = uniform_f64(-ng * nbv);              // 1 / (x0 - beta): the essential part is x_tail / (x0 - beta)
             }
             if (tid == 0) { taus[k] = tau; if (hcoeffs) hcoeffs[cbase + k] = tau; }
             REG_TICK(5);
@@ -338,7 +357,8 @@ bdqr_reg_kernel(WaveBatch nb, const double* __restrict__ tiles, double* __restri
             for (int m = V; m < NCH; ++m) {
                 const int row = LR + 32 * m + 16 * h + l16;
                 const double x = xv[row];
-                xc[m] = row > kp ? x : (row == kp ? s : 0.0);
+                // (only chunk V can hold the diagonal or rows above it; with the diagonal in an LDS row none does)
+                xc[m] = (m > V || in_lds) ? x : (row > kp ? x : (row == kp ? s : 0.0));
             }
             // ---- 4. row kp of this column before the step
             double ak;
