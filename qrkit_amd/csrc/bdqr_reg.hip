@@ -274,7 +274,7 @@ bdqr_reg_kernel(WaveBatch nb, const double* __restrict__ tiles, double* __restri
         auto step = [&](auto tag, const int k) {
             constexpr int V = decltype(tag)::value;        // register chunks [V, NCH) are live
             const int kp = k + off;                        // padded row of the diagonal
-            const bool in_lds = kp < LR;
+            const bool in_lds = V == 0 && kp < LR;         // (from level 1 on the diagonal is in a register row: kp >= LR + 32 V)
             // Everything per-lane is re-derived from an opaque thread id in every step: otherwise hipcc hoists the (loop-invariant)
             // LDS addresses out of the step loop and keeps them in scratch across the factorisation.
             int tid = threadIdx.x;
