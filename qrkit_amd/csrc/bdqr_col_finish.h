@@ -169,7 +169,7 @@ __device__ __forceinline__ void finish_tile_strips(const double* __restrict__ Rw
     //  address arithmetic of all unrolled accesses out of the loops -- and of the tile loop around this call -- and spills it)
 #define QRK_FIN_LANE() int tid = threadIdx.x; asm volatile("" : "+v"(tid)); const int lane = tid & 63, kq = lane >> 4, l15 = lane & 15; (void)lane; (void)kq; (void)l15
 #ifdef QRK_REG_PROF
-    unsigned long long ft[6] = {0, 0, 0, 0, 0, 0}, ft0 = __builtin_amdgcn_s_memtime();
+    unsigned long long ft[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, ft0 = __builtin_amdgcn_s_memtime();
 #define FIN_TICK(z) do { const unsigned long long t1 = __builtin_amdgcn_s_memtime(); ft[z] += t1 - ft0; ft0 = t1; } while (0)
 #else
 #define FIN_TICK(z) do { } while (0)
@@ -283,6 +283,7 @@ __device__ __forceinline__ void finish_tile_strips(const double* __restrict__ Rw
 #pragma unroll
                     for (int z = 0; z < 4; ++z) dv[rt][z] = (16 * rt + kq + 4 * z == 16 * sidx + l15) ? 1.0 : 0.0;
             }
+            FIN_TICK(6);
             d4 acc = d4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
             for (int rt = 0; rt < MAXT; ++rt)
@@ -292,11 +293,13 @@ __device__ __forceinline__ void finish_tile_strips(const double* __restrict__ Rw
                         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(vs[(16 * rt + 4 * z + kq) * VS + l15], dv[rt][z], acc, 0, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);     // (left alone, the scheduler hoists all 64 operand reads ahead of the MFMAs and spills)
                 }
+            FIN_TICK(7);
             d4 uu = d4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks)
                 uu = __builtin_amdgcn_mfma_f64_16x16x4f64(tm[l15 * NB + 4 * ks + kq], acc[ks], uu, 0, 0, 0);
             uu = -uu;
+            FIN_TICK(8);
 #pragma unroll
             for (int rt = 0; rt < MAXT; ++rt)
                 if (rt < mt) {
@@ -317,6 +320,7 @@ __device__ __forceinline__ void finish_tile_strips(const double* __restrict__ Rw
                     __builtin_amdgcn_sched_barrier(0);
                 }
         }
+        FIN_TICK(9);
         first = false;
         __syncthreads();
         FIN_TICK(4);
@@ -324,7 +328,7 @@ __device__ __forceinline__ void finish_tile_strips(const double* __restrict__ Rw
     FIN_TICK(5);
 #ifdef QRK_REG_PROF
     if (blockIdx.x == 0 && threadIdx.x == 0)
-        printf("   finish: R + perm %llu  V panels %llu  V^T V %llu  T %llu  apply %llu  copy %llu\n", ft[0], ft[1], ft[2], ft[3], ft[4], ft[5]);
+        printf("   finish: R + perm %llu  V panels %llu  V^T V %llu  T %llu  apply %llu (wave 0: loads issued %llu  w = V^T q %llu  u = -T w %llu  q += V u and stores %llu  waiting for the others %llu)\n", ft[0], ft[1], ft[2], ft[3], ft[4] + ft[6] + ft[7] + ft[8] + ft[9], ft[6], ft[7], ft[8], ft[9], ft[4]);
 #endif
 #undef FIN_TICK
 #undef QRK_FIN_LANE
