@@ -328,7 +328,13 @@ qrk_status enqueue_factorize(qrk_bd_plan_s* p, const double* tiles, double* q, d
         // the size classes are independent of each other and of the small tiles above: each on its own side stream
         // (forked after what is already queued on the caller's stream, joined back below), so that the tail of one
         // launch overlaps the others
-        static const bool col_serial = !(std::getenv("QRK_COL_CONCURRENT") && std::atoi(std::getenv("QRK_COL_CONCURRENT")) == 1);
+        // Side by side by default since the large classes run on chip (round 3: they no longer cost each other cache, and the small
+        // workgroups of the other classes fill the CUs that the tail of the 512-thread launch leaves idle: 4 000 mixed tiles 8.2 ->
+        // 7.3 ms); QRK_COL_CONCURRENT=0 / 1 forces one way, and with QRK_COL_ONCHIP=0 the round-2 finding stands (serial).
+        static const bool col_serial = [] {
+            if (const char* e = std::getenv("QRK_COL_CONCURRENT")) return std::atoi(e) != 1;
+            return std::getenv("QRK_COL_ONCHIP") && std::atoi(std::getenv("QRK_COL_ONCHIP")) == 0;
+        }();
         if (p->n_col > 0 && col_serial) {
             // one class after the other on the caller's stream, the largest tiles first.  Measured alone the classes of 4 000 mixed
             // 8...256 tiles take 12.7 + 3.65 + 0.53 = 16.9 ms; launched side by side on three streams (QRK_COL_CONCURRENT=1) the
