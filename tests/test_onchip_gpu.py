@@ -172,3 +172,43 @@ print("OK")
 ''' % (ROOT, os.path.join(ROOT, "tests"))
     out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, QRK_COL_ONCHIP="0"), capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "OK" in out.stdout, out.stderr[-2000:]
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_large_tile_batches_match_oracle(seed):
+    """Randomised sweep over the on-chip class: 4...14 tiles with 65...256 columns and 0...60 extra rows (capped at 256), mixed with a few
+    small ones, values from one of four distributions (uniform, wide dynamic range, small integers = ties everywhere -> exact path, one
+    dominant column), both block solvers, both Q formats."""
+    import qrkit_amd
+    from qrkit_amd import _capi as capi
+    rng = np.random.default_rng(7000 + seed)
+    B = int(rng.integers(4, 15))
+    cols = rng.integers(65, 257, B).astype(np.int32)
+    rows = np.minimum(256, cols + rng.integers(0, 61, B)).astype(np.int32)
+    small = rng.integers(1, 65, 3).astype(np.int32)
+    cols = np.concatenate([cols, small]); rows = np.concatenate([rows, small + rng.integers(0, 5, 3).astype(np.int32)])
+    order = rng.permutation(len(cols)); cols, rows = cols[order], rows[order]
+    n = int((rows.astype(np.int64) * cols).sum())
+    kind = seed % 4
+    if kind == 0:
+        tiles = rng.uniform(-1.0, 1.0, n)
+    elif kind == 1:
+        tiles = rng.uniform(-1.0, 1.0, n) * np.exp2(rng.integers(-30, 31, n))
+    elif kind == 2:
+        tiles = rng.integers(-2, 3, n).astype(np.float64)
+    else:
+        tiles = rng.uniform(-1.0, 1.0, n) * 1e-3
+        off = 0
+        for r, c in zip(rows, cols):
+            tiles[off: off + r] += rng.uniform(1.0, 2.0, r)
+            off += int(r) * int(c)
+    solver = capi.COLPIV_HOUSEHOLDER if seed % 3 else capi.HOUSEHOLDER
+    qformat = capi.FULL_Q if seed % 2 else capi.BLOCK_DIAGONAL_Q
+    mat = qrkit_amd.SparseBlockDiagonal.fromTiles(rows, cols, tiles)
+    qr = qrkit_amd.BlockDiagonalSparseQR(mat, blockSolver=solver, qFormat=qformat)
+    _, ref = oracle_factorize(rows, cols, tiles, q_format=qformat, block_solver=solver)
+    assert qr.info() == 0 and qr.rank() == ref.rank
+    np.testing.assert_array_equal(qr.colsPermutation(), ref.perm)
+    sq, sr, _ = tile_sizes(rows, cols)
+    assert per_tile_rel(qr.qValues().cpu().numpy(), ref.Q_vals, sq) <= 10 * RTOL
+    assert per_tile_rel(qr.rValues().cpu().numpy(), ref.R_vals, sr) <= 10 * RTOL
