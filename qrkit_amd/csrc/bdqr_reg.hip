@@ -243,14 +243,15 @@ bdqr_reg_kernel(WaveBatch nb, const double* __restrict__ tiles, double* __restri
                 }
         }
         if (nl > 0) {
-            // lane = row (the top nl <= 64 rows of a column are consecutive in memory), a wave per column, eight loads in flight
-            const int i = lane < nl ? lane : nl - 1;
+            // lane = padded row (the top nl <= 64 rows of a column are consecutive in memory), a wave per column, eight loads in flight;
+            // the padded rows above the tile are zeroed: the step reads and rewrites whole 16-row chunks of the LDS rows
+            const int i = lane >= off ? lane - off : 0;
             for (int j0 = wave; j0 < c; j0 += 8 * NW) {
                 double v[8];
 #pragma unroll
                 for (int u = 0; u < 8; ++u) { const int jj = j0 + NW * u; v[u] = src[(int64_t)(jj < c ? jj : c - 1) * r + i]; }
 #pragma unroll
-                for (int u = 0; u < 8; ++u) { const int jj = j0 + NW * u; if (jj < c && lane < nl) ldsA[(off + lane) * CS + jj] = v[u]; }
+                for (int u = 0; u < 8; ++u) { const int jj = j0 + NW * u; if (jj < c) ldsA[lane * CS + jj] = lane >= off ? v[u] : 0.0; }
             }
         }
         if (tid < 4) flags[tid] = 0;
@@ -387,11 +388,39 @@ bdqr_reg_kernel(WaveBatch nb, const double* __restrict__ tiles, double* __restri
                 QRK_REG_16(QRK_REG_DOT)
 #undef QRK_REG_DOT
             }
+            // the LDS rows: half h takes the 16-row chunks h and h + 2 of padded rows 0..63, with its elements of x' in two more registers
+            // and the same DPP broadcast -- one LDS read per row and pass, eight in flight (a loop that reads x and a for every row and
+            // waits for both made a step with LDS rows 40 % longer than one without)
+            double xl[2];
             if (in_lds) {
-                for (int i = kp + 1 + ((kp + 1 + h) & 1); i < lim; i += 2) d0 = fma(xv[i], ldsA[i * CS + j], d0);
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int row = 16 * (h + 2 * q) + l16;
+                    const double x = xv[row];
+                    xl[q] = row > kp ? x : (row == kp ? s : 0.0);
+                }
+                // (every lane executes the DPP FMAs: a broadcast from a lane that EXEC has switched off does not arrive; lanes without
+                //  a column read column 0 and keep nothing)
+                {
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        if (q == 0 && kp >= 32) continue;        // (rows 0..31 all lie above the diagonal)
+                        asm volatile("s_nop 1" : "+v"(xl[q]));
+                        const double* ap = ldsA + (16 * (h + 2 * q)) * CS + (isA ? j : 0);
+#pragma unroll
+                        for (int u0 = 0; u0 < 16; u0 += 8) {
+                            double al[8];
+#pragma unroll
+                            for (int u = 0; u < 8; ++u) al[u] = ap[(u0 + u) * CS];
+#define QRK_REG_LDOT(U) fmac_bcast<U>((U & 1) ? d1 : d0, xl[q], al[U & 7]);
+                            if (u0 == 0) { QRK_REG_LDOT(0) QRK_REG_LDOT(1) QRK_REG_LDOT(2) QRK_REG_LDOT(3) QRK_REG_LDOT(4) QRK_REG_LDOT(5) QRK_REG_LDOT(6) QRK_REG_LDOT(7) }
+                            else { QRK_REG_LDOT(8) QRK_REG_LDOT(9) QRK_REG_LDOT(10) QRK_REG_LDOT(11) QRK_REG_LDOT(12) QRK_REG_LDOT(13) QRK_REG_LDOT(14) QRK_REG_LDOT(15) }
+#undef QRK_REG_LDOT
+                        }
+                    }
+                }
             }
-            double d = halves_sum(d0 + d1);
-            if (in_lds) d = fma(s, ak, d);
+            double d = halves_sum(d0 + d1);                  // (x' holds s at the diagonal row: d includes s a_k)
             const double ngam = live ? d * ng : 0.0;         // -gamma of this column
             const double an = fma(s, ngam, ak);              // row kp of the updated column
             REG_TICK(7);
@@ -402,9 +431,26 @@ bdqr_reg_kernel(WaveBatch nb, const double* __restrict__ tiles, double* __restri
                 QRK_REG_16(QRK_REG_UPD)
 #undef QRK_REG_UPD
             }
-            if (in_lds && live) {
-                if (((kp ^ h) & 1) == 0) ldsA[kp * CS + j] = an;
-                for (int i = kp + 1 + ((kp + 1 + h) & 1); i < lim; i += 2) ldsA[i * CS + j] = fma(xv[i], ngam, ldsA[i * CS + j]);
+            if (in_lds) {
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    if (q == 0 && kp >= 32) continue;
+                    double* ap = ldsA + (16 * (h + 2 * q)) * CS + (isA ? j : 0);
+#pragma unroll
+                    for (int u0 = 0; u0 < 16; u0 += 8) {
+                        double al[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) al[u] = ap[(u0 + u) * CS];
+#define QRK_REG_LUPD(U) fmac_bcast<U>(al[U & 7], xl[q], ngam);
+                        if (u0 == 0) { QRK_REG_LUPD(0) QRK_REG_LUPD(1) QRK_REG_LUPD(2) QRK_REG_LUPD(3) QRK_REG_LUPD(4) QRK_REG_LUPD(5) QRK_REG_LUPD(6) QRK_REG_LUPD(7) }
+                        else { QRK_REG_LUPD(8) QRK_REG_LUPD(9) QRK_REG_LUPD(10) QRK_REG_LUPD(11) QRK_REG_LUPD(12) QRK_REG_LUPD(13) QRK_REG_LUPD(14) QRK_REG_LUPD(15) }
+#undef QRK_REG_LUPD
+                        if (live) {                          // (only the stores are predicated)
+#pragma unroll
+                            for (int u = 0; u < 8; ++u) ap[(u0 + u) * CS] = al[u];
+                        }
+                    }
+                }
             }
             REG_TICK(8);
             // row k of R and reflector k leave for the workspace now (fire and forget): nothing of a chosen column, and no row above
