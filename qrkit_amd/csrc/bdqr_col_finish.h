@@ -155,8 +155,9 @@ __device__ __forceinline__ void finish_tile(const double* __restrict__ W, const 
 //     dealt over the waves and summed through LDS; T with its row in registers.
 // Inputs, as bdqr_reg.hip leaves them in the workspace: Rw[k * 256 + j] = row k of R in ORIGINAL column order; Vb[k * 256 + i] =
 // essential part of reflector k at row i of the tile (i > k; anything elsewhere).  Qp: the frame.
-// vs [256 * (NB + 1)], gm [NB * NB], tm [NB * NB], gp [CT / 64][NB * NB]: LDS scratch.
-template <int CT>
+// vs [256 * (NB + 1)], gm [NB * NB], tm [NB * NB], gp [CT / 64][NB * NB]: LDS scratch -- TWICE each with PAIR (two panels of 16
+// reflectors per pass over Q: half the loads and stores of the frame, half the barriers; 512 threads).
+template <int CT, bool PAIR>
 __device__ __forceinline__ void finish_tile_strips(const double* __restrict__ Rw, const double* __restrict__ Vb, double* __restrict__ Qp,
                                                    const int r, const int c, const int cbase, const int* col_of_pos, const double* taus,
                                                    double* vs, double* gm, double* tm, double* gp, double* __restrict__ Q,
@@ -199,66 +200,94 @@ __device__ __forceinline__ void finish_tile_strips(const double* __restrict__ Rw
     }
     FIN_TICK(0);
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);      // (uniform for the compiler too: scalar bases below)
+    // LDS scratch per panel of a pass: V [256][VS], G, T, and the waves' partial G's
+    constexpr int NP = PAIR ? 2 : 1;
+    double* const vsp[2] = {vs, vs + 256 * VS};
+    double* const gmp[2] = {gm, gm + NB * NB};
+    double* const tmp_[2] = {tm, tm + NB * NB};
+    double* const gpp[2] = {gp, gp + NW * NB * NB};
+    const int npanels = (c + NB - 1) / NB;
     bool first = true;
-    for (int kp = ((c - 1) / NB) * NB; kp >= 0; kp -= NB) {
-        const int kb = (c - kp) < NB ? (c - kp) : NB;
+    for (int ptop = npanels - 1; ptop >= 0;) {
+        // a pass takes TWO panels (PAIR, and an even number of them left) or one: the strip of Q is loaded once, the upper panel's
+        // block reflector (rows kp + 16 ..) and then the lower one's (rows kp ..) are applied to it in registers, and it is stored once
+        const int npan = (PAIR && (ptop & 1)) ? 2 : 1;
+        const int kp = (ptop - (npan - 1)) * NB;   // first row / column of the pass (the lower panel)
         const int m = r - kp;
-        const int mt = (m + 15) >> 4;          // row tiles of a strip; V is zero-filled up to 16 mt rows
+        const int mt = (m + 15) >> 4;              // row tiles of a strip; V is zero-filled up to whole tiles
+        const int wb = kp + NB * npan;             // Q(wb:, wb:) is what earlier passes have written (unless this is the first)
         QRK_FIN_LANE();
-        {
-            // thread -> reflector l = tid / RPT, rows i = tid % RPT + RPT u: independent loads (a loop with one load per trip is a
-            // chain of memory latencies)
-            constexpr int RPT = CT / NB, NU = LD / RPT;
-            const int l = tid / RPT, i0 = tid % RPT;
-            double vv[NU];
+        // ---- V of the panels: panel x = 0 is the LOWER one (rows kp ..), x = 1 the upper (rows kp + 16 ..)
 #pragma unroll
-            for (int u = 0; u < NU; ++u) {
-                const int i = i0 + RPT * u;
-                vv[u] = (l < kb && i > l && i < m) ? Vb[(kp + l) * LD + kp + i] : (i == l && l < kb ? 1.0 : 0.0);
+        for (int x = 0; x < NP; ++x)
+            if (x < npan) {
+                const int kx = kp + NB * x, kb = (c - kx) < NB ? (c - kx) : NB, mx = r - kx, mtx = (mx + 15) >> 4;
+                // thread -> reflector l = tid / RPT, rows i = tid % RPT + RPT u: independent loads (a loop with one load per trip is a
+                // chain of memory latencies)
+                constexpr int RPT = CT / NB, NU = LD / RPT;
+                const int l = tid / RPT, i0 = tid % RPT;
+                double vv[NU];
+#pragma unroll
+                for (int u = 0; u < NU; ++u) {
+                    const int i = i0 + RPT * u;
+                    vv[u] = (l < kb && i > l && i < mx) ? Vb[(kx + l) * LD + kx + i] : (i == l && l < kb ? 1.0 : 0.0);
+                }
+#pragma unroll
+                for (int u = 0; u < NU; ++u) { const int i = i0 + RPT * u; if (i < 16 * mtx) vsp[x][i * VS + l] = vv[u]; }
             }
-#pragma unroll
-            for (int u = 0; u < NU; ++u) { const int i = i0 + RPT * u; if (i < 16 * mt) vs[i * VS + l] = vv[u]; }
-        }
         __syncthreads();
         FIN_TICK(1);
-        {
-            d4 g = d4{0.0, 0.0, 0.0, 0.0};
-            for (int k = wave_u; k < 4 * mt; k += NW) {
-                const double v = vs[(4 * k + kq) * VS + l15];
-                g = __builtin_amdgcn_mfma_f64_16x16x4f64(v, v, g, 0, 0, 0);
+#pragma unroll
+        for (int x = 0; x < NP; ++x)
+            if (x < npan) {
+                const int mtx = mt - x;
+                d4 g = d4{0.0, 0.0, 0.0, 0.0};
+                for (int k = wave_u; k < 4 * mtx; k += NW) {
+                    const double v = vsp[x][(4 * k + kq) * VS + l15];
+                    g = __builtin_amdgcn_mfma_f64_16x16x4f64(v, v, g, 0, 0, 0);
+                }
+#pragma unroll
+                for (int z = 0; z < 4; ++z) gpp[x][wave * NB * NB + (kq + 4 * z) * NB + l15] = g[z];   // G(row = kq + 4 z, col = l15)
             }
-#pragma unroll
-            for (int z = 0; z < 4; ++z) gp[wave * NB * NB + (kq + 4 * z) * NB + l15] = g[z];   // G(row = kq + 4 z, col = l15)
-        }
         __syncthreads();
-        if (tid < NB * NB) {
-            double g = 0.0;
+        // the first 256 threads sum the partial G's of the lower panel, the next 256 (if there are any) those of the upper one
+        {
+            const int x = PAIR ? (tid >> 8) : 0;
+            if (tid < NB * NB * NP && x < npan) {
+                const int e = tid & 255;
+                double g = 0.0;
 #pragma unroll
-            for (int w = 0; w < NW; ++w) g += gp[w * NB * NB + tid];
-            gm[tid] = g;
+                for (int w = 0; w < NW; ++w) g += gpp[x][w * NB * NB + e];
+                gmp[x][e] = g;
+            }
         }
         __syncthreads();
         FIN_TICK(2);
-        // T (forward, columnwise -- LAPACK larft): T(l,l) = tau_l, T(0:l,l) = -tau_l T(0:l,0:l) (V(:,0:l)^T v_l).  Lane (a, b) of the
-        // first four waves holds T(a, b) in a register; column l is sixteen products T(a, b) G(b, l) summed over b inside the row of
-        // 16 lanes by DPP: no LDS inside the recurrence (one thread per row, reading T and G from LDS, spent 12 000 cycles per panel)
-        if (tid < NB * NB) {
-            const int ta = tid >> 4, tb = tid & 15;
-            double g[NB];
+        // T (forward, columnwise -- LAPACK larft): T(l,l) = tau_l, T(0:l,l) = -tau_l T(0:l,0:l) (V(:,0:l)^T v_l).  Lane (a, b) of four
+        // waves holds T(a, b) in a register; column l is sixteen products T(a, b) G(b, l) summed over b inside the row of 16 lanes by
+        // DPP: no LDS inside the recurrence (one thread per row, reading T and G from LDS, spent 12 000 cycles per panel).  With two
+        // panels the second group of four waves does the upper one at the same time.
+        {
+            const int x = PAIR ? (tid >> 8) : 0;
+            if (tid < NB * NB * NP && x < npan) {           // (whole waves: the DPP sums need every lane of their rows)
+                const int kx = kp + NB * x, kb = (c - kx) < NB ? (c - kx) : NB;
+                const int ta = (tid & 255) >> 4, tb = tid & 15;
+                double g[NB];
 #pragma unroll
-            for (int l = 0; l < NB; ++l) g[l] = gm[tb * NB + l];
-            double tval = 0.0;
+                for (int l = 0; l < NB; ++l) g[l] = gmp[x][tb * NB + l];
+                double tval = 0.0;
 #pragma unroll
-            for (int l = 0; l < NB; ++l) {
-                const double tau = l < kb ? taus[kp + l] : 0.0;
-                double sum = tb < l ? tval * g[l] : 0.0;
-                sum += dpp_f64<0xB1>(sum);
-                sum += dpp_f64<0x4E>(sum);
-                sum += dpp_f64<0x141>(sum);
-                sum += dpp_f64<0x140>(sum);
-                if (tb == l) tval = ta == l ? tau : (ta < l ? -tau * sum : 0.0);
+                for (int l = 0; l < NB; ++l) {
+                    const double tau = l < kb ? taus[kx + l] : 0.0;
+                    double sum = tb < l ? tval * g[l] : 0.0;
+                    sum += dpp_f64<0xB1>(sum);
+                    sum += dpp_f64<0x4E>(sum);
+                    sum += dpp_f64<0x141>(sum);
+                    sum += dpp_f64<0x140>(sum);
+                    if (tb == l) tval = ta == l ? tau : (ta < l ? -tau * sum : 0.0);
+                }
+                tmp_[x][ta * NB + tb] = tval;
             }
-            tm[ta * NB + tb] = tval;
         }
         __syncthreads();
         FIN_TICK(3);
@@ -267,15 +296,18 @@ __device__ __forceinline__ void finish_tile_strips(const double* __restrict__ Rw
             double* qs = Qp + (kp * LD + kp + 16 * sidx);          // uniform: Q(kp + i, kp + 16 sidx + l15) = qs[i * LD + l15]
             const int loff = kq * LD + l15;
             d4 dv[MAXT];
-            // rows kp..kp+15 and columns kp..kp+15 (everything, for the first panel) have not been written yet: identity
-            if (!first && sidx >= 1) {
+            // what no earlier pass has written -- rows or columns below wb; everything, in the first pass -- is the identity
+            if (!first && kp + 16 * sidx >= wb) {
 #pragma unroll
-                for (int z = 0; z < 4; ++z) dv[0][z] = 0.0;
-#pragma unroll
-                for (int rt = 1; rt < MAXT; ++rt)
+                for (int rt = 0; rt < MAXT; ++rt)
                     if (rt < mt) {
+                        if (rt < npan) {
 #pragma unroll
-                        for (int z = 0; z < 4; ++z) dv[rt][z] = (qs + (16 * rt + 4 * z) * LD)[loff];
+                            for (int z = 0; z < 4; ++z) dv[rt][z] = 0.0;
+                        } else {
+#pragma unroll
+                            for (int z = 0; z < 4; ++z) dv[rt][z] = (qs + (16 * rt + 4 * z) * LD)[loff];
+                        }
                     }
             } else {
 #pragma unroll
@@ -284,20 +316,47 @@ __device__ __forceinline__ void finish_tile_strips(const double* __restrict__ Rw
                     for (int z = 0; z < 4; ++z) dv[rt][z] = (16 * rt + kq + 4 * z == 16 * sidx + l15) ? 1.0 : 0.0;
             }
             FIN_TICK(6);
+            // the upper panel first (Q <- H_lower (H_upper Q)): rows kp + 16 .. = tiles 1 .., columns kp + 16 .. = strips 1 ..
+            if (PAIR && npan == 2 && sidx >= 1) {
+                const double* v2 = vsp[1];
+                d4 acc = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int rt = 1; rt < MAXT; ++rt)
+                    if (rt < mt) {
+#pragma unroll
+                        for (int z = 0; z < 4; ++z)
+                            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(v2[(16 * (rt - 1) + 4 * z + kq) * VS + l15], dv[rt][z], acc, 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                d4 uu = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks)
+                    uu = __builtin_amdgcn_mfma_f64_16x16x4f64(tmp_[1][l15 * NB + 4 * ks + kq], acc[ks], uu, 0, 0, 0);
+                uu = -uu;
+#pragma unroll
+                for (int rt = 1; rt < MAXT; ++rt)
+                    if (rt < mt) {
+#pragma unroll
+                        for (int ks = 0; ks < 4; ++ks)
+                            dv[rt] = __builtin_amdgcn_mfma_f64_16x16x4f64(v2[(16 * (rt - 1) + l15) * VS + 4 * ks + kq], uu[ks], dv[rt], 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+            }
+            const double* v1 = vsp[0];
             d4 acc = d4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
             for (int rt = 0; rt < MAXT; ++rt)
                 if (rt < mt) {
 #pragma unroll
                     for (int z = 0; z < 4; ++z)
-                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(vs[(16 * rt + 4 * z + kq) * VS + l15], dv[rt][z], acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(v1[(16 * rt + 4 * z + kq) * VS + l15], dv[rt][z], acc, 0, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);     // (left alone, the scheduler hoists all 64 operand reads ahead of the MFMAs and spills)
                 }
             FIN_TICK(7);
             d4 uu = d4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks)
-                uu = __builtin_amdgcn_mfma_f64_16x16x4f64(tm[l15 * NB + 4 * ks + kq], acc[ks], uu, 0, 0, 0);
+                uu = __builtin_amdgcn_mfma_f64_16x16x4f64(tmp_[0][l15 * NB + 4 * ks + kq], acc[ks], uu, 0, 0, 0);
             uu = -uu;
             FIN_TICK(8);
 #pragma unroll
@@ -305,12 +364,12 @@ __device__ __forceinline__ void finish_tile_strips(const double* __restrict__ Rw
                 if (rt < mt) {
 #pragma unroll
                     for (int ks = 0; ks < 4; ++ks)
-                        dv[rt] = __builtin_amdgcn_mfma_f64_16x16x4f64(vs[(16 * rt + l15) * VS + 4 * ks + kq], uu[ks], dv[rt], 0, 0, 0);
+                        dv[rt] = __builtin_amdgcn_mfma_f64_16x16x4f64(v1[(16 * rt + l15) * VS + 4 * ks + kq], uu[ks], dv[rt], 0, 0, 0);
                     if (kp > 0) {
 #pragma unroll
                         for (int z = 0; z < 4; ++z) (qs + (16 * rt + 4 * z) * LD)[loff] = dv[rt][z];
                     } else {
-                        // the last panel writes every entry of Q: straight to m_Q's values (row-major Q_i; guarded stores cost no wait)
+                        // the last pass writes every entry of Q: straight to m_Q's values (row-major Q_i; guarded stores cost no wait)
 #pragma unroll
                         for (int z = 0; z < 4; ++z) {
                             const int row = 16 * rt + 4 * z + kq, col = 16 * sidx + l15;
@@ -322,6 +381,7 @@ __device__ __forceinline__ void finish_tile_strips(const double* __restrict__ Rw
         }
         FIN_TICK(9);
         first = false;
+        ptop -= npan;
         __syncthreads();
         FIN_TICK(4);
     }

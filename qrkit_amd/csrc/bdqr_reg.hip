@@ -166,7 +166,7 @@ __device__ __forceinline__ double recip(double x)
 }
 
 // doubles of the first LDS region: the LDS rows (8 waves) and, after phase 1, the scratch of the Q accumulation
-constexpr int scratch_doubles(int nw) { return PR * (NB + 1) + (2 + nw) * NB * NB; }
+constexpr int scratch_doubles(int nw) { return (nw == 8 ? 2 : 1) * (PR * (NB + 1) + (2 + nw) * NB * NB); }   // (8 waves: two panels per pass)
 constexpr int region_doubles(int nw) { return nw == 8 ? LR * CS : scratch_doubles(nw); }
 constexpr size_t lds_bytes(int nw)
 {
@@ -503,11 +503,12 @@ bdqr_reg_kernel(WaveBatch nb, const double* __restrict__ tiles, double* __restri
         if (tid == 0 && flags[2] != 0 && redo_count) redo_ids[atomicAdd(redo_count, 1)] = gidx;
         __syncthreads();
         // ---- R, the permutation, Q (scratch in the LDS rows, which are dead now)
+        constexpr int NPF = NW == 8 ? 2 : 1;                 // panels per pass of the Q accumulation
         double* vs = ldsA;
-        double* gm = vs + PR * (NB + 1);
-        double* tm = gm + NB * NB;
-        double* gp = tm + NB * NB;
-        colfin::finish_tile_strips<CT>(Rw, Vb, Qp, r, c, cbase, col_of_pos, taus, vs, gm, tm, gp, q_vals + qoff, r_vals + roff, perm);
+        double* gm = vs + NPF * PR * (NB + 1);
+        double* tm = gm + NPF * NB * NB;
+        double* gp = tm + NPF * NB * NB;
+        colfin::finish_tile_strips<CT, NW == 8>(Rw, Vb, Qp, r, c, cbase, col_of_pos, taus, vs, gm, tm, gp, q_vals + qoff, r_vals + roff, perm);
         __syncthreads();
         REG_TICK(2);
 #ifdef QRK_REG_PROF
