@@ -147,6 +147,7 @@ def parse(argv):
     ap.add_argument("--mixed-blocks", type=int, default=100000, help="N > 1: tiles of the configs[4] strong leg (mixed 8..256; 0 = skip)")
     ap.add_argument("--angular-blocks", type=int, default=20000, help="N > 1: tiles of the configs[3] strong leg (8x6 + 2000 dense columns; 0 = skip)")
     ap.add_argument("--no-e2e", action="store_true", help="N = 1: skip the host-buffer (PCIe-inclusive) figure")
+    ap.add_argument("--no-other", action="store_true", help="N = 1: skip the timing of BASELINE configs[4]'s share of one GPU (12 500 mixed tiles)")
     ap.add_argument("--_cpu-worker", type=float, default=None, help=argparse.SUPPRESS)
     return ap.parse_args(argv)
 
@@ -303,6 +304,11 @@ def main():
         if args.angular_blocks > 0:
             strong["configs3_angular"] = strong_angular(args, ctx, dev, dist, backend, rank, world, torch, np)
 
+    # ---- another BASELINE configuration on this GPU (N = 1; reported next to the headline, never as `value`)
+    other = None
+    if world == 1 and not args.no_other:
+        other = {"configs4_share_of_one_gpu": mixed_share(ctx, dev, torch, np)}
+
     # ---- end to end with host buffers (N = 1): tiles over PCIe in, Q / R / perm back (never the headline value)
     e2e = None
     if world == 1 and not args.no_e2e:
@@ -362,6 +368,8 @@ def main():
             out["strong_scaling"] = strong
         if e2e is not None:
             out["end_to_end_host_buffers"] = e2e
+        if other is not None:
+            out["other_configs"] = other
         if cpu is not None:
             out["cpu_baseline"] = cpu
         print(json.dumps(out), flush=True)
@@ -444,6 +452,40 @@ def _timed(dist, torch, dev, backend, fn, iters):
     tt = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
     dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     return tt.item() / iters
+
+
+def mixed_share(ctx, dev, torch, np, B=12500):
+    """BASELINE configs[4] is 100 000 mixed square tiles, n ~ U{8..256}, over 8 GPUs: one GPU's share, 12 500 tiles (seed 12345), inputs
+    resident in HBM, three warm-up factorisations (clocks), best and mean of five timed ones."""
+    from qrkit_amd import _capi as capi
+    n = np.random.default_rng(12345).integers(8, 257, B).astype(np.int32)
+    n64 = n.astype(np.int64)
+    lay = capi.BDLayout()
+    lay.num_blocks, lay.block_rows, lay.block_cols = B, 0, 0
+    lay.rows = n.ctypes.data_as(C.POINTER(C.c_int32)); lay.cols = n.ctypes.data_as(C.POINTER(C.c_int32))
+    lay.mat_rows = lay.mat_cols = int(n64.sum())
+    plan = C.c_void_p()
+    capi.check(capi.lib().qrk_bd_plan_create(ctx.handle, C.byref(lay), capi.FULL_Q, capi.COLPIV_HOUSEHOLDER, C.byref(plan)), ctx.handle)
+    g = torch.Generator(device=dev); g.manual_seed(777)
+    t = torch.rand(int((n64 * n64).sum()), generator=g, device=dev, dtype=torch.float64) * 2 - 1
+    q = torch.empty(int((n64 * n64).sum()), device=dev, dtype=torch.float64)
+    r = torch.empty(int((n64 * (n64 + 1) // 2).sum()), device=dev, dtype=torch.float64)
+    p = torch.empty(int(n64.sum()), device=dev, dtype=torch.int32)
+
+    def once():
+        capi.check(capi.lib().qrk_bd_factorize(plan, t.data_ptr(), q.data_ptr(), r.data_ptr(), p.data_ptr(), None, capi.MEM_DEVICE), ctx.handle)
+        torch.cuda.synchronize()
+    for _ in range(3):
+        once()
+    ts = []
+    for _ in range(5):
+        t0 = time.perf_counter(); once(); ts.append(time.perf_counter() - t0)
+    capi.lib().qrk_bd_plan_destroy(plan)
+    byts = float((8 * n64 * n64 + 8 * n64 * n64 + 4 * n64 * (n64 + 1) + 4 * n64).sum())
+    flops = float((2 * n64 ** 3 - 2 * n64 ** 3 / 3 + 4 * (n64 ** 3 / 3)).sum())
+    best, mean = min(ts), sum(ts) / len(ts)
+    return {"workload": f"{B} square tiles, n ~ U{{8..256}}, seed 12345: the share of one of 8 GPUs of BASELINE configs[4]; ColPivHouseholderQR, explicit Q",
+            "ms_best": best * 1e3, "ms_mean": mean * 1e3, "tiles_per_s": B / best, "algorithmic_GBs": byts / best / 1e9, "gflops": flops / best / 1e9}
 
 
 def strong_mixed(args, ctx, dev, dist, backend, rank, world, torch, np):

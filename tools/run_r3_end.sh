@@ -7,7 +7,7 @@ timeout -k 10 1100 python -m pytest tests -q -m gpu > $OUT/gpu_tests.txt 2>&1; e
 tail -3 $OUT/gpu_tests.txt
 timeout -k 10 400 python bench.py > $OUT/bench.json 2> $OUT/bench.err; tail -c 600 $OUT/bench.json
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/$OUT/prof -o bench -- python3 $ROOT/bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-steady --no-e2e > $ROOT/$OUT/prof.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/$OUT/prof -o bench -- python3 $ROOT/bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-steady --no-e2e --no-other > $ROOT/$OUT/prof.log 2>&1
 cd $ROOT
 f=$(find $OUT/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cut -c1-220 "$f" | head -8 > $OUT/kernel_stats.csv; cat $OUT/kernel_stats.csv
 tail -1 $OUT/prof.log | cut -c1-400 > $OUT/bench_profiled_line.txt

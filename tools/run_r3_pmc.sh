@@ -8,7 +8,7 @@ K2KERNEL=${3:-bdqr_reg}   # kernel whose dispatches are averaged in the K2 part 
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 mkdir -p "$ROOT/$OUT/k1" "$ROOT/$OUT/k2"
 cd /tmp && export TMPDIR=/tmp
-ARGS="--steps 16 --warmup 4 --no-cpu-baseline --no-steady --no-check --no-e2e"
+ARGS="--steps 16 --warmup 4 --no-cpu-baseline --no-steady --no-check --no-e2e --no-other"
 i=0
 if [ "$WHAT" != k2 ]; then
 for grp in "SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM" \
