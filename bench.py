@@ -138,6 +138,7 @@ def parse(argv):
     ap.add_argument("--steps", type=int, default=400)
     ap.add_argument("--warmup", type=int, default=40)
     ap.add_argument("--sets", type=int, default=8, help="distinct matrices rotated over (working set > L3)")
+    ap.add_argument("--batches", type=int, default=25, help="timed batches of exactly --steps steps each; the line reports the median batch")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true", help="skip the comparison of 500 tiles with the oracle (outside the timed region)")
@@ -248,15 +249,28 @@ def main():
 
     if args.warmup > 0:
         run(plan, args.warmup)
-    barrier()
-    t0 = time.perf_counter()
-    kernel_ms = run(plan, args.steps)   # K launches, HIP events on the launch stream around them
-    barrier()
-    wall = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([wall, kernel_ms], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        wall, kernel_ms = t[0].item(), t[1].item()
+    # A timed batch = EXACTLY --steps steps between barrier + synchronize on both sides, MAX over ranks.  K = 20 steps are 1.7 ms, too
+    # short for one sample to be robust (clock ramps, a neighbour on the host), so the batch is repeated --batches times back to
+    # back and the line reports the MEDIAN batch (every batch is in "timing").
+    walls, kmss = [], []
+    for _ in range(max(1, args.batches)):
+        barrier()
+        t0 = time.perf_counter()
+        kms = run(plan, args.steps)     # K launches, HIP events on the launch stream around them
+        barrier()
+        w = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([w, kms], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            w, kms = t[0].item(), t[1].item()
+        walls.append(w); kmss.append(kms)
+    order = sorted(range(len(walls)), key=lambda i: walls[i])
+    mid = order[len(order) // 2]
+    wall, kernel_ms = walls[mid], kmss[mid]
+    timing = {"batches": len(walls), "steps_per_batch": args.steps, "statistic": "median batch (wall clock around exactly --steps steps)",
+              "batch_ms_per_step_min_median_max": [min(walls) / args.steps * 1e3, wall / args.steps * 1e3, max(walls) / args.steps * 1e3],
+              "kernel_us_min_median_max": [min(kmss) * 1e3, sorted(kmss)[len(kmss) // 2] * 1e3, max(kmss) * 1e3],
+              "timed_region_ms_total": sum(walls) * 1e3}
 
     # ---- outside the timed region: the kernel instantiation that was just timed (tau not stored) against the oracle
     checked = None
@@ -307,7 +321,9 @@ def main():
     # ---- another BASELINE configuration on this GPU (N = 1; reported next to the headline, never as `value`)
     other = None
     if world == 1 and not args.no_other:
-        other = {"configs4_share_of_one_gpu": mixed_share(ctx, dev, torch, np)}
+        other = {"configs4_share_of_one_gpu": mixed_share(ctx, dev, torch, np),
+                 "configs2_strips": strips_config2(ctx, dev, torch, np),
+                 "configs3_angular": angular_config3(ctx, dev, torch, np)}
 
     # ---- end to end with host buffers (N = 1): tiles over PCIe in, Q / R / perm back (never the headline value)
     e2e = None
@@ -361,6 +377,7 @@ def main():
                          "kernel": kname, "avg_launch_ms": kernel_ms,
                          "algorithmic_bytes_per_launch": bytes_per_launch},
             "checked": checked if checked is not None else False,
+            "timing": timing,
         }
         if steady is not None:
             out["steady_state"] = steady
@@ -486,6 +503,73 @@ def mixed_share(ctx, dev, torch, np, B=12500):
     best, mean = min(ts), sum(ts) / len(ts)
     return {"workload": f"{B} square tiles, n ~ U{{8..256}}, seed 12345: the share of one of 8 GPUs of BASELINE configs[4]; ColPivHouseholderQR, explicit Q",
             "ms_best": best * 1e3, "ms_mean": mean * 1e3, "tiles_per_s": B / best, "algorithmic_GBs": byts / best / 1e9, "gflops": flops / best / 1e9}
+
+
+def strips_config2(ctx, dev, torch, np, N=2048):
+    """BASELINE configs[2] (block-banded, 64 x 64 blocks, bandwidth 3): strips of 256 x 192 at column step 64; N of the
+    50 000 strips (the chain's time is linear in N; the full size runs in tests/test_banded_strips_gpu.py).  Stage A (every strip
+    triangularised, all CUs) is also timed on its own through the block-diagonal solver it is; the chain is the difference."""
+    import qrkit_amd
+    from qrkit_amd.banded import BandedStripsQR
+    ms, n, s = 256, 192, 64
+    g = torch.Generator(device=dev); g.manual_seed(5)
+    strips = torch.rand(N * ms * n, device=dev, dtype=torch.float64, generator=g) * 2 - 1
+    qr = BandedStripsQR(N, ms, n, s, context=ctx)
+
+    def timed(fn, reps=3):
+        fn(); torch.cuda.synchronize()
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter(); fn(); torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
+        return min(ts)
+    t_all = timed(lambda: qr.factorize(strips))
+    rows, cols = np.full(N, ms, np.int32), np.full(N, n, np.int32)
+    bd = qrkit_amd.BlockDiagonalSparseQR(solver="householder", context=ctx)
+    mat = qrkit_amd.SparseBlockDiagonal.fromTiles(rows, cols, strips)
+    bd.analyzePattern(mat)
+    t_a = timed(lambda: bd.factorize(mat))
+    b = torch.rand(qr.rows(), device=dev, dtype=torch.float64, generator=g)
+    t_solve = timed(lambda: qr.solve(b), 2)
+    fl_a = N * (2.0 * ms * n * n - 2.0 * n ** 3 / 3)                     # Householder QR of a 256 x 192 strip
+    fl_b = N * 5.0e6                                                     # merge of two triangles (staircase), DESIGN.md K4
+    return {"workload": f"{N} strips of {ms} x {n}, column step {s} (BASELINE configs[2] has 50 000): qrk_bbs_factorize = stage A (strips "
+                        "triangularised as one batch) + stage B (the chain that merges the carried triangle with each strip's)",
+            "ms_total": t_all * 1e3, "ms_per_strip": t_all * 1e3 / N, "stage_a_ms": t_a * 1e3, "chain_ms_per_strip": (t_all - t_a) * 1e3 / N,
+            "projected_s_for_50000_strips": t_all / N * 50000, "solve_ms_per_strip": t_solve * 1e3 / N,
+            "roofline": {"bound": "fp64 of ONE CU for the chain (a true dependency strip to strip), fp64 of the chip for stage A",
+                         "stage_a_TFLOPs": fl_a / t_a / 1e12, "stage_a_frac_of_fp64_peak": fl_a / t_a / 1e12 / 78.6,
+                         "chain_GFLOPs": fl_b / max(t_all - t_a, 1e-9) / 1e9, "one_cu_fp64_peak_GFLOPs": 307.0,
+                         "chain_frac_of_one_cu": fl_b / max(t_all - t_a, 1e-9) / 1e9 / 307.0}}
+
+
+def angular_config3(ctx, dev, torch, np, B=20000, r=8, c=6, m2=2000):
+    """BASELINE configs[3] on ONE GPU: B tiles of 8 x 6 on the diagonal + a dense right block of (8 B) x 2000 (BlockAngularSparseQR:
+    left factor, Q1^T J2, pivoted QR of the bottom rows, makeR); compute() and solve()."""
+    import qrkit_amd
+    g = torch.Generator(device=dev); g.manual_seed(778)
+    tl = torch.rand(B * r * c, generator=g, device=dev, dtype=torch.float64) * 4.5 + 0.5
+    left = qrkit_amd.SparseBlockDiagonal.fromTiles(np.full(B, r, np.int32), np.full(B, c, np.int32), tl)
+    J2 = (torch.rand(m2, B * r, generator=g, device=dev, dtype=torch.float64) * 4.5 + 0.5).t()       # column-major (B r) x m2
+    ba = qrkit_amd.BlockAngularSparseQR(context=ctx)
+    mat = qrkit_amd.BlockMatrix1x2(left, J2)
+    b = torch.rand(B * r, generator=g, device=dev, dtype=torch.float64)
+
+    def timed(fn, reps=3):
+        fn(); torch.cuda.synchronize()
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter(); fn(); torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
+        return min(ts)
+    t_c = timed(lambda: ba.compute(mat))
+    t_s = timed(lambda: ba.solve(b))
+    n1, nb = B * r, B * r - B * c
+    fl_right = 2.0 * nb * m2 * m2 - 2.0 * m2 ** 3 / 3
+    flops = 4.0 * n1 * c * m2 + fl_right
+    return {"workload": f"{B} tiles of {r} x {c} + dense {n1} x {m2} right block on one GPU (BASELINE configs[3] un-sharded)",
+            "compute_ms": t_c * 1e3, "solve_ms": t_s * 1e3,
+            "roofline": {"bound": "mfma (pivoted QR of the dense bottom block, K3), hbm (Q1^T J2)", "TFLOPs": flops / t_c / 1e12,
+                         "fp64_peak_TFLOPs": 78.6, "frac_of_fp64_peak": flops / t_c / 1e12 / 78.6,
+                         "right_block_flop": fl_right, "J2_bytes": 8.0 * n1 * m2}}
 
 
 def strong_mixed(args, ctx, dev, dist, backend, rank, world, torch, np):

@@ -79,6 +79,9 @@
 #ifndef QRK_QSTORE_EVERY
 #define QRK_QSTORE_EVERY 8     // 4, 8 or 16
 #endif
+#ifndef QRK_TAILSQ_READLANE
+#define QRK_TAILSQ_READLANE 0  // 1: |x_tail|^2 leaves the pivot lane through v_readlane (SGPRs) instead of ds_bpermute (round-4 A/B)
+#endif
 
 // Diagnostic only (tools/stamp_run.py): -DQRK_STAMP records s_memtime of lane 0 at phase boundaries
 // of every pair into the hcoeffs buffer (12 x int64 per pair).
@@ -227,6 +230,7 @@ struct LaneState {
     bool live;       // this lane's A column is not yet chosen as a pivot
     bool ispiv;      // this lane's column is the pivot of the step whose head (search_fetch) ran last
     int lbl;         // ... and the pivot lane of this half, 0..31
+    int lpk;         // wave-uniform: pivot lane of half 0 | pivot lane of half 1 << 8
     unsigned long long livemask;   // the same as a wave-uniform lane mask
     int kstep;       // step at which this column was chosen (= its final position), 64 = not yet
     int rows, cols;  // tile shape of this half (rows/cols beyond are zero padding)
@@ -341,12 +345,14 @@ __device__ __forceinline__ void search_fetch(double* hl /* this half's LDS */, L
         const int lA = FULL32 ? __builtin_ctz(tlo) : (tlo ? __builtin_ctz(tlo) : 0);
         const int lB = FULL32 ? __builtin_ctz(thi) : (thi ? __builtin_ctz(thi) : 0);
         lbl = (int)__builtin_amdgcn_ubfe((unsigned)(lA | (lB << 8)), (unsigned)st.sh8, 5u);
+        st.lpk = lA | (lB << 8);
         st.livemask &= ~pm;
         // a chosen column leaves the search: negative "norm" (it only decreases from here on)
         st.nu2 = __hiloint2double(ispiv ? (int)0xBF800000 : khi, __double2loint(st.nu2));
     } else {
         ispiv = act && j == K;   // HouseholderQR: column K
         lbl = K;
+        st.lpk = K | (K << 8);
     }
     if (ispiv) { st.live = false; st.kstep = K; }
     st.ispiv = ispiv;
@@ -438,7 +444,17 @@ __device__ __forceinline__ void pair_step(double (&a)[WR], double (&q)[WR], doub
     //                                     c_i <- c_i - gamma x_i (= c_i - tau ess_i tmp),
     // which needs one square root and one reciprocal (of beta*w > 0) per step and no division.
     // Kept here: nb = -beta = copysign(norm, x0), s = -w = nb + x0, ng = -1/(beta w).
+#if QRK_TAILSQ_READLANE
+    double tailSq;
+    {
+        const int lA = st.lpk & 31, lB = 32 + ((st.lpk >> 8) & 31);
+        const int alo = __builtin_amdgcn_readlane(__double2loint(dA), lA), ahi = __builtin_amdgcn_readlane(__double2hiint(dA), lA);
+        const int blo = __builtin_amdgcn_readlane(__double2loint(dA), lB), bhi = __builtin_amdgcn_readlane(__double2hiint(dA), lB);
+        tailSq = __hiloint2double(st.half ? bhi : ahi, st.half ? blo : alo);
+    }
+#else
     const double tailSq = (QRK_ABL & 2) ? dA : bpermute_f64((lbl << 2) + st.hb4, dA);
+#endif
     const double nrm2 = fma(xk, xk, tailSq);
     const double nrm = (QRK_ABL & 8) ? nrm2 : sqrt_pos(nrm2);
     // Eigen: if (c0 >= 0) beta = -beta; -0.0 counts as >= 0, hence the + 0.0

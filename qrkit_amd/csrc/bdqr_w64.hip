@@ -1,0 +1,393 @@
+// bdqr_w64.hip -- tiles with 32 < max(rows, cols) <= 64 (rows >= cols) of a block-diagonal matrix, factorised ON CHIP by ONE
+// wavefront each: A_i P_i = Q_i R_i with explicit Q_i, for gfx950.
+//
+// Same reference seam as bdqr_pair.hip (the hot loop of QRKit::BlockDiagonalSparseQR::factorize,
+// src/QRKit/BlockDiagonalSparseQR.h:432-526: blockSolver.compute(block) :437-438 -- Eigen ColPivHouseholderQR / HouseholderQR --,
+// Qi = blockSolver.matrixQ() :446, the Q / R value assembly :455-500 and the column-permutation splice :519-521), for the size
+// class that bdqr_col.hip used to serve from an LDS-resident working copy with one thread per column walking down its column
+// (round 3: a 33 x 33 tile 11 x slower than a 32 x 32 one, 64 x 64 at 1.6 % of HBM).
+//
+// Layout: lane j owns column j of the tile in 64 row registers (the tile is aligned to the BOTTOM of a 64-row frame: padded row =
+// row + 64 - rows, so the steps are instantiated per padded row and a shorter tile simply starts later in the unrolled sequence).
+// No workgroup barrier anywhere: one wave per workgroup, LDS is in order.  Two phases, because A and Q do not fit the registers of a
+// wave together (128 + 128 VGPRs, two waves per SIMD):
+//   phase 1  A -> R: the step of bdqr_pair.hip (squared norms with the LAWN-176 downdate, integer arg-max on the high words, the
+//            un-normalised reflector, decisions inside their error margin flag the tile for the exact path), except that the pivot
+//            column reaches the lanes by being PUBLISHED: its lane writes it to LDS (16-byte stores of one lane), where it is also
+//            what phase 2 needs -- reflector k.  Every lane then takes element (lane & 15) of each 16-row chunk into a register and
+//            the dot product / rank-1 update read the column through the DPP row_newbcast operand of v_fmac_f64.  Row k of R stays
+//            in row register k of its lane (later steps only touch the rows below); R leaves the registers at the end of the phase.
+//   phase 2  Q = H_0 ... H_{c-1} I by BACKWARD accumulation (HouseholderSequence::evalTo's order) in the registers phase 1 has
+//            freed: lane j owns column j of Q; step k reads reflector k from LDS the same way.  No search, no square root: a stream
+//            of FMAs that the other wave of the SIMD, which is in another phase of another tile, overlaps with its latency chain.
+// 18.4 KB of LDS per wave: eight tiles in flight per CU.
+#include "qrk_device.h"
+
+#include <float.h>
+#include <cstdlib>
+
+namespace qrk {
+
+namespace w64 {
+
+using namespace decide;
+
+constexpr int WR = 64;                   // rows of the frame = row registers per lane
+constexpr int FILTER = 256;              // pivot candidates: high word of the squared norm within 2^-12 (relative) of the largest
+constexpr double SQRT_EPS_HI = THR_HI;   // sqrt(eps) (1 + 2^-12)
+
+// LDS (doubles): reflector KP (the pivot column of the step at padded row KP, as published) holds padded rows (KP & ~1) .. 63 at
+// cb(KP): every column starts on a 16-byte boundary.
+constexpr int cb(int kp) { int s = 0; for (int k = 0; k < kp; ++k) s += WR - (k & ~1); return s; }
+constexpr int L_V = 0;
+constexpr int L_S = cb(WR);              // [64] s = x0 - beta of the step at padded row KP
+constexpr int L_NG = L_S + WR;           // [64] -1 / (beta (x0 - beta))
+constexpr int L_TAU = L_NG + WR;         // [64]
+constexpr int L_TOTAL = L_TAU + WR;      // 2304 doubles = 18 432 B
+static_assert(cb(WR) == 2112 && (L_TOTAL * 8) * 8 <= 160 * 1024, "eight waves per CU");
+
+#define QRK_W64_0_63(M)                                                                                                              \
+    M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9) M(10) M(11) M(12) M(13) M(14) M(15) M(16) M(17) M(18) M(19) M(20) M(21) M(22)  \
+    M(23) M(24) M(25) M(26) M(27) M(28) M(29) M(30) M(31) M(32) M(33) M(34) M(35) M(36) M(37) M(38) M(39) M(40) M(41) M(42) M(43)   \
+    M(44) M(45) M(46) M(47) M(48) M(49) M(50) M(51) M(52) M(53) M(54) M(55) M(56) M(57) M(58) M(59) M(60) M(61) M(62) M(63)
+#define QRK_W64_63_0(M)                                                                                                              \
+    M(63) M(62) M(61) M(60) M(59) M(58) M(57) M(56) M(55) M(54) M(53) M(52) M(51) M(50) M(49) M(48) M(47) M(46) M(45) M(44) M(43)   \
+    M(42) M(41) M(40) M(39) M(38) M(37) M(36) M(35) M(34) M(33) M(32) M(31) M(30) M(29) M(28) M(27) M(26) M(25) M(24) M(23) M(22)   \
+    M(21) M(20) M(19) M(18) M(17) M(16) M(15) M(14) M(13) M(12) M(11) M(10) M(9) M(8) M(7) M(6) M(5) M(4) M(3) M(2) M(1) M(0)
+
+__device__ __forceinline__ double sqrt_pos(double x)      // <= 1 ulp for positive normal x (bdqr_pair.hip)
+{
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = 0.5 * y;
+    const double e = fma(-h, g, 0.5);
+    g = fma(g, e, g);
+    h = fma(h, e, h);
+    const double d = fma(-g, g, x);
+    return fma(d, h, g);
+}
+__device__ __forceinline__ double recip(double x)
+{
+    double y = __builtin_amdgcn_rcp(x);
+    double e = fma(-x, y, 1.0);
+    y = fma(y, e, y);
+    e = fma(-x, y, 1.0);
+    y = fma(y, e, y);
+    return y;
+}
+
+// d += X[N] * c, X read through DPP row_newbcast (element N of the lane's row of 16 lanes), see bdqr_pair.hip
+template <int N>
+__device__ __forceinline__ void fmac_bcast(double& d, double X, double c)
+{
+    asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(d) : "v"(X), "v"(c), "n"(N));
+}
+// element N of the row's X in every lane of the row
+template <int N>
+__device__ __forceinline__ double bcast_f64(double X)
+{
+    double r;
+    asm("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(X), "n"(N));
+    return r;
+}
+// sum over every row of 16 lanes, the same bits in every lane of the row
+__device__ __forceinline__ double row16_sum(double v)
+{
+    v += dpp_f64<0xB1>(v);
+    v += dpp_f64<0x4E>(v);
+    v += dpp_f64<0x141>(v);
+    v += dpp_f64<0x140>(v);
+    return v;
+}
+__device__ __forceinline__ double uniform_f64(double v)      // a wave-uniform value into scalar registers
+{
+    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
+// max over the wave, in scalar registers
+__device__ __forceinline__ int wave_max_i32(int v)
+{
+    const int m = half32_max_i32_fused(v);
+    const int a = __builtin_amdgcn_readlane(m, 0), b = __builtin_amdgcn_readlane(m, 32);
+    return a > b ? a : b;
+}
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v)
+{
+    const unsigned m = half32_max_u32(v);
+    const unsigned a = (unsigned)__builtin_amdgcn_readlane((int)m, 0), b = (unsigned)__builtin_amdgcn_readlane((int)m, 32);
+    return a > b ? a : b;
+}
+
+struct Lane {
+    int lane;
+    bool live;        // this lane's column of A is not yet chosen
+    bool unclear;     // a decision of the tile was inside its error margin (any lane)
+    int kstep;        // position at which this lane's column was chosen
+    double nu2;       // m_colNormsUpdated^2 (a chosen column carries a negative value: it drops out of the integer arg-max)
+    double thr;       // sqrt(eps) (1 + 2^-12) m_colNormsDirect^2
+    double a2;        // |A|^2: squared norm of the first pivot column (scale of the decision margins); wave-uniform
+};
+
+// The elements of the published column that this lane broadcasts: xc[m] = element 16 m + (lane & 15), for the chunks with rows below KP.
+template <int KP>
+__device__ __forceinline__ void load_chunks(const double* lds, int lane, double (&xc)[4])
+{
+    constexpr int M0 = (KP + 1) >> 4;                              // first chunk with a row > KP
+    const double* vcol = lds + L_V + cb(KP) - (KP & ~1) + (lane & 15);
+#pragma unroll
+    for (int m = M0; m < 4; ++m) xc[m] = vcol[16 * m];
+}
+
+// One step of ColPivHouseholderQR::computeInPlace (Eigen/src/QR/ColPivHouseholderQR.h) / HouseholderQR on the wave's tile; KP = padded
+// row of the diagonal, k = KP - off the step.
+template <int KP, bool PIVOT>
+__device__ __forceinline__ void step(double (&a)[WR], double* lds, Lane& st, const int k, const int rows)
+{
+    const int lane = st.lane;
+    // ---- 1. pivot: first maximum of the updated norms over the live columns.  Non-negative doubles order like their bit patterns:
+    // integer max on the high words; every lane within FILTER units is a candidate, a single candidate is a clear decision
+    int P;
+    if (PIVOT) {
+        const int khi = __double2hiint(st.nu2);
+        const int mh = wave_max_i32(khi);
+        unsigned long long pm = __builtin_amdgcn_ballot_w64(khi >= mh - FILTER);
+        if (__builtin_expect((pm & (pm - 1ull)) != 0ull, 0)) {
+            // several: the largest (lowest lane among exact ties: any valid choice will do, the tile is flagged then) and the check
+            // of the decision: a live column within the error margin of the chosen one sends the tile to the exact path, which owns
+            // Eigen's first-maximum rule on the current positions
+            asm volatile("");
+            bool cand = st.live && khi == mh;
+            const unsigned klo = (unsigned)__double2loint(st.nu2);
+            const unsigned ml = wave_max_u32(cand ? klo : 0u);
+            cand = cand && klo == ml;
+            pm = __builtin_amdgcn_ballot_w64(cand);
+            const int Pn = (int)__builtin_ctzll(pm);
+            const double best = readlane_f64(st.nu2, Pn), thrb = readlane_f64(st.thr, Pn);
+            double margin = MREL * (st.thr + thrb);
+            if (k > 0) margin += 4.547473508864641e-13 /* 2^-41 */ * __builtin_sqrt(st.a2 * (best > 0.0 ? best : 0.0));
+            if (st.live && lane != Pn && st.nu2 >= best - margin) st.unclear = true;
+            pm = 1ull << Pn;
+        }
+        P = (int)__builtin_ctzll(pm);
+        if (k == 0) st.a2 = readlane_f64(st.nu2, P);
+    } else {
+        P = k;
+    }
+    const bool ispiv = lane == P;
+    if (ispiv) {
+        st.live = false; st.kstep = k;
+        st.nu2 = __hiloint2double((int)0xBF800000, __double2loint(st.nu2));
+        // ---- 2. publish the column (it is reflector k of phase 2 as well)
+        double* vcol = lds + L_V + cb(KP) - (KP & ~1);
+#pragma unroll
+        for (int i = KP & ~1; i < WR; i += 2) *reinterpret_cast<double2*>(&vcol[i]) = make_double2(a[i], a[i + 1]);
+    }
+    __builtin_amdgcn_wave_barrier();
+    // ---- 3. the lanes' elements of it, |x_tail|^2 (every row of 16 lanes the same sum in the same order), x0
+    double xc[4] = {0.0, 0.0, 0.0, 0.0};
+    double tsq = 0.0, xk;
+    constexpr int M0 = (KP + 1) >> 4, MK = KP >> 4;
+    if (KP + 1 < WR) {
+        load_chunks<KP>(lds, lane, xc);
+        double p = 0.0;
+#pragma unroll
+        for (int m = M0; m < 4; ++m) {
+            const double x = (m == MK) ? (((lane & 15) > (KP & 15)) ? xc[m] : 0.0) : xc[m];
+            p = fma(x, x, p);
+        }
+        tsq = uniform_f64(row16_sum(p));
+    }
+    if (MK >= M0) xk = uniform_f64(bcast_f64<(KP & 15)>(xc[MK]));
+    else xk = uniform_f64(lds[L_V + cb(KP) + (KP & 1)]);          // (row KP is the last one of its chunk: no element of that chunk was loaded)
+    if (k == 0 && !PIVOT) st.a2 = fma(xk, xk, tsq);
+    if (unclear_reflector(xk, tsq, k + 1 < rows, PIVOT, st.a2)) st.unclear = true;
+    // ---- 4. makeHouseholder in the un-normalised form (bdqr_pair.hip): nb = -beta = copysign(norm, x0), s = x0 - beta,
+    // ng = -1 / (beta (x0 - beta)); Eigen: tailSqNorm <= min() gives tau = 0, beta = x0, H = I
+    double beta, s, ng, tau;
+    if (!(tsq > DBL_MIN)) { beta = xk; s = 0.0; ng = 0.0; tau = 0.0; }
+    else {
+        const double nrm = sqrt_pos(fma(xk, xk, tsq));
+        const double nbv = xk >= 0.0 ? nrm : -nrm;         // (-0.0 counts as >= 0, as in Eigen)
+        beta = uniform_f64(-nbv);
+        s = uniform_f64(nbv + xk);
+        ng = uniform_f64(-recip(nbv * s));
+        tau = -(s * s) * ng;
+    }
+    if (lane == 0) { lds[L_S + KP] = s; lds[L_NG + KP] = ng; lds[L_TAU + KP] = tau; }
+    // ---- 5. d = x_tail^T a_tail, the coefficient of the column, row k of R
+    const double ak = a[KP];
+    double d0 = 0.0, d1 = 0.0;
+#pragma unroll
+    for (int m = M0; m < 4; ++m) asm volatile("s_nop 1" : "+v"(xc[m]));      // (VALU write -> DPP read hazard, hidden from hipcc by the asm)
+#define QRK_W64_DOT(I) if ((I) > KP) fmac_bcast<((I) & 15)>(((I) & 1) ? d1 : d0, xc[(I) >> 4], a[I]);
+    QRK_W64_0_63(QRK_W64_DOT)
+#undef QRK_W64_DOT
+    const double ngam = fma(s, ak, d0 + d1) * ng;            // -gamma of this column
+    double an = fma(s, ngam, ak);
+    if (ispiv) an = beta;                                    // R(k, k)
+    a[KP] = an;                                              // final: later steps work on the rows below
+    // ---- 6. the trailing update a_tail -= gamma x_tail (columns already chosen are not masked out: nothing below the diagonal of R
+    // is ever read, and what they hold stays bounded -- the reflectors are orthogonal)
+#define QRK_W64_UPD(I) if ((I) > KP) fmac_bcast<((I) & 15)>(a[I], xc[(I) >> 4], ngam);
+    QRK_W64_0_63(QRK_W64_UPD)
+#undef QRK_W64_UPD
+    // ---- 7. LAWN-176 norm downdate (squared form; no clamp at zero: a negative value is <= the threshold and recomputed)
+    if (PIVOT && KP + 1 < WR) {
+        const double nn = fma(-an, an, st.nu2);
+        st.nu2 = nn;
+        const bool need = st.live && nn <= st.thr;
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(need) != 0ull, 0)) {
+            asm volatile("");
+            if (need && in_recompute_band(nn, st.thr, st.a2)) st.unclear = true;      // decision (2)
+            double sq = 0.0;
+#define QRK_W64_SQ(I) if ((I) > KP) sq = fma(a[I], a[I], sq);
+            QRK_W64_0_63(QRK_W64_SQ)
+#undef QRK_W64_SQ
+            if (need) { st.nu2 = sq; st.thr = sq * SQRT_EPS_HI; }
+        }
+    }
+}
+
+// Q_k = H_k Q_{k+1} on the wave's columns of Q: reflector k from LDS (x_tail as published, s, ng).
+template <int KP>
+__device__ __forceinline__ void back_step(double (&q)[WR], const double* lds, const int lane)
+{
+    constexpr int M0 = (KP + 1) >> 4;
+    const double s = uniform_f64(lds[L_S + KP]), ng = uniform_f64(lds[L_NG + KP]);
+    double xc[4] = {0.0, 0.0, 0.0, 0.0};
+    if (KP + 1 < WR) load_chunks<KP>(lds, lane, xc);
+    const double qk = q[KP];
+    double d0 = 0.0, d1 = 0.0;
+#pragma unroll
+    for (int m = M0; m < 4; ++m) asm volatile("s_nop 1" : "+v"(xc[m]));
+#define QRK_W64_DOT(I) if ((I) > KP) fmac_bcast<((I) & 15)>(((I) & 1) ? d1 : d0, xc[(I) >> 4], q[I]);
+    QRK_W64_0_63(QRK_W64_DOT)
+#undef QRK_W64_DOT
+    const double ngam = fma(s, qk, d0 + d1) * ng;
+    q[KP] = fma(s, ngam, qk);
+#define QRK_W64_UPD(I) if ((I) > KP) fmac_bcast<((I) & 15)>(q[I], xc[(I) >> 4], ngam);
+    QRK_W64_0_63(QRK_W64_UPD)
+#undef QRK_W64_UPD
+}
+
+}  // namespace w64
+
+// PIVOT: ColPivHouseholderQR (else HouseholderQR).  One wave per workgroup; the workgroups take their tiles through `queue`
+// (largest first: tile_ids is sorted by size).
+template <bool PIVOT>
+__global__ void __launch_bounds__(64, 2)
+bdqr_w64_kernel(WaveBatch nb, const double* __restrict__ tiles, double* __restrict__ q_vals, double* __restrict__ r_vals,
+                int32_t* __restrict__ perm, double* __restrict__ hcoeffs, int32_t* __restrict__ redo_count,
+                int32_t* __restrict__ redo_ids, int32_t* __restrict__ queue)
+{
+    using namespace w64;
+    __shared__ __attribute__((aligned(16))) double lds[L_TOTAL];
+
+    for (int64_t t = blockIdx.x; t < nb.num_tiles;) {
+        const int gidx = nb.tile_ids ? nb.tile_ids[t] : (int)t;
+        int r, c, cbase;
+        int64_t toff, qoff, roff;
+        if (nb.t_rows) {
+            r = nb.t_rows[gidx]; c = nb.t_cols[gidx];
+            toff = nb.t_off[gidx]; qoff = nb.q_off[gidx]; roff = nb.r_off[gidx]; cbase = nb.c_off[gidx];
+        } else {
+            r = nb.rows; c = nb.cols;
+            toff = t * (int64_t)r * c; qoff = t * (int64_t)r * r; roff = t * (int64_t)(c * (c + 1) / 2);
+            cbase = (int)(t * c);
+        }
+        r = __builtin_amdgcn_readfirstlane(r); c = __builtin_amdgcn_readfirstlane(c);
+        const int off = WR - r;                               // padded row of row 0
+        // (per-lane values are re-derived from an opaque lane id in every phase: hipcc otherwise hoists loop-invariant address
+        //  arithmetic out of the tile loop and keeps it in registers across the factorisation)
+        int lane = threadIdx.x;
+        asm volatile("" : "+v"(lane));
+
+        Lane st;
+        st.lane = lane; st.unclear = false; st.kstep = 0; st.a2 = 0.0;
+        {
+            // =============== phase 1: A -> R ===============
+            double a[WR];
+            const bool isA = lane < c;
+            st.live = isA;
+            {
+                // lane j reads its column (unconditional loads from clamped addresses, then a select)
+                const double* colp = tiles + toff + (int64_t)(isA ? lane : 0) * r;
+#pragma unroll
+                for (int i = 0; i < WR; ++i) {
+                    const int row = i - off;
+                    const double v = colp[row > 0 ? row : 0];
+                    a[i] = (isA && row >= 0) ? v : 0.0;
+                }
+            }
+            {
+                double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+                for (int i = 0; i < WR; i += 2) { s0 = fma(a[i], a[i], s0); s1 = fma(a[i + 1], a[i + 1], s1); }
+                const double s = s0 + s1;
+                st.nu2 = isA ? s : -1.0;
+                st.thr = s * SQRT_EPS_HI;
+            }
+#define QRK_W64_STEP(KP) if ((KP) >= off && (KP) - off < c) step<KP, PIVOT>(a, lds, st, (KP) - off, r);
+            QRK_W64_0_63(QRK_W64_STEP)
+#undef QRK_W64_STEP
+
+            // ---- R: lane j holds column p = kstep of R in padded rows off .. off + p; the packed CSC value order of m_R
+            // (BlockDiagonalSparseQR.h:475-479) puts entry (i, p) at p (p + 1) / 2 + i -- a contiguous run per lane, stored straight
+            // from the registers; the permutation splice (:519-521): the column chosen at step p ends at position p
+            int ln = threadIdx.x;
+            asm volatile("" : "+v"(ln));
+            if (ln < c) {
+                const int p = st.kstep;
+                perm[cbase + p] = cbase + ln;
+                double* dst = r_vals + roff + ((p * (p + 1)) >> 1) - off;
+#pragma unroll
+                for (int i = 0; i < WR; ++i)
+                    if (i >= off && i - off <= p) dst[i] = a[i];
+                if (hcoeffs) hcoeffs[cbase + ln] = lds[L_TAU + off + ln];
+            }
+            // a decision inside its error margin: the tile is redone by the exact path (bdqr_exact.hip)
+            if (__builtin_amdgcn_ballot_w64(st.unclear) != 0ull && redo_count && ln == 0) redo_ids[atomicAdd(redo_count, 1)] = gidx;
+        }
+        {
+            // =============== phase 2: Q = H_0 ... H_{c-1}, backward ===============
+            int ln = threadIdx.x;
+            asm volatile("" : "+v"(ln));
+            double q[WR];
+#pragma unroll
+            for (int i = 0; i < WR; ++i) q[i] = (i == ln + off) ? 1.0 : 0.0;       // (lanes >= rows: zero columns, never stored)
+#define QRK_W64_BACK(KP) if ((KP) >= off && (KP) - off < c) back_step<KP>(q, lds, ln);
+            QRK_W64_63_0(QRK_W64_BACK)
+#undef QRK_W64_BACK
+            // row-major rows of Q_i are the CSR value order of m_Q in both FullQ ([U|N] split, :455-471) and BlockDiagonalQ
+            // (:480-492) layouts: one coalesced store per row
+            if (ln < r) {
+                double* dst = q_vals + qoff + ln;
+#pragma unroll
+                for (int i = 0; i < WR; ++i)
+                    if (i >= off) dst[(int64_t)(i - off) * r] = q[i];
+            }
+        }
+        // next tile (the LDS of this one is dead: every lane is past its last read)
+        int nxt = 0;
+        if (threadIdx.x == 0) nxt = (int)gridDim.x + atomicAdd(queue, 1);
+        t = __builtin_amdgcn_readfirstlane(nxt);
+    }
+}
+
+bool bdqr_w64_supported(int rows, int cols) { return rows >= cols && rows <= w64::WR && rows > 32; }
+
+// Tiles with 32 < rows <= 64, cols <= rows.  queue: one int32 (zeroed here) through which the workgroups take their next tile.
+hipError_t launch_bdqr_w64(const WaveBatch& nb, const double* tiles, double* q_vals, double* r_vals, int32_t* perm, double* hcoeffs,
+                           int num_wg, int32_t* redo_count, int32_t* redo_ids, int32_t* queue, hipStream_t stream)
+{
+    if (nb.num_tiles <= 0) return hipSuccess;
+    if (hipError_t e = hipMemsetAsync(queue, 0, sizeof(int32_t), stream)) return e;
+    const int64_t want = nb.num_tiles < (int64_t)num_wg ? nb.num_tiles : (int64_t)num_wg;
+    if (nb.pivoting)
+        hipLaunchKernelGGL(bdqr_w64_kernel<true>, dim3((unsigned)want), dim3(64), 0, stream, nb, tiles, q_vals, r_vals, perm, hcoeffs,
+                           redo_count, redo_ids, queue);
+    else
+        hipLaunchKernelGGL(bdqr_w64_kernel<false>, dim3((unsigned)want), dim3(64), 0, stream, nb, tiles, q_vals, r_vals, perm, hcoeffs,
+                           redo_count, redo_ids, queue);
+    return hipGetLastError();
+}
+
+}  // namespace qrk

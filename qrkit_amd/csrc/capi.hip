@@ -75,6 +75,10 @@ struct qrk_bd_plan_s {
     } col_cls[3];
     int32_t* d_col_ids = nullptr;
     int64_t n_col = 0;
+    // tiles with 32 < rows <= 64 (cols <= rows): one wavefront each, on chip (bdqr_w64.hip); mixed batches: largest first
+    int32_t* d_w64_ids = nullptr;
+    int64_t n_w64 = 0;
+    bool w64_uniform = false;            // a uniform batch of such tiles
     double* d_col_workspace = nullptr;   // one part per class
     // redo list of the exact path: [0], [1] = counters of this / the next factorisation (ping-pong: the exact kernel zeroes the
     // other one, so no memset sits on the stream), [2..2+B) = global tile ids
@@ -304,7 +308,9 @@ qrk_status enqueue_factorize(qrk_bd_plan_s* p, const double* tiles, double* q, d
         const bool full32 = p->r == 32 && p->c == 32 &&
                             ((reinterpret_cast<uintptr_t>(tiles) | reinterpret_cast<uintptr_t>(q) |
                               reinterpret_cast<uintptr_t>(r)) & 15u) == 0;
-        if (p->max_dim > 32 && p->max_dim <= QRK_COL_MAX_DIM) {
+        if (p->w64_uniform)
+            QRK_HIP(h, qrk::launch_bdqr_w64(nb, tiles, q, r, perm, hc, h->num_cus * 8, redo_cnt, redo_ids, p->d_redo + 2 + p->B + 3, h->stream));
+        else if (p->max_dim > 32 && p->max_dim <= QRK_COL_MAX_DIM) {
             const auto& k = p->col_cls[0];
             QRK_HIP(h, launch_col_class(k, nb, tiles, q, r, perm, hc, p->d_col_workspace, redo_cnt, redo_ids, p->d_redo + 2 + p->B, h->stream));
         } else if (p->max_dim > 32)
@@ -325,6 +331,11 @@ qrk_status enqueue_factorize(qrk_bd_plan_s* p, const double* tiles, double* q, d
         nb.t_rows = p->d_rows; nb.t_cols = p->d_cols; nb.t_off = p->d_toff;
         nb.q_off = p->d_qoff; nb.r_off = p->d_roff; nb.c_off = p->d_coff;
         qrk::launch_bdqr_pair(nb, false, tiles, q, r, perm, hc, h->num_cus * h->pair_wgs_per_cu, redo_cnt, redo_ids, h->stream);
+        if (p->n_w64 > 0) {
+            qrk::WaveBatch wb = nb;
+            wb.num_tiles = p->n_w64; wb.tile_ids = p->d_w64_ids;
+            QRK_HIP(h, qrk::launch_bdqr_w64(wb, tiles, q, r, perm, hc, h->num_cus * 8, redo_cnt, redo_ids, p->d_redo + 2 + p->B + 3, h->stream));
+        }
         // the size classes are independent of each other and of the small tiles above: each on its own side stream
         // (forked after what is already queued on the caller's stream, joined back below), so that the tail of one
         // launch overlaps the others
@@ -556,7 +567,9 @@ qrk_status qrk_bd_plan_create(qrk_handle h, const qrk_bd_layout* L, qrk_q_format
 
     const int64_t B = p->B;
     int64_t sum_rows = 0, sum_cols = 0;
-    std::vector<int32_t> coff, rowoff, wave_ids, wg_ids, col_ids, col_bin[3];
+    std::vector<int32_t> coff, rowoff, wave_ids, wg_ids, col_ids, col_bin[3], w64_ids;
+    // 32 < rows <= 64: one wavefront per tile, on chip (bdqr_w64.hip); QRK_W64=0 keeps bdqr_col.hip's LDS-resident form (cross-check)
+    static const bool use_w64 = !(std::getenv("QRK_W64") && std::atoi(std::getenv("QRK_W64")) == 0);
     int64_t ws_stride = 0;
     std::vector<int64_t> toff, qoff, roff;
     if (p->uniform) {
@@ -569,6 +582,7 @@ qrk_status qrk_bd_plan_create(qrk_handle h, const qrk_bd_layout* L, qrk_q_format
         p->landscape = p->r < p->c;
         p->max_dim = p->r > p->c ? p->r : p->c;
         if (p->max_dim > QRK_COL_MAX_DIM) ws_stride = (int64_t)p->r * p->c;
+        else if (use_w64 && !p->landscape && p->max_dim > 32 && qrk::bdqr_w64_supported(p->r, p->c)) p->w64_uniform = true;
         else if (p->max_dim > 32 && !p->landscape) {
             auto& k = p->col_cls[0];
             k.n = B; k.ws_stride = (int64_t)p->r * p->c; k.max_rows = p->r; k.max_cols = p->c;
@@ -589,6 +603,7 @@ qrk_status qrk_bd_plan_create(qrk_handle h, const qrk_bd_layout* L, qrk_q_format
             const int32_t md = r > c ? r : c;
             if (md > p->max_dim) p->max_dim = md;
             if (md <= 32) wave_ids.push_back((int32_t)i);
+            else if (use_w64 && qrk::bdqr_w64_supported(r, c)) w64_ids.push_back((int32_t)i);
             else if (md <= QRK_COL_MAX_DIM && r >= c) {
                 // classes: up to 64 columns (one wave per tile, many workgroups per CU) and the rest (bdqr_col.hip: own instantiation
                 // and LDS layout each)
@@ -678,7 +693,7 @@ qrk_status qrk_bd_plan_create(qrk_handle h, const qrk_bd_layout* L, qrk_q_format
             wgs = std::max<int64_t>(1, std::min(wgs, cap));
         }
         p->exact_num_wg = (int)std::min<int64_t>(wgs, B);
-        if (hipMalloc((void**)&p->d_redo, (size_t)(B + 2 + 3) * sizeof(int32_t)) != hipSuccess ||
+        if (hipMalloc((void**)&p->d_redo, (size_t)(B + 2 + 4) * sizeof(int32_t)) != hipSuccess ||
             hipMemset(p->d_redo, 0, 2 * sizeof(int32_t)) != hipSuccess ||   /* synchronous: the first factorisation may run on another stream */
             (p->exact_ws_stride > 0 &&
              hipMalloc((void**)&p->d_exact_ws, (size_t)p->exact_num_wg * (size_t)p->exact_ws_stride * sizeof(double)) != hipSuccess)) {
@@ -687,17 +702,23 @@ qrk_status qrk_bd_plan_create(qrk_handle h, const qrk_bd_layout* L, qrk_q_format
         }
     }
     if (!p->uniform) {
+        // (largest first: the workgroups take the tiles of a launch through a queue)
+        std::stable_sort(w64_ids.begin(), w64_ids.end(), [&](int32_t a, int32_t b) {
+            return (int64_t)L->rows[a] * L->rows[a] * L->cols[a] > (int64_t)L->rows[b] * L->rows[b] * L->cols[b];
+        });
         std::vector<int32_t> rows(L->rows, L->rows + B), cols(L->cols, L->cols + B);
         qrk_status st;
         if ((st = upload(h, rows, &p->d_rows)) || (st = upload(h, cols, &p->d_cols)) ||
             (st = upload(h, coff, &p->d_coff)) || (st = upload(h, rowoff, &p->d_rowoff)) ||
             (st = upload(h, toff, &p->d_toff)) || (st = upload(h, qoff, &p->d_qoff)) ||
             (st = upload(h, roff, &p->d_roff)) || (st = upload(h, wave_ids, &p->d_wave_ids)) ||
-            (st = upload(h, wg_ids, &p->d_wg_ids)) || (st = upload(h, col_ids, &p->d_col_ids))) {
+            (st = upload(h, wg_ids, &p->d_wg_ids)) || (st = upload(h, col_ids, &p->d_col_ids)) ||
+            (st = upload(h, w64_ids, &p->d_w64_ids))) {
             qrk_bd_plan_destroy(p);
             return st;
         }
         p->n_wave = (int64_t)wave_ids.size();
+        p->n_w64 = (int64_t)w64_ids.size();
         p->n_wg = (int64_t)wg_ids.size();
         p->n_col = (int64_t)col_ids.size();
     }
@@ -709,7 +730,7 @@ qrk_status qrk_bd_plan_destroy(qrk_bd_plan p)
 {
     if (!p) return QRK_STATUS_OK;
     (void)hipFree(p->d_rows); (void)hipFree(p->d_cols); (void)hipFree(p->d_coff); (void)hipFree(p->d_rowoff);
-    (void)hipFree(p->d_toff); (void)hipFree(p->d_qoff); (void)hipFree(p->d_roff); (void)hipFree(p->d_wave_ids);
+    (void)hipFree(p->d_toff); (void)hipFree(p->d_qoff); (void)hipFree(p->d_roff); (void)hipFree(p->d_wave_ids); (void)hipFree(p->d_w64_ids);
     (void)hipFree(p->d_wg_ids); (void)hipFree(p->d_workspace);
     (void)hipFree(p->d_col_ids); (void)hipFree(p->d_col_workspace); (void)hipFree(p->d_redo); (void)hipFree(p->d_exact_ws);
     delete p;
@@ -1958,6 +1979,7 @@ const char* qrk_bd_kernel_name(qrk_bd_plan p, int which)
     const bool piv = p->solver == QRK_COLPIV_HOUSEHOLDER;
     if (h->force_exact) return piv ? "qrk::bdqr_exact_kernel<true>" : "qrk::bdqr_exact_kernel<false>";
     if (p->max_dim > QRK_COL_MAX_DIM) return "qrk::bdqr_wg_kernel";
+    if (p->w64_uniform) return piv ? "qrk::bdqr_w64_kernel<true>" : "qrk::bdqr_w64_kernel<false>";
     if (p->max_dim > 32) return "qrk::bdqr_col_kernel";
     if (p->uniform && p->max_dim <= 16 && p->r >= p->c && p->c <= 2 && h->use_small_kernel && h->use_thin_kernel)
         return piv ? "qrk::thin::bdqr_thin_kernel<true, HC>" : "qrk::thin::bdqr_thin_kernel<false, HC>";

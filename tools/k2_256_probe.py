@@ -20,4 +20,4 @@ for _ in range(reps):
     qr.factorize(mat)
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / reps
-print(f"{s}x{s} B={b} {dt*1e3:.3f} ms/launch {b/dt:.0f} tiles/s {16*s**3/3*b/dt/1e12:.2f} TFLOP/s (16 n^3/3 per tile: R and the full Q)", flush=True)
+print(f"{s}x{s} B={b} {dt*1e3:.3f} ms/launch {b/dt:.0f} tiles/s {8*s**3/3*b/dt/1e12:.2f} TFLOP/s (8 n^3/3 per tile, SURVEY.md 8(d): R and the explicit Q)", flush=True)

@@ -20,7 +20,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "one":
             qr.factorize(mat)
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / 2
-        print(f"  {s:3d}x{s:<3d} B={b:5d} {dt*1e3:9.3f} ms {b/dt:10.0f} tiles/s {16*s**3/3*b/dt/1e12:6.2f} TFLOP/s(16n^3/3)", flush=True)
+        print(f"  {s:3d}x{s:<3d} B={b:5d} {dt*1e3:9.3f} ms {b/dt:10.0f} tiles/s {8*s**3/3*b/dt/1e12:6.2f} TFLOP/s (8 n^3/3 per tile, SURVEY.md 8(d))", flush=True)
     sys.exit(0)
 for w in (sys.argv[1:] or ["0", "48", "64", "96", "128", "192", "256", "384"]):
     env = dict(os.environ)

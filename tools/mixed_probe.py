@@ -31,5 +31,5 @@ def timeit(rows, cols, label, reps=3):
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4000
 n = rng.integers(8, 257, B).astype(np.int32)
 timeit(n, n, "mixed square 8..256")
-for s, b in ((32, 10000), (33, 2000), (33, 20000), (48, 2000), (48, 20000), (64, 2000), (64, 10000), (96, 1000), (128, 1000), (192, 500), (256, 500)):
+for s, b in ((32, 10000), (33, 2000), (33, 20000), (40, 20000), (48, 2000), (48, 20000), (56, 20000), (64, 2000), (64, 10000), (64, 40000), (96, 1000), (128, 1000), (192, 500), (256, 500)):
     timeit(np.full(b, s, np.int32), np.full(b, s, np.int32), f"uniform {s}x{s}")

@@ -28,6 +28,13 @@ stamps = torch.zeros(NP * 20, device="cuda", dtype=torch.int64)
 for _ in range(3):
     capi.check(capi.lib().qrk_bd_factorize(plan, tiles.data_ptr(), qv.data_ptr(), rv.data_ptr(), pm.data_ptr(), stamps.data_ptr(), 0))
 torch.cuda.synchronize()
+# duration of one launch of this (stamped) build by events, to convert s_memtime ticks: ticks of a workgroup's whole life / this
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(20):
+    capi.check(capi.lib().qrk_bd_factorize(plan, tiles.data_ptr(), qv.data_ptr(), rv.data_ptr(), pm.data_ptr(), stamps.data_ptr(), 0))
+e1.record(); torch.cuda.synchronize()
+launch_us = e0.elapsed_time(e1) * 1e3 / 20
 raw = stamps.cpu().numpy()
 s = raw[:NP * 12].reshape(NP, 12)
 tk = raw[NP * 12:].reshape(NP, 8)
@@ -42,6 +49,18 @@ for i, n in enumerate(names):
     print(f"  {n:12s} {d[:, i].mean():8.2f} {np.percentile(d[:, i], 10):8.2f} {np.percentile(d[:, i], 90):8.2f}")
 print(f"  {'pair total':12s} {(rel[:, 6] - rel[:, 0]).mean() / MHZ:8.2f}")
 wg = s[:, 8]
+# round 4: the same in raw s_memtime ticks (= shader cycles on gfx950), by round of the persistent workgroup -- rounds 0 and 1 run two
+# waves per SIMD, the tail round mostly one: what a pair costs when it has the SIMD to itself is the dependent chain of its steps
+nwg0 = int(wg.max()) + 1
+dt = np.diff((s[:, :7] - s[:, :1]).astype(np.float64), axis=1)
+life = np.array([s[[p for p in range(NP) if p % nwg0 == w], :7].max() - s[[p for p in range(NP) if p % nwg0 == w], :7].min() for w in range(0, nwg0, 64)], dtype=np.float64)
+print(f"one launch of the stamped build by events: {launch_us:.1f} us; ticks from a workgroup's first stamp to its last: mean {life.mean():.0f} max {life.max():.0f}"
+      f" -> {life.max() / launch_us / 1e3:.2f} GHz if the longest-lived workgroup spans the launch")
+print("cycles per pair by round (stage | steps 0-7 | 8-15 | 16-23 | 24-31 | epilogue | total), mean over the pairs of the round:")
+for r in range((NP + nwg0 - 1) // nwg0):
+    sel = np.arange(r * nwg0, min((r + 1) * nwg0, NP))
+    print(f"  round {r} ({len(sel):5d} pairs): " + " ".join(f"{x:8.0f}" for x in dt[sel].mean(axis=0)) + f"   total {dt[sel].sum(axis=1).mean():8.0f}"
+          f"   p10 {np.percentile(dt[sel].sum(axis=1), 10):8.0f}  p90 {np.percentile(dt[sel].sum(axis=1), 90):8.0f}")
 if os.environ.get("QRK_PAIR_PERSIST") == "0":
     d0 = (s[:, :7] - s[:, :1]).astype(np.float64)
     print("one pair per workgroup: mean stamp offsets within the workgroup (ticks):", " ".join(f"{x:9.0f}" for x in d0.mean(axis=0)))
