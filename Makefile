@@ -19,7 +19,7 @@ $(OBJDIR)/bdqr_exact.o: HIPFLAGS += -ffp-contract=off
 
 $(LIB): $(OBJS)
 	@mkdir -p qrkit_amd/lib
-	$(HIPCC) -shared -fPIC --offload-arch=$(ARCH) $(OBJS) -o $@
+	$(HIPCC) -shared -fPIC --offload-arch=$(ARCH) $(OBJS) -ldl -o $@
 
 oracle:
 	$(MAKE) -C oracle
@@ -31,6 +31,8 @@ cpptest: $(LIB)
 	    -Wl,-rpath,'$$ORIGIN/../qrkit_amd/lib' -o build/test_block_diagonal
 	g++ -O2 -std=c++14 -Wall -Iinclude tests/cpp/test_compositions.cpp -Lqrkit_amd/lib -lqrkit_amd \
 	    -Wl,-rpath,'$$ORIGIN/../qrkit_amd/lib' -o build/test_compositions
+	g++ -O2 -std=c++14 -Wall -D__HIP_PLATFORM_AMD__ -Iinclude -I/opt/rocm/include tests/cpp/test_sharded.cpp -Lqrkit_amd/lib -lqrkit_amd \
+	    -L/opt/rocm/lib -lrccl -lamdhip64 -Wl,-rpath,'$$ORIGIN/../qrkit_amd/lib' -Wl,-rpath,/opt/rocm/lib -o build/test_sharded
 
 # CPU sanitizer targets (the GPU side has no sanitizer on this pool): the oracle as an ASan + UBSan library for
 # the oracle's own tests, and the host-side integer logic of the banded solver (banded_host.hip is plain C++) with a driver on the

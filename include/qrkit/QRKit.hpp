@@ -206,6 +206,21 @@ class SparseBlockDiagonal {
     const std::vector<int32_t>& blockRows() const { return m_rows; }
     const std::vector<int32_t>& blockCols() const { return m_cols; }
     const std::vector<double>& tiles() const { return m_tiles; }
+    // blocks [first, first + count) as a block-diagonal matrix of their own (the shard of one rank: ShardedBlockDiagonalSparseQR)
+    SparseBlockDiagonal blockRange(StorageIndex first, StorageIndex count) const {
+        SparseBlockDiagonal out;
+        size_t off = 0;
+        for (StorageIndex k = 0; k < first; ++k) off += (size_t)m_rows[(size_t)k] * m_cols[(size_t)k];
+        size_t len = 0; StorageIndex r = 0, c = 0;
+        for (StorageIndex k = first; k < first + count; ++k) {
+            len += (size_t)m_rows[(size_t)k] * m_cols[(size_t)k]; r += m_rows[(size_t)k]; c += m_cols[(size_t)k];
+        }
+        out.m_rows.assign(m_rows.begin() + first, m_rows.begin() + first + count);
+        out.m_cols.assign(m_cols.begin() + first, m_cols.begin() + first + count);
+        out.m_tiles.assign(m_tiles.begin() + (std::ptrdiff_t)off, m_tiles.begin() + (std::ptrdiff_t)(off + len));
+        out.nRows = r; out.nCols = c;
+        return out;
+    }
   protected:
     std::vector<int32_t> m_rows, m_cols;
     std::vector<double> m_tiles;
@@ -420,6 +435,60 @@ class BlockDiagonalSparseQR {
     bool m_isInitialized, m_analysisIsok, m_factorizationIsok;
     qrk_handle m_handle;
     qrk_bd_plan m_plan;
+};
+
+// One process per GPU (the reference is single-threaded -- this is the sharded form of the hot loop
+// BlockDiagonalSparseQR.h:432-526, which carries nothing from block to block but the running offsets): rank g of `world` factorises
+// its contiguous range of the diagonal blocks (qrk_shard_ranges: balanced by r c^2) with the single-GPU solver above -- no
+// data-path collective --, and gatherR() composes the packed R values and the global column permutation on the root
+// (qrk_gather_r: grouped ncclSend / ncclRecv with the true counts, RCCL over xGMI).  ncclComm: the caller's ncclComm_t of `world`
+// ranks (void*: no RCCL header needed here); may be null when world = 1.
+template <typename BlockQRSolver = ColPivHouseholderQR, int QFormat = 0>
+class ShardedBlockDiagonalSparseQR : public BlockDiagonalSparseQR<BlockQRSolver, QFormat> {
+  public:
+    typedef BlockDiagonalSparseQR<BlockQRSolver, QFormat> Base;
+    ShardedBlockDiagonalSparseQR(int rank, int world, void* ncclComm, int device = 0)
+        : Base(device), m_rank(rank), m_world(world), m_comm(ncclComm), m_shards((size_t)world + 1) {
+        if (world <= 0 || rank < 0 || rank >= world) throw std::runtime_error("qrkit: ShardedBlockDiagonalSparseQR: bad rank / world");
+    }
+    // mat: the WHOLE block-diagonal matrix (every rank knows the layout; only the tiles of the rank's own range are read)
+    void compute(const SparseBlockDiagonal& mat) {
+        const qrk_status st = qrk_shard_ranges((int64_t)mat.size(), 0, 0, mat.blockRows().data(), mat.blockCols().data(), (int32_t)m_world,
+                                               m_shards.data());
+        if (st != QRK_STATUS_OK) throw std::runtime_error(std::string("qrkit: ") + qrk_last_error(0));
+        m_local = mat.blockRange((StorageIndex)shard().first_block, (StorageIndex)shard().num_blocks);
+        if (m_local.size() > 0) Base::compute(m_local);
+    }
+    const qrk_shard& shard() const { return m_shards[(size_t)m_rank]; }
+    const std::vector<qrk_shard>& shards() const { return m_shards; }       // world + 1 entries, the last one the end sentinel
+    const SparseBlockDiagonal& localMatrix() const { return m_local; }
+    // On the root: rValues = the packed CSC values of the whole m_R (tile part), perm = m_outputPerm_c.indices() of the whole matrix
+    // (:519-521).  Elsewhere both come back empty.  Collective: every rank calls it.
+    void gatherR(int root, Vector& rValues, std::vector<int>& perm) const {
+        const qrk_shard& end = m_shards[(size_t)m_world];
+        void *dr = 0, *dp = 0;
+        rValues.clear(); perm.clear();
+        if (m_rank == root) {
+            this->check(qrk_device_alloc(this->m_handle, std::max<int64_t>(end.r_off, 1) * (int64_t)sizeof(double), &dr));
+            this->check(qrk_device_alloc(this->m_handle, std::max<int64_t>(end.base_col, 1) * (int64_t)sizeof(int32_t), &dp));
+        }
+        qrk_status st = qrk_gather_r(this->m_handle, m_comm, (int32_t)m_rank, (int32_t)m_world, (int32_t)root, m_shards.data(),
+                                     (const double*)this->m_dr, (const int32_t*)this->m_dperm, (double*)dr, (int32_t*)dp);
+        if (st == QRK_STATUS_OK && m_rank == root) {
+            rValues.assign((size_t)end.r_off, 0.0); perm.assign((size_t)end.base_col, 0);
+            if (end.r_off > 0) st = qrk_memcpy(this->m_handle, rValues.data(), dr, end.r_off * (int64_t)sizeof(double), 1);
+            if (st == QRK_STATUS_OK && end.base_col > 0) st = qrk_memcpy(this->m_handle, perm.data(), dp, end.base_col * (int64_t)sizeof(int32_t), 1);
+        }
+        if (st == QRK_STATUS_OK) st = qrk_synchronize(this->m_handle);
+        if (dr) qrk_device_free(this->m_handle, dr);
+        if (dp) qrk_device_free(this->m_handle, dp);
+        this->check(st);
+    }
+  protected:
+    int m_rank, m_world;
+    void* m_comm;
+    std::vector<qrk_shard> m_shards;
+    SparseBlockDiagonal m_local;
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -1321,6 +1390,9 @@ template <typename BlockMatrixType = Matrix, typename StorageIndex = int> using 
 // BlockDiagonalSparseQR<_BlockQRSolver, _QFormat> (BlockDiagonalSparseQR.h:37)
 template <typename BlockQRSolver = qrkit::ColPivHouseholderQR, int QFormat = 0>
 using BlockDiagonalSparseQR = qrkit::BlockDiagonalSparseQR<BlockQRSolver, QFormat>;
+// no reference counterpart: the multi-GPU form of the same solver (one process per GPU)
+template <typename BlockQRSolver = qrkit::ColPivHouseholderQR, int QFormat = 0>
+using ShardedBlockDiagonalSparseQR = qrkit::ShardedBlockDiagonalSparseQR<BlockQRSolver, QFormat>;
 // BandedBlockedSparseQR<_MatrixType, _BlockQRSolver, _BlockOverlap = Dynamic, _SuggestedBlockCols = 2> (BandedBlockedSparseQR.h:122)
 template <typename MatrixType, typename BlockQRSolver, int BlockOverlap = qrkit::Dynamic, int SuggestedBlockCols = 2>
 using BandedBlockedSparseQR =

@@ -418,6 +418,36 @@ qrk_status qrk_bb_apply_q(qrk_bb_plan plan, const double* y_vals, const double* 
  * plan (the plan keeps its rows on the device). */
 qrk_status qrk_bb_solve_r(qrk_bb_plan plan, double* v, int64_t ldv, int64_t nrhs, qrk_memspace space);
 
+/* ------------------------------------------------------------- multi-GPU: shards of the diagonal blocks */
+
+/* One process per GPU.  The hot loop of BlockDiagonalSparseQR::factorize (src/QRKit/BlockDiagonalSparseQR.h:432-526) carries nothing
+ * from block to block but the running offsets base_row / base_col (:428-431, :524-525), so the blocks shard as CONTIGUOUS ranges
+ * with no data-path collective: rank g factorises blocks [first_block, first_block + num_blocks) with a plan of its own and its
+ * Q / R / permutation shards are already in the global order.  No reference site (the reference is single-threaded): SURVEY.md 8(e).
+ *
+ * qrk_shard_ranges: ranges balanced by the Householder cost r c^2 per block (equal counts for uniform blocks), and the global
+ * offsets of each range.  Host-only integer logic: no handle, no GPU.  Uniform layouts pass rows = cols = NULL and block_rows /
+ * block_cols.  shards: world + 1 entries; entry world is the end sentinel (first_block = num_blocks, num_blocks = 0, the offsets
+ * = the totals), so that the element counts of rank g are differences of consecutive entries. */
+typedef struct qrk_shard {
+    int64_t first_block, num_blocks;
+    int64_t base_row, base_col;      /* rows / columns of the matrix before the range (BlockDiagonalSparseQR.h:428-431) */
+    int64_t tiles_off, q_off, r_off; /* offsets of the range in the global tiles / q_vals (tile part) / r_vals arrays */
+} qrk_shard;
+qrk_status qrk_shard_ranges(int64_t num_blocks, int32_t block_rows, int32_t block_cols, const int32_t* rows, const int32_t* cols,
+                            int32_t world, qrk_shard* shards);
+
+/* The only exchange of the path: the composed R (packed CSC values) and the column permutation gathered on `root` with their TRUE
+ * counts -- ncclGroupStart / one ncclRecv per peer on the root, one ncclSend on every other rank / ncclGroupEnd, on the handle's
+ * stream (RCCL over xGMI; no padding to the largest shard).  nccl_comm: the caller's ncclComm_t of `world` ranks (passed as void*:
+ * this header needs no RCCL header; the library resolves ncclSend / ncclRecv / ncclGroupStart / ncclGroupEnd from the RCCL that
+ * is already loaded in the process, else from librccl.so); may be NULL when world = 1.  r_local / perm_local: this rank's shards
+ * as qrk_bd_factorize of its own plan wrote them (device; permutation indices local to the shard).  r_all [r_off of the sentinel],
+ * perm_all [base_col of the sentinel]: device, root only (ignored elsewhere); perm_all holds GLOBAL column indices
+ * (m_outputPerm_c.indices(), :519-521: the shard's base_col added). */
+qrk_status qrk_gather_r(qrk_handle h, void* nccl_comm, int32_t rank, int32_t world, int32_t root, const qrk_shard* shards,
+                        const double* r_local, const int32_t* perm_local, double* r_all, int32_t* perm_all);
+
 /* ------------------------------------------------------------- measurement */
 
 /* Launch the factorisation kernel(s) of `plan` `iters` times back to back on the

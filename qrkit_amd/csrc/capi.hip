@@ -6,11 +6,14 @@
 // qrk_bd_solve = _solve_impl (:257-280).  There is no CPU fallback anywhere in this file.
 #include "../../include/qrkit_amd.h"
 #include "qrk_device.h"
+#include <rccl/rccl.h>     // types only: the entry points are resolved at run time (qrk_gather_r)
+#include <dlfcn.h>
 #include "banded_host.h"
 
 #include <cstdio>
 #include <cstdlib>
 #include <algorithm>
+#include <cmath>
 #include <cstring>
 #include <new>
 #include <string>
@@ -158,9 +161,15 @@ struct qrk_thin_plan_s {
     int32_t rows = 0, cols = 0, block_cols = 0;
     int32_t rank = 0, maxrows = 0;
     std::vector<int32_t> col_perm, row_perm;       // m_outputPerm_c.indices(), m_rowPerm.indices()
-    struct Panel { int32_t r0, nrows, nnew; double* d_ji; double* d_hc; };
-    std::vector<Panel> panels;                     // packed QR + tau of every panel (maxrows x nnew, leading dimension maxrows)
-    qrk_dense_plan dplan = nullptr, dplan_last = nullptr;   // (maxrows x block_cols) and the last panel's width
+    // A panel is factorised at its OWN height (updateBlockInfo, BlockedThinSparseQR.h:203-238), rounded up to a bucket (a power of two
+    // from 64 up, capped at `rows`: zero rows appended change neither the reflectors nor Eigen's sums) so that a few dense plans serve
+    // every panel: hb = the bucket = leading dimension of the panel's packed QR; plan = index into dplans.
+    struct Panel { int32_t r0, nrows, nnew, hb, plan; double* d_ji; double* d_hc; };
+    std::vector<Panel> panels;                     // packed QR + tau of every panel (hb x nnew)
+    struct BucketPlan { int32_t hb, nnew; qrk_dense_plan plan; };
+    std::vector<BucketPlan> dplans;                // one dense plan per (bucket height, panel width) that occurred
+    std::vector<double*> arena;                    // pooled storage of the panels (chunks; a panel never straddles two)
+    size_t arena_used = 0, arena_cap = 0;          // doubles used / capacity of the last chunk
     double* d_R = nullptr;                         // cols x cols, column-major: R(0:rank, :) upper trapezoidal
     int64_t ldd = 0;
 };
@@ -1460,9 +1469,8 @@ qrk_status qrk_bb_plan_destroy(qrk_bb_plan p)
 qrk_status qrk_thin_destroy(qrk_thin_plan p)
 {
     if (!p) return QRK_STATUS_OK;
-    for (auto& q : p->panels) { (void)hipFree(q.d_ji); (void)hipFree(q.d_hc); }
-    if (p->dplan) (void)qrk_dense_plan_destroy(p->dplan);
-    if (p->dplan_last) (void)qrk_dense_plan_destroy(p->dplan_last);
+    for (double* c : p->arena) (void)hipFree(c);
+    for (auto& b : p->dplans) if (b.plan) (void)qrk_dense_plan_destroy(b.plan);
     (void)hipFree(p->d_R);
     delete p;
     return QRK_STATUS_OK;
@@ -1517,9 +1525,8 @@ qrk_status qrk_thin_sparse_factorize(qrk_handle h, int32_t rows, int32_t cols, i
     for (int32_t j = 0; j < cols; ++j)
         for (int32_t e = pcp[(size_t)j]; e < pcp[(size_t)j + 1]; ++e) lastrow[(size_t)j] = std::max(lastrow[(size_t)j], rperm[(size_t)pri[(size_t)e]]);
 
-    // ---- the working matrix m_pmatDense on the device: the nonzeros cross PCIe, zero rows are appended so that every panel can be
-    // handed to ONE dense plan of `maxrows` rows (appended zero rows change neither the reflectors nor Eigen's sums)
-    // upper bound of a panel's height: rows (the last panel takes everything that is left)
+    // ---- the working matrix m_pmatDense on the device: the nonzeros cross PCIe; `rows` zero rows are appended so that a panel
+    // can be handed to a dense plan of its bucket height wherever it starts (bucket <= rows)
     p->maxrows = rows;
     const int64_t ldd = (int64_t)rows + p->maxrows;
     p->ldd = ldd;
@@ -1558,27 +1565,44 @@ qrk_status qrk_thin_sparse_factorize(qrk_handle h, int32_t rows, int32_t cols, i
         }
         if (nrows < 0) nrows = 0;
         const int32_t r0 = nzp, c0 = solved, k = std::min(nrows, nnew);
-        qrk_dense_plan& dp = nnew == block_cols ? p->dplan : p->dplan_last;
-        if (!dp) {
-            if ((st = qrk_dense_plan_create(h, p->maxrows, nnew, QRK_COLPIV_HOUSEHOLDER, &dp)) != QRK_STATUS_OK) return bail(st);
-            (void)qrk_dense_plan_set_two_stage(dp, 0);      // one plan, many panels that are re-applied later: every Q in the panel's own arrays
+        // the panel's bucket and its plan
+        int32_t hb = 64;
+        while (hb < nrows) hb *= 2;
+        hb = std::min(hb, rows);
+        hb = std::max(hb, nnew);                    // (a dense plan needs rows >= cols)
+        int32_t pi = -1;
+        for (size_t b = 0; b < p->dplans.size(); ++b) if (p->dplans[b].hb == hb && p->dplans[b].nnew == nnew) pi = (int32_t)b;
+        if (pi < 0) {
+            qrk_dense_plan np_ = nullptr;
+            if ((st = qrk_dense_plan_create(h, hb, nnew, QRK_COLPIV_HOUSEHOLDER, &np_)) != QRK_STATUS_OK) return bail(st);
+            (void)qrk_dense_plan_set_two_stage(np_, 0);     // one plan, many panels that are re-applied later: every Q in the panel's own arrays
+            p->dplans.push_back({hb, nnew, np_});
+            pi = (int32_t)p->dplans.size() - 1;
         }
-        qrk_thin_plan_s::Panel pn{r0, nrows, nnew, nullptr, nullptr};
-        if (hipMalloc((void**)&pn.d_ji, (size_t)p->maxrows * nnew * sizeof(double)) != hipSuccess ||
-            hipMalloc((void**)&pn.d_hc, (size_t)std::max(nnew, 1) * sizeof(double)) != hipSuccess) {
-            (void)hipFree(pn.d_ji); (void)hipFree(pn.d_hc);
-            (void)fail(h, QRK_STATUS_ALLOC_FAILED, "qrk_thin_sparse_factorize: cannot allocate a panel");
-            return bail(QRK_STATUS_ALLOC_FAILED);
+        qrk_dense_plan dp = p->dplans[(size_t)pi].plan;
+        // storage from the arena: hb x nnew for the packed QR + nnew for tau
+        const size_t nji = ((size_t)hb * nnew + 31) / 32 * 32;                  // (256-byte granules: the panels keep hipMalloc's alignment)
+        const size_t need = nji + ((size_t)std::max(nnew, 1) + 31) / 32 * 32;
+        if (p->arena.empty() || p->arena_used + need > p->arena_cap) {
+            const size_t chunk = std::max<size_t>(need, std::min<size_t>((size_t)rows * cols + (size_t)cols, (size_t)1 << 24));
+            double* c = nullptr;
+            if (hipMalloc((void**)&c, chunk * sizeof(double)) != hipSuccess) {
+                (void)fail(h, QRK_STATUS_ALLOC_FAILED, "qrk_thin_sparse_factorize: cannot allocate panel storage");
+                return bail(QRK_STATUS_ALLOC_FAILED);
+            }
+            p->arena.push_back(c); p->arena_used = 0; p->arena_cap = chunk;
         }
+        qrk_thin_plan_s::Panel pn{r0, nrows, nnew, hb, pi, p->arena.back() + p->arena_used, p->arena.back() + p->arena_used + nji};
+        p->arena_used += need;
         p->panels.push_back(pn);
         // Ji = copy of the block (the reference factorises a copy), zero rows below it
-        QRK_THIN_HIP(hipMemsetAsync(pn.d_ji, 0, (size_t)p->maxrows * nnew * sizeof(double), h->stream));
+        if (hb > nrows) QRK_THIN_HIP(hipMemsetAsync(pn.d_ji, 0, (size_t)hb * nnew * sizeof(double), h->stream));
         if (nrows > 0)
-            QRK_THIN_HIP(hipMemcpy2DAsync(pn.d_ji, (size_t)p->maxrows * sizeof(double), d_D + (int64_t)c0 * ldd + r0, (size_t)ldd * sizeof(double),
+            QRK_THIN_HIP(hipMemcpy2DAsync(pn.d_ji, (size_t)hb * sizeof(double), d_D + (int64_t)c0 * ldd + r0, (size_t)ldd * sizeof(double),
                                           (size_t)nrows * sizeof(double), (size_t)nnew, hipMemcpyDeviceToDevice, h->stream));
-        if ((st = qrk_dense_factorize(dp, pn.d_ji, p->maxrows, pn.d_hc, d_pp, QRK_MEM_DEVICE)) != QRK_STATUS_OK) return bail(st);
+        if ((st = qrk_dense_factorize(dp, pn.d_ji, hb, pn.d_hc, d_pp, QRK_MEM_DEVICE)) != QRK_STATUS_OK) return bail(st);
         // pivots and permutation of the panel to the host: nonzeroPivots() decides the geometry of the next panel
-        hipLaunchKernelGGL(qrk::thin_pack_kernel, dim3(1), dim3(256), 0, h->stream, pn.d_ji, (int64_t)p->maxrows, d_pp, k, nnew, d_pack);
+        hipLaunchKernelGGL(qrk::thin_pack_kernel, dim3((unsigned)((std::max(k, nnew) + 255) / 256)), dim3(256), 0, h->stream, pn.d_ji, (int64_t)hb, d_pp, k, nnew, d_pack);
         QRK_THIN_HIP(hipMemcpyAsync(pack.data(), d_pack, (size_t)(k + nnew) * sizeof(double), hipMemcpyDeviceToHost, h->stream));
         QRK_THIN_HIP(hipStreamSynchronize(h->stream));
         // Eigen's rule: |R_qq|^2 < (eps |R_00|)^2 (nrows - q) / nrows ends the count
@@ -1592,8 +1616,8 @@ qrk_status qrk_thin_sparse_factorize(qrk_handle h, int32_t rows, int32_t cols, i
         // update of the columns to the right (the rows of the panel and the zero rows below them): Q_panel^T in reflector form
         const int32_t ntrail = cols - (c0 + nnew);
         if (ntrail > 0 && k > 0)
-            if ((st = qrk_dense_apply_q(dp, pn.d_ji, p->maxrows, pn.d_hc, 1, d_D + (int64_t)(c0 + nnew) * ldd + r0, ldd, ntrail, QRK_MEM_DEVICE)) != QRK_STATUS_OK) return bail(st);
-        hipLaunchKernelGGL(qrk::thin_r_columns_kernel, dim3((unsigned)nnew), dim3(256), 0, h->stream, d_D, ldd, pn.d_ji, (int64_t)p->maxrows, d_pp,
+            if ((st = qrk_dense_apply_q(dp, pn.d_ji, hb, pn.d_hc, 1, d_D + (int64_t)(c0 + nnew) * ldd + r0, ldd, ntrail, QRK_MEM_DEVICE)) != QRK_STATUS_OK) return bail(st);
+        hipLaunchKernelGGL(qrk::thin_r_columns_kernel, dim3((unsigned)nnew), dim3(256), 0, h->stream, d_D, ldd, pn.d_ji, (int64_t)hb, d_pp,
                            nzp, c0, k, nnew, p->d_R, (int64_t)cols);
         QRK_THIN_HIP(hipGetLastError());
         new_piv = nz; nzp += nz; prev_rows = nrows; solved += nnew;
@@ -1639,8 +1663,8 @@ qrk_status qrk_thin_apply_q(qrk_thin_plan p, int transpose, double* v, int64_t l
     for (size_t s = 0; s < np; ++s) {
         const auto& q = p->panels[transpose ? s : np - 1 - s];
         if (std::min(q.nrows, q.nnew) == 0) continue;
-        qrk_dense_plan dp = q.nnew == p->block_cols ? p->dplan : p->dplan_last;
-        qrk_status st = qrk_dense_apply_q(dp, q.d_ji, p->maxrows, q.d_hc, transpose ? 1 : 0, v + q.r0, ldv, nrhs, QRK_MEM_DEVICE);
+        qrk_dense_plan dp = p->dplans[(size_t)q.plan].plan;
+        qrk_status st = qrk_dense_apply_q(dp, q.d_ji, q.hb, q.d_hc, transpose ? 1 : 0, v + q.r0, ldv, nrhs, QRK_MEM_DEVICE);
         if (st != QRK_STATUS_OK) return st;
     }
     return QRK_STATUS_OK;
@@ -1969,6 +1993,140 @@ qrk_status qrk_bd_time_factorize(qrk_bd_plan p, const double* tiles, double* q_v
     *avg_ms = ms / (float)iters;
     p->factorized = st == QRK_STATUS_OK;
     return st;
+}
+
+// ---- multi-GPU: contiguous shards of the diagonal blocks -------------------------------------------------------
+qrk_status qrk_shard_ranges(int64_t B, int32_t block_rows, int32_t block_cols, const int32_t* rows, const int32_t* cols, int32_t world,
+                            qrk_shard* shards)
+{
+    if (B < 0 || world <= 0 || !shards || ((rows == nullptr) != (cols == nullptr)) || (!rows && B > 0 && (block_rows <= 0 || block_cols <= 0)))
+        return fail(nullptr, QRK_STATUS_INVALID_ARGUMENT, "qrk_shard_ranges: bad argument");
+    auto br = [&](int64_t i) -> int64_t { return rows ? rows[i] : block_rows; };
+    auto bc = [&](int64_t i) -> int64_t { return cols ? cols[i] : block_cols; };
+    // bounds: the cut closest to k/world of the total Householder cost r c^2 (running sums in double, as the Python mirror's
+    // numpy.cumsum: qrkit_amd/sharding.py::shard_ranges gives the same ranges)
+    std::vector<double> cost((size_t)B);
+    double run = 0.0;
+    for (int64_t i = 0; i < B; ++i) { run += (double)br(i) * (double)bc(i) * (double)bc(i); cost[(size_t)i] = run; }
+    std::vector<int64_t> bounds((size_t)world + 1, B);
+    bounds[0] = 0;
+    for (int32_t k = 1; k < world && B > 0; ++k) {
+        const double target = run * (double)k / (double)world;
+        int64_t idx = (int64_t)(std::lower_bound(cost.begin(), cost.end(), target) - cost.begin()) + 1;   // blocks before the cut
+        if (idx - 1 > bounds[(size_t)k - 1] && std::fabs(cost[(size_t)idx - 2] - target) <= std::fabs(cost[(size_t)idx - 1] - target)) --idx;
+        bounds[(size_t)k] = std::min(std::max(idx, bounds[(size_t)k - 1]), B);
+    }
+    if (B == 0) for (int32_t k = 1; k < world; ++k) bounds[(size_t)k] = 0;
+    // running offsets (BlockDiagonalSparseQR.h:428-431, 524-525) at every bound
+    qrk_shard acc{};
+    int32_t k = 0;
+    for (int64_t i = 0; i <= B; ++i) {
+        while (k <= world && bounds[(size_t)k] == i) {
+            shards[k] = acc;
+            shards[k].first_block = i;
+            shards[k].num_blocks = k < world ? bounds[(size_t)k + 1] - i : 0;
+            ++k;
+        }
+        if (i == B) break;
+        const int64_t r = br(i), c = bc(i);
+        if (r <= 0 || c <= 0) return fail(nullptr, QRK_STATUS_INVALID_ARGUMENT, "qrk_shard_ranges: non-positive tile size");
+        acc.base_row += r; acc.base_col += c;
+        acc.tiles_off += r * c; acc.q_off += r * r; acc.r_off += c * (c + 1) / 2;
+    }
+    return QRK_STATUS_OK;
+}
+
+}  // extern "C"
+
+namespace {
+__global__ void __launch_bounds__(256) add_base_kernel(int32_t* __restrict__ v, int64_t n, int32_t base)
+{
+    for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) v[i] += base;
+}
+
+// The four RCCL entry points the gather needs, taken from the RCCL that the process already has (the one that made the caller's
+// communicator -- torch ships its own copy), else from librccl.so.
+struct RcclApi {
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    bool ok = false;
+};
+const RcclApi& rccl_api()
+{
+    static const RcclApi api = [] {
+        RcclApi a;
+        void* lib = RTLD_DEFAULT;
+        if (!dlsym(lib, "ncclSend")) {
+            lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+            if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+            if (!lib) return a;
+        }
+        a.GroupStart = reinterpret_cast<decltype(a.GroupStart)>(dlsym(lib, "ncclGroupStart"));
+        a.GroupEnd = reinterpret_cast<decltype(a.GroupEnd)>(dlsym(lib, "ncclGroupEnd"));
+        a.Send = reinterpret_cast<decltype(a.Send)>(dlsym(lib, "ncclSend"));
+        a.Recv = reinterpret_cast<decltype(a.Recv)>(dlsym(lib, "ncclRecv"));
+        a.GetErrorString = reinterpret_cast<decltype(a.GetErrorString)>(dlsym(lib, "ncclGetErrorString"));
+        a.ok = a.GroupStart && a.GroupEnd && a.Send && a.Recv;
+        return a;
+    }();
+    return api;
+}
+}  // namespace
+
+extern "C" {
+
+qrk_status qrk_gather_r(qrk_handle h, void* nccl_comm, int32_t rank, int32_t world, int32_t root, const qrk_shard* sh,
+                        const double* r_local, const int32_t* perm_local, double* r_all, int32_t* perm_all)
+{
+    if (!h || !sh || world <= 0 || rank < 0 || rank >= world || root < 0 || root >= world || (world > 1 && !nccl_comm) ||
+        (rank == root && (!r_all || !perm_all)))
+        return fail(h, QRK_STATUS_INVALID_ARGUMENT, "qrk_gather_r: bad argument");
+    QRK_HIP(h, hipSetDevice(h->device));
+    const int64_t nr = sh[rank + 1].r_off - sh[rank].r_off, nc = sh[rank + 1].base_col - sh[rank].base_col;
+    if ((nr > 0 && !r_local) || (nc > 0 && !perm_local)) return fail(h, QRK_STATUS_INVALID_ARGUMENT, "qrk_gather_r: NULL shard");
+    if (rank == root) {
+        if (nr > 0) QRK_HIP(h, hipMemcpyAsync(r_all + sh[rank].r_off, r_local, (size_t)nr * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+        if (nc > 0) QRK_HIP(h, hipMemcpyAsync(perm_all + sh[rank].base_col, perm_local, (size_t)nc * sizeof(int32_t), hipMemcpyDeviceToDevice, h->stream));
+    }
+    if (world > 1) {
+        const RcclApi& api = rccl_api();
+        if (!api.ok) return fail(h, QRK_STATUS_UNSUPPORTED, "qrk_gather_r: no RCCL in this process and librccl.so cannot be loaded");
+        ncclComm_t comm = static_cast<ncclComm_t>(nccl_comm);
+        auto nccl_fail = [&](ncclResult_t e, const char* what) {
+            return fail(h, QRK_STATUS_HIP_ERROR, std::string("qrk_gather_r: ") + what + ": " + (api.GetErrorString ? api.GetErrorString(e) : "RCCL error"));
+        };
+        ncclResult_t e = api.GroupStart();
+        if (e != ncclSuccess) return nccl_fail(e, "ncclGroupStart");
+        if (rank == root) {
+            for (int32_t peer = 0; peer < world && e == ncclSuccess; ++peer) {
+                if (peer == root) continue;
+                const int64_t pr = sh[peer + 1].r_off - sh[peer].r_off, pc = sh[peer + 1].base_col - sh[peer].base_col;
+                if (pr > 0) e = api.Recv(r_all + sh[peer].r_off, (size_t)pr, ncclFloat64, peer, comm, h->stream);
+                if (pc > 0 && e == ncclSuccess) e = api.Recv(perm_all + sh[peer].base_col, (size_t)pc, ncclInt32, peer, comm, h->stream);
+            }
+        } else {
+            if (nr > 0) e = api.Send(r_local, (size_t)nr, ncclFloat64, root, comm, h->stream);
+            if (nc > 0 && e == ncclSuccess) e = api.Send(perm_local, (size_t)nc, ncclInt32, root, comm, h->stream);
+        }
+        const ncclResult_t e2 = api.GroupEnd();
+        if (e != ncclSuccess) return nccl_fail(e, "ncclSend / ncclRecv");
+        if (e2 != ncclSuccess) return nccl_fail(e2, "ncclGroupEnd");
+    }
+    if (rank == root) {
+        // local column indices -> m_outputPerm_c.indices() of the whole matrix (BlockDiagonalSparseQR.h:519-521)
+        for (int32_t g = 0; g < world; ++g) {
+            const int64_t pc = sh[g + 1].base_col - sh[g].base_col;
+            if (pc <= 0 || sh[g].base_col == 0) continue;
+            if (sh[g + 1].base_col > INT32_MAX) return fail(h, QRK_STATUS_UNSUPPORTED, "qrk_gather_r: more than 2^31 columns");
+            const unsigned grid = (unsigned)std::min<int64_t>((pc + 255) / 256, 4096);
+            hipLaunchKernelGGL(add_base_kernel, dim3(grid), dim3(256), 0, h->stream, perm_all + sh[g].base_col, pc, (int32_t)sh[g].base_col);
+        }
+        QRK_HIP(h, hipGetLastError());
+    }
+    return QRK_STATUS_OK;
 }
 
 const char* qrk_bd_kernel_name(qrk_bd_plan p, int which)

@@ -1,0 +1,84 @@
+// The multi-GPU entry of the C ABI and of the facade on ONE GPU: qrk_shard_ranges (host logic, any world size) and
+// ShardedBlockDiagonalSparseQR / qrk_gather_r with world = 1 over a real one-rank RCCL communicator (ncclCommInitRank; a
+// one-rank communicator is legal) -- the path bench.py's N > 1 legs and a C++ user on an 8-GPU node take, minus the peers.
+// The gathered R and permutation must equal the un-sharded solver's, bit for bit (same kernels, same tiles).
+#include <cstdio>
+#include <cstring>
+#include <random>
+
+#include <hip/hip_runtime_api.h>
+#include <rccl/rccl.h>
+
+#include "qrkit/QRKit.hpp"
+
+using namespace qrkit;
+
+static int check_ranges() {
+    // mixed sizes, three ranks: contiguous cover, offsets = prefix sums, sentinel = totals, cost balanced
+    std::mt19937 g(5);
+    std::uniform_int_distribution<int> d(8, 256);
+    const int B = 3000, W = 3;
+    std::vector<int32_t> n((size_t)B);
+    for (auto& v : n) v = d(g);
+    std::vector<qrk_shard> sh((size_t)W + 1);
+    if (qrk_shard_ranges(B, 0, 0, n.data(), n.data(), W, sh.data()) != QRK_STATUS_OK) return 1;
+    if (sh[0].first_block != 0 || sh[W].first_block != B || sh[W].num_blocks != 0) return 1;
+    double cost[3] = {0, 0, 0}, total = 0;
+    int64_t br = 0, bc = 0, to = 0, qo = 0, ro = 0;
+    for (int g2 = 0; g2 < W; ++g2) {
+        if (sh[g2].first_block + sh[g2].num_blocks != sh[g2 + 1].first_block) return 1;
+        if (sh[g2].base_row != br || sh[g2].base_col != bc || sh[g2].tiles_off != to || sh[g2].q_off != qo || sh[g2].r_off != ro) return 1;
+        for (int64_t i = sh[g2].first_block; i < sh[g2 + 1].first_block; ++i) {
+            const int64_t v = n[(size_t)i];
+            br += v; bc += v; to += v * v; qo += v * v; ro += v * (v + 1) / 2;
+            cost[g2] += (double)v * v * v;
+        }
+        total += cost[g2];
+    }
+    if (sh[W].base_row != br || sh[W].r_off != ro) return 1;
+    for (int g2 = 0; g2 < W; ++g2) if (cost[g2] > 1.05 * total / W) return 1;
+    // uniform layout, 8 ranks: equal counts
+    std::vector<qrk_shard> su(9);
+    if (qrk_shard_ranges(10000, 32, 32, 0, 0, 8, su.data()) != QRK_STATUS_OK) return 1;
+    for (int g2 = 0; g2 < 8; ++g2) if (su[g2].num_blocks != 1250 || su[g2].r_off != (int64_t)g2 * 1250 * 528) return 1;
+    return 0;
+}
+
+int main() {
+    int fails = 0;
+    if (check_ranges()) { std::printf("qrk_shard_ranges: Failed.\n"); ++fails; } else std::printf("qrk_shard_ranges: Passed.\n");
+
+    if (hipSetDevice(0) != hipSuccess) { std::printf("no GPU\n"); return 2; }
+    ncclUniqueId id;
+    ncclComm_t comm = 0;
+    if (ncclGetUniqueId(&id) != ncclSuccess || ncclCommInitRank(&comm, 1, id, 0) != ncclSuccess) { std::printf("RCCL communicator: Failed.\n"); return 1; }
+
+    std::mt19937 g(11);
+    std::uniform_int_distribution<int> d(4, 70);
+    std::uniform_real_distribution<double> u(-1.0, 1.0);
+    SparseBlockDiagonal mat;
+    Index rows = 0, cols = 0;
+    for (int i = 0; i < 200; ++i) {
+        const int c = d(g), r = c + d(g) % 5;
+        Matrix m(r, c);
+        for (Index e = 0; e < (Index)r * c; ++e) m.data()[e] = u(g);
+        mat.insertBack(m);
+        rows += r; cols += c;
+    }
+    mat.setDims((int)rows, (int)cols);
+
+    BlockDiagonalSparseQR<ColPivHouseholderQR> whole;
+    whole.compute(mat);
+    ShardedBlockDiagonalSparseQR<ColPivHouseholderQR> shard(0, 1, comm);
+    shard.compute(mat);
+    Vector rv; std::vector<int> perm;
+    shard.gatherR(0, rv, perm);
+    const SparseMatrixColMajor& R = whole.matrixR();
+    bool ok = rv.size() == R.values().size() && std::memcmp(rv.data(), R.values().data(), rv.size() * sizeof(double)) == 0;
+    ok = ok && perm.size() == (size_t)cols;
+    for (size_t j = 0; ok && j < perm.size(); ++j) ok = perm[j] == whole.colsPermutation().indices()[j];
+    std::printf("ShardedBlockDiagonalSparseQR world 1 over RCCL, %zu R values, %zu columns: %s\n", rv.size(), perm.size(), ok ? "Passed." : "Failed.");
+    if (!ok) ++fails;
+    ncclCommDestroy(comm);
+    return fails;
+}

@@ -107,3 +107,37 @@ def test_blocks_from_pattern_matches_oracle_and_known_answers():
         want = orc.from_block_banded_pattern(*args)
         assert want is not None
         np.testing.assert_array_equal(blocks_from_pattern(*args), want)
+
+
+def test_c_shard_ranges_match_the_python_mirror():
+    """qrk_shard_ranges (the C ABI's partition of the diagonal blocks over the ranks: host integer logic, no GPU) against
+    qrkit_amd.sharding.shard_ranges / shard_offsets on uniform, mixed and degenerate layouts."""
+    from qrkit_amd import _capi
+    from qrkit_amd.sharding import shard_offsets, shard_ranges
+    lib = _capi.lib()
+    lib.qrk_shard_ranges.argtypes = [C.c_int64, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int32, C.POINTER(_capi.Shard)]
+    rng = np.random.default_rng(3)
+    cases = [(np.full(10000, 32, np.int32), np.full(10000, 32, np.int32))]
+    for B in (1, 2, 7, 100, 5000):
+        c = rng.integers(1, 257, B).astype(np.int32)
+        cases.append(((c + rng.integers(0, 9, B)).astype(np.int32), c))
+    cases.append((np.zeros(0, np.int32), np.zeros(0, np.int32)))
+    for rows, cols in cases:
+        for world in (1, 2, 3, 8, 13):
+            sh = (_capi.Shard * (world + 1))()
+            st = lib.qrk_shard_ranges(len(rows), 0, 0, rows.ctypes.data_as(C.POINTER(C.c_int32)), cols.ctypes.data_as(C.POINTER(C.c_int32)), world, sh)
+            assert st == _capi.STATUS_OK
+            want = shard_ranges(rows, cols, world)
+            assert [(s.first_block, s.first_block + s.num_blocks) for s in sh[:world]] == [tuple(map(int, w)) for w in want]
+            for g, (a, b) in enumerate(want):
+                br, bc, qo, ro = shard_offsets(rows, cols, a, b)
+                assert (sh[g].base_row, sh[g].base_col, sh[g].q_off, sh[g].r_off) == (br, bc, qo, ro)
+                assert sh[g].tiles_off == int((rows[:a].astype(np.int64) * cols[:a]).sum())
+            assert sh[world].first_block == len(rows) and sh[world].num_blocks == 0
+            assert sh[world].r_off == int((cols.astype(np.int64) * (cols + 1) // 2).sum())
+    # the uniform form (rows = cols = NULL)
+    sh = (_capi.Shard * 9)()
+    assert lib.qrk_shard_ranges(10000, 32, 32, None, None, 8, sh) == _capi.STATUS_OK
+    assert [s.num_blocks for s in sh[:8]] == [1250] * 8 and sh[8].tiles_off == 10000 * 1024
+    assert lib.qrk_shard_ranges(10, 0, 0, None, None, 2, sh) == _capi.STATUS_INVALID_ARGUMENT
+    assert lib.qrk_gather_r(None, None, 0, 1, 0, sh, None, None, None, None) == _capi.STATUS_INVALID_ARGUMENT

@@ -138,3 +138,25 @@ def test_hip_thin_sparse_rank_deficient_matches_oracle(rows, cols, bc, seed):
     QtPM = qr._applyAny(PM[:, :rk], True)
     assert np.linalg.norm(QtPM[:cols] - R[:cols, :rk]) <= 1e-12 * np.linalg.norm(PM) * np.sqrt(cols)
     assert np.linalg.norm(QtPM[cols:]) <= 1e-12 * np.linalg.norm(PM) * np.sqrt(cols)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows,cols,bc,seed", [(900, 300, 300, 7), (1200, 320, 400, 8), (700, 290, 272, 9)])
+def test_hip_thin_sparse_wide_panels(rows, cols, bc, seed):
+    """SuggestedBlockCols of more than 256 columns, and block_cols >= cols > 256 (ONE panel of the whole matrix): the diagonal and the
+    permutation of a panel reach the host through a packing kernel that used to cover the first 256 entries only (round-3 advisor
+    finding: garbage pivots and an out-of-bounds permutation beyond).  Banded-ish input as well: every panel runs at its own height
+    (a bucket of it), not at the height of the whole matrix."""
+    import qrkit_amd
+    M = thin_sparse_problem(rows, cols, seed, density=0.05)
+    ref = orc.bt_sparse_qr(M, bc)
+    ctx = qrkit_amd.Context(0)
+    qr = qrkit_amd.BlockedThinSparseQR(ctx, bc)
+    qr.compute(M)
+    assert qr.rank() == ref.rank
+    np.testing.assert_array_equal(qr.colsPermutation().cpu().numpy(), ref.perm)
+    np.testing.assert_array_equal(qr.rowsPermutation().cpu().numpy(), ref.rowperm)
+    assert rel_fro(qr.matrixR().cpu().numpy(), ref.R) <= 1e-11
+    b = np.random.default_rng(1).uniform(-1, 1, rows)
+    assert rel_fro(qr._applyAny(b, True), orc.bt_apply_q(ref, b, True)) <= 1e-11
+    assert rel_fro(qr._applyAny(qr._applyAny(b, True), False), b) <= 1e-12
