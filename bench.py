@@ -524,7 +524,8 @@ def strips_config2(ctx, dev, torch, np, N=2048):
         return min(ts)
     t_all = timed(lambda: qr.factorize(strips))
     rows, cols = np.full(N, ms, np.int32), np.full(N, n, np.int32)
-    bd = qrkit_amd.BlockDiagonalSparseQR(solver="householder", context=ctx)
+    from qrkit_amd import _capi as capi
+    bd = qrkit_amd.BlockDiagonalSparseQR(blockSolver=capi.HOUSEHOLDER, qFormat=capi.BLOCK_DIAGONAL_Q, context=ctx, hCoeffs=False)
     mat = qrkit_amd.SparseBlockDiagonal.fromTiles(rows, cols, strips)
     bd.analyzePattern(mat)
     t_a = timed(lambda: bd.factorize(mat))

@@ -26,6 +26,13 @@
 #include <float.h>
 #include <cstdlib>
 
+// Diagnostic only: -DQRK_W64_PROF accumulates s_memtime ticks per phase of the step in workgroup 0 and prints them (never a timed build).
+#ifdef QRK_W64_PROF
+#define W64_TICK(z) do { const unsigned long long t1_ = __builtin_amdgcn_s_memtime(); st.pt[z] += t1_ - st.pt0; st.pt0 = t1_; } while (0)
+#else
+#define W64_TICK(z) do { } while (0)
+#endif
+
 namespace qrk {
 
 namespace w64 {
@@ -124,6 +131,9 @@ struct Lane {
     double nu2;       // m_colNormsUpdated^2 (a chosen column carries a negative value: it drops out of the integer arg-max)
     double thr;       // sqrt(eps) (1 + 2^-12) m_colNormsDirect^2
     double a2;        // |A|^2: squared norm of the first pivot column (scale of the decision margins); wave-uniform
+#ifdef QRK_W64_PROF
+    unsigned long long pt[16], pt0;
+#endif
 };
 
 // The elements of the published column that this lane broadcasts: xc[m] = element 16 m + (lane & 15), for the chunks with rows below KP.
@@ -171,6 +181,7 @@ __device__ __forceinline__ void step(double (&a)[WR], double* lds, Lane& st, con
     } else {
         P = k;
     }
+    W64_TICK(0);
     const bool ispiv = lane == P;
     if (ispiv) {
         st.live = false; st.kstep = k;
@@ -181,6 +192,7 @@ __device__ __forceinline__ void step(double (&a)[WR], double* lds, Lane& st, con
         for (int i = KP & ~1; i < WR; i += 2) *reinterpret_cast<double2*>(&vcol[i]) = make_double2(a[i], a[i + 1]);
     }
     __builtin_amdgcn_wave_barrier();
+    W64_TICK(1);
     // ---- 3. the lanes' elements of it, |x_tail|^2 (every row of 16 lanes the same sum in the same order), x0
     double xc[4] = {0.0, 0.0, 0.0, 0.0};
     double tsq = 0.0, xk;
@@ -197,6 +209,7 @@ __device__ __forceinline__ void step(double (&a)[WR], double* lds, Lane& st, con
     }
     if (MK >= M0) xk = uniform_f64(bcast_f64<(KP & 15)>(xc[MK]));
     else xk = uniform_f64(lds[L_V + cb(KP) + (KP & 1)]);          // (row KP is the last one of its chunk: no element of that chunk was loaded)
+    W64_TICK(2);
     if (k == 0 && !PIVOT) st.a2 = fma(xk, xk, tsq);
     if (unclear_reflector(xk, tsq, k + 1 < rows, PIVOT, st.a2)) st.unclear = true;
     // ---- 4. makeHouseholder in the un-normalised form (bdqr_pair.hip): nb = -beta = copysign(norm, x0), s = x0 - beta,
@@ -212,6 +225,7 @@ __device__ __forceinline__ void step(double (&a)[WR], double* lds, Lane& st, con
         tau = -(s * s) * ng;
     }
     if (lane == 0) { lds[L_S + KP] = s; lds[L_NG + KP] = ng; lds[L_TAU + KP] = tau; }
+    W64_TICK(3);
     // ---- 5. d = x_tail^T a_tail, the coefficient of the column, row k of R
     const double ak = a[KP];
     double d0 = 0.0, d1 = 0.0;
@@ -224,11 +238,13 @@ __device__ __forceinline__ void step(double (&a)[WR], double* lds, Lane& st, con
     double an = fma(s, ngam, ak);
     if (ispiv) an = beta;                                    // R(k, k)
     a[KP] = an;                                              // final: later steps work on the rows below
+    W64_TICK(4);
     // ---- 6. the trailing update a_tail -= gamma x_tail (columns already chosen are not masked out: nothing below the diagonal of R
     // is ever read, and what they hold stays bounded -- the reflectors are orthogonal)
 #define QRK_W64_UPD(I) if ((I) > KP) fmac_bcast<((I) & 15)>(a[I], xc[(I) >> 4], ngam);
     QRK_W64_0_63(QRK_W64_UPD)
 #undef QRK_W64_UPD
+    W64_TICK(5);
     // ---- 7. LAWN-176 norm downdate (squared form; no clamp at zero: a negative value is <= the threshold and recomputed)
     if (PIVOT && KP + 1 < WR) {
         const double nn = fma(-an, an, st.nu2);
@@ -244,11 +260,12 @@ __device__ __forceinline__ void step(double (&a)[WR], double* lds, Lane& st, con
             if (need) { st.nu2 = sq; st.thr = sq * SQRT_EPS_HI; }
         }
     }
+    W64_TICK(6);
 }
 
 // Q_k = H_k Q_{k+1} on the wave's columns of Q: reflector k from LDS (x_tail as published, s, ng).
 template <int KP>
-__device__ __forceinline__ void back_step(double (&q)[WR], const double* lds, const int lane)
+__device__ __forceinline__ void back_step(double (&q)[WR], const double* lds, const int lane, Lane& st)
 {
     constexpr int M0 = (KP + 1) >> 4;
     const double s = uniform_f64(lds[L_S + KP]), ng = uniform_f64(lds[L_NG + KP]);
@@ -258,14 +275,17 @@ __device__ __forceinline__ void back_step(double (&q)[WR], const double* lds, co
     double d0 = 0.0, d1 = 0.0;
 #pragma unroll
     for (int m = M0; m < 4; ++m) asm volatile("s_nop 1" : "+v"(xc[m]));
+    W64_TICK(7);
 #define QRK_W64_DOT(I) if ((I) > KP) fmac_bcast<((I) & 15)>(((I) & 1) ? d1 : d0, xc[(I) >> 4], q[I]);
     QRK_W64_0_63(QRK_W64_DOT)
 #undef QRK_W64_DOT
     const double ngam = fma(s, qk, d0 + d1) * ng;
     q[KP] = fma(s, ngam, qk);
+    W64_TICK(8);
 #define QRK_W64_UPD(I) if ((I) > KP) fmac_bcast<((I) & 15)>(q[I], xc[(I) >> 4], ngam);
     QRK_W64_0_63(QRK_W64_UPD)
 #undef QRK_W64_UPD
+    W64_TICK(9);
 }
 
 }  // namespace w64
@@ -302,6 +322,10 @@ bdqr_w64_kernel(WaveBatch nb, const double* __restrict__ tiles, double* __restri
 
         Lane st;
         st.lane = lane; st.unclear = false; st.kstep = 0; st.a2 = 0.0;
+#ifdef QRK_W64_PROF
+        for (int z = 0; z < 16; ++z) st.pt[z] = 0;
+        st.pt0 = __builtin_amdgcn_s_memtime();
+#endif
         {
             // =============== phase 1: A -> R ===============
             double a[WR];
@@ -325,10 +349,12 @@ bdqr_w64_kernel(WaveBatch nb, const double* __restrict__ tiles, double* __restri
                 st.nu2 = isA ? s : -1.0;
                 st.thr = s * SQRT_EPS_HI;
             }
+            W64_TICK(10);
 #define QRK_W64_STEP(KP) if ((KP) >= off && (KP) - off < c) step<KP, PIVOT>(a, lds, st, (KP) - off, r);
             QRK_W64_0_63(QRK_W64_STEP)
 #undef QRK_W64_STEP
 
+            W64_TICK(15);
             // ---- R: lane j holds column p = kstep of R in padded rows off .. off + p; the packed CSC value order of m_R
             // (BlockDiagonalSparseQR.h:475-479) puts entry (i, p) at p (p + 1) / 2 + i -- a contiguous run per lane, stored straight
             // from the registers; the permutation splice (:519-521): the column chosen at step p ends at position p
@@ -346,6 +372,7 @@ bdqr_w64_kernel(WaveBatch nb, const double* __restrict__ tiles, double* __restri
             // a decision inside its error margin: the tile is redone by the exact path (bdqr_exact.hip)
             if (__builtin_amdgcn_ballot_w64(st.unclear) != 0ull && redo_count && ln == 0) redo_ids[atomicAdd(redo_count, 1)] = gidx;
         }
+        W64_TICK(11);
         {
             // =============== phase 2: Q = H_0 ... H_{c-1}, backward ===============
             int ln = threadIdx.x;
@@ -353,9 +380,10 @@ bdqr_w64_kernel(WaveBatch nb, const double* __restrict__ tiles, double* __restri
             double q[WR];
 #pragma unroll
             for (int i = 0; i < WR; ++i) q[i] = (i == ln + off) ? 1.0 : 0.0;       // (lanes >= rows: zero columns, never stored)
-#define QRK_W64_BACK(KP) if ((KP) >= off && (KP) - off < c) back_step<KP>(q, lds, ln);
+#define QRK_W64_BACK(KP) if ((KP) >= off && (KP) - off < c) back_step<KP>(q, lds, ln, st);
             QRK_W64_63_0(QRK_W64_BACK)
 #undef QRK_W64_BACK
+            W64_TICK(15);
             // row-major rows of Q_i are the CSR value order of m_Q in both FullQ ([U|N] split, :455-471) and BlockDiagonalQ
             // (:480-492) layouts: one coalesced store per row
             if (ln < r) {
@@ -365,6 +393,13 @@ bdqr_w64_kernel(WaveBatch nb, const double* __restrict__ tiles, double* __restri
                     if (i >= off) dst[(int64_t)(i - off) * r] = q[i];
             }
         }
+        W64_TICK(12);
+#ifdef QRK_W64_PROF
+        if (blockIdx.x == 0 && threadIdx.x == 0)
+            printf("w64 prof %d x %d (s_memtime ticks per tile): load + norms %llu | steps: search %llu  publish %llu  chunks + |x|^2 %llu  scalars %llu  dot %llu  "
+                   "update %llu  downdate %llu | R out %llu | back: loads %llu  dot %llu  update %llu | Q out %llu\n", r, c, st.pt[10], st.pt[0], st.pt[1],
+                   st.pt[2], st.pt[3], st.pt[4], st.pt[5], st.pt[6], st.pt[11], st.pt[7], st.pt[8], st.pt[9], st.pt[12]);
+#endif
         // next tile (the LDS of this one is dead: every lane is past its last read)
         int nxt = 0;
         if (threadIdx.x == 0) nxt = (int)gridDim.x + atomicAdd(queue, 1);

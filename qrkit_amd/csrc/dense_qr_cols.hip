@@ -286,11 +286,22 @@ __global__ void cols_tail_perm_kernel(int c, int size, Work w, int32_t* __restri
 
 }  // namespace cols
 
+// (the persistent form of dense_qr_pers.hip shares the workspace: its synchronisation words and slots follow the tables)
+static size_t cols_tables_bytes(int cpad) { return ((size_t)cpad * (6 * sizeof(double) + 2 * sizeof(int)) + 256 + 255) / 256 * 256; }
 size_t dense_cols_workspace_bytes(int c, int* cpad_out)
 {
     const int cpad = (c + 63) / 64 * 64;
     *cpad_out = cpad;
-    return (size_t)cpad * (6 * sizeof(double) + 2 * sizeof(int)) + 256;
+    return cols_tables_bytes(cpad) + (c >= 256 ? dense_pers_workspace_bytes() : 0);
+}
+static int device_cus()
+{
+    static const int n = [] {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) v = 0;
+        return v;
+    }();
+    return n;
 }
 bool dense_cols_supported(int r, int c) { return r >= 1 && r <= 8000 && c >= 1; }
 int* dense_cols_unclear_ptr(void* workspace, int cpad)
@@ -306,6 +317,10 @@ hipError_t launch_dense_qr_cols(double* A, int64_t lda, int r, int c, int pivoti
                                 int cpad, double* out, int64_t ldo, hipStream_t stream)
 {
     using namespace cols;
+    // up to 2048 x 2048: ONE persistent launch with the matrix in registers (dense_qr_pers.hip) instead of a launch per reflector
+    if (dense_pers_supported(r, c, device_cus()))
+        return launch_dense_qr_pers(A, lda, r, c, pivoting, hcoeffs, perm, dense_cols_unclear_ptr(workspace, cpad) - 2 /* State: {double a2; int unclear} */,
+                                    static_cast<char*>(workspace) + cols_tables_bytes(cpad), device_cus(), out, ldo, stream);
     Work w;
     char* p = static_cast<char*>(workspace);
     for (int q = 0; q < 2; ++q) { w.nu2[q] = reinterpret_cast<double*>(p); p += (size_t)cpad * sizeof(double); }

@@ -118,6 +118,12 @@ hipError_t launch_caqr_apply(const double* A, int64_t lda, int m, int n, const d
 hipError_t launch_caqr_copy_upper(const double* src, int64_t lds_, double* dst, int64_t ldd, int n, int zero_lower, hipStream_t stream);
 // Column-parallel pivoted Householder QR of a square-ish matrix whose columns fit LDS (dense_qr_cols.hip): one kernel per reflector,
 // a wavefront per column; second stage of the two-stage form.
+// ... and the same as ONE persistent launch with the matrix in registers and a grid barrier per reflector (dense_qr_pers.hip): up to
+// 2048 x 2048, rows >= cols; launch_dense_qr_cols dispatches to it (QRK_DENSE_PERS=0: never)
+size_t dense_pers_workspace_bytes();
+bool dense_pers_supported(int r, int c, int num_cus);
+hipError_t launch_dense_qr_pers(const double* A, int64_t lda, int r, int c, int pivoting, double* hcoeffs, int32_t* perm, void* state,
+                                void* workspace, int num_cus, double* out, int64_t ldo, hipStream_t stream);
 size_t dense_cols_workspace_bytes(int c, int* cpad);
 bool dense_cols_supported(int r, int c);
 int* dense_cols_unclear_ptr(void* workspace, int cpad);
