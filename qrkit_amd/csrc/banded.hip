@@ -221,6 +221,42 @@ __device__ __forceinline__ double bb_recip(double x)
     return y;
 }
 
+// Pipelining of the strips form over several workgroups (round 4).  The chain is a true dependency from strip to strip -- but not
+// from the END of a strip: the carry that panel i takes over from panel i - 1 is rows lo_from .. of panel i - 1, row lo_from + r is
+// final as soon as reflector lo_from + r has been applied (later reflectors only touch the rows below), and a block of panel i only
+// works on the carry rows its staircase reaches (stack rows below rlim).  So workgroup g factorises the panels g, g + G, ..; after
+// every block of columns it publishes how many rows of its panel are final (one word per panel, agent-scope release), and before a
+// block it waits until the previous panel has finalised the carry rows that block needs and copies exactly those rows in -- straight
+// from the previous panel's storage, there is no leftover buffer.  For 256 x 192 strips at column step 64 block b of a panel waits
+// for block b + 2 of the one before: two panels are in flight at any time.
+struct BBPipe {
+    const double* prev;        // storage of the previous panel (row-major, prev_n columns), or null for the first panel
+    const int* prev_done;      // its rows-final word
+    int* my_done;              // this panel's
+    int prev_n, lo_from, lo_rows, lo_cols, lo_stride;
+    int copied;                // carry rows already taken over
+};
+__device__ __forceinline__ void bb_pipe_wait(const int* word, int target)
+{
+    if (threadIdx.x == 0) {
+        unsigned spins = 0;
+        while (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(2);
+            if (++spins > (1u << 27)) break;       // (bounded: a lost partner must not hang the GPU; the result is wrong then, and the tests say so)
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+}
+__device__ __forceinline__ void bb_pipe_publish(int* word, int rows_done)
+{
+    __syncthreads();           // every thread's stores of the block have been issued and waited for (the barrier's release)
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __hip_atomic_store(word, rows_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 // LDS doubles the blocked QR needs next to the OB-column block: T of the block, then the larger of {two published
 // Householder vectors, partial V^T W of 8 column strips}
 __host__ __device__ constexpr int bb_qr_aux_doubles(int OB) { return OB * OB + 8 * (OB / 16) * 256; }
@@ -242,7 +278,8 @@ __host__ __device__ constexpr int bb_qr_aux_doubles(int OB) { return OB * OB + 8
 // NR: 64-row registers per lane that hold a column of the block (a block never works on more than 64 NR rows: the caller picks
 // the smallest instantiation that covers its tallest block -- every reflector costs NR FMAs per column and NR LDS reads)
 template <int OB, int NR = 256 / OB>
-__device__ __attribute__((noinline)) void bb_panel_qr(double* __restrict__ W, const int m, const int n, const int* __restrict__ rlim
+__device__ __attribute__((noinline)) void bb_panel_qr(double* __restrict__ W, const int m, const int n, const int* __restrict__ rlim,
+                                                      BBPipe* __restrict__ pipe
 #ifdef QRK_BB_PROF
                                             , unsigned long long* qt
 #endif
@@ -276,6 +313,23 @@ __device__ __attribute__((noinline)) void bb_panel_qr(double* __restrict__ W, co
         int mtop = m;
         if (rlim) { const int lim = rlim[(jb + ob - 1) >> 4]; mtop = lim < m ? lim : m; }
         const int mr = mtop - jb;              // rows jb.. of the panel take part (local row i = panel row jb + i)
+        // 0. (pipelined chain) the carry rows this block reaches, as soon as the previous panel has finalised them
+        if (pipe && pipe->prev && pipe->copied < pipe->lo_rows) {
+            int need = (mtop + pipe->lo_stride - 1) / pipe->lo_stride;
+            if (need > pipe->lo_rows) need = pipe->lo_rows;
+            if (need > pipe->copied) {
+                bb_pipe_wait(pipe->prev_done, pipe->lo_from + need);
+                const int c0 = pipe->copied, lc = pipe->lo_cols;
+                for (int e = tid; e < (need - c0) * lc; e += BC_THREADS) {
+                    const int i = c0 + e / lc, j = e % lc;
+                    W[(int64_t)(i * pipe->lo_stride) * n + j] =
+                        i <= j ? pipe->prev[(int64_t)(pipe->lo_from + i) * pipe->prev_n + pipe->lo_from + j] : 0.0;
+                }
+                __syncthreads();
+                if (tid == 0) pipe->copied = need;
+                __syncthreads();
+            }
+        }
         // 1. block to LDS (coalesced rows of W), then to the registers of the owning waves
         for (int e = tid; e < mr * OB; e += BC_THREADS) {
             const int i = e / OB, l = e - i * OB;
@@ -366,7 +420,7 @@ __device__ __attribute__((noinline)) void bb_panel_qr(double* __restrict__ W, co
             if (l < ob) W[(int64_t)(jb + i) * n + jb + l] = blk[l * ld + i];
         }
         const int c_first = jb + OB, nt = n - c_first;     // columns to the right
-        if (nt <= 0) { __syncthreads(); BB_QTICK(2); continue; }
+        if (nt <= 0) { __syncthreads(); if (pipe) bb_pipe_publish(pipe->my_done, jb + ob); BB_QTICK(2); continue; }
         __syncthreads();
         // 4. V = unit-lower view of the block (in place); T of the block in the recursive form (as for the panel's T
         //    below)
@@ -537,6 +591,7 @@ __device__ __attribute__((noinline)) void bb_panel_qr(double* __restrict__ W, co
             __syncthreads();
             BB_QTICK(3);
         }
+        if (pipe) bb_pipe_publish(pipe->my_done, jb + ob);
     }
 #undef BB_QTICK
 }
@@ -589,13 +644,18 @@ bb_chain2_kernel(const BBPanel* __restrict__ panels, int num_panels, const int32
                  const int32_t* __restrict__ pcol, const int64_t* __restrict__ pmap, const double* __restrict__ vals,
                  double* __restrict__ lo, double* __restrict__ y_vals,
                  double* __restrict__ t_vals, double* __restrict__ r_stage, int max_act_rows, int max_ncols,
-                 int uni_doubles, const int* __restrict__ rlim_first, const int* __restrict__ rlim_rest)
+                 int uni_doubles, const int* __restrict__ rlim_first, const int* __restrict__ rlim_rest, int* __restrict__ done)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double* hc = smem;                         // [BC_CW] hCoeffs of the panel
     double* sc = hc + BC_CW;                   // [8] scalars of the current reflector (two sets)
     double* uni = sc + 8;                      // the blocked QR's (bb_panel_qr); a tile of R rows on the way out
     const int tid = threadIdx.x;
+    // done != null: the pipelined chain (see BBPipe): this workgroup takes the panels blockIdx.x, blockIdx.x + gridDim.x, ..
+    // (its record lives in the last 64 bytes of the dynamic LDS: the kernel already asks for all 160 KB)
+    BBPipe& s_pipe = *reinterpret_cast<BBPipe*>(uni + uni_doubles);
+    static_assert(sizeof(BBPipe) <= 64, "BBPipe fits its LDS slot");
+    const bool piped = done != nullptr;
 #ifdef QRK_BB_PROF
     unsigned long long pt[6] = {0, 0, 0, 0, 0, 0}, t0 = 0, qt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #define BB_TICK(n) do { const unsigned long long t1 = __builtin_amdgcn_s_memtime(); pt[n] += t1 - t0; t0 = t1; } while (0)
@@ -603,7 +663,7 @@ bb_chain2_kernel(const BBPanel* __restrict__ panels, int num_panels, const int32
 #define BB_TICK(n) do { } while (0)
 #endif
 
-    for (int pi = 0; pi < num_panels; ++pi) {
+    for (int pi = piped ? blockIdx.x : 0; pi < num_panels; pi += piped ? gridDim.x : 1) {
         const BBPanel p = panels[pi];
         const int m = p.act_rows, n = p.ncols;          // W is m x n, row-major: W(i, j) = W[i * n + j]
 #ifdef QRK_BB_PROF
@@ -613,12 +673,24 @@ bb_chain2_kernel(const BBPanel* __restrict__ panels, int num_panels, const int32
         // own storage (the factorisation works in place there: what is left below the diagonal is Y) ...
         double* W = y_vals + p.y_off;
         // ... with its top-left corner replaced by the leftover block of the previous panel (:504-506)
-        for (int e = tid; e < p.lo_rows * p.lo_cols; e += BC_THREADS) {
-            const int i = e / p.lo_cols, j = e - i * p.lo_cols;
-            W[(int64_t)(i * p.lo_stride) * n + j] = lo[e];
+        if (!piped) {
+            for (int e = tid; e < p.lo_rows * p.lo_cols; e += BC_THREADS) {
+                const int i = e / p.lo_cols, j = e - i * p.lo_cols;
+                W[(int64_t)(i * p.lo_stride) * n + j] = lo[e];
+            }
+        } else if (tid == 0) {
+            // (pipelined: bb_panel_qr takes the carry rows over block by block, from the previous panel's own storage)
+            const bool has = pi > 0 && p.lo_rows > 0;
+            s_pipe.prev = has ? y_vals + panels[pi - 1].y_off : nullptr;
+            s_pipe.prev_done = has ? done + pi - 1 : nullptr;
+            s_pipe.my_done = done + pi;
+            s_pipe.prev_n = has ? panels[pi - 1].ncols : 0;
+            s_pipe.lo_from = p.lo_from; s_pipe.lo_rows = p.lo_rows; s_pipe.lo_cols = p.lo_cols; s_pipe.lo_stride = p.lo_stride;
+            s_pipe.copied = 0;
         }
         __syncthreads();
         const int* rlim = pi == 0 ? rlim_first : rlim_rest;
+        BBPipe* pipe = piped ? &s_pipe : nullptr;
 
         BB_TICK(0);
         // ---- Eigen::HouseholderQR of the panel (:459-470): blocks of 32 columns when the block fits the LDS
@@ -635,15 +707,15 @@ bb_chain2_kernel(const BBPanel* __restrict__ panels, int num_panels, const int32
         }
         if ((int64_t)32 * (m | 1) + bb_qr_aux_doubles(32) <= (int64_t)uni_doubles) {
 #ifdef QRK_BB_PROF
-            if (tall <= 192) bb_panel_qr<32, 3>(W, m, n, rlim, qt); else if (tall <= 256) bb_panel_qr<32, 4>(W, m, n, rlim, qt); else bb_panel_qr<32>(W, m, n, rlim, qt);
+            if (tall <= 192) bb_panel_qr<32, 3>(W, m, n, rlim, pipe, qt); else if (tall <= 256) bb_panel_qr<32, 4>(W, m, n, rlim, pipe, qt); else bb_panel_qr<32>(W, m, n, rlim, pipe, qt);
 #else
-            if (tall <= 192) bb_panel_qr<32, 3>(W, m, n, rlim); else if (tall <= 256) bb_panel_qr<32, 4>(W, m, n, rlim); else bb_panel_qr<32>(W, m, n, rlim);
+            if (tall <= 192) bb_panel_qr<32, 3>(W, m, n, rlim, pipe); else if (tall <= 256) bb_panel_qr<32, 4>(W, m, n, rlim, pipe); else bb_panel_qr<32>(W, m, n, rlim, pipe);
 #endif
         } else {
 #ifdef QRK_BB_PROF
-            bb_panel_qr<16>(W, m, n, rlim, qt);
+            bb_panel_qr<16>(W, m, n, rlim, pipe, qt);
 #else
-            bb_panel_qr<16>(W, m, n, rlim);
+            bb_panel_qr<16>(W, m, n, rlim, pipe);
 #endif
         }
         __syncthreads();
@@ -665,7 +737,7 @@ bb_chain2_kernel(const BBPanel* __restrict__ panels, int num_panels, const int32
             }
         }
         // ---- leftover block for the next panel: V.block(lo_from, lo_from, lo_rows, lo_cols) (:505), row-major
-        if (pi + 1 < num_panels) {
+        if (pi + 1 < num_panels && !piped) {
             const BBPanel q = panels[pi + 1];
             for (int e = tid; e < q.lo_rows * q.lo_cols; e += BC_THREADS) {
                 const int i = e / q.lo_cols, j = e - i * q.lo_cols;
@@ -902,7 +974,7 @@ bb_t_kernel(const BBPanel* __restrict__ panels, int num_panels, const double* __
 size_t bb_chain2_smem(int max_act_rows, int* uni_doubles)
 {
     const size_t all = (size_t)160 * 1024;
-    const size_t fixed = (size_t)(BC_CW + 8) * sizeof(double);
+    const size_t fixed = (size_t)(BC_CW + 8 + 8) * sizeof(double);       // hc, sc, and (at the end) the BBPipe record
     const size_t qr = ((size_t)16 * (max_act_rows | 1) + bb_qr_aux_doubles(16)) * sizeof(double);
     *uni_doubles = 0;
     if (fixed + qr > all || max_act_rows > 1024) return 0;      // (bb_panel_qr<16> keeps 16 x 64 rows of a column per wave)
@@ -1172,7 +1244,8 @@ hipError_t launch_bb_chain(const BBPanel* panels, int num_panels, const int32_t*
         hipLaunchKernelGGL(bb_scatter_kernel, dim3((unsigned)num_panels), dim3(BC_THREADS),
                            (size_t)(max_act_rows + 2) * sizeof(int), stream, panels, prowptr, pcol, pmap, vals, y_vals);
         hipLaunchKernelGGL(bb_chain2_kernel, dim3(1), dim3(BC_THREADS), smem2, stream, panels, num_panels, prowptr, pcol, pmap,
-                           vals, lo, y_vals, t_vals, r_stage, max_act_rows, max_ncols, uni_doubles, (const int*)nullptr, (const int*)nullptr);
+                           vals, lo, y_vals, t_vals, r_stage, max_act_rows, max_ncols, uni_doubles, (const int*)nullptr, (const int*)nullptr,
+                           (int*)nullptr);
         const size_t smem_t = bb_t_smem(max_ncols, &t_in_lds);
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(bb_t_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)smem_t);
@@ -1234,9 +1307,10 @@ bbs_scatter_kernel(const BBPanel* __restrict__ panels, const double* __restrict_
     }
 }
 
+// done: num_panels ints (the rows-final words of the pipelined chain; zeroed here), or null: one workgroup walks the strips
 hipError_t launch_bbs_chain(const BBPanel* panels, int num_panels, const double* r_packed, int64_t r_stride, int n, int lo,
                             int max_act_rows, double* lo_buf, double* y_vals, double* t_vals, double* r_stage,
-                            const int* rlim_first, const int* rlim_rest, hipStream_t stream)
+                            const int* rlim_first, const int* rlim_rest, int* done, hipStream_t stream)
 {
     int t_in_lds = 0, uni_doubles = 0;
     const size_t smem2 = bb_chain2_smem(max_act_rows, &uni_doubles);
@@ -1244,9 +1318,16 @@ hipError_t launch_bbs_chain(const BBPanel* panels, int num_panels, const double*
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(bb_chain2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem2);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(bbs_scatter_kernel, dim3((unsigned)num_panels), dim3(256), 0, stream, panels, r_packed, r_stride, n, lo, y_vals);
-    hipLaunchKernelGGL(bb_chain2_kernel, dim3(1), dim3(BC_THREADS), smem2, stream, panels, num_panels, (const int32_t*)nullptr,
+    // workgroups of the pipelined chain (QRK_BBS_PIPE: 1 = the single-workgroup chain of round 3): with the carry taken over block by
+    // block two panels overlap; a third and fourth workgroup only add slack
+    int G = 3;
+    if (const char* e2 = std::getenv("QRK_BBS_PIPE")) { const int v = std::atoi(e2); if (v >= 1 && v <= 16) G = v; }
+    if (G > num_panels) G = num_panels;
+    if (!done || lo <= 0) G = 1;
+    if (G > 1) { e = hipMemsetAsync(done, 0, (size_t)num_panels * sizeof(int), stream); if (e != hipSuccess) return e; }
+    hipLaunchKernelGGL(bb_chain2_kernel, dim3((unsigned)G), dim3(BC_THREADS), smem2, stream, panels, num_panels, (const int32_t*)nullptr,
                        (const int32_t*)nullptr, (const int64_t*)nullptr, (const double*)nullptr, lo_buf, y_vals, t_vals, r_stage,
-                       max_act_rows, n, uni_doubles, rlim_first, rlim_rest);
+                       max_act_rows, n, uni_doubles, rlim_first, rlim_rest, G > 1 ? done : (int*)nullptr);
     const size_t smem_t = bb_t_smem(n, &t_in_lds);
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(bb_t_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_t);
     if (e != hipSuccess) return e;

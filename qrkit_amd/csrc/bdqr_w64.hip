@@ -26,6 +26,13 @@
 #include <float.h>
 #include <cstdlib>
 
+#ifndef QRK_W64_PIPELINE
+#define QRK_W64_PIPELINE 0     // 1: the head of step k + 1 (search, publication) is issued before the trailing update of step k and the
+                               // column goes out one update old (corrected on fetch).  Measured SLOWER (64 x 64: 14.4 vs 16.5 M tiles/s,
+                               // 33 x 33: 27.0 vs 30.0, profiles/r04_w64_probe.txt): with two waves per SIMD the other wave already
+                               // covers the stores, and the correction, the write-back of the corrected elements and the readlane are
+                               // added instructions.  Kept behind the switch, parity-tested both ways.
+#endif
 // Diagnostic only: -DQRK_W64_PROF accumulates s_memtime ticks per phase of the step in workgroup 0 and prints them (never a timed build).
 #ifdef QRK_W64_PROF
 #define W64_TICK(z) do { const unsigned long long t1_ = __builtin_amdgcn_s_memtime(); st.pt[z] += t1_ - st.pt0; st.pt0 = t1_; } while (0)
@@ -131,6 +138,8 @@ struct Lane {
     double nu2;       // m_colNormsUpdated^2 (a chosen column carries a negative value: it drops out of the integer arg-max)
     double thr;       // sqrt(eps) (1 + 2^-12) m_colNormsDirect^2
     double a2;        // |A|^2: squared norm of the first pivot column (scale of the decision margins); wave-uniform
+    int P;            // pivot lane of the step whose head ran last (wave-uniform)
+    double ngp;       // the coefficient the running step's pivot column got in the step before, if it was published before that update
 #ifdef QRK_W64_PROF
     unsigned long long pt[16], pt0;
 #endif
@@ -146,14 +155,16 @@ __device__ __forceinline__ void load_chunks(const double* lds, int lane, double 
     for (int m = M0; m < 4; ++m) xc[m] = vcol[16 * m];
 }
 
-// One step of ColPivHouseholderQR::computeInPlace (Eigen/src/QR/ColPivHouseholderQR.h) / HouseholderQR on the wave's tile; KP = padded
-// row of the diagonal, k = KP - off the step.
+// Head of step k (KP = padded row of its diagonal): the pivot -- first maximum of the updated norms over the live columns -- and
+// the PUBLICATION of its column, rows KP.., by its lane.  Non-negative doubles order like their bit patterns: integer max on the high
+// words; every lane within FILTER units is a candidate, a single candidate is a clear decision.  The steps are software-pipelined
+// (step<KP> issues the head of step KP + 1 BEFORE its own trailing update, whose FMAs then cover the single-lane LDS stores: 650
+// cycles per step when they sat on the chain, profiles/r04_w64_step_profile.txt), so the column goes out one update old; `stale`
+// says so and the fetch adds the missing rank-1 term (correct_chunks).
 template <int KP, bool PIVOT>
-__device__ __forceinline__ void step(double (&a)[WR], double* lds, Lane& st, const int k, const int rows)
+__device__ __forceinline__ void search_publish(const double (&a)[WR], double* lds, Lane& st, const int k)
 {
     const int lane = st.lane;
-    // ---- 1. pivot: first maximum of the updated norms over the live columns.  Non-negative doubles order like their bit patterns:
-    // integer max on the high words; every lane within FILTER units is a candidate, a single candidate is a clear decision
     int P;
     if (PIVOT) {
         const int khi = __double2hiint(st.nu2);
@@ -181,50 +192,69 @@ __device__ __forceinline__ void step(double (&a)[WR], double* lds, Lane& st, con
     } else {
         P = k;
     }
-    W64_TICK(0);
-    const bool ispiv = lane == P;
-    if (ispiv) {
+    st.P = P;
+    if (lane == P) {
         st.live = false; st.kstep = k;
         st.nu2 = __hiloint2double((int)0xBF800000, __double2loint(st.nu2));
-        // ---- 2. publish the column (it is reflector k of phase 2 as well)
         double* vcol = lds + L_V + cb(KP) - (KP & ~1);
 #pragma unroll
         for (int i = KP & ~1; i < WR; i += 2) *reinterpret_cast<double2*>(&vcol[i]) = make_double2(a[i], a[i + 1]);
     }
+}
+
+// One step of ColPivHouseholderQR::computeInPlace (Eigen/src/QR/ColPivHouseholderQR.h) / HouseholderQR on the wave's tile; KP = padded
+// row of the diagonal, k = KP - off the step; its head (search_publish<KP>) has run.  xp: the reflector of the step before (this
+// lane's elements), st.ngp: the coefficient that step gave the pivot column of this one (0: the published column is up to date).
+template <int KP, bool PIVOT>
+__device__ __forceinline__ void step(double (&a)[WR], double* lds, Lane& st, double (&xp)[4], const int k, const int rows, const int cols)
+{
+    const int lane = st.lane;
+    if (!QRK_W64_PIPELINE) search_publish<KP, PIVOT>(a, lds, st, k);
+    const bool ispiv = lane == st.P;
     __builtin_amdgcn_wave_barrier();
     W64_TICK(1);
-    // ---- 3. the lanes' elements of it, |x_tail|^2 (every row of 16 lanes the same sum in the same order), x0
+    // ---- 3. the lanes' elements of the pivot column (+ the rank-1 term of the step before, when it went out one update old; the
+    // corrected elements go back to LDS: they are reflector k of phase 2), |x_tail|^2 (every row of 16 lanes the same sum in the
+    // same order), x0
     double xc[4] = {0.0, 0.0, 0.0, 0.0};
     double tsq = 0.0, xk;
     constexpr int M0 = (KP + 1) >> 4, MK = KP >> 4;
     if (KP + 1 < WR) {
         load_chunks<KP>(lds, lane, xc);
+        if (QRK_W64_PIPELINE) {
+            const double ngp = st.ngp;
+#pragma unroll
+            for (int m = M0; m < 4; ++m) xc[m] = fma(ngp, xp[m], xc[m]);
+            // (the chunk that holds the diagonal starts above the column's storage: only the rows the column owns go back)
+            double* vcol = lds + L_V + cb(KP) - (KP & ~1) + lane;
+#pragma unroll
+            for (int m = M0; m < 4; ++m)
+                if (lane < 16 && (m > MK || 16 * m + lane >= (KP & ~1))) vcol[16 * m] = xc[m];
+        }
         double p = 0.0;
 #pragma unroll
         for (int m = M0; m < 4; ++m) {
             const double x = (m == MK) ? (((lane & 15) > (KP & 15)) ? xc[m] : 0.0) : xc[m];
             p = fma(x, x, p);
         }
-        tsq = uniform_f64(row16_sum(p));
+        tsq = row16_sum(p);
     }
-    if (MK >= M0) xk = uniform_f64(bcast_f64<(KP & 15)>(xc[MK]));
-    else xk = uniform_f64(lds[L_V + cb(KP) + (KP & 1)]);          // (row KP is the last one of its chunk: no element of that chunk was loaded)
+    if (MK >= M0) xk = bcast_f64<(KP & 15)>(xc[MK]);
+    else if (QRK_W64_PIPELINE) xk = fma(st.ngp, readlane_f64(xp[MK], 15), lds[L_V + cb(KP) + (KP & 1)]);   // (row KP is the last one of its chunk: not among the loaded ones)
+    else xk = lds[L_V + cb(KP) + (KP & 1)];
     W64_TICK(2);
     if (k == 0 && !PIVOT) st.a2 = fma(xk, xk, tsq);
     if (unclear_reflector(xk, tsq, k + 1 < rows, PIVOT, st.a2)) st.unclear = true;
     // ---- 4. makeHouseholder in the un-normalised form (bdqr_pair.hip): nb = -beta = copysign(norm, x0), s = x0 - beta,
-    // ng = -1 / (beta (x0 - beta)); Eigen: tailSqNorm <= min() gives tau = 0, beta = x0, H = I
-    double beta, s, ng, tau;
-    if (!(tsq > DBL_MIN)) { beta = xk; s = 0.0; ng = 0.0; tau = 0.0; }
-    else {
-        const double nrm = sqrt_pos(fma(xk, xk, tsq));
-        const double nbv = xk >= 0.0 ? nrm : -nrm;         // (-0.0 counts as >= 0, as in Eigen)
-        beta = uniform_f64(-nbv);
-        s = uniform_f64(nbv + xk);
-        ng = uniform_f64(-recip(nbv * s));
-        tau = -(s * s) * ng;
-    }
-    if (lane == 0) { lds[L_S + KP] = s; lds[L_NG + KP] = ng; lds[L_TAU + KP] = tau; }
+    // ng = -1 / (beta (x0 - beta)); Eigen: tailSqNorm <= min() gives tau = 0, beta = x0, H = I.  (Per-lane values, the same in
+    // every lane: selects instead of a branch, nothing through the scalar registers.)
+    const bool degen = !(tsq > DBL_MIN);
+    const double nrm = sqrt_pos(fma(xk, xk, degen ? 1.0 : tsq));
+    const double nbv = xk >= 0.0 ? nrm : -nrm;             // (-0.0 counts as >= 0, as in Eigen)
+    const double beta = degen ? xk : -nbv;
+    const double s = degen ? 0.0 : nbv + xk;
+    const double ng = degen ? 0.0 : -recip(nbv * (nbv + xk));
+    if (lane == 0) { lds[L_S + KP] = s; lds[L_NG + KP] = ng; lds[L_TAU + KP] = -(s * s) * ng; }
     W64_TICK(3);
     // ---- 5. d = x_tail^T a_tail, the coefficient of the column, row k of R
     const double ak = a[KP];
@@ -239,26 +269,40 @@ __device__ __forceinline__ void step(double (&a)[WR], double* lds, Lane& st, con
     if (ispiv) an = beta;                                    // R(k, k)
     a[KP] = an;                                              // final: later steps work on the rows below
     W64_TICK(4);
-    // ---- 6. the trailing update a_tail -= gamma x_tail (columns already chosen are not masked out: nothing below the diagonal of R
-    // is ever read, and what they hold stays bounded -- the reflectors are orthogonal)
+    // the trailing update a_tail -= gamma x_tail (columns already chosen are not masked out: nothing below the diagonal of R is
+    // ever read, and what they hold stays bounded -- the reflectors are orthogonal)
 #define QRK_W64_UPD(I) if ((I) > KP) fmac_bcast<((I) & 15)>(a[I], xc[(I) >> 4], ngam);
-    QRK_W64_0_63(QRK_W64_UPD)
-#undef QRK_W64_UPD
-    W64_TICK(5);
-    // ---- 7. LAWN-176 norm downdate (squared form; no clamp at zero: a negative value is <= the threshold and recomputed)
+    // ---- 6. LAWN-176 norm downdate (squared form; no clamp at zero: a negative value is <= the threshold and recomputed)
+    bool updated = false;
     if (PIVOT && KP + 1 < WR) {
         const double nn = fma(-an, an, st.nu2);
         st.nu2 = nn;
         const bool need = st.live && nn <= st.thr;
         if (__builtin_expect(__builtin_amdgcn_ballot_w64(need) != 0ull, 0)) {
+            // rare: a column norm has to be recomputed from the UPDATED column before the next search
             asm volatile("");
             if (need && in_recompute_band(nn, st.thr, st.a2)) st.unclear = true;      // decision (2)
+            QRK_W64_0_63(QRK_W64_UPD)
+            updated = true;
             double sq = 0.0;
 #define QRK_W64_SQ(I) if ((I) > KP) sq = fma(a[I], a[I], sq);
             QRK_W64_0_63(QRK_W64_SQ)
 #undef QRK_W64_SQ
             if (need) { st.nu2 = sq; st.thr = sq * SQRT_EPS_HI; }
         }
+    }
+    W64_TICK(5);
+    // ---- 7. head of the next step, then the trailing update of this one
+    if (QRK_W64_PIPELINE && KP + 1 < WR && k + 1 < cols) {
+        search_publish<(KP + 1 < WR ? KP + 1 : KP), PIVOT>(a, lds, st, k + 1);
+        st.ngp = updated ? 0.0 : readlane_f64(ngam, st.P);
+    }
+    W64_TICK(0);
+    if (!updated) { QRK_W64_0_63(QRK_W64_UPD) }
+#undef QRK_W64_UPD
+    if (QRK_W64_PIPELINE) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) xp[m] = xc[m];
     }
     W64_TICK(6);
 }
@@ -350,7 +394,12 @@ bdqr_w64_kernel(WaveBatch nb, const double* __restrict__ tiles, double* __restri
                 st.thr = s * SQRT_EPS_HI;
             }
             W64_TICK(10);
-#define QRK_W64_STEP(KP) if ((KP) >= off && (KP) - off < c) step<KP, PIVOT>(a, lds, st, (KP) - off, r);
+            double xp[4] = {0.0, 0.0, 0.0, 0.0};
+            st.ngp = 0.0; st.P = 0;
+#define QRK_W64_HEAD(KP) if (QRK_W64_PIPELINE && (KP) == off) search_publish<KP, PIVOT>(a, lds, st, 0);
+            QRK_W64_0_63(QRK_W64_HEAD)
+#undef QRK_W64_HEAD
+#define QRK_W64_STEP(KP) if ((KP) >= off && (KP) - off < c) step<KP, PIVOT>(a, lds, st, xp, (KP) - off, r, c);
             QRK_W64_0_63(QRK_W64_STEP)
 #undef QRK_W64_STEP
 

@@ -124,6 +124,7 @@ struct qrk_bbs_plan_s {
     std::vector<qrk::BBPanel> panels;
     qrk::BBPanel* d_panels = nullptr;
     int32_t* d_rlim = nullptr;          // [2][n / 16]: staircase row limits of panel 0 / of the other panels
+    int32_t* d_done = nullptr;          // [N] rows-final words of the pipelined chain (banded.hip, BBPipe)
     double *d_q = nullptr, *d_ra = nullptr;     // stage A: explicit Q_i (ms x ms each), packed R_i
     int32_t* d_perm = nullptr;
     double *d_y = nullptr, *d_t = nullptr, *d_stage = nullptr, *d_lo = nullptr;   // stage B: panels (Y below the diagonal), T, rows of R, carry
@@ -1741,7 +1742,8 @@ qrk_status qrk_bbs_plan_create(qrk_handle h, int64_t num_strips, int32_t strip_r
         hipMalloc((void**)&p->d_y, (size_t)p->y_len * sizeof(double)) != hipSuccess ||
         hipMalloc((void**)&p->d_t, (size_t)p->t_len * sizeof(double)) != hipSuccess ||
         hipMalloc((void**)&p->d_stage, (size_t)p->stage_len * sizeof(double)) != hipSuccess ||
-        hipMalloc((void**)&p->d_lo, (size_t)(lo > 0 ? lo * lo : 1) * sizeof(double)) != hipSuccess) {
+        hipMalloc((void**)&p->d_lo, (size_t)(lo > 0 ? lo * lo : 1) * sizeof(double)) != hipSuccess ||
+        hipMalloc((void**)&p->d_done, (size_t)num_strips * sizeof(int32_t)) != hipSuccess) {
         qrk_bbs_plan_destroy(p);
         return fail(h, QRK_STATUS_ALLOC_FAILED, "qrk_bbs_plan_create: cannot allocate the factors (Q of stage A, panels and T of stage B)");
     }
@@ -1754,7 +1756,7 @@ qrk_status qrk_bbs_plan_destroy(qrk_bbs_plan p)
     if (!p) return QRK_STATUS_OK;
     if (p->bd) (void)qrk_bd_plan_destroy(p->bd);
     (void)hipFree(p->d_panels); (void)hipFree(p->d_rlim); (void)hipFree(p->d_q); (void)hipFree(p->d_ra); (void)hipFree(p->d_perm);
-    (void)hipFree(p->d_y); (void)hipFree(p->d_t); (void)hipFree(p->d_stage); (void)hipFree(p->d_lo);
+    (void)hipFree(p->d_y); (void)hipFree(p->d_t); (void)hipFree(p->d_stage); (void)hipFree(p->d_lo); (void)hipFree(p->d_done);
     delete p;
     return QRK_STATUS_OK;
 }
@@ -1780,7 +1782,7 @@ qrk_status qrk_bbs_factorize(qrk_bbs_plan p, const double* strips)
     // stage B: the chain merges the carried triangle with the strip's
     const int ng = p->n / 16;
     QRK_HIP(h, qrk::launch_bbs_chain(p->d_panels, (int)p->N, p->d_ra, (int64_t)p->n * (p->n + 1) / 2, p->n, p->lo, p->max_act, p->d_lo,
-                                     p->d_y, p->d_t, p->d_stage, p->d_rlim, p->d_rlim + ng, h->stream));
+                                     p->d_y, p->d_t, p->d_stage, p->d_rlim, p->d_rlim + ng, p->d_done, h->stream));
     p->factorized = true;
     if (std::getenv("QRK_BBS_PROF_DUMP")) {
         // diagnostic builds of banded.hip (-DQRK_BB_PROF) leave the chain's tick counts in the T of the last panel
