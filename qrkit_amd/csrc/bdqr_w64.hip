@@ -237,24 +237,29 @@ __device__ __forceinline__ void step(double (&a)[WR], double* lds, Lane& st, dou
             const double x = (m == MK) ? (((lane & 15) > (KP & 15)) ? xc[m] : 0.0) : xc[m];
             p = fma(x, x, p);
         }
-        tsq = row16_sum(p);
+        tsq = uniform_f64(row16_sum(p));
     }
-    if (MK >= M0) xk = bcast_f64<(KP & 15)>(xc[MK]);
-    else if (QRK_W64_PIPELINE) xk = fma(st.ngp, readlane_f64(xp[MK], 15), lds[L_V + cb(KP) + (KP & 1)]);   // (row KP is the last one of its chunk: not among the loaded ones)
-    else xk = lds[L_V + cb(KP) + (KP & 1)];
+    if (MK >= M0) xk = uniform_f64(bcast_f64<(KP & 15)>(xc[MK]));
+    else if (QRK_W64_PIPELINE) xk = uniform_f64(fma(st.ngp, readlane_f64(xp[MK], 15), lds[L_V + cb(KP) + (KP & 1)]));   // (row KP is the last one of its chunk: not among the loaded ones)
+    else xk = uniform_f64(lds[L_V + cb(KP) + (KP & 1)]);
     W64_TICK(2);
     if (k == 0 && !PIVOT) st.a2 = fma(xk, xk, tsq);
     if (unclear_reflector(xk, tsq, k + 1 < rows, PIVOT, st.a2)) st.unclear = true;
     // ---- 4. makeHouseholder in the un-normalised form (bdqr_pair.hip): nb = -beta = copysign(norm, x0), s = x0 - beta,
-    // ng = -1 / (beta (x0 - beta)); Eigen: tailSqNorm <= min() gives tau = 0, beta = x0, H = I.  (Per-lane values, the same in
-    // every lane: selects instead of a branch, nothing through the scalar registers.)
-    const bool degen = !(tsq > DBL_MIN);
-    const double nrm = sqrt_pos(fma(xk, xk, degen ? 1.0 : tsq));
-    const double nbv = xk >= 0.0 ? nrm : -nrm;             // (-0.0 counts as >= 0, as in Eigen)
-    const double beta = degen ? xk : -nbv;
-    const double s = degen ? 0.0 : nbv + xk;
-    const double ng = degen ? 0.0 : -recip(nbv * (nbv + xk));
-    if (lane == 0) { lds[L_S + KP] = s; lds[L_NG + KP] = ng; lds[L_TAU + KP] = -(s * s) * ng; }
+    // ng = -1 / (beta (x0 - beta)); Eigen: tailSqNorm <= min() gives tau = 0, beta = x0, H = I.  The scalars go through the scalar
+    // registers and the degenerate case is a real (uniform) branch: as per-lane values with selects the step becomes one basic block
+    // whose schedule needs 256 VGPRs and 636 spills (64 x 64: 10.8 instead of 16.5 M tiles/s).
+    double beta, s, ng, tau;
+    if (!(tsq > DBL_MIN)) { beta = xk; s = 0.0; ng = 0.0; tau = 0.0; }
+    else {
+        const double nrm = sqrt_pos(fma(xk, xk, tsq));
+        const double nbv = xk >= 0.0 ? nrm : -nrm;         // (-0.0 counts as >= 0, as in Eigen)
+        beta = uniform_f64(-nbv);
+        s = uniform_f64(nbv + xk);
+        ng = uniform_f64(-recip(nbv * s));
+        tau = -(s * s) * ng;
+    }
+    if (lane == 0) { lds[L_S + KP] = s; lds[L_NG + KP] = ng; lds[L_TAU + KP] = tau; }
     W64_TICK(3);
     // ---- 5. d = x_tail^T a_tail, the coefficient of the column, row k of R
     const double ak = a[KP];
@@ -272,6 +277,7 @@ __device__ __forceinline__ void step(double (&a)[WR], double* lds, Lane& st, dou
     // the trailing update a_tail -= gamma x_tail (columns already chosen are not masked out: nothing below the diagonal of R is
     // ever read, and what they hold stays bounded -- the reflectors are orthogonal)
 #define QRK_W64_UPD(I) if ((I) > KP) fmac_bcast<((I) & 15)>(a[I], xc[(I) >> 4], ngam);
+#if QRK_W64_PIPELINE
     // ---- 6. LAWN-176 norm downdate (squared form; no clamp at zero: a negative value is <= the threshold and recomputed)
     bool updated = false;
     if (PIVOT && KP + 1 < WR) {
@@ -293,17 +299,36 @@ __device__ __forceinline__ void step(double (&a)[WR], double* lds, Lane& st, dou
     }
     W64_TICK(5);
     // ---- 7. head of the next step, then the trailing update of this one
-    if (QRK_W64_PIPELINE && KP + 1 < WR && k + 1 < cols) {
+    if (KP + 1 < WR && k + 1 < cols) {
         search_publish<(KP + 1 < WR ? KP + 1 : KP), PIVOT>(a, lds, st, k + 1);
         st.ngp = updated ? 0.0 : readlane_f64(ngam, st.P);
     }
     W64_TICK(0);
     if (!updated) { QRK_W64_0_63(QRK_W64_UPD) }
-#undef QRK_W64_UPD
-    if (QRK_W64_PIPELINE) {
 #pragma unroll
-        for (int m = 0; m < 4; ++m) xp[m] = xc[m];
+    for (int m = 0; m < 4; ++m) xp[m] = xc[m];
+#else
+    // ---- 6. the trailing update, then the LAWN-176 norm downdate (squared form; no clamp at zero: a negative value is <= the
+    // threshold and recomputed from the updated column)
+    QRK_W64_0_63(QRK_W64_UPD)
+    W64_TICK(5);
+    if (PIVOT && KP + 1 < WR) {
+        const double nn = fma(-an, an, st.nu2);
+        st.nu2 = nn;
+        const bool need = st.live && nn <= st.thr;
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(need) != 0ull, 0)) {
+            asm volatile("");
+            if (need && in_recompute_band(nn, st.thr, st.a2)) st.unclear = true;      // decision (2)
+            double sq = 0.0;
+#define QRK_W64_SQ(I) if ((I) > KP) sq = fma(a[I], a[I], sq);
+            QRK_W64_0_63(QRK_W64_SQ)
+#undef QRK_W64_SQ
+            if (need) { st.nu2 = sq; st.thr = sq * SQRT_EPS_HI; }
+        }
     }
+    (void)cols; (void)xp;
+#endif
+#undef QRK_W64_UPD
     W64_TICK(6);
 }
 

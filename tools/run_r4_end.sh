@@ -14,6 +14,7 @@ cd $ROOT
 f=$(find $OUT/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cut -c1-220 "$f" | head -8 > $OUT/kernel_stats.csv; cat $OUT/kernel_stats.csv
 tail -1 $OUT/prof.log | cut -c1-600 > $OUT/bench_profiled_line.txt
 find $OUT/prof -name "*.db" -delete 2>/dev/null; find $OUT/prof -name "*trace.csv" -delete 2>/dev/null
+mkdir -p $OUT/pmc
 cd /tmp
 i=0
 for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES"; do
