@@ -276,8 +276,9 @@ qrk_status qrk_dense_gemv_sub(qrk_handle h, const double* S, int64_t lds, int64_
  * is made dense on the device (its nonzeros cross PCIe) and factorised panel by panel: a panel of block_cols columns takes the rows
  * its sparsity pattern says (updateBlockInfo, :203-238), is factorised by the column-pivoted dense solver (qrk_dense_factorize:
  * decisions inside rounding go through the exact path as everywhere), its reflectors are applied to the columns on the right, and
- * its columns of R are written (:271-279).  The number of nonzero pivots of a panel (Eigen's threshold) decides the rows of the next
- * one, so one word per panel travels to the host.  Both language mirrors (include/qrkit/QRKit.hpp, qrkit_amd/angular.py) call this. */
+ * its columns of R are written (:271-279).  The number of nonzero pivots of a panel (:250-256, Eigen's nonzeroPivots(): counted on the
+ * device from the downdated column norms -- the exact path's own table when a pivot is anywhere near the threshold) decides the rows
+ * of the next one, so one word per panel travels to the host.  Both language mirrors (include/qrkit/QRKit.hpp, qrkit_amd/angular.py) call this. */
 typedef struct qrk_thin_plan_s* qrk_thin_plan;
 qrk_status qrk_thin_sparse_factorize(qrk_handle h, int32_t rows, int32_t cols, int32_t block_cols, const int32_t* colptr,
                                      const int32_t* rowidx, const double* vals, qrk_thin_plan* out);

@@ -143,6 +143,7 @@ dense_exact_kernel(double* __restrict__ A, int64_t lda, int r, int c, const doub
     double* nu = xbuf + r;                // [c] m_colNormsUpdated
     double* nd = nu + c;                  // [c] m_colNormsDirect
     int* pidx = reinterpret_cast<int*>(nd + c);   // [c]
+    double* pivn = reinterpret_cast<double*>(pidx + ((c + 1) & ~1));   // [c] m_colNormsUpdated of the chosen column, per step (wide_ws below)
     if (copy)
         for (int64_t e = t; e < (int64_t)r * c; e += DT) { const int64_t j = e / r; A[j * lda + (e - j * r)] = copy[e]; }
     for (int j = t; j < c; j += DT) pidx[j] = j;
@@ -169,6 +170,7 @@ dense_exact_kernel(double* __restrict__ A, int64_t lda, int r, int c, const doub
                 __syncthreads();
             }
             const int b = spos[0];
+            if (t == 0) pivn[k] = sval[0];        // (Eigen: biggest_col_sq_norm = abs2 of this; nonzeroPivots() is counted from it)
             __syncthreads();
             if (b != k) {       // m_qr.col(k).swap(m_qr.col(b)), the two norm tables, the transposition
                 double* ck = A + (int64_t)k * lda;
@@ -300,11 +302,14 @@ __device__ __forceinline__ void chain_update(const double* x, double* y, int i0,
 #undef QRK_TAIL
 }
 
-struct WideWs { double* xbuf; double* nu; double* nd; int* pidx; };
+// pivn [c]: m_colNormsUpdated of the column chosen at every step (the biggest one, Eigen's biggest_col_sq_norm before squaring): what
+// nonzeroPivots() is counted from (ColPivHouseholderQR::computeInPlace; BlockedThinSparseQR.h:250-256 reads it)
+struct WideWs { double* xbuf; double* nu; double* nd; int* pidx; double* pivn; };
 __host__ __device__ inline WideWs wide_ws(double* ws, int r, int c)
 {
     WideWs w;
     w.xbuf = ws; w.nu = ws + r; w.nd = w.nu + c; w.pidx = reinterpret_cast<int*>(w.nd + c);
+    w.pivn = reinterpret_cast<double*>(w.pidx + ((c + 1) & ~1));
     return w;
 }
 
@@ -343,6 +348,7 @@ dense_exact_wide_head_kernel(double* __restrict__ A, int64_t lda, int r, int c, 
             __syncthreads();
         }
         const int b = spos[0];
+        if (t == 0) w.pivn[k] = sval[0];
         __syncthreads();
         if (b != k) {       // m_qr.col(k).swap(m_qr.col(b)), the two norm tables, the transposition
             double* ck = A + (int64_t)k * lda;
@@ -440,7 +446,8 @@ hipError_t launch_dense_exact_wide(double* A, int64_t lda, int r, int c, int piv
     return hipGetLastError();
 }
 
-size_t dense_exact_workspace_bytes(int r, int c) { return ((size_t)r + 2 * (size_t)c) * sizeof(double) + (size_t)c * sizeof(int) + 64; }
+size_t dense_exact_workspace_bytes(int r, int c) { return ((size_t)r + 3 * (size_t)c) * sizeof(double) + (size_t)(c + 1) * sizeof(int) + 64; }
+const double* dense_exact_pivot_norms(const double* workspace, int r, int c) { return exact::wide_ws(const_cast<double*>(workspace), r, c).pivn; }
 
 hipError_t launch_dense_exact(double* A, int64_t lda, int r, int c, int pivoting, const double* copy, double* hcoeffs,
                               int32_t* perm, const int* unclear, double* workspace, hipStream_t stream)

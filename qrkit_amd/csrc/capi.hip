@@ -148,12 +148,28 @@ thin_r_columns_kernel(const double* __restrict__ D, int64_t ldd, const double* _
     for (int i = threadIdx.x; i < nzp; i += 256) dst[i] = src[i];
     for (int i = threadIdx.x; i < k; i += 256) dst[nzp + i] = i <= bc ? Ji[(int64_t)bc * ldj + i] : 0.0;
 }
-// [diag(Ji)(0:k) | perm as doubles (0:nnew)] in one buffer: one small copy to the host per panel
-__global__ void thin_pack_kernel(const double* __restrict__ Ji, int64_t ldj, const int32_t* __restrict__ pp, int k, int nnew, double* __restrict__ out)
+// [nonzeroPivots() | perm as doubles (0:nnew)] in one buffer: one small copy to the host per panel.  nonzeroPivots() as Eigen counts
+// it (ColPivHouseholderQR::computeInPlace): the first step q whose biggest updated column norm, squared, is below
+// threshold_helper (rows - q), threshold_helper = (largest initial norm * eps)^2 / rows, `rows` = the panel's own height.  The fast
+// kernels only finish a factorisation themselves when every pivot is far above that (a pivot below 2^-30 |A| sends the block to the
+// exact path, decision (5)): then the count is k.  When the exact path ran, its own norm table (m_colNormsUpdated in Eigen's
+// rounding, pivn) decides -- not |R_qq|, which equals the updated norm only up to rounding.
+__global__ void thin_pack_kernel(const int32_t* __restrict__ pp, int k, int nnew, int nrows, const int* __restrict__ flag, int exact_known,
+                                 const double* __restrict__ pivn, double* __restrict__ out)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < k) out[i] = Ji[(int64_t)i * ldj + i];
-    if (i < nnew) out[k + i] = (double)pp[i];
+    if (i < nnew) out[1 + i] = (double)pp[i];
+    if (i == 0) {
+        const bool exact = exact_known >= 0 ? exact_known != 0 : (flag ? *flag != 0 : true);
+        int nz = k;
+        if (exact && k > 0) {
+            const double eps = 2.220446049250313e-16, maxn = pivn[0];
+            const double thr = ((maxn * eps) * (maxn * eps)) / (double)nrows;
+            for (int q = 0; q < k; ++q)
+                if (pivn[q] * pivn[q] < thr * (double)(nrows - q)) { nz = q; break; }
+        }
+        out[0] = (double)nz;
+    }
 }
 }  // namespace qrk
 
@@ -190,6 +206,8 @@ struct qrk_dense_plan_s {
     int* d_unclear = nullptr;
     int* h_unclear = nullptr;      // pinned: where the host reads the flag word (two-stage and exact_wide plans synchronise the stream)
     double* d_exact_ws = nullptr;
+    const int* last_flag = nullptr;   // device word that says whether the last factorisation went through the exact path (null: see last_exact)
+    int last_exact = -1;              // 1 / 0: known on the host (forced, or read back by an exact_wide plan); -1: the device word decides
     // two-stage form of the pivoted factorisation of a tall matrix (caqr.hip): A = Q0 R0 without pivoting on the matrix cores,
     // then R0 P = Q1 R by the level-2 kernels on the n x n triangle.  d_r0 keeps the packed QR of the second stage, d_t the T
     // factors of the first; the caller's array holds the reflectors of Q0 below / inside its top triangles and R above.
@@ -230,6 +248,30 @@ qrk_status fail(qrk_handle h, qrk_status st, const std::string& msg)
             return fail((h), QRK_STATUS_HIP_ERROR,                                             \
                         std::string(#expr) + ": " + hipGetErrorString(e_));                    \
     } while (0)
+
+// The handle's pool of side streams (fork after / join into the caller's stream), created ONCE, when the handle is created: the classes of a
+// mixed batch run on them side by side, and the look-ahead of the dense solver's first stage uses the two high-priority ones.  Why a
+// pool and why eagerly: ROCm maps streams onto a few hardware queues in creation order, and streams that share a queue serialise.
+// With per-plan streams created on first use, the SAME 40 000 x 2 000 factorisation took 47 ms in a fresh process and 59 ms after a
+// mixed batch had created its three streams first (the look-ahead stream then shared a queue with the caller's: profiles/
+// r04_stream_pool.txt); with the pool the assignment is fixed at qrk_create, before the caller's workload has created anything.
+qrk_status ensure_pool(qrk_handle h)
+{
+    if (h->ev_fork) return QRK_STATUS_OK;
+    QRK_HIP(h, hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+    int prio_least = 0, prio_greatest = 0;
+    QRK_HIP(h, hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
+    const bool use_prio = !(std::getenv("QRK_COL_PRIO") && std::atoi(std::getenv("QRK_COL_PRIO")) == 0);
+    for (int z = 2; z >= 0; --z) {
+        // side[2], side[1]: highest priority (the class of the largest tiles of a mixed batch -- the critical path of the batch -- and the
+        // next one; the look-ahead panel and the urgent applies of the dense solver: a panel workgroup needs the LDS of one apply
+        // workgroup and should get the next slot that frees up); side[0]: lowest
+        const int prio = !use_prio ? prio_least : (z >= 1 ? prio_greatest : prio_least);
+        QRK_HIP(h, hipStreamCreateWithPriority(&h->side[z], hipStreamNonBlocking, prio));
+        QRK_HIP(h, hipEventCreateWithFlags(&h->ev_join[z], hipEventDisableTiming));
+    }
+    return QRK_STATUS_OK;
+}
 
 template <typename T>
 qrk_status upload(qrk_handle h, const std::vector<T>& v, T** out)
@@ -369,18 +411,7 @@ qrk_status enqueue_factorize(qrk_bd_plan_s* p, const double* tiles, double* q, d
                 QRK_HIP(h, launch_col_class(k, cb, tiles, q, r, perm, hc, p->d_col_workspace + k.ws_off, redo_cnt, redo_ids, p->d_redo + 2 + p->B + z, h->stream));
             }
         } else if (p->n_col > 0) {
-            if (!h->ev_fork) {
-                QRK_HIP(h, hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
-                int prio_least = 0, prio_greatest = 0;
-                QRK_HIP(h, hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
-                const bool use_prio = !(std::getenv("QRK_COL_PRIO") && std::atoi(std::getenv("QRK_COL_PRIO")) == 0);
-                for (int z = 0; z < 3; ++z) {
-                    // (the class of the largest tiles first in line for the CUs: its tiles are the critical path of a mixed batch)
-                    const int prio = !use_prio ? prio_least : (z == 2 ? prio_greatest : (z == 1 ? (prio_least + prio_greatest) / 2 : prio_least));
-                    QRK_HIP(h, hipStreamCreateWithPriority(&h->side[z], hipStreamNonBlocking, prio));
-                    QRK_HIP(h, hipEventCreateWithFlags(&h->ev_join[z], hipEventDisableTiming));
-                }
-            }
+            if (qrk_status stp = ensure_pool(h)) return stp;
             QRK_HIP(h, hipEventRecord(h->ev_fork, h->stream));
             for (int z = 2; z >= 0; --z) {            // (largest class first)
                 const auto& k = p->col_cls[z];
@@ -456,6 +487,7 @@ qrk_status qrk_create(qrk_handle* out, int device, void* stream)
             return fail(nullptr, QRK_STATUS_UNSUPPORTED, msg);
         }
     }
+    if (qrk_status stp = ensure_pool(h)) { const std::string msg = h->error; qrk_destroy(h); return fail(nullptr, stp, msg); }
     *out = h;
     return QRK_STATUS_OK;
 }
@@ -1057,19 +1089,20 @@ qrk_status qrk_dense_plan_create(qrk_handle h, int32_t rows, int32_t cols, qrk_b
     if (p->two_stage || p->caqr_only) {
         const char* la = std::getenv("QRK_CAQR_LOOKAHEAD");
         // (highest priority: a panel workgroup needs the LDS of one apply workgroup and should get the next slot that frees up)
-        int prio_least = 0, prio_greatest = 0;
-        (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
-        if (!(la && la[0] == '0') &&
-            (hipStreamCreateWithPriority(&p->la_stream, hipStreamNonBlocking, prio_greatest) != hipSuccess ||
-             hipEventCreateWithFlags(&p->la_urgent, hipEventDisableTiming) != hipSuccess ||
-             hipEventCreateWithFlags(&p->la_factored, hipEventDisableTiming) != hipSuccess)) {
-            qrk_dense_plan_destroy(p);
-            return fail(h, QRK_STATUS_ALLOC_FAILED, "qrk_dense_plan_create: cannot create the look-ahead stream");
+        // (the streams are the handle's: ensure_pool)
+        if (!(la && la[0] == '0')) {
+            if (ensure_pool(h) != QRK_STATUS_OK ||
+                hipEventCreateWithFlags(&p->la_urgent, hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&p->la_factored, hipEventDisableTiming) != hipSuccess) {
+                qrk_dense_plan_destroy(p);
+                return fail(h, QRK_STATUS_ALLOC_FAILED, "qrk_dense_plan_create: cannot create the look-ahead events");
+            }
+            p->la_stream = h->side[2];
         }
         const char* pe = std::getenv("QRK_CAQR_PIPE");
         if (p->la_stream && !(pe && pe[0] == '0')) {
-            bool ok = hipStreamCreateWithPriority(&p->la_pipe.urgent, hipStreamNonBlocking, prio_greatest) == hipSuccess &&
-                      hipEventCreateWithFlags(&p->la_pipe.ev_n2, hipEventDisableTiming) == hipSuccess &&
+            p->la_pipe.urgent = h->side[1];
+            bool ok = hipEventCreateWithFlags(&p->la_pipe.ev_n2, hipEventDisableTiming) == hipSuccess &&
                       hipEventCreateWithFlags(&p->la_pipe.ev_u, hipEventDisableTiming) == hipSuccess;
             for (int l = 0; ok && l < qrk::CaqrPipe::MAXL; ++l) ok = hipEventCreateWithFlags(&p->la_pipe.ev_lvl[l], hipEventDisableTiming) == hipSuccess;
             if (!ok) {
@@ -1095,10 +1128,8 @@ qrk_status qrk_dense_plan_destroy(qrk_dense_plan p)
     if (p) {
         (void)hipFree(p->d_ws); (void)hipFree(p->d_copy); (void)hipFree(p->d_unclear); (void)hipFree(p->d_exact_ws);
         if (p->h_unclear) (void)hipHostFree(p->h_unclear);
-        if (p->la_stream) (void)hipStreamDestroy(p->la_stream);
         if (p->la_urgent) (void)hipEventDestroy(p->la_urgent);
         if (p->la_factored) (void)hipEventDestroy(p->la_factored);
-        if (p->la_pipe.urgent) (void)hipStreamDestroy(p->la_pipe.urgent);
         if (p->la_pipe.ev_n2) (void)hipEventDestroy(p->la_pipe.ev_n2);
         if (p->la_pipe.ev_u) (void)hipEventDestroy(p->la_pipe.ev_u);
         for (int l = 0; l < qrk::CaqrPipe::MAXL; ++l) if (p->la_pipe.ev_lvl[l]) (void)hipEventDestroy(p->la_pipe.ev_lvl[l]);
@@ -1208,6 +1239,7 @@ qrk_status qrk_dense_factorize(qrk_dense_plan p, double* a, int64_t lda, double*
                 flag = p->d_unclear;
             }
         }
+        p->last_flag = flag; p->last_exact = flag ? -1 : 1;
         if (p->exact_wide) {
             // large blocks: one workgroup would take minutes, so the host reads the word and runs the exact path over the whole chip
             int unclear = 1;                               // (no flag: the exact path was asked for)
@@ -1216,6 +1248,7 @@ qrk_status qrk_dense_factorize(qrk_dense_plan p, double* a, int64_t lda, double*
                 QRK_HIP(h, hipStreamSynchronize(h->stream));
                 unclear = *p->h_unclear;
             }
+            p->last_exact = unclear ? 1 : 0;
             if (unclear) return exact_wide(da, dhc, dp, unclear);
             return QRK_STATUS_OK;
         }
@@ -1539,7 +1572,7 @@ qrk_status qrk_thin_sparse_factorize(qrk_handle h, int32_t rows, int32_t cols, i
     if (hipMalloc((void**)&d_D, (size_t)ldd * cols * sizeof(double)) != hipSuccess ||
         hipMalloc((void**)&p->d_R, (size_t)cols * cols * sizeof(double)) != hipSuccess ||
         hipMalloc((void**)&d_pp, (size_t)block_cols * sizeof(int32_t)) != hipSuccess ||
-        hipMalloc((void**)&d_pack, (size_t)2 * block_cols * sizeof(double)) != hipSuccess) {
+        hipMalloc((void**)&d_pack, ((size_t)1 + block_cols) * sizeof(double)) != hipSuccess) {
         cleanup(); qrk_thin_destroy(p);
         return fail(h, QRK_STATUS_ALLOC_FAILED, "qrk_thin_sparse_factorize: cannot allocate the dense working matrix");
     }
@@ -1551,9 +1584,8 @@ qrk_status qrk_thin_sparse_factorize(qrk_handle h, int32_t rows, int32_t cols, i
         QRK_THIN_HIP(qrk::launch_sparse_window_to_dense(false, rows, cols, d_cp, d_ri, d_pv, 0, rows, d_map, d_D, ldd, h->stream));
 
     // ---- compute (:105-165): panel by panel
-    const double eps = DBL_EPSILON;
     std::vector<int32_t> nnz_idx, zero_idx;
-    std::vector<double> pack((size_t)2 * block_cols);
+    std::vector<double> pack((size_t)1 + block_cols);
     int32_t nzp = 0, solved = 0, new_piv = 0, prev_rows = 0;
     while (solved < cols) {
         int32_t nnew = block_cols, nrows;
@@ -1603,17 +1635,13 @@ qrk_status qrk_thin_sparse_factorize(qrk_handle h, int32_t rows, int32_t cols, i
                                           (size_t)nrows * sizeof(double), (size_t)nnew, hipMemcpyDeviceToDevice, h->stream));
         if ((st = qrk_dense_factorize(dp, pn.d_ji, hb, pn.d_hc, d_pp, QRK_MEM_DEVICE)) != QRK_STATUS_OK) return bail(st);
         // pivots and permutation of the panel to the host: nonzeroPivots() decides the geometry of the next panel
-        hipLaunchKernelGGL(qrk::thin_pack_kernel, dim3((unsigned)((std::max(k, nnew) + 255) / 256)), dim3(256), 0, h->stream, pn.d_ji, (int64_t)hb, d_pp, k, nnew, d_pack);
-        QRK_THIN_HIP(hipMemcpyAsync(pack.data(), d_pack, (size_t)(k + nnew) * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        hipLaunchKernelGGL(qrk::thin_pack_kernel, dim3((unsigned)((nnew + 255) / 256)), dim3(256), 0, h->stream, d_pp, k, nnew, std::max(nrows, 1),
+                           dp->last_flag, dp->last_exact, qrk::dense_exact_pivot_norms(dp->d_exact_ws, hb, nnew), d_pack);
+        QRK_THIN_HIP(hipMemcpyAsync(pack.data(), d_pack, (size_t)(1 + nnew) * sizeof(double), hipMemcpyDeviceToHost, h->stream));
         QRK_THIN_HIP(hipStreamSynchronize(h->stream));
-        // Eigen's rule: |R_qq|^2 < (eps |R_00|)^2 (nrows - q) / nrows ends the count
-        int32_t nz = k;
-        for (int32_t q = 0; q < k; ++q) {
-            const double dq = std::fabs(pack[(size_t)q]), d0 = std::fabs(pack[0]);
-            if (dq * dq < (d0 * eps) * (d0 * eps) * (double)(nrows - q) / (double)nrows) { nz = q; break; }
-        }
-        for (int32_t c = 0; c < nz; ++c) nnz_idx.push_back(c0 + (int32_t)pack[(size_t)(k + c)]);
-        for (int32_t c = nz; c < nnew; ++c) zero_idx.push_back(c0 + (int32_t)pack[(size_t)(k + c)]);
+        const int32_t nz = (int32_t)pack[0];               // nonzeroPivots() of the panel (BlockedThinSparseQR.h:250-256), counted on the device
+        for (int32_t c = 0; c < nz; ++c) nnz_idx.push_back(c0 + (int32_t)pack[(size_t)(1 + c)]);
+        for (int32_t c = nz; c < nnew; ++c) zero_idx.push_back(c0 + (int32_t)pack[(size_t)(1 + c)]);
         // update of the columns to the right (the rows of the panel and the zero rows below them): Q_panel^T in reflector form
         const int32_t ntrail = cols - (c0 + nnew);
         if (ntrail > 0 && k > 0)

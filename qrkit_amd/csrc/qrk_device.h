@@ -95,6 +95,9 @@ int* dense_tall_unclear_ptr(void* workspace, int G, int cpad);
 hipError_t launch_dense_exact(double* A, int64_t lda, int r, int c, int pivoting, const double* copy, double* hcoeffs,
                               int32_t* perm, const int* unclear, double* workspace, hipStream_t stream);
 size_t dense_exact_workspace_bytes(int r, int c);
+// [c] m_colNormsUpdated of the column chosen at every step of the LAST exact factorisation that used `workspace` (written by both exact
+// forms; Eigen counts nonzeroPivots() from these)
+const double* dense_exact_pivot_norms(const double* workspace, int r, int c);
 // the exact path of a large dense block over the whole chip (A already restored; host-launched sequence, 2 launches per reflector)
 hipError_t launch_dense_exact_wide(double* A, int64_t lda, int r, int c, int pivoting, double* hcoeffs, int32_t* perm,
                                    double* workspace, hipStream_t stream);

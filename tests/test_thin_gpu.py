@@ -160,3 +160,50 @@ def test_hip_thin_sparse_wide_panels(rows, cols, bc, seed):
     b = np.random.default_rng(1).uniform(-1, 1, rows)
     assert rel_fro(qr._applyAny(b, True), orc.bt_apply_q(ref, b, True)) <= 1e-11
     assert rel_fro(qr._applyAny(qr._applyAny(b, True), False), b) <= 1e-12
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_hip_thin_sparse_pivot_at_the_rank_threshold(seed):
+    """nonzeroPivots() of a panel (BlockedThinSparseQR.h:250-256) is counted by Eigen from its DOWNDATED column norms against
+    (largest initial norm * eps)^2 (rows - q) / rows -- not from |R_qq|, which equals the updated norm only up to ~1e-8 relative.  A panel
+    whose last column is dependent up to a perturbation delta: delta is bisected ON THE ORACLE down to two adjacent doubles, one that counts
+    3 nonzero pivots and one that counts 4; the device (whose exact path carries Eigen's own norm table) must agree on both sides, and a few
+    ulp further out."""
+    import qrkit_amd
+    rng = np.random.default_rng(seed)
+    rows, cols, bc = 24, 4, 4
+    C = rng.uniform(0.5, 2.0, (rows, 3))
+    w = rng.uniform(-1.0, 1.0, rows)
+
+    def mat(delta):
+        A = np.empty((rows, cols))
+        A[:, :3] = C
+        A[:, 3] = (C[:, 0] + C[:, 1]) + delta * w
+        return sp.csc_matrix(A)
+
+    lo, hi = 0.0, 1e-12                                     # rank 3 at delta = 0 (dependent up to rounding), 4 at 1e-12
+    if orc.bt_sparse_qr(mat(lo), bc).rank != 3 or orc.bt_sparse_qr(mat(hi), bc).rank != 4:
+        pytest.skip("the bracket does not hold for this seed")
+    while np.nextafter(lo, np.inf) < hi:
+        mid = 0.5 * (lo + hi)
+        if mid == lo or mid == hi:
+            break
+        if orc.bt_sparse_qr(mat(mid), bc).rank == 3:
+            lo = mid
+        else:
+            hi = mid
+    ctx = qrkit_amd.Context(0)
+    deltas = [lo, hi]
+    for _ in range(4):
+        deltas = [np.nextafter(deltas[0], 0.0)] + deltas + [np.nextafter(deltas[-1], np.inf)]
+    seen = set()
+    for d in deltas:
+        M = mat(d)
+        ref = orc.bt_sparse_qr(M, bc)
+        qr = qrkit_amd.BlockedThinSparseQR(ctx, bc)
+        qr.compute(M)
+        assert qr.rank() == ref.rank, (d, qr.rank(), ref.rank)
+        np.testing.assert_array_equal(qr.colsPermutation().cpu().numpy(), ref.perm)
+        seen.add(ref.rank)
+    assert seen == {3, 4}
