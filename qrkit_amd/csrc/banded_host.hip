@@ -15,63 +15,53 @@ struct RowRange {
     int32_t origIdx, start, end;
 };
 
-// BlockBandedMatrixInfo::mergeBlocks (SparseQRUtils.h:308-385) on (order, map) as the reference keeps them.
-bool merge_blocks(std::vector<int32_t>& order, std::map<int32_t, BlockInfo>& bmap, int maxColStep, int suggested,
-                  std::string& err)
+// Panels from the row blocks of a banded matrix: what BlockBandedMatrixInfo::mergeBlocks (SparseQRUtils.h:308-385) computes, as one
+// pass of a panel builder over the blocks in order.  A block whose columns end inside the last finished panel only makes that panel
+// taller; otherwise it extends the panel under construction, which is finished as soon as it is portrait (strictly more rows than
+// columns), at least `min_step` columns wide and at least `suggested`; what is still under construction at the end is finished if it
+// qualifies and otherwise folded into the last panel.  The reference's known answers (test/test-utils.cpp:228-241, 264-271) pin it.
+struct PanelBuilder {
+    std::vector<BlockInfo> done;
+    bool open = false;
+    int32_t row0 = 0, col0 = 0, rows = 0, cols = 0;
+    int32_t min_step, suggested;
+    PanelBuilder(int32_t step, int32_t sugg) : min_step(step), suggested(sugg) {}
+    bool qualifies() const { return rows > cols && cols >= min_step && cols >= suggested; }
+    void finish() {
+        BlockInfo b;
+        b.idxRow = row0; b.idxCol = col0; b.numRows = rows; b.numCols = cols;
+        done.push_back(b);
+        open = false;
+    }
+    void add(const BlockInfo& b) {
+        if (!done.empty() && b.idxCol + b.numCols <= done.back().idxCol + done.back().numCols) { done.back().numRows += b.numRows; return; }
+        if (!open) { open = true; row0 = b.idxRow; col0 = b.idxCol; }
+        rows = b.idxRow + b.numRows - row0;
+        cols = b.idxCol + b.numCols - col0;
+        if (qualifies()) finish();
+    }
+    bool close(std::string& err) {
+        if (!open) return true;
+        if (qualifies()) { finish(); return true; }
+        if (done.empty()) {
+            err = "block structure cannot be merged into portrait panels (the reference reads back() of an empty vector here, "
+                  "SparseQRUtils.h:375)";
+            return false;
+        }
+        BlockInfo& last = done.back();
+        last.numRows += rows;
+        last.numCols = col0 + cols - last.idxCol;
+        open = false;
+        return true;
+    }
+};
+
+bool merge_blocks(const std::vector<BlockInfo>& in, int maxColStep, int suggested, std::vector<BlockInfo>& out, std::string& err)
 {
-    std::map<int32_t, BlockInfo> newMap;
-    std::vector<int32_t> newOrder;
-    BlockInfo first;
-    int currRows = 0, currCols = 0;
-    for (int32_t key : order) {
-        const BlockInfo curr = bmap.at(key);
-        if (!newOrder.empty()) {
-            const BlockInfo last = newMap[newOrder.back()];
-            if (curr.idxCol + curr.numCols <= last.idxCol + last.numCols) {   // column-wise contained: absorb
-                BlockInfo m = last;
-                m.numRows = last.numRows + curr.numRows;
-                newMap[newOrder.back()] = m;
-                continue;
-            }
-        }
-        if (first.numRows == 0) {
-            first = curr;
-            currRows = curr.numRows;
-            currCols = curr.numCols;
-        } else {
-            currRows = curr.idxRow + curr.numRows - first.idxRow;
-            currCols = curr.idxCol + curr.numCols - first.idxCol;
-        }
-        // portrait, at least maxColStep wide, at least the suggested width (:357)
-        if (currRows > currCols && currCols >= maxColStep && currCols >= suggested) {
-            newOrder.push_back(first.idxCol);
-            BlockInfo nb;
-            nb.idxRow = first.idxRow; nb.idxCol = first.idxCol; nb.numRows = currRows; nb.numCols = currCols;
-            newMap.insert(std::make_pair(first.idxCol, nb));
-            first = BlockInfo();
-        }
-    }
-    if (first.numRows != 0) {
-        if (currRows > currCols && currCols >= maxColStep && currCols >= suggested) {
-            newOrder.push_back(first.idxCol);
-            BlockInfo nb;
-            nb.idxRow = first.idxRow; nb.idxCol = first.idxCol; nb.numRows = currRows; nb.numCols = currCols;
-            newMap.insert(std::make_pair(first.idxCol, nb));
-        } else {
-            if (newOrder.empty()) {
-                err = "block structure cannot be merged into portrait panels (the reference reads back() of an empty "
-                      "vector here, SparseQRUtils.h:375)";
-                return false;
-            }
-            const BlockInfo last = newMap[newOrder.back()];
-            BlockInfo m = last;
-            m.numRows = last.numRows + currRows;
-            m.numCols = first.idxCol + currCols - last.idxCol;
-            newMap[newOrder.back()] = m;
-        }
-    }
-    order = newOrder;
-    bmap = newMap;
+    PanelBuilder pb(maxColStep, suggested);
+    for (const BlockInfo& b : in) pb.add(b);
+    if (!pb.close(err)) return false;
+    out.swap(pb.done);
     return true;
 }
 
@@ -79,8 +69,7 @@ bool merge_blocks(std::vector<int32_t>& order, std::map<int32_t, BlockInfo>& bma
 
 // BlockBandedMatrixInfo::fromBlockBandedPattern (SparseQRUtils.h:274-302), before the merge: numBlocks = cols / (blockCols -
 // overlap) blocks (i blockRows, i step, blockRows, blockCols), the last one blockCols - overlap wide
-static bool fixed_block_map(int32_t cols, const FixedBandedPattern& fx, std::vector<int32_t>& order, std::map<int32_t, BlockInfo>& bmap,
-                            int32_t& maxColStep, std::string& err)
+static bool fixed_block_map(int32_t cols, const FixedBandedPattern& fx, std::vector<BlockInfo>& raw, int32_t& maxColStep, std::string& err)
 {
     maxColStep = fx.block_cols - fx.overlap;
     if (fx.block_rows <= 0 || fx.block_cols <= 0 || fx.overlap < 0 || maxColStep <= 0) { err = "bad fixed banded pattern"; return false; }
@@ -89,8 +78,7 @@ static bool fixed_block_map(int32_t cols, const FixedBandedPattern& fx, std::vec
         BlockInfo b;
         b.idxRow = i * fx.block_rows; b.idxCol = i * maxColStep; b.numRows = fx.block_rows;
         b.numCols = i < numBlocks - 1 ? fx.block_cols : fx.block_cols - fx.overlap;
-        order.push_back(b.idxCol);
-        bmap.insert(std::make_pair(b.idxCol, b));
+        raw.push_back(b);
     }
     return true;
 }
@@ -101,14 +89,11 @@ bool banded_block_map_fixed(int32_t rows, int32_t cols, const FixedBandedPattern
                             std::string& err)
 {
     (void)rows;
-    std::vector<int32_t> order;
-    std::map<int32_t, BlockInfo> bmap;
+    std::vector<BlockInfo> raw;
     int32_t maxColStep = 0;
-    if (!fixed_block_map(cols, fx, order, bmap, maxColStep, err)) return false;
-    if (!merge_blocks(order, bmap, maxColStep, suggested, err)) return false;
+    if (!fixed_block_map(cols, fx, raw, maxColStep, err)) return false;
     blocks.clear();
-    for (int32_t key : order) blocks.push_back(bmap.at(key));
-    return true;
+    return merge_blocks(raw, maxColStep, suggested, blocks, err);
 }
 
 bool analyze_banded(int32_t rows, int32_t cols, const int32_t* rowptr, const int32_t* colidx, int32_t suggested,
@@ -160,11 +145,10 @@ bool analyze_banded(int32_t rows, int32_t cols, const int32_t* rowptr, const int
         for (int32_t e = rowptr[o]; e < rowptr[o + 1]; ++e, ++dst) { out.pcol[(size_t)dst] = colidx[e]; out.pmap[(size_t)dst] = e; }
     }
 
-    std::vector<int32_t> order;
-    std::map<int32_t, BlockInfo> bmap;
+    std::vector<BlockInfo> raw;                 // the row blocks before the merge, in row order
     int32_t maxColStep = 0;
     if (fixed) {
-        if (!fixed_block_map(cols, *fixed, order, bmap, maxColStep, err)) return false;
+        if (!fixed_block_map(cols, *fixed, raw, maxColStep, err)) return false;
     } else {
     // ---- BlockBandedMatrixInfo::operator() (SparseQRUtils.h:186-253) on the sorted rows
     std::map<int32_t, int32_t> bandWidths, bandHeights;
@@ -177,19 +161,18 @@ bool analyze_banded(int32_t rows, int32_t cols, const int32_t* rowptr, const int
     }
     for (size_t j = 0; j + 1 < ranges.size(); ++j)
         maxColStep = std::max(maxColStep, ranges[j + 1].start - ranges[j].start);
+    // one block per distinct first column, at the first row that starts there (the rows are sorted by it: a new start is a new block)
     int32_t rowIdx = 0;
     for (const RowRange& rr : ranges) {
-        if (!std::binary_search(order.begin(), order.end(), rr.start) && rr.start < cols) {
-            order.push_back(rr.start);
+        if (rr.start < cols && (raw.empty() || raw.back().idxCol != rr.start)) {
             BlockInfo b;
             b.idxRow = rowIdx; b.idxCol = rr.start; b.numRows = bandHeights.at(rr.start); b.numCols = bandWidths.at(rr.start);
-            bmap.insert(std::make_pair(rr.start, b));
+            raw.push_back(b);
         }
         ++rowIdx;
     }
     }
-    if (!merge_blocks(order, bmap, maxColStep, suggested, err)) return false;
-    for (int32_t key : order) out.blocks.push_back(bmap.at(key));
+    if (!merge_blocks(raw, maxColStep, suggested, out.blocks, err)) return false;
     if (out.blocks.empty()) { err = "no blocks found"; return false; }
     for (const BlockInfo& b : out.blocks)
         if (b.idxRow < 0 || b.idxCol < 0 || b.numRows <= 0 || b.numCols <= 0 || b.idxCol + b.numCols > cols || b.idxRow + b.numRows > rows) {
