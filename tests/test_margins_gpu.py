@@ -58,7 +58,9 @@ FAMILIES = [
     ("K5 small 8x6", 8, 6, [0, 2]),
     ("K5 small 16x16", 16, 16, [0, 4, 8]),
     ("thin 9x2", 9, 2, [0]),
-    ("K2 LDS-resident 48x48", 48, 48, [0, 8, 24]),
+    ("K2 one wave per tile 48x48", 48, 48, [0, 8, 24]),
+    ("K2 one wave per tile 64x64", 64, 64, [0, 16, 40]),
+    ("K2 LDS-resident 80x48", 80, 48, [0, 8, 24]),
     ("K2 on-chip 200x200", 200, 200, [0, 8, 24]),
 ]
 

@@ -91,11 +91,11 @@ def check(qr, ref, rows, cols, bitwise=False):
     return int(same.sum())
 
 
-# 32x32: K1 (uniform persistent kernel); 24x17 / 20x20: K1's ragged kernel; 7x2, 8x6, 9x2, 16x16: K5; 64x64, 48x40: K2;
-# 300x40: the workgroup kernel for tiles above 256
+# 32x32: K1 (uniform persistent kernel); 24x17 / 20x20: K1's ragged kernel; 7x2, 8x6, 9x2, 16x16: K5; 64x64, 48x40, 33x33: K2, one wave per
+# tile (bdqr_w64.hip); 100x48: K2, LDS-resident (bdqr_col.hip); 300x40: the workgroup kernel for tiles above 256
 @pytest.mark.parametrize("kind", KINDS)
 @pytest.mark.parametrize("B,r,c", [(300, 32, 32), (300, 24, 17), (300, 7, 2), (300, 8, 6), (300, 16, 16), (64, 64, 64),
-                                   (48, 48, 40), (6, 300, 40)])
+                                   (48, 48, 40), (64, 33, 33), (24, 100, 48), (6, 300, 40)])
 def test_tie_battery_permutation_bit_exact(qa, ctx, kind, B, r, c):
     tiles = tie_tiles(kind, B, r, c, seed=KINDS.index(kind) * 1000 + 37 * r + c)
     rows, cols = np.full(B, r, np.int32), np.full(B, c, np.int32)
