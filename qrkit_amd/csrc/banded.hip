@@ -1151,7 +1151,7 @@ bb_apply_q_kernel(const BBPanel* __restrict__ panels, int num_panels, const doub
                 const int jl = tid % CW, g = tid / CW, j = j0 + jl;
                 double acc = 0.0;
                 if (g < RG && jl < nc) {
-                    constexpr int U = 8;
+                    constexpr int U = 8;           // loads in flight per thread: the panel streams from memory once, latency is all there is to hide
                     for (int i = j + 1 + g; i < m; i += U * RG) {
                         double yv[U];
 #pragma unroll
@@ -1171,11 +1171,26 @@ bb_apply_q_kernel(const BBPanel* __restrict__ panels, int num_panels, const doub
             }
             // ---- w2 = T^T w1 or T w1 (T upper triangular, column-major)
             if (transpose) {
-                for (int i = wave; i < n; i += BA_WAVES) {
-                    double d = 0.0;
-                    for (int j = lane; j <= i; j += 64) d = fma(T[(int64_t)i * n + j], w1[j], d);
-                    d = bb_wave_sum_dpp(d);
-                    if (lane == 0) w2[i] = d;
+                // a wave per row of T^T, four rows at a time: every load of the batch is issued before the first sum (one row at a
+                // time was one memory latency per row: 12 of them per wave and panel)
+                constexpr int RB = 4, LB = BC_CW / 64;
+                for (int i0 = wave; i0 < n; i0 += RB * BA_WAVES) {
+                    double tv[RB][LB];
+#pragma unroll
+                    for (int rb = 0; rb < RB; ++rb) {
+                        const int i = i0 + rb * BA_WAVES;
+#pragma unroll
+                        for (int q = 0; q < LB; ++q) { const int j = lane + 64 * q; tv[rb][q] = (i < n && j <= i) ? T[(int64_t)i * n + j] : 0.0; }
+                    }
+#pragma unroll
+                    for (int rb = 0; rb < RB; ++rb) {
+                        const int i = i0 + rb * BA_WAVES;
+                        double d = 0.0;
+#pragma unroll
+                        for (int q = 0; q < LB; ++q) { const int j = lane + 64 * q; if (j < n) d = fma(tv[rb][q], w1[j], d); }
+                        d = bb_wave_sum_dpp(d);
+                        if (lane == 0 && i < n) w2[i] = d;
+                    }
                 }
             } else {
                 for (int i0 = 0; i0 < n; i0 += BA_THREADS) {
@@ -1183,7 +1198,16 @@ bb_apply_q_kernel(const BBPanel* __restrict__ panels, int num_panels, const doub
                     const int CW = ((nc + 63) / 64) * 64, RG = BA_THREADS / CW;
                     const int il = tid % CW, g = tid / CW, i = i0 + il;
                     double acc = 0.0;
-                    if (g < RG && il < nc) for (int j = i + g; j < n; j += RG) acc = fma(T[(int64_t)j * n + i], w1[j], acc);
+                    if (g < RG && il < nc) {
+                        constexpr int U = 8;
+                        for (int j = i + g; j < n; j += U * RG) {
+                            double tv[U];
+#pragma unroll
+                            for (int u = 0; u < U; ++u) { const int jj = j + u * RG; tv[u] = T[(int64_t)(jj < n ? jj : n - 1) * n + i]; }
+#pragma unroll
+                            for (int u = 0; u < U; ++u) { const int jj = j + u * RG; if (jj < n) acc = fma(tv[u], w1[jj], acc); }
+                        }
+                    }
                     if (g < RG) part[g * CW + il] = acc;
                     __syncthreads();
                     if (g == 0 && il < nc) {
@@ -1196,10 +1220,24 @@ bb_apply_q_kernel(const BBPanel* __restrict__ panels, int num_panels, const doub
             }
             __syncthreads();
             // ---- seg += Y w2, a wave per row
-            for (int i = wave; i < m; i += BA_WAVES) {
-                const int je = i < n ? i : n;                    // columns left of the diagonal
+            constexpr int RB3 = 4, LB3 = BC_CW / 64;
+            for (int i0 = wave; i0 < m; i0 += RB3 * BA_WAVES) {
+              // (four rows of Y per wave in flight, as above: 16 loads per lane; eight spill at 1 024 threads)
+              double yv[RB3][LB3];
+#pragma unroll
+              for (int rb = 0; rb < RB3; ++rb) {
+                  const int i = i0 + rb * BA_WAVES;
+                  const int je = i < n ? i : n;
+#pragma unroll
+                  for (int q = 0; q < LB3; ++q) { const int j = lane + 64 * q; yv[rb][q] = (i < m && j < je) ? Y[(int64_t)i * n + j] : 0.0; }
+              }
+#pragma unroll
+              for (int rb = 0; rb < RB3; ++rb) {
+                const int i = i0 + rb * BA_WAVES;
+                if (i >= m) break;
                 double d = 0.0;
-                for (int j = lane; j < je; j += 64) d = fma(Y[(int64_t)i * n + j], w2[j], d);
+#pragma unroll
+                for (int q = 0; q < LB3; ++q) { const int j = lane + 64 * q; if (j < n) d = fma(yv[rb][q], w2[j], d); }
                 d = bb_wave_sum_dpp(d);
                 if (lane == 0) {
                     const double val = seg[i] + d + (i < n ? w2[i] : 0.0);
@@ -1215,6 +1253,7 @@ bb_apply_q_kernel(const BBPanel* __restrict__ panels, int num_panels, const doub
                         else yi[i - S.lo] = val;
                     }
                 }
+              }
             }
             if (strips) {
                 // the components stage A left out of the chain (rows n.. of the strip's vector) pass through
