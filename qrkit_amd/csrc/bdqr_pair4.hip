@@ -1,0 +1,450 @@
+// bdqr_pair4.hip -- uniform batches of 32 x 32 tiles, TWO tiles per wavefront and FOUR wavefronts per SIMD: A_i P_i = Q_i R_i with
+// explicit Q_i, for gfx950.  The second generation of the headline kernel (bdqr_pair.hip is the first; QRK_PAIR_V2 selects).
+//
+// Same reference seam as bdqr_pair.hip: the body of the hot loop of QRKit::BlockDiagonalSparseQR::factorize
+// (src/QRKit/BlockDiagonalSparseQR.h:432-526): blockSolver.compute(block) (:437-438, Eigen ColPivHouseholderQR / HouseholderQR),
+// Qi = blockSolver.matrixQ() (:446), the Q / R value assembly (:455-500) and the column-permutation splice (:519-521).
+//
+// Why a second generation.  bdqr_pair.hip is bounded by the dependent chain of its steps, not by memory or issue: a pair that has its
+// SIMD to itself takes 41 790 cycles, two per SIMD overlap almost completely, and 10 000 tiles are three rounds of that chain
+// (profiles/r04_k1_critical_path.txt: 0.37 of HBM at any schedule).  More chains per SIMD are what it needs, and two resources cap it at
+// two waves per SIMD: the LDS image of A through which the pivot column is fetched (8.7 KB per tile) and the 128 data registers of a
+// wave that carries A and Q^T together.  This kernel is bdqr_w64.hip's design at 32 rows:
+//   * no image: the pivot lane of each half PUBLISHES its column to LDS (16-byte stores of two lanes), every lane takes element
+//     lane & 15 of the two 16-row chunks, and the dot / update FMAs read it through the DPP row_newbcast operand; |x_tail|^2 is a DPP
+//     row sum of those elements; the published column is also reflector k of phase 2 -- 4.75 KB of LDS per tile;
+//   * two phases in the same registers: A -> R (row k of R stays in row register k of its lane and leaves at the end of the phase as
+//     one contiguous run per lane), then Q = H_0 ... H_31 by backward accumulation (HouseholderSequence::evalTo's order) from the
+//     reflectors in LDS -- 64 data registers per wave instead of 128;
+//   * <= 128 VGPRs and 10 KB of LDS per wave: sixteen waves per CU, 4 096 pairs resident on the chip: 10 000 tiles are ONE round and a
+//     fifth of a second one, spread evenly over the SIMDs.
+// Decisions and the exact path exactly as bdqr_pair.hip ("Decisions and the exact path" there): integer arg-max on the high words
+// with a filter, margins, LAWN-176 band, degenerate reflector, noise-level pivot; a flagged tile is redone by the wave itself with the
+// exact-arithmetic routine after its rounds (working copy in a global scratch: the LDS of this kernel is too small for it).
+#include "qrk_device.h"
+#include "bdqr_exact_tile.h"
+
+#include <float.h>
+#include <cstdlib>
+
+namespace qrk {
+
+namespace p4 {
+
+using namespace decide;
+
+constexpr int WR = 32;
+constexpr int FILTER = 256;              // pivot candidates: high word of the squared norm within 2^-12 (relative) of the largest
+// LDS per HALF (doubles): reflector K (the pivot column of step K, as published) holds rows (K & ~1) .. 31 at cb(K): 16-byte aligned
+constexpr int cb(int k) { int s = 0; for (int q = 0; q < k; ++q) s += WR - (q & ~1); return s; }
+constexpr int L_V = 0;
+constexpr int L_S = cb(WR);              // [32] s = x0 - beta
+constexpr int L_NG = L_S + WR;           // [32] -1 / (beta (x0 - beta))
+constexpr int L_TAU = L_NG + WR;         // [32]
+constexpr int L_HALF = L_TAU + WR;       // 640 doubles = 5 120 B per half, 10 240 B per wave: 16 waves per CU
+static_assert(cb(WR) == 544 && L_HALF * 8 * 2 * 16 <= 160 * 1024, "sixteen waves per CU");
+constexpr int STAGE_LD = WR + 1;         // the staging of a tile (lane = row -> lane = column) uses [32][33] doubles of the wave's LDS
+static_assert(WR * STAGE_LD <= 2 * L_HALF, "the staging buffer fits the wave's LDS");
+
+#define QRK_P4_0_31(M)                                                                           \
+    M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9) M(10) M(11) M(12) M(13) M(14) M(15) M(16)  \
+    M(17) M(18) M(19) M(20) M(21) M(22) M(23) M(24) M(25) M(26) M(27) M(28) M(29) M(30) M(31)
+#define QRK_P4_31_0(M)                                                                           \
+    M(31) M(30) M(29) M(28) M(27) M(26) M(25) M(24) M(23) M(22) M(21) M(20) M(19) M(18) M(17)    \
+    M(16) M(15) M(14) M(13) M(12) M(11) M(10) M(9) M(8) M(7) M(6) M(5) M(4) M(3) M(2) M(1) M(0)
+
+__device__ __forceinline__ double sqrt_pos(double x)      // <= 1 ulp for positive normal x (bdqr_pair.hip)
+{
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = 0.5 * y;
+    const double e = fma(-h, g, 0.5);
+    g = fma(g, e, g);
+    h = fma(h, e, h);
+    const double d = fma(-g, g, x);
+    return fma(d, h, g);
+}
+__device__ __forceinline__ double recip(double x)
+{
+    double y = __builtin_amdgcn_rcp(x);
+    double e = fma(-x, y, 1.0);
+    y = fma(y, e, y);
+    e = fma(-x, y, 1.0);
+    y = fma(y, e, y);
+    return y;
+}
+// d += X[N] * c, X read through DPP row_newbcast (element N of the lane's row of 16 lanes)
+template <int N>
+__device__ __forceinline__ void fmac_bcast(double& d, double X, double c)
+{
+    asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(d) : "v"(X), "v"(c), "n"(N));
+}
+template <int N>
+__device__ __forceinline__ double bcast_f64(double X)
+{
+    double r;
+    asm("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(X), "n"(N));
+    return r;
+}
+// sum over every row of 16 lanes, the same bits in every lane of the row
+__device__ __forceinline__ double row16_sum(double v)
+{
+    v += dpp_f64<0xB1>(v);
+    v += dpp_f64<0x4E>(v);
+    v += dpp_f64<0x141>(v);
+    v += dpp_f64<0x140>(v);
+    return v;
+}
+__device__ __forceinline__ double bpermute_f64(int byte_addr, double v)
+{
+    const int lo = __builtin_amdgcn_ds_bpermute(byte_addr, __double2loint(v));
+    const int hi = __builtin_amdgcn_ds_bpermute(byte_addr, __double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+
+struct Lane {
+    int lane, j, half;
+    unsigned long long livemask;   // (wave-uniform) the lanes whose column of A is not yet chosen
+    bool unclear;     // a decision of this half's tile was inside its error margin (any lane of the half)
+    int kstep;        // position at which this lane's column was chosen
+    double nu2;       // m_colNormsUpdated^2 (a chosen column carries a negative value)
+    double thr;       // sqrt(eps) (1 + 2^-12) m_colNormsDirect^2
+    double a2;        // |A|^2 of this half's tile: squared norm of its first pivot column (scale of the decision margins)
+};
+
+// The elements of the published column that this lane broadcasts: xc[m] = element 16 m + (lane & 15) of the half's column
+template <int K>
+__device__ __forceinline__ void load_chunks(const double* hl, int lane, double (&xc)[2])
+{
+    constexpr int M0 = (K + 1) >> 4;
+    const double* vcol = hl + L_V + cb(K) - (K & ~1) + (lane & 15);
+#pragma unroll
+    for (int m = M0; m < 2; ++m) xc[m] = vcol[16 * m];
+}
+
+// One step of ColPivHouseholderQR::computeInPlace / HouseholderQR on both tiles of the wave (see bdqr_pair.hip for the arithmetic: squared
+// norms, un-normalised reflector, decisions).
+template <int K, bool PIVOT, bool HC>
+__device__ __forceinline__ void step(double (&a)[WR], double* hl /* this half's LDS */, Lane& st)
+{
+    const int lane = st.lane;
+    if (!PIVOT) __builtin_amdgcn_sched_barrier(0);          // (no branch separates the steps here: keep hipcc from interleaving them)
+    // ---- 1. pivot of each half
+    bool ispiv;
+    unsigned long long pm;                                  // ballot of ispiv
+    if (PIVOT) {
+        const int khi = __double2hiint(st.nu2);
+        const int mh = half32_max_i32_fused(khi);
+        ispiv = khi >= mh - FILTER;
+        pm = __builtin_amdgcn_ballot_w64(ispiv);
+        unsigned tlo = (unsigned)pm, thi = (unsigned)(pm >> 32);
+        if (__builtin_expect(((tlo & (tlo - 1u)) | (thi & (thi - 1u))) != 0u, 0)) {
+            // several candidates in a half: the largest (lowest lane among exact ties: the tile is flagged then) and the check of the
+            // decision -- a live column within the error margin of the chosen one sends the tile to the exact path, which owns
+            // Eigen's first-maximum rule on the current positions
+            asm volatile("");
+            const bool live = ((st.livemask >> lane) & 1ull) != 0ull;
+            bool cand = live && khi == mh;
+            const unsigned klo = (unsigned)__double2loint(st.nu2);
+            const unsigned ml = half32_max_u32(cand ? klo : 0u);
+            cand = cand && klo == ml;
+            const unsigned long long cm = __builtin_amdgcn_ballot_w64(cand);
+            const unsigned clo = (unsigned)cm, chi = (unsigned)(cm >> 32);
+            const int lA = clo ? __builtin_ctz(clo) : 0, lB = chi ? __builtin_ctz(chi) : 0;
+            const int lbl = st.half ? lB : lA;
+            ispiv = cand && st.j == lbl;
+            const int src = ((st.half << 5) + lbl) << 2;
+            const double best = bpermute_f64(src, st.nu2), thrb = bpermute_f64(src, st.thr);
+            double margin = MREL * (st.thr + thrb);
+            if (K > 0) margin += 4.547473508864641e-13 /* 2^-41 */ * __builtin_sqrt(st.a2 * (best > 0.0 ? best : 0.0));
+            if (live && !ispiv && st.nu2 >= best - margin) st.unclear = true;
+            pm = __builtin_amdgcn_ballot_w64(ispiv);
+        }
+        st.livemask &= ~pm;
+    } else {
+        ispiv = st.j == K;
+        pm = __builtin_amdgcn_ballot_w64(ispiv);
+    }
+    if (K == 0 && PIVOT) {
+        // the scale of the tile: the squared norm of its first pivot, to every lane of the half
+        const unsigned tlo = (unsigned)pm, thi = (unsigned)(pm >> 32);
+        const int lA = tlo ? __builtin_ctz(tlo) : 0, lB = thi ? __builtin_ctz(thi) : 0;
+        st.a2 = bpermute_f64(((st.half << 5) + (st.half ? lB : lA)) << 2, st.nu2);
+    }
+    if (ispiv) {
+        st.kstep = K;
+        st.nu2 = __hiloint2double((int)0xBF800000, __double2loint(st.nu2));
+        // ---- 2. publish the column (it is reflector K of phase 2 as well)
+        double* vcol = hl + L_V + cb(K) - (K & ~1);
+#pragma unroll
+        for (int i = K & ~1; i < WR; i += 2) *reinterpret_cast<double2*>(&vcol[i]) = make_double2(a[i], a[i + 1]);
+    }
+    __builtin_amdgcn_wave_barrier();
+    // ---- 3. the lanes' elements of it, x0
+    double xc[2] = {0.0, 0.0};
+    double xk;
+    constexpr int M0 = (K + 1) >> 4, MK = K >> 4;
+    if (K + 1 < WR) load_chunks<K>(hl, lane, xc);
+    if (MK >= M0) xk = bcast_f64<(K & 15)>(xc[MK]);
+    else xk = hl[L_V + cb(K) + (K & 1)];                      // (row K is the last one of its chunk: not among the loaded ones)
+    // ---- 4. d = x_tail^T a_tail of every column; the pivot lane's own is |x_tail|^2, handed to its half through LDS (the slot of
+    // tau_K, which is written after it) -- no cross-lane sum
+    const double ak = a[K];
+    double d0 = 0.0, d1 = 0.0;
+#pragma unroll
+    for (int m = M0; m < 2; ++m) asm volatile("s_nop 1" : "+v"(xc[m]));      // (VALU write -> DPP read hazard, hidden from hipcc by the asm)
+#define QRK_P4_DOT(I) if ((I) > K) fmac_bcast<((I) & 15)>(((I) & 1) ? d1 : d0, xc[(I) >> 4], a[I]);
+    QRK_P4_0_31(QRK_P4_DOT)
+#undef QRK_P4_DOT
+    const double dsum = d0 + d1;
+    double tsq = 0.0;
+    if (K + 1 < WR) {
+        if (ispiv) hl[L_TAU + K] = dsum;
+        __builtin_amdgcn_wave_barrier();
+        tsq = hl[L_TAU + K];
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (K == 0 && !PIVOT) st.a2 = fma(xk, xk, tsq);
+    if (unclear_reflector(xk, tsq, K + 1 < WR, PIVOT, st.a2)) st.unclear = true;
+    // ---- 5. makeHouseholder in the un-normalised form: nb = -beta = copysign(norm, x0), s = x0 - beta, ng = -1 / (beta (x0 - beta));
+    // Eigen: tailSqNorm <= min() gives tau = 0, beta = x0, H = I (rare: a real branch on a wave-level test, selects inside)
+    const double nrm = sqrt_pos(fma(xk, xk, tsq));
+    // (Eigen's test is x0 >= 0, which takes -0.0 as positive: a zero x0 with a tail is one of unclear_reflector's cases -- the tile is
+    //  redone by the exact path -- and without a tail the branch below overrides)
+    double nbv = __builtin_copysign(nrm, xk);                // beta = -nbv
+    double s = nbv + xk;
+    double ng = -recip(nbv * s);
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(!(tsq > DBL_MIN)) != 0ull, 0)) {
+        asm volatile("");
+        if (!(tsq > DBL_MIN)) { nbv = -xk; s = 0.0; ng = 0.0; }
+    }
+    if (st.j == 0) {
+        hl[L_S + K] = s; hl[L_NG + K] = ng;
+        if (HC) hl[L_TAU + K] = -(s * s) * ng;
+    }
+    const double ngam = fma(s, ak, dsum) * ng;               // -gamma of this column
+    double an = fma(s, ngam, ak);
+    {
+        // R(K, K) = beta = -nbv in the pivot lane: two selects, the sign through the source modifier
+        int hi = __double2hiint(an), lo = __double2loint(an);
+        asm("v_cndmask_b32_e64 %0, %0, -%1, %2" : "+v"(hi) : "v"(__double2hiint(nbv)), "s"(pm));
+        asm("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(lo) : "v"(__double2loint(nbv)), "s"(pm));
+        an = __hiloint2double(hi, lo);
+    }
+    a[K] = an;                                               // final: later steps work on the rows below
+    if (!PIVOT) asm volatile("" : "+v"(a[K]));                  // (hipcc otherwise sinks the 32 selects to the store of R and keeps every beta alive)
+    // ---- 6. the trailing update (columns already chosen are not masked out: nothing below the diagonal of R is ever read, and what
+    // they hold stays bounded -- the reflectors are orthogonal)
+#define QRK_P4_UPD(I) if ((I) > K) fmac_bcast<((I) & 15)>(a[I], xc[(I) >> 4], ngam);
+    QRK_P4_0_31(QRK_P4_UPD)
+#undef QRK_P4_UPD
+    // ---- 7. LAWN-176 norm downdate (squared form; no clamp at zero: a negative value is <= the threshold and recomputed)
+    if (PIVOT && K + 1 < WR) {
+        const double nn = fma(-an, an, st.nu2);
+        st.nu2 = nn;
+        const unsigned long long needm = __builtin_amdgcn_ballot_w64(nn <= st.thr) & st.livemask;
+        if (__builtin_expect(needm != 0ull, 0)) {
+            asm volatile("");
+            const bool need = ((needm >> lane) & 1ull) != 0ull;
+            if (need && in_recompute_band(nn, st.thr, st.a2)) st.unclear = true;      // decision (2)
+            double sq = 0.0;
+#define QRK_P4_SQ(I) if ((I) > K) sq = fma(a[I], a[I], sq);
+            QRK_P4_0_31(QRK_P4_SQ)
+#undef QRK_P4_SQ
+            if (need) { st.nu2 = sq; st.thr = sq * THR_HI; }
+        }
+    }
+}
+
+// Q_k = H_k Q_{k+1} on the wave's columns of Q (both tiles): reflector K from the half's LDS (x_tail as published, s, ng)
+template <int K>
+__device__ __forceinline__ void back_step(double (&q)[WR], const double* hl, const int lane)
+{
+    constexpr int M0 = (K + 1) >> 4;
+    const double s = hl[L_S + K], ng = hl[L_NG + K];
+    double xc[2] = {0.0, 0.0};
+    if (K + 1 < WR) load_chunks<K>(hl, lane, xc);
+    const double qk = q[K];
+    double d0 = 0.0, d1 = 0.0;
+#pragma unroll
+    for (int m = M0; m < 2; ++m) asm volatile("s_nop 1" : "+v"(xc[m]));
+#define QRK_P4_DOT(I) if ((I) > K) fmac_bcast<((I) & 15)>(((I) & 1) ? d1 : d0, xc[(I) >> 4], q[I]);
+    QRK_P4_0_31(QRK_P4_DOT)
+#undef QRK_P4_DOT
+    const double ngam = fma(s, qk, d0 + d1) * ng;
+    q[K] = fma(s, ngam, qk);
+#define QRK_P4_UPD(I) if ((I) > K) fmac_bcast<((I) & 15)>(q[I], xc[(I) >> 4], ngam);
+    QRK_P4_0_31(QRK_P4_UPD)
+#undef QRK_P4_UPD
+}
+
+// A flagged tile again, by the wave that factorised it, in Eigen's own operation order (bdqr_exact_tile.h; bitwise what
+// bdqr_exact_kernel computes).  The small tables live in the wave's LDS, the working copy and Q in the wave's global scratch.
+template <bool PIVOT>
+__device__ __noinline__ void redo_exact(int64_t t, double* lds, double* scratch, const double* __restrict__ tiles, double* __restrict__ q_vals,
+                                        double* __restrict__ r_vals, int32_t* __restrict__ perm, double* __restrict__ hcoeffs)
+{
+    exact::Shared sh;
+    (void)exact::carve_shared<64>(reinterpret_cast<unsigned char*>(lds), 32, 32, sh);
+    double* W = scratch;
+    double* q = scratch + 1024;
+    __syncthreads();
+    exact::tile_qr<PIVOT, 64>(32, 32, tiles + t * 1024, W, q, sh);
+    exact::tile_store<64>(32, 32, (int)(t * 32), W, q, sh, perm, hcoeffs, r_vals + t * 528, q_vals + t * 1024);
+    __syncthreads();
+}
+
+}  // namespace p4
+
+// PIVOT: ColPivHouseholderQR (else HouseholderQR).  HC: also emit the Householder coefficients.  One wave per workgroup, persistent over
+// the pairs blockIdx.x, blockIdx.x + gridDim.x, ..; scratch: 2048 doubles per workgroup (the exact path's working copy).
+template <bool PIVOT, bool HC>
+__global__ void __launch_bounds__(64, 4)
+bdqr_pair4_kernel(int64_t num_tiles, const double* __restrict__ tiles, double* __restrict__ q_vals, double* __restrict__ r_vals,
+                  int32_t* __restrict__ perm, double* __restrict__ hcoeffs, double* __restrict__ scratch)
+{
+    using namespace p4;
+    __shared__ __attribute__((aligned(16))) double lds[2 * L_HALF];
+    const int64_t npairs = (num_tiles + 1) / 2;
+    constexpr int CHUNK = 32;                // rounds per chunk: one 32-bit word per half remembers the flagged rounds
+    for (int64_t pi0 = blockIdx.x; pi0 < npairs; pi0 += (int64_t)CHUNK * gridDim.x) {
+    unsigned flagbits = 0u;                  // bit r: the tile of this half in round r of the chunk was flagged
+    int64_t pi = pi0;
+    for (int round = 0; round < CHUNK && pi < npairs; ++round, pi += gridDim.x) {
+        // (per-lane values are re-derived from an opaque lane id in every round: hipcc otherwise hoists loop-invariant address
+        //  arithmetic out of the loop and keeps it in registers across the factorisation)
+        int lane = threadIdx.x;
+        asm volatile("" : "+v"(lane));
+        const int half = lane >> 5, j = lane & 31;
+        double* hl = lds + half * L_HALF;
+        const int64_t t = 2 * pi + half;
+        const bool valid = t < num_tiles;
+        Lane st;
+        st.lane = lane; st.j = j; st.half = half; st.unclear = false; st.kstep = 0; st.a2 = 0.0; st.livemask = ~0ull;
+        {
+            // =============== phase 1: A -> R ===============
+            double a[WR];
+            {
+                // both tiles of the pair, one after the other through the wave's LDS: lane l takes row l & 31 of columns 16 (l >> 5) ..
+                // (two runs of 256 bytes per load instruction), the tile is written column by column with a padded stride and the lanes of
+                // its half read their columns back.  The loads of the second tile are in flight while the first one is staged.
+                double ld0[16], ld1[16];
+                const int r = lane & 31, g = lane >> 5;
+                const int64_t t0 = 2 * pi, t1 = 2 * pi + 1;
+                const double* s0 = tiles + t0 * 1024 + (16 * g) * 32 + r;
+                const double* s1 = tiles + (t1 < num_tiles ? t1 : t0) * 1024 + (16 * g) * 32 + r;
+#pragma unroll
+                for (int m = 0; m < 16; ++m) ld0[m] = s0[32 * m];
+#pragma unroll
+                for (int m = 0; m < 16; ++m) ld1[m] = s1[32 * m];
+#pragma unroll
+                for (int m = 0; m < 16; ++m) lds[(16 * g + m) * STAGE_LD + r] = ld0[m];
+                __builtin_amdgcn_wave_barrier();
+                // (both halves read: a conditional first definition would leave a[] undefined on one side, which hipcc carries
+                //  around the round loop as live values)
+#pragma unroll
+                for (int i = 0; i < WR; ++i) a[i] = lds[j * STAGE_LD + i];
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int m = 0; m < 16; ++m) lds[(16 * g + m) * STAGE_LD + r] = ld1[m];
+                __builtin_amdgcn_wave_barrier();
+                if (half == 1) {
+                    // (the missing partner of an odd last tile: diag(64..33) -- distinct norms, no tie-breaking; nothing of it is stored)
+#pragma unroll
+                    for (int i = 0; i < WR; ++i) a[i] = valid ? lds[j * STAGE_LD + i] : ((i == j) ? (double)(64 - j) : 0.0);
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+            {
+                double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+                for (int i = 0; i < WR; i += 2) { s0 = fma(a[i], a[i], s0); s1 = fma(a[i + 1], a[i + 1], s1); }
+                st.nu2 = s0 + s1;
+                st.thr = st.nu2 * THR_HI;
+            }
+#define QRK_P4_STEP(K) step<K, PIVOT, HC>(a, hl, st);
+            QRK_P4_0_31(QRK_P4_STEP)
+#undef QRK_P4_STEP
+            // ---- R: lane j holds column p = kstep of R in rows 0 .. p; the packed CSC value order of m_R (BlockDiagonalSparseQR.h:475-479)
+            // puts entry (i, p) at p (p + 1) / 2 + i -- a contiguous run per lane, stored straight from the registers, two rows at a time;
+            // the permutation splice (:519-521): the column chosen at step p ends at position p
+            int ln = threadIdx.x;
+            asm volatile("" : "+v"(ln));
+            if (valid) {
+                const int p = st.kstep, jj = ln & 31;
+                const int cbase = (int)(t * 32);
+                perm[cbase + p] = cbase + jj;
+                double* dst = r_vals + t * 528 + ((p * (p + 1)) >> 1);
+                typedef double d2u __attribute__((ext_vector_type(2), aligned(8)));
+#pragma unroll
+                for (int i = 0; i < WR; i += 2) {
+                    if (i + 1 <= p) *reinterpret_cast<d2u*>(dst + i) = d2u{a[i], a[i + 1]};
+                    else if (i == p) dst[i] = a[i];
+                }
+                if (HC && hcoeffs) hcoeffs[cbase + jj] = lds[(ln >> 5) * L_HALF + L_TAU + jj];
+            }
+        }
+        // a decision inside its error margin, anywhere in the half: the tile is redone by the exact path after the rounds
+        {
+            const unsigned long long um = __builtin_amdgcn_ballot_w64(st.unclear);
+            const bool f = half ? (um >> 32) != 0ull : (um & 0xffffffffull) != 0ull;
+            if (f && valid) flagbits |= 1u << round;
+        }
+        {
+            // =============== phase 2: Q = H_0 ... H_31, backward ===============
+            int ln = threadIdx.x;
+            asm volatile("" : "+v"(ln));
+            const int jj = ln & 31;
+            const double* hl2 = lds + (ln >> 5) * L_HALF;
+            double q[WR];
+#pragma unroll
+            for (int i = 0; i < WR; ++i) q[i] = (i == jj) ? 1.0 : 0.0;
+#define QRK_P4_BACK(K) back_step<K>(q, hl2, ln);
+            QRK_P4_31_0(QRK_P4_BACK)
+#undef QRK_P4_BACK
+            // row-major rows of Q_i are the CSR value order of m_Q in both FullQ ([U|N] split, :455-471) and BlockDiagonalQ (:480-492)
+            // layouts: lane j holds COLUMN j of Q_i, one coalesced store of 256 bytes per row and half
+            if (valid) {
+                double* dst = q_vals + t * 1024 + jj;
+#pragma unroll
+                for (int i = 0; i < WR; ++i) dst[32 * i] = q[i];
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    // ---- the flagged tiles, again, with the reference's own operation order (rare: generic data never gets here)
+    {
+        const unsigned f0 = (unsigned)__builtin_amdgcn_readlane((int)flagbits, 0), f1 = (unsigned)__builtin_amdgcn_readlane((int)flagbits, 32);
+        if (__builtin_expect((f0 | f1) != 0u, 0)) {
+            double* sc = scratch + (int64_t)blockIdx.x * 2048;
+            for (int h2 = 0; h2 < 2; ++h2) {
+                unsigned m = h2 ? f1 : f0;
+                while (m) {
+                    const int rnd = __builtin_ctz(m);
+                    m &= m - 1;
+                    redo_exact<PIVOT>(2 * (pi0 + (int64_t)rnd * gridDim.x) + h2, lds, sc, tiles, q_vals, r_vals, perm,
+                                      HC ? hcoeffs : nullptr);
+                }
+            }
+        }
+    }
+    }
+}
+
+int64_t bdqr_pair4_scratch_doubles(int num_wg) { return (int64_t)num_wg * 2048; }
+
+// Uniform 32 x 32 batches (any alignment).  num_wg: resident wave slots (16 per CU).
+hipError_t launch_bdqr_pair4(int64_t num_tiles, int pivoting, const double* tiles, double* q_vals, double* r_vals, int32_t* perm,
+                             double* hcoeffs, double* scratch, int num_wg, hipStream_t stream)
+{
+    if (num_tiles <= 0) return hipSuccess;
+    const int64_t npairs = (num_tiles + 1) / 2;
+    const int64_t nwg = npairs < num_wg ? npairs : num_wg;
+    const dim3 grid((unsigned)nwg), block(64);
+#define QRK_P4_LAUNCH(P, H) hipLaunchKernelGGL((bdqr_pair4_kernel<P, H>), grid, block, 0, stream, num_tiles, tiles, q_vals, r_vals, perm, hcoeffs, scratch)
+    if (pivoting) { if (hcoeffs) QRK_P4_LAUNCH(true, true); else QRK_P4_LAUNCH(true, false); }
+    else { if (hcoeffs) QRK_P4_LAUNCH(false, true); else QRK_P4_LAUNCH(false, false); }
+#undef QRK_P4_LAUNCH
+    return hipGetLastError();
+}
+
+}  // namespace qrk

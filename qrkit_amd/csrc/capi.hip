@@ -86,6 +86,8 @@ struct qrk_bd_plan_s {
     // redo list of the exact path: [0], [1] = counters of this / the next factorisation (ping-pong: the exact kernel zeroes the
     // other one, so no memset sits on the stream), [2..2+B) = global tile ids
     int32_t* d_redo = nullptr;
+    double* d_p4_scratch = nullptr;   // QRK_PAIR_V2=1 (bdqr_pair4.hip): working copies of its exact path
+    int p4_wgs = 0;
     int redo_parity = 0;
     double* d_exact_ws = nullptr;        // working copies of tiles too large for the exact kernel's LDS
     int64_t exact_ws_stride = 0;
@@ -371,7 +373,11 @@ qrk_status enqueue_factorize(qrk_bd_plan_s* p, const double* tiles, double* q, d
             qrk::launch_bdqr_thin(p->B, p->r, p->c, nb.pivoting, tiles, q, r, perm, hc, h->num_cus * 32, redo_cnt, redo_ids, h->stream);
         else if (p->max_dim <= 16 && p->r >= p->c && h->use_small_kernel)   // 64/G tiles per wavefront (bdqr_small.hip)
             qrk::launch_bdqr_small(p->B, p->r, p->c, nb.pivoting, tiles, q, r, perm, hc, h->num_cus * 32, redo_cnt, redo_ids, h->stream);
-        else {
+        else if (p->d_p4_scratch) {
+            // (experiment, QRK_PAIR_V2=1: the two-phase 32 x 32 kernel of bdqr_pair4.hip; it redoes its flagged tiles itself)
+            QRK_HIP(h, qrk::launch_bdqr_pair4(p->B, nb.pivoting, tiles, q, r, perm, hc, p->d_p4_scratch, p->p4_wgs, h->stream));
+            redo_pass = false;
+        } else {
             int wgs = h->num_cus * h->pair_wgs_per_cu;
             if (const char* e = std::getenv("QRK_PAIR_WGS")) { const int v = std::atoi(e); if (v > 0) wgs = v; }   // (experiments)
             qrk::launch_bdqr_pair(nb, full32, tiles, q, r, perm, hc, wgs, redo_cnt, redo_ids, h->stream);
@@ -743,6 +749,14 @@ qrk_status qrk_bd_plan_create(qrk_handle h, const qrk_bd_layout* L, qrk_q_format
             return fail(h, QRK_STATUS_ALLOC_FAILED, "qrk_bd_plan_create: cannot allocate the redo list / workspace of the exact path");
         }
     }
+    if (p->uniform && p->r == 32 && p->c == 32 && std::getenv("QRK_PAIR_V2") && std::atoi(std::getenv("QRK_PAIR_V2")) == 1) {
+        p->p4_wgs = h->num_cus * 16;
+        if (const char* e = std::getenv("QRK_PAIR_WGS")) { const int v = std::atoi(e); if (v > 0) p->p4_wgs = v; }
+        if (hipMalloc((void**)&p->d_p4_scratch, (size_t)qrk::bdqr_pair4_scratch_doubles(p->p4_wgs) * sizeof(double)) != hipSuccess) {
+            qrk_bd_plan_destroy(p);
+            return fail(h, QRK_STATUS_ALLOC_FAILED, "qrk_bd_plan_create: cannot allocate the scratch of the 32 x 32 kernel");
+        }
+    }
     if (!p->uniform) {
         // (largest first: the workgroups take the tiles of a launch through a queue)
         std::stable_sort(w64_ids.begin(), w64_ids.end(), [&](int32_t a, int32_t b) {
@@ -775,6 +789,7 @@ qrk_status qrk_bd_plan_destroy(qrk_bd_plan p)
     (void)hipFree(p->d_toff); (void)hipFree(p->d_qoff); (void)hipFree(p->d_roff); (void)hipFree(p->d_wave_ids); (void)hipFree(p->d_w64_ids);
     (void)hipFree(p->d_wg_ids); (void)hipFree(p->d_workspace);
     (void)hipFree(p->d_col_ids); (void)hipFree(p->d_col_workspace); (void)hipFree(p->d_redo); (void)hipFree(p->d_exact_ws);
+    (void)hipFree(p->d_p4_scratch);
     delete p;
     return QRK_STATUS_OK;
 }
