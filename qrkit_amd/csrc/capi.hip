@@ -86,7 +86,7 @@ struct qrk_bd_plan_s {
     // redo list of the exact path: [0], [1] = counters of this / the next factorisation (ping-pong: the exact kernel zeroes the
     // other one, so no memset sits on the stream), [2..2+B) = global tile ids
     int32_t* d_redo = nullptr;
-    double* d_p4_scratch = nullptr;   // QRK_PAIR_V2=1 (bdqr_pair4.hip): working copies of its exact path
+    double* d_p4_scratch = nullptr;   // bdqr_pair4.hip (uniform 32 x 32): working copies of its exact path
     int p4_wgs = 0;
     int redo_parity = 0;
     double* d_exact_ws = nullptr;        // working copies of tiles too large for the exact kernel's LDS
@@ -374,7 +374,7 @@ qrk_status enqueue_factorize(qrk_bd_plan_s* p, const double* tiles, double* q, d
         else if (p->max_dim <= 16 && p->r >= p->c && h->use_small_kernel)   // 64/G tiles per wavefront (bdqr_small.hip)
             qrk::launch_bdqr_small(p->B, p->r, p->c, nb.pivoting, tiles, q, r, perm, hc, h->num_cus * 32, redo_cnt, redo_ids, h->stream);
         else if (p->d_p4_scratch) {
-            // (experiment, QRK_PAIR_V2=1: the two-phase 32 x 32 kernel of bdqr_pair4.hip; it redoes its flagged tiles itself)
+            // the two-phase 32 x 32 kernel of bdqr_pair4.hip (four waves per SIMD); it redoes its flagged tiles itself
             QRK_HIP(h, qrk::launch_bdqr_pair4(p->B, nb.pivoting, tiles, q, r, perm, hc, p->d_p4_scratch, p->p4_wgs, h->stream));
             redo_pass = false;
         } else {
@@ -749,7 +749,8 @@ qrk_status qrk_bd_plan_create(qrk_handle h, const qrk_bd_layout* L, qrk_q_format
             return fail(h, QRK_STATUS_ALLOC_FAILED, "qrk_bd_plan_create: cannot allocate the redo list / workspace of the exact path");
         }
     }
-    if (p->uniform && p->r == 32 && p->c == 32 && std::getenv("QRK_PAIR_V2") && std::atoi(std::getenv("QRK_PAIR_V2")) == 1) {
+    // uniform 32 x 32 batches: the second-generation kernel (bdqr_pair4.hip); QRK_PAIR_V2=0 keeps the first (bdqr_pair.hip)
+    if (p->uniform && p->r == 32 && p->c == 32 && B > 0 && !(std::getenv("QRK_PAIR_V2") && std::atoi(std::getenv("QRK_PAIR_V2")) == 0)) {
         p->p4_wgs = h->num_cus * 16;
         if (const char* e = std::getenv("QRK_PAIR_WGS")) { const int v = std::atoi(e); if (v > 0) p->p4_wgs = v; }
         if (hipMalloc((void**)&p->d_p4_scratch, (size_t)qrk::bdqr_pair4_scratch_doubles(p->p4_wgs) * sizeof(double)) != hipSuccess) {
@@ -2189,6 +2190,7 @@ const char* qrk_bd_kernel_name(qrk_bd_plan p, int which)
     if (p->uniform && p->max_dim <= 16 && p->r >= p->c && h->use_small_kernel)
         return piv ? "qrk::bdqr_small_kernel<G, true>" : "qrk::bdqr_small_kernel<G, false>";
     // (tau is not stored by the measurement entry point and by callers that pass hcoeffs = NULL: the <.., false> instantiation)
+    if (p->d_p4_scratch) return piv ? "qrk::bdqr_pair4_kernel<true, false>" : "qrk::bdqr_pair4_kernel<false, false>";
     if (p->uniform && p->r == 32 && p->c == 32) return piv ? "qrk::bdqr_pair32_kernel<true, false>" : "qrk::bdqr_pair32_kernel<false, false>";
     return piv ? "qrk::bdqr_pair_kernel<false, true, true>" : "qrk::bdqr_pair_kernel<false, false, true>";
 }

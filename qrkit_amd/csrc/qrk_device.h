@@ -44,7 +44,7 @@ struct TileGeom {
 
 // ---- host-side launchers (defined next to their kernels)
 // redo_count / redo_ids: list of tiles whose decisions were not clear of rounding (redone by launch_bdqr_exact)
-// bdqr_pair4.hip (experiment, QRK_PAIR_V2=1): uniform 32 x 32 batches, two tiles per wavefront, four wavefronts per SIMD
+// bdqr_pair4.hip (QRK_PAIR_V2=0 disables): uniform 32 x 32 batches, two tiles per wavefront, four wavefronts per SIMD
 int64_t bdqr_pair4_scratch_doubles(int num_wg);
 hipError_t launch_bdqr_pair4(int64_t num_tiles, int pivoting, const double* tiles, double* q_vals, double* r_vals, int32_t* perm,
                              double* hcoeffs, double* scratch, int num_wg, hipStream_t stream);

@@ -16,10 +16,7 @@ from qrkit_amd import _capi as capi                # noqa: E402
 
 
 def make_plan(ctx, B, pivoting, v2):
-    if v2:
-        os.environ["QRK_PAIR_V2"] = "1"
-    else:
-        os.environ.pop("QRK_PAIR_V2", None)
+    os.environ["QRK_PAIR_V2"] = "1" if v2 else "0"
     lay = capi.BDLayout()
     lay.num_blocks, lay.block_rows, lay.block_cols = B, 32, 32
     lay.rows = lay.cols = None

@@ -8,8 +8,8 @@ import p4_check as pc  # noqa: E402
 import qrkit_amd       # noqa: E402
 
 ctx = qrkit_amd.Context(0)
-for B in (10000, 100000):
-    for wgs in (1024, 2048, 3072, 4096):
+for B in (10000,):
+    for wgs in (2500, 2560, 2816, 3328, 4096):
         os.environ["QRK_PAIR_WGS"] = str(wgs)
         t = pc.timeit(ctx, B, True, True)
         print(f"B={B} waves={wgs} ({wgs // 1024}/SIMD): {t:.2f} us", flush=True)

@@ -22,7 +22,7 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_I
   timeout -k 10 240 rocprofv3 --pmc $grp --output-format csv -d "$ROOT/$OUT/pmc/p$i" -- python3 "$ROOT/bench.py" $ARGS > "$ROOT/$OUT/pmc/p$i.log" 2>&1 || echo "PMC pass $i failed: $grp"
 done
 cd $ROOT
-python3 tools/pmc_summary.py $OUT/pmc bdqr_pair32 > $OUT/k1_pmc_summary.txt 2>&1; cat $OUT/k1_pmc_summary.txt
+python3 tools/pmc_summary.py $OUT/pmc bdqr_pair4 > $OUT/k1_pmc_summary.txt 2>&1; cat $OUT/k1_pmc_summary.txt
 find $OUT/pmc -name "*.db" -delete 2>/dev/null; find $OUT/pmc -name "*agent_info.csv" -delete 2>/dev/null
 timeout -k 10 300 python tools/mixed_probe.py 4000 2>&1 | grep tiles/s > $OUT/mixed_probe.txt; head -14 $OUT/mixed_probe.txt
 timeout -k 10 200 python tools/k2_wgs_probe.py 0 2>&1 | grep tiles/s > $OUT/k2_sizes.txt; cat $OUT/k2_sizes.txt

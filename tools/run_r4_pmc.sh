@@ -11,5 +11,5 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_I
   timeout -k 10 240 rocprofv3 --pmc $grp --output-format csv -d "$ROOT/$OUT/pmc/p$i" -- python3 "$ROOT/bench.py" $ARGS > "$ROOT/$OUT/pmc/p$i.log" 2>&1 || echo "PMC pass $i failed: $grp"
 done
 cd $ROOT
-python3 tools/pmc_summary.py $OUT/pmc bdqr_pair32 > $OUT/k1_pmc_summary.txt 2>&1; cat $OUT/k1_pmc_summary.txt
+python3 tools/pmc_summary.py $OUT/pmc bdqr_pair4 > $OUT/k1_pmc_summary.txt 2>&1; cat $OUT/k1_pmc_summary.txt
 find $OUT/pmc -name "*.db" -delete 2>/dev/null; find $OUT/pmc -name "*agent_info.csv" -delete 2>/dev/null
