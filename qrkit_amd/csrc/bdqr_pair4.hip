@@ -33,6 +33,14 @@ namespace p4 {
 
 using namespace decide;
 
+// Diagnostic only (tools/p4_stamps.py): -DQRK_P4_STAMP records s_memrealtime (100 MHz, one clock for the whole chip) of every pair at
+// the start of its round, when its tiles are in registers, at the end of phase 1 and at the end -- in the array passed as `hcoeffs`
+#ifdef QRK_P4_STAMP
+#define QRK_P4_STAMP_AT(slot) do { if (threadIdx.x == 0) reinterpret_cast<long long*>(hcoeffs)[pi * 4 + (slot)] = (long long)__builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define QRK_P4_STAMP_AT(slot) do { } while (0)
+#endif
+
 constexpr int WR = 32;
 constexpr int FILTER = 256;              // pivot candidates: high word of the squared norm within 2^-12 (relative) of the largest
 // LDS per HALF (doubles): reflector K (the pivot column of step K, as published) holds rows (K & ~1) .. 31 at cb(K): 16-byte aligned
@@ -43,7 +51,7 @@ constexpr int L_NG = L_S + WR;           // [32] -1 / (beta (x0 - beta))
 constexpr int L_TAU = L_NG + WR;         // [32]
 constexpr int L_HALF = L_TAU + WR;       // 640 doubles = 5 120 B per half, 10 240 B per wave: 16 waves per CU
 static_assert(cb(WR) == 544 && L_HALF * 8 * 2 * 16 <= 160 * 1024, "sixteen waves per CU");
-constexpr int STAGE_LD = WR + 1;         // the staging of a tile (lane = row -> lane = column) uses [32][33] doubles of the wave's LDS
+constexpr int STAGE_LD = WR + 2;         // the staging of a tile (lane = two rows -> lane = column) uses [32][34] doubles of the wave's LDS
 static_assert(WR * STAGE_LD <= 2 * L_HALF, "the staging buffer fits the wave's LDS");
 
 #define QRK_P4_0_31(M)                                                                           \
@@ -306,6 +314,20 @@ bdqr_pair4_kernel(int64_t num_tiles, const double* __restrict__ tiles, double* _
     __shared__ __attribute__((aligned(16))) double lds[2 * L_HALF];
     const int64_t npairs = (num_tiles + 1) / 2;
     constexpr int CHUNK = 32;                // rounds per chunk: one 32-bit word per half remembers the flagged rounds
+#ifndef QRK_P4_PRIO
+#define QRK_P4_PRIO 0
+#endif
+    // QRK_P4_PRIO: 1 = the waves that have one pair more than the others go first on their SIMD and in the memory queues (their two
+    // chains are the critical path of a launch of 1 .. 2 rounds); 2 = the later a wave is dispatched the higher its priority
+    if (QRK_P4_PRIO == 1 && (int64_t)blockIdx.x + (npairs / gridDim.x) * gridDim.x < npairs) __builtin_amdgcn_s_setprio(3);
+    if (QRK_P4_PRIO == 2) {
+        switch ((int)(((uint64_t)blockIdx.x * 4u) / gridDim.x)) {
+            case 1: __builtin_amdgcn_s_setprio(1); break;
+            case 2: __builtin_amdgcn_s_setprio(2); break;
+            case 3: __builtin_amdgcn_s_setprio(3); break;
+            default: break;
+        }
+    }
     for (int64_t pi0 = blockIdx.x; pi0 < npairs; pi0 += (int64_t)CHUNK * gridDim.x) {
     unsigned flagbits = 0u;                  // bit r: the tile of this half in round r of the chunk was flagged
     int64_t pi = pi0;
@@ -322,38 +344,59 @@ bdqr_pair4_kernel(int64_t num_tiles, const double* __restrict__ tiles, double* _
         st.lane = lane; st.j = j; st.half = half; st.unclear = false; st.kstep = 0; st.a2 = 0.0; st.livemask = ~0ull;
         {
             // =============== phase 1: A -> R ===============
+            QRK_P4_STAMP_AT(0);
             double a[WR];
             {
-                // both tiles of the pair, one after the other through the wave's LDS: lane l takes row l & 31 of columns 16 (l >> 5) ..
-                // (two runs of 256 bytes per load instruction), the tile is written column by column with a padded stride and the lanes of
-                // its half read their columns back.  The loads of the second tile are in flight while the first one is staged.
-                double ld0[16], ld1[16];
-                const int r = lane & 31, g = lane >> 5;
+                // both tiles of the pair, one after the other through the wave's LDS: every load instruction takes 1 KB of a tile (lane l
+                // rows 2 (l & 15), +1 of column 4 m + (l >> 4)), the tile is written column by column with a padded stride (16-byte
+                // stores) and the lanes of its half read their columns back (16-byte loads, conflict-free: 34 doubles between lanes).
+                // The loads of the second tile are in flight while the first one is staged.
+                typedef double d2u __attribute__((ext_vector_type(2), aligned(8)));
+                typedef double d2a __attribute__((ext_vector_type(2), aligned(16)));
+                d2u ld0[8], ld1[8];
                 const int64_t t0 = 2 * pi, t1 = 2 * pi + 1;
-                const double* s0 = tiles + t0 * 1024 + (16 * g) * 32 + r;
-                const double* s1 = tiles + (t1 < num_tiles ? t1 : t0) * 1024 + (16 * g) * 32 + r;
+                const double* s0 = tiles + t0 * 1024 + 2 * lane;
+                const double* s1 = tiles + (t1 < num_tiles ? t1 : t0) * 1024 + 2 * lane;
 #pragma unroll
-                for (int m = 0; m < 16; ++m) ld0[m] = s0[32 * m];
+                for (int m = 0; m < 8; ++m) ld0[m] = *reinterpret_cast<const d2u*>(s0 + 128 * m);
 #pragma unroll
-                for (int m = 0; m < 16; ++m) ld1[m] = s1[32 * m];
+                for (int m = 0; m < 8; ++m) ld1[m] = *reinterpret_cast<const d2u*>(s1 + 128 * m);
+                if (QRK_P4_PRIO == 3 && round == 0 && pi0 == blockIdx.x) {
+                    // (after the loads are queued in dispatch order: the later a wave's tiles arrive, the higher its priority on the SIMD)
+                    switch ((int)(((uint64_t)blockIdx.x * 4u) / gridDim.x)) {
+                        case 1: __builtin_amdgcn_s_setprio(1); break;
+                        case 2: __builtin_amdgcn_s_setprio(2); break;
+                        case 3: __builtin_amdgcn_s_setprio(3); break;
+                        default: break;
+                    }
+                }
+                double* sw = lds + (lane >> 4) * STAGE_LD + 2 * (lane & 15);
 #pragma unroll
-                for (int m = 0; m < 16; ++m) lds[(16 * g + m) * STAGE_LD + r] = ld0[m];
+                for (int m = 0; m < 8; ++m) *reinterpret_cast<d2a*>(sw + 4 * m * STAGE_LD) = d2a{ld0[m].x, ld0[m].y};
                 __builtin_amdgcn_wave_barrier();
                 // (both halves read: a conditional first definition would leave a[] undefined on one side, which hipcc carries
                 //  around the round loop as live values)
 #pragma unroll
-                for (int i = 0; i < WR; ++i) a[i] = lds[j * STAGE_LD + i];
+                for (int i = 0; i < WR; i += 2) {
+                    const d2a v = *reinterpret_cast<const d2a*>(lds + j * STAGE_LD + i);
+                    a[i] = v.x; a[i + 1] = v.y;
+                }
                 __builtin_amdgcn_wave_barrier();
 #pragma unroll
-                for (int m = 0; m < 16; ++m) lds[(16 * g + m) * STAGE_LD + r] = ld1[m];
+                for (int m = 0; m < 8; ++m) *reinterpret_cast<d2a*>(sw + 4 * m * STAGE_LD) = d2a{ld1[m].x, ld1[m].y};
                 __builtin_amdgcn_wave_barrier();
                 if (half == 1) {
                     // (the missing partner of an odd last tile: diag(64..33) -- distinct norms, no tie-breaking; nothing of it is stored)
 #pragma unroll
-                    for (int i = 0; i < WR; ++i) a[i] = valid ? lds[j * STAGE_LD + i] : ((i == j) ? (double)(64 - j) : 0.0);
+                    for (int i = 0; i < WR; i += 2) {
+                        const d2a v = *reinterpret_cast<const d2a*>(lds + j * STAGE_LD + i);
+                        a[i] = valid ? v.x : ((i == j) ? (double)(64 - j) : 0.0);
+                        a[i + 1] = valid ? v.y : ((i + 1 == j) ? (double)(64 - j) : 0.0);
+                    }
                 }
                 __builtin_amdgcn_wave_barrier();
             }
+            QRK_P4_STAMP_AT(1);
             {
                 double s0 = 0.0, s1 = 0.0;
 #pragma unroll
@@ -391,6 +434,7 @@ bdqr_pair4_kernel(int64_t num_tiles, const double* __restrict__ tiles, double* _
         }
         {
             // =============== phase 2: Q = H_0 ... H_31, backward ===============
+            QRK_P4_STAMP_AT(2);
             int ln = threadIdx.x;
             asm volatile("" : "+v"(ln));
             const int jj = ln & 31;
@@ -408,8 +452,10 @@ bdqr_pair4_kernel(int64_t num_tiles, const double* __restrict__ tiles, double* _
 #pragma unroll
                 for (int i = 0; i < WR; ++i) dst[32 * i] = q[i];
             }
+            QRK_P4_STAMP_AT(3);
         }
         __builtin_amdgcn_wave_barrier();
+        if (QRK_P4_PRIO >= 2) __builtin_amdgcn_s_setprio(3);     // (a further pair of this wave starts later than anything else)
     }
     // ---- the flagged tiles, again, with the reference's own operation order (rare: generic data never gets here)
     {
@@ -441,8 +487,12 @@ hipError_t launch_bdqr_pair4(int64_t num_tiles, int pivoting, const double* tile
     const int64_t nwg = npairs < num_wg ? npairs : num_wg;
     const dim3 grid((unsigned)nwg), block(64);
 #define QRK_P4_LAUNCH(P, H) hipLaunchKernelGGL((bdqr_pair4_kernel<P, H>), grid, block, 0, stream, num_tiles, tiles, q_vals, r_vals, perm, hcoeffs, scratch)
+#ifdef QRK_P4_STAMP
+    if (pivoting) QRK_P4_LAUNCH(true, false); else QRK_P4_LAUNCH(false, false);
+#else
     if (pivoting) { if (hcoeffs) QRK_P4_LAUNCH(true, true); else QRK_P4_LAUNCH(true, false); }
     else { if (hcoeffs) QRK_P4_LAUNCH(false, true); else QRK_P4_LAUNCH(false, false); }
+#endif
 #undef QRK_P4_LAUNCH
     return hipGetLastError();
 }
