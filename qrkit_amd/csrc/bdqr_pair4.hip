@@ -54,6 +54,23 @@ static_assert(cb(WR) == 544 && L_HALF * 8 * 2 * 16 <= 160 * 1024, "sixteen waves
 constexpr int STAGE_LD = WR + 2;         // the staging of a tile (lane = two rows -> lane = column) uses [32][34] doubles of the wave's LDS
 static_assert(WR * STAGE_LD <= 2 * L_HALF, "the staging buffer fits the wave's LDS");
 
+// QRK_P4_NT: 1 = the tiles are loaded, 2 = Q and R are stored, 3 = both with the non-temporal hint.  Measured (profiles/r04_p4_nt.txt):
+// loads 78.0 -> 74.3 us per 10 000 tiles (the input does not displace the results being merged in L2); stores 130 us (16-byte pieces of
+// R no longer merge)
+#ifndef QRK_P4_NT
+#define QRK_P4_NT 1
+#endif
+#if QRK_P4_NT & 1
+#define QRK_P4_LOAD(p) __builtin_nontemporal_load(p)
+#else
+#define QRK_P4_LOAD(p) (*(p))
+#endif
+#if QRK_P4_NT & 2
+#define QRK_P4_STORE(v, p) __builtin_nontemporal_store((v), (p))
+#else
+#define QRK_P4_STORE(v, p) (*(p) = (v))
+#endif
+
 #define QRK_P4_0_31(M)                                                                           \
     M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9) M(10) M(11) M(12) M(13) M(14) M(15) M(16)  \
     M(17) M(18) M(19) M(20) M(21) M(22) M(23) M(24) M(25) M(26) M(27) M(28) M(29) M(30) M(31)
@@ -358,9 +375,9 @@ bdqr_pair4_kernel(int64_t num_tiles, const double* __restrict__ tiles, double* _
                 const double* s0 = tiles + t0 * 1024 + 2 * lane;
                 const double* s1 = tiles + (t1 < num_tiles ? t1 : t0) * 1024 + 2 * lane;
 #pragma unroll
-                for (int m = 0; m < 8; ++m) ld0[m] = *reinterpret_cast<const d2u*>(s0 + 128 * m);
+                for (int m = 0; m < 8; ++m) ld0[m] = QRK_P4_LOAD(reinterpret_cast<const d2u*>(s0 + 128 * m));
 #pragma unroll
-                for (int m = 0; m < 8; ++m) ld1[m] = *reinterpret_cast<const d2u*>(s1 + 128 * m);
+                for (int m = 0; m < 8; ++m) ld1[m] = QRK_P4_LOAD(reinterpret_cast<const d2u*>(s1 + 128 * m));
                 if (QRK_P4_PRIO == 3 && round == 0 && pi0 == blockIdx.x) {
                     // (after the loads are queued in dispatch order: the later a wave's tiles arrive, the higher its priority on the SIMD)
                     switch ((int)(((uint64_t)blockIdx.x * 4u) / gridDim.x)) {
@@ -420,8 +437,8 @@ bdqr_pair4_kernel(int64_t num_tiles, const double* __restrict__ tiles, double* _
                 typedef double d2u __attribute__((ext_vector_type(2), aligned(8)));
 #pragma unroll
                 for (int i = 0; i < WR; i += 2) {
-                    if (i + 1 <= p) *reinterpret_cast<d2u*>(dst + i) = d2u{a[i], a[i + 1]};
-                    else if (i == p) dst[i] = a[i];
+                    if (i + 1 <= p) QRK_P4_STORE((d2u{a[i], a[i + 1]}), reinterpret_cast<d2u*>(dst + i));
+                    else if (i == p) QRK_P4_STORE(a[i], dst + i);
                 }
                 if (HC && hcoeffs) hcoeffs[cbase + jj] = lds[(ln >> 5) * L_HALF + L_TAU + jj];
             }
@@ -450,7 +467,7 @@ bdqr_pair4_kernel(int64_t num_tiles, const double* __restrict__ tiles, double* _
             if (valid) {
                 double* dst = q_vals + t * 1024 + jj;
 #pragma unroll
-                for (int i = 0; i < WR; ++i) dst[32 * i] = q[i];
+                for (int i = 0; i < WR; ++i) QRK_P4_STORE(q[i], dst + 32 * i);
             }
             QRK_P4_STAMP_AT(3);
         }
