@@ -47,7 +47,7 @@ constexpr int FILTER = 256;              // pivot candidates: high word of the s
 constexpr int cb(int k) { int s = 0; for (int q = 0; q < k; ++q) s += WR - (q & ~1); return s; }
 constexpr int L_V = 0;
 constexpr int L_S = cb(WR);              // [32] s = x0 - beta
-constexpr int L_NG = L_S + WR;           // [32] -1 / (beta (x0 - beta))
+constexpr int L_NG = L_S + WR;           // [32] 1 / (beta (beta - x0)) (the sign of -gamma goes into the multiply's source modifier)
 constexpr int L_TAU = L_NG + WR;         // [32]
 constexpr int L_HALF = L_TAU + WR;       // 640 doubles = 5 120 B per half, 10 240 B per wave: 16 waves per CU
 static_assert(cb(WR) == 544 && L_HALF * 8 * 2 * 16 <= 160 * 1024, "sixteen waves per CU");
@@ -69,6 +69,12 @@ static_assert(WR * STAGE_LD <= 2 * L_HALF, "the staging buffer fits the wave's L
 #define QRK_P4_STORE(v, p) __builtin_nontemporal_store((v), (p))
 #else
 #define QRK_P4_STORE(v, p) (*(p) = (v))
+#endif
+
+#if QRK_P4_NT & 4
+#define QRK_P4_STOREQ(v, p) __builtin_nontemporal_store((v), (p))
+#else
+#define QRK_P4_STOREQ(v, p) (*(p) = (v))
 #endif
 
 #define QRK_P4_0_31(M)                                                                           \
@@ -129,7 +135,7 @@ __device__ __forceinline__ double bpermute_f64(int byte_addr, double v)
 struct Lane {
     int lane, j, half;
     unsigned long long livemask;   // (wave-uniform) the lanes whose column of A is not yet chosen
-    bool unclear;     // a decision of this half's tile was inside its error margin (any lane of the half)
+    unsigned long long unclearm;   // (wave-uniform) lanes that saw a decision of their tile inside its error margin
     int kstep;        // position at which this lane's column was chosen
     double nu2;       // m_colNormsUpdated^2 (a chosen column carries a negative value)
     double thr;       // sqrt(eps) (1 + 2^-12) m_colNormsDirect^2
@@ -181,7 +187,7 @@ __device__ __forceinline__ void step(double (&a)[WR], double* hl /* this half's 
             const double best = bpermute_f64(src, st.nu2), thrb = bpermute_f64(src, st.thr);
             double margin = MREL * (st.thr + thrb);
             if (K > 0) margin += 4.547473508864641e-13 /* 2^-41 */ * __builtin_sqrt(st.a2 * (best > 0.0 ? best : 0.0));
-            if (live && !ispiv && st.nu2 >= best - margin) st.unclear = true;
+            st.unclearm |= __builtin_amdgcn_ballot_w64(live && !ispiv && st.nu2 >= best - margin);
             pm = __builtin_amdgcn_ballot_w64(ispiv);
         }
         st.livemask &= ~pm;
@@ -201,7 +207,11 @@ __device__ __forceinline__ void step(double (&a)[WR], double* hl /* this half's 
         // ---- 2. publish the column (it is reflector K of phase 2 as well)
         double* vcol = hl + L_V + cb(K) - (K & ~1);
 #pragma unroll
+#ifdef QRK_P4_ABL      // (timing ablation only: results are wrong) 1: publish 16 bytes instead of the column
+        for (int i = K & ~1; i < ((QRK_P4_ABL & 1) ? (K & ~1) + 2 : WR); i += 2) *reinterpret_cast<double2*>(&vcol[i]) = make_double2(a[i], a[i + 1]);
+#else
         for (int i = K & ~1; i < WR; i += 2) *reinterpret_cast<double2*>(&vcol[i]) = make_double2(a[i], a[i + 1]);
+#endif
     }
     __builtin_amdgcn_wave_barrier();
     // ---- 3. the lanes' elements of it, x0
@@ -229,7 +239,15 @@ __device__ __forceinline__ void step(double (&a)[WR], double* hl /* this half's 
         __builtin_amdgcn_wave_barrier();
     }
     if (K == 0 && !PIVOT) st.a2 = fma(xk, xk, tsq);
-    if (unclear_reflector(xk, tsq, K + 1 < WR, PIVOT, st.a2)) st.unclear = true;
+    // (decide::unclear_reflector without short-circuit evaluation: three compares, no control flow)
+    const bool degenerate = !(tsq > DBL_MIN);
+    {
+        const double n2 = fma(xk, xk, tsq);
+        bool u = false;
+        if (K + 1 < WR) u = degenerate | (xk * xk <= X0_TINY2 * st.a2);
+        if (PIVOT) u = u | (n2 <= PIV_TINY2 * st.a2);
+        st.unclearm |= __builtin_amdgcn_ballot_w64(u);
+    }
     // ---- 5. makeHouseholder in the un-normalised form: nb = -beta = copysign(norm, x0), s = x0 - beta, ng = -1 / (beta (x0 - beta));
     // Eigen: tailSqNorm <= min() gives tau = 0, beta = x0, H = I (rare: a real branch on a wave-level test, selects inside)
     const double nrm = sqrt_pos(fma(xk, xk, tsq));
@@ -237,16 +255,16 @@ __device__ __forceinline__ void step(double (&a)[WR], double* hl /* this half's 
     //  redone by the exact path -- and without a tail the branch below overrides)
     double nbv = __builtin_copysign(nrm, xk);                // beta = -nbv
     double s = nbv + xk;
-    double ng = -recip(nbv * s);
-    if (__builtin_expect(__builtin_amdgcn_ballot_w64(!(tsq > DBL_MIN)) != 0ull, 0)) {
+    double ngp = recip(nbv * s);                             // -ng
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(degenerate) != 0ull, 0)) {
         asm volatile("");
-        if (!(tsq > DBL_MIN)) { nbv = -xk; s = 0.0; ng = 0.0; }
+        if (degenerate) { nbv = -xk; s = 0.0; ngp = 0.0; }
     }
     if (st.j == 0) {
-        hl[L_S + K] = s; hl[L_NG + K] = ng;
-        if (HC) hl[L_TAU + K] = -(s * s) * ng;
+        hl[L_S + K] = s; hl[L_NG + K] = ngp;
+        if (HC) hl[L_TAU + K] = (s * s) * ngp;
     }
-    const double ngam = fma(s, ak, dsum) * ng;               // -gamma of this column
+    const double ngam = fma(s, ak, dsum) * -ngp;             // -gamma of this column
     double an = fma(s, ngam, ak);
     {
         // R(K, K) = beta = -nbv in the pivot lane: two selects, the sign through the source modifier
@@ -270,7 +288,7 @@ __device__ __forceinline__ void step(double (&a)[WR], double* hl /* this half's 
         if (__builtin_expect(needm != 0ull, 0)) {
             asm volatile("");
             const bool need = ((needm >> lane) & 1ull) != 0ull;
-            if (need && in_recompute_band(nn, st.thr, st.a2)) st.unclear = true;      // decision (2)
+            st.unclearm |= __builtin_amdgcn_ballot_w64(need && in_recompute_band(nn, st.thr, st.a2));      // decision (2)
             double sq = 0.0;
 #define QRK_P4_SQ(I) if ((I) > K) sq = fma(a[I], a[I], sq);
             QRK_P4_0_31(QRK_P4_SQ)
@@ -285,7 +303,7 @@ template <int K>
 __device__ __forceinline__ void back_step(double (&q)[WR], const double* hl, const int lane)
 {
     constexpr int M0 = (K + 1) >> 4;
-    const double s = hl[L_S + K], ng = hl[L_NG + K];
+    const double s = hl[L_S + K], ngp = hl[L_NG + K];
     double xc[2] = {0.0, 0.0};
     if (K + 1 < WR) load_chunks<K>(hl, lane, xc);
     const double qk = q[K];
@@ -295,7 +313,7 @@ __device__ __forceinline__ void back_step(double (&q)[WR], const double* hl, con
 #define QRK_P4_DOT(I) if ((I) > K) fmac_bcast<((I) & 15)>(((I) & 1) ? d1 : d0, xc[(I) >> 4], q[I]);
     QRK_P4_0_31(QRK_P4_DOT)
 #undef QRK_P4_DOT
-    const double ngam = fma(s, qk, d0 + d1) * ng;
+    const double ngam = fma(s, qk, d0 + d1) * -ngp;
     q[K] = fma(s, ngam, qk);
 #define QRK_P4_UPD(I) if ((I) > K) fmac_bcast<((I) & 15)>(q[I], xc[(I) >> 4], ngam);
     QRK_P4_0_31(QRK_P4_UPD)
@@ -358,7 +376,7 @@ bdqr_pair4_kernel(int64_t num_tiles, const double* __restrict__ tiles, double* _
         const int64_t t = 2 * pi + half;
         const bool valid = t < num_tiles;
         Lane st;
-        st.lane = lane; st.j = j; st.half = half; st.unclear = false; st.kstep = 0; st.a2 = 0.0; st.livemask = ~0ull;
+        st.lane = lane; st.j = j; st.half = half; st.unclearm = 0ull; st.kstep = 0; st.a2 = 0.0; st.livemask = ~0ull;
         {
             // =============== phase 1: A -> R ===============
             QRK_P4_STAMP_AT(0);
@@ -378,9 +396,11 @@ bdqr_pair4_kernel(int64_t num_tiles, const double* __restrict__ tiles, double* _
                 for (int m = 0; m < 8; ++m) ld0[m] = QRK_P4_LOAD(reinterpret_cast<const d2u*>(s0 + 128 * m));
 #pragma unroll
                 for (int m = 0; m < 8; ++m) ld1[m] = QRK_P4_LOAD(reinterpret_cast<const d2u*>(s1 + 128 * m));
-                if (QRK_P4_PRIO == 3 && round == 0 && pi0 == blockIdx.x) {
-                    // (after the loads are queued in dispatch order: the later a wave's tiles arrive, the higher its priority on the SIMD)
-                    switch ((int)(((uint64_t)blockIdx.x * 4u) / gridDim.x)) {
+                if (QRK_P4_PRIO >= 3 && round == 0 && pi0 == blockIdx.x) {
+                    // (after the loads are queued in dispatch order: the later a wave's tiles arrive, the higher its priority on the SIMD;
+                    //  4, 5: the waves that carry one pair more than the others -- two chains back to back -- are in the top class)
+                    const bool longw = QRK_P4_PRIO >= 4 && (int64_t)blockIdx.x + (npairs / gridDim.x) * gridDim.x < npairs;
+                    switch (longw ? 3 : (int)(((uint64_t)blockIdx.x * 4u) / gridDim.x)) {
                         case 1: __builtin_amdgcn_s_setprio(1); break;
                         case 2: __builtin_amdgcn_s_setprio(2); break;
                         case 3: __builtin_amdgcn_s_setprio(3); break;
@@ -445,7 +465,11 @@ bdqr_pair4_kernel(int64_t num_tiles, const double* __restrict__ tiles, double* _
         }
         // a decision inside its error margin, anywhere in the half: the tile is redone by the exact path after the rounds
         {
-            const unsigned long long um = __builtin_amdgcn_ballot_w64(st.unclear);
+#ifdef QRK_P4_ABL
+            const unsigned long long um = 0ull;
+#else
+            const unsigned long long um = st.unclearm;
+#endif
             const bool f = half ? (um >> 32) != 0ull : (um & 0xffffffffull) != 0ull;
             if (f && valid) flagbits |= 1u << round;
         }
@@ -467,12 +491,13 @@ bdqr_pair4_kernel(int64_t num_tiles, const double* __restrict__ tiles, double* _
             if (valid) {
                 double* dst = q_vals + t * 1024 + jj;
 #pragma unroll
-                for (int i = 0; i < WR; ++i) QRK_P4_STORE(q[i], dst + 32 * i);
+                for (int i = 0; i < WR; ++i) QRK_P4_STOREQ(q[i], dst + 32 * i);
             }
             QRK_P4_STAMP_AT(3);
         }
         __builtin_amdgcn_wave_barrier();
-        if (QRK_P4_PRIO >= 2) __builtin_amdgcn_s_setprio(3);     // (a further pair of this wave starts later than anything else)
+        if (QRK_P4_PRIO == 2 || QRK_P4_PRIO == 3) __builtin_amdgcn_s_setprio(3);     // (a further pair of this wave starts later than anything else)
+        if (QRK_P4_PRIO == 5 && !((int64_t)blockIdx.x + (npairs / gridDim.x) * gridDim.x < npairs)) __builtin_amdgcn_s_setprio(0);
     }
     // ---- the flagged tiles, again, with the reference's own operation order (rare: generic data never gets here)
     {
