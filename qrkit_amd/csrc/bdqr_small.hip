@@ -131,7 +131,7 @@ bdqr_small_kernel(int64_t num_tiles, int r, int c, const double* __restrict__ ti
         // ---- tiles in: one coalesced sweep
         {
             const double* src = tiles + t0 * rc;
-            for (int e = tid; e < nt * rc; e += 256) buf[e] = src[e];
+            for (int e = tid; e < nt * rc; e += 256) buf[e] = QRK_TILE_LOAD(src + e);
         }
         __syncthreads();
         const bool valid = tl < nt;

@@ -53,7 +53,7 @@ bdqr_thin_kernel(int64_t num_tiles, int r, int c, const double* __restrict__ til
             const int n = nt * rc;
             for (int e = tid; e < n; e += 256) {
                 const int tl = (int)(((float)e + 0.5f) / (float)rc);
-                thin_lds[tl * sin + (e - tl * rc)] = src[e];
+                thin_lds[tl * sin + (e - tl * rc)] = QRK_TILE_LOAD(src + e);
             }
         }
         __syncthreads();

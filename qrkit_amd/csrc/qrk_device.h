@@ -215,6 +215,19 @@ __device__ __forceinline__ bool unclear_reflector(double xk, double tsq, bool ta
 constexpr int PIVOTING_SIGN_FREE = 2;     // bit of the launchers' `pivoting` argument that sets sign_free
 }  // namespace decide
 
+// Tiles are read once per factorisation: the non-temporal hint keeps them from displacing the results that are being merged in L2
+// (bdqr_pair4.hip: 78.0 -> 74.3 us per 10 000 tiles of 32 x 32; the small-tile kernels + 2-4 %; profiles/r04_p4_nt.txt).  Only where
+// every byte of a line is taken by one load instruction: bdqr_w64 / bdqr_reg read a column per lane and live on the reuse of
+// their lines (64 x 64: 16.5 -> 13 M tiles/s with the hint).  -DQRK_NT_TILES=0: plain loads.
+#ifndef QRK_NT_TILES
+#define QRK_NT_TILES 1
+#endif
+#if QRK_NT_TILES
+#define QRK_TILE_LOAD(p) __builtin_nontemporal_load(p)
+#else
+#define QRK_TILE_LOAD(p) (*(p))
+#endif
+
 // ---- cross-lane helpers (wave64) ---------------------------------------------------------
 
 __device__ __forceinline__ double readlane_f64(double v, int lane)
