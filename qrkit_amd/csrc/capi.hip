@@ -137,6 +137,12 @@ struct qrk_bbs_plan_s {
 
 // ---- QRKit::BlockedThinSparseQR on the device (include/qrkit_amd.h, qrk_thin_*) -----------------------------------------------
 namespace qrk {
+// the identity permutation of an un-pivoted factorisation (no host vector, no synchronisation)
+__global__ void __launch_bounds__(256) identity_perm_kernel(int32_t* __restrict__ p, int n)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) p[i] = i;
+}
 // columns of R that a panel finishes (BlockedThinSparseQR.h:271-279): column nzp + bc of R takes the rows above the panel from
 // column c0 + p[bc] of the working matrix and the panel's own upper triangle below them
 __global__ void __launch_bounds__(256)
@@ -753,7 +759,9 @@ qrk_status qrk_bd_plan_create(qrk_handle h, const qrk_bd_layout* L, qrk_q_format
     if (p->uniform && p->r == 32 && p->c == 32 && B > 0 && !(std::getenv("QRK_PAIR_V2") && std::atoi(std::getenv("QRK_PAIR_V2")) == 0)) {
         p->p4_wgs = h->num_cus * 16;
         if (const char* e = std::getenv("QRK_PAIR_WGS")) { const int v = std::atoi(e); if (v > 0) p->p4_wgs = v; }
-        if (hipMalloc((void**)&p->d_p4_scratch, (size_t)qrk::bdqr_pair4_scratch_doubles(p->p4_wgs) * sizeof(double)) != hipSuccess) {
+        // (one working copy per workgroup that can exist: the launch has min(pairs, p4_wgs) of them)
+        const int64_t p4_live = std::min<int64_t>((B + 1) / 2, p->p4_wgs);
+        if (hipMalloc((void**)&p->d_p4_scratch, (size_t)qrk::bdqr_pair4_scratch_doubles((int)p4_live) * sizeof(double)) != hipSuccess) {
             qrk_bd_plan_destroy(p);
             return fail(h, QRK_STATUS_ALLOC_FAILED, "qrk_bd_plan_create: cannot allocate the scratch of the 32 x 32 kernel");
         }
@@ -1201,10 +1209,8 @@ qrk_status qrk_dense_factorize(qrk_dense_plan p, double* a, int64_t lda, double*
             QRK_HIP(h, qrk::launch_caqr_factorize(da, lda, p->rows, p->cols, p->d_t, h->stream, p->la_stream, p->la_urgent, p->la_factored,
                                                   p->la_pipe.urgent ? &p->la_pipe : nullptr));
             QRK_HIP(h, hipMemsetAsync(dhc, 0, (size_t)size * sizeof(double), h->stream));        // (no Householder coefficients in this format)
-            std::vector<int32_t> ident((size_t)p->cols);
-            for (int32_t j = 0; j < p->cols; ++j) ident[(size_t)j] = j;
-            QRK_HIP(h, hipMemcpyAsync(dp, ident.data(), (size_t)p->cols * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
-            QRK_HIP(h, hipStreamSynchronize(h->stream));                                         // (the host vector goes out of scope)
+            hipLaunchKernelGGL(qrk::identity_perm_kernel, dim3((unsigned)((p->cols + 255) / 256)), dim3(256), 0, h->stream, dp, p->cols);
+            QRK_HIP(h, hipGetLastError());                                                       // (no host vector, no synchronisation)
             p->ts_active = true;
             p->ts_owner = static_cast<const void*>(a);
             return QRK_STATUS_OK;
