@@ -148,3 +148,20 @@ def test_baseline_size_properties(qa, ctx, generation):
     assert ((Q @ R - AP).abs().amax(dim=(1, 2)) / A.abs().amax(dim=(1, 2))).max().item() < 1e-13
     d = torch.diagonal(R, dim1=1, dim2=2).abs()
     assert bool((d[:, :-1] >= d[:, 1:] * (1 - 1e-9)).all())          # pivoted: |R_kk| non-increasing
+
+
+@pytest.mark.parametrize("wgs,B", [(16, 3001), (7, 1200)])
+def test_many_rounds_per_workgroup(qa, ctx, monkeypatch, wgs, B):
+    """Few workgroups (QRK_PAIR_WGS): a workgroup runs more than the 32 rounds whose flags one word remembers -- several chunks of
+    rounds, each followed by the exact redo of its flagged tiles; tie tiles in every chunk."""
+    monkeypatch.delenv("QRK_PAIR_V2", raising=False)
+    monkeypatch.setenv("QRK_PAIR_WGS", str(wgs))
+    rng = np.random.default_rng(B)
+    a = rng.uniform(-1, 1, size=(B, 32, 32))
+    ties = rng.choice(B, size=B // 7, replace=False)
+    a[ties] = rng.choice([-1.0, 1.0], size=(len(ties), 32, 32))
+    tiles = np.ascontiguousarray(a).reshape(-1)
+    rows = cols = np.full(B, 32, np.int32)
+    qr = qa.BlockDiagonalSparseQR(qa.SparseBlockDiagonal.fromTiles(rows, cols, tiles), context=ctx)
+    _, ref = oracle_factorize(rows, cols, tiles)
+    check(qr, ref, rows, cols)
