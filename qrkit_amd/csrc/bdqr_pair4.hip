@@ -327,9 +327,15 @@ __device__ __noinline__ void redo_exact(int64_t t, double* lds, double* scratch,
                                         double* __restrict__ r_vals, int32_t* __restrict__ perm, double* __restrict__ hcoeffs)
 {
     exact::Shared sh;
-    (void)exact::carve_shared<64>(reinterpret_cast<unsigned char*>(lds), 32, 32, sh);
-    double* W = scratch;
-    double* q = scratch + 1024;
+    double* rest = exact::carve_shared<64>(reinterpret_cast<unsigned char*>(lds), 32, 32, sh);
+    // one of the two 8 KB arrays fits the wave's LDS next to the tables (QRK_P4_EXACT_LDS: 1 = the working copy, 2 = Q, 0 = neither).  10 000
+    // tiles of +-1 (every tile redone): 2.14 / 1.64 / 1.60 ms for 0 / 1 / 2; the first-generation kernel 1.59 (profiles/r04_p4_vs_k1.txt)
+#ifndef QRK_P4_EXACT_LDS
+#define QRK_P4_EXACT_LDS 2
+#endif
+    static_assert(2 * L_HALF * 8 >= 2048 + 8192, "tables + one 32 x 32 array in the wave's LDS");
+    double* W = QRK_P4_EXACT_LDS == 1 ? rest : scratch;
+    double* q = QRK_P4_EXACT_LDS == 2 ? rest : scratch + 1024;
     __syncthreads();
     exact::tile_qr<PIVOT, 64>(32, 32, tiles + t * 1024, W, q, sh);
     exact::tile_store<64>(32, 32, (int)(t * 32), W, q, sh, perm, hcoeffs, r_vals + t * 528, q_vals + t * 1024);
