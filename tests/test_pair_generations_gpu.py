@@ -165,3 +165,36 @@ def test_many_rounds_per_workgroup(qa, ctx, monkeypatch, wgs, B):
     qr = qa.BlockDiagonalSparseQR(qa.SparseBlockDiagonal.fromTiles(rows, cols, tiles), context=ctx)
     _, ref = oracle_factorize(rows, cols, tiles)
     check(qr, ref, rows, cols)
+
+
+def test_eight_byte_aligned_arrays(qa, ctx, generation):
+    """The C ABI takes any double-aligned arrays: tiles, Q and R that start 8 bytes off a 16-byte boundary (16-byte loads and stores of
+    the kernels at 8-byte alignment) give the same result as aligned ones."""
+    import ctypes as C
+    import torch
+    from qrkit_amd import _capi as capi
+    B = 257
+    lay = capi.BDLayout()
+    lay.num_blocks, lay.block_rows, lay.block_cols = B, 32, 32
+    lay.rows = lay.cols = None
+    lay.mat_rows = lay.mat_cols = B * 32
+    plan = C.c_void_p()
+    capi.check(capi.lib().qrk_bd_plan_create(ctx.handle, C.byref(lay), capi.BLOCK_DIAGONAL_Q, capi.COLPIV_HOUSEHOLDER, C.byref(plan)))
+    g = torch.Generator(device="cuda").manual_seed(17)
+    out = []
+    for shift in (0, 1):
+        tbuf = torch.zeros(B * 1024 + 2, device="cuda", dtype=torch.float64)
+        g.manual_seed(17)
+        tbuf[shift:shift + B * 1024] = torch.rand(B * 1024, device="cuda", dtype=torch.float64, generator=g) * 4.5 + 0.5
+        qbuf = torch.zeros(B * 1024 + 2, device="cuda", dtype=torch.float64)
+        rbuf = torch.zeros(B * 528 + 2, device="cuda", dtype=torch.float64)
+        pm = torch.zeros(B * 32, device="cuda", dtype=torch.int32)
+        capi.check(capi.lib().qrk_bd_factorize(plan, tbuf.data_ptr() + 8 * shift, qbuf.data_ptr() + 8 * shift, rbuf.data_ptr() + 8 * shift,
+                                               pm.data_ptr(), None, capi.MEM_DEVICE))
+        torch.cuda.synchronize()
+        assert qbuf[:shift].abs().sum().item() == 0.0 and qbuf[shift + B * 1024:].abs().sum().item() == 0.0     # nothing outside
+        assert rbuf[:shift].abs().sum().item() == 0.0 and rbuf[shift + B * 528:].abs().sum().item() == 0.0
+        out.append((qbuf[shift:shift + B * 1024].clone(), rbuf[shift:shift + B * 528].clone(), pm.clone()))
+    capi.lib().qrk_bd_plan_destroy(plan)
+    for x, y in zip(out[0], out[1]):
+        assert torch.equal(x, y)
