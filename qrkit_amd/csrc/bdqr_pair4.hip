@@ -447,7 +447,11 @@ bdqr_pair4_kernel(int64_t num_tiles, const double* __restrict__ tiles, double* _
                 st.nu2 = s0 + s1;
                 st.thr = st.nu2 * THR_HI;
             }
+#if defined(QRK_P4_ABL) && (QRK_P4_ABL & 2)     // (timing ablation: every second pair of a wave skips steps 16..31 and back steps 31..16)
+#define QRK_P4_STEP(K) if ((K) < 16 || !(round & 1)) step<K, PIVOT, HC>(a, hl, st);
+#else
 #define QRK_P4_STEP(K) step<K, PIVOT, HC>(a, hl, st);
+#endif
             QRK_P4_0_31(QRK_P4_STEP)
 #undef QRK_P4_STEP
             // ---- R: lane j holds column p = kstep of R in rows 0 .. p; the packed CSC value order of m_R (BlockDiagonalSparseQR.h:475-479)
@@ -489,7 +493,11 @@ bdqr_pair4_kernel(int64_t num_tiles, const double* __restrict__ tiles, double* _
             double q[WR];
 #pragma unroll
             for (int i = 0; i < WR; ++i) q[i] = (i == jj) ? 1.0 : 0.0;
+#if defined(QRK_P4_ABL) && (QRK_P4_ABL & 2)
+#define QRK_P4_BACK(K) if ((K) < 16 || !(round & 1)) back_step<K>(q, hl2, ln);
+#else
 #define QRK_P4_BACK(K) back_step<K>(q, hl2, ln);
+#endif
             QRK_P4_31_0(QRK_P4_BACK)
 #undef QRK_P4_BACK
             // row-major rows of Q_i are the CSR value order of m_Q in both FullQ ([U|N] split, :455-471) and BlockDiagonalQ (:480-492)
