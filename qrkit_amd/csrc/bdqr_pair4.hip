@@ -77,6 +77,12 @@ static_assert(WR * STAGE_LD <= 2 * L_HALF, "the staging buffer fits the wave's L
 #define QRK_P4_STOREQ(v, p) (*(p) = (v))
 #endif
 
+#ifndef QRK_P4_EXACT_LDS
+#define QRK_P4_EXACT_LDS 2
+#endif
+// doubles of global scratch per workgroup: what the exact routine does not keep in LDS (its working copy; with QRK_P4_EXACT_LDS != 2 also Q)
+constexpr int EXACT_SCRATCH = QRK_P4_EXACT_LDS == 2 ? 1024 : 2048;
+
 #define QRK_P4_0_31(M)                                                                           \
     M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9) M(10) M(11) M(12) M(13) M(14) M(15) M(16)  \
     M(17) M(18) M(19) M(20) M(21) M(22) M(23) M(24) M(25) M(26) M(27) M(28) M(29) M(30) M(31)
@@ -330,9 +336,6 @@ __device__ __noinline__ void redo_exact(int64_t t, double* lds, double* scratch,
     double* rest = exact::carve_shared<64>(reinterpret_cast<unsigned char*>(lds), 32, 32, sh);
     // one of the two 8 KB arrays fits the wave's LDS next to the tables (QRK_P4_EXACT_LDS: 1 = the working copy, 2 = Q, 0 = neither).  10 000
     // tiles of +-1 (every tile redone): 2.14 / 1.64 / 1.60 ms for 0 / 1 / 2; the first-generation kernel 1.59 (profiles/r04_p4_vs_k1.txt)
-#ifndef QRK_P4_EXACT_LDS
-#define QRK_P4_EXACT_LDS 2
-#endif
     static_assert(2 * L_HALF * 8 >= 2048 + 8192, "tables + one 32 x 32 array in the wave's LDS");
     double* W = QRK_P4_EXACT_LDS == 1 ? rest : scratch;
     double* q = QRK_P4_EXACT_LDS == 2 ? rest : scratch + 1024;
@@ -345,7 +348,7 @@ __device__ __noinline__ void redo_exact(int64_t t, double* lds, double* scratch,
 }  // namespace p4
 
 // PIVOT: ColPivHouseholderQR (else HouseholderQR).  HC: also emit the Householder coefficients.  One wave per workgroup, persistent over
-// the pairs blockIdx.x, blockIdx.x + gridDim.x, ..; scratch: 2048 doubles per workgroup (the exact path's working copy).
+// the pairs blockIdx.x, blockIdx.x + gridDim.x, ..; scratch: p4::EXACT_SCRATCH doubles per workgroup (the exact path's working copy).
 template <bool PIVOT, bool HC>
 __global__ void __launch_bounds__(64, 4)
 bdqr_pair4_kernel(int64_t num_tiles, const double* __restrict__ tiles, double* __restrict__ q_vals, double* __restrict__ r_vals,
@@ -517,7 +520,7 @@ bdqr_pair4_kernel(int64_t num_tiles, const double* __restrict__ tiles, double* _
     {
         const unsigned f0 = (unsigned)__builtin_amdgcn_readlane((int)flagbits, 0), f1 = (unsigned)__builtin_amdgcn_readlane((int)flagbits, 32);
         if (__builtin_expect((f0 | f1) != 0u, 0)) {
-            double* sc = scratch + (int64_t)blockIdx.x * 2048;
+            double* sc = scratch + (int64_t)blockIdx.x * EXACT_SCRATCH;
             for (int h2 = 0; h2 < 2; ++h2) {
                 unsigned m = h2 ? f1 : f0;
                 while (m) {
@@ -532,7 +535,7 @@ bdqr_pair4_kernel(int64_t num_tiles, const double* __restrict__ tiles, double* _
     }
 }
 
-int64_t bdqr_pair4_scratch_doubles(int num_wg) { return (int64_t)num_wg * 2048; }
+int64_t bdqr_pair4_scratch_doubles(int num_wg) { return (int64_t)num_wg * p4::EXACT_SCRATCH; }
 
 // Uniform 32 x 32 batches (any alignment).  num_wg: resident wave slots (16 per CU).
 hipError_t launch_bdqr_pair4(int64_t num_tiles, int pivoting, const double* tiles, double* q_vals, double* r_vals, int32_t* perm,
