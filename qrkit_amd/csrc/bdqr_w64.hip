@@ -361,14 +361,18 @@ __device__ __forceinline__ void back_step(double (&q)[WR], const double* lds, co
 
 // PIVOT: ColPivHouseholderQR (else HouseholderQR).  One wave per workgroup; the workgroups take their tiles through `queue`
 // (largest first: tile_ids is sorted by size).
-template <bool PIVOT>
-__global__ void __launch_bounds__(64, 2)
+// WPS: waves per SIMD the instantiation is compiled for.  The reflectors of a tile with r rows occupy the TAIL of the LDS layout
+// (cb(64 - r) ..): the launch allocates only what its tallest tile needs (lds_shift = the unused head, in doubles), and tiles of up to
+// 52 rows leave room for twelve waves per CU -- three per SIMD at the kernel's 167 registers -- instead of eight.
+template <bool PIVOT, int WPS>
+__global__ void __launch_bounds__(64, WPS)
 bdqr_w64_kernel(WaveBatch nb, const double* __restrict__ tiles, double* __restrict__ q_vals, double* __restrict__ r_vals,
                 int32_t* __restrict__ perm, double* __restrict__ hcoeffs, int32_t* __restrict__ redo_count,
-                int32_t* __restrict__ redo_ids, int32_t* __restrict__ queue)
+                int32_t* __restrict__ redo_ids, int32_t* __restrict__ queue, int lds_shift)
 {
     using namespace w64;
-    __shared__ __attribute__((aligned(16))) double lds[L_TOTAL];
+    extern __shared__ __attribute__((aligned(16))) double lds_dyn[];
+    double* const lds = lds_dyn - lds_shift;
 
     for (int64_t t = blockIdx.x; t < nb.num_tiles;) {
         const int gidx = nb.tile_ids ? nb.tile_ids[t] : (int)t;
@@ -484,18 +488,28 @@ bdqr_w64_kernel(WaveBatch nb, const double* __restrict__ tiles, double* __restri
 bool bdqr_w64_supported(int rows, int cols) { return rows >= cols && rows <= w64::WR && rows > 32; }
 
 // Tiles with 32 < rows <= 64, cols <= rows.  queue: one int32 (zeroed here) through which the workgroups take their next tile.
+// max_rows: the tallest tile of the launch (33 .. 64); num_cus: workgroups are 8 or 12 per CU by what the LDS of the launch allows.
 hipError_t launch_bdqr_w64(const WaveBatch& nb, const double* tiles, double* q_vals, double* r_vals, int32_t* perm, double* hcoeffs,
-                           int num_wg, int32_t* redo_count, int32_t* redo_ids, int32_t* queue, hipStream_t stream)
+                           int num_cus, int max_rows, int32_t* redo_count, int32_t* redo_ids, int32_t* queue, hipStream_t stream)
 {
     if (nb.num_tiles <= 0) return hipSuccess;
+    if (max_rows < 33 || max_rows > w64::WR) return hipErrorInvalidValue;
     if (hipError_t e = hipMemsetAsync(queue, 0, sizeof(int32_t), stream)) return e;
-    const int64_t want = nb.num_tiles < (int64_t)num_wg ? nb.num_tiles : (int64_t)num_wg;
-    if (nb.pivoting)
-        hipLaunchKernelGGL(bdqr_w64_kernel<true>, dim3((unsigned)want), dim3(64), 0, stream, nb, tiles, q_vals, r_vals, perm, hcoeffs,
-                           redo_count, redo_ids, queue);
-    else
-        hipLaunchKernelGGL(bdqr_w64_kernel<false>, dim3((unsigned)want), dim3(64), 0, stream, nb, tiles, q_vals, r_vals, perm, hcoeffs,
-                           redo_count, redo_ids, queue);
+    // the reflector of padded row KP starts at cb(KP) and load_chunks reads up to 15 doubles below the column it fetches
+    int shift = w64::cb(w64::WR - max_rows) - 16;
+    if (shift < 0) shift = 0;
+    const size_t lds_bytes = (size_t)(w64::L_TOTAL - shift) * sizeof(double);
+    static const bool three = !(std::getenv("QRK_W64_WPS") && std::atoi(std::getenv("QRK_W64_WPS")) == 2);
+    int per_cu = (int)((size_t)(160 * 1024) / lds_bytes);     // waves of one CU by LDS: 8 (64 rows) .. 12 (the register file's limit)
+    per_cu = !three ? 8 : (per_cu > 12 ? 12 : (per_cu < 8 ? 8 : per_cu));
+    const bool wps3 = per_cu > 8;
+    const int64_t num_wg = (int64_t)num_cus * per_cu;
+    const int64_t want = nb.num_tiles < num_wg ? nb.num_tiles : num_wg;
+#define QRK_W64_LAUNCH(P, W) hipLaunchKernelGGL((bdqr_w64_kernel<P, W>), dim3((unsigned)want), dim3(64), lds_bytes, stream, nb, tiles, q_vals, \
+                                                r_vals, perm, hcoeffs, redo_count, redo_ids, queue, shift)
+    if (nb.pivoting) { if (wps3) QRK_W64_LAUNCH(true, 3); else QRK_W64_LAUNCH(true, 2); }
+    else { if (wps3) QRK_W64_LAUNCH(false, 3); else QRK_W64_LAUNCH(false, 2); }
+#undef QRK_W64_LAUNCH
     return hipGetLastError();
 }
 

@@ -80,6 +80,7 @@ struct qrk_bd_plan_s {
     int64_t n_col = 0;
     // tiles with 32 < rows <= 64 (cols <= rows): one wavefront each, on chip (bdqr_w64.hip); mixed batches: largest first
     int32_t* d_w64_ids = nullptr;
+    int32_t w64_maxr = 0;          // tallest of them (sizes the LDS of the launch)
     int64_t n_w64 = 0;
     bool w64_uniform = false;            // a uniform batch of such tiles
     double* d_col_workspace = nullptr;   // one part per class
@@ -369,7 +370,7 @@ qrk_status enqueue_factorize(qrk_bd_plan_s* p, const double* tiles, double* q, d
                             ((reinterpret_cast<uintptr_t>(tiles) | reinterpret_cast<uintptr_t>(q) |
                               reinterpret_cast<uintptr_t>(r)) & 15u) == 0;
         if (p->w64_uniform)
-            QRK_HIP(h, qrk::launch_bdqr_w64(nb, tiles, q, r, perm, hc, h->num_cus * 8, redo_cnt, redo_ids, p->d_redo + 2 + p->B + 3, h->stream));
+            QRK_HIP(h, qrk::launch_bdqr_w64(nb, tiles, q, r, perm, hc, h->num_cus, p->r, redo_cnt, redo_ids, p->d_redo + 2 + p->B + 3, h->stream));
         else if (p->max_dim > 32 && p->max_dim <= QRK_COL_MAX_DIM) {
             const auto& k = p->col_cls[0];
             QRK_HIP(h, launch_col_class(k, nb, tiles, q, r, perm, hc, p->d_col_workspace, redo_cnt, redo_ids, p->d_redo + 2 + p->B, h->stream));
@@ -398,7 +399,7 @@ qrk_status enqueue_factorize(qrk_bd_plan_s* p, const double* tiles, double* q, d
         if (p->n_w64 > 0) {
             qrk::WaveBatch wb = nb;
             wb.num_tiles = p->n_w64; wb.tile_ids = p->d_w64_ids;
-            QRK_HIP(h, qrk::launch_bdqr_w64(wb, tiles, q, r, perm, hc, h->num_cus * 8, redo_cnt, redo_ids, p->d_redo + 2 + p->B + 3, h->stream));
+            QRK_HIP(h, qrk::launch_bdqr_w64(wb, tiles, q, r, perm, hc, h->num_cus, p->w64_maxr, redo_cnt, redo_ids, p->d_redo + 2 + p->B + 3, h->stream));
         }
         // the size classes are independent of each other and of the small tiles above: each on its own side stream
         // (forked after what is already queued on the caller's stream, joined back below), so that the tail of one
@@ -657,7 +658,7 @@ qrk_status qrk_bd_plan_create(qrk_handle h, const qrk_bd_layout* L, qrk_q_format
             const int32_t md = r > c ? r : c;
             if (md > p->max_dim) p->max_dim = md;
             if (md <= 32) wave_ids.push_back((int32_t)i);
-            else if (use_w64 && qrk::bdqr_w64_supported(r, c)) w64_ids.push_back((int32_t)i);
+            else if (use_w64 && qrk::bdqr_w64_supported(r, c)) { w64_ids.push_back((int32_t)i); p->w64_maxr = std::max(p->w64_maxr, r); }
             else if (md <= QRK_COL_MAX_DIM && r >= c) {
                 // classes: up to 64 columns (one wave per tile, many workgroups per CU) and the rest (bdqr_col.hip: own instantiation
                 // and LDS layout each)

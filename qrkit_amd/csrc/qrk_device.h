@@ -69,7 +69,7 @@ hipError_t launch_bdqr_reg(const WaveBatch& nb, const double* tiles, double* q_v
 // Tiles with 32 < rows <= 64, cols <= rows: one wavefront per tile, registers + LDS, no workspace (bdqr_w64.hip).
 bool bdqr_w64_supported(int rows, int cols);
 hipError_t launch_bdqr_w64(const WaveBatch& nb, const double* tiles, double* q_vals, double* r_vals, int32_t* perm, double* hcoeffs,
-                           int num_wg, int32_t* redo_count, int32_t* redo_ids, int32_t* queue, hipStream_t stream);
+                           int num_cus, int max_rows, int32_t* redo_count, int32_t* redo_ids, int32_t* queue, hipStream_t stream);
 int64_t bdqr_reg_ws_doubles();      // workspace of one workgroup of launch_bdqr_reg
 bool bdqr_reg_small(int max_rows, int max_cols);   // the launch runs the 4-wave instantiation: two workgroups per CU
 int bdqr_col_w_lds(int64_t max_rc, int64_t max_rc_fitting);
