@@ -46,6 +46,13 @@ SHAPES = [
     (9, 64, 33),
     (600, 64, 64),    # the full frame; more tiles than the launch has waves: the queue
     (9, 50, 32),      # cols <= 32 < rows
+    # more tiles than resident waves at the heights where the LDS of the launch changes the workgroups per CU (12 up to 52 rows,
+    # 11, 10, 9, then 8 from 61 rows on): every wave slot of a CU in use, the queue behind them
+    (3200, 33, 33),
+    (3200, 52, 52),
+    (3000, 53, 40),
+    (2800, 57, 57),
+    (2600, 61, 30),
 ]
 
 
