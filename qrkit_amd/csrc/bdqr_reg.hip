@@ -194,7 +194,7 @@ bdqr_reg_kernel(WaveBatch nb, const double* __restrict__ tiles, double* __restri
     int* flags = reinterpret_cast<int*>(cands + NW);       // [4]
     int* col_of_pos = flags + 4;                           // [PR]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int h = lane >> 5, j = wave * 32 + (lane & 31), l16 = lane & 15;
+    const int h = lane >> 5, j = wave * 32 + (lane & 31);
 
     for (int64_t t = blockIdx.x; t < nb.num_tiles;) {
         const int gidx = nb.tile_ids ? nb.tile_ids[t] : (int)t;
