@@ -358,6 +358,7 @@ bdqr_pair4_kernel(int64_t num_tiles, const double* __restrict__ tiles, double* _
     __shared__ __attribute__((aligned(16))) double lds[2 * L_HALF];
     const int64_t npairs = (num_tiles + 1) / 2;
     constexpr int CHUNK = 32;                // rounds per chunk: one 32-bit word per half remembers the flagged rounds
+    const bool steady = npairs >= 3 * (int64_t)gridDim.x;
 #ifndef QRK_P4_PRIO
 #define QRK_P4_PRIO 0
 #endif
@@ -389,6 +390,11 @@ bdqr_pair4_kernel(int64_t num_tiles, const double* __restrict__ tiles, double* _
         {
             // =============== phase 1: A -> R ===============
             QRK_P4_STAMP_AT(0);
+            // steady state (three rounds or more per wave): the latency chain of phase 1 goes ahead of the FMA stream of phase 2 on the
+            // SIMD: 100 000 tiles 621 -> 599 us; at BASELINE's 10 000 tiles (1.2 rounds) the same costs 10 % (the first waves' phase 2
+            // is starved and their second pairs start late), so the launch decides.  QRK_P4_PRIO 6 / 7: always / the reverse (measured)
+            if ((QRK_P4_PRIO == 0 && steady) || QRK_P4_PRIO == 6) __builtin_amdgcn_s_setprio(2);
+            if (QRK_P4_PRIO == 7) __builtin_amdgcn_s_setprio(0);
             double a[WR];
             {
                 // both tiles of the pair, one after the other through the wave's LDS: every load instruction takes 1 KB of a tile (lane l
@@ -489,6 +495,8 @@ bdqr_pair4_kernel(int64_t num_tiles, const double* __restrict__ tiles, double* _
         {
             // =============== phase 2: Q = H_0 ... H_31, backward ===============
             QRK_P4_STAMP_AT(2);
+            if ((QRK_P4_PRIO == 0 && steady) || QRK_P4_PRIO == 6) __builtin_amdgcn_s_setprio(0);
+            if (QRK_P4_PRIO == 7) __builtin_amdgcn_s_setprio(2);
             int ln = threadIdx.x;
             asm volatile("" : "+v"(ln));
             const int jj = ln & 31;
