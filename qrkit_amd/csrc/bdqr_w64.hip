@@ -401,6 +401,14 @@ bdqr_w64_kernel(WaveBatch nb, const double* __restrict__ tiles, double* __restri
 #endif
         {
             // =============== phase 1: A -> R ===============
+            // wave priority by phase (s_setprio): the FMA stream of phase 2 ahead of the latency chain of phase 1 desynchronises the waves of
+            // a SIMD: 56 x 56 20.9 -> 22.0 M tiles/s, 64 x 64 16.3 -> 17.0 M, smaller tiles and small batches unchanged; the reverse (1)
+            // gains as much at 56 / 64 rows and loses 15 % at 33 x 33 (profiles/r04_w64_probe.txt)
+#ifndef QRK_W64_PRIO
+#define QRK_W64_PRIO 2
+#endif
+            if (QRK_W64_PRIO == 1) __builtin_amdgcn_s_setprio(2);      // (1: the chain of phase 1 ahead of the FMA stream of phase 2; 2: the reverse)
+            if (QRK_W64_PRIO == 2) __builtin_amdgcn_s_setprio(0);
             double a[WR];
             const bool isA = lane < c;
             st.live = isA;
@@ -453,6 +461,8 @@ bdqr_w64_kernel(WaveBatch nb, const double* __restrict__ tiles, double* __restri
         W64_TICK(11);
         {
             // =============== phase 2: Q = H_0 ... H_{c-1}, backward ===============
+            if (QRK_W64_PRIO == 1) __builtin_amdgcn_s_setprio(0);
+            if (QRK_W64_PRIO == 2) __builtin_amdgcn_s_setprio(2);
             int ln = threadIdx.x;
             asm volatile("" : "+v"(ln));
             double q[WR];
