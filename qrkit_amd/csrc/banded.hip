@@ -233,20 +233,35 @@ struct BBPipe {
     const double* prev;        // storage of the previous panel (row-major, prev_n columns), or null for the first panel
     const int* prev_done;      // its rows-final word
     int* my_done;              // this panel's
+    int* abortw;               // the chain's abort word (done[num_panels]): set by the workgroup whose wait ran out, seen by every waiter
     int prev_n, lo_from, lo_rows, lo_cols, lo_stride;
     int copied;                // carry rows already taken over
+    unsigned spin_limit;       // polls of a rows-final word before the chain is given up
+    int aborted;               // this workgroup leaves (its own wait ran out, or a partner's did)
 };
-__device__ __forceinline__ void bb_pipe_wait(const int* word, int target)
+// Waits until `word` reaches `target`.  The workgroups of the chain are not guaranteed to be co-resident (three 160 KB workgroups of
+// an ordinary launch), so the wait is bounded: when it runs out the workgroup raises the chain's abort word and leaves, every other
+// waiter sees the word and leaves too, and the host (launch_bbs_chain's caller, qrk_bbs_factorize) reads the word at its
+// synchronisation point and runs the chain again on ONE workgroup.  Returns false (to every thread) when the chain is aborted.
+__device__ __forceinline__ bool bb_pipe_wait(BBPipe* pipe, const int* word, int target)
 {
     if (threadIdx.x == 0) {
         unsigned spins = 0;
+        int bad = 0;
         while (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            if (__hip_atomic_load(pipe->abortw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { bad = 1; break; }
+            if (++spins > pipe->spin_limit) {
+                __hip_atomic_store(pipe->abortw, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                bad = 1;
+                break;
+            }
             __builtin_amdgcn_s_sleep(2);
-            if (++spins > (1u << 27)) break;       // (bounded: a lost partner must not hang the GPU; the result is wrong then, and the tests say so)
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        if (bad) pipe->aborted = 1;
     }
     __syncthreads();
+    return pipe->aborted == 0;
 }
 __device__ __forceinline__ void bb_pipe_publish(int* word, int rows_done)
 {
@@ -318,7 +333,7 @@ __device__ __attribute__((noinline)) void bb_panel_qr(double* __restrict__ W, co
             int need = (mtop + pipe->lo_stride - 1) / pipe->lo_stride;
             if (need > pipe->lo_rows) need = pipe->lo_rows;
             if (need > pipe->copied) {
-                bb_pipe_wait(pipe->prev_done, pipe->lo_from + need);
+                if (!bb_pipe_wait(pipe, pipe->prev_done, pipe->lo_from + need)) return;       // (uniform: the chain is given up)
                 const int c0 = pipe->copied, lc = pipe->lo_cols;
                 for (int e = tid; e < (need - c0) * lc; e += BC_THREADS) {
                     const int i = c0 + e / lc, j = e % lc;
@@ -644,7 +659,8 @@ bb_chain2_kernel(const BBPanel* __restrict__ panels, int num_panels, const int32
                  const int32_t* __restrict__ pcol, const int64_t* __restrict__ pmap, const double* __restrict__ vals,
                  double* __restrict__ lo, double* __restrict__ y_vals,
                  double* __restrict__ t_vals, double* __restrict__ r_stage, int max_act_rows, int max_ncols,
-                 int uni_doubles, const int* __restrict__ rlim_first, const int* __restrict__ rlim_rest, int* __restrict__ done)
+                 int uni_doubles, const int* __restrict__ rlim_first, const int* __restrict__ rlim_rest, int* __restrict__ done,
+                 unsigned spin_limit)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double* hc = smem;                         // [BC_CW] hCoeffs of the panel
@@ -684,6 +700,9 @@ bb_chain2_kernel(const BBPanel* __restrict__ panels, int num_panels, const int32
             s_pipe.prev = has ? y_vals + panels[pi - 1].y_off : nullptr;
             s_pipe.prev_done = has ? done + pi - 1 : nullptr;
             s_pipe.my_done = done + pi;
+            s_pipe.abortw = done + num_panels;
+            s_pipe.spin_limit = spin_limit;
+            if (pi == (int)blockIdx.x) s_pipe.aborted = 0;
             s_pipe.prev_n = has ? panels[pi - 1].ncols : 0;
             s_pipe.lo_from = p.lo_from; s_pipe.lo_rows = p.lo_rows; s_pipe.lo_cols = p.lo_cols; s_pipe.lo_stride = p.lo_stride;
             s_pipe.copied = 0;
@@ -719,6 +738,7 @@ bb_chain2_kernel(const BBPanel* __restrict__ panels, int num_panels, const int32
 #endif
         }
         __syncthreads();
+        if (piped && s_pipe.aborted) break;            // (uniform: the chain was given up -- bb_pipe_wait; the host runs it again on one workgroup)
 
         BB_TICK(1);
         // ---- rows of R solved by this panel: V = triu(packed QR), explicit zeros kept (:484-491).  r_stage is
@@ -1284,7 +1304,7 @@ hipError_t launch_bb_chain(const BBPanel* panels, int num_panels, const int32_t*
                            (size_t)(max_act_rows + 2) * sizeof(int), stream, panels, prowptr, pcol, pmap, vals, y_vals);
         hipLaunchKernelGGL(bb_chain2_kernel, dim3(1), dim3(BC_THREADS), smem2, stream, panels, num_panels, prowptr, pcol, pmap,
                            vals, lo, y_vals, t_vals, r_stage, max_act_rows, max_ncols, uni_doubles, (const int*)nullptr, (const int*)nullptr,
-                           (int*)nullptr);
+                           (int*)nullptr, 0u);
         const size_t smem_t = bb_t_smem(max_ncols, &t_in_lds);
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(bb_t_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)smem_t);
@@ -1346,10 +1366,12 @@ bbs_scatter_kernel(const BBPanel* __restrict__ panels, const double* __restrict_
     }
 }
 
-// done: num_panels ints (the rows-final words of the pipelined chain; zeroed here), or null: one workgroup walks the strips
+// done: num_panels + 1 ints (the rows-final words of the pipelined chain and its abort word; zeroed here), or null: one workgroup
+// walks the strips.  single != 0: one workgroup whatever QRK_BBS_PIPE says (the caller's second run after an aborted chain).
+// *piped_out: the chain ran on more than one workgroup -- the caller must read done[num_panels] once the stream has drained.
 hipError_t launch_bbs_chain(const BBPanel* panels, int num_panels, const double* r_packed, int64_t r_stride, int n, int lo,
                             int max_act_rows, double* lo_buf, double* y_vals, double* t_vals, double* r_stage,
-                            const int* rlim_first, const int* rlim_rest, int* done, hipStream_t stream)
+                            const int* rlim_first, const int* rlim_rest, int* done, int single, int* piped_out, hipStream_t stream)
 {
     int t_in_lds = 0, uni_doubles = 0;
     const size_t smem2 = bb_chain2_smem(max_act_rows, &uni_doubles);
@@ -1362,11 +1384,16 @@ hipError_t launch_bbs_chain(const BBPanel* panels, int num_panels, const double*
     int G = 3;
     if (const char* e2 = std::getenv("QRK_BBS_PIPE")) { const int v = std::atoi(e2); if (v >= 1 && v <= 16) G = v; }
     if (G > num_panels) G = num_panels;
-    if (!done || lo <= 0) G = 1;
-    if (G > 1) { e = hipMemsetAsync(done, 0, (size_t)num_panels * sizeof(int), stream); if (e != hipSuccess) return e; }
+    if (!done || lo <= 0 || single) G = 1;
+    // polls of a rows-final word before a workgroup gives the chain up (about a microsecond each: seconds, not minutes;
+    // QRK_BBS_PIPE_SPINS=0 makes the first unsatisfied wait abort -- the test of the fall-back)
+    unsigned spin_limit = 1u << 21;
+    if (const char* e3 = std::getenv("QRK_BBS_PIPE_SPINS")) spin_limit = (unsigned)std::strtoul(e3, nullptr, 10);
+    if (G > 1) { e = hipMemsetAsync(done, 0, (size_t)(num_panels + 1) * sizeof(int), stream); if (e != hipSuccess) return e; }
+    if (piped_out) *piped_out = G > 1;
     hipLaunchKernelGGL(bb_chain2_kernel, dim3((unsigned)G), dim3(BC_THREADS), smem2, stream, panels, num_panels, (const int32_t*)nullptr,
                        (const int32_t*)nullptr, (const int64_t*)nullptr, (const double*)nullptr, lo_buf, y_vals, t_vals, r_stage,
-                       max_act_rows, n, uni_doubles, rlim_first, rlim_rest, G > 1 ? done : (int*)nullptr);
+                       max_act_rows, n, uni_doubles, rlim_first, rlim_rest, G > 1 ? done : (int*)nullptr, spin_limit);
     const size_t smem_t = bb_t_smem(n, &t_in_lds);
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(bb_t_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_t);
     if (e != hipSuccess) return e;

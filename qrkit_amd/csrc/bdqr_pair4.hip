@@ -80,6 +80,46 @@ static_assert(WR * STAGE_LD <= 2 * L_HALF, "the staging buffer fits the wave's L
 #ifndef QRK_P4_EXACT_LDS
 #define QRK_P4_EXACT_LDS 2
 #endif
+// round 5 experiments (profiles/r05_k1_*.txt)
+#ifndef QRK_P4_PRIO
+#define QRK_P4_PRIO 0
+#endif
+#ifndef QRK_P4_T1
+#define QRK_P4_T1 11
+#endif
+#ifndef QRK_P4_T2
+#define QRK_P4_T2 22
+#endif
+#ifndef QRK_P4_PH2
+#define QRK_P4_PH2 0
+#endif
+#ifndef QRK_P4_DOT4
+#define QRK_P4_DOT4 0
+#endif
+#ifndef QRK_P4_RCPSEED
+#define QRK_P4_RCPSEED 0
+#endif
+#ifndef QRK_P4_TSQB
+#define QRK_P4_TSQB 0
+#endif
+#ifndef QRK_P4_PREFETCH
+#define QRK_P4_PREFETCH 0
+#endif
+#ifndef QRK_P4_DIRECT      // 1: every lane loads its column straight from the tile (16-byte loads, 256 bytes between lanes): no staging through LDS
+#define QRK_P4_DIRECT 0
+#endif
+#ifndef QRK_P4_S2REG       // 1: phase 2 takes s_K and 1 / (beta (beta - x0)) from registers (lane l holds entries l & 15 and 16 + (l & 15)) through DPP
+#define QRK_P4_S2REG 0
+#endif
+#ifndef QRK_P4_RD1         // 1: the two 16-row chunks of a column by two ds_read_b64 instead of one ds_read2_b64 (tools/ubench8.hip: 3.7 against 13.6 ns)
+#define QRK_P4_RD1 0
+#endif
+#ifndef QRK_P4_PUB64       // 1: the pivot lane publishes its column with 8-byte stores (tools/ubench8.hip: 10.3 ns each against 22.5 for 16 bytes)
+#define QRK_P4_PUB64 0
+#endif
+#ifndef QRK_P4_DIET        // 1: decision masks straight from v_cmp (no bool round trip); R(K, K) is the updated entry itself (= beta to rounding)
+#define QRK_P4_DIET 0
+#endif
 // doubles of global scratch per workgroup: what the exact routine does not keep in LDS (its working copy; with QRK_P4_EXACT_LDS != 2 also Q)
 constexpr int EXACT_SCRATCH = QRK_P4_EXACT_LDS == 2 ? 1024 : 2048;
 
@@ -138,6 +178,8 @@ __device__ __forceinline__ double bpermute_f64(int byte_addr, double v)
     return __hiloint2double(hi, lo);
 }
 
+typedef __attribute__((address_space(3))) double lds_f64;      // (volatile accesses through a generic pointer would become flat_*)
+
 struct Lane {
     int lane, j, half;
     unsigned long long livemask;   // (wave-uniform) the lanes whose column of A is not yet chosen
@@ -146,6 +188,8 @@ struct Lane {
     double nu2;       // m_colNormsUpdated^2 (a chosen column carries a negative value)
     double thr;       // sqrt(eps) (1 + 2^-12) m_colNormsDirect^2
     double a2;        // |A|^2 of this half's tile: squared norm of its first pivot column (scale of the decision margins)
+    bool lpf;         // (wave-uniform) priorities by progress are in use in this launch (not in the steady state)
+    bool notlast;     // (wave-uniform) the wave has a further pair after this one: its chain is the critical path of a short launch
 };
 
 // The elements of the published column that this lane broadcasts: xc[m] = element 16 m + (lane & 15) of the half's column
@@ -155,7 +199,7 @@ __device__ __forceinline__ void load_chunks(const double* hl, int lane, double (
     constexpr int M0 = (K + 1) >> 4;
     const double* vcol = hl + L_V + cb(K) - (K & ~1) + (lane & 15);
 #pragma unroll
-    for (int m = M0; m < 2; ++m) xc[m] = vcol[16 * m];
+    for (int m = M0; m < 2; ++m) xc[m] = QRK_P4_RD1 ? *(const volatile lds_f64*)(vcol + 16 * m) : vcol[16 * m];
 }
 
 // One step of ColPivHouseholderQR::computeInPlace / HouseholderQR on both tiles of the wave (see bdqr_pair.hip for the arithmetic: squared
@@ -165,6 +209,18 @@ __device__ __forceinline__ void step(double (&a)[WR], double* hl /* this half's 
 {
     const int lane = st.lane;
     if (!PIVOT) __builtin_amdgcn_sched_barrier(0);          // (no branch separates the steps here: keep hipcc from interleaving them)
+    // least progress first (short launches, QRK_P4_PRIO 8): the last pair of a wave drops a class after steps T1 and T2, so the waves of
+    // a SIMD end together instead of oldest first; a pair that is not the wave's last stays in the top class (two chains back to back
+    // are the critical path).  9: the class is 3 - K / 8 for every pair; 10: the same, but a pair that is not the last stays at 3
+    if (QRK_P4_PRIO == 8 && st.lpf && !st.notlast) {
+        if (K == QRK_P4_T1) __builtin_amdgcn_s_setprio(1);
+        if (K == QRK_P4_T2) __builtin_amdgcn_s_setprio(0);
+    }
+    if ((QRK_P4_PRIO == 9 || (QRK_P4_PRIO == 10 && !st.notlast)) && st.lpf) {
+        if (K == 8) __builtin_amdgcn_s_setprio(2);
+        if (K == 16) __builtin_amdgcn_s_setprio(1);
+        if (K == 24) __builtin_amdgcn_s_setprio(0);
+    }
     // ---- 1. pivot of each half
     bool ispiv;
     unsigned long long pm;                                  // ballot of ispiv
@@ -215,6 +271,8 @@ __device__ __forceinline__ void step(double (&a)[WR], double* hl /* this half's 
 #pragma unroll
 #ifdef QRK_P4_ABL      // (timing ablation only: results are wrong) 1: publish 16 bytes instead of the column
         for (int i = K & ~1; i < ((QRK_P4_ABL & 1) ? (K & ~1) + 2 : WR); i += 2) *reinterpret_cast<double2*>(&vcol[i]) = make_double2(a[i], a[i + 1]);
+#elif QRK_P4_PUB64
+        for (int i = K; i < WR; ++i) *(volatile lds_f64*)(&vcol[i]) = a[i];
 #else
         for (int i = K & ~1; i < WR; i += 2) *reinterpret_cast<double2*>(&vcol[i]) = make_double2(a[i], a[i + 1]);
 #endif
@@ -233,19 +291,42 @@ __device__ __forceinline__ void step(double (&a)[WR], double* hl /* this half's 
     double d0 = 0.0, d1 = 0.0;
 #pragma unroll
     for (int m = M0; m < 2; ++m) asm volatile("s_nop 1" : "+v"(xc[m]));      // (VALU write -> DPP read hazard, hidden from hipcc by the asm)
+#if QRK_P4_DOT4
+    double d2 = 0.0, d3 = 0.0;
+#define QRK_P4_DOT(I) if ((I) > K) fmac_bcast<((I) & 15)>(((I) & 2) ? (((I) & 1) ? d3 : d2) : (((I) & 1) ? d1 : d0), xc[(I) >> 4], a[I]);
+    QRK_P4_0_31(QRK_P4_DOT)
+#undef QRK_P4_DOT
+    const double dsum = (d0 + d1) + (d2 + d3);
+#else
 #define QRK_P4_DOT(I) if ((I) > K) fmac_bcast<((I) & 15)>(((I) & 1) ? d1 : d0, xc[(I) >> 4], a[I]);
     QRK_P4_0_31(QRK_P4_DOT)
 #undef QRK_P4_DOT
     const double dsum = d0 + d1;
+#endif
     double tsq = 0.0;
     if (K + 1 < WR) {
         if (ispiv) hl[L_TAU + K] = dsum;
         __builtin_amdgcn_wave_barrier();
         tsq = hl[L_TAU + K];
-        __builtin_amdgcn_wave_barrier();
+        if (HC || !QRK_P4_TSQB) __builtin_amdgcn_wave_barrier();   // (the slot is written again below only with HC)
     }
     if (K == 0 && !PIVOT) st.a2 = fma(xk, xk, tsq);
     // (decide::unclear_reflector without short-circuit evaluation: three compares, no control flow)
+#if QRK_P4_DIET
+    unsigned long long degm = 0ull;          // lanes whose tail is empty to rounding: !(tsq > DBL_MIN)
+    {
+        const double n2 = fma(xk, xk, tsq);
+        unsigned long long um = 0ull;
+        if (K + 1 < WR) {
+            degm = __builtin_amdgcn_fcmp(tsq, DBL_MIN, 13 /* ULE */);
+            um = degm | __builtin_amdgcn_fcmp(xk * xk, X0_TINY2 * st.a2, 5 /* OLE */);
+        } else {
+            degm = ~0ull;
+        }
+        if (PIVOT) um |= __builtin_amdgcn_fcmp(n2, PIV_TINY2 * st.a2, 5 /* OLE */);
+        st.unclearm |= um;
+    }
+#else
     const bool degenerate = !(tsq > DBL_MIN);
     {
         const double n2 = fma(xk, xk, tsq);
@@ -254,25 +335,62 @@ __device__ __forceinline__ void step(double (&a)[WR], double* hl /* this half's 
         if (PIVOT) u = u | (n2 <= PIV_TINY2 * st.a2);
         st.unclearm |= __builtin_amdgcn_ballot_w64(u);
     }
+#endif
     // ---- 5. makeHouseholder in the un-normalised form: nb = -beta = copysign(norm, x0), s = x0 - beta, ng = -1 / (beta (x0 - beta));
     // Eigen: tailSqNorm <= min() gives tau = 0, beta = x0, H = I (rare: a real branch on a wave-level test, selects inside)
+#if QRK_P4_RCPSEED
+    // the reciprocal's seed from the UN-refined square root: v_rcp runs beside the Goldschmidt step instead of behind it, and the
+    // two Newton steps that follow use the final denominator
+    double nrm, rseed;
+    {
+        const double x2 = fma(xk, xk, tsq);
+        const double y = __builtin_amdgcn_rsq(x2);
+        double g = x2 * y, h = 0.5 * y;
+        rseed = __builtin_amdgcn_rcp(fma(__builtin_fabs(xk), g, x2));      // beta (beta - x0) = |x|^2 + |x0| |x|
+        const double e = fma(-h, g, 0.5);
+        g = fma(g, e, g);
+        h = fma(h, e, h);
+        const double d = fma(-g, g, x2);
+        nrm = fma(d, h, g);
+    }
+    double nbv = __builtin_copysign(nrm, xk);                // beta = -nbv
+    double s = nbv + xk;
+    double ngp;
+    {
+        const double den = nbv * s;
+        double e = fma(-den, rseed, 1.0);
+        ngp = fma(rseed, e, rseed);
+        e = fma(-den, ngp, 1.0);
+        ngp = fma(ngp, e, ngp);
+    }
+#else
     const double nrm = sqrt_pos(fma(xk, xk, tsq));
     // (Eigen's test is x0 >= 0, which takes -0.0 as positive: a zero x0 with a tail is one of unclear_reflector's cases -- the tile is
     //  redone by the exact path -- and without a tail the branch below overrides)
     double nbv = __builtin_copysign(nrm, xk);                // beta = -nbv
     double s = nbv + xk;
     double ngp = recip(nbv * s);                             // -ng
+#endif
+#if QRK_P4_DIET
+    if (__builtin_expect(degm != 0ull, 0)) {
+        asm volatile("");
+        if ((degm >> lane) & 1ull) { nbv = -xk; s = 0.0; ngp = 0.0; }
+    }
+#else
     if (__builtin_expect(__builtin_amdgcn_ballot_w64(degenerate) != 0ull, 0)) {
         asm volatile("");
         if (degenerate) { nbv = -xk; s = 0.0; ngp = 0.0; }
     }
+#endif
     if (st.j == 0) {
         hl[L_S + K] = s; hl[L_NG + K] = ngp;
         if (HC) hl[L_TAU + K] = (s * s) * ngp;
     }
     const double ngam = fma(s, ak, dsum) * -ngp;             // -gamma of this column
     double an = fma(s, ngam, ak);
-    {
+    // (QRK_P4_DIET: in the pivot lane s x0 + |x_tail|^2 = beta (beta - x0), so the updated entry x0 - s (1 + delta) IS beta to a few
+    //  ulp -- no select; Eigen stores the beta it computed from the norm, and the fast path answers for 1e-12 only)
+    if (!QRK_P4_DIET) {
         // R(K, K) = beta = -nbv in the pivot lane: two selects, the sign through the source modifier
         int hi = __double2hiint(an), lo = __double2loint(an);
         asm("v_cndmask_b32_e64 %0, %0, -%1, %2" : "+v"(hi) : "v"(__double2hiint(nbv)), "s"(pm));
@@ -306,10 +424,12 @@ __device__ __forceinline__ void step(double (&a)[WR], double* hl /* this half's 
 
 // Q_k = H_k Q_{k+1} on the wave's columns of Q (both tiles): reflector K from the half's LDS (x_tail as published, s, ng)
 template <int K>
-__device__ __forceinline__ void back_step(double (&q)[WR], const double* hl, const int lane)
+__device__ __forceinline__ void back_step(double (&q)[WR], const double* hl, const int lane, const double (&sv)[2], const double (&ngv)[2])
 {
     constexpr int M0 = (K + 1) >> 4;
+#if !QRK_P4_S2REG
     const double s = hl[L_S + K], ngp = hl[L_NG + K];
+#endif
     double xc[2] = {0.0, 0.0};
     if (K + 1 < WR) load_chunks<K>(hl, lane, xc);
     const double qk = q[K];
@@ -319,8 +439,18 @@ __device__ __forceinline__ void back_step(double (&q)[WR], const double* hl, con
 #define QRK_P4_DOT(I) if ((I) > K) fmac_bcast<((I) & 15)>(((I) & 1) ? d1 : d0, xc[(I) >> 4], q[I]);
     QRK_P4_0_31(QRK_P4_DOT)
 #undef QRK_P4_DOT
+#if QRK_P4_S2REG
+    // the same three operations with s_K and ng_K read from lane K & 15 of the row through DPP (bitwise the LDS form)
+    double t = d0 + d1;
+    fmac_bcast<(K & 15)>(t, sv[K >> 4], qk);
+    const double ngam = t * -bcast_f64<(K & 15)>(ngv[K >> 4]);
+    double qn = qk;
+    fmac_bcast<(K & 15)>(qn, sv[K >> 4], ngam);
+    q[K] = qn;
+#else
     const double ngam = fma(s, qk, d0 + d1) * -ngp;
     q[K] = fma(s, ngam, qk);
+#endif
 #define QRK_P4_UPD(I) if ((I) > K) fmac_bcast<((I) & 15)>(q[I], xc[(I) >> 4], ngam);
     QRK_P4_0_31(QRK_P4_UPD)
 #undef QRK_P4_UPD
@@ -359,9 +489,6 @@ bdqr_pair4_kernel(int64_t num_tiles, const double* __restrict__ tiles, double* _
     const int64_t npairs = (num_tiles + 1) / 2;
     constexpr int CHUNK = 32;                // rounds per chunk: one 32-bit word per half remembers the flagged rounds
     const bool steady = npairs >= 3 * (int64_t)gridDim.x;
-#ifndef QRK_P4_PRIO
-#define QRK_P4_PRIO 0
-#endif
     // QRK_P4_PRIO: 1 = the waves that have one pair more than the others go first on their SIMD and in the memory queues (their two
     // chains are the critical path of a launch of 1 .. 2 rounds); 2 = the later a wave is dispatched the higher its priority
     if (QRK_P4_PRIO == 1 && (int64_t)blockIdx.x + (npairs / gridDim.x) * gridDim.x < npairs) __builtin_amdgcn_s_setprio(3);
@@ -393,9 +520,33 @@ bdqr_pair4_kernel(int64_t num_tiles, const double* __restrict__ tiles, double* _
             // steady state (three rounds or more per wave): the latency chain of phase 1 goes ahead of the FMA stream of phase 2 on the
             // SIMD: 100 000 tiles 621 -> 599 us; at BASELINE's 10 000 tiles (1.2 rounds) the same costs 10 % (the first waves' phase 2
             // is starved and their second pairs start late), so the launch decides.  QRK_P4_PRIO 6 / 7: always / the reverse (measured)
-            if ((QRK_P4_PRIO == 0 && steady) || QRK_P4_PRIO == 6) __builtin_amdgcn_s_setprio(2);
+            if (((QRK_P4_PRIO == 0 || QRK_P4_PRIO >= 8) && steady) || QRK_P4_PRIO == 6) __builtin_amdgcn_s_setprio(2);
             if (QRK_P4_PRIO == 7) __builtin_amdgcn_s_setprio(0);
+            st.lpf = QRK_P4_PRIO >= 8 && !steady;
+            st.notlast = pi + (int64_t)gridDim.x < npairs;
             double a[WR];
+#if QRK_P4_DIRECT
+            {
+                // every lane its own column, straight from the tile: 16 loads of 16 bytes, 256 bytes between lanes (plain loads: the lines
+                // are re-used by the following loads of the same lane) -- no trip through LDS
+                typedef double d2u __attribute__((ext_vector_type(2), aligned(8)));
+                const double* src = tiles + (valid ? t : 2 * pi) * 1024 + j * 32;
+#pragma unroll
+                for (int i = 0; i < WR; i += 2) {
+                    const d2u v = *reinterpret_cast<const d2u*>(src + i);
+                    a[i] = v.x; a[i + 1] = v.y;
+                }
+                if (QRK_P4_PRIO >= 8 && st.lpf) {
+                    if (st.notlast || QRK_P4_PRIO == 9) __builtin_amdgcn_s_setprio(3);
+                    else if (QRK_P4_PRIO == 8) __builtin_amdgcn_s_setprio(2);
+                    else __builtin_amdgcn_s_setprio(3);
+                }
+                if (!valid) {
+#pragma unroll
+                    for (int i = 0; i < WR; ++i) a[i] = (i == j) ? (double)(64 - j) : 0.0;
+                }
+            }
+#else
             {
                 // both tiles of the pair, one after the other through the wave's LDS: every load instruction takes 1 KB of a tile (lane l
                 // rows 2 (l & 15), +1 of column 4 m + (l >> 4)), the tile is written column by column with a padded stride (16-byte
@@ -411,7 +562,13 @@ bdqr_pair4_kernel(int64_t num_tiles, const double* __restrict__ tiles, double* _
                 for (int m = 0; m < 8; ++m) ld0[m] = QRK_P4_LOAD(reinterpret_cast<const d2u*>(s0 + 128 * m));
 #pragma unroll
                 for (int m = 0; m < 8; ++m) ld1[m] = QRK_P4_LOAD(reinterpret_cast<const d2u*>(s1 + 128 * m));
-                if (QRK_P4_PRIO >= 3 && round == 0 && pi0 == blockIdx.x) {
+                // (QRK_P4_PRIO >= 8, after the loads are queued -- the priority orders the memory queues too)
+                if (QRK_P4_PRIO >= 8 && st.lpf) {
+                    if (st.notlast || QRK_P4_PRIO == 9) __builtin_amdgcn_s_setprio(3);
+                    else if (QRK_P4_PRIO == 8) __builtin_amdgcn_s_setprio(2);
+                    else __builtin_amdgcn_s_setprio(3);
+                }
+                if (QRK_P4_PRIO >= 3 && QRK_P4_PRIO < 8 && round == 0 && pi0 == blockIdx.x) {
                     // (after the loads are queued in dispatch order: the later a wave's tiles arrive, the higher its priority on the SIMD;
                     //  4, 5: the waves that carry one pair more than the others -- two chains back to back -- are in the top class)
                     const bool longw = QRK_P4_PRIO >= 4 && (int64_t)blockIdx.x + (npairs / gridDim.x) * gridDim.x < npairs;
@@ -448,6 +605,7 @@ bdqr_pair4_kernel(int64_t num_tiles, const double* __restrict__ tiles, double* _
                 }
                 __builtin_amdgcn_wave_barrier();
             }
+#endif
             QRK_P4_STAMP_AT(1);
             {
                 double s0 = 0.0, s1 = 0.0;
@@ -495,8 +653,23 @@ bdqr_pair4_kernel(int64_t num_tiles, const double* __restrict__ tiles, double* _
         {
             // =============== phase 2: Q = H_0 ... H_31, backward ===============
             QRK_P4_STAMP_AT(2);
-            if ((QRK_P4_PRIO == 0 && steady) || QRK_P4_PRIO == 6) __builtin_amdgcn_s_setprio(0);
+            if (((QRK_P4_PRIO == 0 || QRK_P4_PRIO >= 8) && steady) || QRK_P4_PRIO == 6) __builtin_amdgcn_s_setprio(0);
             if (QRK_P4_PRIO == 7) __builtin_amdgcn_s_setprio(2);
+            if (QRK_P4_PRIO >= 8 && !steady && (QRK_P4_PRIO == 9 || !(pi + (int64_t)gridDim.x < npairs))) {
+                if (QRK_P4_PH2 == 0) __builtin_amdgcn_s_setprio(0);
+                if (QRK_P4_PH2 == 1) __builtin_amdgcn_s_setprio(1);
+                if (QRK_P4_PH2 == 2) __builtin_amdgcn_s_setprio(2);
+                if (QRK_P4_PH2 == 3) __builtin_amdgcn_s_setprio(3);
+            }
+#if QRK_P4_PREFETCH
+            // the wave's next pair (16 KB, contiguous) is pulled into L2 while this pair's Q is formed: one dword per 128-byte line
+            int pf0 = 0, pf1 = 0;
+            if (pi + (int64_t)gridDim.x < npairs) {
+                const int* nx = reinterpret_cast<const int*>(tiles + 2 * (pi + (int64_t)gridDim.x) * 1024) + 32 * threadIdx.x;
+                pf0 = __builtin_nontemporal_load(nx);
+                if (2 * (pi + (int64_t)gridDim.x) + 1 < num_tiles) pf1 = __builtin_nontemporal_load(nx + 2048);
+            }
+#endif
             int ln = threadIdx.x;
             asm volatile("" : "+v"(ln));
             const int jj = ln & 31;
@@ -504,10 +677,15 @@ bdqr_pair4_kernel(int64_t num_tiles, const double* __restrict__ tiles, double* _
             double q[WR];
 #pragma unroll
             for (int i = 0; i < WR; ++i) q[i] = (i == jj) ? 1.0 : 0.0;
+            double sv[2] = {0.0, 0.0}, ngv[2] = {0.0, 0.0};
+#if QRK_P4_S2REG
+#pragma unroll
+            for (int m = 0; m < 2; ++m) { sv[m] = hl2[L_S + 16 * m + (ln & 15)]; ngv[m] = hl2[L_NG + 16 * m + (ln & 15)]; }
+#endif
 #if defined(QRK_P4_ABL) && (QRK_P4_ABL & 2)
-#define QRK_P4_BACK(K) if ((K) < 16 || !(round & 1)) back_step<K>(q, hl2, ln);
+#define QRK_P4_BACK(K) if ((K) < 16 || !(round & 1)) back_step<K>(q, hl2, ln, sv, ngv);
 #else
-#define QRK_P4_BACK(K) back_step<K>(q, hl2, ln);
+#define QRK_P4_BACK(K) back_step<K>(q, hl2, ln, sv, ngv);
 #endif
             QRK_P4_31_0(QRK_P4_BACK)
 #undef QRK_P4_BACK
@@ -519,6 +697,9 @@ bdqr_pair4_kernel(int64_t num_tiles, const double* __restrict__ tiles, double* _
                 for (int i = 0; i < WR; ++i) QRK_P4_STOREQ(q[i], dst + 32 * i);
             }
             QRK_P4_STAMP_AT(3);
+#if QRK_P4_PREFETCH
+            asm volatile("" :: "v"(pf0), "v"(pf1));
+#endif
         }
         __builtin_amdgcn_wave_barrier();
         if (QRK_P4_PRIO == 2 || QRK_P4_PRIO == 3) __builtin_amdgcn_s_setprio(3);     // (a further pair of this wave starts later than anything else)

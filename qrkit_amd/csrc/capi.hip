@@ -127,7 +127,8 @@ struct qrk_bbs_plan_s {
     std::vector<qrk::BBPanel> panels;
     qrk::BBPanel* d_panels = nullptr;
     int32_t* d_rlim = nullptr;          // [2][n / 16]: staircase row limits of panel 0 / of the other panels
-    int32_t* d_done = nullptr;          // [N] rows-final words of the pipelined chain (banded.hip, BBPipe)
+    int32_t* d_done = nullptr;          // [N + 1] rows-final words of the pipelined chain and its abort word (banded.hip, BBPipe)
+    int64_t chain_reruns = 0;           // factorisations whose pipelined chain was given up and run again on one workgroup
     double *d_q = nullptr, *d_ra = nullptr;     // stage A: explicit Q_i (ms x ms each), packed R_i
     int32_t* d_perm = nullptr;
     double *d_y = nullptr, *d_t = nullptr, *d_stage = nullptr, *d_lo = nullptr;   // stage B: panels (Y below the diagonal), T, rows of R, carry
@@ -1794,7 +1795,7 @@ qrk_status qrk_bbs_plan_create(qrk_handle h, int64_t num_strips, int32_t strip_r
         hipMalloc((void**)&p->d_t, (size_t)p->t_len * sizeof(double)) != hipSuccess ||
         hipMalloc((void**)&p->d_stage, (size_t)p->stage_len * sizeof(double)) != hipSuccess ||
         hipMalloc((void**)&p->d_lo, (size_t)(lo > 0 ? lo * lo : 1) * sizeof(double)) != hipSuccess ||
-        hipMalloc((void**)&p->d_done, (size_t)num_strips * sizeof(int32_t)) != hipSuccess) {
+        hipMalloc((void**)&p->d_done, (size_t)(num_strips + 1) * sizeof(int32_t)) != hipSuccess) {
         qrk_bbs_plan_destroy(p);
         return fail(h, QRK_STATUS_ALLOC_FAILED, "qrk_bbs_plan_create: cannot allocate the factors (Q of stage A, panels and T of stage B)");
     }
@@ -1832,8 +1833,24 @@ qrk_status qrk_bbs_factorize(qrk_bbs_plan p, const double* strips)
     if (st != QRK_STATUS_OK) return st;
     // stage B: the chain merges the carried triangle with the strip's
     const int ng = p->n / 16;
+    int piped = 0;
     QRK_HIP(h, qrk::launch_bbs_chain(p->d_panels, (int)p->N, p->d_ra, (int64_t)p->n * (p->n + 1) / 2, p->n, p->lo, p->max_act, p->d_lo,
-                                     p->d_y, p->d_t, p->d_stage, p->d_rlim, p->d_rlim + ng, p->d_done, h->stream));
+                                     p->d_y, p->d_t, p->d_stage, p->d_rlim, p->d_rlim + ng, p->d_done, 0, &piped, h->stream));
+    if (piped) {
+        // the workgroups of the pipelined chain are an ordinary launch, not guaranteed to be co-resident: a wait that ran out raised
+        // the chain's abort word (banded.hip, bb_pipe_wait) and the factors are unfinished -- run stage B again on ONE workgroup
+        int32_t aborted = 0;
+        QRK_HIP(h, hipMemcpyAsync(&aborted, p->d_done + p->N, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+        QRK_HIP(h, hipStreamSynchronize(h->stream));
+        if (aborted) {
+            ++p->chain_reruns;
+            QRK_HIP(h, qrk::launch_bbs_chain(p->d_panels, (int)p->N, p->d_ra, (int64_t)p->n * (p->n + 1) / 2, p->n, p->lo, p->max_act,
+                                             p->d_lo, p->d_y, p->d_t, p->d_stage, p->d_rlim, p->d_rlim + ng, p->d_done, 1, nullptr,
+                                             h->stream));
+            if (std::getenv("QRK_BBS_PIPE_VERBOSE"))
+                std::fprintf(stderr, "qrk_bbs_factorize: the pipelined chain was given up (a wait ran out); stage B ran again on one workgroup\n");
+        }
+    }
     p->factorized = true;
     if (std::getenv("QRK_BBS_PROF_DUMP")) {
         // diagnostic builds of banded.hip (-DQRK_BB_PROF) leave the chain's tick counts in the T of the last panel
@@ -2027,22 +2044,24 @@ qrk_status qrk_bd_time_factorize(qrk_bd_plan p, const double* tiles, double* q_v
     qrk_handle h = p->h;
     if (p->landscape) return fail(h, QRK_STATUS_INVALID_ARGUMENT, "qrk_bd_time_factorize: landscape tile");
     QRK_HIP(h, hipSetDevice(h->device));
-    hipEvent_t e0, e1;
-    QRK_HIP(h, hipEventCreate(&e0));
-    QRK_HIP(h, hipEventCreate(&e1));
-    QRK_HIP(h, hipEventRecord(e0, h->stream));
+    // (the events are destroyed on every path: a guard instead of QRK_HIP's early return past them)
+    struct Events {
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        ~Events() { if (e0) (void)hipEventDestroy(e0); if (e1) (void)hipEventDestroy(e1); }
+    } ev;
+    QRK_HIP(h, hipEventCreate(&ev.e0));
+    QRK_HIP(h, hipEventCreate(&ev.e1));
+    QRK_HIP(h, hipEventRecord(ev.e0, h->stream));
     qrk_status st = QRK_STATUS_OK;
     for (int it = 0; it < iters && st == QRK_STATUS_OK; ++it) {
         const int64_t s = it % nsets;
         st = enqueue_factorize(p, tiles + s * p->tiles_len, q_vals + s * p->nnz_q, r_vals + s * p->nnz_r,
                                perm + s * (int64_t)p->mat_cols, nullptr);
     }
-    QRK_HIP(h, hipEventRecord(e1, h->stream));
-    QRK_HIP(h, hipEventSynchronize(e1));
+    QRK_HIP(h, hipEventRecord(ev.e1, h->stream));
+    QRK_HIP(h, hipEventSynchronize(ev.e1));
     float ms = 0.f;
-    QRK_HIP(h, hipEventElapsedTime(&ms, e0, e1));
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
+    QRK_HIP(h, hipEventElapsedTime(&ms, ev.e0, ev.e1));
     *avg_ms = ms / (float)iters;
     p->factorized = st == QRK_STATUS_OK;
     return st;

@@ -159,7 +159,7 @@ size_t bb_apply_smem(int max_act_rows, int max_ncols);
 // strips form of the banded factorisation (banded.hip): stage B on the triangles stage A left
 hipError_t launch_bbs_chain(const BBPanel* panels, int num_panels, const double* r_packed, int64_t r_stride, int n, int lo,
                             int max_act_rows, double* lo_buf, double* y_vals, double* t_vals, double* r_stage,
-                            const int* rlim_first, const int* rlim_rest, int* done, hipStream_t stream);
+                            const int* rlim_first, const int* rlim_rest, int* done, int single, int* piped_out, hipStream_t stream);
 hipError_t launch_bbs_apply(const BBPanel* panels, int num_panels, const double* y_vals, const double* t_vals, int transpose,
                             double* ya, int64_t ya_ld, double* full, int64_t full_ld, int64_t nrhs, int ms, int n, int s, int lo,
                             int cols, int max_act_rows, hipStream_t stream);

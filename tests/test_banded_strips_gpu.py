@@ -141,3 +141,39 @@ def test_strips_configs2_full_size():
                 col[i * s:i * s + blk.shape[0]] = blk[:, c - i * s]
         assert float((q[:cols] - col).norm()) <= 1e-11 * float(e.norm()), c
         assert float(q[cols:].norm()) <= 1e-11 * float(e.norm()), c
+
+
+@pytest.mark.gpu
+def test_given_up_pipeline_falls_back_to_one_workgroup(capfd):
+    """A wait of the pipelined chain that runs out (QRK_BBS_PIPE_SPINS=0: the first unsatisfied wait) raises the chain's abort word;
+    qrk_bbs_factorize reads it at its synchronisation point and runs stage B again on one workgroup: same R as the single-workgroup
+    chain, never a silently unfinished factor (round-4 advisor finding on banded.hip's bounded wait)."""
+    import qrkit_amd
+    from qrkit_amd.banded import BandedStripsQR
+    N, ms, n, s = 24, 256, 192, 64
+    strips = make(N, ms, n, s, seed=77)
+    dev = to_device(strips)
+    old = {k: os.environ.get(k) for k in ("QRK_BBS_PIPE", "QRK_BBS_PIPE_SPINS", "QRK_BBS_PIPE_VERBOSE")}
+    try:
+        os.environ["QRK_BBS_PIPE"] = "1"
+        qr1 = BandedStripsQR(N, ms, n, s, context=qrkit_amd.Context(0))
+        qr1.factorize(dev)
+        R1 = qr1.matrixR_dense()
+        os.environ["QRK_BBS_PIPE"] = "3"
+        os.environ["QRK_BBS_PIPE_SPINS"] = "0"
+        os.environ["QRK_BBS_PIPE_VERBOSE"] = "1"
+        qr3 = BandedStripsQR(N, ms, n, s, context=qrkit_amd.Context(0))
+        qr3.factorize(dev)
+        R3 = qr3.matrixR_dense()
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    err = capfd.readouterr().err
+    assert "ran again on one workgroup" in err, "the shortened wait did not trigger the fall-back"
+    assert np.array_equal(R1, R3), "the fall-back differs from the single-workgroup chain"
+    Rl = np.linalg.qr(assemble(strips, N, ms, n, s), mode="r")
+    sg = np.sign(np.diag(R3)) * np.sign(np.diag(Rl))
+    assert (np.linalg.norm(R3 * sg[:, None] - Rl, axis=1) / np.linalg.norm(Rl, axis=1)).max() <= 1e-11

@@ -5,7 +5,7 @@ start of its round, when its tiles are in registers, at the end of phase 1 and a
 import os, subprocess, sys, ctypes as C
 ROOT = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
-out = os.path.join(ROOT, "tools", "abl", "libqrk_p4stamp%s.so" % os.environ.get("QRK_P4_TAG", ""))
+out = os.path.join(ROOT, "tools", "abl_stamp", "libqrk_p4stamp%s.so" % os.environ.get("QRK_P4_TAG", ""))
 if len(sys.argv) > 1 and sys.argv[1] == "build":
     import glob
     os.makedirs(os.path.dirname(out), exist_ok=True)
