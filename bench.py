@@ -321,7 +321,8 @@ def main():
     # ---- another BASELINE configuration on this GPU (N = 1; reported next to the headline, never as `value`)
     other = None
     if world == 1 and not args.no_other:
-        other = {"configs4_share_of_one_gpu": mixed_share(ctx, dev, torch, np),
+        other = {"strong_shard_emulation": strong_shard_emulation(ctx, dev, torch, np, make_plan, run),
+                 "configs4_share_of_one_gpu": mixed_share(ctx, dev, torch, np),
                  "configs2_strips": strips_config2(ctx, dev, torch, np),
                  "configs3_angular": angular_config3(ctx, dev, torch, np)}
 
@@ -469,6 +470,43 @@ def _timed(dist, torch, dev, backend, fn, iters):
     tt = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
     dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     return tt.item() / iters
+
+
+def strong_shard_emulation(ctx, dev, torch, np, make_plan, run):
+    """What ONE GPU would do in the strong-scaling legs (B tiles of 32 x 32 cut into N contiguous shards, R and perm of
+    the remote shards gathered on rank 0), timed on this one GPU: T(B / N) for N in {1, 2, 4, 8} of B = 10 000 and B = 1 000 000, the
+    bytes rank 0 receives, and the speed-up these imply at best (the gather priced at one xGMI link per sender, 153 GB/s nominal).
+    UNMEASURED on more than one GPU: an upper bound from the kernel's own latency law, not a scaling result."""
+    from qrkit_amd import _capi as capi
+    XGMI_LINK_GBS = 153.0
+    out = []
+    for B, iters in ((10000, 200), (1000000, 6)):
+        per = {}
+        for N in (1, 2, 4, 8):
+            nb = B // N
+            plan = make_plan(nb)
+            S = max(1, min(8, 80000 // nb)) if nb < 80000 else 1
+            g = torch.Generator(device=dev); g.manual_seed(4321 + N)
+            t = torch.rand(S * nb * BR * BC, generator=g, device=dev, dtype=torch.float64) * 4.5 + 0.5
+            q = torch.empty(S * nb * BR * BR, device=dev, dtype=torch.float64)
+            r = torch.empty(S * nb * 528, device=dev, dtype=torch.float64)
+            p = torch.empty(S * nb * BC, device=dev, dtype=torch.int32)
+            run(plan, max(2, iters // 10), t, q, r, p, S)
+            per[N] = min(run(plan, iters, t, q, r, p, S) for _ in range(3)) * 1e3      # us per launch
+            capi.lib().qrk_bd_plan_destroy(plan)
+            del t, q, r, p
+        legs = []
+        for N in (2, 4, 8):
+            recv = (B - B // N) * (528 * 8 + BC * 4)                 # bytes rank 0 receives (R f64 + perm i32 of the other shards)
+            gather_us = (B // N) * (528 * 8 + BC * 4) / (XGMI_LINK_GBS * 1e3)        # every sender on its own link to rank 0, concurrently
+            legs.append({"gpus": N, "tiles_per_gpu": B // N, "shard_us": per[N], "gather_bytes_to_rank0": recv,
+                         "gather_us_at_one_link_per_sender": gather_us,
+                         "speedup_upper_bound_no_gather": per[1] / per[N],
+                         "speedup_upper_bound_with_gather": per[1] / (per[N] + gather_us)})
+        out.append({"blocks": B, "one_gpu_us": per[1], "legs": legs})
+    return {"what": "one-GPU emulation of the per-GPU shard of the strong-scaling legs (unmeasured on 8 GPUs): the shard's launch time on "
+                    "this GPU, the bytes of the R / perm gather and the speed-up they bound",
+            "xgmi_link_GBs_nominal": XGMI_LINK_GBS, "runs": out}
 
 
 def mixed_share(ctx, dev, torch, np, B=12500):

@@ -150,6 +150,52 @@ class SparseMatrix {
 typedef SparseMatrix<true> SparseMatrixRowMajor;
 typedef SparseMatrix<false> SparseMatrixColMajor;
 
+// solve() with a SPARSE right-hand side (the SparseMatrixBase overload of every reference solver, e.g. BlockDiagonalSparseQR.h:293-299;
+// Eigen evaluates Solve<Dec, SparseRhs> with internal::solve_sparse_through_dense_panels): the columns of B go through the solver's
+// dense path in panels of four, and the result keeps the entries that are not exactly zero (tmpX.sparseView()).  `Panel` = the
+// solver's dense solve() takes several columns at once (rows x k, column-major); otherwise one column per call.
+namespace detail {
+template <bool Panel, typename Solver, bool RM>
+inline SparseMatrix<false> solveSparseThroughDensePanels(const Solver& dec, Index decRows, Index decCols, const SparseMatrix<RM>& B) {
+    assert(decRows == B.rows() && "SparseQR::solve() : invalid number of rows in the right hand side matrix");
+    const Index rhsCols = B.cols(), NbColsAtOnce = 4;
+    // column access to B whatever its storage order
+    std::vector<std::vector<std::pair<int, double> > > colsOfB((size_t)rhsCols);
+    for (Index o = 0; o < B.outerSize(); ++o)
+        for (int p = B.outerIndex()[(size_t)o]; p < B.outerIndex()[(size_t)o + 1]; ++p) {
+            const int in = B.innerIndex()[(size_t)p];
+            if (RM) colsOfB[(size_t)in].push_back(std::make_pair((int)o, B.values()[(size_t)p]));
+            else colsOfB[(size_t)o].push_back(std::make_pair(in, B.values()[(size_t)p]));
+        }
+    SparseMatrix<false> X(decCols, rhsCols);
+    std::vector<int>& outer = X.outerIndex();
+    for (Index k = 0; k < rhsCols; k += NbColsAtOnce) {
+        const Index actualCols = std::min<Index>(rhsCols - k, NbColsAtOnce);
+        Vector tmp((size_t)(decRows * actualCols), 0.0), tmpX;
+        for (Index c = 0; c < actualCols; ++c)
+            for (size_t q = 0; q < colsOfB[(size_t)(k + c)].size(); ++q)
+                tmp[(size_t)(c * decRows + colsOfB[(size_t)(k + c)][q].first)] = colsOfB[(size_t)(k + c)][q].second;
+        if (Panel) {
+            tmpX = dec.solve(tmp);
+        } else {
+            tmpX.resize((size_t)(decCols * actualCols));
+            for (Index c = 0; c < actualCols; ++c) {
+                const Vector xc = dec.solve(Vector(tmp.begin() + c * decRows, tmp.begin() + (c + 1) * decRows));
+                std::copy(xc.begin(), xc.begin() + decCols, tmpX.begin() + c * decCols);
+            }
+        }
+        for (Index c = 0; c < actualCols; ++c) {
+            for (Index i = 0; i < decCols; ++i) {
+                const double v = tmpX[(size_t)(c * decCols + i)];
+                if (v != 0.0) { X.innerIndex().push_back((int)i); X.values().push_back(v); }
+            }
+            outer[(size_t)(k + c + 1)] = (int)X.innerIndex().size();
+        }
+    }
+    return X;
+}
+}  // namespace detail
+
 // QRKit::SparseBlockDiagonal (SparseBlockDiagonal.h:43-163): the blocks are kept packed back to back
 // (column-major), which is what std::vector<Matrix<double,r,c>> is for fixed-size blocks.
 class SparseBlockDiagonal {
@@ -337,6 +383,8 @@ class BlockDiagonalSparseQR {
         return true;
     }
     Vector solve(const Vector& B) const { Vector x; _solve_impl(B, x); return x; }
+    // the SparseMatrixBase overload (:293-299)
+    template <bool RM> SparseMatrix<false> solve(const SparseMatrix<RM>& B) const { return detail::solveSparseThroughDensePanels<true>(*this, rows(), cols(), B); }
     // the triangular step alone, on the device: z = R(0:cols,0:cols).triangularView<Upper>().solve(y) (:271); y: cols x nrhs
     Vector solveR(const Vector& y) const {
         assert(m_isInitialized && (Index)y.size() % cols() == 0);
@@ -657,6 +705,8 @@ class BandedBlockedSparseQR {
         for (int64_t c = 0; c < nrhs; ++c) std::copy(y.begin() + c * m_rows, y.begin() + c * m_rows + m_cols, x.begin() + c * m_cols);
         return x;
     }
+    // the SparseMatrixBase overload (BandedBlockedSparseQR.h: solve(const SparseMatrixBase<Rhs>&))
+    template <bool RM2> SparseMatrix<false> solve(const SparseMatrix<RM2>& B) const { return detail::solveSparseThroughDensePanels<true>(*this, rows(), cols(), B); }
     // Q^T v / Q v and the triangular step on device pointers (the ABI works in place: in is copied to out first)
     void applyQDevice(const double* d_in, int64_t nrhs, double* d_out, bool transpose) const {
         check(qrk_memcpy_2d(m_handle, d_out, m_rows * (int64_t)sizeof(double), d_in, m_rows * (int64_t)sizeof(double),
@@ -919,6 +969,8 @@ class BlockedThinDenseQR {
         m_dev.solveR(z, cols(), 1);
         return z;
     }
+    // the SparseMatrixBase overload (BlockedThinQRBase.h: solve(const SparseMatrixBase<Rhs>&))
+    template <bool RM2> SparseMatrix<false> solve(const SparseMatrix<RM2>& B) const { return detail::solveSparseThroughDensePanels<false>(*this, rows(), cols(), B); }
 
   protected:
     Vector applyQImpl(const Vector& v, bool transpose) const {
@@ -1024,6 +1076,8 @@ class BlockedThinSparseQR {
         check(qrk_memcpy(m_handle, x.data(), d.p, (int64_t)(m_cols * (Index)sizeof(double)), 1));
         return x;
     }
+    // the SparseMatrixBase overload (BlockedThinQRBase.h: solve(const SparseMatrixBase<Rhs>&))
+    template <bool RM2> SparseMatrix<false> solve(const SparseMatrix<RM2>& B) const { return detail::solveSparseThroughDensePanels<false>(*this, rows(), cols(), B); }
 
   protected:
     // device copy of nrhs columns with the zero rows the panels are applied with (leading dimension 2 rows)
@@ -1223,6 +1277,8 @@ class BlockAngularSparseQR {
         check(qrk_memcpy(m_handle, z.data() + m_m1, z2.p, m_m2 * D, 1));
         return m_outputPerm_c * z;
     }
+    // the SparseMatrixBase overload (BlockAngularSparseQR.h: solve(const SparseMatrixBase<Rhs>&))
+    template <bool RM2> SparseMatrix<false> solve(const SparseMatrix<RM2>& B) const { return detail::solveSparseThroughDensePanels<false>(*this, rows(), cols(), B); }
 
   protected:
     // the factorisation proper: `top(dTop, rp, identity)` puts rows [0, n1) of J2 on the device (n1 x m2, column-major, source row

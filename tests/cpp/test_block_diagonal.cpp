@@ -39,6 +39,39 @@ static void generate_block_diagonal_matrix(Index numParams, Index numResiduals, 
     spJ.setFromTriplets(jvals);
 }
 
+// solve() with a sparse right-hand side (the SparseMatrixBase overload of every reference solver): five columns -- b, -2 b, an empty
+// one, b again, 0.5 b -- so the panels of four and the remainder are both exercised; the result must be the dense solve() of every
+// column with the exact zeros dropped (an empty column stays empty).
+template <typename Solver>
+static int checkSparseRhs(const Solver& dec, const Vector& b, const char* what) {
+    const Index rows = (Index)b.size();
+    const double scale[5] = {1.0, -2.0, 0.0, 1.0, 0.5};
+    std::vector<Triplet> trips;
+    for (int c = 0; c < 5; ++c) for (Index i = 0; i < rows; ++i) if (scale[c] != 0.0 && b[(size_t)i] != 0.0) trips.push_back(Triplet((int)i, c, scale[c] * b[(size_t)i]));
+    SparseMatrixColMajor Bc(rows, 5);
+    Bc.setFromTriplets(trips);
+    SparseMatrixRowMajor Br(rows, 5);
+    Br.setFromTriplets(trips);
+    const Vector xd = dec.solve(b);
+    int fails = 0;
+    for (int pass = 0; pass < 2; ++pass) {
+        const SparseMatrixColMajor X = pass ? dec.solve(Br) : dec.solve(Bc);
+        if (X.rows() != (Index)xd.size() || X.cols() != 5) { std::printf("  %s: sparse solve() has the wrong shape\n", what); return 1; }
+        if (X.outerIndex()[3] != X.outerIndex()[2]) { std::printf("  %s: the empty column did not stay empty\n", what); ++fails; }
+        for (int c = 0; c < 5; ++c) {
+            Vector col(xd.size(), 0.0);
+            for (int p = X.outerIndex()[(size_t)c]; p < X.outerIndex()[(size_t)c + 1]; ++p) {
+                if (X.values()[(size_t)p] == 0.0) { std::printf("  %s: explicit zero kept\n", what); ++fails; }
+                col[(size_t)X.innerIndex()[(size_t)p]] = X.values()[(size_t)p];
+            }
+            double num = 0.0, den = 0.0;
+            for (size_t i = 0; i < xd.size(); ++i) { const double d = col[i] - scale[c] * xd[i]; num += d * d; den += xd[i] * xd[i]; }
+            if (std::sqrt(num) > 1e-10 * std::sqrt(den)) { std::printf("  %s: column %d of the sparse solve() differs from the dense one\n", what, c); ++fails; }
+        }
+    }
+    return fails;
+}
+
 static int test_block_diagonal(int numVars, int br, int bc) {
     const Index numParams = (Index)numVars * bc, numResiduals = (Index)numVars * br;
     SparseMatrixColMajor spJ;
@@ -78,6 +111,7 @@ static int test_block_diagonal(int numVars, int br, int bc) {
     if (!approx(xm, bm, 1e-10)) { std::printf("LS recovery failed\n"); ++fails; }                        // (:203)
     if (!approx(xm, sm, 1e-10)) { std::printf("solve() recovery failed\n"); ++fails; }
     Vector yd = bdqr.applyQt(b);
+    fails += checkSparseRhs(bdqr, b, "BlockDiagonalSparseQR");
     for (size_t i = 0; i < y.size(); ++i) if (std::fabs(yd[i] - y[i]) > 1e-12 * (1.0 + std::fabs(y[i]))) { std::printf("applyQt mismatch\n"); ++fails; break; }
     std::printf("test_block_diagonal %dx%d x %d blocks: %s\n", br, bc, numVars, fails ? "Failed." : "Passed.");
     return fails;

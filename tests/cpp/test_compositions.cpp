@@ -79,6 +79,39 @@ static void generate_block_angular(Index numParams, Index numAngularParams, Inde
     left.setFromTriplets(jvals);
 }
 
+// solve() with a sparse right-hand side (the SparseMatrixBase overload of every reference solver): five columns -- b, -2 b, an empty
+// one, b again, 0.5 b -- so the panels of four and the remainder are both exercised; the result must be the dense solve() of every
+// column with the exact zeros dropped (an empty column stays empty).
+template <typename Solver>
+static int checkSparseRhs(const Solver& dec, const Vector& b, const char* what) {
+    const Index rows = (Index)b.size();
+    const double scale[5] = {1.0, -2.0, 0.0, 1.0, 0.5};
+    std::vector<Triplet> trips;
+    for (int c = 0; c < 5; ++c) for (Index i = 0; i < rows; ++i) if (scale[c] != 0.0 && b[(size_t)i] != 0.0) trips.push_back(Triplet((int)i, c, scale[c] * b[(size_t)i]));
+    SparseMatrixColMajor Bc(rows, 5);
+    Bc.setFromTriplets(trips);
+    SparseMatrixRowMajor Br(rows, 5);
+    Br.setFromTriplets(trips);
+    const Vector xd = dec.solve(b);
+    int fails = 0;
+    for (int pass = 0; pass < 2; ++pass) {
+        const SparseMatrixColMajor X = pass ? dec.solve(Br) : dec.solve(Bc);
+        if (X.rows() != (Index)xd.size() || X.cols() != 5) { std::printf("  %s: sparse solve() has the wrong shape\n", what); return 1; }
+        if (X.outerIndex()[3] != X.outerIndex()[2]) { std::printf("  %s: the empty column did not stay empty\n", what); ++fails; }
+        for (int c = 0; c < 5; ++c) {
+            Vector col(xd.size(), 0.0);
+            for (int p = X.outerIndex()[(size_t)c]; p < X.outerIndex()[(size_t)c + 1]; ++p) {
+                if (X.values()[(size_t)p] == 0.0) { std::printf("  %s: explicit zero kept\n", what); ++fails; }
+                col[(size_t)X.innerIndex()[(size_t)p]] = X.values()[(size_t)p];
+            }
+            double num = 0.0, den = 0.0;
+            for (size_t i = 0; i < xd.size(); ++i) { const double d = col[i] - scale[c] * xd[i]; num += d * d; den += xd[i] * xd[i]; }
+            if (std::sqrt(num) > 1e-10 * std::sqrt(den)) { std::printf("  %s: column %d of the sparse solve() differs from the dense one\n", what, c); ++fails; }
+        }
+    }
+    return fails;
+}
+
 static int test_banded_blocked(const SparseMatrixColMajor& spJ, const char* name) {
     int fails = 0;
     BandedBlockedQRSolver slvr;
@@ -109,6 +142,7 @@ static int test_banded_blocked(const SparseMatrixColMajor& spJ, const char* name
     if (!approx(matmul(slvrQt, JP, false), Rd, 1e-10)) { std::printf("  (Q^T)*P*J != R\n"); ++fails; }           // (:252)
     if (!approxVec(x, backperm, 1e-8)) { std::printf("  LS recovery failed\n"); ++fails; }                        // (:253)
     if (!approxVec(x, slvr.solve(b), 1e-8)) { std::printf("  solve() recovery failed\n"); ++fails; }
+    fails += checkSparseRhs(slvr, b, "BandedBlockedSparseQR");
     std::printf("test_banded_blocked [%s] %lld blocks: %s\n", name, (long long)slvr.numBlocks(), fails ? "Failed." : "Passed.");
     return fails;
 }
@@ -144,6 +178,7 @@ static int test_block_angular_as(const LeftMat& leftForSolver, const SparseMatri
     for (Index i = 0; i < cols; ++i) backperm[(size_t)baqr.colsPermutation().indices()[(size_t)i]] = solved[(size_t)i];   // (:286-288)
     if (!approxVec(x, backperm, 1e-8)) { std::printf("  LS recovery failed\n"); ++fails; }                    // (:290)
     if (!approxVec(x, baqr.solve(b), 1e-8)) { std::printf("  solve() recovery failed\n"); ++fails; }
+    fails += checkSparseRhs(baqr, b, "BlockAngularSparseQR");
     // Q Q^T b = b and |Q^T b| = |b|
     const Vector back = baqr.matrixQ() * y;
     if (!approxVec(b, back, 1e-10)) { std::printf("  Q*(Q^T*b) != b\n"); ++fails; }
@@ -188,6 +223,7 @@ static int test_blocked_thin(const Matrix& A) {
     Vector b((size_t)rows, 0.0);
     for (Index j = 0; j < cols; ++j) for (Index i = 0; i < rows; ++i) b[(size_t)i] += A(i, j) * x[(size_t)j];
     if (!approxVec(x, slvr.solve(b), 1e-8)) { std::printf("  LS recovery failed\n"); ++fails; }
+    fails += checkSparseRhs(slvr, b, "BlockedThin*QR");
     std::printf("test_blocked_thin %lld x %lld: %s\n", (long long)rows, (long long)cols, fails ? "Failed." : "Passed.");
     return fails;
 }
