@@ -322,6 +322,7 @@ def main():
     other = None
     if world == 1 and not args.no_other:
         other = {"strong_shard_emulation": strong_shard_emulation(ctx, dev, torch, np, make_plan, run),
+                 "small_tiles": small_tiles(ctx, dev, torch, np),
                  "configs4_share_of_one_gpu": mixed_share(ctx, dev, torch, np),
                  "configs2_strips": strips_config2(ctx, dev, torch, np),
                  "configs3_angular": angular_config3(ctx, dev, torch, np)}
@@ -507,6 +508,40 @@ def strong_shard_emulation(ctx, dev, torch, np, make_plan, run):
     return {"what": "one-GPU emulation of the per-GPU shard of the strong-scaling legs (unmeasured on 8 GPUs): the shard's launch time on "
                     "this GPU, the bytes of the R / perm gather and the speed-up they bound",
             "xgmi_link_GBs_nominal": XGMI_LINK_GBS, "runs": out}
+
+
+def small_tiles(ctx, dev, torch, np):
+    """Uniform batches of the small and middle tile classes on the final build (tiles/s and the fraction of the HBM roofline at the
+    algorithmic bytes of SURVEY.md 8(d): 8 r c in, 8 r^2 + 4 c (c + 1) + 4 c out): 8 x 6 is the left stage of BASELINE configs[3], 7 x 2 and
+    9 x 2 the reference's own test blocks, 16 x 16 the top of bdqr_small, 33 x 33 / 64 x 64 the ends of bdqr_w64."""
+    import qrkit_amd
+    out = []
+    for r, c, B in ((7, 2, 1000000), (9, 2, 1000000), (8, 6, 20000), (8, 6, 1000000), (16, 16, 400000), (33, 33, 2000), (33, 33, 20000),
+                    (64, 64, 2000), (64, 64, 40000)):
+        g = torch.Generator(device=dev); g.manual_seed(7 * r + c)
+        tiles = torch.rand(B * r * c, generator=g, device=dev, dtype=torch.float64) * 2.0 - 1.0
+        rows, cols = np.full(B, r, np.int32), np.full(B, c, np.int32)
+        mat = qrkit_amd.SparseBlockDiagonal.fromTiles(rows, cols, tiles)
+        qr = qrkit_amd.BlockDiagonalSparseQR(context=ctx)
+        qr.analyzePattern(mat)
+
+        def once():
+            qr.factorize(mat)
+        for _ in range(3):
+            once()
+        torch.cuda.synchronize()
+        best = 1e30
+        for _ in range(3):
+            t0 = time.perf_counter()
+            for _ in range(10):
+                once()
+            torch.cuda.synchronize()
+            best = min(best, (time.perf_counter() - t0) / 10)
+        by = 8 * r * c + 8 * r * r + 4 * c * (c + 1) + 4 * c
+        out.append({"tile": f"{r}x{c}", "tiles": B, "ms": best * 1e3, "tiles_per_s": B / best, "algorithmic_GBs": B * by / best / 1e9,
+                    "frac_of_hbm": B * by / best / 1e9 / HBM_PEAK_GBS})
+        del qr, mat, tiles
+    return out
 
 
 def mixed_share(ctx, dev, torch, np, B=12500):

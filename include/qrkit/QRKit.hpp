@@ -1419,6 +1419,189 @@ class BlockAngularSparseQR {
     PermutationType m_outputPerm_c, m_rowPerm;
 };
 
+
+// ---------------------------------------------------------------------------------------------
+// QRKit::BlockAngularSparseQR with the ROWS sharded over the GPUs of a node (BASELINE configs[3], "8 x MI355X sharded"; the C++
+// counterpart of qrkit_amd/sharding.py::ShardedBlockAngularQR; SURVEY.md 8(e) -- no reference site for the sharding itself).
+// One process per GPU.  Rank g holds a contiguous range of the tiles of the block-diagonal left block J1 and the rows of the dense
+// right block J2 that belong to them (any rows of J2 below J1 go to one rank).  compute (BlockAngularSparseQR.h:459-514):
+//   * J1_g = Q1_g R1_g and T = Q1_g^T J2_g on the rank, no exchange (:472-475, solveRightBlock :361-369); the strip S_g = T(0:m1_g, :)
+//     stays on the rank;
+//   * the rows of T below it are reduced ON THE RANK to one m2 x m2 triangle (qrk_tsqr_*: un-pivoted CAQR on the matrix cores);
+//   * the root gathers `world` triangles (m2^2 doubles each: qrk_gather_equal), stacks them and runs the pivoted right solver on
+//     the stack -- tall-skinny QR across ranks: the Gram structure of the columns, hence Eigen's pivots, is that of the un-sharded block;
+//   * the permutation P2 of the right block goes back to every rank (qrk_bcast).
+// solve (_solve_impl :202-227) follows the same route with one m2-vector per rank up and z2 down; every rank gets the entries of x
+// of its own tiles and the m2 entries of the right block.
+template <typename LeftSolver = BlockDiagonalSparseQR<> >
+class ShardedBlockAngularSparseQR {
+  public:
+    ShardedBlockAngularSparseQR(int rank, int world, void* ncclComm, int device = 0, int root = 0)
+        : m_rank(rank), m_world(world), m_root(root), m_comm(ncclComm), m_leftSolver(device), m_handle(0), m_tsqr(0) {
+        if (world <= 0 || rank < 0 || rank >= world || root < 0 || root >= world) throw std::runtime_error("qrkit: ShardedBlockAngularSparseQR: bad rank / world / root");
+        if (qrk_create(&m_handle, device, 0) != QRK_STATUS_OK) throw std::runtime_error("qrkit: ShardedBlockAngularSparseQR: no device");
+    }
+    ~ShardedBlockAngularSparseQR() {
+        m_right.release();
+        if (m_tsqr) qrk_tsqr_plan_destroy(m_tsqr);
+        for (void* p : {m_dS, m_dBottom, m_dP2}) if (p) qrk_device_free(m_handle, p);
+        if (m_handle) qrk_destroy(m_handle);
+    }
+    ShardedBlockAngularSparseQR(const ShardedBlockAngularSparseQR&) = delete;
+    ShardedBlockAngularSparseQR& operator=(const ShardedBlockAngularSparseQR&) = delete;
+
+    // localLeft: this rank's tiles of J1; localRight: this rank's rows of J2 (rows >= localLeft.rows(), m2 columns)
+    void compute(const SparseBlockDiagonal& localLeft, const Matrix& localRight) {
+        const int64_t D = (int64_t)sizeof(double);
+        m_n1 = localLeft.rows(); m_m1 = localLeft.cols(); m_m2 = localRight.cols();
+        const Index nloc = localRight.rows();
+        if (nloc < m_n1) throw std::runtime_error("qrkit: ShardedBlockAngularSparseQR: the right block has fewer rows than the left one");
+        m_leftSolver.compute(localLeft);
+        m_info = m_leftSolver.info();
+        if (m_info != Success) throw std::runtime_error("qrkit: ShardedBlockAngularSparseQR: the left solver failed (a collective would hang)");
+        m_nb = nloc - m_m1;                                           // rows of this rank's bottom block
+        freeBuf(m_dS); freeBuf(m_dBottom);
+        // T = Q1^T (rowPerm1 J2.top(n1)) on the device
+        Buf dTop(m_handle, m_n1 * m_m2), dT(m_handle, m_n1 * m_m2);
+        {
+            const std::vector<int>& rp = m_leftSolver.rowsPermutation().indices();
+            Matrix top(m_n1, m_m2);
+            for (Index j = 0; j < m_m2; ++j) for (Index i = 0; i < m_n1; ++i) top(rp[(size_t)i], j) = localRight(i, j);
+            check(qrk_memcpy(m_handle, dTop.p, top.data(), m_n1 * m_m2 * D, 0));
+        }
+        m_leftSolver.applyQDevice(dTop.ptr(), m_m2, dT.ptr(), true);
+        check(qrk_device_alloc(m_handle, std::max<int64_t>(m_m1 * m_m2 * D, 8), &m_dS));
+        check(qrk_memcpy_2d(m_handle, m_dS, m_m1 * D, dT.ptr(), m_n1 * D, m_m1 * D, m_m2, 2));
+        // bottom_g = [T(m1:n1, :); J2 below J1], m_nb x m2, column-major
+        const Index ldb = std::max<Index>(m_nb, m_m2);                 // (fewer rows than columns: zero rows below, see below)
+        check(qrk_device_alloc(m_handle, std::max<int64_t>(ldb * m_m2 * D, 8), &m_dBottom));
+        if (ldb > m_nb) {
+            Vector zeros((size_t)(ldb * m_m2), 0.0);
+            check(qrk_memcpy(m_handle, m_dBottom, zeros.data(), ldb * m_m2 * D, 0));
+        }
+        if (m_n1 > m_m1) check(qrk_memcpy_2d(m_handle, m_dBottom, ldb * D, dT.ptr() + m_m1, m_n1 * D, (m_n1 - m_m1) * D, m_m2, 2));
+        if (nloc > m_n1) {
+            Matrix below(nloc - m_n1, m_m2);
+            for (Index j = 0; j < m_m2; ++j) for (Index i = m_n1; i < nloc; ++i) below(i - m_n1, j) = localRight(i, j);
+            check(qrk_memcpy_2d(m_handle, (double*)m_dBottom + (m_n1 - m_m1), ldb * D, below.data(), (nloc - m_n1) * D, (nloc - m_n1) * D, m_m2, 0));
+        }
+        // its triangle: un-pivoted CAQR on the rank (with fewer rows than columns the rows themselves, zero-padded, are the "triangle")
+        Buf tri(m_handle, m_m2 * m_m2);
+        m_reduced = m_nb >= m_m2;
+        if (m_reduced) {
+            if (m_tsqr) { qrk_tsqr_plan_destroy(m_tsqr); m_tsqr = 0; }
+            check(qrk_tsqr_plan_create(m_handle, (int32_t)m_nb, (int32_t)m_m2, &m_tsqr));
+            check(qrk_tsqr_factorize(m_tsqr, (double*)m_dBottom, ldb, QRK_MEM_DEVICE));
+            Vector host((size_t)(m_m2 * m_m2));
+            check(qrk_memcpy_2d(m_handle, host.data(), m_m2 * D, m_dBottom, ldb * D, m_m2 * D, m_m2, 1));
+            for (Index j = 0; j < m_m2; ++j) for (Index i = j + 1; i < m_m2; ++i) host[(size_t)(j * m_m2 + i)] = 0.0;     // (reflectors below R0)
+            check(qrk_memcpy(m_handle, tri.p, host.data(), m_m2 * m_m2 * D, 0));
+        } else {
+            check(qrk_memcpy_2d(m_handle, tri.p, m_m2 * D, m_dBottom, ldb * D, m_m2 * D, m_m2, 2));
+        }
+        // the triangles to the root, the pivoted right solver on their stack there, P2 back
+        Buf parts(m_handle, m_rank == m_root ? (Index)m_world * m_m2 * m_m2 : 1);
+        check(qrk_gather_equal(m_handle, m_comm, m_rank, m_world, m_root, tri.ptr(), m_m2 * m_m2, parts.ptr()));
+        check(qrk_synchronize(m_handle));
+        if (!m_dP2) check(qrk_device_alloc(m_handle, std::max<int64_t>(m_m2 * (int64_t)sizeof(int32_t), 8), &m_dP2));
+        m_P2.assign((size_t)m_m2, 0);
+        if (m_rank == m_root) {
+            const Index sr = (Index)m_world * m_m2;
+            void* stack = m_right.acquireBuffer(m_handle, sr, m_m2);
+            for (int g = 0; g < m_world; ++g)
+                check(qrk_memcpy_2d(m_handle, (double*)stack + g * m_m2, sr * D, parts.ptr() + (Index)g * m_m2 * m_m2, m_m2 * D, m_m2 * D, m_m2, 2));
+            std::vector<int32_t> p2;
+            m_right.factorizeDevice(m_handle, stack, sr, m_m2, QRK_COLPIV_HOUSEHOLDER, m_hc, p2);
+            for (Index j = 0; j < m_m2; ++j) m_P2[(size_t)j] = p2[(size_t)j];
+            check(qrk_memcpy(m_handle, m_dP2, m_P2.data(), m_m2 * (int64_t)sizeof(int32_t), 0));
+        }
+        check(qrk_bcast(m_handle, m_comm, m_rank, m_world, m_root, m_dP2, m_m2 * (int64_t)sizeof(int32_t)));
+        check(qrk_synchronize(m_handle));
+        check(qrk_memcpy(m_handle, m_P2.data(), m_dP2, m_m2 * (int64_t)sizeof(int32_t), 1));
+        m_isInitialized = true;
+    }
+    ComputationInfo info() const { return m_info; }
+    const LeftSolver& leftSolver() const { return m_leftSolver; }
+    // colsPermutation() of the right block: column j of (J2 P2) is column colsPermutationRight()[j] of J2 -- the same on every rank
+    const std::vector<int>& colsPermutationRight() const { return m_P2; }
+
+    // Least squares: b_local = this rank's rows of the right-hand side.  x1_local: the entries of x that belong to this rank's tiles
+    // (in the order of its columns of J1), x2: the m2 entries of the right block (on every rank).
+    void solve(const Vector& b_local, Vector& x1_local, Vector& x2) const {
+        assert(m_isInitialized && "The factorization should be called first, use compute()");
+        const int64_t D = (int64_t)sizeof(double);
+        const Index nloc = m_m1 + m_nb, ldb = std::max<Index>(m_nb, m_m2);
+        assert((Index)b_local.size() == nloc);
+        Buf b(m_handle, m_n1), y(m_handle, m_n1), yb(m_handle, ldb), t(m_handle, m_m2);
+        {
+            const std::vector<int>& rp = m_leftSolver.rowsPermutation().indices();
+            Vector top((size_t)m_n1);
+            for (Index i = 0; i < m_n1; ++i) top[(size_t)rp[(size_t)i]] = b_local[(size_t)i];
+            check(qrk_memcpy(m_handle, b.p, top.data(), m_n1 * D, 0));
+        }
+        m_leftSolver.applyQDevice(b.ptr(), 1, y.ptr(), true);
+        {
+            Vector host((size_t)ldb, 0.0), ytop((size_t)m_n1);
+            check(qrk_memcpy(m_handle, ytop.data(), y.p, m_n1 * D, 1));
+            for (Index i = m_m1; i < m_n1; ++i) host[(size_t)(i - m_m1)] = ytop[(size_t)i];
+            for (Index i = m_n1; i < nloc; ++i) host[(size_t)(i - m_m1)] = b_local[(size_t)i];
+            check(qrk_memcpy(m_handle, yb.p, host.data(), ldb * D, 0));
+        }
+        if (m_reduced) check(qrk_tsqr_apply_q(m_tsqr, (const double*)m_dBottom, ldb, 1, yb.ptr(), ldb, 1, QRK_MEM_DEVICE));
+        check(qrk_memcpy_2d(m_handle, t.p, m_m2 * D, yb.p, ldb * D, m_m2 * D, 1, 2));
+        Buf parts(m_handle, m_rank == m_root ? (Index)m_world * m_m2 : 1), z2(m_handle, m_m2);
+        check(qrk_gather_equal(m_handle, m_comm, m_rank, m_world, m_root, t.ptr(), m_m2, parts.ptr()));
+        check(qrk_synchronize(m_handle));
+        if (m_rank == m_root) {
+            m_right.applyQDevice(parts.ptr(), 1, true);               // (the stack of the m2-vectors, in the order of the triangles)
+            check(qrk_memcpy_2d(m_handle, z2.p, m_m2 * D, parts.p, m_m2 * D, m_m2 * D, 1, 2));
+            m_right.solveRDevice(z2.ptr(), m_m2, 1);
+        }
+        check(qrk_bcast(m_handle, m_comm, m_rank, m_world, m_root, z2.p, m_m2 * D));
+        check(qrk_synchronize(m_handle));
+        // z1 = R1^-1 (y1 - S(:, P2) z2) on the device; x1 = colsPermutation1 * z1, x2 = P2 * z2
+        check(qrk_dense_gemv_sub(m_handle, (const double*)m_dS, m_m1, m_m1, m_m2, (const int32_t*)m_dP2, z2.ptr(), y.ptr()));
+        check(qrk_synchronize(m_handle));
+        Buf z1(m_handle, m_m1);
+        m_leftSolver.solveRDevice(y.ptr(), 1, z1.ptr());
+        Vector hz1((size_t)m_m1), hz2((size_t)m_m2);
+        check(qrk_memcpy(m_handle, hz1.data(), z1.p, m_m1 * D, 1));
+        check(qrk_memcpy(m_handle, hz2.data(), z2.p, m_m2 * D, 1));
+        x1_local = m_leftSolver.colsPermutation() * hz1;
+        x2.assign((size_t)m_m2, 0.0);
+        for (Index j = 0; j < m_m2; ++j) x2[(size_t)m_P2[(size_t)j]] = hz2[(size_t)j];
+    }
+
+  protected:
+    struct Buf {                 // scoped device buffer of doubles
+        qrk_handle h; void* p;
+        Buf(qrk_handle hh, Index count) : h(hh), p(0) {
+            if (qrk_device_alloc(h, std::max<int64_t>(count, 1) * (int64_t)sizeof(double), &p) != QRK_STATUS_OK)
+                throw std::runtime_error(std::string("qrkit: ") + qrk_last_error(h));
+        }
+        ~Buf() { if (p) qrk_device_free(h, p); }
+        double* ptr() const { return (double*)p; }
+        Buf(const Buf&) = delete;
+        Buf& operator=(const Buf&) = delete;
+    };
+    void freeBuf(void*& p) { if (p) { qrk_device_free(m_handle, p); p = 0; } }
+    void check(qrk_status st) const {
+        if (st != QRK_STATUS_OK) throw std::runtime_error(std::string("qrkit: ") + qrk_last_error(m_handle));
+    }
+    int m_rank, m_world, m_root;
+    void* m_comm;
+    LeftSolver m_leftSolver;
+    qrk_handle m_handle;
+    qrk_tsqr_plan m_tsqr;
+    mutable DenseDeviceQR m_right;      // root only: the pivoted QR of the stacked triangles
+    ComputationInfo m_info = Success;
+    bool m_isInitialized = false, m_reduced = false;
+    Index m_n1 = 0, m_m1 = 0, m_m2 = 0, m_nb = 0;
+    void *m_dS = 0, *m_dBottom = 0, *m_dP2 = 0;
+    std::vector<double> m_hc;
+    std::vector<int> m_P2;
+};
+
 }  // namespace qrkit
 
 // The reference's namespace and template parameter lists (src/QRKit/*.h), so that code written against QRKit compiles against

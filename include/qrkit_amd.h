@@ -449,6 +449,15 @@ qrk_status qrk_shard_ranges(int64_t num_blocks, int32_t block_rows, int32_t bloc
 qrk_status qrk_gather_r(qrk_handle h, void* nccl_comm, int32_t rank, int32_t world, int32_t root, const qrk_shard* shards,
                         const double* r_local, const int32_t* perm_local, double* r_all, int32_t* perm_all);
 
+/* The two exchanges of the ANGULAR solver sharded by rows (the TSQR route of qrk_tsqr_* above; BlockAngularSparseQR.h:361-369, 459-514;
+ * host side: qrkit::ShardedBlockAngularSparseQR, qrkit_amd/sharding.py): every rank's `count` doubles to `root` (recv: world * count
+ * doubles on the root, piece g at g * count; one n x n triangle, or one n-vector, per rank), and `bytes` bytes at `buf` from `root` to
+ * every rank (the permutation of the right block, z2).  Device memory, the handle's stream, grouped ncclSend / ncclRecv on the caller's
+ * communicator exactly as qrk_gather_r.  Collective: every rank calls them with the same world / root / count / bytes. */
+qrk_status qrk_gather_equal(qrk_handle h, void* nccl_comm, int32_t rank, int32_t world, int32_t root, const double* send, int64_t count,
+                            double* recv);
+qrk_status qrk_bcast(qrk_handle h, void* nccl_comm, int32_t rank, int32_t world, int32_t root, void* buf, int64_t bytes);
+
 /* ------------------------------------------------------------- measurement */
 
 /* Launch the factorisation kernel(s) of `plan` `iters` times back to back on the

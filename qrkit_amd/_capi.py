@@ -26,7 +26,7 @@ EXPORTS = (
     "qrk_bd_tiles_from_sparse", "qrk_bd_factorize", "qrk_bd_info", "qrk_bd_apply_qt", "qrk_bd_apply_q", "qrk_bd_solve", "qrk_bd_solve_r", "qrk_dense_plan_create",
     "qrk_dense_plan_destroy", "qrk_dense_factorize", "qrk_dense_plan_set_two_stage", "qrk_dense_plan_two_stage", "qrk_dense_apply_q", "qrk_bb_plan_create", "qrk_bb_plan_destroy", "qrk_bb_plan_create_fixed", "qrk_bb_blocks_from_pattern", "qrk_bb_analyze_host",
     "qrk_bb_plan_info", "qrk_bb_plan_blocks", "qrk_bb_pattern", "qrk_bb_factorize", "qrk_bb_apply_q", "qrk_bb_solve_r", "qrk_dense_solve_r", "qrk_bd_time_factorize", "qrk_bd_kernel_name",
-    "qrk_memcpy_2d", "qrk_dense_gemv_sub", "qrk_tsqr_plan_create", "qrk_tsqr_plan_destroy", "qrk_tsqr_factorize", "qrk_tsqr_apply_q",
+    "qrk_memcpy_2d", "qrk_dense_gemv_sub", "qrk_gather_equal", "qrk_bcast", "qrk_tsqr_plan_create", "qrk_tsqr_plan_destroy", "qrk_tsqr_factorize", "qrk_tsqr_apply_q",
     "qrk_sparse_window_to_dense",
     "qrk_thin_sparse_factorize", "qrk_thin_destroy", "qrk_thin_info", "qrk_thin_matrix_r", "qrk_thin_apply_q", "qrk_thin_solve",
     "qrk_bbs_plan_create", "qrk_bbs_plan_destroy", "qrk_bbs_plan_sizes", "qrk_bbs_factorize", "qrk_bbs_r_rows", "qrk_bbs_apply_q", "qrk_bbs_solve",

@@ -173,7 +173,14 @@ __device__ __forceinline__ void load_chunks(const double* hl, int lane, double (
 
 // One step of ColPivHouseholderQR::computeInPlace / HouseholderQR on both tiles of the wave (see bdqr_pair.hip for the arithmetic: squared
 // norms, un-normalised reflector, decisions).
-template <int K, bool PIVOT, bool HC>
+// OWN: the pivot lane itself sums the squares of its tail and computes the reflector's scalars while its column is on the way to LDS, and
+// s, ng travel with the column: the step loses the |x_tail|^2 hand-off (an LDS write and read behind the dot product) for 31 - K more
+// FMAs.  The sums are the same products in the same order as the pivot lane's dot product of the other form: bitwise the same factors.
+// Built in round 5 as a LATENCY form for small launches -- and measured the other way round (profiles/r05_k1_own_norm.txt): a launch of
+// at most one round is 2-4 % SLOWER with it (1 250 tiles 26.2 -> 27.1 us: the chain it removes is not the critical one there), a launch
+// of more than one round 1-1.6 % faster (10 000 tiles 72.3 -> 71.4 us, 100 000 tiles 581 -> 571: two LDS instructions fewer per step
+// where the LDS pipe is the co-bottleneck).  The launcher picks it for more than one round.
+template <int K, bool PIVOT, bool HC, bool OWN>
 __device__ __forceinline__ void step(double (&a)[WR], double* hl /* this half's LDS */, Lane& st)
 {
     const int lane = st.lane;
@@ -233,15 +240,49 @@ __device__ __forceinline__ void step(double (&a)[WR], double* hl /* this half's 
         //  keeps hipcc from merging them back)
         for (int i = K; i < WR; ++i) *(volatile lds_f64*)(&vcol[i]) = a[i];
 #endif
+        if (OWN) __builtin_amdgcn_sched_barrier(0);          // (the stores are issued BEFORE the arithmetic below, which they then hide)
+    }
+    double n2p = 0.0;                                       // (OWN) |x|^2 of the pivot column, in its lane
+    if (OWN) {
+        bool u = false;
+        if (ispiv) {
+            // the same products in the same order as the dot product of the column with itself (QRK_P4_DOT below)
+            double q0 = 0.0, q1 = 0.0;
+#define QRK_P4_SQ(I) if ((I) > K) { if ((I) & 1) q1 = fma(a[I], a[I], q1); else q0 = fma(a[I], a[I], q0); }
+            QRK_P4_0_31(QRK_P4_SQ)
+#undef QRK_P4_SQ
+            const double tsq = q0 + q1, xk = a[K];
+            n2p = fma(xk, xk, tsq);
+            const double a2 = (K == 0 && !PIVOT) ? n2p : st.a2;
+            const bool degenerate = !(tsq > DBL_MIN);
+            if (K + 1 < WR) u = degenerate | (xk * xk <= X0_TINY2 * a2);
+            if (PIVOT) u = u | (n2p <= PIV_TINY2 * a2);
+            const double nrm = sqrt_pos(n2p);
+            double nbv = __builtin_copysign(nrm, xk);        // beta = -nbv
+            double s = nbv + xk;
+            double ngp = recip(nbv * s);                     // -ng
+            if (degenerate) { nbv = -xk; s = 0.0; ngp = 0.0; }
+            *(volatile lds_f64*)(&hl[L_S + K]) = s;
+            *(volatile lds_f64*)(&hl[L_NG + K]) = ngp;
+            if (HC) hl[L_TAU + K] = (s * s) * ngp;
+        }
+        st.unclearm |= __builtin_amdgcn_ballot_w64(u);
+        if (K == 0 && !PIVOT) st.a2 = bpermute_f64((st.half << 5) << 2, n2p);      // (the pivot lane of step 0 is lane 0 of its half)
     }
     __builtin_amdgcn_wave_barrier();
     // ---- 3. the lanes' elements of it, x0
     double xc[2] = {0.0, 0.0};
-    double xk;
+    double xk = 0.0;
     constexpr int M0 = (K + 1) >> 4, MK = K >> 4;
     if (K + 1 < WR) load_chunks<K>(hl, lane, xc);
-    if (MK >= M0) xk = bcast_f64<(K & 15)>(xc[MK]);
-    else xk = hl[L_V + cb(K) + (K & 1)];                      // (row K is the last one of its chunk: not among the loaded ones)
+    double s = 0.0, ngp = 0.0;
+    if (OWN) {
+        s = *(const volatile lds_f64*)(&hl[L_S + K]);
+        ngp = *(const volatile lds_f64*)(&hl[L_NG + K]);
+    } else {
+        if (MK >= M0) xk = bcast_f64<(K & 15)>(xc[MK]);
+        else xk = hl[L_V + cb(K) + (K & 1)];                  // (row K is the last one of its chunk: not among the loaded ones)
+    }
     // ---- 4. d = x_tail^T a_tail of every column; the pivot lane's own is |x_tail|^2, handed to its half through LDS (the slot of
     // tau_K, which is written after it) -- no cross-lane sum
     const double ak = a[K];
@@ -252,43 +293,46 @@ __device__ __forceinline__ void step(double (&a)[WR], double* hl /* this half's 
     QRK_P4_0_31(QRK_P4_DOT)
 #undef QRK_P4_DOT
     const double dsum = d0 + d1;
-    double tsq = 0.0;
-    if (K + 1 < WR) {
-        if (ispiv) hl[L_TAU + K] = dsum;
-        __builtin_amdgcn_wave_barrier();
-        tsq = hl[L_TAU + K];
-        __builtin_amdgcn_wave_barrier();
-    }
-    if (K == 0 && !PIVOT) st.a2 = fma(xk, xk, tsq);
-    // (decide::unclear_reflector without short-circuit evaluation: three compares straight into wave masks, no control flow)
-    unsigned long long degm = 0ull;          // lanes whose tail is empty to rounding: !(tsq > DBL_MIN)
-    {
-        const double n2 = fma(xk, xk, tsq);
-        unsigned long long um = 0ull;
+    if (!OWN) {
+        double tsq = 0.0;
         if (K + 1 < WR) {
-            degm = __builtin_amdgcn_fcmp(tsq, DBL_MIN, 13 /* ULE */);
-            um = degm | __builtin_amdgcn_fcmp(xk * xk, X0_TINY2 * st.a2, 5 /* OLE */);
-        } else {
-            degm = ~0ull;
+            if (ispiv) hl[L_TAU + K] = dsum;
+            __builtin_amdgcn_wave_barrier();
+            tsq = hl[L_TAU + K];
+            __builtin_amdgcn_wave_barrier();
         }
-        if (PIVOT) um |= __builtin_amdgcn_fcmp(n2, PIV_TINY2 * st.a2, 5 /* OLE */);
-        st.unclearm |= um;
-    }
-    // ---- 5. makeHouseholder in the un-normalised form: nb = -beta = copysign(norm, x0), s = x0 - beta, ng = -1 / (beta (x0 - beta));
-    // Eigen: tailSqNorm <= min() gives tau = 0, beta = x0, H = I (rare: a real branch on a wave-level test, selects inside)
-    const double nrm = sqrt_pos(fma(xk, xk, tsq));
-    // (Eigen's test is x0 >= 0, which takes -0.0 as positive: a zero x0 with a tail is one of unclear_reflector's cases -- the tile is
-    //  redone by the exact path -- and without a tail the branch below overrides)
-    double nbv = __builtin_copysign(nrm, xk);                // beta = -nbv
-    double s = nbv + xk;
-    double ngp = recip(nbv * s);                             // -ng
-    if (__builtin_expect(degm != 0ull, 0)) {
-        asm volatile("");
-        if ((degm >> lane) & 1ull) { nbv = -xk; s = 0.0; ngp = 0.0; }
-    }
-    if (st.j == 0) {
-        hl[L_S + K] = s; hl[L_NG + K] = ngp;
-        if (HC) hl[L_TAU + K] = (s * s) * ngp;
+        if (K == 0 && !PIVOT) st.a2 = fma(xk, xk, tsq);
+        // (decide::unclear_reflector without short-circuit evaluation: three compares straight into wave masks, no control flow)
+        unsigned long long degm = 0ull;          // lanes whose tail is empty to rounding: !(tsq > DBL_MIN)
+        {
+            const double n2 = fma(xk, xk, tsq);
+            unsigned long long um = 0ull;
+            if (K + 1 < WR) {
+                degm = __builtin_amdgcn_fcmp(tsq, DBL_MIN, 13 /* ULE */);
+                um = degm | __builtin_amdgcn_fcmp(xk * xk, X0_TINY2 * st.a2, 5 /* OLE */);
+            } else {
+                degm = ~0ull;
+            }
+            if (PIVOT) um |= __builtin_amdgcn_fcmp(n2, PIV_TINY2 * st.a2, 5 /* OLE */);
+            st.unclearm |= um;
+        }
+        // ---- 5. makeHouseholder in the un-normalised form: nb = -beta = copysign(norm, x0), s = x0 - beta, ng = -1 / (beta (x0 - beta));
+        // Eigen: tailSqNorm <= min() gives tau = 0, beta = x0, H = I (rare: a real branch on a wave-level test, selects inside)
+        const double nrm = sqrt_pos(fma(xk, xk, tsq));
+        // (Eigen's test is x0 >= 0, which takes -0.0 as positive: a zero x0 with a tail is one of unclear_reflector's cases -- the tile is
+        //  redone by the exact path -- and without a tail the branch below overrides)
+        double nbv = __builtin_copysign(nrm, xk);                // beta = -nbv
+        double s_ = nbv + xk;
+        double ngp_ = recip(nbv * s_);                             // -ng
+        if (__builtin_expect(degm != 0ull, 0)) {
+            asm volatile("");
+            if ((degm >> lane) & 1ull) { nbv = -xk; s_ = 0.0; ngp_ = 0.0; }
+        }
+        if (st.j == 0) {
+            hl[L_S + K] = s_; hl[L_NG + K] = ngp_;
+            if (HC) hl[L_TAU + K] = (s_ * s_) * ngp_;
+        }
+        s = s_; ngp = ngp_;
     }
     const double ngam = fma(s, ak, dsum) * -ngp;             // -gamma of this column
     // R(K, K): in the pivot lane s x0 + |x_tail|^2 = beta (beta - x0), so its updated entry x0 - s (1 + delta) IS beta to a few ulp -- no
@@ -368,7 +412,7 @@ __device__ __noinline__ void redo_exact(int64_t t, double* lds, double* scratch,
 
 // PIVOT: ColPivHouseholderQR (else HouseholderQR).  HC: also emit the Householder coefficients.  One wave per workgroup, persistent over
 // the pairs blockIdx.x, blockIdx.x + gridDim.x, ..; scratch: p4::EXACT_SCRATCH doubles per workgroup (the exact path's working copy).
-template <bool PIVOT, bool HC>
+template <bool PIVOT, bool HC, bool OWN>
 __global__ void __launch_bounds__(64, 4)
 bdqr_pair4_kernel(int64_t num_tiles, const double* __restrict__ tiles, double* __restrict__ q_vals, double* __restrict__ r_vals,
                   int32_t* __restrict__ perm, double* __restrict__ hcoeffs, double* __restrict__ scratch)
@@ -490,9 +534,9 @@ bdqr_pair4_kernel(int64_t num_tiles, const double* __restrict__ tiles, double* _
                 st.thr = st.nu2 * THR_HI;
             }
 #if defined(QRK_P4_ABL) && (QRK_P4_ABL & 2)     // (timing ablation: every second pair of a wave skips steps 16..31 and back steps 31..16)
-#define QRK_P4_STEP(K) if ((K) < 16 || !(round & 1)) step<K, PIVOT, HC>(a, hl, st);
+#define QRK_P4_STEP(K) if ((K) < 16 || !(round & 1)) step<K, PIVOT, HC, OWN>(a, hl, st);
 #else
-#define QRK_P4_STEP(K) step<K, PIVOT, HC>(a, hl, st);
+#define QRK_P4_STEP(K) step<K, PIVOT, HC, OWN>(a, hl, st);
 #endif
             QRK_P4_0_31(QRK_P4_STEP)
 #undef QRK_P4_STEP
@@ -590,13 +634,19 @@ hipError_t launch_bdqr_pair4(int64_t num_tiles, int pivoting, const double* tile
     const int64_t npairs = (num_tiles + 1) / 2;
     const int64_t nwg = npairs < num_wg ? npairs : num_wg;
     const dim3 grid((unsigned)nwg), block(64);
-#define QRK_P4_LAUNCH(P, H) hipLaunchKernelGGL((bdqr_pair4_kernel<P, H>), grid, block, 0, stream, num_tiles, tiles, q_vals, r_vals, perm, hcoeffs, scratch)
+    // step<.., OWN> (the pivot lane's own norm) for launches of more than one round of the resident waves, see step; QRK_P4_OWN=0 / 1
+    // forces the choice (diagnostic)
+    bool own = npairs > (int64_t)num_wg;
+    if (const char* e = std::getenv("QRK_P4_OWN")) own = std::atoi(e) != 0;
+#define QRK_P4_LAUNCH(P, H, L) hipLaunchKernelGGL((bdqr_pair4_kernel<P, H, L>), grid, block, 0, stream, num_tiles, tiles, q_vals, r_vals, perm, hcoeffs, scratch)
+#define QRK_P4_LAUNCH2(P, H) do { if (own) QRK_P4_LAUNCH(P, H, true); else QRK_P4_LAUNCH(P, H, false); } while (0)
 #ifdef QRK_P4_STAMP
-    if (pivoting) QRK_P4_LAUNCH(true, false); else QRK_P4_LAUNCH(false, false);
+    if (pivoting) QRK_P4_LAUNCH2(true, false); else QRK_P4_LAUNCH2(false, false);
 #else
-    if (pivoting) { if (hcoeffs) QRK_P4_LAUNCH(true, true); else QRK_P4_LAUNCH(true, false); }
-    else { if (hcoeffs) QRK_P4_LAUNCH(false, true); else QRK_P4_LAUNCH(false, false); }
+    if (pivoting) { if (hcoeffs) QRK_P4_LAUNCH2(true, true); else QRK_P4_LAUNCH2(true, false); }
+    else { if (hcoeffs) QRK_P4_LAUNCH2(false, true); else QRK_P4_LAUNCH2(false, false); }
 #endif
+#undef QRK_P4_LAUNCH2
 #undef QRK_P4_LAUNCH
     return hipGetLastError();
 }

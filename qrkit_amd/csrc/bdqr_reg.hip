@@ -285,9 +285,22 @@ bdqr_reg_kernel(WaveBatch nb, const double* __restrict__ tiles, double* __restri
             // ---- 1. pivot
             int P = k, ppos = k;
             if (pivoting) {
-                Cand cd{live ? nu2 : -1.0, (pos << 8) | j};
-                cd = half_best(cd);
-                if (lane == 0) cands[wave] = make_double2(cd.val, __hiloint2double(0, cd.key));
+                // The wave's candidate.  Fast path (round 5): the largest HIGH WORD of the squared norms by an integer DPP max (four fused
+                // stages + one swap instead of five three-instruction f64 stages and five key stages); a lane that holds it ALONE holds the
+                // largest norm (a > b implies hi(a) >= hi(b)) and writes the candidate itself.  Several holders (norms within 2^-20 of each
+                // other, or no live column in the wave): the exact (norm, position) arg-max as before.
+                const double cv = live ? nu2 : -1.0;
+                const int khi = __double2hiint(cv);
+                const int mh = half32_max_i32_fused(khi);
+                const bool top = khi == mh;
+                const unsigned tm = (unsigned)__builtin_amdgcn_ballot_w64(top);      // (lanes 0..31: both halves hold the same columns)
+                if (__builtin_expect((tm & (tm - 1u)) == 0u && mh >= 0, 1)) {
+                    if (top && h == 0) cands[wave] = make_double2(cv, __hiloint2double(0, (pos << 8) | j));
+                } else {
+                    Cand cd{cv, (pos << 8) | j};
+                    cd = half_best(cd);
+                    if (lane == 0) cands[wave] = make_double2(cd.val, __hiloint2double(0, cd.key));
+                }
             }
             REG_TICK(1);
             lds_barrier();      // (also: every read of xv of the step before is done)
@@ -295,7 +308,29 @@ bdqr_reg_kernel(WaveBatch nb, const double* __restrict__ tiles, double* __restri
             if (pivoting) {
                 // lane l takes the candidate of wave l % 8: one LDS read, three DPP stages
                 const double2 cw = cands[lane & (NW - 1)];
-                const Cand bb = best8(Cand{cw.x, __double2loint(cw.y)});
+                Cand bb;
+                {
+                    // the same shortcut over the eight candidates: the wave whose candidate alone has the largest high word wins, and
+                    // its norm and key come out as scalars (v_readlane from that lane); otherwise the exact comparison
+                    const int ch = __double2hiint(cw.x);
+                    int cmx;
+                    asm("s_nop 1\n\t"
+                        "v_max_i32_dpp %0, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                        "s_nop 1\n\t"
+                        "v_max_i32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                        "s_nop 1\n\t"
+                        "v_max_i32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf"
+                        : "=&v"(cmx) : "v"(ch));
+                    const unsigned wm = (unsigned)__builtin_amdgcn_ballot_w64(ch == cmx) & (NW == 8 ? 0xffu : 0xfu);
+                    const int cm0 = __builtin_amdgcn_readfirstlane(cmx);
+                    if (__builtin_expect((wm & (wm - 1u)) == 0u && cm0 >= 0, 1)) {
+                        const int wl = __builtin_ctz(wm);
+                        bb.val = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(cw.x), wl), __builtin_amdgcn_readlane(__double2loint(cw.x), wl));
+                        bb.key = __builtin_amdgcn_readlane(__double2loint(cw.y), wl);
+                    } else {
+                        bb = best8(Cand{cw.x, __double2loint(cw.y)});
+                    }
+                }
                 P = bb.key & 255; ppos = bb.key >> 8;
                 if (k == 0) a2 = uniform_f64(bb.val);
                 if (live && j != P) {

@@ -2150,6 +2150,65 @@ const RcclApi& rccl_api()
 
 extern "C" {
 
+// Equal pieces to the root / one buffer from the root: the two exchanges of the angular solver sharded by rows (one n x n triangle per
+// rank up, the permutation of the right block down; BlockAngularSparseQR.h:361-369, 459-514 -- include/qrkit_amd.h).  Grouped
+// ncclSend / ncclRecv on the handle's stream like qrk_gather_r, whose caveat applies: the checks below depend only on arguments that
+// are the same on every rank, so that all ranks enter the group or none does.
+qrk_status qrk_gather_equal(qrk_handle h, void* nccl_comm, int32_t rank, int32_t world, int32_t root, const double* send, int64_t count,
+                            double* recv)
+{
+    if (!h || world <= 0 || rank < 0 || rank >= world || root < 0 || root >= world || count < 0 || (world > 1 && !nccl_comm))
+        return fail(h, QRK_STATUS_INVALID_ARGUMENT, "qrk_gather_equal: bad argument");
+    if (world > 1 && !rccl_api().ok) return fail(h, QRK_STATUS_UNSUPPORTED, "qrk_gather_equal: no RCCL in this process and librccl.so cannot be loaded");
+    QRK_HIP(h, hipSetDevice(h->device));
+    const bool local_ok = (count == 0 || send) && (rank != root || count == 0 || recv);
+    if (rank == root && local_ok && count > 0)
+        QRK_HIP(h, hipMemcpyAsync(recv + (int64_t)rank * count, send, (size_t)count * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    if (world > 1 && count > 0) {
+        const RcclApi& api = rccl_api();
+        ncclComm_t comm = static_cast<ncclComm_t>(nccl_comm);
+        ncclResult_t e = api.GroupStart();
+        if (e == ncclSuccess && local_ok) {
+            if (rank == root) {
+                for (int32_t peer = 0; peer < world && e == ncclSuccess; ++peer)
+                    if (peer != root) e = api.Recv(recv + (int64_t)peer * count, (size_t)count, ncclFloat64, peer, comm, h->stream);
+            } else {
+                e = api.Send(send, (size_t)count, ncclFloat64, root, comm, h->stream);
+            }
+        }
+        const ncclResult_t e2 = api.GroupEnd();
+        if (e != ncclSuccess || e2 != ncclSuccess)
+            return fail(h, QRK_STATUS_HIP_ERROR, std::string("qrk_gather_equal: RCCL: ") + (api.GetErrorString ? api.GetErrorString(e != ncclSuccess ? e : e2) : "error"));
+    }
+    if (!local_ok) return fail(h, QRK_STATUS_INVALID_ARGUMENT, "qrk_gather_equal: NULL buffer (this rank sent / received nothing: its peers wait)");
+    return QRK_STATUS_OK;
+}
+
+qrk_status qrk_bcast(qrk_handle h, void* nccl_comm, int32_t rank, int32_t world, int32_t root, void* buf, int64_t bytes)
+{
+    if (!h || world <= 0 || rank < 0 || rank >= world || root < 0 || root >= world || bytes < 0 || (world > 1 && !nccl_comm))
+        return fail(h, QRK_STATUS_INVALID_ARGUMENT, "qrk_bcast: bad argument");
+    if (world == 1 || bytes == 0) return QRK_STATUS_OK;
+    const RcclApi& api = rccl_api();
+    if (!api.ok) return fail(h, QRK_STATUS_UNSUPPORTED, "qrk_bcast: no RCCL in this process and librccl.so cannot be loaded");
+    QRK_HIP(h, hipSetDevice(h->device));
+    ncclComm_t comm = static_cast<ncclComm_t>(nccl_comm);
+    ncclResult_t e = api.GroupStart();
+    if (e == ncclSuccess && buf) {
+        if (rank == root) {
+            for (int32_t peer = 0; peer < world && e == ncclSuccess; ++peer)
+                if (peer != root) e = api.Send(buf, (size_t)bytes, ncclInt8, peer, comm, h->stream);
+        } else {
+            e = api.Recv(buf, (size_t)bytes, ncclInt8, root, comm, h->stream);
+        }
+    }
+    const ncclResult_t e2 = api.GroupEnd();
+    if (e != ncclSuccess || e2 != ncclSuccess)
+        return fail(h, QRK_STATUS_HIP_ERROR, std::string("qrk_bcast: RCCL: ") + (api.GetErrorString ? api.GetErrorString(e != ncclSuccess ? e : e2) : "error"));
+    if (!buf) return fail(h, QRK_STATUS_INVALID_ARGUMENT, "qrk_bcast: NULL buffer");
+    return QRK_STATUS_OK;
+}
+
 qrk_status qrk_gather_r(qrk_handle h, void* nccl_comm, int32_t rank, int32_t world, int32_t root, const qrk_shard* sh,
                         const double* r_local, const int32_t* perm_local, double* r_all, int32_t* perm_all)
 {

@@ -3,6 +3,7 @@
 // one-rank communicator is legal) -- the path bench.py's N > 1 legs and a C++ user on an 8-GPU node take, minus the peers.
 // The gathered R and permutation must equal the un-sharded solver's, bit for bit (same kernels, same tiles).
 #include <cstdio>
+#include <cmath>
 #include <cstring>
 #include <random>
 
@@ -79,6 +80,51 @@ int main() {
     for (size_t j = 0; ok && j < perm.size(); ++j) ok = perm[j] == whole.colsPermutation().indices()[j];
     std::printf("ShardedBlockDiagonalSparseQR world 1 over RCCL, %zu R values, %zu columns: %s\n", rv.size(), perm.size(), ok ? "Passed." : "Failed.");
     if (!ok) ++fails;
+
+    // ShardedBlockAngularSparseQR with world = 1 over the same communicator: 400 tiles of 8 x 6 on the left, 96 dense columns on the
+    // right, rows below the left block as well; the least-squares solution must be the un-sharded BlockAngularSparseQR's and the
+    // generating x, the permutation of the right block must be a permutation
+    {
+        const int nt = 400, br = 8, bc = 6, m2 = 96, extra = 50;
+        SparseBlockDiagonal left;
+        std::vector<Triplet> lt;
+        for (int i = 0; i < nt; ++i) {
+            Matrix m(br, bc);
+            for (Index e = 0; e < (Index)br * bc; ++e) m.data()[e] = u(g);
+            left.insertBack(m);
+            for (int c = 0; c < bc; ++c) for (int r = 0; r < br; ++r) lt.push_back(Triplet(i * br + r, i * bc + c, m(r, c)));
+        }
+        const Index n1 = (Index)nt * br, m1 = (Index)nt * bc, nrows = n1 + extra;
+        left.setDims((int)n1, (int)m1);
+        Matrix right(nrows, m2);
+        for (Index e = 0; e < nrows * m2; ++e) right.data()[e] = u(g);
+        Vector x((size_t)(m1 + m2));
+        for (double& v : x) v = u(g);
+        Vector b((size_t)nrows, 0.0);
+        for (const Triplet& t : lt) b[(size_t)t.row] += t.value * x[(size_t)t.col];
+        for (Index j = 0; j < m2; ++j) for (Index i = 0; i < nrows; ++i) b[(size_t)i] += right(i, j) * x[(size_t)(m1 + j)];
+        ShardedBlockAngularSparseQR<> sharded(0, 1, comm);
+        sharded.compute(left, right);
+        Vector x1, x2;
+        sharded.solve(b, x1, x2);
+        double num = 0.0, den = 0.0;
+        for (Index i = 0; i < m1; ++i) { const double dlt = x1[(size_t)i] - x[(size_t)i]; num += dlt * dlt; den += x[(size_t)i] * x[(size_t)i]; }
+        for (Index j = 0; j < m2; ++j) { const double dlt = x2[(size_t)j] - x[(size_t)(m1 + j)]; num += dlt * dlt; den += x[(size_t)(m1 + j)] * x[(size_t)(m1 + j)]; }
+        bool ok2 = std::sqrt(num) <= 1e-9 * std::sqrt(den);
+        std::vector<int> seen((size_t)m2, 0);
+        for (int v : sharded.colsPermutationRight()) { if (v < 0 || v >= m2 || seen[(size_t)v]++) ok2 = false; }
+        // the un-sharded solver on the same matrix: same pivots of the right block, same solution
+        BlockAngularSparseQR<BlockDiagonalSparseQR<>, ColPivHouseholderQR> whole2;
+        BlockMatrix1x2<SparseBlockDiagonal, Matrix> blk(left, right);
+        whole2.compute(blk);
+        const Vector xs = whole2.solve(whole2.rowsPermutation() * b);
+        double num2 = 0.0;
+        for (Index i = 0; i < m1 + m2; ++i) { const double dlt = xs[(size_t)i] - (i < m1 ? x1[(size_t)i] : x2[(size_t)(i - m1)]); num2 += dlt * dlt; }
+        ok2 = ok2 && std::sqrt(num2) <= 1e-9 * std::sqrt(den);
+        for (Index j = 0; ok2 && j < m2; ++j) ok2 = whole2.colsPermutation().indices()[(size_t)(m1 + j)] == (int)m1 + sharded.colsPermutationRight()[(size_t)j];
+        std::printf("ShardedBlockAngularSparseQR world 1 over RCCL, %d tiles + %d dense columns: %s\n", nt, m2, ok2 ? "Passed." : "Failed.");
+        if (!ok2) ++fails;
+    }
     ncclCommDestroy(comm);
     return fails;
 }
