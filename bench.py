@@ -270,6 +270,9 @@ def main():
     timing = {"batches": len(walls), "steps_per_batch": args.steps, "statistic": "median batch (wall clock around exactly --steps steps)",
               "batch_ms_per_step_min_median_max": [min(walls) / args.steps * 1e3, wall / args.steps * 1e3, max(walls) / args.steps * 1e3],
               "kernel_us_min_median_max": [min(kmss) * 1e3, sorted(kmss)[len(kmss) // 2] * 1e3, max(kmss) * 1e3],
+              "first_batch_ms_per_step": walls[0] / args.steps * 1e3,
+              "note": "value / ms_per_step are the MEDIAN batch since round 4; rounds 1-3 reported one batch of --steps steps: "
+                      "first_batch_ms_per_step is that statistic for like-for-like comparison across rounds",
               "timed_region_ms_total": sum(walls) * 1e3}
 
     # ---- outside the timed region: the kernel instantiation that was just timed (tau not stored) against the oracle

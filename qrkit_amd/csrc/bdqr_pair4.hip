@@ -624,6 +624,14 @@ bdqr_pair4_kernel(int64_t num_tiles, const double* __restrict__ tiles, double* _
     }
 }
 
+// step<.., OWN> (the pivot lane's own norm) for launches of more than one round of the resident waves, see step; QRK_P4_OWN=0 / 1 forces
+// the choice (diagnostic)
+bool bdqr_pair4_own_norm(int64_t num_tiles, int num_wg)
+{
+    if (const char* e = std::getenv("QRK_P4_OWN")) return std::atoi(e) != 0;
+    return (num_tiles + 1) / 2 > (int64_t)num_wg;
+}
+
 int64_t bdqr_pair4_scratch_doubles(int num_wg) { return (int64_t)num_wg * p4::EXACT_SCRATCH; }
 
 // Uniform 32 x 32 batches (any alignment).  num_wg: resident wave slots (16 per CU).
@@ -634,10 +642,7 @@ hipError_t launch_bdqr_pair4(int64_t num_tiles, int pivoting, const double* tile
     const int64_t npairs = (num_tiles + 1) / 2;
     const int64_t nwg = npairs < num_wg ? npairs : num_wg;
     const dim3 grid((unsigned)nwg), block(64);
-    // step<.., OWN> (the pivot lane's own norm) for launches of more than one round of the resident waves, see step; QRK_P4_OWN=0 / 1
-    // forces the choice (diagnostic)
-    bool own = npairs > (int64_t)num_wg;
-    if (const char* e = std::getenv("QRK_P4_OWN")) own = std::atoi(e) != 0;
+    const bool own = bdqr_pair4_own_norm(num_tiles, num_wg);
 #define QRK_P4_LAUNCH(P, H, L) hipLaunchKernelGGL((bdqr_pair4_kernel<P, H, L>), grid, block, 0, stream, num_tiles, tiles, q_vals, r_vals, perm, hcoeffs, scratch)
 #define QRK_P4_LAUNCH2(P, H) do { if (own) QRK_P4_LAUNCH(P, H, true); else QRK_P4_LAUNCH(P, H, false); } while (0)
 #ifdef QRK_P4_STAMP

@@ -209,6 +209,7 @@ struct qrk_dense_plan_s {
     bool tall = false;
     void* d_ws = nullptr;
     int G = 0, cpad = 0, rows_per = 0;
+    int pers_cus = 0;          // > 0: the column-parallel stage may run as ONE persistent launch (dense_qr_pers.hip, QRK_DENSE_PERS=1 at plan creation) on that many CUs
     bool persistent = false;   // the whole factorisation as ONE cooperative kernel (all slabs resident); QRK_DENSE_PERSISTENT=1 enables
     // exact path: copy of the input (rows x cols, restored when a decision of the fast kernels was not clear of rounding),
     // the flag word of the single-workgroup kernel, workspace of the exact kernel
@@ -1084,7 +1085,8 @@ qrk_status qrk_dense_plan_create(qrk_handle h, int32_t rows, int32_t cols, qrk_b
     p->cols_direct = p->tall && !p->two_stage && !p->caqr_only && !p->persistent && qrk::dense_cols_supported(rows, cols);
     if (const char* e = std::getenv("QRK_DENSE_PATH")) { if (!std::strcmp(e, "slabs")) p->cols_direct = false; }
     if (p->cols_direct) {
-        const size_t bytes2 = qrk::dense_cols_workspace_bytes(cols, &p->cpad2);
+        p->pers_cus = qrk::dense_pers_supported(rows, cols, h->num_cus) ? h->num_cus : 0;
+        const size_t bytes2 = qrk::dense_cols_workspace_bytes(cols, &p->cpad2, p->pers_cus > 0);
         if (hipMalloc((void**)&p->d_q1, (size_t)rows * (size_t)cols * sizeof(double)) != hipSuccess || hipMalloc(&p->d_ws2, bytes2) != hipSuccess) {
             qrk_dense_plan_destroy(p);
             return fail(h, QRK_STATUS_ALLOC_FAILED, "qrk_dense_plan_create: cannot allocate the workspaces of the column-parallel kernel");
@@ -1101,7 +1103,10 @@ qrk_status qrk_dense_plan_create(qrk_handle h, int32_t rows, int32_t cols, qrk_b
         if (const char* e = std::getenv("QRK_DENSE_STAGE2")) p->cols2 = p->cols2 && std::strcmp(e, "slabs") != 0;
         p->tall2 = !p->cols2 && (!fits2 || (int64_t)cols * cols >= 65536);
         size_t bytes2 = 0;
-        if (p->cols2) bytes2 = qrk::dense_cols_workspace_bytes(cols, &p->cpad2);
+        if (p->cols2) {
+            p->pers_cus = qrk::dense_pers_supported(cols, cols, h->num_cus) ? h->num_cus : 0;
+            bytes2 = qrk::dense_cols_workspace_bytes(cols, &p->cpad2, p->pers_cus > 0);
+        }
         else if (p->tall2) bytes2 = qrk::dense_tall_workspace_bytes(cols, cols, h->num_cus, &p->G2, &p->cpad2, &p->rows_per2);
         if (hipMalloc((void**)&p->d_t, qrk::caqr_t_bytes(rows, cols)) != hipSuccess ||
             hipMalloc((void**)&p->d_r0, (size_t)cols * (size_t)cols * sizeof(double)) != hipSuccess ||
@@ -1225,7 +1230,7 @@ qrk_status qrk_dense_factorize(qrk_dense_plan p, double* a, int64_t lda, double*
                                                   p->la_pipe.urgent ? &p->la_pipe : nullptr));
             QRK_HIP(h, qrk::launch_caqr_copy_upper(da, lda, p->d_r0, n, n, 1, h->stream));
             if (p->cols2) {
-                QRK_HIP(h, qrk::launch_dense_qr_cols(p->d_r0, n, n, n, piv2, dhc, dp, p->d_ws2, p->cpad2, p->d_q1, n, h->stream));
+                QRK_HIP(h, qrk::launch_dense_qr_cols(p->d_r0, n, n, n, piv2, dhc, dp, p->d_ws2, p->cpad2, p->d_q1, n, p->pers_cus, h->stream));
                 flag = qrk::dense_cols_unclear_ptr(p->d_ws2, p->cpad2);
             } else if (p->tall2) {
                 QRK_HIP(h, qrk::launch_dense_qr_tall(p->d_r0, n, n, n, piv2, dhc, dp, p->d_ws2, p->G2, p->cpad2, p->rows_per2, false, h->stream));
@@ -1249,7 +1254,7 @@ qrk_status qrk_dense_factorize(qrk_dense_plan p, double* a, int64_t lda, double*
         }
         if (!h->force_exact) {
             if (p->cols_direct) {
-                QRK_HIP(h, qrk::launch_dense_qr_cols(da, lda, p->rows, p->cols, piv, dhc, dp, p->d_ws2, p->cpad2, p->d_q1, p->rows, h->stream));
+                QRK_HIP(h, qrk::launch_dense_qr_cols(da, lda, p->rows, p->cols, piv, dhc, dp, p->d_ws2, p->cpad2, p->d_q1, p->rows, p->pers_cus, h->stream));
                 QRK_HIP(h, hipMemcpy2DAsync(da, (size_t)lda * sizeof(double), p->d_q1, (size_t)p->rows * sizeof(double),
                                             (size_t)p->rows * sizeof(double), (size_t)p->cols, hipMemcpyDeviceToDevice, h->stream));
                 flag = qrk::dense_cols_unclear_ptr(p->d_ws2, p->cpad2);
@@ -1664,6 +1669,20 @@ qrk_status qrk_thin_sparse_factorize(qrk_handle h, int32_t rows, int32_t cols, i
         QRK_THIN_HIP(hipMemcpyAsync(pack.data(), d_pack, (size_t)(1 + nnew) * sizeof(double), hipMemcpyDeviceToHost, h->stream));
         QRK_THIN_HIP(hipStreamSynchronize(h->stream));
         const int32_t nz = (int32_t)pack[0];               // nonzeroPivots() of the panel (BlockedThinSparseQR.h:250-256), counted on the device
+        if (k < nnew) {
+            // A panel with fewer rows than columns is factorised here with zero rows appended, for nnew steps; Eigen's
+            // ColPivHouseholderQR stops after k = min(rows, cols) steps and leaves the other columns where its k transpositions put
+            // them.  The steps beyond k pivot among columns that are zero up to the rounding of the norm downdates, so the order of
+            // the tail is restored from the first k choices: idx after the transpositions (q, position of the q-th chosen column).
+            // (The reference itself is outside its domain for such a panel: it reads matrixQR()(br, bc) for br up to bc, :275-277.)
+            std::vector<int32_t> idx((size_t)nnew), posof((size_t)nnew);
+            for (int32_t c = 0; c < nnew; ++c) idx[(size_t)c] = posof[(size_t)c] = c;
+            for (int32_t q = 0; q < k; ++q) {
+                const int32_t c = (int32_t)pack[(size_t)(1 + q)], b = posof[(size_t)c], o = idx[(size_t)q];
+                idx[(size_t)q] = c; idx[(size_t)b] = o; posof[(size_t)c] = q; posof[(size_t)o] = b;
+            }
+            for (int32_t c = k; c < nnew; ++c) pack[(size_t)(1 + c)] = (double)idx[(size_t)c];
+        }
         for (int32_t c = 0; c < nz; ++c) nnz_idx.push_back(c0 + (int32_t)pack[(size_t)(1 + c)]);
         for (int32_t c = nz; c < nnew; ++c) zero_idx.push_back(c0 + (int32_t)pack[(size_t)(1 + c)]);
         // update of the columns to the right (the rows of the panel and the zero rows below them): Q_panel^T in reflector form
@@ -2275,7 +2294,12 @@ const char* qrk_bd_kernel_name(qrk_bd_plan p, int which)
     if (p->uniform && p->max_dim <= 16 && p->r >= p->c && h->use_small_kernel)
         return piv ? "qrk::bdqr_small_kernel<G, true>" : "qrk::bdqr_small_kernel<G, false>";
     // (tau is not stored by the measurement entry point and by callers that pass hcoeffs = NULL: the <.., false> instantiation)
-    if (p->d_p4_scratch) return piv ? "qrk::bdqr_pair4_kernel<true, false>" : "qrk::bdqr_pair4_kernel<false, false>";
+    if (p->d_p4_scratch) {
+        // (third parameter: the own-norm step, which launch_bdqr_pair4 picks for more than one round of the resident waves)
+        const bool own = qrk::bdqr_pair4_own_norm(p->B, p->p4_wgs);
+        if (piv) return own ? "qrk::bdqr_pair4_kernel<true, false, true>" : "qrk::bdqr_pair4_kernel<true, false, false>";
+        return own ? "qrk::bdqr_pair4_kernel<false, false, true>" : "qrk::bdqr_pair4_kernel<false, false, false>";
+    }
     if (p->uniform && p->r == 32 && p->c == 32) return piv ? "qrk::bdqr_pair32_kernel<true, false>" : "qrk::bdqr_pair32_kernel<false, false>";
     return piv ? "qrk::bdqr_pair_kernel<false, true, true>" : "qrk::bdqr_pair_kernel<false, false, true>";
 }

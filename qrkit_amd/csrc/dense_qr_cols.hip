@@ -288,20 +288,13 @@ __global__ void cols_tail_perm_kernel(int c, int size, Work w, int32_t* __restri
 
 // (the persistent form of dense_qr_pers.hip shares the workspace: its synchronisation words and slots follow the tables)
 static size_t cols_tables_bytes(int cpad) { return ((size_t)cpad * (6 * sizeof(double) + 2 * sizeof(int)) + 256 + 255) / 256 * 256; }
-size_t dense_cols_workspace_bytes(int c, int* cpad_out)
+// pers: the plan may run the persistent form of dense_qr_pers.hip (opt-in, decided ONCE at plan creation: dense_pers_supported with
+// the handle's own CU count); only then does the workspace carry its 16.8 MB of synchronisation words and slots
+size_t dense_cols_workspace_bytes(int c, int* cpad_out, bool pers)
 {
     const int cpad = (c + 63) / 64 * 64;
     *cpad_out = cpad;
-    return cols_tables_bytes(cpad) + (c >= 256 ? dense_pers_workspace_bytes() : 0);
-}
-static int device_cus()
-{
-    static const int n = [] {
-        int dev = 0, v = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) v = 0;
-        return v;
-    }();
-    return n;
+    return cols_tables_bytes(cpad) + (pers ? dense_pers_workspace_bytes() : 0);
 }
 bool dense_cols_supported(int r, int c) { return r >= 1 && r <= 8000 && c >= 1; }
 int* dense_cols_unclear_ptr(void* workspace, int cpad)
@@ -314,13 +307,14 @@ int* dense_cols_unclear_ptr(void* workspace, int cpad)
 // A (r x c, column-major, r <= 8000) is the input and the scratch of the factorisation; `out` (ldo >= r) receives Eigen's packed QR
 // in pivoted column order, hcoeffs the tau, perm the column permutation.
 hipError_t launch_dense_qr_cols(double* A, int64_t lda, int r, int c, int pivoting, double* hcoeffs, int32_t* perm, void* workspace,
-                                int cpad, double* out, int64_t ldo, hipStream_t stream)
+                                int cpad, double* out, int64_t ldo, int pers_cus, hipStream_t stream)
 {
     using namespace cols;
     // up to 2048 x 2048: ONE persistent launch with the matrix in registers (dense_qr_pers.hip) instead of a launch per reflector
-    if (dense_pers_supported(r, c, device_cus()))
+    // (pers_cus > 0: the plan was created with the persistent form enabled and its workspace, for a device of that many CUs)
+    if (pers_cus > 0 && dense_pers_supported(r, c, pers_cus))
         return launch_dense_qr_pers(A, lda, r, c, pivoting, hcoeffs, perm, dense_cols_unclear_ptr(workspace, cpad) - 2 /* State: {double a2; int unclear} */,
-                                    static_cast<char*>(workspace) + cols_tables_bytes(cpad), device_cus(), out, ldo, stream);
+                                    static_cast<char*>(workspace) + cols_tables_bytes(cpad), pers_cus, out, ldo, stream);
     Work w;
     char* p = static_cast<char*>(workspace);
     for (int q = 0; q < 2; ++q) { w.nu2[q] = reinterpret_cast<double*>(p); p += (size_t)cpad * sizeof(double); }

@@ -46,6 +46,7 @@ struct TileGeom {
 // redo_count / redo_ids: list of tiles whose decisions were not clear of rounding (redone by launch_bdqr_exact)
 // bdqr_pair4.hip (QRK_PAIR_V2=0 disables): uniform 32 x 32 batches, two tiles per wavefront, four wavefronts per SIMD
 int64_t bdqr_pair4_scratch_doubles(int num_wg);
+bool bdqr_pair4_own_norm(int64_t num_tiles, int num_wg);
 hipError_t launch_bdqr_pair4(int64_t num_tiles, int pivoting, const double* tiles, double* q_vals, double* r_vals, int32_t* perm,
                              double* hcoeffs, double* scratch, int num_wg, hipStream_t stream);
 void launch_bdqr_pair(const WaveBatch& nb, bool full32, const double* tiles, double* q_vals,
@@ -131,11 +132,11 @@ size_t dense_pers_workspace_bytes();
 bool dense_pers_supported(int r, int c, int num_cus);
 hipError_t launch_dense_qr_pers(const double* A, int64_t lda, int r, int c, int pivoting, double* hcoeffs, int32_t* perm, void* state,
                                 void* workspace, int num_cus, double* out, int64_t ldo, hipStream_t stream);
-size_t dense_cols_workspace_bytes(int c, int* cpad);
+size_t dense_cols_workspace_bytes(int c, int* cpad, bool pers);
 bool dense_cols_supported(int r, int c);
 int* dense_cols_unclear_ptr(void* workspace, int cpad);
 hipError_t launch_dense_qr_cols(double* A, int64_t lda, int r, int c, int pivoting, double* hcoeffs, int32_t* perm, void* workspace,
-                                int cpad, double* out, int64_t ldo, hipStream_t stream);
+                                int cpad, double* out, int64_t ldo, int pers_cus, hipStream_t stream);
 // y(0:rows) -= sum_c S(:, colidx[c]) z[c] (bd_aux.hip): the strip term of the angular back substitution
 hipError_t launch_gemv_sub(const double* S, int64_t lds, int64_t rows, int64_t cols, const int32_t* colidx, const double* z, double* y,
                            hipStream_t stream);
