@@ -26,6 +26,10 @@
 #include <float.h>
 #include <cstdlib>
 
+#ifndef QRK_W64_OWN
+#define QRK_W64_OWN 1          // 1: the pivot lane sums the squares of its own tail and computes the reflector's scalars WHILE its column is on the
+#endif                         // way to LDS (s, ng, tau travel with the column): the DPP row sum of |x_tail|^2 and the square-root / reciprocal
+                               // chain leave the step's critical path, which the single-lane stores (650 cycles at 64 rows) cover
 #ifndef QRK_W64_PIPELINE
 #define QRK_W64_PIPELINE 0     // 1: the head of step k + 1 (search, publication) is issued before the trailing update of step k and the
                                // column goes out one update old (corrected on fetch).  Measured SLOWER (64 x 64: 14.4 vs 16.5 M tiles/s,
@@ -139,6 +143,8 @@ struct Lane {
     double thr;       // sqrt(eps) (1 + 2^-12) m_colNormsDirect^2
     double a2;        // |A|^2: squared norm of the first pivot column (scale of the decision margins); wave-uniform
     int P;            // pivot lane of the step whose head ran last (wave-uniform)
+    double betap;     // (QRK_W64_OWN) beta of the step in which this lane's column was chosen: its R(k, k)
+    double n2p;       // (QRK_W64_OWN) |x|^2 of that column
     double ngp;       // the coefficient the running step's pivot column got in the step before, if it was published before that update
 #ifdef QRK_W64_PROF
     unsigned long long pt[16], pt0;
@@ -162,7 +168,7 @@ __device__ __forceinline__ void load_chunks(const double* lds, int lane, double 
 // cycles per step when they sat on the chain, profiles/r04_w64_step_profile.txt), so the column goes out one update old; `stale`
 // says so and the fetch adds the missing rank-1 term (correct_chunks).
 template <int KP, bool PIVOT>
-__device__ __forceinline__ void search_publish(const double (&a)[WR], double* lds, Lane& st, const int k)
+__device__ __forceinline__ void search_publish(const double (&a)[WR], double* lds, Lane& st, const int k, const int rows)
 {
     const int lane = st.lane;
     int P;
@@ -199,6 +205,29 @@ __device__ __forceinline__ void search_publish(const double (&a)[WR], double* ld
         double* vcol = lds + L_V + cb(KP) - (KP & ~1);
 #pragma unroll
         for (int i = KP & ~1; i < WR; i += 2) *reinterpret_cast<double2*>(&vcol[i]) = make_double2(a[i], a[i + 1]);
+#if QRK_W64_OWN && !QRK_W64_PIPELINE
+        __builtin_amdgcn_sched_barrier(0);                 // (the stores go out BEFORE the arithmetic below, which they then cover)
+        // |x_tail|^2 from the lane's own registers, the decisions and makeHouseholder in the un-normalised form (see step)
+        double q0 = 0.0, q1 = 0.0;
+#define QRK_W64_SQ(I) if ((I) > KP) { if ((I) & 1) q1 = fma(a[I], a[I], q1); else q0 = fma(a[I], a[I], q0); }
+        QRK_W64_0_63(QRK_W64_SQ)
+#undef QRK_W64_SQ
+        const double tsq = q0 + q1, xk = a[KP];
+        st.n2p = fma(xk, xk, tsq);
+        if (unclear_reflector(xk, tsq, k + 1 < rows, PIVOT, (k == 0 && !PIVOT) ? st.n2p : st.a2)) st.unclear = true;
+        double beta, s, ng, tau;
+        if (!(tsq > DBL_MIN)) { beta = xk; s = 0.0; ng = 0.0; tau = 0.0; }
+        else {
+            const double nrm = sqrt_pos(st.n2p);
+            const double nbv = xk >= 0.0 ? nrm : -nrm;     // (-0.0 counts as >= 0, as in Eigen)
+            beta = -nbv;
+            s = nbv + xk;
+            ng = -recip(nbv * s);
+            tau = -(s * s) * ng;
+        }
+        st.betap = beta;
+        lds[L_S + KP] = s; lds[L_NG + KP] = ng; lds[L_TAU + KP] = tau;
+#endif
     }
 }
 
@@ -209,13 +238,23 @@ template <int KP, bool PIVOT>
 __device__ __forceinline__ void step(double (&a)[WR], double* lds, Lane& st, double (&xp)[4], const int k, const int rows, const int cols)
 {
     const int lane = st.lane;
-    if (!QRK_W64_PIPELINE) search_publish<KP, PIVOT>(a, lds, st, k);
+    if (!QRK_W64_PIPELINE) search_publish<KP, PIVOT>(a, lds, st, k, rows);
     const bool ispiv = lane == st.P;
     __builtin_amdgcn_wave_barrier();
     W64_TICK(1);
     // ---- 3. the lanes' elements of the pivot column (+ the rank-1 term of the step before, when it went out one update old; the
     // corrected elements go back to LDS: they are reflector k of phase 2), |x_tail|^2 (every row of 16 lanes the same sum in the
     // same order), x0
+#if QRK_W64_OWN && !QRK_W64_PIPELINE
+    // (the pivot lane has computed the reflector's scalars beside its stores: search_publish)
+    double xc[4] = {0.0, 0.0, 0.0, 0.0};
+    constexpr int M0 = (KP + 1) >> 4;
+    if (KP + 1 < WR) load_chunks<KP>(lds, lane, xc);
+    const double s = uniform_f64(lds[L_S + KP]), ng = uniform_f64(lds[L_NG + KP]);
+    const double beta = st.betap;                            // (meaningful in the pivot lane, the only one that uses it)
+    if (k == 0 && !PIVOT) st.a2 = readlane_f64(st.n2p, st.P);
+    W64_TICK(2);
+#else
     double xc[4] = {0.0, 0.0, 0.0, 0.0};
     double tsq = 0.0, xk;
     constexpr int M0 = (KP + 1) >> 4, MK = KP >> 4;
@@ -260,6 +299,7 @@ __device__ __forceinline__ void step(double (&a)[WR], double* lds, Lane& st, dou
         tau = -(s * s) * ng;
     }
     if (lane == 0) { lds[L_S + KP] = s; lds[L_NG + KP] = ng; lds[L_TAU + KP] = tau; }
+#endif
     W64_TICK(3);
     // ---- 5. d = x_tail^T a_tail, the coefficient of the column, row k of R
     const double ak = a[KP];
@@ -300,7 +340,7 @@ __device__ __forceinline__ void step(double (&a)[WR], double* lds, Lane& st, dou
     W64_TICK(5);
     // ---- 7. head of the next step, then the trailing update of this one
     if (KP + 1 < WR && k + 1 < cols) {
-        search_publish<(KP + 1 < WR ? KP + 1 : KP), PIVOT>(a, lds, st, k + 1);
+        search_publish<(KP + 1 < WR ? KP + 1 : KP), PIVOT>(a, lds, st, k + 1, rows);
         st.ngp = updated ? 0.0 : readlane_f64(ngam, st.P);
     }
     W64_TICK(0);
@@ -433,7 +473,7 @@ bdqr_w64_kernel(WaveBatch nb, const double* __restrict__ tiles, double* __restri
             W64_TICK(10);
             double xp[4] = {0.0, 0.0, 0.0, 0.0};
             st.ngp = 0.0; st.P = 0;
-#define QRK_W64_HEAD(KP) if (QRK_W64_PIPELINE && (KP) == off) search_publish<KP, PIVOT>(a, lds, st, 0);
+#define QRK_W64_HEAD(KP) if (QRK_W64_PIPELINE && (KP) == off) search_publish<KP, PIVOT>(a, lds, st, 0, r);
             QRK_W64_0_63(QRK_W64_HEAD)
 #undef QRK_W64_HEAD
 #define QRK_W64_STEP(KP) if ((KP) >= off && (KP) - off < c) step<KP, PIVOT>(a, lds, st, xp, (KP) - off, r, c);
