@@ -207,3 +207,40 @@ def test_hip_thin_sparse_pivot_at_the_rank_threshold(seed):
         np.testing.assert_array_equal(qr.colsPermutation().cpu().numpy(), ref.perm)
         seen.add(ref.rank)
     assert seen == {3, 4}
+
+
+def short_panel_problem(rows=120, cols=24, seed=11):
+    """Columns 0..3 are the four sparsest and only have entries in the same two rows.  (ColumnDensity's permutation maps column j to the
+    density RANK of column j, SparseQROrdering.h:43-46: the four columns of rank 0..3 stay in front exactly when they are columns 0..3.)
+    With block_cols = 4 the first panel is 2 x 4 -- fewer rows than columns."""
+    rng = np.random.default_rng(seed)
+    M = sp.lil_matrix(thin_sparse_problem(rows, cols, seed, density=0.35))
+    for j in (0, 1, 2, 3):
+        M[:, j] = 0.0
+        M[5, j] = rng.uniform(0.5, 5.0)
+        M[77, j] = rng.uniform(0.5, 5.0)
+    M = sp.csc_matrix(M)
+    M.eliminate_zeros()
+    return M
+
+
+def test_oracle_thin_sparse_short_panel_is_in_the_fixture_shape():
+    M = short_panel_problem()
+    ref = orc.bt_sparse_qr(M, 4)
+    assert ref.blocks[0][1].shape[0] == 2, "the first panel of the fixture is meant to have two rows"
+    assert sorted(ref.perm.tolist()) == list(range(M.shape[1]))
+
+
+@pytest.mark.gpu
+def test_hip_thin_sparse_panel_with_fewer_rows_than_columns():
+    """A panel with fewer rows than columns (round-4 advisor finding): Eigen's ColPivHouseholderQR stops after min(rows, cols) steps and
+    leaves the other columns where its transpositions put them; the device factorises the panel zero-padded for all its columns, so the
+    order of the tail is restored on the host from the first k choices.  Rank and both permutations against the oracle."""
+    import qrkit_amd
+    M = short_panel_problem()
+    ref = orc.bt_sparse_qr(M, 4)
+    qr = qrkit_amd.BlockedThinSparseQR(qrkit_amd.Context(0), 4)
+    qr.compute(M)
+    assert qr.rank() == ref.rank
+    np.testing.assert_array_equal(qr.colsPermutation().cpu().numpy(), ref.perm)
+    np.testing.assert_array_equal(qr.rowsPermutation().cpu().numpy(), ref.rowperm)
