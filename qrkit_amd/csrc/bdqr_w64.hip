@@ -404,7 +404,10 @@ __device__ __forceinline__ void back_step(double (&q)[WR], const double* lds, co
 // WPS: waves per SIMD the instantiation is compiled for.  The reflectors of a tile with r rows occupy the TAIL of the LDS layout
 // (cb(64 - r) ..): the launch allocates only what its tallest tile needs (lds_shift = the unused head, in doubles), and tiles of up to
 // 52 rows leave room for twelve waves per CU -- three per SIMD at the kernel's 167 registers -- instead of eight.
-template <bool PIVOT, int WPS>
+// R0: the first frame row the instantiation works on -- its tiles have at most WR - R0 rows, the row registers a[0 .. R0) do not exist for
+// the register allocator and the steps above R0 are not instantiated: R0 = 20 (tiles of 33 .. 44 rows) fits 128 VGPRs and 10 KB of LDS per
+// wave, FOUR waves per SIMD (round 5).
+template <bool PIVOT, int WPS, int R0>
 __global__ void __launch_bounds__(64, WPS)
 bdqr_w64_kernel(WaveBatch nb, const double* __restrict__ tiles, double* __restrict__ q_vals, double* __restrict__ r_vals,
                 int32_t* __restrict__ perm, double* __restrict__ hcoeffs, int32_t* __restrict__ redo_count,
@@ -456,7 +459,7 @@ bdqr_w64_kernel(WaveBatch nb, const double* __restrict__ tiles, double* __restri
                 // lane j reads its column (unconditional loads from clamped addresses, then a select)
                 const double* colp = tiles + toff + (int64_t)(isA ? lane : 0) * r;
 #pragma unroll
-                for (int i = 0; i < WR; ++i) {
+                for (int i = R0; i < WR; ++i) {
                     const int row = i - off;
                     const double v = colp[row > 0 ? row : 0];     // (plain loads: the 64 row loads of a lane share its cache lines; non-temporal: 16.5 -> 13 M tiles/s)
                     a[i] = (isA && row >= 0) ? v : 0.0;
@@ -465,7 +468,7 @@ bdqr_w64_kernel(WaveBatch nb, const double* __restrict__ tiles, double* __restri
             {
                 double s0 = 0.0, s1 = 0.0;
 #pragma unroll
-                for (int i = 0; i < WR; i += 2) { s0 = fma(a[i], a[i], s0); s1 = fma(a[i + 1], a[i + 1], s1); }
+                for (int i = R0; i < WR; i += 2) { s0 = fma(a[i], a[i], s0); s1 = fma(a[i + 1], a[i + 1], s1); }
                 const double s = s0 + s1;
                 st.nu2 = isA ? s : -1.0;
                 st.thr = s * SQRT_EPS_HI;
@@ -473,10 +476,10 @@ bdqr_w64_kernel(WaveBatch nb, const double* __restrict__ tiles, double* __restri
             W64_TICK(10);
             double xp[4] = {0.0, 0.0, 0.0, 0.0};
             st.ngp = 0.0; st.P = 0;
-#define QRK_W64_HEAD(KP) if (QRK_W64_PIPELINE && (KP) == off) search_publish<KP, PIVOT>(a, lds, st, 0, r);
+#define QRK_W64_HEAD(KP) if ((KP) >= R0 && QRK_W64_PIPELINE && (KP) == off) search_publish<KP, PIVOT>(a, lds, st, 0, r);
             QRK_W64_0_63(QRK_W64_HEAD)
 #undef QRK_W64_HEAD
-#define QRK_W64_STEP(KP) if ((KP) >= off && (KP) - off < c) step<KP, PIVOT>(a, lds, st, xp, (KP) - off, r, c);
+#define QRK_W64_STEP(KP) if ((KP) >= R0 && (KP) >= off && (KP) - off < c) step<KP, PIVOT>(a, lds, st, xp, (KP) - off, r, c);
             QRK_W64_0_63(QRK_W64_STEP)
 #undef QRK_W64_STEP
 
@@ -491,7 +494,7 @@ bdqr_w64_kernel(WaveBatch nb, const double* __restrict__ tiles, double* __restri
                 perm[cbase + p] = cbase + ln;
                 double* dst = r_vals + roff + ((p * (p + 1)) >> 1) - off;
 #pragma unroll
-                for (int i = 0; i < WR; ++i)
+                for (int i = R0; i < WR; ++i)
                     if (i >= off && i - off <= p) dst[i] = a[i];
                 if (hcoeffs) hcoeffs[cbase + ln] = lds[L_TAU + off + ln];
             }
@@ -507,8 +510,8 @@ bdqr_w64_kernel(WaveBatch nb, const double* __restrict__ tiles, double* __restri
             asm volatile("" : "+v"(ln));
             double q[WR];
 #pragma unroll
-            for (int i = 0; i < WR; ++i) q[i] = (i == ln + off) ? 1.0 : 0.0;       // (lanes >= rows: zero columns, never stored)
-#define QRK_W64_BACK(KP) if ((KP) >= off && (KP) - off < c) back_step<KP>(q, lds, ln, st);
+            for (int i = R0; i < WR; ++i) q[i] = (i == ln + off) ? 1.0 : 0.0;      // (lanes >= rows: zero columns, never stored)
+#define QRK_W64_BACK(KP) if ((KP) >= R0 && (KP) >= off && (KP) - off < c) back_step<KP>(q, lds, ln, st);
             QRK_W64_63_0(QRK_W64_BACK)
 #undef QRK_W64_BACK
             W64_TICK(15);
@@ -517,7 +520,7 @@ bdqr_w64_kernel(WaveBatch nb, const double* __restrict__ tiles, double* __restri
             if (ln < r) {
                 double* dst = q_vals + qoff + ln;
 #pragma unroll
-                for (int i = 0; i < WR; ++i)
+                for (int i = R0; i < WR; ++i)
                     if (i >= off) dst[(int64_t)(i - off) * r] = q[i];
             }
         }
@@ -549,16 +552,21 @@ hipError_t launch_bdqr_w64(const WaveBatch& nb, const double* tiles, double* q_v
     int shift = w64::cb(w64::WR - max_rows) - 16;
     if (shift < 0) shift = 0;
     const size_t lds_bytes = (size_t)(w64::L_TOTAL - shift) * sizeof(double);
-    static const bool three = !(std::getenv("QRK_W64_WPS") && std::atoi(std::getenv("QRK_W64_WPS")) == 2);
-    int per_cu = (int)((size_t)(160 * 1024) / lds_bytes);     // waves of one CU by LDS: 8 (64 rows) .. 12 (the register file's limit)
-    per_cu = !three ? 8 : (per_cu > 12 ? 12 : (per_cu < 8 ? 8 : per_cu));
-    const bool wps3 = per_cu > 8;
+    static const int wps_env = std::getenv("QRK_W64_WPS") ? std::atoi(std::getenv("QRK_W64_WPS")) : 0;      // (diagnostic: 2 / 3 cap the occupancy)
+    int per_cu = (int)((size_t)(160 * 1024) / lds_bytes);     // waves of one CU by LDS: 8 (64 rows) .. 16
+    const int cap = wps_env == 2 ? 8 : (wps_env == 3 ? 12 : 16);
+    per_cu = per_cu > cap ? cap : (per_cu < 8 ? 8 : per_cu);
+    // four waves per SIMD: the instantiation without the frame rows above 20 (tiles of at most 44 rows), whose LDS leaves room for 16 waves
+    const bool wps4 = per_cu >= 16 && max_rows <= w64::WR - 20;
+    if (!wps4 && per_cu > 12) per_cu = 12;
+    const bool wps3 = !wps4 && per_cu > 8;
+    if (wps3) per_cu = 12; else if (!wps4) per_cu = 8;
     const int64_t num_wg = (int64_t)num_cus * per_cu;
     const int64_t want = nb.num_tiles < num_wg ? nb.num_tiles : num_wg;
-#define QRK_W64_LAUNCH(P, W) hipLaunchKernelGGL((bdqr_w64_kernel<P, W>), dim3((unsigned)want), dim3(64), lds_bytes, stream, nb, tiles, q_vals, \
-                                                r_vals, perm, hcoeffs, redo_count, redo_ids, queue, shift)
-    if (nb.pivoting) { if (wps3) QRK_W64_LAUNCH(true, 3); else QRK_W64_LAUNCH(true, 2); }
-    else { if (wps3) QRK_W64_LAUNCH(false, 3); else QRK_W64_LAUNCH(false, 2); }
+#define QRK_W64_LAUNCH(P, W, R) hipLaunchKernelGGL((bdqr_w64_kernel<P, W, R>), dim3((unsigned)want), dim3(64), lds_bytes, stream, nb, tiles, q_vals, \
+                                                   r_vals, perm, hcoeffs, redo_count, redo_ids, queue, shift)
+    if (nb.pivoting) { if (wps4) QRK_W64_LAUNCH(true, 4, 20); else if (wps3) QRK_W64_LAUNCH(true, 3, 0); else QRK_W64_LAUNCH(true, 2, 0); }
+    else { if (wps4) QRK_W64_LAUNCH(false, 4, 20); else if (wps3) QRK_W64_LAUNCH(false, 3, 0); else QRK_W64_LAUNCH(false, 2, 0); }
 #undef QRK_W64_LAUNCH
     return hipGetLastError();
 }
