@@ -1,0 +1,427 @@
+// bdqr_quad.hip -- uniform batches of tiles with 9 .. 16 rows (cols <= rows), FOUR tiles per wavefront: A_i P_i = Q_i R_i with explicit
+// Q_i, for gfx950.  The design of bdqr_pair4.hip (round 4 / 5) at 16 rows; round 5.
+//
+// Same reference seam as the other block-diagonal kernels: the body of the hot loop of QRKit::BlockDiagonalSparseQR::factorize
+// (src/QRKit/BlockDiagonalSparseQR.h:432-526): blockSolver.compute(block) (:437-438, Eigen ColPivHouseholderQR / HouseholderQR),
+// Qi = blockSolver.matrixQ() (:446), the Q / R value assembly (:455-500) and the column-permutation splice (:519-521).
+//
+// Why.  bdqr_small.hip gives a tile of up to 16 rows a group of 16 lanes that carries A and Q^T TOGETHER (64 data registers) and moves
+// the pivot column through ds_bpermute (2 (16 - k) LDS-pipe instructions per step): 16 x 16 ran at 0.24 of the HBM roofline with 167
+// registers, three waves per SIMD.  Here:
+//   * lane 16 g + j owns column j of tile g in 16 row registers -- a tile is exactly one DPP row;
+//   * the pivot lane of each tile publishes its column to LDS (8-byte stores of four lanes at once), every lane takes element
+//     lane & 15 and the dot / update FMAs read it through the DPP row_newbcast operand -- no register of the broadcast, no bpermute;
+//   * two phases in the same registers: A -> R, then Q = H_0 ... H_{c-1} by backward accumulation from the reflectors in LDS;
+//   * 32 data registers, 1.5 KB of LDS per tile: more waves per SIMD than the LDS pipe can use.
+// Tiles with fewer than 16 rows are zero-padded below (zero rows change neither the reflectors nor any sum); the steps run to the
+// launch's number of columns.  Decisions exactly as bdqr_pair.hip ("Decisions and the exact path"): integer arg-max on the high
+// words with a filter, margins, LAWN-176 band, degenerate reflector, sign of beta, noise-level pivot; a flagged tile goes to the redo
+// list of the exact path (bdqr_exact.hip), like bdqr_small.hip's.
+#include "qrk_device.h"
+
+#include <float.h>
+
+namespace qrk {
+
+namespace q16 {
+
+using namespace decide;
+
+constexpr int WR = 16;
+constexpr int FILTER = 256;              // pivot candidates: high word of the squared norm within 2^-12 (relative) of the largest
+// LDS per TILE (doubles): reflector K (the pivot column of step K, as published) holds rows K .. 15 at cb(K)
+constexpr int cb(int k) { int s = 0; for (int q = 0; q < k; ++q) s += WR - q; return s; }
+constexpr int L_V = 0;
+constexpr int L_S = cb(WR);              // [16] s = x0 - beta
+constexpr int L_NG = L_S + WR;           // [16] 1 / (beta (beta - x0))
+constexpr int L_TAU = L_NG + WR;         // [16] tau; before that, the hand-off word of |x_tail|^2 of the step
+constexpr int L_TILE = L_TAU + WR;       // 184 doubles = 1 472 B per tile, 5 888 B per wave
+static_assert(cb(WR) == 136, "the triangle of the reflectors");
+
+typedef __attribute__((address_space(3))) double lds_f64;      // (volatile accesses through a generic pointer would become flat_*)
+
+#define QRK_Q16_0_15(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9) M(10) M(11) M(12) M(13) M(14) M(15)
+#define QRK_Q16_15_0(M) M(15) M(14) M(13) M(12) M(11) M(10) M(9) M(8) M(7) M(6) M(5) M(4) M(3) M(2) M(1) M(0)
+
+__device__ __forceinline__ double sqrt_pos(double x)      // <= 1 ulp for positive normal x (bdqr_pair.hip)
+{
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = 0.5 * y;
+    const double e = fma(-h, g, 0.5);
+    g = fma(g, e, g);
+    h = fma(h, e, h);
+    const double d = fma(-g, g, x);
+    return fma(d, h, g);
+}
+__device__ __forceinline__ double recip(double x)
+{
+    double y = __builtin_amdgcn_rcp(x);
+    double e = fma(-x, y, 1.0);
+    y = fma(y, e, y);
+    e = fma(-x, y, 1.0);
+    y = fma(y, e, y);
+    return y;
+}
+// d += X[N] * c, X read through DPP row_newbcast (element N of the lane's row of 16 lanes = of its tile)
+template <int N>
+__device__ __forceinline__ void fmac_bcast(double& d, double X, double c)
+{
+    asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(d) : "v"(X), "v"(c), "n"(N));
+}
+template <int N>
+__device__ __forceinline__ double bcast_f64(double X)
+{
+    double r;
+    asm("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(X), "n"(N));
+    return r;
+}
+__device__ __forceinline__ double bpermute_f64(int byte_addr, double v)
+{
+    const int lo = __builtin_amdgcn_ds_bpermute(byte_addr, __double2loint(v));
+    const int hi = __builtin_amdgcn_ds_bpermute(byte_addr, __double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+// max over every row of 16 lanes, in every lane of the row: four fused DPP stages
+__device__ __forceinline__ int row16_max_i32_fused(int v)
+{
+    int m;
+    asm("s_nop 1\n\t"
+        "v_max_i32_dpp %0, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_i32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_i32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_i32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf"
+        : "=&v"(m) : "v"(v));
+    return m;
+}
+__device__ __forceinline__ unsigned row16_max_u32(unsigned v)
+{
+    v = max(v, (unsigned)dpp_i32<0xB1>((int)v));
+    v = max(v, (unsigned)dpp_i32<0x4E>((int)v));
+    v = max(v, (unsigned)dpp_i32<0x141>((int)v));
+    v = max(v, (unsigned)dpp_i32<0x140>((int)v));
+    return v;
+}
+
+struct Lane {
+    int lane, j, g;
+    unsigned long long livemask;   // (wave-uniform) the lanes whose column of A is not yet chosen
+    unsigned long long unclearm;   // (wave-uniform) lanes that saw a decision of their tile inside its error margin
+    int kstep;        // position at which this lane's column was chosen
+    double nu2;       // m_colNormsUpdated^2 (a chosen or non-existent column carries a negative value)
+    double thr;       // sqrt(eps) (1 + 2^-12) m_colNormsDirect^2
+    double a2;        // |A|^2 of this lane's tile: squared norm of its first pivot column (scale of the decision margins)
+};
+
+// One step of ColPivHouseholderQR::computeInPlace / HouseholderQR on the four tiles of the wave (bdqr_pair4.hip's step; see
+// bdqr_pair.hip for the arithmetic: squared norms, un-normalised reflector, decisions).  r: rows of the tiles (the launch is uniform).
+template <int K, bool PIVOT, bool HC>
+__device__ __forceinline__ void step(double (&a)[WR], double* tl /* this tile's LDS */, Lane& st, const int r)
+{
+    const int lane = st.lane;
+    // ---- 1. pivot of each tile
+    bool ispiv;
+    unsigned long long pm;                                  // ballot of ispiv: one lane per tile
+    if (PIVOT) {
+        const int khi = __double2hiint(st.nu2);
+        const int mh = row16_max_i32_fused(khi);
+        ispiv = khi >= mh - FILTER;
+        pm = __builtin_amdgcn_ballot_w64(ispiv);
+        // (every tile has at least one candidate, so subtracting one from each 16-bit field never borrows across fields)
+        if (__builtin_expect((pm & (pm - 0x0001000100010001ull)) != 0ull, 0)) {
+            // several candidates in a tile: the largest (lowest lane among exact ties: the tile is flagged then) and the check of the
+            // decision -- a live column within the error margin of the chosen one sends the tile to the exact path, which owns
+            // Eigen's first-maximum rule on the current positions
+            asm volatile("");
+            const bool live = ((st.livemask >> lane) & 1ull) != 0ull;
+            bool cand = live && khi == mh;
+            const unsigned klo = (unsigned)__double2loint(st.nu2);
+            const unsigned ml = row16_max_u32(cand ? klo : 0u);
+            cand = cand && klo == ml;
+            const unsigned long long cm = __builtin_amdgcn_ballot_w64(cand);
+            const unsigned f = (unsigned)(cm >> (16 * st.g)) & 0xffffu;
+            const int lbl = f ? __builtin_ctz(f) : 0;
+            ispiv = cand && st.j == lbl;
+            const int src = ((st.g << 4) + lbl) << 2;
+            const double best = bpermute_f64(src, st.nu2), thrb = bpermute_f64(src, st.thr);
+            double margin = MREL * (st.thr + thrb);
+            if (K > 0) margin += 4.547473508864641e-13 /* 2^-41 */ * __builtin_sqrt(st.a2 * (best > 0.0 ? best : 0.0));
+            st.unclearm |= __builtin_amdgcn_ballot_w64(live && !ispiv && st.nu2 >= best - margin);
+            pm = __builtin_amdgcn_ballot_w64(ispiv);
+        }
+        st.livemask &= ~pm;
+    } else {
+        ispiv = st.j == K;
+        pm = __builtin_amdgcn_ballot_w64(ispiv);
+    }
+    if (K == 0 && PIVOT) {
+        // the scale of the tile: the squared norm of its first pivot, to every lane of the tile
+        const unsigned f = (unsigned)(pm >> (16 * st.g)) & 0xffffu;
+        st.a2 = bpermute_f64(((st.g << 4) + (f ? __builtin_ctz(f) : 0)) << 2, st.nu2);
+    }
+    if (ispiv) {
+        st.kstep = K;
+        st.nu2 = __hiloint2double((int)0xBF800000, __double2loint(st.nu2));
+        // ---- 2. publish the column (it is reflector K of phase 2 as well): 8-byte stores (tools/ubench8.hip)
+        double* vcol = tl + L_V + cb(K) - K;
+#pragma unroll
+        for (int i = K; i < WR; ++i) *(volatile lds_f64*)(&vcol[i]) = a[i];
+    }
+    __builtin_amdgcn_wave_barrier();
+    // ---- 3. the lanes' elements of it (element lane & 15; the elements above row K are not data and are never used), x0
+    double xc = *(const volatile lds_f64*)(tl + L_V + cb(K) - K + (lane & 15));
+    const double xk = bcast_f64<K>(xc);
+    // ---- 4. d = x_tail^T a_tail of every column; the pivot lane's own is |x_tail|^2, handed to its tile through LDS (the slot of
+    // tau_K, which is written after it) -- no cross-lane sum
+    const double ak = a[K];
+    double d0 = 0.0, d1 = 0.0;
+    asm volatile("s_nop 1" : "+v"(xc));                      // (VALU write -> DPP read hazard, hidden from hipcc by the asm)
+#define QRK_Q16_DOT(I) if ((I) > K) fmac_bcast<(I)>(((I) & 1) ? d1 : d0, xc, a[I]);
+    QRK_Q16_0_15(QRK_Q16_DOT)
+#undef QRK_Q16_DOT
+    const double dsum = d0 + d1;
+    double tsq = 0.0;
+    if (K + 1 < WR) {
+        if (ispiv) tl[L_TAU + K] = dsum;
+        __builtin_amdgcn_wave_barrier();
+        tsq = tl[L_TAU + K];
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (K == 0 && !PIVOT) st.a2 = fma(xk, xk, tsq);
+    // (decide::unclear_reflector without short-circuit evaluation: compares straight into wave masks, no control flow; a tail exists
+    //  when row K is not the tile's last)
+    unsigned long long degm;                 // lanes whose tail is empty to rounding: !(tsq > DBL_MIN)
+    {
+        const double n2 = fma(xk, xk, tsq);
+        unsigned long long um = 0ull;
+        if (K + 1 < WR) {
+            degm = __builtin_amdgcn_fcmp(tsq, DBL_MIN, 13 /* ULE */);
+            if (K + 1 < r) um = degm | __builtin_amdgcn_fcmp(xk * xk, X0_TINY2 * st.a2, 5 /* OLE */);
+        } else {
+            degm = ~0ull;
+        }
+        if (PIVOT) um |= __builtin_amdgcn_fcmp(n2, PIV_TINY2 * st.a2, 5 /* OLE */);
+        st.unclearm |= um;
+    }
+    // ---- 5. makeHouseholder in the un-normalised form: nb = -beta = copysign(norm, x0), s = x0 - beta, ng = -1 / (beta (x0 - beta));
+    // Eigen: tailSqNorm <= min() gives tau = 0, beta = x0, H = I (rare: a real branch on a wave-level test, selects inside)
+    const double nrm = sqrt_pos(fma(xk, xk, tsq));
+    double nbv = __builtin_copysign(nrm, xk);                // beta = -nbv
+    double s = nbv + xk;
+    double ngp = recip(nbv * s);                             // -ng
+    if (__builtin_expect(degm != 0ull, 0)) {
+        asm volatile("");
+        if ((degm >> lane) & 1ull) { nbv = -xk; s = 0.0; ngp = 0.0; }
+    }
+    if (st.j == 0) {
+        tl[L_S + K] = s; tl[L_NG + K] = ngp;
+        if (HC) tl[L_TAU + K] = (s * s) * ngp;
+    }
+    const double ngam = fma(s, ak, dsum) * -ngp;             // -gamma of this column
+    // R(K, K): in the pivot lane s x0 + |x_tail|^2 = beta (beta - x0), so its updated entry IS beta to a few ulp (bdqr_pair4.hip)
+    const double an = fma(s, ngam, ak);
+    a[K] = an;                                               // final: later steps work on the rows below
+    if (!PIVOT) asm volatile("" : "+v"(a[K]));
+    // ---- 6. the trailing update (columns already chosen are not masked out: nothing below the diagonal of R is ever read)
+#define QRK_Q16_UPD(I) if ((I) > K) fmac_bcast<(I)>(a[I], xc, ngam);
+    QRK_Q16_0_15(QRK_Q16_UPD)
+#undef QRK_Q16_UPD
+    // ---- 7. LAWN-176 norm downdate (squared form; no clamp at zero: a negative value is <= the threshold and recomputed)
+    if (PIVOT && K + 1 < WR) {
+        const double nn = fma(-an, an, st.nu2);
+        st.nu2 = nn;
+        const unsigned long long needm = __builtin_amdgcn_ballot_w64(nn <= st.thr) & st.livemask;
+        if (__builtin_expect(needm != 0ull, 0)) {
+            asm volatile("");
+            const bool need = ((needm >> lane) & 1ull) != 0ull;
+            st.unclearm |= __builtin_amdgcn_ballot_w64(need && in_recompute_band(nn, st.thr, st.a2));      // decision (2)
+            double sq = 0.0;
+#define QRK_Q16_SQ(I) if ((I) > K) sq = fma(a[I], a[I], sq);
+            QRK_Q16_0_15(QRK_Q16_SQ)
+#undef QRK_Q16_SQ
+            if (need) { st.nu2 = sq; st.thr = sq * THR_HI; }
+        }
+    }
+}
+
+// Q_k = H_k Q_{k+1} on the wave's columns of Q (four tiles): reflector K from the tile's LDS (x_tail as published); s_K and ng_K come
+// from lane K of the tile through DPP (lane l holds entry l & 15 of both)
+template <int K>
+__device__ __forceinline__ void back_step(double (&q)[WR], const double* tl, const int lane, const double sv, const double ngv)
+{
+    double xc = 0.0;
+    if (K + 1 < WR) xc = *(const volatile lds_f64*)(tl + L_V + cb(K) - K + (lane & 15));
+    const double qk = q[K];
+    double d0 = 0.0, d1 = 0.0;
+    asm volatile("s_nop 1" : "+v"(xc));
+#define QRK_Q16_DOT(I) if ((I) > K) fmac_bcast<(I)>(((I) & 1) ? d1 : d0, xc, q[I]);
+    QRK_Q16_0_15(QRK_Q16_DOT)
+#undef QRK_Q16_DOT
+    double t = d0 + d1;
+    fmac_bcast<K>(t, sv, qk);
+    const double ngam = t * -bcast_f64<K>(ngv);
+    double qn = qk;
+    fmac_bcast<K>(qn, sv, ngam);
+    q[K] = qn;
+#define QRK_Q16_UPD(I) if ((I) > K) fmac_bcast<(I)>(q[I], xc, ngam);
+    QRK_Q16_0_15(QRK_Q16_UPD)
+#undef QRK_Q16_UPD
+}
+
+}  // namespace q16
+
+#ifndef QRK_QUAD_WAVES
+#define QRK_QUAD_WAVES 5       // waves per SIMD the kernel is compiled for (96 VGPRs, no spill; 6: 80 VGPRs with 3-5 spills in the staging)
+#endif
+
+// PIVOT: ColPivHouseholderQR (else HouseholderQR).  HC: also emit the Householder coefficients.  One wave per workgroup, persistent over
+// the quads blockIdx.x, blockIdx.x + gridDim.x, ..; r x c: the size of every tile (9 <= r <= 16, c <= r).
+template <bool PIVOT, bool HC>
+__global__ void __launch_bounds__(64, QRK_QUAD_WAVES)
+bdqr_quad_kernel(int64_t num_tiles, int r, int c, const double* __restrict__ tiles, double* __restrict__ q_vals, double* __restrict__ r_vals,
+                 int32_t* __restrict__ perm, double* __restrict__ hcoeffs, int32_t* __restrict__ redo_count, int32_t* __restrict__ redo_ids)
+{
+    using namespace q16;
+    __shared__ __attribute__((aligned(16))) double lds[4 * L_TILE];
+    const int64_t nquads = (num_tiles + 3) / 4;
+    const int rc = r * c, rr = r * r, nr = (c * (c + 1)) >> 1;
+    for (int64_t qi = blockIdx.x; qi < nquads; qi += gridDim.x) {
+        // (per-lane values are re-derived from an opaque lane id in every round: hipcc otherwise hoists loop-invariant address
+        //  arithmetic out of the loop and keeps it in registers across the factorisation)
+        int lane = threadIdx.x;
+        asm volatile("" : "+v"(lane));
+        const int g = lane >> 4, j = lane & 15;
+        double* tl = lds + g * L_TILE;
+        const int64_t t = 4 * qi + g;
+        const bool valid = t < num_tiles;
+        Lane st;
+        st.lane = lane; st.j = j; st.g = g; st.unclearm = 0ull; st.kstep = 0; st.a2 = 0.0;
+        const bool isA = j < c;
+        st.livemask = __builtin_amdgcn_ballot_w64(isA);
+        double a[WR];
+        {
+            // =============== phase 1: A -> R ===============
+            // The four tiles of the quad are 4 r c consecutive doubles: sixteen coalesced 512-byte loads, then through the wave's LDS (idle
+            // until the first publication) to lane = column, two tiles at a time with an odd column stride.  (Every lane loading its own
+            // column directly costs 64 separate cache lines per load instruction: 20 000 tiles of 16 x 16 took 99 us that way, 69 with
+            // bdqr_small.hip's staged sweeps.)
+            const int half = 2 * rc;                                  // doubles of a pair of tiles (<= 512)
+            const int n4 = (int)(num_tiles - 4 * qi < 4 ? num_tiles - 4 * qi : 4) * rc;
+            const double* qbase = tiles + 4 * qi * rc;
+            const int pad = (r & 1) ? 0 : 1, RS = r + pad;
+            const unsigned M = (65536u + (unsigned)r - 1u) / (unsigned)r;      // (e M) >> 16 = e / r for e < 1024, 9 <= r <= 16
+            const double* colp = lds + ((g & 1) * c + (isA ? j : 0)) * RS;
+            {
+                // (the loads of the second pair are issued when the first pair's registers are free: 16 + 16 live values otherwise)
+                double ld[8];
+#pragma unroll
+                for (int m = 0; m < 8; ++m) { const int e = 64 * m + lane; ld[m] = QRK_TILE_LOAD(qbase + ((e < half && e < n4) ? e : 0)); }
+#pragma unroll
+                for (int m = 0; m < 8; ++m) {
+                    const int e = 64 * m + lane;
+                    if (e < half && e < n4) lds[e + (pad ? (int)(((unsigned)e * M) >> 16) : 0)] = ld[m];
+                }
+            }
+            double ld2[8];
+#pragma unroll
+            for (int m = 0; m < 8; ++m) { const int e2 = 64 * m + lane; ld2[m] = QRK_TILE_LOAD(qbase + ((e2 < half && half + e2 < n4) ? half + e2 : 0)); }
+            __builtin_amdgcn_wave_barrier();
+            // (every lane reads in the first pass: an array that is first defined under a condition is carried around the loop as live values)
+#pragma unroll
+            for (int i = 0; i < WR; ++i) a[i] = colp[i < r ? i : 0];
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int m = 0; m < 8; ++m) {
+                const int e2 = 64 * m + lane;
+                if (e2 < half && half + e2 < n4) lds[e2 + (pad ? (int)(((unsigned)e2 * M) >> 16) : 0)] = ld2[m];
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (g >= 2) {
+#pragma unroll
+                for (int i = 0; i < WR; ++i) a[i] = colp[i < r ? i : 0];
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int i = 0; i < WR; ++i) {
+                // rows >= r are zero; a lane without a column holds zeros; a tile beyond the batch: diag(64 .. 49), nothing of it is stored
+                const double v = (isA && i < r) ? a[i] : 0.0;
+                a[i] = valid ? v : ((i == j) ? (double)(64 - j) : 0.0);
+            }
+            {
+                double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+                for (int i = 0; i < WR; i += 2) { s0 = fma(a[i], a[i], s0); s1 = fma(a[i + 1], a[i + 1], s1); }
+                const double s = s0 + s1;
+                st.nu2 = isA ? s : -1.0;                     // (a lane without a column never becomes a pivot)
+                st.thr = s * THR_HI;
+            }
+#define QRK_Q16_STEP(K) if ((K) < c) step<K, PIVOT, HC>(a, tl, st, r);
+            QRK_Q16_0_15(QRK_Q16_STEP)
+#undef QRK_Q16_STEP
+            // ---- R: lane j holds column p = kstep of R in rows 0 .. p; the packed CSC value order of m_R (BlockDiagonalSparseQR.h:475-479)
+            // puts entry (i, p) at p (p + 1) / 2 + i -- a contiguous run per lane; the permutation splice (:519-521): the column chosen at
+            // step p ends at position p
+            int ln = threadIdx.x;
+            asm volatile("" : "+v"(ln));
+            const int jj = ln & 15;
+            if (valid && jj < c) {
+                const int p = st.kstep;
+                const int cbase = (int)(t * c);
+                perm[cbase + p] = cbase + jj;
+                double* dst = r_vals + t * nr + ((p * (p + 1)) >> 1);
+#pragma unroll
+                for (int i = 0; i < WR; ++i)
+                    if (i <= p) dst[i] = a[i];
+                if (HC && hcoeffs) hcoeffs[cbase + jj] = lds[(ln >> 4) * L_TILE + L_TAU + jj];
+            }
+            // a decision inside its error margin, anywhere in the tile: the exact path redoes it (bdqr_exact.hip)
+            const bool f = ((st.unclearm >> (16 * (ln >> 4))) & 0xffffull) != 0ull;
+            if (f && valid && jj == 0 && redo_count) redo_ids[atomicAdd(redo_count, 1)] = (int32_t)t;
+        }
+        {
+            // =============== phase 2: Q = H_0 ... H_{c-1}, backward ===============
+            int ln = threadIdx.x;
+            asm volatile("" : "+v"(ln));
+            const int jj = ln & 15;
+            const double* tl2 = lds + (ln >> 4) * L_TILE;
+            double q[WR];
+#pragma unroll
+            for (int i = 0; i < WR; ++i) q[i] = (i == jj) ? 1.0 : 0.0;
+            // (s_K and ng_K of the tile's reflectors: lane l keeps entry l & 15; back_step reads them through DPP)
+            const double sv = tl2[L_S + jj], ngv = tl2[L_NG + jj];
+#define QRK_Q16_BACK(K) if ((K) < c) back_step<K>(q, tl2, ln, sv, ngv);
+            QRK_Q16_15_0(QRK_Q16_BACK)
+#undef QRK_Q16_BACK
+            // row-major rows of Q_i are the CSR value order of m_Q in both FullQ ([U|N] split, :455-471) and BlockDiagonalQ (:480-492)
+            // layouts: lane j holds COLUMN j of Q_i, one coalesced store of r doubles per row and tile
+            if (valid && jj < r) {
+                double* dst = q_vals + t * rr + jj;
+#pragma unroll
+                for (int i = 0; i < WR; ++i)
+                    if (i < r) dst[i * r] = q[i];
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+int bdqr_quad_waves_per_cu() { return 4 * QRK_QUAD_WAVES; }
+bool bdqr_quad_supported(int r, int c) { return r > 8 && r <= q16::WR && c >= 1 && c <= r; }
+
+// Uniform batches of r x c tiles, 9 <= r <= 16, c <= r.  num_wg: resident wave slots.
+void launch_bdqr_quad(int64_t num_tiles, int r, int c, int pivoting, const double* tiles, double* q_vals, double* r_vals, int32_t* perm,
+                      double* hcoeffs, int num_wg, int32_t* redo_count, int32_t* redo_ids, hipStream_t stream)
+{
+    if (num_tiles <= 0) return;
+    const int64_t nquads = (num_tiles + 3) / 4;
+    const int64_t nwg = nquads < num_wg ? nquads : num_wg;
+    const dim3 grid((unsigned)nwg), block(64);
+#define QRK_Q16_LAUNCH(P, H) hipLaunchKernelGGL((bdqr_quad_kernel<P, H>), grid, block, 0, stream, num_tiles, r, c, tiles, q_vals, r_vals, perm, hcoeffs, redo_count, redo_ids)
+    if (pivoting) { if (hcoeffs) QRK_Q16_LAUNCH(true, true); else QRK_Q16_LAUNCH(true, false); }
+    else { if (hcoeffs) QRK_Q16_LAUNCH(false, true); else QRK_Q16_LAUNCH(false, false); }
+#undef QRK_Q16_LAUNCH
+}
+
+}  // namespace qrk
