@@ -27,16 +27,19 @@ namespace q16 {
 
 using namespace decide;
 
-constexpr int WR = 16;
 constexpr int FILTER = 256;              // pivot candidates: high word of the squared norm within 2^-12 (relative) of the largest
-// LDS per TILE (doubles): reflector K (the pivot column of step K, as published) holds rows K .. 15 at cb(K)
-constexpr int cb(int k) { int s = 0; for (int q = 0; q < k; ++q) s += WR - q; return s; }
-constexpr int L_V = 0;
-constexpr int L_S = cb(WR);              // [16] s = x0 - beta
-constexpr int L_NG = L_S + WR;           // [16] 1 / (beta (beta - x0))
-constexpr int L_TAU = L_NG + WR;         // [16] tau; before that, the hand-off word of |x_tail|^2 of the step
-constexpr int L_TILE = L_TAU + WR;       // 184 doubles = 1 472 B per tile, 5 888 B per wave
-static_assert(cb(WR) == 136, "the triangle of the reflectors");
+// WR: row registers per lane (16: tiles of 9 .. 16 rows; 8: tiles of up to 8 rows -- still sixteen lanes per tile, the lanes beyond the
+// tile's columns idle).  LDS per TILE (doubles): reflector K (the pivot column of step K, as published) holds rows K .. WR - 1 at cb(K)
+template <int WR>
+struct Lay {
+    static constexpr int cb(int k) { int s = 0; for (int q = 0; q < k; ++q) s += WR - q; return s; }
+    static constexpr int L_V = 0;
+    static constexpr int L_S = cb(WR);           // [WR] s = x0 - beta
+    static constexpr int L_NG = L_S + WR;        // [WR] 1 / (beta (beta - x0))
+    static constexpr int L_TAU = L_NG + WR;      // [WR] tau; before that, the hand-off word of |x_tail|^2 of the step
+    static constexpr int L_TILE = L_TAU + WR;    // WR = 16: 184 doubles = 1 472 B per tile, 5 888 B per wave
+};
+static_assert(Lay<16>::cb(16) == 136 && Lay<8>::L_TILE == 60, "the triangle of the reflectors");
 
 typedef __attribute__((address_space(3))) double lds_f64;      // (volatile accesses through a generic pointer would become flat_*)
 
@@ -117,9 +120,11 @@ struct Lane {
 
 // One step of ColPivHouseholderQR::computeInPlace / HouseholderQR on the four tiles of the wave (bdqr_pair4.hip's step; see
 // bdqr_pair.hip for the arithmetic: squared norms, un-normalised reflector, decisions).  r: rows of the tiles (the launch is uniform).
-template <int K, bool PIVOT, bool HC>
+template <int WR, int K, bool PIVOT, bool HC>
 __device__ __forceinline__ void step(double (&a)[WR], double* tl /* this tile's LDS */, Lane& st, const int r)
 {
+    typedef Lay<WR> L;
+    constexpr int L_V = L::L_V, L_S = L::L_S, L_NG = L::L_NG, L_TAU = L::L_TAU;
     const int lane = st.lane;
     // ---- 1. pivot of each tile
     bool ispiv;
@@ -165,20 +170,20 @@ __device__ __forceinline__ void step(double (&a)[WR], double* tl /* this tile's 
         st.kstep = K;
         st.nu2 = __hiloint2double((int)0xBF800000, __double2loint(st.nu2));
         // ---- 2. publish the column (it is reflector K of phase 2 as well): 8-byte stores (tools/ubench8.hip)
-        double* vcol = tl + L_V + cb(K) - K;
+        double* vcol = tl + L_V + L::cb(K) - K;
 #pragma unroll
         for (int i = K; i < WR; ++i) *(volatile lds_f64*)(&vcol[i]) = a[i];
     }
     __builtin_amdgcn_wave_barrier();
     // ---- 3. the lanes' elements of it (element lane & 15; the elements above row K are not data and are never used), x0
-    double xc = *(const volatile lds_f64*)(tl + L_V + cb(K) - K + (lane & 15));
+    double xc = *(const volatile lds_f64*)(tl + L_V + L::cb(K) - K + (lane & 15));
     const double xk = bcast_f64<K>(xc);
     // ---- 4. d = x_tail^T a_tail of every column; the pivot lane's own is |x_tail|^2, handed to its tile through LDS (the slot of
     // tau_K, which is written after it) -- no cross-lane sum
     const double ak = a[K];
     double d0 = 0.0, d1 = 0.0;
     asm volatile("s_nop 1" : "+v"(xc));                      // (VALU write -> DPP read hazard, hidden from hipcc by the asm)
-#define QRK_Q16_DOT(I) if ((I) > K) fmac_bcast<(I)>(((I) & 1) ? d1 : d0, xc, a[I]);
+#define QRK_Q16_DOT(I) if ((I) > K && (I) < WR) fmac_bcast<(I)>(((I) & 1) ? d1 : d0, xc, a[(I) < WR ? (I) : 0]);
     QRK_Q16_0_15(QRK_Q16_DOT)
 #undef QRK_Q16_DOT
     const double dsum = d0 + d1;
@@ -225,7 +230,7 @@ __device__ __forceinline__ void step(double (&a)[WR], double* tl /* this tile's 
     a[K] = an;                                               // final: later steps work on the rows below
     if (!PIVOT) asm volatile("" : "+v"(a[K]));
     // ---- 6. the trailing update (columns already chosen are not masked out: nothing below the diagonal of R is ever read)
-#define QRK_Q16_UPD(I) if ((I) > K) fmac_bcast<(I)>(a[I], xc, ngam);
+#define QRK_Q16_UPD(I) if ((I) > K && (I) < WR) fmac_bcast<(I)>(a[(I) < WR ? (I) : 0], xc, ngam);
     QRK_Q16_0_15(QRK_Q16_UPD)
 #undef QRK_Q16_UPD
     // ---- 7. LAWN-176 norm downdate (squared form; no clamp at zero: a negative value is <= the threshold and recomputed)
@@ -238,7 +243,7 @@ __device__ __forceinline__ void step(double (&a)[WR], double* tl /* this tile's 
             const bool need = ((needm >> lane) & 1ull) != 0ull;
             st.unclearm |= __builtin_amdgcn_ballot_w64(need && in_recompute_band(nn, st.thr, st.a2));      // decision (2)
             double sq = 0.0;
-#define QRK_Q16_SQ(I) if ((I) > K) sq = fma(a[I], a[I], sq);
+#define QRK_Q16_SQ(I) if ((I) > K && (I) < WR) sq = fma(a[(I) < WR ? (I) : 0], a[(I) < WR ? (I) : 0], sq);
             QRK_Q16_0_15(QRK_Q16_SQ)
 #undef QRK_Q16_SQ
             if (need) { st.nu2 = sq; st.thr = sq * THR_HI; }
@@ -248,15 +253,16 @@ __device__ __forceinline__ void step(double (&a)[WR], double* tl /* this tile's 
 
 // Q_k = H_k Q_{k+1} on the wave's columns of Q (four tiles): reflector K from the tile's LDS (x_tail as published); s_K and ng_K come
 // from lane K of the tile through DPP (lane l holds entry l & 15 of both)
-template <int K>
+template <int WR, int K>
 __device__ __forceinline__ void back_step(double (&q)[WR], const double* tl, const int lane, const double sv, const double ngv)
 {
+    typedef Lay<WR> L;
     double xc = 0.0;
-    if (K + 1 < WR) xc = *(const volatile lds_f64*)(tl + L_V + cb(K) - K + (lane & 15));
+    if (K + 1 < WR) xc = *(const volatile lds_f64*)(tl + L::L_V + L::cb(K) - K + (lane & 15));
     const double qk = q[K];
     double d0 = 0.0, d1 = 0.0;
     asm volatile("s_nop 1" : "+v"(xc));
-#define QRK_Q16_DOT(I) if ((I) > K) fmac_bcast<(I)>(((I) & 1) ? d1 : d0, xc, q[I]);
+#define QRK_Q16_DOT(I) if ((I) > K && (I) < WR) fmac_bcast<(I)>(((I) & 1) ? d1 : d0, xc, q[(I) < WR ? (I) : 0]);
     QRK_Q16_0_15(QRK_Q16_DOT)
 #undef QRK_Q16_DOT
     double t = d0 + d1;
@@ -265,7 +271,7 @@ __device__ __forceinline__ void back_step(double (&q)[WR], const double* tl, con
     double qn = qk;
     fmac_bcast<K>(qn, sv, ngam);
     q[K] = qn;
-#define QRK_Q16_UPD(I) if ((I) > K) fmac_bcast<(I)>(q[I], xc, ngam);
+#define QRK_Q16_UPD(I) if ((I) > K && (I) < WR) fmac_bcast<(I)>(q[(I) < WR ? (I) : 0], xc, ngam);
     QRK_Q16_0_15(QRK_Q16_UPD)
 #undef QRK_Q16_UPD
 }
@@ -273,17 +279,23 @@ __device__ __forceinline__ void back_step(double (&q)[WR], const double* tl, con
 }  // namespace q16
 
 #ifndef QRK_QUAD_WAVES
-#define QRK_QUAD_WAVES 5       // waves per SIMD the kernel is compiled for (96 VGPRs, no spill; 6: 80 VGPRs with 3-5 spills in the staging)
+#define QRK_QUAD_WAVES 5       // waves per SIMD the 16-row instantiation is compiled for (96 VGPRs, no spill; 6: 80 VGPRs with 3-5 spills in the staging)
+#endif
+#ifndef QRK_QUAD_WAVES8
+#define QRK_QUAD_WAVES8 8      // ... and the 8-row instantiation
 #endif
 
 // PIVOT: ColPivHouseholderQR (else HouseholderQR).  HC: also emit the Householder coefficients.  One wave per workgroup, persistent over
 // the quads blockIdx.x, blockIdx.x + gridDim.x, ..; r x c: the size of every tile (9 <= r <= 16, c <= r).
-template <bool PIVOT, bool HC>
-__global__ void __launch_bounds__(64, QRK_QUAD_WAVES)
+template <int WR, bool PIVOT, bool HC>
+__global__ void __launch_bounds__(64, (WR == 16 ? QRK_QUAD_WAVES : QRK_QUAD_WAVES8))
 bdqr_quad_kernel(int64_t num_tiles, int r, int c, const double* __restrict__ tiles, double* __restrict__ q_vals, double* __restrict__ r_vals,
                  int32_t* __restrict__ perm, double* __restrict__ hcoeffs, int32_t* __restrict__ redo_count, int32_t* __restrict__ redo_ids)
 {
     using namespace q16;
+    typedef Lay<WR> L;
+    constexpr int L_TILE = L::L_TILE, L_S = L::L_S, L_NG = L::L_NG, L_TAU = L::L_TAU;
+    constexpr int MLD = (2 * WR * WR + 63) / 64;                      // load instructions per pair of tiles
     __shared__ __attribute__((aligned(16))) double lds[4 * L_TILE];
     const int64_t nquads = (num_tiles + 3) / 4;
     const int rc = r * c, rr = r * r, nr = (c * (c + 1)) >> 1;
@@ -315,25 +327,25 @@ bdqr_quad_kernel(int64_t num_tiles, int r, int c, const double* __restrict__ til
             const double* colp = lds + ((g & 1) * c + (isA ? j : 0)) * RS;
             {
                 // (the loads of the second pair are issued when the first pair's registers are free: 16 + 16 live values otherwise)
-                double ld[8];
+                double ld[MLD];
 #pragma unroll
-                for (int m = 0; m < 8; ++m) { const int e = 64 * m + lane; ld[m] = QRK_TILE_LOAD(qbase + ((e < half && e < n4) ? e : 0)); }
+                for (int m = 0; m < MLD; ++m) { const int e = 64 * m + lane; ld[m] = QRK_TILE_LOAD(qbase + ((e < half && e < n4) ? e : 0)); }
 #pragma unroll
-                for (int m = 0; m < 8; ++m) {
+                for (int m = 0; m < MLD; ++m) {
                     const int e = 64 * m + lane;
                     if (e < half && e < n4) lds[e + (pad ? (int)(((unsigned)e * M) >> 16) : 0)] = ld[m];
                 }
             }
-            double ld2[8];
+            double ld2[MLD];
 #pragma unroll
-            for (int m = 0; m < 8; ++m) { const int e2 = 64 * m + lane; ld2[m] = QRK_TILE_LOAD(qbase + ((e2 < half && half + e2 < n4) ? half + e2 : 0)); }
+            for (int m = 0; m < MLD; ++m) { const int e2 = 64 * m + lane; ld2[m] = QRK_TILE_LOAD(qbase + ((e2 < half && half + e2 < n4) ? half + e2 : 0)); }
             __builtin_amdgcn_wave_barrier();
             // (every lane reads in the first pass: an array that is first defined under a condition is carried around the loop as live values)
 #pragma unroll
             for (int i = 0; i < WR; ++i) a[i] = colp[i < r ? i : 0];
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
-            for (int m = 0; m < 8; ++m) {
+            for (int m = 0; m < MLD; ++m) {
                 const int e2 = 64 * m + lane;
                 if (e2 < half && half + e2 < n4) lds[e2 + (pad ? (int)(((unsigned)e2 * M) >> 16) : 0)] = ld2[m];
             }
@@ -357,7 +369,7 @@ bdqr_quad_kernel(int64_t num_tiles, int r, int c, const double* __restrict__ til
                 st.nu2 = isA ? s : -1.0;                     // (a lane without a column never becomes a pivot)
                 st.thr = s * THR_HI;
             }
-#define QRK_Q16_STEP(K) if ((K) < c) step<K, PIVOT, HC>(a, tl, st, r);
+#define QRK_Q16_STEP(K) if ((K) < WR && (K) < c) step<WR, ((K) < WR ? (K) : 0), PIVOT, HC>(a, tl, st, r);
             QRK_Q16_0_15(QRK_Q16_STEP)
 #undef QRK_Q16_STEP
             // ---- R: lane j holds column p = kstep of R in rows 0 .. p; the packed CSC value order of m_R (BlockDiagonalSparseQR.h:475-479)
@@ -391,7 +403,7 @@ bdqr_quad_kernel(int64_t num_tiles, int r, int c, const double* __restrict__ til
             for (int i = 0; i < WR; ++i) q[i] = (i == jj) ? 1.0 : 0.0;
             // (s_K and ng_K of the tile's reflectors: lane l keeps entry l & 15; back_step reads them through DPP)
             const double sv = tl2[L_S + jj], ngv = tl2[L_NG + jj];
-#define QRK_Q16_BACK(K) if ((K) < c) back_step<K>(q, tl2, ln, sv, ngv);
+#define QRK_Q16_BACK(K) if ((K) < WR && (K) < c) back_step<WR, ((K) < WR ? (K) : 0)>(q, tl2, ln, sv, ngv);
             QRK_Q16_15_0(QRK_Q16_BACK)
 #undef QRK_Q16_BACK
             // row-major rows of Q_i are the CSR value order of m_Q in both FullQ ([U|N] split, :455-471) and BlockDiagonalQ (:480-492)
@@ -407,10 +419,12 @@ bdqr_quad_kernel(int64_t num_tiles, int r, int c, const double* __restrict__ til
     }
 }
 
-int bdqr_quad_waves_per_cu() { return 4 * QRK_QUAD_WAVES; }
-bool bdqr_quad_supported(int r, int c) { return r > 8 && r <= q16::WR && c >= 1 && c <= r; }
+int bdqr_quad_waves_per_cu(int r) { (void)r; return 4 * QRK_QUAD_WAVES; }
+// 9 .. 16 rows.  (The 8-row instantiation -- still sixteen lanes per tile, four tiles per wave -- was measured against bdqr_small.hip's groups of
+// 8 lanes, eight tiles per wave: 10 % faster at 20 000 tiles, 12-28 % slower at 10^6, profiles/r05_quad.txt; it is not instantiated.)
+bool bdqr_quad_supported(int r, int c) { return r > 8 && r <= 16 && c >= 1 && c <= r; }
 
-// Uniform batches of r x c tiles, 9 <= r <= 16, c <= r.  num_wg: resident wave slots.
+// Uniform batches of r x c tiles, r <= 16, c <= r.  num_wg: resident wave slots.
 void launch_bdqr_quad(int64_t num_tiles, int r, int c, int pivoting, const double* tiles, double* q_vals, double* r_vals, int32_t* perm,
                       double* hcoeffs, int num_wg, int32_t* redo_count, int32_t* redo_ids, hipStream_t stream)
 {
@@ -418,9 +432,11 @@ void launch_bdqr_quad(int64_t num_tiles, int r, int c, int pivoting, const doubl
     const int64_t nquads = (num_tiles + 3) / 4;
     const int64_t nwg = nquads < num_wg ? nquads : num_wg;
     const dim3 grid((unsigned)nwg), block(64);
-#define QRK_Q16_LAUNCH(P, H) hipLaunchKernelGGL((bdqr_quad_kernel<P, H>), grid, block, 0, stream, num_tiles, r, c, tiles, q_vals, r_vals, perm, hcoeffs, redo_count, redo_ids)
-    if (pivoting) { if (hcoeffs) QRK_Q16_LAUNCH(true, true); else QRK_Q16_LAUNCH(true, false); }
-    else { if (hcoeffs) QRK_Q16_LAUNCH(false, true); else QRK_Q16_LAUNCH(false, false); }
+#define QRK_Q16_LAUNCH(W, P, H) hipLaunchKernelGGL((bdqr_quad_kernel<W, P, H>), grid, block, 0, stream, num_tiles, r, c, tiles, q_vals, r_vals, perm, hcoeffs, redo_count, redo_ids)
+#define QRK_Q16_LAUNCH2(W) do { if (pivoting) { if (hcoeffs) QRK_Q16_LAUNCH(W, true, true); else QRK_Q16_LAUNCH(W, true, false); } \
+                                else { if (hcoeffs) QRK_Q16_LAUNCH(W, false, true); else QRK_Q16_LAUNCH(W, false, false); } } while (0)
+    QRK_Q16_LAUNCH2(16);
+#undef QRK_Q16_LAUNCH2
 #undef QRK_Q16_LAUNCH
 }
 

@@ -37,7 +37,8 @@ struct qrk_context_s {
                                    // to a scalar evaluation of Eigen's algorithm, ~30x slower; the fast kernels send only the tiles
                                    // whose decisions are not clear of rounding there
     bool use_thin_kernel = true;   // ... and of those the tiles with 1 or 2 columns: one tile per lane (bdqr_thin.hip); QRK_THIN=0 disables
-    bool use_quad_kernel = true;   // uniform tiles with 9 .. 16 rows: four tiles per wavefront (bdqr_quad.hip); QRK_QUAD=0: bdqr_small.hip's 16-lane groups
+    bool use_quad_kernel = true;   // uniform tiles with 9 .. 16 rows: four tiles per wavefront (bdqr_quad.hip); QRK_QUAD=0: bdqr_small.hip's groups of 8 / 16 lanes
+    int quad_min_rows = 9;         // (QRK_QUAD_MIN_ROWS: diagnostic)
     bool use_small_kernel = true;  // uniform tiles with at most 16 rows: 64/G tiles per wavefront (bdqr_small.hip); QRK_SMALL=0 disables
     // side streams for the size classes of a mixed batch (fork after / join into `stream`), created on first use
     hipStream_t side[3] = {nullptr, nullptr, nullptr};
@@ -381,8 +382,8 @@ qrk_status enqueue_factorize(qrk_bd_plan_s* p, const double* tiles, double* q, d
             qrk::launch_bdqr_wg(nb, tiles, q, r, perm, hc, p->d_workspace, p->ws_stride, p->num_wg, p->max_dim, redo_cnt, redo_ids, h->stream);
         else if (p->max_dim <= 16 && p->r >= p->c && p->c <= 2 && h->use_small_kernel && h->use_thin_kernel)   // a tile per lane (bdqr_thin.hip)
             qrk::launch_bdqr_thin(p->B, p->r, p->c, nb.pivoting, tiles, q, r, perm, hc, h->num_cus * 32, redo_cnt, redo_ids, h->stream);
-        else if (p->max_dim <= 16 && h->use_small_kernel && h->use_quad_kernel && qrk::bdqr_quad_supported(p->r, p->c))   // four tiles per wavefront
-            qrk::launch_bdqr_quad(p->B, p->r, p->c, nb.pivoting, tiles, q, r, perm, hc, h->num_cus * qrk::bdqr_quad_waves_per_cu(), redo_cnt, redo_ids, h->stream);
+        else if (p->max_dim <= 16 && h->use_small_kernel && h->use_quad_kernel && p->r >= h->quad_min_rows && qrk::bdqr_quad_supported(p->r, p->c))   // four tiles per wavefront
+            qrk::launch_bdqr_quad(p->B, p->r, p->c, nb.pivoting, tiles, q, r, perm, hc, h->num_cus * qrk::bdqr_quad_waves_per_cu(p->r), redo_cnt, redo_ids, h->stream);
         else if (p->max_dim <= 16 && p->r >= p->c && h->use_small_kernel)   // 64/G tiles per wavefront (bdqr_small.hip)
             qrk::launch_bdqr_small(p->B, p->r, p->c, nb.pivoting, tiles, q, r, perm, hc, h->num_cus * 32, redo_cnt, redo_ids, h->stream);
         else if (p->d_p4_scratch) {
@@ -490,6 +491,7 @@ qrk_status qrk_create(qrk_handle* out, int device, void* stream)
     if (const char* k = std::getenv("QRK_EXACT")) h->force_exact = k[0] == '1';
     if (const char* k = std::getenv("QRK_SMALL")) h->use_small_kernel = k[0] != '0';
     if (const char* k = std::getenv("QRK_QUAD")) h->use_quad_kernel = k[0] != '0';
+    if (const char* k = std::getenv("QRK_QUAD_MIN_ROWS")) h->quad_min_rows = std::atoi(k);
     if (const char* k = std::getenv("QRK_THIN")) h->use_thin_kernel = k[0] != '0';
     if (const char* k = std::getenv("QRK_PAIR_WGS_PER_CU")) { const int v = std::atoi(k); if (v > 0) h->pair_wgs_per_cu = v; }
     if (hipSetDevice(device) != hipSuccess) {
@@ -2295,8 +2297,8 @@ const char* qrk_bd_kernel_name(qrk_bd_plan p, int which)
     if (p->max_dim > 32) return "qrk::bdqr_col_kernel";
     if (p->uniform && p->max_dim <= 16 && p->r >= p->c && p->c <= 2 && h->use_small_kernel && h->use_thin_kernel)
         return piv ? "qrk::thin::bdqr_thin_kernel<true, HC>" : "qrk::thin::bdqr_thin_kernel<false, HC>";
-    if (p->uniform && p->max_dim <= 16 && h->use_small_kernel && h->use_quad_kernel && qrk::bdqr_quad_supported(p->r, p->c))
-        return piv ? "qrk::bdqr_quad_kernel<true, HC>" : "qrk::bdqr_quad_kernel<false, HC>";
+    if (p->uniform && p->max_dim <= 16 && h->use_small_kernel && h->use_quad_kernel && p->r >= h->quad_min_rows && qrk::bdqr_quad_supported(p->r, p->c))
+        return piv ? "qrk::bdqr_quad_kernel<WR, true, HC>" : "qrk::bdqr_quad_kernel<WR, false, HC>";
     if (p->uniform && p->max_dim <= 16 && p->r >= p->c && h->use_small_kernel)
         return piv ? "qrk::bdqr_small_kernel<G, true>" : "qrk::bdqr_small_kernel<G, false>";
     // (tau is not stored by the measurement entry point and by callers that pass hcoeffs = NULL: the <.., false> instantiation)

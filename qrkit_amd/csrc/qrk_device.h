@@ -55,7 +55,7 @@ void launch_bdqr_pair(const WaveBatch& nb, bool full32, const double* tiles, dou
 // Uniform batches of small tiles (rows <= 16, cols <= rows): 64/G tiles per wavefront (bdqr_small.hip).
 // bdqr_quad.hip: uniform tiles with 9 .. 16 rows, four tiles per wavefront (two phases, DPP broadcast); flagged tiles -> redo list
 bool bdqr_quad_supported(int r, int c);
-int bdqr_quad_waves_per_cu();
+int bdqr_quad_waves_per_cu(int r);
 void launch_bdqr_quad(int64_t num_tiles, int r, int c, int pivoting, const double* tiles, double* q_vals, double* r_vals, int32_t* perm,
                       double* hcoeffs, int num_wg, int32_t* redo_count, int32_t* redo_ids, hipStream_t stream);
 void launch_bdqr_small(int64_t num_tiles, int r, int c, int pivoting, const double* tiles, double* q_vals, double* r_vals,

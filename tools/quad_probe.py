@@ -7,8 +7,9 @@ import torch
 import qrkit_amd
 from qrkit_amd import _capi as capi
 ctx = qrkit_amd.Context(0)
-for (r, c) in ((16, 16), (12, 12), (9, 9), (16, 8), (12, 6), (10, 4)):
-    for B in (20000, 400000):
+SHAPES = ((16, 16), (12, 12), (9, 9), (16, 8), (12, 6), (10, 4)) if len(sys.argv) < 2 else ((8, 8), (8, 6), (6, 6), (7, 4), (5, 5), (8, 3))
+for (r, c) in SHAPES:
+    for B in ((20000, 400000) if r > 8 else (20000, 1000000)):
         lay = capi.BDLayout(); lay.num_blocks, lay.block_rows, lay.block_cols = B, r, c; lay.rows = lay.cols = None; lay.mat_rows, lay.mat_cols = B * r, B * c
         plan = C.c_void_p(); capi.check(capi.lib().qrk_bd_plan_create(ctx.handle, C.byref(lay), 0, 0, C.byref(plan)))
         S = max(1, min(8, 800000 // B))
