@@ -1,5 +1,5 @@
-// bdqr_quad.hip -- uniform batches of tiles with 9 .. 16 rows (cols <= rows), FOUR tiles per wavefront: A_i P_i = Q_i R_i with explicit
-// Q_i, for gfx950.  The design of bdqr_pair4.hip (round 4 / 5) at 16 rows; round 5.
+// bdqr_quad.hip -- uniform batches of tiles with 5 .. 16 rows (cols <= rows), FOUR tiles per wavefront (9 .. 16 rows) or EIGHT (5 .. 8
+// rows): A_i P_i = Q_i R_i with explicit Q_i, for gfx950.  The design of bdqr_pair4.hip (round 4 / 5) at 16 and at 8 rows; round 5.
 //
 // Same reference seam as the other block-diagonal kernels: the body of the hot loop of QRKit::BlockDiagonalSparseQR::factorize
 // (src/QRKit/BlockDiagonalSparseQR.h:432-526): blockSolver.compute(block) (:437-438, Eigen ColPivHouseholderQR / HouseholderQR),
@@ -13,7 +13,10 @@
 //     lane & 15 and the dot / update FMAs read it through the DPP row_newbcast operand -- no register of the broadcast, no bpermute;
 //   * two phases in the same registers: A -> R, then Q = H_0 ... H_{c-1} by backward accumulation from the reflectors in LDS;
 //   * 32 data registers, 1.5 KB of LDS per tile: more waves per SIMD than the LDS pipe can use.
-// Tiles with fewer than 16 rows are zero-padded below (zero rows change neither the reflectors nor any sum); the steps run to the
+// Tiles of 5 .. 8 rows (WR = 8): lane 8 g + j owns column j of tile g in 8 row registers, TWO tiles share a DPP row; every FMA with a
+// row_newbcast operand becomes two, told apart by the bank mask (lanes 0..7 read lane N of the row, lanes 8..15 lane 8 + N); the maximum
+// over a tile stops at the half-row mirror.  See the hazard note at fmac_bcast.
+// Tiles with fewer than 16 (8) rows are zero-padded below (zero rows change neither the reflectors nor any sum); the steps run to the
 // launch's number of columns.  Decisions exactly as bdqr_pair.hip ("Decisions and the exact path"): integer arg-max on the high
 // words with a filter, margins, LAWN-176 band, degenerate reflector, sign of beta, noise-level pivot; a flagged tile goes to the redo
 // list of the exact path (bdqr_exact.hip), like bdqr_small.hip's.
@@ -28,8 +31,8 @@ namespace q16 {
 using namespace decide;
 
 constexpr int FILTER = 256;              // pivot candidates: high word of the squared norm within 2^-12 (relative) of the largest
-// WR: row registers per lane (16: tiles of 9 .. 16 rows; 8: tiles of up to 8 rows -- still sixteen lanes per tile, the lanes beyond the
-// tile's columns idle).  LDS per TILE (doubles): reflector K (the pivot column of step K, as published) holds rows K .. WR - 1 at cb(K)
+// WR: row registers per lane = lanes per tile (16: tiles of 9 .. 16 rows, four per wavefront; 8: tiles of 5 .. 8 rows, eight per
+// wavefront).  LDS per TILE (doubles): reflector K (the pivot column of step K, as published) holds rows K .. WR - 1 at cb(K)
 template <int WR>
 struct Lay {
     static constexpr int cb(int k) { int s = 0; for (int q = 0; q < k; ++q) s += WR - q; return s; }
@@ -65,17 +68,69 @@ __device__ __forceinline__ double recip(double x)
     y = fma(y, e, y);
     return y;
 }
-// d += X[N] * c, X read through DPP row_newbcast (element N of the lane's row of 16 lanes = of its tile)
-template <int N>
+// d += X[N] * c with X[N] = element N of the lane's TILE, through the DPP row_newbcast operand.  WR = 16: a tile is a DPP row of 16 lanes.
+// WR = 8: two tiles share a row -- lanes 0..7 read lane N, lanes 8..15 lane 8 + N, two instructions told apart by the bank mask (a bank
+// is four lanes; a lane outside the mask keeps its value).
+// HAZARD (gfx950, tools/ubench_dpp64_bankmask.hip, profiles/r05_quad.txt): two DPP operations with DIFFERENT bank masks that write the
+// same register back to back lose the first one's lanes (the second takes its accumulator from the forwarding path, which holds nothing
+// valid for the lanes the first one masked off).  One instruction of any kind between the two is enough; the same mask twice in a row,
+// or an ordinary VALU write before a masked operation, is fine.  Hence the s_nop 0 here and the two-row form below, where the second
+// row's instruction is the one in between.
+template <int WR, int N>
 __device__ __forceinline__ void fmac_bcast(double& d, double X, double c)
 {
-    asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(d) : "v"(X), "v"(c), "n"(N));
+    if (WR == 16) {
+        asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(d) : "v"(X), "v"(c), "n"(N));
+    } else {
+        asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0x3\n\t"
+            "s_nop 0\n\t"
+            "v_fmac_f64_dpp %0, %1, %2 row_newbcast:%4 row_mask:0xf bank_mask:0xc" : "+v"(d) : "v"(X), "v"(c), "n"(N & 7), "n"((N & 7) + 8));
+    }
 }
-template <int N>
+// (WR = 8) dN += X[N] * cN and dM += X[M] * cM: low halves of both, then high halves of both -- no wait state
+template <int N, int M>
+__device__ __forceinline__ void fmac_bcast2_oct(double& dN, double& dM, double X, double cN, double cM)
+{
+    asm("v_fmac_f64_dpp %0, %2, %3 row_newbcast:%5 row_mask:0xf bank_mask:0x3\n\t"
+        "v_fmac_f64_dpp %1, %2, %4 row_newbcast:%6 row_mask:0xf bank_mask:0x3\n\t"
+        "v_fmac_f64_dpp %0, %2, %3 row_newbcast:%7 row_mask:0xf bank_mask:0xc\n\t"
+        "v_fmac_f64_dpp %1, %2, %4 row_newbcast:%8 row_mask:0xf bank_mask:0xc"
+        : "+v"(dN), "+v"(dM) : "v"(X), "v"(cN), "v"(cM), "n"(N & 7), "n"(M & 7), "n"((N & 7) + 8), "n"((M & 7) + 8));
+}
+// (WR = 8) the rows I..7 of a dot product (accumulators by the parity of the row, as in the 16-lane form) and of an update, two rows at
+// a time
+template <int I>
+__device__ __forceinline__ void dot_rows_oct(double& d0, double& d1, double xc, const double (&a)[8])
+{
+    if constexpr (I + 1 < 8) {
+        if constexpr ((I & 1) != 0) fmac_bcast2_oct<I, I + 1>(d1, d0, xc, a[I], a[I + 1]);
+        else fmac_bcast2_oct<I, I + 1>(d0, d1, xc, a[I], a[I + 1]);
+        dot_rows_oct<I + 2>(d0, d1, xc, a);
+    } else if constexpr (I < 8) {
+        fmac_bcast<8, I>((I & 1) ? d1 : d0, xc, a[I]);
+    }
+}
+template <int I>
+__device__ __forceinline__ void upd_rows_oct(double (&a)[8], double xc, double ngam)
+{
+    if constexpr (I + 1 < 8) {
+        fmac_bcast2_oct<I, I + 1>(a[I], a[I + 1], xc, ngam, ngam);
+        upd_rows_oct<I + 2>(a, xc, ngam);
+    } else if constexpr (I < 8) {
+        fmac_bcast<8, I>(a[I], xc, ngam);
+    }
+}
+template <int WR, int N>
 __device__ __forceinline__ double bcast_f64(double X)
 {
     double r;
-    asm("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(X), "n"(N));
+    if (WR == 16) {
+        asm("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(X), "n"(N));
+    } else {
+        asm("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0x3\n\t"
+            "s_nop 0\n\t"
+            "v_mov_b64_dpp %0, %1 row_newbcast:%3 row_mask:0xf bank_mask:0xc" : "=&v"(r) : "v"(X), "n"(N & 7), "n"((N & 7) + 8));
+    }
     return r;
 }
 __device__ __forceinline__ double bpermute_f64(int byte_addr, double v)
@@ -84,27 +139,39 @@ __device__ __forceinline__ double bpermute_f64(int byte_addr, double v)
     const int hi = __builtin_amdgcn_ds_bpermute(byte_addr, __double2hiint(v));
     return __hiloint2double(hi, lo);
 }
-// max over every row of 16 lanes, in every lane of the row: four fused DPP stages
-__device__ __forceinline__ int row16_max_i32_fused(int v)
+// max over the WR lanes of every tile, in every lane of the tile: fused DPP stages (quad xor 1, quad xor 2, half-row mirror = 8 lanes;
+// row mirror = 16)
+template <int WR>
+__device__ __forceinline__ int tile_max_i32_fused(int v)
 {
     int m;
-    asm("s_nop 1\n\t"
-        "v_max_i32_dpp %0, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\t"
-        "v_max_i32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\t"
-        "v_max_i32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\t"
-        "v_max_i32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf"
-        : "=&v"(m) : "v"(v));
+    if (WR == 16)
+        asm("s_nop 1\n\t"
+            "v_max_i32_dpp %0, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+            "s_nop 1\n\t"
+            "v_max_i32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+            "s_nop 1\n\t"
+            "v_max_i32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+            "s_nop 1\n\t"
+            "v_max_i32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf"
+            : "=&v"(m) : "v"(v));
+    else
+        asm("s_nop 1\n\t"
+            "v_max_i32_dpp %0, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+            "s_nop 1\n\t"
+            "v_max_i32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+            "s_nop 1\n\t"
+            "v_max_i32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf"
+            : "=&v"(m) : "v"(v));
     return m;
 }
-__device__ __forceinline__ unsigned row16_max_u32(unsigned v)
+template <int WR>
+__device__ __forceinline__ unsigned tile_max_u32(unsigned v)
 {
     v = max(v, (unsigned)dpp_i32<0xB1>((int)v));
     v = max(v, (unsigned)dpp_i32<0x4E>((int)v));
     v = max(v, (unsigned)dpp_i32<0x141>((int)v));
-    v = max(v, (unsigned)dpp_i32<0x140>((int)v));
+    if (WR == 16) v = max(v, (unsigned)dpp_i32<0x140>((int)v));
     return v;
 }
 
@@ -131,11 +198,12 @@ __device__ __forceinline__ void step(double (&a)[WR], double* tl /* this tile's 
     unsigned long long pm;                                  // ballot of ispiv: one lane per tile
     if (PIVOT) {
         const int khi = __double2hiint(st.nu2);
-        const int mh = row16_max_i32_fused(khi);
+        const int mh = tile_max_i32_fused<WR>(khi);
         ispiv = khi >= mh - FILTER;
         pm = __builtin_amdgcn_ballot_w64(ispiv);
-        // (every tile has at least one candidate, so subtracting one from each 16-bit field never borrows across fields)
-        if (__builtin_expect((pm & (pm - 0x0001000100010001ull)) != 0ull, 0)) {
+        // (every tile has at least one candidate, so subtracting one from each WR-bit field never borrows across fields)
+        constexpr unsigned long long ONES = WR == 16 ? 0x0001000100010001ull : 0x0101010101010101ull;
+        if (__builtin_expect((pm & (pm - ONES)) != 0ull, 0)) {
             // several candidates in a tile: the largest (lowest lane among exact ties: the tile is flagged then) and the check of the
             // decision -- a live column within the error margin of the chosen one sends the tile to the exact path, which owns
             // Eigen's first-maximum rule on the current positions
@@ -143,13 +211,13 @@ __device__ __forceinline__ void step(double (&a)[WR], double* tl /* this tile's 
             const bool live = ((st.livemask >> lane) & 1ull) != 0ull;
             bool cand = live && khi == mh;
             const unsigned klo = (unsigned)__double2loint(st.nu2);
-            const unsigned ml = row16_max_u32(cand ? klo : 0u);
+            const unsigned ml = tile_max_u32<WR>(cand ? klo : 0u);
             cand = cand && klo == ml;
             const unsigned long long cm = __builtin_amdgcn_ballot_w64(cand);
-            const unsigned f = (unsigned)(cm >> (16 * st.g)) & 0xffffu;
+            const unsigned f = (unsigned)(cm >> (WR * st.g)) & ((1u << WR) - 1u);
             const int lbl = f ? __builtin_ctz(f) : 0;
             ispiv = cand && st.j == lbl;
-            const int src = ((st.g << 4) + lbl) << 2;
+            const int src = (st.g * WR + lbl) << 2;
             const double best = bpermute_f64(src, st.nu2), thrb = bpermute_f64(src, st.thr);
             double margin = MREL * (st.thr + thrb);
             if (K > 0) margin += 4.547473508864641e-13 /* 2^-41 */ * __builtin_sqrt(st.a2 * (best > 0.0 ? best : 0.0));
@@ -163,8 +231,8 @@ __device__ __forceinline__ void step(double (&a)[WR], double* tl /* this tile's 
     }
     if (K == 0 && PIVOT) {
         // the scale of the tile: the squared norm of its first pivot, to every lane of the tile
-        const unsigned f = (unsigned)(pm >> (16 * st.g)) & 0xffffu;
-        st.a2 = bpermute_f64(((st.g << 4) + (f ? __builtin_ctz(f) : 0)) << 2, st.nu2);
+        const unsigned f = (unsigned)(pm >> (WR * st.g)) & ((1u << WR) - 1u);
+        st.a2 = bpermute_f64((st.g * WR + (f ? __builtin_ctz(f) : 0)) << 2, st.nu2);
     }
     if (ispiv) {
         st.kstep = K;
@@ -176,16 +244,20 @@ __device__ __forceinline__ void step(double (&a)[WR], double* tl /* this tile's 
     }
     __builtin_amdgcn_wave_barrier();
     // ---- 3. the lanes' elements of it (element lane & 15; the elements above row K are not data and are never used), x0
-    double xc = *(const volatile lds_f64*)(tl + L_V + L::cb(K) - K + (lane & 15));
-    const double xk = bcast_f64<K>(xc);
+    double xc = *(const volatile lds_f64*)(tl + L_V + L::cb(K) - K + (lane & (WR - 1)));
+    const double xk = bcast_f64<WR, K>(xc);
     // ---- 4. d = x_tail^T a_tail of every column; the pivot lane's own is |x_tail|^2, handed to its tile through LDS (the slot of
     // tau_K, which is written after it) -- no cross-lane sum
     const double ak = a[K];
     double d0 = 0.0, d1 = 0.0;
     asm volatile("s_nop 1" : "+v"(xc));                      // (VALU write -> DPP read hazard, hidden from hipcc by the asm)
-#define QRK_Q16_DOT(I) if ((I) > K && (I) < WR) fmac_bcast<(I)>(((I) & 1) ? d1 : d0, xc, a[(I) < WR ? (I) : 0]);
-    QRK_Q16_0_15(QRK_Q16_DOT)
+    if constexpr (WR == 8) {
+        dot_rows_oct<K + 1>(d0, d1, xc, a);
+    } else {
+#define QRK_Q16_DOT(I) if ((I) > K && (I) < WR) fmac_bcast<WR, (I)>(((I) & 1) ? d1 : d0, xc, a[(I) < WR ? (I) : 0]);
+        QRK_Q16_0_15(QRK_Q16_DOT)
 #undef QRK_Q16_DOT
+    }
     const double dsum = d0 + d1;
     double tsq = 0.0;
     if (K + 1 < WR) {
@@ -230,9 +302,13 @@ __device__ __forceinline__ void step(double (&a)[WR], double* tl /* this tile's 
     a[K] = an;                                               // final: later steps work on the rows below
     if (!PIVOT) asm volatile("" : "+v"(a[K]));
     // ---- 6. the trailing update (columns already chosen are not masked out: nothing below the diagonal of R is ever read)
-#define QRK_Q16_UPD(I) if ((I) > K && (I) < WR) fmac_bcast<(I)>(a[(I) < WR ? (I) : 0], xc, ngam);
-    QRK_Q16_0_15(QRK_Q16_UPD)
+    if constexpr (WR == 8) {
+        upd_rows_oct<K + 1>(a, xc, ngam);
+    } else {
+#define QRK_Q16_UPD(I) if ((I) > K && (I) < WR) fmac_bcast<WR, (I)>(a[(I) < WR ? (I) : 0], xc, ngam);
+        QRK_Q16_0_15(QRK_Q16_UPD)
 #undef QRK_Q16_UPD
+    }
     // ---- 7. LAWN-176 norm downdate (squared form; no clamp at zero: a negative value is <= the threshold and recomputed)
     if (PIVOT && K + 1 < WR) {
         const double nn = fma(-an, an, st.nu2);
@@ -258,22 +334,30 @@ __device__ __forceinline__ void back_step(double (&q)[WR], const double* tl, con
 {
     typedef Lay<WR> L;
     double xc = 0.0;
-    if (K + 1 < WR) xc = *(const volatile lds_f64*)(tl + L::L_V + L::cb(K) - K + (lane & 15));
+    if (K + 1 < WR) xc = *(const volatile lds_f64*)(tl + L::L_V + L::cb(K) - K + (lane & (WR - 1)));
     const double qk = q[K];
     double d0 = 0.0, d1 = 0.0;
     asm volatile("s_nop 1" : "+v"(xc));
-#define QRK_Q16_DOT(I) if ((I) > K && (I) < WR) fmac_bcast<(I)>(((I) & 1) ? d1 : d0, xc, q[(I) < WR ? (I) : 0]);
-    QRK_Q16_0_15(QRK_Q16_DOT)
+    if constexpr (WR == 8) {
+        dot_rows_oct<K + 1>(d0, d1, xc, q);
+    } else {
+#define QRK_Q16_DOT(I) if ((I) > K && (I) < WR) fmac_bcast<WR, (I)>(((I) & 1) ? d1 : d0, xc, q[(I) < WR ? (I) : 0]);
+        QRK_Q16_0_15(QRK_Q16_DOT)
 #undef QRK_Q16_DOT
+    }
     double t = d0 + d1;
-    fmac_bcast<K>(t, sv, qk);
-    const double ngam = t * -bcast_f64<K>(ngv);
+    fmac_bcast<WR, K>(t, sv, qk);
+    const double ngam = t * -bcast_f64<WR, K>(ngv);
     double qn = qk;
-    fmac_bcast<K>(qn, sv, ngam);
+    fmac_bcast<WR, K>(qn, sv, ngam);
     q[K] = qn;
-#define QRK_Q16_UPD(I) if ((I) > K && (I) < WR) fmac_bcast<(I)>(q[(I) < WR ? (I) : 0], xc, ngam);
-    QRK_Q16_0_15(QRK_Q16_UPD)
+    if constexpr (WR == 8) {
+        upd_rows_oct<K + 1>(q, xc, ngam);
+    } else {
+#define QRK_Q16_UPD(I) if ((I) > K && (I) < WR) fmac_bcast<WR, (I)>(q[(I) < WR ? (I) : 0], xc, ngam);
+        QRK_Q16_0_15(QRK_Q16_UPD)
 #undef QRK_Q16_UPD
+    }
 }
 
 }  // namespace q16
@@ -295,18 +379,20 @@ bdqr_quad_kernel(int64_t num_tiles, int r, int c, const double* __restrict__ til
     using namespace q16;
     typedef Lay<WR> L;
     constexpr int L_TILE = L::L_TILE, L_S = L::L_S, L_NG = L::L_NG, L_TAU = L::L_TAU;
-    constexpr int MLD = (2 * WR * WR + 63) / 64;                      // load instructions per pair of tiles
-    __shared__ __attribute__((aligned(16))) double lds[4 * L_TILE];
-    const int64_t nquads = (num_tiles + 3) / 4;
+    constexpr int TPW = 64 / WR, HT = TPW / 2;                        // tiles per wave (4 or 8); tiles per staging pass
+    constexpr int LG = WR == 16 ? 4 : 3;                              // log2 of the lanes of a tile
+    constexpr int MLD = (HT * WR * WR + 63) / 64;                     // load instructions per staging pass
+    __shared__ __attribute__((aligned(16))) double lds[TPW * L_TILE];
+    const int64_t nquads = (num_tiles + TPW - 1) / TPW;
     const int rc = r * c, rr = r * r, nr = (c * (c + 1)) >> 1;
     for (int64_t qi = blockIdx.x; qi < nquads; qi += gridDim.x) {
         // (per-lane values are re-derived from an opaque lane id in every round: hipcc otherwise hoists loop-invariant address
         //  arithmetic out of the loop and keeps it in registers across the factorisation)
         int lane = threadIdx.x;
         asm volatile("" : "+v"(lane));
-        const int g = lane >> 4, j = lane & 15;
+        const int g = lane >> LG, j = lane & (WR - 1);
         double* tl = lds + g * L_TILE;
-        const int64_t t = 4 * qi + g;
+        const int64_t t = (int64_t)TPW * qi + g;
         const bool valid = t < num_tiles;
         Lane st;
         st.lane = lane; st.j = j; st.g = g; st.unclearm = 0ull; st.kstep = 0; st.a2 = 0.0;
@@ -319,12 +405,12 @@ bdqr_quad_kernel(int64_t num_tiles, int r, int c, const double* __restrict__ til
             // until the first publication) to lane = column, two tiles at a time with an odd column stride.  (Every lane loading its own
             // column directly costs 64 separate cache lines per load instruction: 20 000 tiles of 16 x 16 took 99 us that way, 69 with
             // bdqr_small.hip's staged sweeps.)
-            const int half = 2 * rc;                                  // doubles of a pair of tiles (<= 512)
-            const int n4 = (int)(num_tiles - 4 * qi < 4 ? num_tiles - 4 * qi : 4) * rc;
-            const double* qbase = tiles + 4 * qi * rc;
+            const int half = HT * rc;                                 // doubles of one staging pass: half the wave's tiles (<= 512)
+            const int n4 = (int)(num_tiles - TPW * qi < TPW ? num_tiles - TPW * qi : TPW) * rc;
+            const double* qbase = tiles + (int64_t)TPW * qi * rc;
             const int pad = (r & 1) ? 0 : 1, RS = r + pad;
             const unsigned M = (65536u + (unsigned)r - 1u) / (unsigned)r;      // (e M) >> 16 = e / r for e < 1024, 9 <= r <= 16
-            const double* colp = lds + ((g & 1) * c + (isA ? j : 0)) * RS;
+            const double* colp = lds + ((g & (HT - 1)) * c + (isA ? j : 0)) * RS;
             {
                 // (the loads of the second pair are issued when the first pair's registers are free: 16 + 16 live values otherwise)
                 double ld[MLD];
@@ -350,7 +436,7 @@ bdqr_quad_kernel(int64_t num_tiles, int r, int c, const double* __restrict__ til
                 if (e2 < half && half + e2 < n4) lds[e2 + (pad ? (int)(((unsigned)e2 * M) >> 16) : 0)] = ld2[m];
             }
             __builtin_amdgcn_wave_barrier();
-            if (g >= 2) {
+            if (g >= HT) {
 #pragma unroll
                 for (int i = 0; i < WR; ++i) a[i] = colp[i < r ? i : 0];
             }
@@ -377,7 +463,7 @@ bdqr_quad_kernel(int64_t num_tiles, int r, int c, const double* __restrict__ til
             // step p ends at position p
             int ln = threadIdx.x;
             asm volatile("" : "+v"(ln));
-            const int jj = ln & 15;
+            const int jj = ln & (WR - 1);
             if (valid && jj < c) {
                 const int p = st.kstep;
                 const int cbase = (int)(t * c);
@@ -386,18 +472,18 @@ bdqr_quad_kernel(int64_t num_tiles, int r, int c, const double* __restrict__ til
 #pragma unroll
                 for (int i = 0; i < WR; ++i)
                     if (i <= p) dst[i] = a[i];
-                if (HC && hcoeffs) hcoeffs[cbase + jj] = lds[(ln >> 4) * L_TILE + L_TAU + jj];
+                if (HC && hcoeffs) hcoeffs[cbase + jj] = lds[(ln >> LG) * L_TILE + L_TAU + jj];
             }
             // a decision inside its error margin, anywhere in the tile: the exact path redoes it (bdqr_exact.hip)
-            const bool f = ((st.unclearm >> (16 * (ln >> 4))) & 0xffffull) != 0ull;
+            const bool f = ((st.unclearm >> (WR * (ln >> LG))) & ((1ull << WR) - 1ull)) != 0ull;
             if (f && valid && jj == 0 && redo_count) redo_ids[atomicAdd(redo_count, 1)] = (int32_t)t;
         }
         {
             // =============== phase 2: Q = H_0 ... H_{c-1}, backward ===============
             int ln = threadIdx.x;
             asm volatile("" : "+v"(ln));
-            const int jj = ln & 15;
-            const double* tl2 = lds + (ln >> 4) * L_TILE;
+            const int jj = ln & (WR - 1);
+            const double* tl2 = lds + (ln >> LG) * L_TILE;
             double q[WR];
 #pragma unroll
             for (int i = 0; i < WR; ++i) q[i] = (i == jj) ? 1.0 : 0.0;
@@ -419,23 +505,23 @@ bdqr_quad_kernel(int64_t num_tiles, int r, int c, const double* __restrict__ til
     }
 }
 
-int bdqr_quad_waves_per_cu(int r) { (void)r; return 4 * QRK_QUAD_WAVES; }
-// 9 .. 16 rows.  (The 8-row instantiation -- still sixteen lanes per tile, four tiles per wave -- was measured against bdqr_small.hip's groups of
-// 8 lanes, eight tiles per wave: 10 % faster at 20 000 tiles, 12-28 % slower at 10^6, profiles/r05_quad.txt; it is not instantiated.)
-bool bdqr_quad_supported(int r, int c) { return r > 8 && r <= 16 && c >= 1 && c <= r; }
+int bdqr_quad_waves_per_cu(int r) { return 4 * (r > 8 ? QRK_QUAD_WAVES : QRK_QUAD_WAVES8); }
+// 9 .. 16 rows: four tiles per wave; 5 .. 8 rows: eight (two tiles per DPP row, the FMAs told apart by the bank mask)
+bool bdqr_quad_supported(int r, int c) { return r >= 5 && r <= 16 && c >= 1 && c <= r; }
 
 // Uniform batches of r x c tiles, r <= 16, c <= r.  num_wg: resident wave slots.
 void launch_bdqr_quad(int64_t num_tiles, int r, int c, int pivoting, const double* tiles, double* q_vals, double* r_vals, int32_t* perm,
                       double* hcoeffs, int num_wg, int32_t* redo_count, int32_t* redo_ids, hipStream_t stream)
 {
     if (num_tiles <= 0) return;
-    const int64_t nquads = (num_tiles + 3) / 4;
+    const int tpw = r > 8 ? 4 : 8;
+    const int64_t nquads = (num_tiles + tpw - 1) / tpw;
     const int64_t nwg = nquads < num_wg ? nquads : num_wg;
     const dim3 grid((unsigned)nwg), block(64);
 #define QRK_Q16_LAUNCH(W, P, H) hipLaunchKernelGGL((bdqr_quad_kernel<W, P, H>), grid, block, 0, stream, num_tiles, r, c, tiles, q_vals, r_vals, perm, hcoeffs, redo_count, redo_ids)
 #define QRK_Q16_LAUNCH2(W) do { if (pivoting) { if (hcoeffs) QRK_Q16_LAUNCH(W, true, true); else QRK_Q16_LAUNCH(W, true, false); } \
                                 else { if (hcoeffs) QRK_Q16_LAUNCH(W, false, true); else QRK_Q16_LAUNCH(W, false, false); } } while (0)
-    QRK_Q16_LAUNCH2(16);
+    if (r > 8) QRK_Q16_LAUNCH2(16); else QRK_Q16_LAUNCH2(8);
 #undef QRK_Q16_LAUNCH2
 #undef QRK_Q16_LAUNCH
 }

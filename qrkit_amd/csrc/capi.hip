@@ -37,8 +37,8 @@ struct qrk_context_s {
                                    // to a scalar evaluation of Eigen's algorithm, ~30x slower; the fast kernels send only the tiles
                                    // whose decisions are not clear of rounding there
     bool use_thin_kernel = true;   // ... and of those the tiles with 1 or 2 columns: one tile per lane (bdqr_thin.hip); QRK_THIN=0 disables
-    bool use_quad_kernel = true;   // uniform tiles with 9 .. 16 rows: four tiles per wavefront (bdqr_quad.hip); QRK_QUAD=0: bdqr_small.hip's groups of 8 / 16 lanes
-    int quad_min_rows = 9;         // (QRK_QUAD_MIN_ROWS: diagnostic)
+    bool use_quad_kernel = true;   // uniform tiles with 5 .. 16 rows: four or eight tiles per wavefront (bdqr_quad.hip); QRK_QUAD=0: bdqr_small.hip's groups of 8 / 16 lanes
+    int quad_min_rows = 5;         // (QRK_QUAD_MIN_ROWS: diagnostic -- shorter tiles stay on bdqr_small.hip)
     bool use_small_kernel = true;  // uniform tiles with at most 16 rows: 64/G tiles per wavefront (bdqr_small.hip); QRK_SMALL=0 disables
     // side streams for the size classes of a mixed batch (fork after / join into `stream`), created on first use
     hipStream_t side[3] = {nullptr, nullptr, nullptr};

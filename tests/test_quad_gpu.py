@@ -1,6 +1,7 @@
-"""GPU parity of the four-tiles-per-wavefront kernel (bdqr_quad.hip: uniform batches of tiles with 9..16 rows, cols <= rows; the design of
-bdqr_pair4.hip at 16 rows) against the oracle, per tile; against bdqr_small.hip's 16-lane groups, which it replaces for those shapes
-(QRK_QUAD=0); run to run; and at a large batch by size-independent properties."""
+"""GPU parity of the several-tiles-per-wavefront kernel (bdqr_quad.hip: uniform batches of tiles with 5..16 rows, cols <= rows; the design
+of bdqr_pair4.hip at 16 rows, four tiles per wavefront, and at 8 rows, eight tiles per wavefront with two tiles per DPP row) against the
+oracle, per tile; against bdqr_small.hip's lane groups, which it replaces for those shapes (QRK_QUAD=0); run to run; and at a large batch
+by size-independent properties."""
 import os
 
 import numpy as np
@@ -33,7 +34,10 @@ def factor(qa, rows, cols, tiles, solver=0, hc=True, quad=True):
 
 
 @pytest.mark.parametrize("B,r,c", [(1, 16, 16), (2, 16, 16), (3, 16, 16), (4, 16, 16), (5, 16, 16), (1001, 16, 16), (257, 9, 9), (130, 12, 12),
-                                   (66, 16, 9), (67, 13, 7), (40, 10, 3), (33, 15, 15), (9, 11, 10), (12, 14, 14)])
+                                   (66, 16, 9), (67, 13, 7), (40, 10, 3), (33, 15, 15), (9, 11, 10), (12, 14, 14),
+                                   # eight tiles per wavefront (5..8 rows): every count of tiles in the last wavefront
+                                   (1, 8, 8), (2, 8, 8), (3, 8, 6), (7, 8, 8), (8, 8, 8), (9, 8, 8), (15, 7, 7), (1003, 8, 8), (777, 8, 6), (260, 6, 6),
+                                   (131, 7, 4), (99, 5, 5), (64, 8, 3), (41, 6, 5), (23, 5, 3)])
 @pytest.mark.parametrize("solver", [0, 1])
 def test_quad_matches_oracle_per_tile(qa, B, r, c, solver):
     tiles = seeded_tiles(1000 + B + 16 * r + c, -1.0, 1.0, B * r * c)
@@ -53,14 +57,15 @@ def test_quad_matches_oracle_per_tile(qa, B, r, c, solver):
 def test_quad_kernel_is_the_one_that_runs(qa):
     import ctypes as C
     from qrkit_amd import _capi as capi
-    rows = np.full(8, 16, np.int32)
-    qr = factor(qa, rows, rows, seeded_tiles(3, -1.0, 1.0, 8 * 256))
     capi.lib().qrk_bd_kernel_name.restype = C.c_char_p
     capi.lib().qrk_bd_kernel_name.argtypes = [C.c_void_p, C.c_int]
-    assert b"bdqr_quad_kernel" in capi.lib().qrk_bd_kernel_name(qr._plan, 0)
+    for n in (16, 8, 5):
+        rows = np.full(8, n, np.int32)
+        qr = factor(qa, rows, rows, seeded_tiles(3, -1.0, 1.0, 8 * n * n))
+        assert b"bdqr_quad_kernel" in capi.lib().qrk_bd_kernel_name(qr._plan, 0)
 
 
-@pytest.mark.parametrize("r,c", [(16, 16), (12, 9), (9, 9)])
+@pytest.mark.parametrize("r,c", [(16, 16), (12, 9), (9, 9), (8, 8), (8, 6), (6, 6), (5, 4)])
 def test_quad_against_the_sixteen_lane_groups_and_run_to_run(qa, r, c):
     B = 403
     tiles = seeded_tiles(77 + r, 0.5, 5.0, B * r * c)
@@ -76,17 +81,18 @@ def test_quad_against_the_sixteen_lane_groups_and_run_to_run(qa, r, c):
     assert per_tile_rel(a.rValues().cpu().numpy(), s.rValues().cpu().numpy(), nr) <= 1e-12
 
 
+@pytest.mark.parametrize("n", [16, 8])
 @pytest.mark.parametrize("kind", ["pm1", "small_int", "dup_cols", "zero", "graded"])
-def test_quad_tie_and_degenerate_tiles_take_the_exact_path(qa, kind):
+def test_quad_tie_and_degenerate_tiles_take_the_exact_path(qa, kind, n):
     """Tiles whose decisions are ties or inside rounding: the permutation must be the oracle's, the values bitwise where the exact path ran."""
     rng = np.random.default_rng(5)
-    B, r, c = 120, 16, 16
+    B, r, c = 120, n, n
     if kind == "pm1":
         t = rng.choice([-1.0, 1.0], size=(B, c, r))
     elif kind == "small_int":
         t = rng.integers(-3, 4, size=(B, c, r)).astype(np.float64)
     elif kind == "dup_cols":
-        t = rng.uniform(-1, 1, (B, c, r)); t[:, 5] = t[:, 2]; t[:, 11] = t[:, 2]
+        t = rng.uniform(-1, 1, (B, c, r)); t[:, 5] = t[:, 2]; t[:, c - 1] = t[:, 2]
     elif kind == "zero":
         t = rng.uniform(-1, 1, (B, c, r)); t[::3] = 0.0; t[1::3, 4] = 0.0
     else:
@@ -116,9 +122,10 @@ def test_quad_tie_and_degenerate_tiles_take_the_exact_path(qa, kind):
             assert np.linalg.norm(Q[i].T @ Q[i] - np.eye(r)) <= 1e-12
 
 
-def test_quad_large_batch_by_properties(qa):
+@pytest.mark.parametrize("n", [16, 8])
+def test_quad_large_batch_by_properties(qa, n):
     import torch
-    B, n = 200000, 16
+    B = 200000
     g = torch.Generator(device="cuda").manual_seed(9)
     tiles = torch.rand(B * n * n, device="cuda", dtype=torch.float64, generator=g) * 2 - 1
     rows = np.full(B, n, np.int32)
