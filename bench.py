@@ -324,7 +324,8 @@ def main():
     # ---- another BASELINE configuration on this GPU (N = 1; reported next to the headline, never as `value`)
     other = None
     if world == 1 and not args.no_other:
-        other = {"strong_shard_emulation": strong_shard_emulation(ctx, dev, torch, np, make_plan, run),
+        other = {"concurrent_streams": concurrent_streams(dev, torch, tiles, qv, rv, pm, S),
+                 "strong_shard_emulation": strong_shard_emulation(ctx, dev, torch, np, make_plan, run),
                  "small_tiles": small_tiles(ctx, dev, torch, np),
                  "configs4_share_of_one_gpu": mixed_share(ctx, dev, torch, np),
                  "configs2_strips": strips_config2(ctx, dev, torch, np),
@@ -511,6 +512,54 @@ def strong_shard_emulation(ctx, dev, torch, np, make_plan, run):
     return {"what": "one-GPU emulation of the per-GPU shard of the strong-scaling legs (unmeasured on 8 GPUs): the shard's launch time on "
                     "this GPU, the bytes of the R / perm gather and the speed-up they bound",
             "xgmi_link_GBs_nominal": XGMI_LINK_GBS, "runs": out}
+
+
+def concurrent_streams(dev, torch, tiles, qv, rv, pm, S, steps=300):
+    """The headline workload (a stream of independent 10 000-tile matrices, distinct buffers per matrix in flight) through ONE handle --
+    what `value` reports: every launch waits for the previous one to drain, so the 20-us chain of its last pairs is paid per launch --
+    against TWO and THREE handles on their own HIP streams, alternating: the tail of one launch runs beside the head of the next.  Wall
+    clock around `steps` factorisations.  What a caller with independent matrices gets by creating one handle per stream; never `value`
+    (there a launch is measured alone, and `roofline` prices that launch)."""
+    import qrkit_amd
+    from qrkit_amd import _capi as capi
+    lib = capi.lib()
+    res = {}
+    for n in (1, 2, 3):
+        lanes = []
+        for _ in range(n):
+            st = torch.cuda.Stream(device=dev)
+            with torch.cuda.stream(st):
+                c = qrkit_amd.Context(dev.index)                 # (bound to the stream that is current here)
+            lay = capi.BDLayout()
+            lay.num_blocks, lay.block_rows, lay.block_cols = BLOCKS, BR, BC
+            lay.rows = lay.cols = None
+            lay.mat_rows, lay.mat_cols = BLOCKS * BR, BLOCKS * BC
+            plan = C.c_void_p()
+            capi.check(lib.qrk_bd_plan_create(c.handle, C.byref(lay), capi.FULL_Q, capi.COLPIV_HOUSEHOLDER, C.byref(plan)), c.handle)
+            lanes.append((st, c, plan))
+
+        def step(it):
+            _, c, plan = lanes[it % n]
+            k = it % S
+            capi.check(lib.qrk_bd_factorize(plan, tiles.data_ptr() + 8 * k * BLOCKS * BR * BC, qv.data_ptr() + 8 * k * BLOCKS * BR * BR,
+                                            rv.data_ptr() + 8 * k * BLOCKS * 528, pm.data_ptr() + 4 * k * BLOCKS * BC, None, capi.MEM_DEVICE), c.handle)
+        for it in range(20):
+            step(it)
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            for it in range(steps):
+                step(it)
+            torch.cuda.synchronize()
+            ts.append((time.perf_counter() - t0) / steps)
+        us = sorted(ts)[1] * 1e6
+        res[str(n)] = {"us_per_factorization": us, "factorizations_per_s": 1e6 / us,
+                       "algorithmic_GBs": BYTES_PER_TILE * BLOCKS / us / 1e3, "frac_of_hbm": BYTES_PER_TILE * BLOCKS / us / 1e3 / HBM_PEAK_GBS}
+        for _, c, plan in lanes:
+            lib.qrk_bd_plan_destroy(plan)
+    return {"what": "configs[1] as a stream of independent matrices through 1 / 2 / 3 handles on their own HIP streams (wall clock, "
+                    "qrk_bd_factorize called from Python per step; 1 = the headline's schedule); not `value`", "handles": res}
 
 
 def small_tiles(ctx, dev, torch, np):

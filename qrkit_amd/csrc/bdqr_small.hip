@@ -271,7 +271,7 @@ bdqr_small_kernel(int64_t num_tiles, int r, int c, const double* __restrict__ ti
         __syncthreads();
         {
             double* dst = r_vals + t0 * nr;
-            for (int e = tid; e < nt * nr; e += 256) dst[e] = buf[e];
+            for (int e = tid; e < nt * nr; e += 256) QRK_OUT_STORE(dst + e, buf[e]);
         }
         __syncthreads();
         // ---- Q: lane j holds row j of Q_i
@@ -283,7 +283,7 @@ bdqr_small_kernel(int64_t num_tiles, int r, int c, const double* __restrict__ ti
         __syncthreads();
         {
             double* dst = q_vals + t0 * rr;
-            for (int e = tid; e < nt * rr; e += 256) dst[e] = buf[e];
+            for (int e = tid; e < nt * rr; e += 256) QRK_OUT_STORE(dst + e, buf[e]);
         }
         __syncthreads();
     }

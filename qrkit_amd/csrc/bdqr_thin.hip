@@ -162,7 +162,7 @@ bdqr_thin_kernel(int64_t num_tiles, int r, int c, const double* __restrict__ til
                 const double* o = thin_lds + tl * sout;
                 const double v1k = o[r + k];
                 const double wk = fma(-o[2 * r + 2], v1k, o[k]);                    // w(k) = v0(k) - tau1 (v0 . v1) v1(k)
-                dst[e] = fma(-(o[2 * r + 1] * o[r + j]), v1k, fma(-(o[2 * r] * o[j]), wk, j == k ? 1.0 : 0.0));
+                QRK_OUT_STORE(dst + e, fma(-(o[2 * r + 1] * o[r + j]), v1k, fma(-(o[2 * r] * o[j]), wk, j == k ? 1.0 : 0.0)));
             }
         }
         __syncthreads();

@@ -233,6 +233,17 @@ constexpr int PIVOTING_SIGN_FREE = 2;     // bit of the launchers' `pivoting` ar
 #else
 #define QRK_TILE_LOAD(p) (*(p))
 #endif
+// Results that leave in coalesced sweeps of whole cache lines (the LDS-staged small-tile kernels).  -DQRK_NT_OUT=1: non-temporal stores
+// (tools/ubench_stream_mix.hip: a 1 : 4 read : write stream of 1 GB runs at 0.65 of the nominal HBM rate with plain and at 0.85 with
+// non-temporal stores).  NOT for stores that fill a line piecewise (bdqr_pair4's rows of Q and columns of R: 2 x slower, r04_p4_nt.txt).
+#ifndef QRK_NT_OUT
+#define QRK_NT_OUT 0
+#endif
+#if QRK_NT_OUT
+#define QRK_OUT_STORE(p, v) __builtin_nontemporal_store((v), (p))
+#else
+#define QRK_OUT_STORE(p, v) (*(p) = (v))
+#endif
 
 // ---- cross-lane helpers (wave64) ---------------------------------------------------------
 
