@@ -130,8 +130,16 @@ bdqr_small_kernel(int64_t num_tiles, int r, int c, const double* __restrict__ ti
         const int nt = num_tiles - t0 < TW ? (int)(num_tiles - t0) : TW;
         // ---- tiles in: one coalesced sweep
         {
+            // (all the loads of a thread in flight before the first wait; clamped addresses, not predicated loads: bdqr_thin.hip)
             const double* src = tiles + t0 * rc;
-            for (int e = tid; e < nt * rc; e += 256) buf[e] = QRK_TILE_LOAD(src + e);
+            const int n = nt * rc;
+            for (int base = tid; base < n; base += 256 * 8) {
+                double v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { const int e = base + 256 * u; v[u] = QRK_TILE_LOAD(src + (e < n ? e : n - 1)); }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { const int e = base + 256 * u; if (e < n) buf[e] = v[u]; }
+            }
         }
         __syncthreads();
         const bool valid = tl < nt;

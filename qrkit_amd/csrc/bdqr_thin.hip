@@ -27,6 +27,29 @@ namespace thin {
 using namespace decide;
 constexpr int RM = 16;      // rows of a tile at most
 
+// sqrt and 1 / x to <= 1 ulp for positive normal x / normal x, as in the 32 x 32 kernels (bdqr_pair.hip): v_rsq / v_rcp and two
+// Newton / Goldschmidt steps instead of the library's sqrt and division sequences (four divisions and two square roots per tile were
+// a quarter of the instructions of the arithmetic phase)
+__device__ __forceinline__ double sqrt_pos(double x)
+{
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = 0.5 * y;
+    const double e = fma(-h, g, 0.5);
+    g = fma(g, e, g);
+    h = fma(h, e, h);
+    const double d = fma(-g, g, x);
+    return fma(d, h, g);
+}
+__device__ __forceinline__ double recip(double x)
+{
+    double y = __builtin_amdgcn_rcp(x);
+    double e = fma(-x, y, 1.0);
+    y = fma(y, e, y);
+    e = fma(-x, y, 1.0);
+    y = fma(y, e, y);
+    return y;
+}
+
 // One workgroup = 256 lanes = 256 consecutive tiles.  I/O goes through LDS so that every global access is a coalesced sweep over the
 // workgroup's contiguous run of `tiles` / `q_vals` (a lane reading or writing its own tile directly touches 64 different lines per
 // instruction: measured at 27 % of the roofline whatever the shape):
@@ -47,13 +70,47 @@ bdqr_thin_kernel(int64_t num_tiles, int r, int c, const double* __restrict__ til
     const float inv_rr = 1.0f / (float)rr, inv_r = 1.0f / (float)r;
     for (int64_t t0 = (int64_t)blockIdx.x * 256; t0 < num_tiles; t0 += (int64_t)gridDim.x * 256) {
         const int nt = (int)(num_tiles - t0 < 256 ? num_tiles - t0 : 256);
-        // ---- in: coalesced copy of the workgroup's tiles
+        // ---- in: coalesced copy of the workgroup's tiles.  All the loads of a thread are issued before the first one is waited for
+        // (a loop of load -> wait -> LDS write, one 8-byte word at a time, cost 40 of the 132 us of a 7 x 2 batch: profiles/r05_thin.txt);
+        // with an even number of words per tile a 16-byte word never straddles two tiles.  (Addresses are clamped, not the loads
+        // predicated: a load under a condition gets its own wait.)
         {
             const double* src = tiles + t0 * (int64_t)rc;
             const int n = nt * rc;
-            for (int e = tid; e < n; e += 256) {
-                const int tl = (int)(((float)e + 0.5f) / (float)rc);
-                thin_lds[tl * sin + (e - tl * rc)] = QRK_TILE_LOAD(src + e);
+            if ((rc & 1) == 0) {
+                typedef double d2 __attribute__((ext_vector_type(2)));
+                const d2* src2 = reinterpret_cast<const d2*>(src);             // (t0 is a multiple of 256: 16-byte aligned)
+                const int n2 = n >> 1, h2 = rc >> 1;
+                const float inv_h2 = 1.0f / (float)h2;
+                for (int base = tid; base < n2; base += 256 * 8) {
+                    d2 v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) { const int e = base + 256 * u; v[u] = QRK_TILE_LOAD(src2 + (e < n2 ? e : n2 - 1)); }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int e = base + 256 * u;
+                        if (e < n2) {
+                            const int tl = (int)(((float)e + 0.5f) * inv_h2);
+                            double* o = thin_lds + tl * sin + 2 * (e - tl * h2);
+                            o[0] = v[u].x; o[1] = v[u].y;
+                        }
+                    }
+                }
+            } else {
+                const float inv_rc = 1.0f / (float)rc;
+                for (int base = tid; base < n; base += 256 * 8) {
+                    double v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) { const int e = base + 256 * u; v[u] = QRK_TILE_LOAD(src + (e < n ? e : n - 1)); }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int e = base + 256 * u;
+                        if (e < n) {
+                            const int tl = (int)(((float)e + 0.5f) * inv_rc);
+                            thin_lds[tl * sin + (e - tl * rc)] = v[u];
+                        }
+                    }
+                }
             }
         }
         __syncthreads();
@@ -93,10 +150,10 @@ bdqr_thin_kernel(int64_t num_tiles, int r, int c, const double* __restrict__ til
         double tau0, beta0, inv0;
         if (!(tsq > DBL_MIN)) { tau0 = 0.0; beta0 = x0; inv0 = 0.0; }
         else {
-            beta0 = sqrt(fma(x0, x0, tsq));
+            beta0 = sqrt_pos(fma(x0, x0, tsq));
             if (x0 >= 0.0) beta0 = -beta0;
-            inv0 = 1.0 / (x0 - beta0);
-            tau0 = (beta0 - x0) / beta0;
+            inv0 = recip(x0 - beta0);
+            tau0 = (beta0 - x0) * recip(beta0);
         }
         a0[0] = 1.0;                                      // v0 = [1; essential] in place
 #pragma unroll
@@ -120,10 +177,10 @@ bdqr_thin_kernel(int64_t num_tiles, int r, int c, const double* __restrict__ til
             double inv1;
             if (!(tsq1 > DBL_MIN)) { tau1 = 0.0; beta1 = y0; inv1 = 0.0; }
             else {
-                beta1 = sqrt(fma(y0, y0, tsq1));
+                beta1 = sqrt_pos(fma(y0, y0, tsq1));
                 if (y0 >= 0.0) beta1 = -beta1;
-                inv1 = 1.0 / (y0 - beta1);
-                tau1 = (beta1 - y0) / beta1;
+                inv1 = recip(y0 - beta1);
+                tau1 = (beta1 - y0) * recip(beta1);
             }
             a1[0] = 0.0; a1[1] = 1.0;                     // v1 = [0; 1; essential]
 #pragma unroll
