@@ -6,7 +6,13 @@
 // qrk_bd_solve = _solve_impl (:257-280).  There is no CPU fallback anywhere in this file.
 #include "../../include/qrkit_amd.h"
 #include "qrk_device.h"
-#include <rccl/rccl.h>     // types only: the entry points are resolved at run time (qrk_gather_r)
+// The few RCCL / NCCL types the exchanges need, declared here so that the library builds on hosts without RCCL headers (the entry
+// points are resolved at run time, rccl_api() below; the values are the ABI of nccl.h / rccl.h: ncclSuccess = 0, ncclInt8 = 0,
+// ncclInt32 = 2, ncclFloat64 = 8)
+typedef struct ncclComm* ncclComm_t;
+typedef int ncclResult_t;
+typedef int ncclDataType_t;
+enum : int { ncclSuccess = 0, ncclInt8 = 0, ncclInt32 = 2, ncclFloat64 = 8 };
 #include <dlfcn.h>
 #include "banded_host.h"
 
@@ -2155,9 +2161,14 @@ const RcclApi& rccl_api()
 {
     static const RcclApi api = [] {
         RcclApi a;
+        // the RCCL that made the caller's communicator: global symbols first (torch links its own copy), then a librccl that is
+        // ALREADY loaded under either name (RTLD_NOLOAD: never a second instance beside it), and only then a fresh load -- a process
+        // whose communicator came from a statically linked or differently named RCCL must export ncclSend itself
         void* lib = RTLD_DEFAULT;
         if (!dlsym(lib, "ncclSend")) {
-            lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+            lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);
+            if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_NOLOAD);
+            if (!lib) lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
             if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
             if (!lib) return a;
         }
