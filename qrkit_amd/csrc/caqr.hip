@@ -38,7 +38,7 @@ constexpr int NB = 32;          // panel width = rows of a chunk
 constexpr int FAN = 8;          // chunks per slab
 constexpr int SR = NB * FAN;    // virtual rows of a slab
 constexpr int LS = NB + 1;      // LDS row stride (doubles): conflict-free by rows and by columns
-constexpr size_t PANEL_LDS = (size_t)(SR * LS + 2 * FAN * NB + 2 * FAN + 2 * NB + 2) * sizeof(double);            // 72 KB: fits where an apply workgroup (76 KB) was
+constexpr size_t PANEL_LDS = (size_t)(SR * LS + 2 * FAN * NB + FAN + 2 * NB + 1) * sizeof(double);            // 72 KB: fits where an apply workgroup (76 KB) was
 constexpr size_t APPLY_LDS = (size_t)(SR * LS + NB * LS) * sizeof(double);                                            // 76 KB
 // LDS asked for by the apply launch that runs BESIDE the factorisation of the next panel when QRK_CAQR_BESIDE=1: more than half a CU's
 // 160 KB, so that one apply workgroup per CU is resident and a panel workgroup (72 KB, 240 VGPRs) finds room at once instead of waiting
@@ -96,26 +96,6 @@ struct PanelLds {
 #endif
 };
 
-// The owners of column J (one thread per chunk) hand it to the slab: the column itself, the chunk's share of |x_tail|^2 (rows below the
-// pivot: the same FMAs in the same order as the sweep over the published column made them until round 5 -- two accumulators, rows
-// 0, 2 (mod 4) and 1, 3 (mod 4); a zero above the pivot adds nothing), and the pivot entry.  nrm / x0s are double-buffered by the parity
-// of J: the readers of step J - 1 may still be at it.
-template <int J>
-__device__ __forceinline__ void publish_column(const double (&a)[NB], const PanelLds& L, int i)
-{
-#pragma unroll
-    for (int r2 = 0; r2 < NB; r2 += 2) *reinterpret_cast<double2*>(&L.vb[i][r2]) = make_double2(a[r2], a[r2 + 1]);
-    double s0 = 0.0, s1 = 0.0;
-#pragma unroll
-    for (int r2 = 0; r2 < NB; r2 += 4) {
-        const double v0 = (r2 <= J && i == 0) ? 0.0 : a[r2], v1 = (r2 + 1 <= J && i == 0) ? 0.0 : a[r2 + 1];
-        const double v2 = (r2 + 2 <= J && i == 0) ? 0.0 : a[r2 + 2], v3 = (r2 + 3 <= J && i == 0) ? 0.0 : a[r2 + 3];
-        s0 = fma(v0, v0, s0); s1 = fma(v1, v1, s1); s0 = fma(v2, v2, s0); s1 = fma(v3, v3, s1);
-    }
-    L.nrm[(J & 1) * FAN + i] = s0 + s1;
-    if (i == 0) L.x0s[J & 1] = a[J < NB ? J : 0];
-}
-
 // Reflector J of the slab (every index into the register arrays is a compile-time constant: a rolled loop leaves them in scratch).
 template <int J>
 __device__ __forceinline__ void panel_step(double (&a)[NB], const PanelLds& L, int c, int i, int w)
@@ -134,23 +114,29 @@ __device__ __forceinline__ void panel_step(double (&a)[NB], const PanelLds& L, i
         const double2 t2 = *reinterpret_cast<const double2*>(&L.vb[i][r2]);
         v[r2] = t2.x; v[r2 + 1] = t2.y;
     }
+    const double xj = v[J];                                  // pivot entry (meaningful in chunk 0)
 #pragma unroll
     for (int r2 = 0; r2 < NB; ++r2) if (r2 <= J) v[r2] = (i == 0) ? 0.0 : v[r2];   // rows above and at the pivot are not part of the tail
-    // |x_tail|^2 (per chunk) and the pivot entry were left by the column's owners when they published it (publish_column): the reflector's
-    // scalars -- square root, two reciprocals, a dependent chain of ~350 cycles -- need nothing else and run beside the dot products
-    // instead of behind barrier (B) (round 5)
-    double nn[FAN];
-#pragma unroll
-    for (int ii = 0; ii < FAN; ++ii) nn[ii] = L.nrm[(J & 1) * FAN + ii];
-    const double x0 = L.x0s[J & 1];
-    double d0 = 0.0, d1 = 0.0, d2 = 0.0, d3 = 0.0;           // partial sums: no FMA waits for its predecessor
+    double d0 = 0.0, d1 = 0.0, d2 = 0.0, d3 = 0.0, s0 = 0.0, s1 = 0.0;    // partial sums: no FMA waits for its predecessor
 #pragma unroll
     for (int r2 = 0; r2 < NB; r2 += 4) {
         d0 = fma(v[r2], a[r2], d0); d1 = fma(v[r2 + 1], a[r2 + 1], d1); d2 = fma(v[r2 + 2], a[r2 + 2], d2); d3 = fma(v[r2 + 3], a[r2 + 3], d3);
+        s0 = fma(v[r2], v[r2], s0); s1 = fma(v[r2 + 1], v[r2 + 1], s1); s0 = fma(v[r2 + 2], v[r2 + 2], s0); s1 = fma(v[r2 + 3], v[r2 + 3], s1);
     }
     L.red[i][c] = (d0 + d1) + (d2 + d3);
-    if (i == 0) L.prow[c] = a[J];
+    if (c == 0) L.nrm[i] = s0 + s1;
+    if (i == 0) { L.prow[c] = a[J]; if (c == 0) *L.x0s = xj; }
+    QRK_FINE(2);
+    __syncthreads();                                         // (B)
+    QRK_FINE(3);
+    double rr[FAN], nn[FAN];
+#pragma unroll
+    for (int ii = 0; ii < FAN; ++ii) { rr[ii] = L.red[ii][c]; nn[ii] = L.nrm[ii]; }
+    const double D = ((rr[0] + rr[1]) + (rr[2] + rr[3])) + ((rr[4] + rr[5]) + (rr[6] + rr[7]));
     const double tailSq = ((nn[0] + nn[1]) + (nn[2] + nn[3])) + ((nn[4] + nn[5]) + (nn[6] + nn[7]));
+    static_assert((SR * LS) % 2 == 0, "vb is read and written with 16-byte LDS accesses");
+    static_assert(FAN == 8, "the sums above are written for 8 chunks");
+    const double x0 = *L.x0s, a0c = L.prow[c];
     double tau, beta, inv;
     if (tailSq <= DBL_MIN) { tau = 0.0; beta = x0; inv = 0.0; }
     else {
@@ -160,16 +146,6 @@ __device__ __forceinline__ void panel_step(double (&a)[NB], const PanelLds& L, i
         inv = fast_recip(wv);
         tau = -wv * fast_recip(beta);                // (beta - x0) / beta
     }
-    QRK_FINE(2);
-    __syncthreads();                                         // (B)
-    QRK_FINE(3);
-    double rr[FAN];
-#pragma unroll
-    for (int ii = 0; ii < FAN; ++ii) rr[ii] = L.red[ii][c];
-    const double D = ((rr[0] + rr[1]) + (rr[2] + rr[3])) + ((rr[4] + rr[5]) + (rr[6] + rr[7]));
-    static_assert((SR * LS) % 2 == 0, "vb is read and written with 16-byte LDS accesses");
-    static_assert(FAN == 8, "the sums above are written for 8 chunks");
-    const double a0c = L.prow[c];
     const double tmp = fma(inv, D, a0c);                     // row0 + essential^T bottom
     QRK_FINE(4);
     // columns right of J: c_J -= tau tmp, tail -= tau tmp essential; column J itself: the essential part in place, beta on the
@@ -191,7 +167,10 @@ __device__ __forceinline__ void panel_step(double (&a)[NB], const PanelLds& L, i
         L.zz[c][J] = tmp;                                    // y_c^T y_J = Y(J, c) + Y(tail, c)^T essential
     }
     QRK_FINE(5);
-    if (J + 1 < w && c == J + 1) publish_column<J + 1>(a, L, i);
+    if (J + 1 < w && c == J + 1) {
+#pragma unroll
+        for (int r2 = 0; r2 < NB; r2 += 2) *reinterpret_cast<double2*>(&L.vb[i][r2]) = make_double2(a[r2], a[r2 + 1]);
+    }
     QRK_FINE(6);
 }
 
@@ -213,9 +192,9 @@ caqr_panel_kernel(double* __restrict__ A, int64_t lda, int m, int pc, int w, Sla
                                                                                   // transposing buffer, which is idle between the load and the store (behind
                                                                                   // the two T scratch areas): 72 KB in all, the LDS slot of one apply workgroup
     double* nrm = &red[FAN][0];                                                   // [FAN] partial squared tail norms
-    double* prow = nrm + 2 * FAN;                                                 // [NB] pivot row      (nrm: [2][FAN], by the parity of the step)
+    double* prow = nrm + FAN;                                                     // [NB] pivot row
     double* taus = prow + NB;                                                     // [NB]
-    double* x0s = taus + NB;                                                      // [2] pivot entry, by the parity of the step
+    double& x0s = taus[NB];
 
     const int t = blockIdx.x;
     const int tid = threadIdx.x, c = tid & 31, i = tid >> 5;
@@ -241,6 +220,10 @@ caqr_panel_kernel(double* __restrict__ A, int64_t lda, int m, int pc, int w, Sla
     __syncthreads();                     // (the buffer has been read: its space now serves zz)
     for (int e = tid; e < NB * LS; e += 256) (&zz[0][0])[e] = 0.0;
 
+    if (c == 0) {
+#pragma unroll
+        for (int r2 = 0; r2 < NB; ++r2) vb[i][r2] = a[r2];
+    }
 #ifdef QRK_CAQR_STAMP   // diagnostic only (tools/caqr_bench.hip): s_memtime at phase boundaries, parked in the (zero) strictly lower part of T
 #define QRK_CAQR_STAMP_AT(n) do { if (tid == 0) stamps[n] = __builtin_amdgcn_s_memtime(); } while (0)
     __shared__ unsigned long long stamps[8];
@@ -250,11 +233,10 @@ caqr_panel_kernel(double* __restrict__ A, int64_t lda, int m, int pc, int w, Sla
     QRK_CAQR_STAMP_AT(0);
 #ifdef QRK_CAQR_STAMP
     __shared__ unsigned long long fine[8];
-    PanelLds L{vb, red, zz, nrm, prow, taus, x0s, fine};
+    PanelLds L{vb, red, zz, nrm, prow, taus, &x0s, fine};
 #else
-    PanelLds L{vb, red, zz, nrm, prow, taus, x0s};
+    PanelLds L{vb, red, zz, nrm, prow, taus, &x0s};
 #endif
-    if (c == 0) publish_column<0>(a, L, i);
 #define QRK_CAQR_STEP(J) if ((J) < w) panel_step<J>(a, L, c, i, w);
     QRK_CAQR_STEP(0) QRK_CAQR_STEP(1) QRK_CAQR_STEP(2) QRK_CAQR_STEP(3) QRK_CAQR_STEP(4) QRK_CAQR_STEP(5) QRK_CAQR_STEP(6) QRK_CAQR_STEP(7)
     QRK_CAQR_STAMP_AT(1);
