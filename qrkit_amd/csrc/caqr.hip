@@ -98,7 +98,7 @@ struct PanelLds {
 
 // Reflector J of the slab (every index into the register arrays is a compile-time constant: a rolled loop leaves them in scratch).
 template <int J>
-__device__ __forceinline__ void panel_step(double (&a)[NB], const PanelLds& L, int c, int i, int w)
+__device__ __forceinline__ void panel_step(double (&a)[NB], double& myinv, const PanelLds& L, int c, int i, int w)
 {
 #ifdef QRK_CAQR_STAMP
 #define QRK_FINE(n) do { if (J == 16 && c == 0 && i == 0) L.fine[n] = __builtin_amdgcn_s_memtime(); } while (0)
@@ -148,28 +148,27 @@ __device__ __forceinline__ void panel_step(double (&a)[NB], const PanelLds& L, i
     }
     const double tmp = fma(inv, D, a0c);                     // row0 + essential^T bottom
     QRK_FINE(4);
-    // columns right of J: c_J -= tau tmp, tail -= tau tmp essential; column J itself: the essential part in place, beta on the
-    // diagonal (coefficient and multiplier chosen per thread so that one FMA sweep serves both)
+    // columns right of J: c_J -= tau tmp, tail -= tau tmp essential -- ONE sweep for every lane, coefficient 0 for the columns up to J
+    // (until round 5 three divergent branches, which every wave ran one after the other: each has lanes with c < J, c == J and c > J;
+    // profiles/r05_caqr_panel.txt).  Column J: beta on the diagonal now; its essential part x_tail / (x0 - beta) is a scaling of
+    // registers that nothing reads again before the store: the thread keeps 1 / (x0 - beta) and scales at the end (same product, same bits).
     const double g = tau * tmp;
     const double coef = c > J ? -(g * inv) : 0.0;
-    if (c > J) {
-        if (i == 0) a[J] -= g;
+    if (i == 0 && c > J) a[J] -= g;
 #pragma unroll
-        for (int r2 = 0; r2 < NB; ++r2) a[r2] = fma(coef, v[r2], a[r2]);
-    } else if (c == J) {
-#pragma unroll
-        for (int r2 = 0; r2 < NB; ++r2) {                        // essential part, in place (chunk 0 keeps its rows of R above the pivot)
-            if (r2 > J) a[r2] = v[r2] * inv;
-            else a[r2] = (i == 0) ? a[r2] : v[r2] * inv;
-        }
-        if (i == 0) { a[J] = beta; L.taus[J] = tau; }
-    } else if (i == 0) {
-        L.zz[c][J] = tmp;                                    // y_c^T y_J = Y(J, c) + Y(tail, c)^T essential
-    }
+    for (int r2 = 0; r2 < NB; ++r2) a[r2] = fma(coef, v[r2], a[r2]);
     QRK_FINE(5);
+    // the next column goes out as soon as it is updated: everything below is off the chain
     if (J + 1 < w && c == J + 1) {
 #pragma unroll
         for (int r2 = 0; r2 < NB; r2 += 2) *reinterpret_cast<double2*>(&L.vb[i][r2]) = make_double2(a[r2], a[r2 + 1]);
+    }
+    if (c == J) {
+        myinv = inv;
+        if (i == 0) { a[J] = beta; L.taus[J] = tau; }
+    } else if (c < J && i == 0) {
+        // y_c^T y_J = Y(J, c) + Y(tail, c)^T essential; column c is still x_tail, not yet x_tail / (x0 - beta): the factor goes on the sum
+        L.zz[c][J] = tmp * myinv;
     }
     QRK_FINE(6);
 }
@@ -237,7 +236,8 @@ caqr_panel_kernel(double* __restrict__ A, int64_t lda, int m, int pc, int w, Sla
 #else
     PanelLds L{vb, red, zz, nrm, prow, taus, &x0s};
 #endif
-#define QRK_CAQR_STEP(J) if ((J) < w) panel_step<J>(a, L, c, i, w);
+    double myinv = 0.0;                  // 1 / (x0 - beta) of this thread's own column, once it has been the reflector
+#define QRK_CAQR_STEP(J) if ((J) < w) panel_step<J>(a, myinv, L, c, i, w);
     QRK_CAQR_STEP(0) QRK_CAQR_STEP(1) QRK_CAQR_STEP(2) QRK_CAQR_STEP(3) QRK_CAQR_STEP(4) QRK_CAQR_STEP(5) QRK_CAQR_STEP(6) QRK_CAQR_STEP(7)
     QRK_CAQR_STAMP_AT(1);
     QRK_CAQR_STEP(8) QRK_CAQR_STEP(9) QRK_CAQR_STEP(10) QRK_CAQR_STEP(11) QRK_CAQR_STEP(12) QRK_CAQR_STEP(13) QRK_CAQR_STEP(14) QRK_CAQR_STEP(15)
@@ -247,6 +247,11 @@ caqr_panel_kernel(double* __restrict__ A, int64_t lda, int m, int pc, int w, Sla
     QRK_CAQR_STEP(24) QRK_CAQR_STEP(25) QRK_CAQR_STEP(26) QRK_CAQR_STEP(27) QRK_CAQR_STEP(28) QRK_CAQR_STEP(29) QRK_CAQR_STEP(30) QRK_CAQR_STEP(31)
 #undef QRK_CAQR_STEP
     QRK_CAQR_STAMP_AT(4);
+    // the essential parts: column c below its pivot (chunk 0 keeps its rows of R up to the diagonal), scaled by 1 / (x0 - beta)
+    if (c < w) {
+#pragma unroll
+        for (int r2 = 0; r2 < NB; ++r2) a[r2] = (i > 0 || r2 > c) ? a[r2] * myinv : a[r2];
+    }
     __syncthreads();
     // ---- T (LAPACK larft forward/columnwise = Eigen make_block_householder_triangular_factor): T(l,l) = tau_l,
     // T(0:l,l) = -tau_l T(0:l,0:l) U(0:l,l) with U = strictly upper part of Y^T Y (zz).  In the recursive form: the four 8 x 8 diagonal

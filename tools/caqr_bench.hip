@@ -12,11 +12,18 @@ int main()
     hipMalloc(&A, h.size() * 8); hipMalloc(&T, (size_t)S * 1024 * 8);
     hipFuncSetAttribute(reinterpret_cast<const void*>(caqr_panel_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)PANEL_LDS);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int grid : {1, S}) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(caqr_panel_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)PANEL_LDS);
+    // grid 1 / S: level 0 (dense slabs); -20 / -3 / -1: the upper levels of the tree (stacks of triangles, chunk stride 8 / 64 / 512)
+    for (int grid : {1, S, -20, -3, -1}) {
         for (int it = 0; it < 3; ++it) {
             hipMemcpy(A, h.data(), h.size() * 8, hipMemcpyHostToDevice);
             hipEventRecord(e0);
-            hipLaunchKernelGGL((caqr_panel_kernel<false>), dim3(grid), dim3(256), PANEL_LDS, 0, A, (int64_t)m, m, 0, 32, Slab{0, 1, m / 32}, T);
+            if (grid > 0) hipLaunchKernelGGL((caqr_panel_kernel<false>), dim3(grid), dim3(256), PANEL_LDS, 0, A, (int64_t)m, m, 0, 32, Slab{0, 1, m / 32}, T);
+            else {
+                const int stride = grid == -20 ? 8 : (grid == -3 ? 64 : 512);
+                const int nch = (m / 32 + stride - 1) / stride;
+                hipLaunchKernelGGL((caqr_panel_kernel<true>), dim3(-grid), dim3(256), PANEL_LDS, 0, A, (int64_t)m, m, 0, 32, Slab{0, stride, nch}, T);
+            }
             hipEventRecord(e1); hipEventSynchronize(e1);
             float ms; hipEventElapsedTime(&ms, e0, e1);
             std::vector<double> t(1024);
