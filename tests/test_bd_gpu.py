@@ -385,3 +385,55 @@ def test_mixed_8_to_256_full_share_of_one_gpu(qa, ctx):
     _, qr2 = run_gpu(qa, ctx, n, n, tiles)
     np.testing.assert_array_equal(qr2.colsPermutation(), perm)
     assert torch.equal(qr2.qValues(), q1) and torch.equal(qr2.rValues(), r1)
+
+
+@pytest.mark.parametrize("n,B", [(32, 3000), (8, 5000), (48, 700)])
+def test_two_handles_on_two_streams_side_by_side(qa, n, B):
+    """Independent matrices through two handles on their own HIP streams, launches alternating (what bench.py's concurrent_streams leg
+    times): every factorisation must be bitwise what the same handle gives when it runs alone, and match the oracle."""
+    import ctypes as C
+    import torch
+    from qrkit_amd import _capi as capi
+    lib = capi.lib()
+    dev = torch.device("cuda", 0)
+    rows = np.full(B, n, np.int32)
+    lanes = []
+    for k in range(2):
+        st = torch.cuda.Stream(device=dev)
+        with torch.cuda.stream(st):
+            c = qa.Context(0)
+        lay = capi.BDLayout()
+        lay.num_blocks, lay.block_rows, lay.block_cols = B, n, n
+        lay.rows = lay.cols = None
+        lay.mat_rows = lay.mat_cols = B * n
+        plan = C.c_void_p()
+        capi.check(lib.qrk_bd_plan_create(c.handle, C.byref(lay), capi.FULL_Q, capi.COLPIV_HOUSEHOLDER, C.byref(plan)), c.handle)
+        g = torch.Generator(device=dev); g.manual_seed(100 + k)
+        t = torch.rand(B * n * n, generator=g, device=dev, dtype=torch.float64) * 2 - 1
+        q = torch.empty(B * n * n, device=dev, dtype=torch.float64)
+        r = torch.empty(B * (n * (n + 1) // 2), device=dev, dtype=torch.float64)
+        p = torch.empty(B * n, device=dev, dtype=torch.int32)
+        lanes.append((st, c, plan, t, q, r, p))
+    torch.cuda.synchronize()
+
+    def fact(k):
+        _, c, plan, t, q, r, p = lanes[k]
+        capi.check(lib.qrk_bd_factorize(plan, t.data_ptr(), q.data_ptr(), r.data_ptr(), p.data_ptr(), None, capi.MEM_DEVICE), c.handle)
+    alone = []
+    for k in range(2):
+        fact(k); torch.cuda.synchronize()
+        alone.append((lanes[k][4].clone(), lanes[k][5].clone(), lanes[k][6].clone()))
+        lanes[k][4].zero_(); lanes[k][5].zero_(); lanes[k][6].zero_()
+    torch.cuda.synchronize()
+    for it in range(6):
+        fact(it % 2)
+    torch.cuda.synchronize()
+    for k in range(2):
+        _, c, plan, t, q, r, p = lanes[k]
+        assert torch.equal(q, alone[k][0]) and torch.equal(r, alone[k][1]) and torch.equal(p, alone[k][2]), "side by side differs from alone"
+        _, ref = oracle_factorize(rows[:200], rows[:200], t[:200 * n * n].cpu().numpy())
+        np.testing.assert_array_equal(p[:200 * n].cpu().numpy(), ref.perm)
+        sq, sr, _ = tile_sizes(rows[:200], rows[:200])
+        assert per_tile_rel(q[:200 * n * n].cpu().numpy(), ref.Q_vals, sq) <= RTOL
+        assert per_tile_rel(r[:200 * (n * (n + 1) // 2)].cpu().numpy(), ref.R_vals, sr) <= RTOL
+        lib.qrk_bd_plan_destroy(plan)
