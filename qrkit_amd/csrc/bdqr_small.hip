@@ -1,6 +1,9 @@
 // bdqr_small.hip -- 64/G tiles per wavefront for uniform batches of SMALL tiles (rows <= G, G = 4, 8 or 16):
 // the shapes the reference itself runs -- 7x2 (test/test-qrkit.cpp:49-51), 9x2 LM-damped (test-utils.cpp:254-274),
 // 6x6 / 8x6 (BASELINE block-angular left part) -- for gfx950.
+// Since round 5 the default for these shapes is elsewhere -- 1 or 2 columns: bdqr_thin.hip (round 2), 5 .. 16 rows: bdqr_quad.hip
+// (round 5) -- and this kernel runs the tiles of at most 4 rows with 3 or 4 columns; QRK_THIN=0 / QRK_QUAD=0 bring the others back
+// here (the cross-checks of tests/test_quad_gpu.py and tests/test_small_tiles_gpu.py).
 //
 // Replaces, for those shapes, the body of the hot loop of QRKit::BlockDiagonalSparseQR::factorize
 // (src/QRKit/BlockDiagonalSparseQR.h:432-526): blockSolver.compute(block) (:437-438, Eigen ColPivHouseholderQR /

@@ -1,4 +1,4 @@
-"""Kernel time (qrk_bd_time_factorize) of uniform batches of small tiles: the four-tiles-per-wave kernel (bdqr_quad.hip, 9..16 rows) against
+"""Kernel time (qrk_bd_time_factorize) of uniform batches of small tiles: the several-tiles-per-wave kernel (bdqr_quad.hip: 9..16 rows four per wave; with the argument `small` 5..8 rows, eight per wave) against
 bdqr_small.hip's 16-lane groups (QRK_QUAD=0).  Usage (GPU box): python tools/quad_probe.py"""
 import os, sys, ctypes as C
 ROOT = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
