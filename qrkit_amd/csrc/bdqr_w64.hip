@@ -20,7 +20,7 @@
 //   phase 2  Q = H_0 ... H_{c-1} I by BACKWARD accumulation (HouseholderSequence::evalTo's order) in the registers phase 1 has
 //            freed: lane j owns column j of Q; step k reads reflector k from LDS the same way.  No search, no square root: a stream
 //            of FMAs that the other wave of the SIMD, which is in another phase of another tile, overlaps with its latency chain.
-// 18.4 KB of LDS per wave: eight tiles in flight per CU.
+// 17.9 KB of LDS per wave at 64 rows: nine tiles in flight per CU (round 5: tau no longer kept in LDS; eight before).
 #include "qrk_device.h"
 
 #include <float.h>
@@ -60,9 +60,10 @@ constexpr int cb(int kp) { int s = 0; for (int k = 0; k < kp; ++k) s += WR - (k 
 constexpr int L_V = 0;
 constexpr int L_S = cb(WR);              // [64] s = x0 - beta of the step at padded row KP
 constexpr int L_NG = L_S + WR;           // [64] -1 / (beta (x0 - beta))
-constexpr int L_TAU = L_NG + WR;         // [64]
-constexpr int L_TOTAL = L_TAU + WR;      // 2304 doubles = 18 432 B
-static_assert(cb(WR) == 2112 && (L_TOTAL * 8) * 8 <= 160 * 1024, "eight waves per CU");
+// (tau is not kept in LDS since round 5: the lane that computes it stores it to hCoeffs at once -- nothing on chip reads it again -- and
+//  the 512 bytes are what a NINTH wave per CU was missing at 64 rows)
+constexpr int L_TOTAL = L_NG + WR;       // 2240 doubles = 17 920 B
+static_assert(cb(WR) == 2112 && (L_TOTAL * 8) * 9 <= 160 * 1024, "nine waves per CU");
 
 #define QRK_W64_0_63(M)                                                                                                              \
     M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9) M(10) M(11) M(12) M(13) M(14) M(15) M(16) M(17) M(18) M(19) M(20) M(21) M(22)  \
@@ -146,6 +147,7 @@ struct Lane {
     double betap;     // (QRK_W64_OWN) beta of the step in which this lane's column was chosen: its R(k, k)
     double n2p;       // (QRK_W64_OWN) |x|^2 of that column
     double ngp;       // the coefficient the running step's pivot column got in the step before, if it was published before that update
+    double* hc_out;   // (wave-uniform) hCoeffs of this tile, or null: tau of step k goes to hc_out[k] from the lane that computes it
 #ifdef QRK_W64_PROF
     unsigned long long pt[16], pt0;
 #endif
@@ -226,7 +228,8 @@ __device__ __forceinline__ void search_publish(const double (&a)[WR], double* ld
             tau = -(s * s) * ng;
         }
         st.betap = beta;
-        lds[L_S + KP] = s; lds[L_NG + KP] = ng; lds[L_TAU + KP] = tau;
+        lds[L_S + KP] = s; lds[L_NG + KP] = ng;
+        if (st.hc_out) st.hc_out[k] = tau;
 #endif
     }
 }
@@ -298,7 +301,7 @@ __device__ __forceinline__ void step(double (&a)[WR], double* lds, Lane& st, dou
         ng = uniform_f64(-recip(nbv * s));
         tau = -(s * s) * ng;
     }
-    if (lane == 0) { lds[L_S + KP] = s; lds[L_NG + KP] = ng; lds[L_TAU + KP] = tau; }
+    if (lane == 0) { lds[L_S + KP] = s; lds[L_NG + KP] = ng; if (st.hc_out) st.hc_out[k] = tau; }
 #endif
     W64_TICK(3);
     // ---- 5. d = x_tail^T a_tail, the coefficient of the column, row k of R
@@ -437,7 +440,7 @@ bdqr_w64_kernel(WaveBatch nb, const double* __restrict__ tiles, double* __restri
         asm volatile("" : "+v"(lane));
 
         Lane st;
-        st.lane = lane; st.unclear = false; st.kstep = 0; st.a2 = 0.0;
+        st.lane = lane; st.unclear = false; st.kstep = 0; st.a2 = 0.0; st.hc_out = hcoeffs ? hcoeffs + cbase : nullptr;
 #ifdef QRK_W64_PROF
         for (int z = 0; z < 16; ++z) st.pt[z] = 0;
         st.pt0 = __builtin_amdgcn_s_memtime();
@@ -496,7 +499,6 @@ bdqr_w64_kernel(WaveBatch nb, const double* __restrict__ tiles, double* __restri
 #pragma unroll
                 for (int i = R0; i < WR; ++i)
                     if (i >= off && i - off <= p) dst[i] = a[i];
-                if (hcoeffs) hcoeffs[cbase + ln] = lds[L_TAU + off + ln];
             }
             // a decision inside its error margin: the tile is redone by the exact path (bdqr_exact.hip)
             if (__builtin_amdgcn_ballot_w64(st.unclear) != 0ull && redo_count && ln == 0) redo_ids[atomicAdd(redo_count, 1)] = gidx;
@@ -541,7 +543,7 @@ bdqr_w64_kernel(WaveBatch nb, const double* __restrict__ tiles, double* __restri
 bool bdqr_w64_supported(int rows, int cols) { return rows >= cols && rows <= w64::WR && rows > 32; }
 
 // Tiles with 32 < rows <= 64, cols <= rows.  queue: one int32 (zeroed here) through which the workgroups take their next tile.
-// max_rows: the tallest tile of the launch (33 .. 64); num_cus: workgroups are 8 or 12 per CU by what the LDS of the launch allows.
+// max_rows: the tallest tile of the launch (33 .. 64); num_cus: the grid is 8, 12 or 16 workgroups per CU by what the LDS of the launch allows (9 .. 11 resident ones run the 12-per-CU grid).
 hipError_t launch_bdqr_w64(const WaveBatch& nb, const double* tiles, double* q_vals, double* r_vals, int32_t* perm, double* hcoeffs,
                            int num_cus, int max_rows, int32_t* redo_count, int32_t* redo_ids, int32_t* queue, hipStream_t stream)
 {
