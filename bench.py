@@ -324,12 +324,19 @@ def main():
     # ---- another BASELINE configuration on this GPU (N = 1; reported next to the headline, never as `value`)
     other = None
     if world == 1 and not args.no_other:
-        other = {"concurrent_streams": concurrent_streams(dev, torch, tiles, qv, rv, pm, S),
-                 "strong_shard_emulation": strong_shard_emulation(ctx, dev, torch, np, make_plan, run),
-                 "small_tiles": small_tiles(ctx, dev, torch, np),
-                 "configs4_share_of_one_gpu": mixed_share(ctx, dev, torch, np),
-                 "configs2_strips": strips_config2(ctx, dev, torch, np),
-                 "configs3_angular": angular_config3(ctx, dev, torch, np)}
+        # (auxiliary legs: a failure in one of them is reported in its place and does not cost the line)
+        def leg(fn, *a):
+            try:
+                return fn(*a)
+            except Exception as e:          # noqa: BLE001
+                torch.cuda.synchronize()
+                return {"error": f"{type(e).__name__}: {e}"}
+        other = {"concurrent_streams": leg(concurrent_streams, dev, torch, tiles, qv, rv, pm, S),
+                 "strong_shard_emulation": leg(strong_shard_emulation, ctx, dev, torch, np, make_plan, run),
+                 "small_tiles": leg(small_tiles, ctx, dev, torch, np),
+                 "configs4_share_of_one_gpu": leg(mixed_share, ctx, dev, torch, np),
+                 "configs2_strips": leg(strips_config2, ctx, dev, torch, np),
+                 "configs3_angular": leg(angular_config3, ctx, dev, torch, np)}
 
     # ---- end to end with host buffers (N = 1): tiles over PCIe in, Q / R / perm back (never the headline value)
     e2e = None
