@@ -5,8 +5,11 @@
 //    pure functions of the tile sizes, so they are generated on the device with coalesced stores
 //    instead of one insertBack() per entry.
 //  * bd_apply_qt / bd_solve: y = Q^T b and x = P R^-1 (Q^T b)_top of _solve_impl (:257-280);
-//    both are block-local, one wavefront per tile and right-hand side.
+//    both are block-local: one wavefront per tile and right-hand side, or (solve, tiles of at most 32 columns, round 5) a group of
+//    2 .. 32 lanes per tile.
 #include "qrk_device.h"
+
+#include <cstdlib>
 
 namespace qrk {
 
@@ -251,6 +254,67 @@ bd_solve_kernel(TileGeom g, const double* __restrict__ q_vals, const double* __r
     }
 }
 
+// The same with G lanes per tile (G = 2 .. 32, a power of two >= the widest tile of the launch), 64 / G tiles per wavefront (round 5):
+// one wavefront per tile left 62 of 64 lanes idle on the reference's 7 x 2 blocks (0.11 of the HBM roofline at 10^6 tiles; 32 x 32: 0.27)
+// and read Q one row per trip -- a chain of memory latencies.  Here lane k of a group owns entry k of y: eight rows of Q in flight per
+// lane (clamped addresses, not predicated loads), the lane's row of R (entries (k, kk), kk >= k) prefetched into registers before the
+// substitution, whose steps are unrolled (static register indices) and broadcast the solved entry by ds_bpermute.  The sums run in the
+// same order as in bd_solve_kernel: the results are bitwise the same.
+template <int G>
+__global__ void __launch_bounds__(64)
+bd_solve_group_kernel(TileGeom g, const double* __restrict__ q_vals, const double* __restrict__ r_vals,
+                      const int32_t* __restrict__ perm, const double* __restrict__ b, int64_t nrhs,
+                      double* __restrict__ x)
+{
+    constexpr int TPW = 64 / G;
+    const int lane = threadIdx.x, grp = lane / G, k = lane % G;
+    const int64_t ntg = (g.num_tiles + TPW - 1) / TPW;
+    const int64_t total = ntg * nrhs;
+    for (int64_t w = blockIdx.x; w < total; w += gridDim.x) {
+        const int64_t t = (w % ntg) * TPW + grp, rhs = w / ntg;
+        const bool valid = t < g.num_tiles;
+        int r, c, base_row, base_col;
+        int64_t qoff, roff;
+        tile_geom(g, valid ? t : 0, r, c, qoff, roff, base_row, base_col);
+        if (!valid) { r = 0; c = 0; }
+        const bool act = k < c;
+        // the lane's row of R: entry (k, kk) of the packed upper triangle is at kk (kk + 1) / 2 + k
+        double rrow[G];
+#pragma unroll
+        for (int kk = 0; kk < G; ++kk) {
+            const double v = r_vals[roff + ((act && kk >= k && kk < c) ? (int64_t)kk * (kk + 1) / 2 + k : 0)];
+            rrow[kk] = (act && kk >= k && kk < c) ? v : 1.0;
+        }
+        // y_k = sum_j Q(j, k) b_j, j ascending (one accumulator: the order of bd_solve_kernel)
+        const double* bb = b + rhs * (int64_t)g.mat_rows + base_row;
+        const double* qk = q_vals + qoff + (act ? k : 0);
+        int rmax = r;                                          // (ragged batches: the tallest tile of the wave bounds the loop)
+        if (g.t_rows) {
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) { const int other = __shfl_xor(rmax, o, 64); rmax = other > rmax ? other : rmax; }
+        }
+        double yk = 0.0;
+        for (int j0 = 0; j0 < rmax; j0 += 8) {
+            double qv[8], bv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int j = (j0 + u < r) ? j0 + u : 0; qv[u] = qk[(int64_t)j * r]; bv[u] = bb[j]; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) if (act && j0 + u < r) yk = fma(qv[u], bv[u], yk);
+        }
+        // column-oriented back substitution (the triangularView<Upper>().solve of _solve_impl, :271)
+#pragma unroll
+        for (int kk = G - 1; kk >= 0; --kk) {
+            const double pv = yk / rrow[kk];                   // (meaningful in lane kk of the group)
+            const double piv = __shfl(pv, grp * G + kk, 64);
+            if (kk < c) {
+                if (k == kk) yk = piv;
+                else if (k < kk) yk = fma(-rrow[kk], piv, yk);
+            }
+        }
+        if (act) x[rhs * (int64_t)g.mat_cols + perm[base_col + k]] = yk;
+    }
+}
+
 // Block upper-triangular solve only: z = R(0:cols,0:cols)^-1 y with y, z: mat_cols x nrhs (the
 // triangularView<Upper>().solve step of _solve_impl, BlockDiagonalSparseQR.h:271, on its own; the
 // angular composition needs it with a modified right-hand side).  One workgroup per tile and RHS.
@@ -468,7 +532,18 @@ void launch_bd_solve(const TileGeom& g, int max_cols, const double* q_vals, cons
     const int64_t total = g.num_tiles * nrhs;
     if (total <= 0) return;
     const unsigned grid = (unsigned)(total < 262144 ? total : 262144);
-    if (max_cols <= 64)
+    static const bool grouped = !(std::getenv("QRK_SOLVE_GROUPED") && std::getenv("QRK_SOLVE_GROUPED")[0] == '0');   // (0: one wavefront per tile, rounds 1-4)
+    // (up to 32 columns; at 33 .. 64 a group is the whole wavefront and the 64 row registers + 64 unrolled steps were slower than the
+    //  loop of bd_solve_kernel: 64 x 64, 20 000 tiles: 393 against 286 us)
+    if (max_cols <= 32 && grouped) {
+        int G = 2;
+        while (G < max_cols) G *= 2;
+        const int64_t waves = ((g.num_tiles + 64 / G - 1) / (64 / G)) * nrhs;
+        const unsigned gg = (unsigned)(waves < 262144 ? waves : 262144);
+#define QRK_SOLVE_G(GG) case GG: hipLaunchKernelGGL((bd_solve_group_kernel<GG>), dim3(gg), dim3(64), 0, stream, g, q_vals, r_vals, perm, b, nrhs, x); break;
+        switch (G) { QRK_SOLVE_G(2) QRK_SOLVE_G(4) QRK_SOLVE_G(8) QRK_SOLVE_G(16) QRK_SOLVE_G(32) default: break; }
+#undef QRK_SOLVE_G
+    } else if (max_cols <= 64)
         hipLaunchKernelGGL(bd_solve_kernel, dim3(grid), dim3(64), 0, stream, g, q_vals, r_vals, perm, b, nrhs, x);
     else
         hipLaunchKernelGGL(bd_solve_wg_kernel, dim3(grid), dim3(256), (size_t)max_cols * sizeof(double), stream, g, q_vals,

@@ -62,6 +62,7 @@ struct qrk_bd_plan_s {
     int64_t tiles_len = 0, nnz_q_tiles = 0, nnz_q = 0, nnz_r = 0;
     bool landscape = false;       // some tile has rows < cols -> InvalidInput
     int32_t max_dim = 0;          // largest tile dimension
+    int32_t max_cols = 0;         // widest tile (the lanes per tile of the grouped solve kernel)
     bool factorized = false;
     // device-resident per-tile descriptors (mixed batches only)
     int32_t *d_rows = nullptr, *d_cols = nullptr, *d_coff = nullptr, *d_rowoff = nullptr;
@@ -650,6 +651,7 @@ qrk_status qrk_bd_plan_create(qrk_handle h, const qrk_bd_layout* L, qrk_q_format
         p->nnz_r = B * (int64_t)(p->c * (p->c + 1) / 2);
         p->landscape = p->r < p->c;
         p->max_dim = p->r > p->c ? p->r : p->c;
+        p->max_cols = p->c;
         if (p->max_dim > QRK_COL_MAX_DIM) ws_stride = (int64_t)p->r * p->c;
         else if (use_w64 && !p->landscape && p->max_dim > 32 && qrk::bdqr_w64_supported(p->r, p->c)) p->w64_uniform = true;
         else if (p->max_dim > 32 && !p->landscape) {
@@ -671,6 +673,7 @@ qrk_status qrk_bd_plan_create(qrk_handle h, const qrk_bd_layout* L, qrk_q_format
             if (r < c) p->landscape = true;
             const int32_t md = r > c ? r : c;
             if (md > p->max_dim) p->max_dim = md;
+            if (c > p->max_cols) p->max_cols = c;
             if (md <= 32) wave_ids.push_back((int32_t)i);
             else if (use_w64 && qrk::bdqr_w64_supported(r, c)) { w64_ids.push_back((int32_t)i); p->w64_maxr = std::max(p->w64_maxr, r); }
             else if (md <= QRK_COL_MAX_DIM && r >= c) {
@@ -998,7 +1001,7 @@ qrk_status qrk_bd_solve(qrk_bd_plan p, const double* q_vals, const double* r_val
     QRK_HIP(h, hipSetDevice(h->device));
     const qrk::TileGeom g = make_geom(p);
     if (space == QRK_MEM_DEVICE) {
-        qrk::launch_bd_solve(g, p->max_dim, q_vals, r_vals, perm, b, nrhs, x, h->stream);
+        qrk::launch_bd_solve(g, p->max_cols, q_vals, r_vals, perm, b, nrhs, x, h->stream);
         QRK_HIP(h, hipGetLastError());
         return QRK_STATUS_OK;
     }
@@ -1010,7 +1013,7 @@ qrk_status qrk_bd_solve(qrk_bd_plan p, const double* q_vals, const double* r_val
         (st = s.in(perm, (int64_t)p->mat_cols, &d_p)) || (st = s.in(b, nrhs * p->mat_rows, &d_b)) ||
         (st = s.out(nrhs * p->mat_cols, &d_x)))
         return st;
-    qrk::launch_bd_solve(g, p->max_dim, d_q, d_r, d_p, d_b, nrhs, d_x, h->stream);
+    qrk::launch_bd_solve(g, p->max_cols, d_q, d_r, d_p, d_b, nrhs, d_x, h->stream);
     QRK_HIP(h, hipGetLastError());
     if ((st = s.back(x, d_x, nrhs * p->mat_cols))) return st;
     QRK_HIP(h, hipStreamSynchronize(h->stream));

@@ -233,6 +233,37 @@ def test_mixed_sizes_8_to_256_match_oracle(qa, ctx):
         np.testing.assert_array_equal(got, want)
 
 
+@pytest.mark.parametrize("B,r,c,nrhs", [(1, 7, 2, 1), (33, 7, 2, 2), (1000, 7, 2, 1), (257, 9, 2, 3), (65, 8, 6, 1), (400, 8, 6, 2), (31, 6, 6, 1),
+                                        (70, 16, 16, 2), (19, 16, 9, 1), (5, 32, 32, 1), (101, 32, 20, 2), (40, 5, 1, 1), (12, 40, 24, 1)])
+def test_solve_grouped_kernel_matches_oracle(qa, ctx, B, r, c, nrhs):
+    """solve() of uniform batches of at most 32 columns (2 .. 32 lanes per tile, 64 / G tiles per wavefront, bd_aux.hip): every filling
+    of the last wavefront, several right-hand sides, tall tiles; against the oracle's solve and per tile against numpy's least squares."""
+    tiles = seeded_tiles(40 + B + r, 0.5, 5.0, B * r * c)
+    rows, cols = np.full(B, r, np.int32), np.full(B, c, np.int32)
+    _, qr = run_gpu(qa, ctx, rows, cols, tiles)
+    prob, ref = oracle_factorize(rows, cols, tiles)
+    b = np.random.default_rng(B).uniform(-1, 1, (B * r, nrhs))
+    x = qr.solve(b if nrhs > 1 else b[:, 0])
+    xr = prob.solve(ref, b if nrhs > 1 else b[:, 0])
+    assert rel_fro(x, xr) <= 1e-9
+    A = tiles.reshape(B, c, r).transpose(0, 2, 1)
+    for i in (0, B // 2, B - 1):
+        xi = np.linalg.lstsq(A[i], b[i * r:(i + 1) * r], rcond=None)[0]
+        got = np.asarray(x).reshape(B * c, -1)[i * c:(i + 1) * c]
+        assert np.linalg.norm(got - xi) <= 1e-9 * max(1.0, np.linalg.norm(xi))
+
+
+def test_solve_ragged_small_tiles_matches_oracle(qa, ctx):
+    rng = np.random.default_rng(77)
+    rows = rng.integers(2, 33, 300).astype(np.int32)
+    cols = np.minimum(rows, rng.integers(1, 33, 300)).astype(np.int32)
+    tiles = seeded_tiles(78, -1.0, 1.0, int((rows.astype(np.int64) * cols).sum()))
+    _, qr = run_gpu(qa, ctx, rows, cols, tiles)
+    prob, ref = oracle_factorize(rows, cols, tiles)
+    b = rng.uniform(-1, 1, (int(rows.sum()), 2))
+    assert rel_fro(qr.solve(b), prob.solve(ref, b)) <= 1e-8
+
+
 def test_solve_large_tiles(qa, ctx):
     B, r, c = 6, 150, 90
     tiles = seeded_tiles(8, -1.0, 1.0, B * r * c)
