@@ -260,7 +260,8 @@ bd_solve_kernel(TileGeom g, const double* __restrict__ q_vals, const double* __r
 // lane (clamped addresses, not predicated loads), the lane's row of R (entries (k, kk), kk >= k) prefetched into registers before the
 // substitution, whose steps are unrolled (static register indices) and broadcast the solved entry by ds_bpermute.  The sums run in the
 // same order as in bd_solve_kernel: the results are bitwise the same.
-template <int G>
+// WITH_Q = false: the back substitution alone (bd_solve_r_kernel's job: z = R^-1 y, both indexed by column, no permutation).
+template <int G, bool WITH_Q>
 __global__ void __launch_bounds__(64)
 bd_solve_group_kernel(TileGeom g, const double* __restrict__ q_vals, const double* __restrict__ r_vals,
                       const int32_t* __restrict__ perm, const double* __restrict__ b, int64_t nrhs,
@@ -285,21 +286,25 @@ bd_solve_group_kernel(TileGeom g, const double* __restrict__ q_vals, const doubl
             const double v = r_vals[roff + ((act && kk >= k && kk < c) ? (int64_t)kk * (kk + 1) / 2 + k : 0)];
             rrow[kk] = (act && kk >= k && kk < c) ? v : 1.0;
         }
-        // y_k = sum_j Q(j, k) b_j, j ascending (one accumulator: the order of bd_solve_kernel)
-        const double* bb = b + rhs * (int64_t)g.mat_rows + base_row;
-        const double* qk = q_vals + qoff + (act ? k : 0);
-        int rmax = r;                                          // (ragged batches: the tallest tile of the wave bounds the loop)
-        if (g.t_rows) {
-#pragma unroll
-            for (int o = 32; o >= 1; o >>= 1) { const int other = __shfl_xor(rmax, o, 64); rmax = other > rmax ? other : rmax; }
-        }
         double yk = 0.0;
-        for (int j0 = 0; j0 < rmax; j0 += 8) {
-            double qv[8], bv[8];
+        if (WITH_Q) {
+            // y_k = sum_j Q(j, k) b_j, j ascending (one accumulator: the order of bd_solve_kernel)
+            const double* bb = b + rhs * (int64_t)g.mat_rows + base_row;
+            const double* qk = q_vals + qoff + (act ? k : 0);
+            int rmax = r;                                      // (ragged batches: the tallest tile of the wave bounds the loop)
+            if (g.t_rows) {
 #pragma unroll
-            for (int u = 0; u < 8; ++u) { const int j = (j0 + u < r) ? j0 + u : 0; qv[u] = qk[(int64_t)j * r]; bv[u] = bb[j]; }
+                for (int o = 32; o >= 1; o >>= 1) { const int other = __shfl_xor(rmax, o, 64); rmax = other > rmax ? other : rmax; }
+            }
+            for (int j0 = 0; j0 < rmax; j0 += 8) {
+                double qv[8], bv[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) if (act && j0 + u < r) yk = fma(qv[u], bv[u], yk);
+                for (int u = 0; u < 8; ++u) { const int j = (j0 + u < r) ? j0 + u : 0; qv[u] = qk[(int64_t)j * r]; bv[u] = bb[j]; }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) if (act && j0 + u < r) yk = fma(qv[u], bv[u], yk);
+            }
+        } else if (act) {
+            yk = b[rhs * (int64_t)g.mat_cols + base_col + k];
         }
         // column-oriented back substitution (the triangularView<Upper>().solve of _solve_impl, :271)
 #pragma unroll
@@ -311,7 +316,79 @@ bd_solve_group_kernel(TileGeom g, const double* __restrict__ q_vals, const doubl
                 else if (k < kk) yk = fma(-rrow[kk], piv, yk);
             }
         }
-        if (act) x[rhs * (int64_t)g.mat_cols + perm[base_col + k]] = yk;
+        if (act) x[rhs * (int64_t)g.mat_cols + (WITH_Q ? perm[base_col + k] : base_col + k)] = yk;
+    }
+}
+
+// y = Q b with RP lanes per tile (RP = 2 .. 64 >= the tallest tile), 64 / RP tiles per wavefront (round 5; bd_apply_q_kernel: one
+// wavefront per tile and one entry of Q per loop trip): lane j of a group owns row j of Q_i, all of it in flight before the first use
+// (clamped addresses); lane k also fetches the k-th entry of the tile's part of b, which reaches the others by ds_bpermute.  Same
+// products in the same order.
+template <int RP>
+__global__ void __launch_bounds__(64)
+bd_apply_q_group_kernel(TileGeom g, const double* __restrict__ q_vals, const double* __restrict__ b, int64_t nrhs,
+                        double* __restrict__ y)
+{
+    constexpr int TPW = 64 / RP;
+    const int lane = threadIdx.x, grp = lane / RP, j = lane % RP;
+    const int64_t ntg = (g.num_tiles + TPW - 1) / TPW;
+    const int64_t total = ntg * nrhs;
+    for (int64_t w = blockIdx.x; w < total; w += gridDim.x) {
+        const int64_t t = (w % ntg) * TPW + grp, rhs = w / ntg;
+        const bool valid = t < g.num_tiles;
+        int r, c, base_row, base_col;
+        int64_t qoff, roff;
+        tile_geom(g, valid ? t : 0, r, c, qoff, roff, base_row, base_col);
+        if (!valid) r = 0;
+        const bool act = j < r;
+        double qv[RP];
+        if (!g.t_rows) {
+            // uniform tiles: the wave's 64 / RP tiles are one contiguous run of q_vals -- coalesced loads (eight per lane in flight) into
+            // LDS, row stride RP + 1, then every lane its row (a lane reading its row straight from memory touches 64 lines per
+            // instruction: 16 x 16 ran at 0.25 of the roofline that way)
+            __shared__ double lq[64 * (RP + 1)];
+            const int ru = g.rows, rr = ru * ru;               // (r is 0 in the lanes of a group beyond the batch: they still help to load)
+            const int64_t first = (w % ntg) * TPW;
+            const int ntw = (int)(g.num_tiles - first < TPW ? g.num_tiles - first : TPW);
+            const int n = ntw * rr;
+            const double* src = q_vals + first * (int64_t)rr;
+            const float inv_rr = 1.0f / (float)rr, inv_r = 1.0f / (float)ru;
+            __builtin_amdgcn_wave_barrier();                   // (the rows of the round before have been read)
+            for (int e0 = lane; e0 < n; e0 += 64 * 8) {
+                double ld[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { const int e = e0 + 64 * u; ld[u] = src[e < n ? e : n - 1]; }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int e = e0 + 64 * u;
+                    if (e < n) {
+                        const int tl = (int)(((float)e + 0.5f) * inv_rr), rem = e - tl * rr;
+                        const int row = (int)(((float)rem + 0.5f) * inv_r), col = rem - row * ru;
+                        lq[(tl * RP + row) * (RP + 1) + col] = ld[u];
+                    }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            const double* lrow = lq + (grp * RP + (act ? j : 0)) * (RP + 1);
+#pragma unroll
+            for (int k = 0; k < RP; ++k) { const double v = lrow[k]; qv[k] = (act && k < r) ? v : 0.0; }
+        } else {
+            const double* qrow = q_vals + qoff + (int64_t)(act ? j : 0) * r;
+#pragma unroll
+            for (int k = 0; k < RP; ++k) { const double v = qrow[k < r ? k : 0]; qv[k] = (act && k < r) ? v : 0.0; }
+        }
+        // entry j of the tile's part of b: FullQ reads b at base_col + k (k < c) and at N + m1 + (k - c); BlockDiagonalQ at base_row + k
+        int idx;
+        if (g.q_format == 0) idx = j < c ? base_col + j : g.mat_cols + (base_row - base_col) + (j - c);
+        else idx = base_row + j;
+        const double bj = act ? b[rhs * (int64_t)g.mat_rows + idx] : 0.0;
+        double s = 0.0;
+#pragma unroll
+        for (int k = 0; k < RP; ++k) {
+            const double bk = __shfl(bj, grp * RP + k, 64);
+            if (k < r) s = fma(qv[k], bk, s);
+        }
+        if (act) y[rhs * (int64_t)g.mat_rows + base_row + j] = s;
     }
 }
 
@@ -503,10 +580,19 @@ tail:
                            b, nrhs, y);
 }
 
-void launch_bd_apply_q(const TileGeom& g, const double* q_vals, const double* b, int64_t nrhs, double* y, hipStream_t stream)
+void launch_bd_apply_q(const TileGeom& g, int max_rows, const double* q_vals, const double* b, int64_t nrhs, double* y, hipStream_t stream)
 {
     const int64_t total = g.num_tiles * nrhs;
-    if (total > 0) {
+    static const bool grouped = !(std::getenv("QRK_SOLVE_GROUPED") && std::getenv("QRK_SOLVE_GROUPED")[0] == '0');
+    if (total > 0 && grouped && max_rows <= 64) {
+        int RP = 2;
+        while (RP < max_rows) RP *= 2;
+        const int64_t waves = ((g.num_tiles + 64 / RP - 1) / (64 / RP)) * nrhs;
+        const unsigned gg = (unsigned)(waves < 262144 ? waves : 262144);
+#define QRK_APQ_G(GG) case GG: hipLaunchKernelGGL((bd_apply_q_group_kernel<GG>), dim3(gg), dim3(64), 0, stream, g, q_vals, b, nrhs, y); break;
+        switch (RP) { QRK_APQ_G(2) QRK_APQ_G(4) QRK_APQ_G(8) QRK_APQ_G(16) QRK_APQ_G(32) QRK_APQ_G(64) default: break; }
+#undef QRK_APQ_G
+    } else if (total > 0) {
         const unsigned grid = (unsigned)(total < 262144 ? total : 262144);
         hipLaunchKernelGGL(bd_apply_q_kernel, dim3(grid), dim3(64), 0, stream, g, q_vals, b, nrhs, y);
     }
@@ -520,6 +606,17 @@ void launch_bd_solve_r(const TileGeom& g, int max_cols, const double* r_vals, co
 {
     const int64_t total = g.num_tiles * nrhs;
     if (total <= 0) return;
+    static const bool grouped = !(std::getenv("QRK_SOLVE_GROUPED") && std::getenv("QRK_SOLVE_GROUPED")[0] == '0');
+    if (grouped && max_cols <= 32) {
+        int G = 2;
+        while (G < max_cols) G *= 2;
+        const int64_t waves = ((g.num_tiles + 64 / G - 1) / (64 / G)) * nrhs;
+        const unsigned gg = (unsigned)(waves < 262144 ? waves : 262144);
+#define QRK_SOLVER_G(GG) case GG: hipLaunchKernelGGL((bd_solve_group_kernel<GG, false>), dim3(gg), dim3(64), 0, stream, g, nullptr, r_vals, nullptr, y, nrhs, z); break;
+        switch (G) { QRK_SOLVER_G(2) QRK_SOLVER_G(4) QRK_SOLVER_G(8) QRK_SOLVER_G(16) QRK_SOLVER_G(32) default: break; }
+#undef QRK_SOLVER_G
+        return;
+    }
     const unsigned grid = (unsigned)(total < 262144 ? total : 262144);
     const unsigned threads = max_cols <= 64 ? 64 : 256;
     hipLaunchKernelGGL(bd_solve_r_kernel, dim3(grid), dim3(threads), (size_t)max_cols * sizeof(double), stream, g, r_vals, y,
@@ -540,7 +637,7 @@ void launch_bd_solve(const TileGeom& g, int max_cols, const double* q_vals, cons
         while (G < max_cols) G *= 2;
         const int64_t waves = ((g.num_tiles + 64 / G - 1) / (64 / G)) * nrhs;
         const unsigned gg = (unsigned)(waves < 262144 ? waves : 262144);
-#define QRK_SOLVE_G(GG) case GG: hipLaunchKernelGGL((bd_solve_group_kernel<GG>), dim3(gg), dim3(64), 0, stream, g, q_vals, r_vals, perm, b, nrhs, x); break;
+#define QRK_SOLVE_G(GG) case GG: hipLaunchKernelGGL((bd_solve_group_kernel<GG, true>), dim3(gg), dim3(64), 0, stream, g, q_vals, r_vals, perm, b, nrhs, x); break;
         switch (G) { QRK_SOLVE_G(2) QRK_SOLVE_G(4) QRK_SOLVE_G(8) QRK_SOLVE_G(16) QRK_SOLVE_G(32) default: break; }
 #undef QRK_SOLVE_G
     } else if (max_cols <= 64)

@@ -972,7 +972,7 @@ qrk_status qrk_bd_apply_q(qrk_bd_plan p, const double* q_vals, const double* b, 
     QRK_HIP(h, hipSetDevice(h->device));
     const qrk::TileGeom g = make_geom(p);
     if (space == QRK_MEM_DEVICE) {
-        qrk::launch_bd_apply_q(g, q_vals, b, nrhs, y, h->stream);
+        qrk::launch_bd_apply_q(g, p->max_dim, q_vals, b, nrhs, y, h->stream);
         QRK_HIP(h, hipGetLastError());
         return QRK_STATUS_OK;
     }
@@ -982,7 +982,7 @@ qrk_status qrk_bd_apply_q(qrk_bd_plan p, const double* q_vals, const double* b, 
     if ((st = s.in(q_vals, p->nnz_q, &d_q)) || (st = s.in(b, nrhs * p->mat_rows, &d_b)) ||
         (st = s.out(nrhs * p->mat_rows, &d_y)))
         return st;
-    qrk::launch_bd_apply_q(g, d_q, d_b, nrhs, d_y, h->stream);
+    qrk::launch_bd_apply_q(g, p->max_dim, d_q, d_b, nrhs, d_y, h->stream);
     QRK_HIP(h, hipGetLastError());
     if ((st = s.back(y, d_y, nrhs * p->mat_rows))) return st;
     QRK_HIP(h, hipStreamSynchronize(h->stream));
@@ -1031,7 +1031,7 @@ qrk_status qrk_bd_solve_r(qrk_bd_plan p, const double* r_vals, const double* y, 
     QRK_HIP(h, hipSetDevice(h->device));
     const qrk::TileGeom g = make_geom(p);
     if (space == QRK_MEM_DEVICE) {
-        qrk::launch_bd_solve_r(g, p->max_dim, r_vals, y, nrhs, z, h->stream);
+        qrk::launch_bd_solve_r(g, p->max_cols, r_vals, y, nrhs, z, h->stream);
         QRK_HIP(h, hipGetLastError());
         return QRK_STATUS_OK;
     }
@@ -1041,7 +1041,7 @@ qrk_status qrk_bd_solve_r(qrk_bd_plan p, const double* r_vals, const double* y, 
     if ((st = s.in(r_vals, p->nnz_r, &d_r)) || (st = s.in(y, nrhs * p->mat_cols, &d_y)) ||
         (st = s.out(nrhs * p->mat_cols, &d_z)))
         return st;
-    qrk::launch_bd_solve_r(g, p->max_dim, d_r, d_y, nrhs, d_z, h->stream);
+    qrk::launch_bd_solve_r(g, p->max_cols, d_r, d_y, nrhs, d_z, h->stream);
     QRK_HIP(h, hipGetLastError());
     if ((st = s.back(z, d_z, nrhs * p->mat_cols))) return st;
     QRK_HIP(h, hipStreamSynchronize(h->stream));

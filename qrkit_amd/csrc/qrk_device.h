@@ -176,7 +176,7 @@ void launch_bd_cut_tiles(const TileGeom& g, const int64_t* t_off, int row_major,
 void launch_bd_q_tail_ones(double* q_vals, int64_t start, int64_t count, hipStream_t stream);
 void launch_bd_apply_qt(const TileGeom& g, const double* q_vals, const double* b, int64_t nrhs,
                         double* y, hipStream_t stream);
-void launch_bd_apply_q(const TileGeom& g, const double* q_vals, const double* b, int64_t nrhs, double* y, hipStream_t stream);
+void launch_bd_apply_q(const TileGeom& g, int max_rows, const double* q_vals, const double* b, int64_t nrhs, double* y, hipStream_t stream);
 void launch_bd_solve_r(const TileGeom& g, int max_cols, const double* r_vals, const double* y, int64_t nrhs, double* z,
                        hipStream_t stream);
 void launch_bd_solve(const TileGeom& g, int max_cols, const double* q_vals, const double* r_vals,

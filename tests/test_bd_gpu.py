@@ -468,3 +468,20 @@ def test_two_handles_on_two_streams_side_by_side(qa, n, B):
         assert per_tile_rel(q[:200 * n * n].cpu().numpy(), ref.Q_vals, sq) <= RTOL
         assert per_tile_rel(r[:200 * (n * (n + 1) // 2)].cpu().numpy(), ref.R_vals, sr) <= RTOL
         lib.qrk_bd_plan_destroy(plan)
+
+
+@pytest.mark.parametrize("B,r,c", [(1, 7, 2), (65, 8, 6), (300, 9, 2), (33, 16, 16), (7, 32, 32), (40, 20, 11), (5, 64, 40)])
+def test_solve_r_alone_matches_per_tile_triangular_solves(qa, ctx, B, r, c):
+    """qrk_bd_solve_r (the per-block back substitutions of BlockAngularSparseQR::makeR, BlockAngularSparseQR.h:285-335): z = R^-1 y per
+    tile; the grouped kernel for tiles of at most 32 columns, the workgroup kernel above."""
+    tiles = seeded_tiles(90 + B, 0.5, 5.0, B * r * c)
+    rows, cols = np.full(B, r, np.int32), np.full(B, c, np.int32)
+    _, qr = run_gpu(qa, ctx, rows, cols, tiles)
+    Rv = qr.rValues().cpu().numpy().reshape(B, -1)
+    y = np.random.default_rng(B).uniform(-1, 1, (B * c, 2))
+    z = np.asarray(qr.solveR(y))
+    iu = np.tril_indices(c)
+    for i in (0, B // 2, B - 1):
+        R = np.zeros((c, c)); R[iu[1], iu[0]] = Rv[i]
+        want = np.linalg.solve(R, y[i * c:(i + 1) * c])
+        assert np.linalg.norm(z[i * c:(i + 1) * c] - want) <= 1e-10 * max(1.0, np.linalg.norm(want))

@@ -23,7 +23,11 @@ def ctx(qa):
 
 
 @pytest.mark.parametrize("B,r,c,extra,qf", [(300, 7, 2, 0, 0), (300, 7, 2, 3, 0), (50, 32, 32, 0, 0), (40, 20, 9, 5, 1),
-                                            (7, 100, 37, 0, 0)])
+                                            (7, 100, 37, 0, 0),
+                                            # the grouped kernels of round 5 (2 .. 64 lanes per tile): every filling of the last wavefront,
+                                            # both Q formats, tiles of 33 .. 64 rows (one tile per wavefront, staged through LDS)
+                                            (1, 7, 2, 0, 0), (33, 8, 6, 0, 0), (129, 8, 6, 2, 1), (17, 16, 16, 0, 0), (9, 13, 5, 0, 1),
+                                            (3, 32, 32, 1, 0), (21, 40, 40, 0, 0), (10, 64, 48, 0, 0), (6, 64, 64, 4, 1), (130, 5, 1, 0, 0)])
 def test_block_diagonal_q_times_b_on_device(qa, ctx, B, r, c, extra, qf):
     """qrk_bd_apply_q: matrixQ() * b with the explicit Q (FullQ [U|N] split and BlockDiagonalQ), trailing identity rows."""
     tiles = seeded_tiles(B + r, -1.0, 1.0, B * r * c)
