@@ -56,6 +56,8 @@ def expected_tiles(mat, r, c):
     (1000, 32, 32, 0, 0, 1.0),      # BASELINE configs[0] shape
     (256, 7, 2, 0, 0, 1.0),         # the reference's test shape (test-qrkit.cpp:369-377)
     (300, 8, 6, 5, 200, 0.7),       # zeros inside the blocks, entries outside them, trailing rows
+    (3000, 7, 2, 3, 500, 0.8),      # many small blocks: the thread-per-outer-index kernel (round 5), with zeros, strays, trailing rows
+    (1500, 8, 6, 0, 0, 1.0), (1100, 16, 16, 2, 300, 0.6), (2000, 5, 1, 0, 100, 1.0),
     (40, 100, 37, 0, 50, 0.9),
     (6, 200, 150, 3, 0, 0.5),       # pieces: 200 x 20 columns at a time
     (2, 2000, 3, 0, 10, 0.8),       # the tallest tiles a plan takes: two columns per piece
