@@ -334,6 +334,7 @@ def main():
         other = {"concurrent_streams": leg(concurrent_streams, dev, torch, tiles, qv, rv, pm, S),
                  "strong_shard_emulation": leg(strong_shard_emulation, ctx, dev, torch, np, make_plan, run),
                  "small_tiles": leg(small_tiles, ctx, dev, torch, np),
+                 "solve": leg(solve_leg, ctx, dev, torch, np),
                  "configs4_share_of_one_gpu": leg(mixed_share, ctx, dev, torch, np),
                  "configs2_strips": leg(strips_config2, ctx, dev, torch, np),
                  "configs3_angular": leg(angular_config3, ctx, dev, torch, np)}
@@ -567,6 +568,35 @@ def concurrent_streams(dev, torch, tiles, qv, rv, pm, S, steps=300):
             lib.qrk_bd_plan_destroy(plan)
     return {"what": "configs[1] as a stream of independent matrices through 1 / 2 / 3 handles on their own HIP streams (wall clock, "
                     "qrk_bd_factorize called from Python per step; 1 = the headline's schedule); not `value`", "handles": res}
+
+
+def solve_leg(ctx, dev, torch, np):
+    """solve() of the block-diagonal solver (_solve_impl, BlockDiagonalSparseQR.h:257-280 -- Q^T b, per-tile back
+    substitution with the packed R, the column permutation) for one right-hand side resident in HBM: configs[1]'s matrix, the reference's
+    own 7 x 2 blocks and configs[3]'s 8 x 6 left stage; us per solve and the fraction of the HBM roofline at Q, R, b read once, x written."""
+    import qrkit_amd
+    out = []
+    for r, c, B in ((32, 32, BLOCKS), (7, 2, 1000000), (8, 6, 20000), (8, 6, 1000000)):
+        g = torch.Generator(device=dev); g.manual_seed(11 * r + c)
+        tiles = torch.rand(B * r * c, generator=g, device=dev, dtype=torch.float64) * 4.5 + 0.5
+        rows, cols = np.full(B, r, np.int32), np.full(B, c, np.int32)
+        qr = qrkit_amd.BlockDiagonalSparseQR(context=ctx)
+        qr.compute(qrkit_amd.SparseBlockDiagonal.fromTiles(rows, cols, tiles))
+        b = torch.rand(B * r, generator=g, device=dev, dtype=torch.float64)
+        for _ in range(3):
+            qr.solve(b)
+        torch.cuda.synchronize()
+        best = 1e30
+        for _ in range(3):
+            t0 = time.perf_counter()
+            for _ in range(10):
+                qr.solve(b)
+            torch.cuda.synchronize()
+            best = min(best, (time.perf_counter() - t0) / 10)
+        by = B * (8 * r * r + 4 * c * (c + 1) + 8 * r + 8 * c + 4 * c)
+        out.append({"tile": f"{r}x{c}", "tiles": B, "us": best * 1e6, "algorithmic_GBs": by / best / 1e9, "frac_of_hbm": by / best / 1e9 / HBM_PEAK_GBS})
+        del qr, tiles, b
+    return out
 
 
 def small_tiles(ctx, dev, torch, np):
