@@ -242,8 +242,17 @@ bd_solve_kernel(TileGeom g, const double* __restrict__ q_vals, const double* __r
         tile_geom(g, t, r, c, qoff, roff, base_row, base_col);
         const double* bb = b + rhs * (int64_t)g.mat_rows + base_row;
         double yk = 0.0;
-        if (lane < c)
-            for (int j = 0; j < r; ++j) yk = fma(q_vals[qoff + (int64_t)j * r + lane], bb[j], yk);
+        {
+            // (eight rows of Q in flight per lane, clamped addresses: one load per trip was a chain of memory latencies; round 5)
+            const double* qk = q_vals + qoff + (lane < c ? lane : 0);
+            for (int j0 = 0; j0 < r; j0 += 8) {
+                double qv[8], bv[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { const int j = (j0 + u < r) ? j0 + u : 0; qv[u] = qk[(int64_t)j * r]; bv[u] = bb[j]; }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) if (lane < c && j0 + u < r) yk = fma(qv[u], bv[u], yk);
+            }
+        }
         for (int kk = c - 1; kk >= 0; --kk) {
             const double* colk = r_vals + roff + (int64_t)kk * (kk + 1) / 2;
             const double piv = readlane_f64(yk, kk) / colk[kk];
@@ -439,7 +448,14 @@ bd_solve_wg_kernel(TileGeom g, const double* __restrict__ q_vals, const double* 
         const double* bb = b + rhs * (int64_t)g.mat_rows + base_row;
         for (int k = tid; k < c; k += blockDim.x) {
             double s = 0.0;
-            for (int j = 0; j < r; ++j) s = fma(q_vals[qoff + (int64_t)j * r + k], bb[j], s);
+            const double* qk = q_vals + qoff + k;
+            for (int j0 = 0; j0 < r; j0 += 8) {
+                double qv[8], bv[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { const int j = (j0 + u < r) ? j0 + u : 0; qv[u] = qk[(int64_t)j * r]; bv[u] = bb[j]; }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) if (j0 + u < r) s = fma(qv[u], bv[u], s);
+            }
             ysm[k] = s;
         }
         __syncthreads();
