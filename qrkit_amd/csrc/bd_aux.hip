@@ -129,7 +129,13 @@ bd_apply_qt_small_kernel(TileGeom g, const double* __restrict__ q_vals, const do
         const double* bb = b + rhs * (int64_t)g.mat_rows + base_row;
         double* yy = y + rhs * (int64_t)g.mat_rows;
         double s = 0.0;
-        for (int j = 0; j < r; ++j) s = fma(q[j * r + k], bb[j], s);
+        {
+            double qv[RP], bv[RP];                             // (every row in flight before the first use; round 5)
+#pragma unroll
+            for (int j = 0; j < RP; ++j) { const int jj = j < r ? j : 0; qv[j] = q[jj * r + k]; bv[j] = bb[jj]; }
+#pragma unroll
+            for (int j = 0; j < RP; ++j) if (j < r) s = fma(qv[j], bv[j], s);
+        }
         int idx;
         if (g.q_format == 0) idx = k < c ? base_col + k : g.mat_cols + (base_row - base_col) + (k - c);
         else idx = base_row + k;
