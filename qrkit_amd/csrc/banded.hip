@@ -1425,11 +1425,91 @@ hipError_t launch_bb_solve_r(const BBPanel* panels, int num_panels, const double
     return hipGetLastError();
 }
 
-// b(0:n, :) <- R^-1 b(0:n, :) for the upper triangle R (n x n) of a column-major array with leading dimension lda
-hipError_t launch_dense_solve_r(const double* qr, int64_t lda, int n, double* b, int64_t ldb, int64_t nrhs, hipStream_t stream)
+// One dense upper triangle, a few right-hand sides, MANY workgroups (round 5).  bb_solve_r_kernel gives a right-hand side one workgroup,
+// which pulls the 16 MB of a 2 000 x 2 000 triangle through one CU, 64 rows at a time: 1.37 ms of the 8 ms of configs[3]'s solve().  Here
+// the block of 64 rows kb has a workgroup of its own (blockIdx.x = 0 is the BOTTOM block): it takes the column blocks jb > kb in the
+// order in which their x becomes available -- bottom first -- waiting on one flag word each, subtracts R(kb, jb) x_jb with its four
+// waves, solves its diagonal block as bb_solve_r_kernel does and publishes x_kb.  A workgroup only ever waits for workgroups with a
+// SMALLER blockIdx.x, which were dispatched before it: no co-residency assumption, no deadlock; the wait is bounded all the same.
+// flags: [nrhs][nblk] ints, zero before the launch.  (The sums run over the column blocks from the bottom up: not the order of the
+// one-workgroup kernel, the same result to rounding.)
+__global__ void __launch_bounds__(BS_THREADS)
+dense_solve_r_coop_kernel(const double* __restrict__ R, int64_t lda, int n, double* __restrict__ b, int64_t ldb, int* __restrict__ flags,
+                          int nblk)
+{
+    __shared__ double blk[64 * 65];          // diagonal block, blk[j * 65 + i] = R(i, j)
+    __shared__ double part[4 * 64];
+    const int tid = threadIdx.x, ln = tid & 63, grp = tid >> 6;
+    const int kb = nblk - 1 - (int)blockIdx.x;
+    const int c0 = kb * 64, nr = (n - c0) < 64 ? (n - c0) : 64;
+    double* x = b + (int64_t)blockIdx.y * ldb;
+    int* fl = flags + (int64_t)blockIdx.y * nblk;
+    for (int e = tid; e < nr * nr; e += BS_THREADS) {
+        const int j = e / nr, i = e - j * nr;
+        blk[j * 65 + i] = R[(int64_t)(c0 + j) * lda + c0 + i];
+    }
+    double acc = 0.0;
+    const double* rrow = R + c0 + (ln < nr ? ln : 0);
+    for (int jb = nblk - 1; jb > kb; --jb) {
+        if (tid == 0) {
+            int spins = 0;
+            while (__hip_atomic_load(&fl[jb], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0 && ++spins < (1 << 22)) __builtin_amdgcn_s_sleep(2);
+        }
+        __syncthreads();
+        __threadfence();                                     // (x of block jb as its owner wrote it, not a stale line of this CU's L1)
+        const int j0 = jb * 64, j1 = (n - j0) < 64 ? n : j0 + 64;
+        // the 64 columns of the block dealt round-robin to the four waves, eight loads in flight
+        constexpr int U = 8;
+        for (int j = j0 + grp; j < j1; j += 4 * U) {
+            double rv[U], xv[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int jj = j + 4 * u, jc = jj < j1 ? jj : j1 - 1;
+                rv[u] = rrow[(int64_t)jc * lda];
+                xv[u] = jj < j1 ? __builtin_nontemporal_load(&x[jc]) : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) acc = fma(rv[u], xv[u], acc);
+        }
+    }
+    part[grp * 64 + ln] = acc;
+    __syncthreads();
+    if (grp == 0) {
+        double t = 0.0;
+        if (ln < nr) t = x[c0 + ln] - ((part[ln] + part[64 + ln]) + (part[128 + ln] + part[192 + ln]));
+        // back substitution inside the block.  The 64 dependent divisions were 60 % of the chain of a block (32 blocks in a row at
+        // n = 2 000): lane i divides ONCE, ahead of the chain, and a step is t_i * (1 / d_i) with one residual correction
+        // (x + (t - x d) / d: the quotient to the last bit but for rare ties)
+        const double dl = blk[(ln < nr ? ln : 0) * 65 + (ln < nr ? ln : 0)];
+        const double rdl = 1.0 / dl;
+        for (int i = nr - 1; i >= 0; --i) {
+            const double ti = readlane_f64(t, i), di = readlane_f64(dl, i), ri = readlane_f64(rdl, i);
+            double xi = ti * ri;
+            xi = fma(fma(-xi, di, ti), ri, xi);
+            if (ln < i) t = fma(-blk[i * 65 + ln], xi, t);
+            else if (ln == i) t = xi;
+        }
+        if (ln < nr) x[c0 + ln] = t;
+        __threadfence();
+        if (ln == 0) __hip_atomic_store(&fl[kb], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// b(0:n, :) <- R^-1 b(0:n, :) for the upper triangle R (n x n) of a column-major array with leading dimension lda.
+// flags (or null): flags_cap ints of device scratch for the many-workgroup form (n >= 512 and nrhs * ceil(n / 64) <= flags_cap).
+hipError_t launch_dense_solve_r(const double* qr, int64_t lda, int n, double* b, int64_t ldb, int64_t nrhs, hipStream_t stream, int* flags,
+                                int flags_cap)
 {
     if (nrhs <= 0 || n <= 0) return hipSuccess;
     if (lda > INT32_MAX) return hipErrorInvalidValue;
+    static const bool coop = !(std::getenv("QRK_SOLVE_R_COOP") && std::getenv("QRK_SOLVE_R_COOP")[0] == '0');
+    const int nblk = (n + 63) / 64;
+    if (coop && flags && n >= 512 && nrhs * nblk <= flags_cap) {
+        if (hipError_t e = hipMemsetAsync(flags, 0, (size_t)nrhs * nblk * sizeof(int), stream)) return e;
+        hipLaunchKernelGGL(dense_solve_r_coop_kernel, dim3((unsigned)nblk, (unsigned)nrhs), dim3(BS_THREADS), 0, stream, qr, lda, n, b, ldb,
+                           flags, nblk);
+        return hipGetLastError();
+    }
     BBPanel one{};
     one.col0 = 0; one.ncols = n; one.solved = (int32_t)lda; one.r_off = 0;     // R(i, j) = qr[j * lda + i]
     hipLaunchKernelGGL(bb_solve_r_kernel, dim3((unsigned)nrhs), dim3(BS_THREADS), 0, stream, (const BBPanel*)nullptr, one, 1, qr, n, b,

@@ -49,6 +49,8 @@ struct qrk_context_s {
     // side streams for the size classes of a mixed batch (fork after / join into `stream`), created on first use
     hipStream_t side[3] = {nullptr, nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
+    int* d_solve_flags = nullptr;  // scratch of the many-workgroup triangular solve (launch_dense_solve_r), allocated on first use
+    static constexpr int SOLVE_FLAGS = 8192;
     std::string error;
 };
 
@@ -528,6 +530,7 @@ qrk_status qrk_destroy(qrk_handle h)
             if (h->ev_join[z]) (void)hipEventDestroy(h->ev_join[z]);
         }
         if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+        if (h->d_solve_flags) (void)hipFree(h->d_solve_flags);
     }
     delete h;
     return QRK_STATUS_OK;
@@ -1363,6 +1366,13 @@ qrk_status qrk_dense_apply_q(qrk_dense_plan p, const double* qr, int64_t lda, co
     return QRK_STATUS_OK;
 }
 
+// (null when the allocation fails: the one-workgroup kernel serves then)
+static int* solve_flags(qrk_handle h)
+{
+    if (!h->d_solve_flags && hipMalloc((void**)&h->d_solve_flags, qrk_context_s::SOLVE_FLAGS * sizeof(int)) != hipSuccess) h->d_solve_flags = nullptr;
+    return h->d_solve_flags;
+}
+
 qrk_status qrk_dense_solve_r(qrk_dense_plan p, const double* qr, int64_t lda, double* b, int64_t ldb, int64_t nrhs,
                              qrk_memspace space)
 {
@@ -1371,14 +1381,14 @@ qrk_status qrk_dense_solve_r(qrk_dense_plan p, const double* qr, int64_t lda, do
     qrk_handle h = p->h;
     QRK_HIP(h, hipSetDevice(h->device));
     if (space == QRK_MEM_DEVICE) {
-        QRK_HIP(h, qrk::launch_dense_solve_r(qr, lda, p->cols, b, ldb, nrhs, h->stream));
+        QRK_HIP(h, qrk::launch_dense_solve_r(qr, lda, p->cols, b, ldb, nrhs, h->stream, solve_flags(h), qrk_context_s::SOLVE_FLAGS));
         return QRK_STATUS_OK;
     }
     Staging s(h);
     double *d_qr, *d_b;
     qrk_status st;
     if ((st = s.in(qr, lda * p->cols, &d_qr)) || (st = s.in((const double*)b, ldb * nrhs, &d_b))) return st;
-    QRK_HIP(h, qrk::launch_dense_solve_r(d_qr, lda, p->cols, d_b, ldb, nrhs, h->stream));
+    QRK_HIP(h, qrk::launch_dense_solve_r(d_qr, lda, p->cols, d_b, ldb, nrhs, h->stream, solve_flags(h), qrk_context_s::SOLVE_FLAGS));
     if ((st = s.back(b, d_b, ldb * nrhs))) return st;
     QRK_HIP(h, hipStreamSynchronize(h->stream));
     return QRK_STATUS_OK;
@@ -1764,7 +1774,7 @@ qrk_status qrk_thin_solve(qrk_thin_plan p, double* v, int64_t ldv, int64_t nrhs)
     qrk_status st = qrk_thin_apply_q(p, 1, v, ldv, nrhs);
     if (st != QRK_STATUS_OK) return st;
     qrk_handle h = p->h;
-    if (p->rank > 0) QRK_HIP(h, qrk::launch_dense_solve_r(p->d_R, p->cols, p->rank, v, ldv, nrhs, h->stream));
+    if (p->rank > 0) QRK_HIP(h, qrk::launch_dense_solve_r(p->d_R, p->cols, p->rank, v, ldv, nrhs, h->stream, solve_flags(h), qrk_context_s::SOLVE_FLAGS));
     if (p->rank < p->cols)
         QRK_HIP(h, hipMemset2DAsync(v + p->rank, (size_t)ldv * sizeof(double), 0, (size_t)(p->cols - p->rank) * sizeof(double), (size_t)nrhs, h->stream));
     return QRK_STATUS_OK;

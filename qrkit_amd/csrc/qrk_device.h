@@ -157,7 +157,8 @@ hipError_t launch_bb_chain(const BBPanel* panels, int num_panels, const int32_t*
 hipError_t launch_bb_apply_q(const BBPanel* panels, int num_panels, const double* y_vals, const double* t_vals,
                              int transpose, double* v, int64_t ldv, int64_t nrhs, int max_act_rows, int max_ncols,
                              hipStream_t stream);
-hipError_t launch_dense_solve_r(const double* qr, int64_t lda, int n, double* b, int64_t ldb, int64_t nrhs, hipStream_t stream);
+hipError_t launch_dense_solve_r(const double* qr, int64_t lda, int n, double* b, int64_t ldb, int64_t nrhs, hipStream_t stream,
+                                int* flags = nullptr, int flags_cap = 0);
 hipError_t launch_bb_solve_r(const BBPanel* panels, int num_panels, const double* r_stage, int cols, double* v, int64_t ldv,
                              int64_t nrhs, hipStream_t stream);
 size_t bb_chain_smem(int max_act_rows, int max_ncols);
