@@ -642,9 +642,18 @@ caqr_apply_vec_kernel(const double* __restrict__ A, int64_t lda, int m, int pc, 
         }
     }
     const double* Tt = Tin + (int64_t)t * (NB * NB);
+    // the row / column of T this thread multiplies with: fetched with the loads of Y, not after w is known (the kernel is a chain of
+    // dependent steps of 1-2 us each, 252 of them per solve(): every one taken off it counts; round 5)
+    double trow[NB];
+    if (tid < NB) {
+#pragma unroll
+        for (int k = 0; k < NB; ++k) trow[k] = transpose ? Tt[k * NB + tid] : Tt[tid * NB + k];
+    }
+    double cfirst = 0.0;
+    if (ncols > 0 && rok) cfirst = C[row0 + x];
     for (int v = 0; v < ncols; ++v) {
         double* cp = C + (int64_t)v * ldc + row0 + x;
-        double c = rok ? *cp : 0.0;
+        double c = v == 0 ? cfirst : (rok ? *cp : 0.0);
         // w = Y^T c
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -669,7 +678,8 @@ caqr_apply_vec_kernel(const double* __restrict__ A, int64_t lda, int m, int pc, 
         // w' = -(T^T or T) w
         if (tid < NB) {
             double sacc = 0.0;
-            for (int k = 0; k < NB; ++k) sacc = fma(transpose ? Tt[k * NB + tid] : Tt[tid * NB + k], wv[k], sacc);
+#pragma unroll
+            for (int k = 0; k < NB; ++k) sacc = fma(trow[k], wv[k], sacc);
             wp[tid] = -sacc;
         }
         __syncthreads();

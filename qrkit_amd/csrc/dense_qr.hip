@@ -12,6 +12,8 @@
 // for right blocks of BASELINE configs[3] size (40000 x 2000).
 #include "qrk_device.h"
 
+#include <cstdlib>
+
 #include <float.h>
 
 namespace qrk {
@@ -24,6 +26,17 @@ __device__ __forceinline__ double dq_wave_sum(double v)
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
     return v;
+}
+
+// the same sum by DPP steps inside the rows of 16 lanes and four v_readlane pairs: no trip through the LDS pipe (__shfl_xor is
+// ds_bpermute: six dependent LDS operations per sum; dense_apply_q_kernel does one per reflector, 2 000 in a row)
+__device__ __forceinline__ double dq_wave_sum_dpp(double v)
+{
+    v += dpp_f64<0xB1>(v);    // quad_perm [1,0,3,2]
+    v += dpp_f64<0x4E>(v);    // quad_perm [2,3,0,1]
+    v += dpp_f64<0x141>(v);   // row_half_mirror
+    v += dpp_f64<0x140>(v);   // row_mirror
+    return (readlane_f64(v, 0) + readlane_f64(v, 16)) + (readlane_f64(v, 32) + readlane_f64(v, 48));
 }
 
 __device__ __forceinline__ double dq_block_sum(double v, double* red)
@@ -206,7 +219,7 @@ dense_apply_q_kernel(const double* __restrict__ QR, int64_t lda, int r, int nref
                 double part = 0.0;
 #pragma unroll
                 for (int e = 0; e < APQ_EPT; ++e) { const int i = k + 1 + tid + 256 * e; part = fma(vc[e], bs[i < r ? i : r - 1], part); }
-                part = dq_wave_sum(part);
+                part = dq_wave_sum_dpp(part);
                 if ((tid & 63) == 0) red[tid >> 6] = part;
                 __syncthreads();
                 const double tt = tau * (red[0] + red[1] + red[2] + red[3] + xk);
