@@ -146,6 +146,11 @@ struct qrk_bbs_plan_s {
     int64_t y_len = 0, t_len = 0, stage_len = 0;
     int32_t max_act = 0;
     bool factorized = false;
+    // the chains of Q^T b / Q x / R^-1 y through one small matrix per strip (banded_maps.hip): built on the first product after a
+    // factorisation, kept until the next one; QRK_BBS_MAPS=0, or an allocation that fails, leaves the one-workgroup chains in charge
+    double *d_cmap = nullptr, *d_gmap = nullptr, *d_carry = nullptr;   // [N][lo][lo], [N][64][lo], [carry_cap][N][lo]
+    int64_t carry_cap = 0;
+    bool maps_ready = false, maps_off = false;
 };
 
 // ---- QRKit::BlockedThinSparseQR on the device (include/qrkit_amd.h, qrk_thin_*) -----------------------------------------------
@@ -1853,6 +1858,7 @@ qrk_status qrk_bbs_plan_destroy(qrk_bbs_plan p)
     if (p->bd) (void)qrk_bd_plan_destroy(p->bd);
     (void)hipFree(p->d_panels); (void)hipFree(p->d_rlim); (void)hipFree(p->d_q); (void)hipFree(p->d_ra); (void)hipFree(p->d_perm);
     (void)hipFree(p->d_y); (void)hipFree(p->d_t); (void)hipFree(p->d_stage); (void)hipFree(p->d_lo); (void)hipFree(p->d_done);
+    (void)hipFree(p->d_cmap); (void)hipFree(p->d_gmap); (void)hipFree(p->d_carry);
     delete p;
     return QRK_STATUS_OK;
 }
@@ -1872,6 +1878,7 @@ qrk_status qrk_bbs_factorize(qrk_bbs_plan p, const double* strips)
     qrk_handle h = p->h;
     QRK_HIP(h, hipSetDevice(h->device));
     p->factorized = false;
+    p->maps_ready = false;
     // stage A on all CUs: every strip triangularised on its own
     qrk_status st = qrk_bd_factorize(p->bd, strips, p->d_q, p->d_ra, p->d_perm, nullptr, QRK_MEM_DEVICE);
     if (st != QRK_STATUS_OK) return st;
@@ -1918,6 +1925,32 @@ qrk_status qrk_bbs_r_rows(qrk_bbs_plan p, int64_t strip, double* r_rows)
     return QRK_STATUS_OK;
 }
 
+// The maps of the current factorisation and the carry scratch for nrhs right-hand sides (banded_maps.hip).  False: the one-workgroup
+// chains run (lo = 0 or a single strip: there is no chain; QRK_BBS_MAPS=0; more than 65 535 right-hand sides; no memory for the maps:
+// 131 KB + 65 KB per strip at the BASELINE configs[2] shape).
+static bool bbs_maps(qrk_bbs_plan p, int64_t nrhs)
+{
+    const char* sw = std::getenv("QRK_BBS_MAPS");          // (read per call: the tests switch between the two forms in one process)
+    const bool off = sw && sw[0] == '0';
+    if (off || p->maps_off || p->lo <= 0 || p->N < 2 || nrhs > 65535 || nrhs <= 0) return false;
+    qrk_handle h = p->h;
+    auto give_up = [&]() { (void)hipGetLastError(); p->maps_off = true; return false; };
+    if (!p->d_cmap && hipMalloc((void**)&p->d_cmap, (size_t)p->N * p->lo * p->lo * sizeof(double)) != hipSuccess) return give_up();
+    if (p->s <= 64 && !p->d_gmap && hipMalloc((void**)&p->d_gmap, (size_t)p->N * 64 * p->lo * sizeof(double)) != hipSuccess) return give_up();
+    if (nrhs > p->carry_cap) {
+        (void)hipStreamSynchronize(h->stream);      // (a product that still reads the old scratch)
+        (void)hipFree(p->d_carry); p->d_carry = nullptr; p->carry_cap = 0;
+        if (hipMalloc((void**)&p->d_carry, (size_t)nrhs * p->N * p->lo * sizeof(double)) != hipSuccess) return give_up();
+        p->carry_cap = nrhs;
+    }
+    if (!p->maps_ready) {
+        if (qrk::launch_bbs_maps(p->d_panels, (int)p->N, p->d_y, p->d_t, p->d_stage, p->n, p->lo, p->d_cmap, p->d_gmap, h->stream) != hipSuccess)
+            return give_up();
+        p->maps_ready = true;
+    }
+    return true;
+}
+
 qrk_status qrk_bbs_apply_q(qrk_bbs_plan p, int transpose, const double* v, double* out, int64_t nrhs, double* work)
 {
     if (!p || !v || !out || !work || nrhs < 0 || v == out)
@@ -1926,14 +1959,23 @@ qrk_status qrk_bbs_apply_q(qrk_bbs_plan p, int transpose, const double* v, doubl
     qrk_handle h = p->h;
     QRK_HIP(h, hipSetDevice(h->device));
     qrk_status st;
+    const bool maps = bbs_maps(p, nrhs);
     if (transpose) {
         // work = per strip Q_i^T v_i, then the chain: out = Q^T v in the layout of the header
         if ((st = qrk_bd_apply_qt(p->bd, p->d_q, v, nrhs, work, QRK_MEM_DEVICE)) != QRK_STATUS_OK) return st;
-        QRK_HIP(h, qrk::launch_bbs_apply(p->d_panels, (int)p->N, p->d_y, p->d_t, 1, work, p->rows, out, p->rows, nrhs, p->ms, p->n, p->s,
-                                         p->lo, (int)p->cols, p->max_act, h->stream));
+        if (maps)
+            QRK_HIP(h, qrk::launch_bbs_apply_maps(p->d_panels, (int)p->N, p->d_y, p->d_t, p->d_cmap, 1, work, p->rows, out, p->rows, nrhs, p->ms,
+                                                  p->n, p->s, p->lo, (int)p->cols, p->max_act, p->d_carry, h->stream));
+        else
+            QRK_HIP(h, qrk::launch_bbs_apply(p->d_panels, (int)p->N, p->d_y, p->d_t, 1, work, p->rows, out, p->rows, nrhs, p->ms, p->n, p->s,
+                                             p->lo, (int)p->cols, p->max_act, h->stream));
     } else {
-        QRK_HIP(h, qrk::launch_bbs_apply(p->d_panels, (int)p->N, p->d_y, p->d_t, 0, work, p->rows, const_cast<double*>(v), p->rows, nrhs,
-                                         p->ms, p->n, p->s, p->lo, (int)p->cols, p->max_act, h->stream));
+        if (maps)
+            QRK_HIP(h, qrk::launch_bbs_apply_maps(p->d_panels, (int)p->N, p->d_y, p->d_t, p->d_cmap, 0, work, p->rows, const_cast<double*>(v),
+                                                  p->rows, nrhs, p->ms, p->n, p->s, p->lo, (int)p->cols, p->max_act, p->d_carry, h->stream));
+        else
+            QRK_HIP(h, qrk::launch_bbs_apply(p->d_panels, (int)p->N, p->d_y, p->d_t, 0, work, p->rows, const_cast<double*>(v), p->rows, nrhs,
+                                             p->ms, p->n, p->s, p->lo, (int)p->cols, p->max_act, h->stream));
         if ((st = qrk_bd_apply_q(p->bd, p->d_q, work, nrhs, out, QRK_MEM_DEVICE)) != QRK_STATUS_OK) return st;
     }
     return QRK_STATUS_OK;
@@ -1949,7 +1991,11 @@ qrk_status qrk_bbs_solve(qrk_bbs_plan p, const double* b, double* x, int64_t nrh
     double* qtb = work + p->rows * nrhs;
     qrk_status st = qrk_bbs_apply_q(p, 1, b, qtb, nrhs, work);
     if (st != QRK_STATUS_OK) return st;
-    QRK_HIP(h, qrk::launch_bb_solve_r(p->d_panels, (int)p->N, p->d_stage, (int)p->cols, qtb, p->rows, nrhs, h->stream));
+    if (bbs_maps(p, nrhs) && p->d_gmap)
+        QRK_HIP(h, qrk::launch_bbs_solve_r_maps(p->d_panels, (int)p->N, p->d_stage, p->d_gmap, p->n, p->s, p->lo, (int)p->cols, qtb, p->rows,
+                                                nrhs, h->stream));
+    else
+        QRK_HIP(h, qrk::launch_bb_solve_r(p->d_panels, (int)p->N, p->d_stage, (int)p->cols, qtb, p->rows, nrhs, h->stream));
     QRK_HIP(h, hipMemcpy2DAsync(x, (size_t)p->cols * sizeof(double), qtb, (size_t)p->rows * sizeof(double), (size_t)p->cols * sizeof(double),
                                 (size_t)nrhs, hipMemcpyDeviceToDevice, h->stream));
     return QRK_STATUS_OK;
