@@ -219,96 +219,116 @@ bbs_panel_apply_kernel(const BBPanel* __restrict__ panels, int num_panels, const
     }
 }
 
-// ---- 3: the chain of the carries -------------------------------------------------------------------------------------------------------
-// One workgroup per right-hand side.  Q^T (TR): for p = 1 .. N - 2: carr[p + 1] += M_p carr[p];  Q: for p = N - 2 .. 1:
-// carr[p - 1] += M_p^T carr[p].  M_p row-major lo x lo at cmap + p lo^2.  FAST (lo <= 128): every thread owns 16 entries of M_p and the
-// ones of the next step are in flight while this step is summed.
+// ---- 3: an affine chain  v <- Op(M_p) v + add_p  over the maps p of a range ------------------------------------------------------------------
+// One kernel for the three chains of the strips form (d = lo, maps row-major d x d at maps + p d^2, vectors at vecs + index * d):
+//   Q^T b      p = 1 .. N - 2 ascending,   Op = M_p,    in = vecs[p],     out = vecs[p + 1]   (the carries)
+//   Q x        p = N - 2 .. 1 descending,  Op = M_p^T,  in = vecs[p],     out = vecs[p - 1]
+//   R^-1 y     p = N - 2 .. 0 descending,  Op = A_p,    in = vecs[p + 1], out = vecs[p]       (the state x[p s .. p s + lo))
+// Step: out <- Op(M_p) in + out (out holds the additive term on entry); the out of a step is the in of the next.  One CU pulls a map of
+// 131 KB out of HBM in about 6 us (its own outstanding requests are the limit: prefetching two steps ahead changed nothing), so a chain
+// of N steps on one workgroup costs N x 6 us.  Hence TWO LEVELS: the range is cut into groups of K maps (blockIdx.y = group),
+//   mode 1  every group at once from a ZERO vector, nothing stored but the group's result e_j          (gvec: [ngroups + 1][d])
+//   mode 0  on the group products P_j (bbs_group_product_kernel) and the e_j: the true vector at every group boundary -- ngroups steps
+//   mode 3  every group at once again from its true entering vector, storing every step
+// i.e. 2 K + N / K sequential steps instead of N.  mode 0 with K >= the whole range is the plain one-workgroup chain (short chains, d > 128).
+// blockIdx.x = right-hand side.  gvec index of the vector ENTERING group j: j (ascending) or j + 1 (descending).
 template <bool TR, bool FAST>
 __global__ void __launch_bounds__(bbm::CH_THREADS)
-bbs_carry_chain_kernel(const double* __restrict__ cmap, double* __restrict__ carr_all, int num_panels, int lo)
+bbs_affine_chain_kernel(const double* __restrict__ maps, double* __restrict__ vecs_all, int64_t vecs_stride, int d, int p_lo, int p_hi, int K,
+                        int dir, int in_off, int out_off, int mode, double* __restrict__ gvec_all, int64_t gvec_stride)
 {
     using namespace bbm;
     __shared__ double cv[2][256];
     __shared__ double part[CH_THREADS];
-    const int tid = threadIdx.x;
-    double* carr = carr_all + (int64_t)blockIdx.x * num_panels * lo;
-    if (num_panels < 3) return;
-    const int64_t l2 = (int64_t)lo * lo;
-    const int first = TR ? 1 : num_panels - 2, last = TR ? num_panels - 2 : 1, dir = TR ? 1 : -1;
-    // thread -> entries of M.  TR: chunk e = (row a, 16 columns from 16 q): partial of out[a].  Q: (column b, rows g, g + G, ..): partial of out[b].
-    const int Q = lo / 16, G = CH_THREADS / lo;
-    const int a = TR ? tid / Q : 0, q = TR ? tid % Q : 0, b = TR ? 0 : tid % lo, g = TR ? 0 : tid / lo;
-    const bool act = TR ? tid < lo * Q : g < G;
-    if (tid < lo) cv[0][tid] = carr[(int64_t)first * lo + tid];
+    const int tid = threadIdx.x, j = blockIdx.y, ng = gridDim.y;
+    double* vecs = vecs_all + (int64_t)blockIdx.x * vecs_stride;
+    double* gvec = gvec_all ? gvec_all + (int64_t)blockIdx.x * gvec_stride : nullptr;
+    const int ga = p_lo + j * K, gb = (ga + K - 1 < p_hi) ? ga + K - 1 : p_hi;
+    if (ga > gb) return;
+    const int nsteps = gb - ga + 1, pfirst = dir > 0 ? ga : gb;
+    const int64_t l2 = (int64_t)d * d;
+    if (tid < d) {
+        double v0 = 0.0;
+        if (mode == 0) v0 = vecs[(int64_t)(pfirst + in_off) * d + tid];
+        else if (mode == 3) v0 = gvec[(int64_t)(dir > 0 ? j : j + 1) * d + tid];
+        else if (dir > 0 ? j == 0 : j == ng - 1) gvec[(int64_t)(dir > 0 ? 0 : ng) * d + tid] = vecs[(int64_t)(pfirst + in_off) * d + tid];   // the chain's start
+        cv[0][tid] = v0;
+    }
     int buf = 0;
+    const int Q = d / 16;
     if (FAST) {
+        // d <= 128: every thread owns 16 entries of a map -- TR: 16 consecutive of row a (a partial sum of out[a]); else column b of the
+        // rows g, g + G, .. (a partial sum of out[b]) -- and the entries of the next step are in flight while this one is summed
         typedef double d2 __attribute__((ext_vector_type(2)));
+        const int G = CH_THREADS / d;
+        const int a = TR ? tid / Q : 0, q = TR ? tid % Q : 0, b = TR ? 0 : tid % d, g = TR ? 0 : tid / d;
+        const bool act = TR ? tid < d * Q : g < G;
+        // (a uniform base and a 32-bit offset per thread: one address register per load instead of two)
+        const unsigned mine = act ? (TR ? (unsigned)(a * d + 16 * q) : (unsigned)(g * d + b)) : 0u;
         double cur[16], nxt[16];
         double addc = 0.0, addn = 0.0;
         auto load = [&](int p, double (&dst)[16], double& add) {
-            const double* M = cmap + (int64_t)p * l2;
+            const double* M = maps + (int64_t)p * l2;
             if (TR) {
-                const d2* src = reinterpret_cast<const d2*>(M + (int64_t)(act ? a : 0) * lo + 16 * (act ? q : 0));
+                const d2* src = reinterpret_cast<const d2*>(M + mine);
 #pragma unroll
                 for (int u = 0; u < 8; ++u) { const d2 v = src[u]; dst[2 * u] = v.x; dst[2 * u + 1] = v.y; }
             } else {
+                // (rows beyond d read the thread's first row and meet a zero below)
 #pragma unroll
-                for (int u = 0; u < 16; ++u) { const int r = g + G * u; dst[u] = M[(int64_t)((act && r < lo) ? r : 0) * lo + (act ? b : 0)]; }
+                for (int u = 0; u < 16; ++u) dst[u] = M[mine + ((g + G * u < d) ? (unsigned)(G * u * d) : 0u)];
             }
-            add = tid < lo ? carr[(int64_t)(p + dir) * lo + tid] : 0.0;
+            add = tid < d ? vecs[(int64_t)(p + out_off) * d + tid] : 0.0;
         };
-        load(first, cur, addc);
+        load(pfirst, cur, addc);
         __syncthreads();
-        for (int p = first;; p += dir) {
-            const bool more = p != last;
+        int p = pfirst;
+        for (int k = 0; k < nsteps; ++k, p += dir) {
+            const bool more = k + 1 < nsteps;
             if (more) load(p + dir, nxt, addn);
-            double acc = 0.0;
+            double a0 = 0.0, a1 = 0.0;
             if (TR) {
                 const double* c = &cv[buf][16 * q];
-                double a0 = 0.0, a1 = 0.0;
 #pragma unroll
                 for (int u = 0; u < 16; u += 2) { a0 = fma(cur[u], c[u], a0); a1 = fma(cur[u + 1], c[u + 1], a1); }
-                acc = a0 + a1;
             } else {
-                double a0 = 0.0, a1 = 0.0;
 #pragma unroll
                 for (int u = 0; u < 16; u += 2) {
                     const int r0 = g + G * u, r1 = g + G * (u + 1);
-                    a0 = fma(cur[u], r0 < lo ? cv[buf][r0] : 0.0, a0);
-                    a1 = fma(cur[u + 1], r1 < lo ? cv[buf][r1] : 0.0, a1);
+                    a0 = fma(cur[u], r0 < d ? cv[buf][r0] : 0.0, a0);
+                    a1 = fma(cur[u + 1], r1 < d ? cv[buf][r1] : 0.0, a1);
                 }
-                acc = a0 + a1;
             }
-            if (act) part[tid] = acc;
+            if (act) part[tid] = a0 + a1;
             lds_barrier();
-            if (tid < lo) {
+            if (tid < d) {
                 double sum = addc;
                 if (TR) { for (int z = 0; z < Q; ++z) sum += part[tid * Q + z]; }
-                else { for (int z = 0; z < G; ++z) sum += part[z * lo + tid]; }
+                else { for (int z = 0; z < G; ++z) sum += part[z * d + tid]; }
                 cv[buf ^ 1][tid] = sum;
-                carr[(int64_t)(p + dir) * lo + tid] = sum;
+                if (mode != 1) vecs[(int64_t)(p + out_off) * d + tid] = sum;
             }
             lds_barrier();
             buf ^= 1;
-            if (!more) break;
 #pragma unroll
             for (int u = 0; u < 16; ++u) cur[u] = nxt[u];
             addc = addn;
         }
     } else {
+        const int G = CH_THREADS / d, b = tid % d, g = tid / d;      // (not TR: column b of the rows g, g + G, ..)
         __syncthreads();
-        for (int p = first;; p += dir) {
-            const double* M = cmap + (int64_t)p * l2;
+        int p = pfirst;
+        for (int k = 0; k < nsteps; ++k, p += dir) {
+            const double* M = maps + (int64_t)p * l2;
             double acc = 0.0;
             if (TR) {
-                // chunks of 16 entries of a row in passes of CH_THREADS chunks (lo <= 240: at most four); the partial sums of a row meet
-                // in LDS after every pass
-                const int nch = lo * Q;
+                // 16-entry pieces of the rows in passes of CH_THREADS pieces (d <= 240: at most four); the partial sums of a row meet in LDS
+                const int nch = d * Q;
                 for (int base = 0; base < nch; base += CH_THREADS) {
                     const int e = base + tid;
                     if (e < nch) {
                         const int ra = e / Q, cq = e % Q;
-                        const double* src = M + (int64_t)ra * lo + 16 * cq;
+                        const double* src = M + (int64_t)ra * d + 16 * cq;
                         double v[16];
 #pragma unroll
                         for (int u = 0; u < 16; ++u) v[u] = src[u];
@@ -318,7 +338,7 @@ bbs_carry_chain_kernel(const double* __restrict__ cmap, double* __restrict__ car
                         part[tid] = sacc;
                     }
                     lds_barrier();
-                    if (tid < lo) {
+                    if (tid < d) {
                         int z0 = tid * Q, z1 = z0 + Q;
                         if (z0 < base) z0 = base;
                         if (z1 > base + CH_THREADS) z1 = base + CH_THREADS;
@@ -330,29 +350,83 @@ bbs_carry_chain_kernel(const double* __restrict__ cmap, double* __restrict__ car
             } else {
                 if (g < G) {
                     constexpr int U = 8;
-                    for (int r = g; r < lo; r += U * G) {
+                    for (int r = g; r < d; r += U * G) {
                         double v[U];
 #pragma unroll
-                        for (int u = 0; u < U; ++u) { const int rr = r + G * u; v[u] = M[(int64_t)(rr < lo ? rr : 0) * lo + b]; }
+                        for (int u = 0; u < U; ++u) { const int rr = r + G * u; v[u] = M[(int64_t)(rr < d ? rr : 0) * d + b]; }
 #pragma unroll
-                        for (int u = 0; u < U; ++u) { const int rr = r + G * u; if (rr < lo) acc = fma(v[u], cv[buf][rr], acc); }
+                        for (int u = 0; u < U; ++u) { const int rr = r + G * u; if (rr < d) acc = fma(v[u], cv[buf][rr], acc); }
                     }
                     part[tid] = acc;
                 }
                 lds_barrier();
                 acc = 0.0;
-                if (tid < lo) for (int z = 0; z < G; ++z) acc += part[z * lo + tid];
+                if (tid < d) for (int z = 0; z < G; ++z) acc += part[z * d + tid];
             }
-            if (tid < lo) {
-                const double sum = acc + carr[(int64_t)(p + dir) * lo + tid];
+            if (tid < d) {
+                const double sum = acc + vecs[(int64_t)(p + out_off) * d + tid];
                 cv[buf ^ 1][tid] = sum;
-                carr[(int64_t)(p + dir) * lo + tid] = sum;
+                if (mode != 1) vecs[(int64_t)(p + out_off) * d + tid] = sum;
             }
             __syncthreads();
             buf ^= 1;
-            if (p == last) break;
         }
     }
+    if (mode == 1 && tid < d) gvec[(int64_t)(dir > 0 ? j + 1 : j) * d + tid] = cv[buf][tid];
+}
+
+// P_j = M_last .. M_first over the maps of group j in the order the chain takes them (dir > 0: ascending p), d <= 128: C <- M_p C in LDS,
+// 256 threads as 16 x 16 with an 8 x 8 tile each, M_p through LDS in slabs of 16 columns.  (Op = M^T chains use the same products: the
+// descending chain over a group applies M_first^T .. -- the transpose of the ascending product.)
+__global__ void __launch_bounds__(256)
+bbs_group_product_kernel(const double* __restrict__ maps, int d, int p_lo, int p_hi, int K, int dir, double* __restrict__ pmap)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    constexpr int MS = 132;                  // stride of a slab row (doubles)
+    double* C = smem;                        // [d][d]
+    double* Ms = C + d * d;                  // [16][MS]: Ms[kk][r] = M(r, k0 + kk)
+    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4, j = blockIdx.x;
+    const int ga = p_lo + j * K, gb = (ga + K - 1 < p_hi) ? ga + K - 1 : p_hi;
+    if (ga > gb) return;
+    const int nsteps = gb - ga + 1, pfirst = dir > 0 ? ga : gb;
+    const int64_t l2 = (int64_t)d * d;
+    for (int e = tid; e < d * d; e += 256) C[e] = maps[(int64_t)pfirst * l2 + e];
+    __syncthreads();
+    const bool mine = 8 * ty < d && 8 * tx < d;
+    int p = pfirst + dir;
+    for (int k = 1; k < nsteps; ++k, p += dir) {
+        const double* M = maps + (int64_t)p * l2;
+        double acc[8][8] = {};
+        for (int k0 = 0; k0 < d; k0 += 16) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = tid + 256 * u, r = e >> 4, kk = e & 15;
+                Ms[kk * MS + r] = r < d ? M[(int64_t)r * d + k0 + kk] : 0.0;
+            }
+            __syncthreads();
+            if (mine) {
+#pragma unroll
+                for (int kk = 0; kk < 16; ++kk) {
+                    double av[8], bv[8];
+#pragma unroll
+                    for (int z = 0; z < 8; ++z) { av[z] = Ms[kk * MS + 8 * ty + z]; bv[z] = C[(k0 + kk) * d + 8 * tx + z]; }
+#pragma unroll
+                    for (int r = 0; r < 8; ++r)
+#pragma unroll
+                        for (int c = 0; c < 8; ++c) acc[r][c] = fma(av[r], bv[c], acc[r][c]);
+                }
+            }
+            __syncthreads();
+        }
+        if (mine) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r)
+#pragma unroll
+                for (int c = 0; c < 8; ++c) C[(8 * ty + r) * d + 8 * tx + c] = acc[r][c];
+        }
+        __syncthreads();
+    }
+    for (int e = tid; e < d * d; e += 256) pmap[(int64_t)j * l2 + e] = C[e];
 }
 
 // ---- 1: M_p = S_o (I + Y' T^T Y'^T) E_c of the panels 1 .. N - 2 -------------------------------------------------------------------------
@@ -446,16 +520,20 @@ bbs_carry_map_kernel(const BBPanel* __restrict__ panels, const double* __restric
 }
 
 // ---- the triangular solve ------------------------------------------------------------------------------------------------------------------
-// G_p = D_p^-1 U_p of the panels 0 .. N - 2 (solved = s <= 64 rows each): D = R(0:s, 0:s), U = R(0:s, s:n); R(i, j) = R[j s + i] in the
-// staging array.  A thread per column of U, the column in registers, the triangle padded to 64 x 64 with the identity.  gmap: [N][64][lo].
+// Panel p <= N - 2 (solved = s <= 64 rows): x_p = D_p^-1 (y_p - U_p x_right), D = R(0:s, 0:s), U = R(0:s, s:n), R(i, j) = R[j s + i] in the
+// staging array.  With the state u_p = x[p s .. p s + lo): u_p = A_p u_{p+1} + [D_p^-1 y_p; 0],
+//      A_p = [ -D_p^-1 U_p ]   s rows
+//            [  I   0       ]   lo - s rows (the entries of u_{p+1} that are still in the window)
+// -- an affine chain like the carries'.  A thread per column of U, the column in registers, the triangle padded to 64 x 64 with the
+// identity.  amap: [N][lo][lo], panels 0 .. N - 2 written.
 __global__ void __launch_bounds__(256)
-bbs_backsub_map_kernel(const BBPanel* __restrict__ panels, const double* __restrict__ r_stage, int lo, double* __restrict__ gmap)
+bbs_backsub_map_kernel(const BBPanel* __restrict__ panels, const double* __restrict__ r_stage, int lo, double* __restrict__ amap)
 {
     __shared__ double blk[64 * 65];          // blk[j * 65 + i] = D(i, j)
     __shared__ double rd[64];
     const int tid = threadIdx.x;
     const BBPanel p = panels[blockIdx.x];
-    const int n = p.ncols, sv = p.solved;
+    const int sv = p.solved;
     const double* R = r_stage + p.r_off;
     for (int e = tid; e < 64 * 64; e += 256) {
         const int j = e >> 6, i = e & 63;
@@ -464,32 +542,41 @@ bbs_backsub_map_kernel(const BBPanel* __restrict__ panels, const double* __restr
     __syncthreads();
     if (tid < 64) rd[tid] = 1.0 / blk[tid * 65 + tid];
     __syncthreads();
-    double* Gp = gmap + (int64_t)blockIdx.x * 64 * lo;
-    for (int c = tid; c < n - sv && c < lo; c += 256) {
+    double* Ap = amap + (int64_t)blockIdx.x * lo * lo;
+    for (int c = tid; c < lo; c += 256) {
         double x[64];
 #pragma unroll
         for (int i = 0; i < 64; ++i) x[i] = i < sv ? R[(int64_t)(sv + c) * sv + i] : 0.0;
 #pragma unroll
         for (int i = 63; i >= 0; --i) {
-            const double d = blk[i * 65 + i], r = rd[i];
+            const double dd = blk[i * 65 + i], r = rd[i];
             double xi = x[i] * r;
-            xi = fma(fma(-xi, d, x[i]), r, xi);          // the quotient to the last bit but for rare ties (banded.hip, dense_solve_r_coop_kernel)
+            xi = fma(fma(-xi, dd, x[i]), r, xi);         // the quotient to the last bit but for rare ties (banded.hip, dense_solve_r_coop_kernel)
             x[i] = xi;
 #pragma unroll
             for (int k = 0; k < i; ++k) x[k] = fma(-blk[i * 65 + k], xi, x[k]);
         }
 #pragma unroll
-        for (int i = 0; i < 64; ++i) if (i < sv) Gp[(int64_t)i * lo + c] = x[i];
+        for (int i = 0; i < 64; ++i) if (i < sv) Ap[(int64_t)i * lo + c] = -x[i];
     }
+    for (int e = tid; e < (lo - sv) * lo; e += 256) { const int i = sv + e / lo, c = e % lo; Ap[(int64_t)i * lo + c] = (c == i - sv) ? 1.0 : 0.0; }
 }
 
-// h_p = D_p^-1 y_p in place for the panels 0 .. N - 2: blockIdx.x = panel, blockIdx.y = group of four right-hand sides (a wave each)
+// The additive terms of that chain: U[p] = [D_p^-1 y_p; 0] for the panels p <= N - 2 (blockIdx.x = panel, a wave per right-hand side, four
+// to a workgroup) and U[N - 1] = the first lo entries of x of the last panel, which bb_solve_r_kernel has solved by now.  U: [nrhs][N][lo].
 __global__ void __launch_bounds__(256)
-bbs_backsub_diag_kernel(const BBPanel* __restrict__ panels, const double* __restrict__ r_stage, double* __restrict__ v, int64_t ldv, int64_t nrhs)
+bbs_backsub_diag_kernel(const BBPanel* __restrict__ panels, int num_panels, const double* __restrict__ r_stage, const double* __restrict__ v,
+                        int64_t ldv, int64_t nrhs, int lo, double* __restrict__ U)
 {
     __shared__ double blk[64 * 65];
     const int tid = threadIdx.x, ln = tid & 63, grp = tid >> 6;
-    const BBPanel p = panels[blockIdx.x];
+    const int pidx = blockIdx.x;
+    const BBPanel p = panels[pidx];
+    const int64_t col = (int64_t)blockIdx.y * 4 + grp;
+    if (pidx == num_panels - 1) {
+        if (col < nrhs) for (int i = ln; i < lo; i += 64) U[(col * num_panels + pidx) * lo + i] = v[col * ldv + p.col0 + i];
+        return;
+    }
     const int sv = p.solved;
     const double* R = r_stage + p.r_off;
     for (int e = tid; e < sv * sv; e += 256) {
@@ -497,9 +584,8 @@ bbs_backsub_diag_kernel(const BBPanel* __restrict__ panels, const double* __rest
         blk[j * 65 + i] = R[(int64_t)j * sv + i];
     }
     __syncthreads();
-    const int64_t col = (int64_t)blockIdx.y * 4 + grp;
     if (col >= nrhs) return;
-    double* x = v + col * ldv + p.col0;
+    const double* x = v + col * ldv + p.col0;
     double t = ln < sv ? x[ln] : 0.0;
     const double dl = blk[(ln < sv ? ln : 0) * 65 + (ln < sv ? ln : 0)];
     const double rdl = 1.0 / dl;
@@ -510,80 +596,107 @@ bbs_backsub_diag_kernel(const BBPanel* __restrict__ panels, const double* __rest
         if (ln < i) t = fma(-blk[i * 65 + ln], xi, t);
         else if (ln == i) t = xi;
     }
-    if (ln < sv) x[ln] = t;
+    double* u = U + (col * num_panels + pidx) * lo;
+    for (int i = ln; i < lo; i += 64) u[i] = i < sv ? t : 0.0;     // (sv <= 64: lane i holds x_i)
 }
 
-// x_p = h_p - G_p x_right for p = N - 2 .. 0, one workgroup per right-hand side; x of the last panel is final when this starts.  The last
-// n + s entries of x live in a ring in LDS; every thread owns 16 entries of G_p and those of the next panel are in flight meanwhile.
-__global__ void __launch_bounds__(bbm::CH_THREADS)
-bbs_backsub_chain_kernel(const double* __restrict__ gmap, int num_panels, int n, int s, int lo, double* __restrict__ v, int64_t ldv)
+// x[p s + i] = U[p][i], i < s, for the panels p <= N - 2
+__global__ void __launch_bounds__(64)
+bbs_backsub_scatter_kernel(int num_panels, int s, int lo, const double* __restrict__ U, double* __restrict__ v, int64_t ldv)
 {
-    using namespace bbm;
-    typedef double d2 __attribute__((ext_vector_type(2)));
-    __shared__ double xs[512];
-    __shared__ double part[CH_THREADS];
-    const int tid = threadIdx.x;
-    double* x = v + (int64_t)blockIdx.x * ldv;
-    const int Q = lo / 16;
-    const int r = tid / Q, q = tid % Q;
-    const bool act = tid < s * Q;
-    const int64_t cl = (int64_t)(num_panels - 1) * s;            // col0 of the last panel
-    for (int t = tid; t < n; t += CH_THREADS) xs[(cl + t) & 511] = x[cl + t];
-    double cur[16], nxt[16], hc = 0.0, hn = 0.0;
-    auto load = [&](int p, double (&dst)[16], double& h) {
-        const d2* src = reinterpret_cast<const d2*>(gmap + (int64_t)p * 64 * lo + (int64_t)(act ? r : 0) * lo + 16 * (act ? q : 0));
-#pragma unroll
-        for (int u = 0; u < 8; ++u) { const d2 g2 = src[u]; dst[2 * u] = g2.x; dst[2 * u + 1] = g2.y; }
-        h = tid < s ? x[(int64_t)p * s + tid] : 0.0;
-    };
-    load(num_panels - 2, cur, hc);
-    __syncthreads();
-    for (int p = num_panels - 2; p >= 0; --p) {
-        if (p > 0) load(p - 1, nxt, hn);
-        const int64_t c0 = (int64_t)p * s;
-        double a0 = 0.0, a1 = 0.0;
-#pragma unroll
-        for (int u = 0; u < 16; u += 2) {
-            a0 = fma(cur[u], xs[(c0 + s + 16 * q + u) & 511], a0);
-            a1 = fma(cur[u + 1], xs[(c0 + s + 16 * q + u + 1) & 511], a1);
-        }
-        if (act) part[tid] = a0 + a1;
-        lds_barrier();
-        if (tid < s) {
-            double sum = 0.0;
-            for (int z = 0; z < Q; ++z) sum += part[tid * Q + z];
-            const double xi = hc - sum;
-            xs[(c0 + tid) & 511] = xi;
-            x[c0 + tid] = xi;
-        }
-        lds_barrier();
-#pragma unroll
-        for (int u = 0; u < 16; ++u) cur[u] = nxt[u];
-        hc = hn;
-    }
+    const int pidx = blockIdx.x;
+    const int64_t col = blockIdx.y;
+    if (threadIdx.x < s) v[col * ldv + (int64_t)pidx * s + threadIdx.x] = U[(col * num_panels + pidx) * lo + threadIdx.x];
 }
 
 // ---- launchers ----------------------------------------------------------------------------------------------------------------------------
-// the maps of a factorisation: cmap [N][lo][lo] (panels 1 .. N - 2 are written), gmap [N][64][lo] or null (s > 64: the triangular solve
-// stays on bb_solve_r_kernel)
+namespace bbm {
+// group size of the two-level chains: 2 K + range / K sequential steps are least at K = sqrt(range / 2); 0: one level (short chains, and
+// d > 128, for which there is no product kernel)
+int group_size(int num_panels, int lo)
+{
+    if (lo > 128 || num_panels < 64) return 0;
+    int K = 8;
+    while ((int64_t)2 * (K + 1) * (K + 1) <= num_panels) ++K;
+    return K;
+}
+int groups(int range, int K) { return K > 0 ? (range + K - 1) / K : 1; }
+
+template <bool TR>
+void launch_chain(bool fast, dim3 grid, hipStream_t stream, const double* maps, double* vecs, int64_t vstride, int d, int p_lo, int p_hi, int K,
+                  int dir, int in_off, int out_off, int mode, double* gvec, int64_t gstride)
+{
+    if (fast) hipLaunchKernelGGL((bbs_affine_chain_kernel<TR, true>), grid, dim3(CH_THREADS), 0, stream, maps, vecs, vstride, d, p_lo, p_hi, K, dir,
+                                 in_off, out_off, mode, gvec, gstride);
+    else hipLaunchKernelGGL((bbs_affine_chain_kernel<TR, false>), grid, dim3(CH_THREADS), 0, stream, maps, vecs, vstride, d, p_lo, p_hi, K, dir,
+                            in_off, out_off, mode, gvec, gstride);
+}
+
+// the chain over the maps [p_lo, p_hi] in one or two levels; prods: the group products of that range (K > 0); gvec: [nrhs][groups + 1][d]
+template <bool TR>
+void run_chain(hipStream_t stream, const double* maps, const double* prods, int K, double* vecs, int64_t vstride, int d, int p_lo, int p_hi,
+               int dir, int in_off, int out_off, int64_t nrhs, double* gvec)
+{
+    if (p_hi < p_lo) return;
+    const bool fast = d <= 128;
+    const int range = p_hi - p_lo + 1;
+    if (K <= 0 || range <= K) {
+        launch_chain<TR>(fast, dim3((unsigned)nrhs, 1), stream, maps, vecs, vstride, d, p_lo, p_hi, range, dir, in_off, out_off, 0, nullptr, 0);
+        return;
+    }
+    const int ng = groups(range, K);
+    const int64_t gstride = (int64_t)(ng + 1) * d;
+    launch_chain<TR>(fast, dim3((unsigned)nrhs, (unsigned)ng), stream, maps, vecs, vstride, d, p_lo, p_hi, K, dir, in_off, out_off, 1, gvec, gstride);
+    // the boundaries: vectors gvec[0 .. ng], maps prods[0 .. ng - 1]; ascending: in = gvec[j], out = gvec[j + 1]; descending: in = gvec[j + 1], out = gvec[j]
+    launch_chain<TR>(fast, dim3((unsigned)nrhs, 1), stream, prods, gvec, gstride, d, 0, ng - 1, ng, dir, dir > 0 ? 0 : 1, dir > 0 ? 1 : 0, 0, nullptr, 0);
+    launch_chain<TR>(fast, dim3((unsigned)nrhs, (unsigned)ng), stream, maps, vecs, vstride, d, p_lo, p_hi, K, dir, in_off, out_off, 3, gvec, gstride);
+}
+}  // namespace bbm
+
+// sizes of the scratch a plan keeps for these products (doubles): products of the carry chain / of the back substitution, boundary vectors per rhs
+void bbs_maps_sizes(int num_panels, int lo, int* K, int64_t* cprod_len, int64_t* aprod_len, int64_t* gvec_len_per_rhs)
+{
+    const int k = bbm::group_size(num_panels, lo);
+    const int ngc = bbm::groups(num_panels - 2, k), nga = bbm::groups(num_panels - 1, k);
+    if (K) *K = k;
+    if (cprod_len) *cprod_len = k > 0 ? (int64_t)ngc * lo * lo : 0;
+    if (aprod_len) *aprod_len = k > 0 ? (int64_t)nga * lo * lo : 0;
+    if (gvec_len_per_rhs) *gvec_len_per_rhs = (int64_t)((nga > ngc ? nga : ngc) + 1) * lo;
+}
+
+// the maps of a factorisation: cmap [N][lo][lo] (panels 1 .. N - 2 written), amap [N][lo][lo] or null (s > 64: the triangular solve stays
+// on bb_solve_r_kernel), and with K > 0 the group products cprod / aprod (bbs_maps_sizes)
 hipError_t launch_bbs_maps(const BBPanel* panels, int num_panels, const double* y_vals, const double* t_vals, const double* r_stage, int n,
-                           int lo, double* cmap, double* gmap, hipStream_t stream)
+                           int lo, double* cmap, double* amap, int K, double* cprod, double* aprod, hipStream_t stream)
 {
     if (lo <= 0 || num_panels < 2) return hipSuccess;
+    const size_t psmem = (size_t)(lo * lo + 16 * 132) * sizeof(double);
+    if (K > 0) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(bbs_group_product_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)psmem);
+        if (e != hipSuccess) return e;
+    }
     if (num_panels >= 3) {
         const size_t smem = (size_t)(2 * 16 * 68 + n * 64) * sizeof(double);
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(bbs_carry_map_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(bbs_carry_map_kernel, dim3((unsigned)(num_panels - 2)), dim3(256), smem, stream, panels, y_vals, t_vals, lo, cmap);
+        if (K > 0 && num_panels - 2 > K)
+            hipLaunchKernelGGL(bbs_group_product_kernel, dim3((unsigned)bbm::groups(num_panels - 2, K)), dim3(256), psmem, stream, cmap, lo, 1,
+                               num_panels - 2, K, 1, cprod);
     }
-    if (gmap) hipLaunchKernelGGL(bbs_backsub_map_kernel, dim3((unsigned)(num_panels - 1)), dim3(256), 0, stream, panels, r_stage, lo, gmap);
+    if (amap) {
+        hipLaunchKernelGGL(bbs_backsub_map_kernel, dim3((unsigned)(num_panels - 1)), dim3(256), 0, stream, panels, r_stage, lo, amap);
+        if (K > 0 && num_panels - 1 > K)
+            hipLaunchKernelGGL(bbs_group_product_kernel, dim3((unsigned)bbm::groups(num_panels - 1, K)), dim3(256), psmem, stream, amap, lo, 0,
+                               num_panels - 2, K, -1, aprod);
+    }
     return hipGetLastError();
 }
 
-// Q^T (transpose) or Q through the carry maps; carr: [nrhs][N][lo] scratch
+// Q^T (transpose) or Q through the carry maps; carr: [nrhs][N][lo] scratch, gvec: [nrhs][bbs_maps_sizes] scratch
 hipError_t launch_bbs_apply_maps(const BBPanel* panels, int num_panels, const double* y_vals, const double* t_vals, const double* cmap,
-                                 int transpose, double* ya, int64_t ya_ld, double* full, int64_t full_ld, int64_t nrhs, int ms, int n, int s,
-                                 int lo, int cols, int max_act, double* carr, hipStream_t stream)
+                                 const double* cprod, int K, int transpose, double* ya, int64_t ya_ld, double* full, int64_t full_ld,
+                                 int64_t nrhs, int ms, int n, int s, int lo, int cols, int max_act, double* carr, double* gvec, hipStream_t stream)
 {
     using namespace bbm;
     if (nrhs <= 0) return hipSuccess;
@@ -594,33 +707,28 @@ hipError_t launch_bbs_apply_maps(const BBPanel* panels, int num_panels, const do
     const dim3 grid((unsigned)num_panels, (unsigned)nrhs);
     hipLaunchKernelGGL(bbs_panel_apply_kernel, grid, dim3(PA_THREADS), smem, stream, panels, num_panels, y_vals, t_vals, transpose, 1, ya, ya_ld,
                        full, full_ld, carr, ms, s, lo, cols, max_act, n);
-    if (num_panels >= 3) {
-        const bool fast = lo <= 128;
-        if (transpose) {
-            if (fast) hipLaunchKernelGGL((bbs_carry_chain_kernel<true, true>), dim3((unsigned)nrhs), dim3(CH_THREADS), 0, stream, cmap, carr, num_panels, lo);
-            else hipLaunchKernelGGL((bbs_carry_chain_kernel<true, false>), dim3((unsigned)nrhs), dim3(CH_THREADS), 0, stream, cmap, carr, num_panels, lo);
-        } else {
-            if (fast) hipLaunchKernelGGL((bbs_carry_chain_kernel<false, true>), dim3((unsigned)nrhs), dim3(CH_THREADS), 0, stream, cmap, carr, num_panels, lo);
-            else hipLaunchKernelGGL((bbs_carry_chain_kernel<false, false>), dim3((unsigned)nrhs), dim3(CH_THREADS), 0, stream, cmap, carr, num_panels, lo);
-        }
-    }
+    const int64_t vstride = (int64_t)num_panels * lo;
+    if (transpose) run_chain<true>(stream, cmap, cprod, K, carr, vstride, lo, 1, num_panels - 2, 1, 0, 1, nrhs, gvec);
+    else run_chain<false>(stream, cmap, cprod, K, carr, vstride, lo, 1, num_panels - 2, -1, 0, -1, nrhs, gvec);
     hipLaunchKernelGGL(bbs_panel_apply_kernel, grid, dim3(PA_THREADS), smem, stream, panels, num_panels, y_vals, t_vals, transpose, 2, ya, ya_ld,
                        full, full_ld, carr, ms, s, lo, cols, max_act, n);
     return hipGetLastError();
 }
 
-// x(0:cols) <- R^-1 x(0:cols) through G_p (s <= 64): the last panel as before, h_p of every other panel at once, then the chain
-hipError_t launch_bbs_solve_r_maps(const BBPanel* panels, int num_panels, const double* r_stage, const double* gmap, int n, int s, int lo,
-                                   int cols, double* v, int64_t ldv, int64_t nrhs, hipStream_t stream)
+// x(0:cols) <- R^-1 x(0:cols) through A_p (s <= 64): the last panel as before, the additive terms of every other panel at once, the chain
+// of the states, x out of the states.  U: [nrhs][N][lo] scratch (the carry scratch), gvec as above.
+hipError_t launch_bbs_solve_r_maps(const BBPanel* panels, int num_panels, const double* r_stage, const double* amap, const double* aprod, int K,
+                                   int s, int lo, int cols, double* v, int64_t ldv, int64_t nrhs, double* U, double* gvec, hipStream_t stream)
 {
     using namespace bbm;
     if (nrhs <= 0) return hipSuccess;
-    if (nrhs > 65535 || s > 64 || lo <= 0 || lo % 16 || num_panels < 2 || !gmap) return hipErrorInvalidValue;
+    if (nrhs > 65535 || s > 64 || lo <= 0 || lo % 16 || num_panels < 2 || !amap) return hipErrorInvalidValue;
     hipError_t e = launch_bb_solve_r(panels + (num_panels - 1), 1, r_stage, cols, v, ldv, nrhs, stream);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(bbs_backsub_diag_kernel, dim3((unsigned)(num_panels - 1), (unsigned)((nrhs + 3) / 4)), dim3(256), 0, stream, panels, r_stage,
-                       v, ldv, nrhs);
-    hipLaunchKernelGGL(bbs_backsub_chain_kernel, dim3((unsigned)nrhs), dim3(CH_THREADS), 0, stream, gmap, num_panels, n, s, lo, v, ldv);
+    hipLaunchKernelGGL(bbs_backsub_diag_kernel, dim3((unsigned)num_panels, (unsigned)((nrhs + 3) / 4)), dim3(256), 0, stream, panels, num_panels,
+                       r_stage, v, ldv, nrhs, lo, U);
+    run_chain<true>(stream, amap, aprod, K, U, (int64_t)num_panels * lo, lo, 0, num_panels - 2, -1, 1, 0, nrhs, gvec);
+    hipLaunchKernelGGL(bbs_backsub_scatter_kernel, dim3((unsigned)(num_panels - 1), (unsigned)nrhs), dim3(64), 0, stream, num_panels, s, lo, U, v, ldv);
     return hipGetLastError();
 }
 

@@ -148,8 +148,10 @@ struct qrk_bbs_plan_s {
     bool factorized = false;
     // the chains of Q^T b / Q x / R^-1 y through one small matrix per strip (banded_maps.hip): built on the first product after a
     // factorisation, kept until the next one; QRK_BBS_MAPS=0, or an allocation that fails, leaves the one-workgroup chains in charge
-    double *d_cmap = nullptr, *d_gmap = nullptr, *d_carry = nullptr;   // [N][lo][lo], [N][64][lo], [carry_cap][N][lo]
-    int64_t carry_cap = 0;
+    double *d_cmap = nullptr, *d_amap = nullptr, *d_carry = nullptr;   // [N][lo][lo] each (carries / back substitution), [carry_cap][N][lo]
+    double *d_cprod = nullptr, *d_aprod = nullptr, *d_gvec = nullptr;   // group products of the two-level chains, [carry_cap] boundary vectors
+    int32_t maps_K = 0;                 // group size (0: one level)
+    int64_t carry_cap = 0, gvec_per_rhs = 0;
     bool maps_ready = false, maps_off = false;
 };
 
@@ -1858,7 +1860,8 @@ qrk_status qrk_bbs_plan_destroy(qrk_bbs_plan p)
     if (p->bd) (void)qrk_bd_plan_destroy(p->bd);
     (void)hipFree(p->d_panels); (void)hipFree(p->d_rlim); (void)hipFree(p->d_q); (void)hipFree(p->d_ra); (void)hipFree(p->d_perm);
     (void)hipFree(p->d_y); (void)hipFree(p->d_t); (void)hipFree(p->d_stage); (void)hipFree(p->d_lo); (void)hipFree(p->d_done);
-    (void)hipFree(p->d_cmap); (void)hipFree(p->d_gmap); (void)hipFree(p->d_carry);
+    (void)hipFree(p->d_cmap); (void)hipFree(p->d_amap); (void)hipFree(p->d_carry); (void)hipFree(p->d_cprod); (void)hipFree(p->d_aprod);
+    (void)hipFree(p->d_gvec);
     delete p;
     return QRK_STATUS_OK;
 }
@@ -1925,9 +1928,9 @@ qrk_status qrk_bbs_r_rows(qrk_bbs_plan p, int64_t strip, double* r_rows)
     return QRK_STATUS_OK;
 }
 
-// The maps of the current factorisation and the carry scratch for nrhs right-hand sides (banded_maps.hip).  False: the one-workgroup
-// chains run (lo = 0 or a single strip: there is no chain; QRK_BBS_MAPS=0; more than 65 535 right-hand sides; no memory for the maps:
-// 131 KB + 65 KB per strip at the BASELINE configs[2] shape).
+// The maps of the current factorisation and the scratch for nrhs right-hand sides (banded_maps.hip).  False: the one-workgroup chains run
+// (lo = 0 or a single strip: there is no chain; QRK_BBS_MAPS=0; more than 65 535 right-hand sides; no memory for the maps: 2 x 131 KB per
+// strip at the BASELINE configs[2] shape).
 static bool bbs_maps(qrk_bbs_plan p, int64_t nrhs)
 {
     const char* sw = std::getenv("QRK_BBS_MAPS");          // (read per call: the tests switch between the two forms in one process)
@@ -1935,16 +1938,33 @@ static bool bbs_maps(qrk_bbs_plan p, int64_t nrhs)
     if (off || p->maps_off || p->lo <= 0 || p->N < 2 || nrhs > 65535 || nrhs <= 0) return false;
     qrk_handle h = p->h;
     auto give_up = [&]() { (void)hipGetLastError(); p->maps_off = true; return false; };
-    if (!p->d_cmap && hipMalloc((void**)&p->d_cmap, (size_t)p->N * p->lo * p->lo * sizeof(double)) != hipSuccess) return give_up();
-    if (p->s <= 64 && !p->d_gmap && hipMalloc((void**)&p->d_gmap, (size_t)p->N * 64 * p->lo * sizeof(double)) != hipSuccess) return give_up();
+    const size_t l2 = (size_t)p->lo * p->lo * sizeof(double);
+    if (!p->d_cmap) {
+        int64_t cl = 0, al = 0;
+        int K = 0;
+        qrk::bbs_maps_sizes((int)p->N, p->lo, &K, &cl, &al, &p->gvec_per_rhs);
+        if (const char* e = std::getenv("QRK_BBS_MAPS_K")) {      // (group size by hand; 0: one level)
+            K = std::atoi(e);
+            if (K < 0 || p->lo > 128) K = 0;
+            if (K > 0) { cl = ((p->N - 2 + K - 1) / K) * (int64_t)p->lo * p->lo; al = ((p->N - 1 + K - 1) / K) * (int64_t)p->lo * p->lo;
+                         p->gvec_per_rhs = ((p->N - 1 + K - 1) / K + 1) * (int64_t)p->lo; }
+        }
+        p->maps_K = K;
+        if (hipMalloc((void**)&p->d_cmap, (size_t)p->N * l2) != hipSuccess) return give_up();
+        if (p->s <= 64 && hipMalloc((void**)&p->d_amap, (size_t)p->N * l2) != hipSuccess) return give_up();
+        if (K > 0 && (hipMalloc((void**)&p->d_cprod, (size_t)(cl > 0 ? cl : 1) * sizeof(double)) != hipSuccess ||
+                      hipMalloc((void**)&p->d_aprod, (size_t)(al > 0 ? al : 1) * sizeof(double)) != hipSuccess)) return give_up();
+    }
     if (nrhs > p->carry_cap) {
         (void)hipStreamSynchronize(h->stream);      // (a product that still reads the old scratch)
-        (void)hipFree(p->d_carry); p->d_carry = nullptr; p->carry_cap = 0;
-        if (hipMalloc((void**)&p->d_carry, (size_t)nrhs * p->N * p->lo * sizeof(double)) != hipSuccess) return give_up();
+        (void)hipFree(p->d_carry); (void)hipFree(p->d_gvec); p->d_carry = p->d_gvec = nullptr; p->carry_cap = 0;
+        if (hipMalloc((void**)&p->d_carry, (size_t)nrhs * p->N * p->lo * sizeof(double)) != hipSuccess ||
+            hipMalloc((void**)&p->d_gvec, (size_t)nrhs * p->gvec_per_rhs * sizeof(double)) != hipSuccess) return give_up();
         p->carry_cap = nrhs;
     }
     if (!p->maps_ready) {
-        if (qrk::launch_bbs_maps(p->d_panels, (int)p->N, p->d_y, p->d_t, p->d_stage, p->n, p->lo, p->d_cmap, p->d_gmap, h->stream) != hipSuccess)
+        if (qrk::launch_bbs_maps(p->d_panels, (int)p->N, p->d_y, p->d_t, p->d_stage, p->n, p->lo, p->d_cmap, p->d_amap, p->maps_K, p->d_cprod,
+                                 p->d_aprod, h->stream) != hipSuccess)
             return give_up();
         p->maps_ready = true;
     }
@@ -1964,15 +1984,16 @@ qrk_status qrk_bbs_apply_q(qrk_bbs_plan p, int transpose, const double* v, doubl
         // work = per strip Q_i^T v_i, then the chain: out = Q^T v in the layout of the header
         if ((st = qrk_bd_apply_qt(p->bd, p->d_q, v, nrhs, work, QRK_MEM_DEVICE)) != QRK_STATUS_OK) return st;
         if (maps)
-            QRK_HIP(h, qrk::launch_bbs_apply_maps(p->d_panels, (int)p->N, p->d_y, p->d_t, p->d_cmap, 1, work, p->rows, out, p->rows, nrhs, p->ms,
-                                                  p->n, p->s, p->lo, (int)p->cols, p->max_act, p->d_carry, h->stream));
+            QRK_HIP(h, qrk::launch_bbs_apply_maps(p->d_panels, (int)p->N, p->d_y, p->d_t, p->d_cmap, p->d_cprod, p->maps_K, 1, work, p->rows, out,
+                                                  p->rows, nrhs, p->ms, p->n, p->s, p->lo, (int)p->cols, p->max_act, p->d_carry, p->d_gvec, h->stream));
         else
             QRK_HIP(h, qrk::launch_bbs_apply(p->d_panels, (int)p->N, p->d_y, p->d_t, 1, work, p->rows, out, p->rows, nrhs, p->ms, p->n, p->s,
                                              p->lo, (int)p->cols, p->max_act, h->stream));
     } else {
         if (maps)
-            QRK_HIP(h, qrk::launch_bbs_apply_maps(p->d_panels, (int)p->N, p->d_y, p->d_t, p->d_cmap, 0, work, p->rows, const_cast<double*>(v),
-                                                  p->rows, nrhs, p->ms, p->n, p->s, p->lo, (int)p->cols, p->max_act, p->d_carry, h->stream));
+            QRK_HIP(h, qrk::launch_bbs_apply_maps(p->d_panels, (int)p->N, p->d_y, p->d_t, p->d_cmap, p->d_cprod, p->maps_K, 0, work, p->rows,
+                                                  const_cast<double*>(v), p->rows, nrhs, p->ms, p->n, p->s, p->lo, (int)p->cols, p->max_act,
+                                                  p->d_carry, p->d_gvec, h->stream));
         else
             QRK_HIP(h, qrk::launch_bbs_apply(p->d_panels, (int)p->N, p->d_y, p->d_t, 0, work, p->rows, const_cast<double*>(v), p->rows, nrhs,
                                              p->ms, p->n, p->s, p->lo, (int)p->cols, p->max_act, h->stream));
@@ -1991,9 +2012,9 @@ qrk_status qrk_bbs_solve(qrk_bbs_plan p, const double* b, double* x, int64_t nrh
     double* qtb = work + p->rows * nrhs;
     qrk_status st = qrk_bbs_apply_q(p, 1, b, qtb, nrhs, work);
     if (st != QRK_STATUS_OK) return st;
-    if (bbs_maps(p, nrhs) && p->d_gmap)
-        QRK_HIP(h, qrk::launch_bbs_solve_r_maps(p->d_panels, (int)p->N, p->d_stage, p->d_gmap, p->n, p->s, p->lo, (int)p->cols, qtb, p->rows,
-                                                nrhs, h->stream));
+    if (bbs_maps(p, nrhs) && p->d_amap)
+        QRK_HIP(h, qrk::launch_bbs_solve_r_maps(p->d_panels, (int)p->N, p->d_stage, p->d_amap, p->d_aprod, p->maps_K, p->s, p->lo, (int)p->cols,
+                                                qtb, p->rows, nrhs, p->d_carry, p->d_gvec, h->stream));
     else
         QRK_HIP(h, qrk::launch_bb_solve_r(p->d_panels, (int)p->N, p->d_stage, (int)p->cols, qtb, p->rows, nrhs, h->stream));
     QRK_HIP(h, hipMemcpy2DAsync(x, (size_t)p->cols * sizeof(double), qtb, (size_t)p->rows * sizeof(double), (size_t)p->cols * sizeof(double),

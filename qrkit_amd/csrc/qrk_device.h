@@ -170,14 +170,16 @@ hipError_t launch_bbs_chain(const BBPanel* panels, int num_panels, const double*
 hipError_t launch_bbs_apply(const BBPanel* panels, int num_panels, const double* y_vals, const double* t_vals, int transpose,
                             double* ya, int64_t ya_ld, double* full, int64_t full_ld, int64_t nrhs, int ms, int n, int s, int lo,
                             int cols, int max_act_rows, hipStream_t stream);
-// strips form through the carry maps (banded_maps.hip): the chains of Q^T b / Q x / R^-1 y reduced to one small matrix per strip
+// strips form through the carry maps (banded_maps.hip): the chains of Q^T b / Q x / R^-1 y reduced to one small matrix per strip and run
+// in two levels (groups of K strips at once, then the group boundaries)
+void bbs_maps_sizes(int num_panels, int lo, int* K, int64_t* cprod_len, int64_t* aprod_len, int64_t* gvec_len_per_rhs);
 hipError_t launch_bbs_maps(const BBPanel* panels, int num_panels, const double* y_vals, const double* t_vals, const double* r_stage, int n,
-                           int lo, double* cmap, double* gmap, hipStream_t stream);
+                           int lo, double* cmap, double* amap, int K, double* cprod, double* aprod, hipStream_t stream);
 hipError_t launch_bbs_apply_maps(const BBPanel* panels, int num_panels, const double* y_vals, const double* t_vals, const double* cmap,
-                                 int transpose, double* ya, int64_t ya_ld, double* full, int64_t full_ld, int64_t nrhs, int ms, int n, int s,
-                                 int lo, int cols, int max_act, double* carr, hipStream_t stream);
-hipError_t launch_bbs_solve_r_maps(const BBPanel* panels, int num_panels, const double* r_stage, const double* gmap, int n, int s, int lo,
-                                   int cols, double* v, int64_t ldv, int64_t nrhs, hipStream_t stream);
+                                 const double* cprod, int K, int transpose, double* ya, int64_t ya_ld, double* full, int64_t full_ld,
+                                 int64_t nrhs, int ms, int n, int s, int lo, int cols, int max_act, double* carr, double* gvec, hipStream_t stream);
+hipError_t launch_bbs_solve_r_maps(const BBPanel* panels, int num_panels, const double* r_stage, const double* amap, const double* aprod, int K,
+                                   int s, int lo, int cols, double* v, int64_t ldv, int64_t nrhs, double* U, double* gvec, hipStream_t stream);
 void launch_bd_pattern(const TileGeom& g, int64_t nnz_r, int32_t* q_rowptr, int32_t* q_colidx,
                        int32_t* r_colptr, int32_t* r_rowidx, hipStream_t stream);
 void launch_bd_cut_tiles(const TileGeom& g, const int64_t* t_off, int row_major, const int32_t* outer_ptr,

@@ -181,13 +181,15 @@ def test_given_up_pipeline_falls_back_to_one_workgroup(capfd):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("N,ms,n,s", [(2, 64, 48, 16), (3, 64, 48, 16), (9, 40, 32, 16), (12, 96, 64, 32), (24, 256, 192, 64), (7, 256, 256, 64),
-                                      (6, 256, 192, 96), (5, 256, 240, 16), (40, 128, 128, 64)])
+                                      (6, 256, 192, 96), (5, 256, 240, 16), (40, 128, 128, 64), (70, 64, 48, 16), (131, 96, 64, 32),
+                                      (100, 256, 192, 64), (66, 256, 240, 16)])
 def test_carry_maps_agree_with_the_one_workgroup_chains(N, ms, n, s):
     """banded_maps.hip: Q^T b, Q x and the triangular solve through one small matrix per strip (M_i = the linear map of the carry,
     G_i = D_i^-1 U_i) against the chains that walk the strips on one workgroup (QRK_BBS_MAPS=0): the same operators associated
     differently, so agreement to rounding -- one and several right-hand sides, carries of 16 ... 224 entries (both forms of the chain
-    kernel), column steps above 64 (the triangular solve stays on the old kernel there), and a second factorisation on the same
-    plan (the maps are rebuilt)."""
+    kernel), column steps above 64 (the triangular solve stays on the old kernel there), 64 strips and more (the chains run in two
+    levels: groups of K strips at once, then the group boundaries through the products of the groups' maps; QRK_BBS_MAPS_K), and a
+    second factorisation on the same plan (the maps are rebuilt)."""
     import torch
     import qrkit_amd
     from qrkit_amd.banded import BandedStripsQR
@@ -209,8 +211,8 @@ def test_carry_maps_agree_with_the_one_workgroup_chains(N, ms, n, s):
     qr = BandedStripsQR(N, ms, n, s, context=qrkit_amd.Context(0))
     for rep in range(2):
         strips = make(N, ms, n, s, seed=100 * rep + N + n)
-        J = assemble(strips, N, ms, n, s)
-        rows, cols = J.shape
+        rows, cols = N * ms, (N - 1) * s + n
+        J = assemble(strips, N, ms, n, s) if rows * cols <= 4e6 else None
         qr.factorize(to_device(strips))
         rng = np.random.default_rng(rep)
         for nrhs in (1, 5):
@@ -223,5 +225,6 @@ def test_carry_maps_agree_with_the_one_workgroup_chains(N, ms, n, s):
             assert rel_fro(z1, b.cpu().numpy()) <= 1e-12
             x0, x1 = both(lambda: qr.solve(b))
             assert rel_fro(x1, x0) <= 1e-10, (rep, nrhs)
-            ref = np.linalg.lstsq(J, b.cpu().numpy(), rcond=None)[0]
-            assert rel_fro(x1, ref) <= 1e-9
+            if J is not None:
+                ref = np.linalg.lstsq(J, b.cpu().numpy(), rcond=None)[0]
+                assert rel_fro(x1, ref) <= 1e-9

@@ -22,8 +22,11 @@ for N in [int(a) for a in sys.argv[1:]] or [2048]:
     strips = torch.rand(N * ms * n, device="cuda", dtype=torch.float64) * 2 - 1
     b = torch.rand(N * ms, device="cuda", dtype=torch.float64)
     res = {}
-    for sw in ("0", "1"):
+    for sw, kk in (("0", None), ("1", "0"), ("1", None)):
         os.environ["QRK_BBS_MAPS"] = sw
+        os.environ.pop("QRK_BBS_MAPS_K", None)
+        if kk is not None:
+            os.environ["QRK_BBS_MAPS_K"] = kk
         qr = BandedStripsQR(N, ms, n, s, context=ctx)
         qr.factorize(strips); torch.cuda.synchronize()
         t0 = time.perf_counter(); x = qr.solve(b); torch.cuda.synchronize(); first = time.perf_counter() - t0
@@ -33,7 +36,7 @@ for N in [int(a) for a in sys.argv[1:]] or [2048]:
         t_q = timed(lambda: qr.applyQ(y, transpose=False))
         back = qr.applyQ(y, transpose=False)
         res[sw] = x
-        print(f"N={N} QRK_BBS_MAPS={sw}: solve first call {first * 1e3:8.2f} ms, steady {t_solve * 1e3:8.2f} ms = {t_solve / N * 1e6:7.2f} us per strip; "
+        print(f"N={N} QRK_BBS_MAPS={sw} K={kk if kk is not None else 'auto'}: solve first call {first * 1e3:8.2f} ms, steady {t_solve * 1e3:8.2f} ms = {t_solve / N * 1e6:7.2f} us per strip; "
               f"Q^T b {t_qt * 1e3:8.2f} ms, Q x {t_q * 1e3:8.2f} ms; |QQ^T b - b|/|b| = {float((back - b).norm() / b.norm()):.2e}", flush=True)
         del qr
     print(f"   solutions of the two forms differ by {float((res['1'] - res['0']).norm() / res['0'].norm()):.2e} (relative)", flush=True)
