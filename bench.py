@@ -692,6 +692,8 @@ def strips_config2(ctx, dev, torch, np, N=2048):
     bd.analyzePattern(mat)
     t_a = timed(lambda: bd.factorize(mat))
     b = torch.rand(qr.rows(), device=dev, dtype=torch.float64, generator=g)
+    torch.cuda.synchronize(); t0 = time.perf_counter(); qr.solve(b); torch.cuda.synchronize()
+    t_solve_first = time.perf_counter() - t0                             # (builds the per-strip maps of banded_maps.hip: once per factorisation)
     t_solve = timed(lambda: qr.solve(b), 2)
     fl_a = N * (2.0 * ms * n * n - 2.0 * n ** 3 / 3)                     # Householder QR of a 256 x 192 strip
     fl_b = N * 5.0e6                                                     # merge of two triangles (staircase), DESIGN.md K4
@@ -699,6 +701,9 @@ def strips_config2(ctx, dev, torch, np, N=2048):
                         "triangularised as one batch) + stage B (the chain that merges the carried triangle with each strip's)",
             "ms_total": t_all * 1e3, "ms_per_strip": t_all * 1e3 / N, "stage_a_ms": t_a * 1e3, "chain_ms_per_strip": (t_all - t_a) * 1e3 / N,
             "projected_s_for_50000_strips": t_all / N * 50000, "solve_ms_per_strip": t_solve * 1e3 / N,
+            "solve_ms": t_solve * 1e3, "solve_first_call_ms": t_solve_first * 1e3,
+            "solve_note": "Q^T b and R^-1 y through one small matrix per strip and two-level chains (banded_maps.hip); the first solve after "
+                          "a factorisation also builds those matrices; rounds 3-4 (one workgroup walking the strips): 0.071 ms per strip",
             "roofline": {"bound": "fp64 of ONE CU for the chain (a true dependency strip to strip), fp64 of the chip for stage A",
                          "stage_a_TFLOPs": fl_a / t_a / 1e12, "stage_a_frac_of_fp64_peak": fl_a / t_a / 1e12 / 78.6,
                          "chain_GFLOPs": fl_b / max(t_all - t_a, 1e-9) / 1e9, "one_cu_fp64_peak_GFLOPs": 307.0,

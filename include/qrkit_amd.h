@@ -326,7 +326,12 @@ qrk_status qrk_bbs_factorize(qrk_bbs_plan plan, const double* strips);
  * leading dimension = the number of rows (col_step; strip_cols for the last strip), upper trapezoidal */
 qrk_status qrk_bbs_r_rows(qrk_bbs_plan plan, int64_t strip, double* r_rows);
 /* out = Q^T v (transpose != 0) or Q v; v, out: rows x nrhs (ld = rows), distinct; work: rows x nrhs doubles.  v is not modified
- * logically (the Q v direction reads it only). */
+ * logically (the Q v direction reads it only).
+ * The chain from strip to strip carries strip_cols - col_step numbers and every strip acts on them linearly, so the first product
+ * (or solve) after a factorisation forms one small matrix per strip on all CUs (qrkit_amd/csrc/banded_maps.hip: 2 x 8 (strip_cols -
+ * col_step)^2 bytes per strip, kept by the plan until the next factorisation) and the products then run every strip at once plus a
+ * two-level chain of those matrices: 0.8 us per strip instead of 70 at the BASELINE configs[2] shape.  QRK_BBS_MAPS=0, more than
+ * 65 535 right-hand sides, or no memory for the matrices: one workgroup walks the strips as before (same result to rounding). */
 qrk_status qrk_bbs_apply_q(qrk_bbs_plan plan, int transpose, const double* v, double* out, int64_t nrhs, double* work);
 /* least squares: x (cols x nrhs, ld = cols) = R^-1 (Q^T b)(0:cols) (BandedBlockedSparseQR::_solve_impl, :290-311);
  * b: rows x nrhs; work: 2 rows nrhs doubles */

@@ -224,9 +224,9 @@ bbs_panel_apply_kernel(const BBPanel* __restrict__ panels, int num_panels, const
 //   Q^T b      p = 1 .. N - 2 ascending,   Op = M_p,    in = vecs[p],     out = vecs[p + 1]   (the carries)
 //   Q x        p = N - 2 .. 1 descending,  Op = M_p^T,  in = vecs[p],     out = vecs[p - 1]
 //   R^-1 y     p = N - 2 .. 0 descending,  Op = A_p,    in = vecs[p + 1], out = vecs[p]       (the state x[p s .. p s + lo))
-// Step: out <- Op(M_p) in + out (out holds the additive term on entry); the out of a step is the in of the next.  One CU pulls a map of
-// 131 KB out of HBM in about 6 us (its own outstanding requests are the limit: prefetching two steps ahead changed nothing), so a chain
-// of N steps on one workgroup costs N x 6 us.  Hence TWO LEVELS: the range is cut into groups of K maps (blockIdx.y = group),
+// Step: out <- Op(M_p) in + out (out holds the additive term on entry); the out of a step is the in of the next.  One workgroup pulls a
+// map of 131 KB out of HBM in about 6 us even with the next step's entries in flight (21 GB/s into one CU, profiles/
+// r05_banded_solve_maps.txt), so a chain of N steps on one workgroup costs N x 6 us.  Hence TWO LEVELS: the range is cut into groups of K maps (blockIdx.y = group),
 //   mode 1  every group at once from a ZERO vector, nothing stored but the group's result e_j          (gvec: [ngroups + 1][d])
 //   mode 0  on the group products P_j (bbs_group_product_kernel) and the e_j: the true vector at every group boundary -- ngroups steps
 //   mode 3  every group at once again from its true entering vector, storing every step

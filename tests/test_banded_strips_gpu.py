@@ -120,7 +120,13 @@ def test_strips_configs2_full_size():
         i1 = min(N, i0 + 2000)
         idx = (torch.arange(i0, i1, device="cuda") * s)[:, None] + torch.arange(n, device="cuda")[None, :]
         b.view(N, ms)[i0:i1] = torch.einsum("inm,in->im", S3[i0:i1], x[idx])
+    torch.cuda.synchronize(); t0 = time.perf_counter()
     xs = qr.solve(b)
+    torch.cuda.synchronize(); t1 = time.perf_counter()
+    xs2 = qr.solve(b)
+    torch.cuda.synchronize(); t2 = time.perf_counter()
+    print(f"configs[2] solve: first call {t1 - t0:.3f} s (builds the maps of banded_maps.hip), then {t2 - t1:.3f} s = {(t2 - t1) / N * 1e6:.2f} us per strip")
+    assert torch.equal(xs, xs2)
     err = float((xs - x).norm() / x.norm())
     print(f"configs[2] LS recovery: {err:.2e}")
     assert err <= 1e-8
