@@ -247,6 +247,7 @@ bbs_affine_chain_kernel(const double* __restrict__ maps, double* __restrict__ ve
     if (ga > gb) return;
     const int nsteps = gb - ga + 1, pfirst = dir > 0 ? ga : gb;
     const int64_t l2 = (int64_t)d * d;
+    if (tid >= d && tid < 256) { cv[0][tid] = 0.0; cv[1][tid] = 0.0; }      // (the Op = M^T form reads entries beyond d against rows it does not have)
     if (tid < d) {
         double v0 = 0.0;
         if (mode == 0) v0 = vecs[(int64_t)(pfirst + in_off) * d + tid];
@@ -293,10 +294,9 @@ bbs_affine_chain_kernel(const double* __restrict__ maps, double* __restrict__ ve
                 for (int u = 0; u < 16; u += 2) { a0 = fma(cur[u], c[u], a0); a1 = fma(cur[u + 1], c[u + 1], a1); }
             } else {
 #pragma unroll
-                for (int u = 0; u < 16; u += 2) {
-                    const int r0 = g + G * u, r1 = g + G * (u + 1);
-                    a0 = fma(cur[u], r0 < d ? cv[buf][r0] : 0.0, a0);
-                    a1 = fma(cur[u + 1], r1 < d ? cv[buf][r1] : 0.0, a1);
+                for (int u = 0; u < 16; u += 2) {      // (rows g + G u >= d: cv is zero there; g + 15 G < 256)
+                    a0 = fma(cur[u], cv[buf][g + G * u], a0);
+                    a1 = fma(cur[u + 1], cv[buf][g + G * (u + 1)], a1);
                 }
             }
             if (act) part[tid] = a0 + a1;
