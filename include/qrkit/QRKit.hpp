@@ -790,6 +790,144 @@ class BandedBlockedSparseQR {
     PermutationType m_rowPerm, m_outputPerm_c;
 };
 
+// The STRIPS FORM of the banded solver behind the same interface (qrk_bbs_*, qrkit_amd/csrc/banded.hip + banded_maps.hip): a block-banded
+// matrix whose block row i is a dense BlockRows x BlockCols strip at the columns [i (BlockCols - BlockOverlap), ..) -- the pattern
+// BandedBlockedSparseQR's fixed template parameters describe (BandedBlockedSparseQR.h:398-408, fromBlockBandedPattern,
+// SparseQRUtils.h:274-302) and BASELINE configs[2]'s.  Every strip is triangularised on all CUs, a chain merges the triangles, solve()
+// and the products with Q run every strip at once plus a two-level chain of one small matrix per strip; 64-bit offsets throughout, so
+// the 50 000-strip shape the CSR entry cannot index fits (compute() from a SparseMatrix is for matrices the host can hold; factorizeStrips()
+// takes the strips directly).  R is the reference's up to the sign of each row (unique up to row signs for a fixed column order); the rows
+// of Q^T v are ordered [the cols entries that meet R | per strip: chain residuals, stage-A residuals] (include/qrkit_amd.h).
+// Constraints of the entry: BlockRows >= BlockCols, both and the column step multiples of 16, at most 256.
+template <int BlockRows, int BlockCols, int BlockOverlap>
+class BandedStripsSparseQR {
+  public:
+    typedef SparseMatrixColMajor MatrixRType;
+    typedef PermutationMatrix PermutationType;
+    typedef QProduct<BandedStripsSparseQR> MatrixQType;
+    enum { ColStep = BlockCols - BlockOverlap };
+
+    explicit BandedStripsSparseQR(int device = 0) : m_info(Success), m_isInitialized(false), m_handle(0), m_plan(0), m_strips(0), m_rows(0), m_cols(0) {
+        if (qrk_create(&m_handle, device, 0) != QRK_STATUS_OK)
+            throw std::runtime_error(std::string("qrkit: ") + qrk_last_error(0));
+    }
+    ~BandedStripsSparseQR() { if (m_plan) qrk_bbs_plan_destroy(m_plan); if (m_handle) qrk_destroy(m_handle); }
+    BandedStripsSparseQR(const BandedStripsSparseQR&) = delete;
+    BandedStripsSparseQR& operator=(const BandedStripsSparseQR&) = delete;
+
+    template <bool RM> void compute(const SparseMatrix<RM>& mat) { analyzePattern(mat); factorize(mat); }
+    // the geometry alone decides the plan: rows = N BlockRows, cols = (N - 1) ColStep + BlockCols
+    template <bool RM> void analyzePattern(const SparseMatrix<RM>& mat) { plan(mat.rows() / BlockRows, mat.rows(), mat.cols()); }
+    // every stored entry must lie inside its strip (InvalidInput otherwise, nothing is factorised)
+    template <bool RM> void factorize(const SparseMatrix<RM>& mat) {
+        assert(m_plan && mat.rows() == m_rows && mat.cols() == m_cols && "analyzePattern() should be called first");
+        std::vector<double> strips((size_t)m_strips * BlockRows * BlockCols, 0.0);
+        m_info = Success;
+        for (Index o = 0; o < mat.outerSize(); ++o)
+            for (int p = mat.outerIndex()[(size_t)o]; p < mat.outerIndex()[(size_t)o + 1]; ++p) {
+                const Index r = RM ? o : mat.innerIndex()[(size_t)p], c = RM ? mat.innerIndex()[(size_t)p] : o;
+                const Index i = r / BlockRows, lc = c - i * ColStep;
+                if (lc < 0 || lc >= BlockCols) { m_info = InvalidInput; m_isInitialized = false; return; }
+                strips[(size_t)((i * BlockCols + lc) * BlockRows + (r - i * BlockRows))] = mat.values()[(size_t)p];
+            }
+        factorizeStrips(strips.data(), m_strips);
+    }
+    // strips: strip i column-major (BlockRows x BlockCols) at strips + i BlockRows BlockCols, host memory
+    void factorizeStrips(const double* strips, Index numStrips) {
+        if (!m_plan || numStrips != m_strips) plan(numStrips, numStrips * BlockRows, (numStrips - 1) * ColStep + BlockCols);
+        const int64_t bytes = (int64_t)m_strips * BlockRows * BlockCols * (int64_t)sizeof(double);
+        Dev d(*this, bytes);
+        check(qrk_memcpy(m_handle, d.p, strips, bytes, 0));
+        check(qrk_bbs_factorize(m_plan, (const double*)d.p));
+        check(qrk_synchronize(m_handle));
+        m_Rsynced = false;
+        m_isInitialized = true;
+        m_info = Success;
+    }
+
+    Index rows() const { return m_rows; }
+    Index cols() const { return m_cols; }
+    Index rank() const { assert(m_isInitialized); return m_cols; }          // (BandedBlockedSparseQR.h:513 "assuming all cols are nonzero")
+    ComputationInfo info() const { return m_info; }
+    const PermutationType& colsPermutation() const { return m_perm_c; }      // identity, as the reference's
+    const PermutationType& rowsPermutation() const { return m_perm_r; }      // identity: the strips are given in band order
+    MatrixQType matrixQ() const { return MatrixQType(*this, false); }
+    // R as a sparse matrix: strip i emits the rows [i ColStep, ..) over its own columns (dense inside the band, explicit zeros kept
+    // as the reference keeps them, BandedBlockedSparseQR.h:484-491)
+    const MatrixRType& matrixR() const {
+        assert(m_isInitialized);
+        if (m_Rsynced) return m_R;
+        std::vector<Triplet> t;
+        Dev d(*this, (int64_t)BlockCols * BlockCols * (int64_t)sizeof(double));
+        std::vector<double> blk((size_t)BlockCols * BlockCols);
+        for (Index i = 0; i < m_strips; ++i) {
+            const Index solved = i + 1 < m_strips ? ColStep : BlockCols;
+            check(qrk_bbs_r_rows(m_plan, (int64_t)i, (double*)d.p));
+            check(qrk_memcpy(m_handle, blk.data(), d.p, (int64_t)(solved * BlockCols) * (int64_t)sizeof(double), 1));
+            for (Index c = 0; c < BlockCols; ++c)
+                for (Index r = 0; r < solved && r <= c; ++r) t.push_back(Triplet((int)(i * ColStep + r), (int)(i * ColStep + c), blk[(size_t)(c * solved + r)]));
+        }
+        m_R.resize(m_rows, m_cols);
+        m_R.setFromTriplets(t);
+        m_Rsynced = true;
+        return m_R;
+    }
+    Vector applyQ(const Vector& v) const { return apply(v, 0); }
+    Vector applyQt(const Vector& v) const { return apply(v, 1); }
+    // _solve_impl (BandedBlockedSparseQR.h:290-311): x = R^-1 (Q^T B)(0:cols); B: rows x nrhs column-major
+    Vector solve(const Vector& B) const {
+        assert(m_isInitialized && "The factorization should be called first, use compute()");
+        const int64_t nrhs = (int64_t)B.size() / m_rows, bytes = (int64_t)(B.size() * sizeof(double));
+        Dev b(*this, bytes), x(*this, m_cols * nrhs * (int64_t)sizeof(double)), w(*this, 2 * bytes);
+        check(qrk_memcpy(m_handle, b.p, B.data(), bytes, 0));
+        check(qrk_bbs_solve(m_plan, (const double*)b.p, (double*)x.p, nrhs, (double*)w.p));
+        Vector out((size_t)(m_cols * nrhs));
+        check(qrk_memcpy(m_handle, out.data(), x.p, (int64_t)(out.size() * sizeof(double)), 1));
+        return out;
+    }
+    template <bool RM2> SparseMatrix<false> solve(const SparseMatrix<RM2>& B) const { return detail::solveSparseThroughDensePanels<true>(*this, rows(), cols(), B); }
+
+  protected:
+    struct Dev {                 // scoped device scratch
+        const BandedStripsSparseQR& s; void* p;
+        Dev(const BandedStripsSparseQR& ss, int64_t bytes) : s(ss), p(0) { s.check(qrk_device_alloc(s.m_handle, bytes > 0 ? bytes : 8, &p)); }
+        ~Dev() { if (p) qrk_device_free(s.m_handle, p); }
+        Dev(const Dev&) = delete;
+        Dev& operator=(const Dev&) = delete;
+    };
+    void plan(Index numStrips, Index rows, Index cols) {
+        if (m_plan) { qrk_bbs_plan_destroy(m_plan); m_plan = 0; }
+        m_isInitialized = false;
+        if (numStrips < 1 || rows != numStrips * BlockRows || cols != (numStrips - 1) * ColStep + BlockCols)
+            throw std::runtime_error("qrkit: BandedStripsSparseQR: the matrix is not N strips of BlockRows x BlockCols at column step BlockCols - BlockOverlap");
+        check(qrk_bbs_plan_create(m_handle, (int64_t)numStrips, BlockRows, BlockCols, ColStep, &m_plan));
+        m_strips = numStrips; m_rows = rows; m_cols = cols;
+        m_perm_c.setIdentity(m_cols); m_perm_r.setIdentity(m_rows);
+        m_Rsynced = false;
+    }
+    Vector apply(const Vector& v, int transpose) const {
+        assert(m_isInitialized && (Index)v.size() % m_rows == 0);
+        const int64_t nrhs = (int64_t)v.size() / m_rows, bytes = (int64_t)(v.size() * sizeof(double));
+        Dev in(*this, bytes), out(*this, bytes), w(*this, bytes);
+        check(qrk_memcpy(m_handle, in.p, v.data(), bytes, 0));
+        check(qrk_bbs_apply_q(m_plan, transpose, (const double*)in.p, (double*)out.p, nrhs, (double*)w.p));
+        Vector r(v.size());
+        check(qrk_memcpy(m_handle, r.data(), out.p, bytes, 1));
+        return r;
+    }
+    void check(qrk_status st) const {
+        if (st != QRK_STATUS_OK) throw std::runtime_error(std::string("qrkit: ") + qrk_last_error(m_handle));
+    }
+    ComputationInfo m_info;
+    bool m_isInitialized;
+    qrk_handle m_handle;
+    qrk_bbs_plan m_plan;
+    Index m_strips, m_rows, m_cols;
+    mutable MatrixRType m_R;
+    mutable bool m_Rsynced = false;
+    PermutationType m_perm_c, m_perm_r;
+};
+
 // Dense Householder QR kept on the device (qrk_dense_*): the packed QR and tau stay resident after factorize(), products
 // with Q and the triangular solve move only their vectors.  Shared by the thin solvers and the angular right block.
 class DenseDeviceQR {

@@ -238,7 +238,7 @@ bbs_affine_chain_kernel(const double* __restrict__ maps, double* __restrict__ ve
                         int dir, int in_off, int out_off, int mode, double* __restrict__ gvec_all, int64_t gvec_stride)
 {
     using namespace bbm;
-    __shared__ double cv[2][256];
+    __shared__ double cv[2][CH_THREADS];      // the vector of the step, double-buffered; zero beyond d
     __shared__ double part[CH_THREADS];
     const int tid = threadIdx.x, j = blockIdx.y, ng = gridDim.y;
     double* vecs = vecs_all + (int64_t)blockIdx.x * vecs_stride;
@@ -247,7 +247,7 @@ bbs_affine_chain_kernel(const double* __restrict__ maps, double* __restrict__ ve
     if (ga > gb) return;
     const int nsteps = gb - ga + 1, pfirst = dir > 0 ? ga : gb;
     const int64_t l2 = (int64_t)d * d;
-    if (tid >= d && tid < 256) { cv[0][tid] = 0.0; cv[1][tid] = 0.0; }      // (the Op = M^T form reads entries beyond d against rows it does not have)
+    if (tid >= d) { cv[0][tid] = 0.0; cv[1][tid] = 0.0; }      // (the Op = M^T form reads entries beyond d against rows it does not have)
     if (tid < d) {
         double v0 = 0.0;
         if (mode == 0) v0 = vecs[(int64_t)(pfirst + in_off) * d + tid];
@@ -294,7 +294,7 @@ bbs_affine_chain_kernel(const double* __restrict__ maps, double* __restrict__ ve
                 for (int u = 0; u < 16; u += 2) { a0 = fma(cur[u], c[u], a0); a1 = fma(cur[u + 1], c[u + 1], a1); }
             } else {
 #pragma unroll
-                for (int u = 0; u < 16; u += 2) {      // (rows g + G u >= d: cv is zero there; g + 15 G < 256)
+                for (int u = 0; u < 16; u += 2) {      // (rows g + G u >= d meet a zero: cv[d .. 1023] = 0 and g + 15 G < 16 * 1024 / d <= 1024)
                     a0 = fma(cur[u], cv[buf][g + G * u], a0);
                     a1 = fma(cur[u + 1], cv[buf][g + G * (u + 1)], a1);
                 }

@@ -147,6 +147,76 @@ static int test_banded_blocked(const SparseMatrixColMajor& spJ, const char* name
     return fails;
 }
 
+// The strips form of the banded solver behind the facade (BandedStripsSparseQR<BlockRows, BlockCols, BlockOverlap>, qrk_bbs_*): the
+// reference's own invariants of test_banded_blocked (test-qrkit.cpp:249-253) on a block-banded matrix of N dense strips, solve() with
+// dense and sparse right-hand sides, and R against the CSR entry's (the reference's elimination order) after aligning the sign of
+// each row -- for a fixed column order R is unique up to row signs.  N >= 64 runs the chains of solve() / Q products in two levels.
+template <int BR, int BC, int BO>
+static int test_banded_strips(Index N, const char* name) {
+    int fails = 0;
+    const Index step = BC - BO, rows = N * BR, cols = (N - 1) * step + BC;
+    std::mt19937_64 rng(11 + (unsigned)N);
+    std::uniform_real_distribution<double> ud(-1.0, 1.0);
+    std::vector<Triplet> t;
+    for (Index i = 0; i < N; ++i)
+        for (Index c = 0; c < BC; ++c)
+            for (Index r = 0; r < BR; ++r) { const double v = ud(rng); t.emplace_back((int)(i * BR + r), (int)(i * step + c), v + (v < 0 ? -0.25 : 0.25)); }
+    SparseMatrixColMajor spJ(rows, cols);
+    spJ.setFromTriplets(t);
+    BandedStripsSparseQR<BR, BC, BO> slvr;
+    slvr.compute(spJ);
+    if (slvr.info() != Success) { std::printf("  info() != Success\n"); ++fails; }
+    const Matrix J = spJ.toDense(), Rd = slvr.matrixR().toDense();
+    Vector x((size_t)cols);
+    for (double& v : x) v = ud(rng);
+    const Vector b = spJ * x;
+    if (rows <= 1200) {
+        const Matrix I = identity(rows);
+        const Matrix Q = slvr.matrixQ() * I, Qt = slvr.matrixQ().transpose() * I;
+        if (!approx(matmul(Q, Rd, false), J, 1e-10)) { std::printf("  Q*R != J\n"); ++fails; }
+        if (!approx(matmul(Q, J, true), Rd, 1e-10)) { std::printf("  Q^T*J != R\n"); ++fails; }
+        if (!approx(matmul(Qt, Rd, true), J, 1e-10)) { std::printf("  (Q^T)^T*R != J\n"); ++fails; }
+        if (!approx(matmul(Qt, J, false), Rd, 1e-10)) { std::printf("  (Q^T)*J != R\n"); ++fails; }
+    } else {
+        const Vector y = slvr.matrixQ().transpose() * b, back = slvr.matrixQ() * y;
+        if (!approxVec(back, b, 1e-12)) { std::printf("  Q Q^T b != b\n"); ++fails; }
+        double tail = 0, all = 0;
+        for (size_t i = 0; i < y.size(); ++i) { all += y[i] * y[i]; if ((Index)i >= cols) tail += y[i] * y[i]; }
+        if (std::sqrt(tail) > 1e-11 * std::sqrt(all)) { std::printf("  Q^T (J x) leaves the range of R\n"); ++fails; }
+    }
+    const Vector y = slvr.matrixQ().transpose() * b;
+    if (!approxVec(x, solveUpperCsc(slvr.matrixR(), cols, y), 1e-8)) { std::printf("  LS recovery failed\n"); ++fails; }
+    if (!approxVec(x, slvr.solve(b), 1e-8)) { std::printf("  solve() recovery failed\n"); ++fails; }
+    fails += checkSparseRhs(slvr, b, "BandedStripsSparseQR");
+    {   // the same matrix through the CSR entry in the reference's order
+        BandedBlockedSparseQR<8> ref;
+        ref.compute(spJ);
+        const Matrix Rr = ref.matrixR().toDense();
+        double worst = 0.0;
+        for (Index i = 0; i < cols; ++i) {
+            const double sg = (Rd(i, i) < 0) == (Rr(i, i) < 0) ? 1.0 : -1.0;
+            double d = 0, nr = 0;
+            for (Index j = i; j < cols; ++j) { const double e = sg * Rd(i, j) - Rr(i, j); d += e * e; nr += Rr(i, j) * Rr(i, j); }
+            worst = std::max(worst, std::sqrt(d / nr));
+        }
+        if (!(worst <= 1e-10)) { std::printf("  R differs from the CSR entry's beyond row signs: %.2e\n", worst); ++fails; }
+    }
+    // an entry outside its strip: InvalidInput, nothing factorised
+    {
+        std::vector<Triplet> t2 = t;
+        if (N >= 3) {
+            t2.emplace_back((int)0, (int)(cols - 1), 1.0);
+            SparseMatrixColMajor bad(rows, cols);
+            bad.setFromTriplets(t2);
+            BandedStripsSparseQR<BR, BC, BO> s2;
+            s2.compute(bad);
+            if (s2.info() != InvalidInput) { std::printf("  an entry outside the band was accepted\n"); ++fails; }
+        }
+    }
+    std::printf("test_banded_strips [%s] %lld strips of %d x %d, overlap %d: %s\n", name, (long long)N, BR, BC, BO, fails ? "Failed." : "Passed.");
+    return fails;
+}
+
 template <typename Solver, typename LeftMat, typename RightMat>
 static int test_block_angular_as(const LeftMat& leftForSolver, const SparseMatrixColMajor& leftSparse, const Matrix& right,
                                  const RightMat& rightForSolver, const char* name);
@@ -284,6 +354,10 @@ int main() {
         fails += test_banded_blocked(spJ, "overlapping");
         generate_banded(numParams, numResiduals, true, 5, spJ);
         fails += test_banded_blocked(spJ, "overlapping, rows shuffled");
+    }
+    {   // the strips form behind the facade: few strips (one-level chains), 70 strips (two levels)
+        fails += test_banded_strips<64, 48, 32>(9, "one level");
+        fails += test_banded_strips<64, 48, 32>(70, "two levels");
     }
     {   // :386-395 at a quarter of the reference's size (numVars = 1024, 384 angular parameters there)
         const Index numVars = 256, numParams = numVars * 2, numResiduals = numVars * 3 + numVars + numVars * 3, numAngular = 96;

@@ -206,6 +206,11 @@ def test_carry_maps_agree_with_the_one_workgroup_chains(N, ms, n, s):
         try:
             for sw in ("0", "1"):
                 os.environ["QRK_BBS_MAPS"] = sw
+                # (the scratch and the result of a call come out of torch's caching allocator: make them NaN, not the other form's
+                #  answer -- an entry one form fails to write must not be masked by what the other left in the same block)
+                torch.cuda.synchronize(); torch.cuda.empty_cache()
+                junk = torch.full((1 << 22,), float("nan"), dtype=torch.float64, device="cuda")
+                del junk
                 out.append(fn().cpu().numpy())
         finally:
             if old is None:

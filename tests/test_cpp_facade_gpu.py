@@ -25,7 +25,7 @@ def test_cpp_facade_compositions():
     out = subprocess.run([os.path.join(ROOT, "build", "test_compositions")], capture_output=True, text=True, timeout=600)
     print(out.stdout, out.stderr)
     assert out.returncode == 0, out.stdout + out.stderr
-    assert "Failed." not in out.stdout and out.stdout.count("Passed.") == 14
+    assert "Failed." not in out.stdout and out.stdout.count("Passed.") == 16
 
 
 @pytest.mark.gpu
