@@ -196,6 +196,9 @@ __device__ __forceinline__ double bb_wave_sum_dpp(double v)
 }
 
 typedef double bb_d4 __attribute__((ext_vector_type(4)));
+#ifndef QRK_BB_PMAX
+#define QRK_BB_PMAX 8    // most row parts a strip of the block update is split into (each part costs a barrier when the partial sums meet)
+#endif
 #ifndef QRK_BB_ABL
 #define QRK_BB_ABL 0      // timing experiments only (wrong results): 1 = no MFMA in the block update, 2 = no W loads, 4 = no W stores
 #endif
@@ -392,7 +395,13 @@ __device__ __attribute__((noinline)) void bb_panel_qr(double* __restrict__ W, co
                 };
                 if (CPW == 1 || (j >> 4) == 0) head(col[0]); else head(col[CPW - 1]);
             }
+#ifdef QRK_BB_PROF
+            const unsigned long long tw0 = __builtin_amdgcn_s_memtime();
+#endif
             __syncthreads();
+#ifdef QRK_BB_PROF
+            if (wv != (j & 15)) qt[11] += __builtin_amdgcn_s_memtime() - tw0;      // a non-owner's wait for the head of the step
+#endif
             const double s2 = scj[0], ng = scj[1];
             bool any = false;
 #pragma unroll
@@ -435,8 +444,9 @@ __device__ __attribute__((noinline)) void bb_panel_qr(double* __restrict__ W, co
             if (l < ob) W[(int64_t)(jb + i) * n + jb + l] = blk[l * ld + i];
         }
         const int c_first = jb + OB, nt = n - c_first;     // columns to the right
-        if (nt <= 0) { __syncthreads(); if (pipe) bb_pipe_publish(pipe->my_done, jb + ob); BB_QTICK(2); continue; }
+        if (nt <= 0) { __syncthreads(); if (pipe) bb_pipe_publish(pipe->my_done, jb + ob); BB_QTICK(8); continue; }
         __syncthreads();
+        BB_QTICK(8);
         // 4. V = unit-lower view of the block (in place); T of the block in the recursive form (as for the panel's T
         //    below)
         for (int e = tid; e < OB * OB; e += BC_THREADS) {
@@ -444,6 +454,7 @@ __device__ __attribute__((noinline)) void bb_panel_qr(double* __restrict__ W, co
             if (i < mr) { if (i == l) blk[l * ld + i] = 1.0; else if (i < l) blk[l * ld + i] = 0.0; }
         }
         __syncthreads();
+        BB_QTICK(9);
         {   // G = V^T V above the diagonal (v_mfma_f64_16x16x4_f64, the rows split over the waves), into tb
             constexpr int NT = MT * (MT + 1) / 2, PG = OB == 32 ? 5 : 8;      // tiles of G, row parts: NT * PG <= 16 waves
             const int tile = wv % NT, part = wv / NT;
@@ -467,45 +478,46 @@ __device__ __attribute__((noinline)) void bb_panel_qr(double* __restrict__ W, co
                 double sum = 0.0;
                 for (int pp = 0; pp < PG; ++pp) sum += red[((t * PG + pp) * 4 + z) * 64 + l];
                 const int a = 16 * (t == 2 ? 1 : 0) + (l >> 4) + 4 * z, b = 16 * (t == 0 ? 0 : 1) + (l & 15);
-                if (a < b) tb[a * OB + b] = sum;
+                if (a < b) { tb[a * OB + b] = sum; tb[b * OB + a] = sum; }     // (the mirror: read below as rows without bank conflicts)
             }
         }
         __syncthreads();
-        if (wv < OB / 8) {          // diagonal 8 x 8 blocks by the column recurrence, one wave each
-            const int base = 8 * wv;
-            for (int j = 1; j < 8; ++j) {
-                const int c = base + j;
-                double sum = 0.0;
-                if (ln < j) { const int a = base + ln; for (int b = a; b < c; ++b) sum = fma(tb[a * OB + b], tb[b * OB + c], sum); }
-                const double tc = tb[c * OB + c];
-                __builtin_amdgcn_wave_barrier();
-                if (ln < j) tb[(base + ln) * OB + c] = -tc * sum;
-                __builtin_amdgcn_wave_barrier();
+        BB_QTICK(10);
+        {
+            // T = (diag(1 / tau) + strict upper part of G)^-1 by back substitution on e_c, a column at a time per wave (two per wave for
+            // OB = 32): lane i < OB keeps row i of G in registers (zero up to the diagonal) and y_i; step k (c .. 1): the wave reads
+            // x_k = y_k tau_k from lane k and y_i <- y_i - G(i, k) x_k (lanes i >= k hold a zero there and keep what they have); column c
+            // of T is y tau.  A reflector with tau = 0 drops out by itself.  Four instructions per step, c steps per column.
+            // (Round 5: the column recurrence on 8 x 8 diagonal blocks + two merge levels took 20 000 cycles per block -- ten barriers
+            //  and dependent loops over LDS; a first form of this one with two columns per wave side by side and every step run for
+            //  every column 13 000; this one see profiles/r05_banded_chain_T.txt.)
+            const bool rowact = ln < OB;
+            const int li = rowact ? ln : 0;
+            double srow[OB];                             // G(li, k), k > li, from the mirror below the diagonal: consecutive lanes, consecutive words
+#pragma unroll
+            for (int k = 0; k < OB; ++k) { const double gv = tb[k * OB + li]; srow[k] = (rowact && k > li) ? gv : 0.0; }
+            const double tau_own = rowact ? tb[li * OB + li] : 0.0;
+            __syncthreads();                             // every lane has its row of G before T overwrites it
+            for (int c = wv; c < OB; c += 16) {
+                double y = ln == c ? 1.0 : 0.0;
+#pragma unroll
+                for (int k = OB - 1; k >= 1; --k) {
+                    if (k <= c) {                        // (wave-uniform)
+                        const double xk = readlane_f64(y * tau_own, k);
+                        y = fma(-srow[k], xk, y);
+                    }
+                }
+                if (rowact) tb[li * OB + c] = y * tau_own;       // (zero below the diagonal: the mirror is gone with this)
             }
         }
         __syncthreads();
-        for (int sz = 8; sz < OB; sz *= 2) {       // T12 = -T11 G12 T22, pair by pair
-            const int ss = sz * sz, total = (OB / (2 * sz)) * ss;
-            const int q = tid / ss, rem = tid - q * ss, jj = rem / sz, ii = rem - jj * sz;
-            const int r0 = 2 * q * sz, c0 = r0 + sz;
-            double acc = 0.0;
-            if (tid < total) for (int k = 0; k <= jj; ++k) acc = fma(tb[(r0 + ii) * OB + c0 + k], tb[(c0 + k) * OB + c0 + jj], acc);
-            __syncthreads();
-            if (tid < total) tb[(r0 + ii) * OB + c0 + jj] = acc;
-            __syncthreads();
-            acc = 0.0;
-            if (tid < total) for (int k = ii; k < sz; ++k) acc = fma(tb[(r0 + ii) * OB + r0 + k], tb[(r0 + k) * OB + c0 + jj], acc);
-            __syncthreads();
-            if (tid < total) tb[(r0 + ii) * OB + c0 + jj] = -acc;
-            __syncthreads();
-        }
         BB_QTICK(2);
         // 5. W(jb:, c_first:) <- (I - V T^T V^T) W(jb:, c_first:): strips of 16 columns, the rows split over the waves
         //    that are left
         const int S_all = (nt + 15) >> 4;
         for (int g0 = 0; g0 < S_all; g0 += 8) {            // (at most 8 strips at a time: LDS for their partial sums)
             const int S = (S_all - g0) < 8 ? (S_all - g0) : 8;
-            int P = 16 / S; if (P > 8) P = 8;
+            int P = 16 / S; if (P > QRK_BB_PMAX) P = QRK_BB_PMAX;
             const bool act = wv < S * P;
             const int strip = act ? wv % S : 0, part = act ? wv / S : 0;
             const int colg = c_first + 16 * (g0 + strip) + (ln & 15);
@@ -673,7 +685,7 @@ bb_chain2_kernel(const BBPanel* __restrict__ panels, int num_panels, const int32
     static_assert(sizeof(BBPipe) <= 64, "BBPipe fits its LDS slot");
     const bool piped = done != nullptr;
 #ifdef QRK_BB_PROF
-    unsigned long long pt[6] = {0, 0, 0, 0, 0, 0}, t0 = 0, qt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long pt[6] = {0, 0, 0, 0, 0, 0}, t0 = 0, qt[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #define BB_TICK(n) do { const unsigned long long t1 = __builtin_amdgcn_s_memtime(); pt[n] += t1 - t0; t0 = t1; } while (0)
 #else
 #define BB_TICK(n) do { } while (0)
@@ -780,7 +792,7 @@ bb_chain2_kernel(const BBPanel* __restrict__ panels, int num_panels, const int32
         if (pi == num_panels - 1 && tid == 0) {
             double* T = t_vals + p.t_off;
             for (int z = 0; z < 6; ++z) T[z] = (double)pt[z];
-            for (int z = 0; z < 8; ++z) T[6 + z] = (double)qt[z];
+            for (int z = 0; z < 12; ++z) T[6 + z] = (double)qt[z];
         }
 #endif
     }
