@@ -1939,6 +1939,7 @@ static bool bbs_maps(qrk_bbs_plan p, int64_t nrhs)
     qrk_handle h = p->h;
     auto give_up = [&]() { (void)hipGetLastError(); p->maps_off = true; return false; };
     const size_t l2 = (size_t)p->lo * p->lo * sizeof(double);
+    if (std::getenv("QRK_BBS_MAPS_FAIL")) return give_up();      // (tests: an allocation of the maps that fails -- the plan stays on the old chains)
     if (!p->d_cmap) {
         int64_t cl = 0, al = 0;
         int K = 0;

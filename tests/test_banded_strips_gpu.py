@@ -239,3 +239,37 @@ def test_carry_maps_agree_with_the_one_workgroup_chains(N, ms, n, s):
             if J is not None:
                 ref = np.linalg.lstsq(J, b.cpu().numpy(), rcond=None)[0]
                 assert rel_fro(x1, ref) <= 1e-9
+
+
+@pytest.mark.gpu
+def test_maps_that_cannot_be_allocated_leave_the_old_chains_in_charge():
+    """bbs_maps() gives the per-strip maps up for good when their memory is not there (13 GB at the full configs[2] size) and the plan keeps
+    answering through the one-workgroup chains: QRK_BBS_MAPS_FAIL forces that branch on the first product; the answers stay right, with
+    the switch removed as well (maps_off is a property of the plan), and a fresh plan goes through the maps again."""
+    import torch
+    import qrkit_amd
+    from qrkit_amd.banded import BandedStripsQR
+    N, ms, n, s = 70, 64, 48, 16
+    strips = make(N, ms, n, s, seed=5)
+    J = assemble(strips, N, ms, n, s)
+    b = np.random.default_rng(0).uniform(-1, 1, J.shape[0])
+    ref = np.linalg.lstsq(J, b, rcond=None)[0]
+    old = os.environ.get("QRK_BBS_MAPS_FAIL")
+    qr = BandedStripsQR(N, ms, n, s, context=qrkit_amd.Context(0))
+    qr.factorize(to_device(strips))
+    try:
+        os.environ["QRK_BBS_MAPS_FAIL"] = "1"
+        x1 = qr.solve(torch.from_numpy(b).cuda()).cpu().numpy()
+    finally:
+        if old is None:
+            os.environ.pop("QRK_BBS_MAPS_FAIL", None)
+        else:
+            os.environ["QRK_BBS_MAPS_FAIL"] = old
+    x2 = qr.solve(torch.from_numpy(b).cuda()).cpu().numpy()
+    assert rel_fro(x1, ref) <= 1e-9 and rel_fro(x2, ref) <= 1e-9
+    assert np.array_equal(x1, x2)                       # the same kernels both times: the plan gave the maps up
+    qr2 = BandedStripsQR(N, ms, n, s, context=qrkit_amd.Context(0))
+    qr2.factorize(to_device(strips))
+    x3 = qr2.solve(torch.from_numpy(b).cuda()).cpu().numpy()
+    assert rel_fro(x3, ref) <= 1e-9 and rel_fro(x3, x1) <= 1e-10
+    assert not np.array_equal(x3, x1)                   # (the maps associate the products differently: equal to rounding, not bitwise)
