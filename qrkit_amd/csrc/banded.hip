@@ -196,6 +196,9 @@ __device__ __forceinline__ double bb_wave_sum_dpp(double v)
 }
 
 typedef double bb_d4 __attribute__((ext_vector_type(4)));
+#ifndef QRK_BB_PIPE_OB16
+#define QRK_BB_PIPE_OB16 1    // blocks of 16 columns in the pipelined strips chain (0: 32 as in round 4, for A/B builds)
+#endif
 #ifndef QRK_BB_PMAX
 #define QRK_BB_PMAX 8    // most row parts a strip of the block update is split into (each part costs a barrier when the partial sums meet)
 #endif
@@ -736,6 +739,20 @@ bb_chain2_kernel(const BBPanel* __restrict__ panels, int num_panels, const int32
                 tall = (lim - jb) > tall ? (lim - jb) : tall;
             }
         }
+#if QRK_BB_PIPE_OB16
+        // The pipelined chain works in blocks of 16 columns (round 5): a panel publishes its final rows block by block and the next panel's
+        // block b waits for the rows of column step + 16 (b + 1) columns, so the grain of the blocks is the grain of the overlap -- with
+        // 32-column blocks a panel starts when the one before has done 96 of its 192 columns, with 16-column blocks after 80:
+        // 0.1654 -> 0.1336 ms per strip at the BASELINE configs[2] shape although a panel ALONE is slower in blocks of 16 (twice the
+        // block updates).  One workgroup alone (no partner to wait for) keeps the 32-column blocks.
+        if (pipe) {
+#ifdef QRK_BB_PROF
+            if (tall <= 192) bb_panel_qr<16, 3>(W, m, n, rlim, pipe, qt); else if (tall <= 256) bb_panel_qr<16, 4>(W, m, n, rlim, pipe, qt); else bb_panel_qr<16>(W, m, n, rlim, pipe, qt);
+#else
+            if (tall <= 192) bb_panel_qr<16, 3>(W, m, n, rlim, pipe); else if (tall <= 256) bb_panel_qr<16, 4>(W, m, n, rlim, pipe); else bb_panel_qr<16>(W, m, n, rlim, pipe);
+#endif
+        } else
+#endif
         if ((int64_t)32 * (m | 1) + bb_qr_aux_doubles(32) <= (int64_t)uni_doubles) {
 #ifdef QRK_BB_PROF
             if (tall <= 192) bb_panel_qr<32, 3>(W, m, n, rlim, pipe, qt); else if (tall <= 256) bb_panel_qr<32, 4>(W, m, n, rlim, pipe, qt); else bb_panel_qr<32>(W, m, n, rlim, pipe, qt);
