@@ -17,6 +17,7 @@
 
 #include <float.h>
 #include <cstdlib>
+#include <type_traits>
 
 namespace qrk {
 
@@ -369,6 +370,10 @@ __device__ __attribute__((noinline)) void bb_panel_qr(double* __restrict__ W, co
         BB_QTICK(0);
         // 2. the reflectors of the block.  Local row j is the pivot row of reflector j: lane j of the first row register.
         //    Rows beyond mr hold zeros in col[] and in the published vectors, so only that register needs a mask.
+        //    The loop is instantiated for the row registers the BLOCK reaches (64 rows each): the first blocks of a staircase panel are short
+        //    (32 .. 96 rows in the strips form) and they are the ones the next panel of the pipelined chain waits for.
+        auto reflectors = [&](auto nrb_tag) {
+        constexpr int NRB = decltype(nrb_tag)::value;
         for (int j = 0; j < ob; ++j) {
             double* vj = vcol + (j & 1) * VL;
             double* scj = sc + (j & 1) * 4;
@@ -377,7 +382,7 @@ __device__ __attribute__((noinline)) void bb_panel_qr(double* __restrict__ W, co
                 auto head = [&](double (&x)[NR]) {
                     double part = ln > j ? x[0] * x[0] : 0.0;
 #pragma unroll
-                    for (int r = 1; r < NR; ++r) part = fma(x[r], x[r], part);
+                    for (int r = 1; r < NRB; ++r) part = fma(x[r], x[r], part);
                     const double tsq = bb_wave_sum_dpp(part);
                     const double xk = readlane_f64(x[0], j);
                     double nb_, s2, ng, tau, inv_s;
@@ -394,7 +399,7 @@ __device__ __attribute__((noinline)) void bb_panel_qr(double* __restrict__ W, co
                     if (ln > j) vj[ln] = x[0];
                     x[0] = ln > j ? x[0] * inv_s : (ln == j ? -nb_ : x[0]);      // essential part (:471-475), beta
 #pragma unroll
-                    for (int r = 1; r < NR; ++r) { vj[r * 64 + ln] = x[r]; x[r] *= inv_s; }
+                    for (int r = 1; r < NRB; ++r) { vj[r * 64 + ln] = x[r]; x[r] *= inv_s; }
                 };
                 if (CPW == 1 || (j >> 4) == 0) head(col[0]); else head(col[CPW - 1]);
             }
@@ -413,25 +418,29 @@ __device__ __attribute__((noinline)) void bb_panel_qr(double* __restrict__ W, co
                 double v[NR];
                 v[0] = ln > j ? vj[ln] : 0.0;
 #pragma unroll
-                for (int r = 1; r < NR; ++r) v[r] = vj[r * 64 + ln];
+                for (int r = 1; r < NRB; ++r) v[r] = vj[r * 64 + ln];
 #pragma unroll
                 for (int s = 0; s < CPW; ++s) {
                     const int c = wv + 16 * s;
                     if (c > j && c < ob) {
                         double part = 0.0;
 #pragma unroll
-                        for (int r = 0; r < NR; ++r) part = fma(v[r], col[s][r], part);
+                        for (int r = 0; r < NRB; ++r) part = fma(v[r], col[s][r], part);
                         const double d = bb_wave_sum_dpp(part);
                         const double ak = readlane_f64(col[s][0], j);
                         const double ngam = fma(s2, ak, d) * ng;
                         const double rjv = fma(s2, ngam, ak);              // row j of R
                         col[s][0] = ln == j ? rjv : fma(ngam, v[0], col[s][0]);
 #pragma unroll
-                        for (int r = 1; r < NR; ++r) col[s][r] = fma(ngam, v[r], col[s][r]);
+                        for (int r = 1; r < NRB; ++r) col[s][r] = fma(ngam, v[r], col[s][r]);
                     }
                 }
             }
         }
+        };
+        if (NR >= 3 && mr <= 64) reflectors(std::integral_constant<int, 1>());
+        else if (NR >= 3 && mr <= 128) reflectors(std::integral_constant<int, 2>());
+        else reflectors(std::integral_constant<int, NR>());
         BB_QTICK(1);
         // 3. packed block back to LDS and to the panel
         __syncthreads();
@@ -442,21 +451,18 @@ __device__ __attribute__((noinline)) void bb_panel_qr(double* __restrict__ W, co
             for (int r = 0; r < NR; ++r) { const int i = r * 64 + ln; if (i < mr && c < ob) blk[c * ld + i] = col[s][r]; }
         }
         __syncthreads();
+        // (the same pass leaves V = the unit-lower view of the block in LDS for step 4: an entry is read, stored and masked by one thread)
         for (int e = tid; e < mr * OB; e += BC_THREADS) {
             const int i = e / OB, l = e - i * OB;
-            if (l < ob) W[(int64_t)(jb + i) * n + jb + l] = blk[l * ld + i];
+            const double bv = blk[l * ld + i];
+            if (l < ob) W[(int64_t)(jb + i) * n + jb + l] = bv;
+            if (i == l) blk[l * ld + i] = 1.0; else if (i < l) blk[l * ld + i] = 0.0;
         }
         const int c_first = jb + OB, nt = n - c_first;     // columns to the right
         if (nt <= 0) { __syncthreads(); if (pipe) bb_pipe_publish(pipe->my_done, jb + ob); BB_QTICK(8); continue; }
         __syncthreads();
         BB_QTICK(8);
-        // 4. V = unit-lower view of the block (in place); T of the block in the recursive form (as for the panel's T
-        //    below)
-        for (int e = tid; e < OB * OB; e += BC_THREADS) {
-            const int i = e / OB, l = e - i * OB;
-            if (i < mr) { if (i == l) blk[l * ld + i] = 1.0; else if (i < l) blk[l * ld + i] = 0.0; }
-        }
-        __syncthreads();
+        // 4. T of the block from V (unit-lower, in LDS since the pass above)
         BB_QTICK(9);
         {   // G = V^T V above the diagonal (v_mfma_f64_16x16x4_f64, the rows split over the waves), into tb
             constexpr int NT = MT * (MT + 1) / 2, PG = OB == 32 ? 5 : 8;      // tiles of G, row parts: NT * PG <= 16 waves
