@@ -340,7 +340,13 @@ __device__ __attribute__((noinline)) void bb_panel_qr(double* __restrict__ W, co
             int need = (mtop + pipe->lo_stride - 1) / pipe->lo_stride;
             if (need > pipe->lo_rows) need = pipe->lo_rows;
             if (need > pipe->copied) {
+#ifdef QRK_BB_PROF
+                const unsigned long long tq0 = __builtin_amdgcn_s_memtime();
+#endif
                 if (!bb_pipe_wait(pipe, pipe->prev_done, pipe->lo_from + need)) return;       // (uniform: the chain is given up)
+#ifdef QRK_BB_PROF
+                qt[13] += __builtin_amdgcn_s_memtime() - tq0;
+#endif
                 const int c0 = pipe->copied, lc = pipe->lo_cols;
                 for (int e = tid; e < (need - c0) * lc; e += BC_THREADS) {
                     const int i = c0 + e / lc, j = e % lc;
@@ -627,7 +633,11 @@ __device__ __attribute__((noinline)) void bb_panel_qr(double* __restrict__ W, co
             __syncthreads();
             BB_QTICK(3);
         }
+#ifdef QRK_BB_PROF
+        { const unsigned long long tp0 = __builtin_amdgcn_s_memtime(); if (pipe) bb_pipe_publish(pipe->my_done, jb + ob); qt[12] += __builtin_amdgcn_s_memtime() - tp0; q0 = __builtin_amdgcn_s_memtime(); }
+#else
         if (pipe) bb_pipe_publish(pipe->my_done, jb + ob);
+#endif
     }
 #undef BB_QTICK
 }
@@ -694,7 +704,7 @@ bb_chain2_kernel(const BBPanel* __restrict__ panels, int num_panels, const int32
     static_assert(sizeof(BBPipe) <= 64, "BBPipe fits its LDS slot");
     const bool piped = done != nullptr;
 #ifdef QRK_BB_PROF
-    unsigned long long pt[6] = {0, 0, 0, 0, 0, 0}, t0 = 0, qt[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long pt[6] = {0, 0, 0, 0, 0, 0}, t0 = 0, qt[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #define BB_TICK(n) do { const unsigned long long t1 = __builtin_amdgcn_s_memtime(); pt[n] += t1 - t0; t0 = t1; } while (0)
 #else
 #define BB_TICK(n) do { } while (0)
@@ -815,7 +825,7 @@ bb_chain2_kernel(const BBPanel* __restrict__ panels, int num_panels, const int32
         if (pi == num_panels - 1 && tid == 0) {
             double* T = t_vals + p.t_off;
             for (int z = 0; z < 6; ++z) T[z] = (double)pt[z];
-            for (int z = 0; z < 12; ++z) T[6 + z] = (double)qt[z];
+            for (int z = 0; z < 14; ++z) T[6 + z] = (double)qt[z];
         }
 #endif
     }

@@ -1908,12 +1908,12 @@ qrk_status qrk_bbs_factorize(qrk_bbs_plan p, const double* strips)
     p->factorized = true;
     if (std::getenv("QRK_BBS_PROF_DUMP")) {
         // diagnostic builds of banded.hip (-DQRK_BB_PROF) leave the chain's tick counts in the T of the last panel
-        double t[18];
+        double t[20];
         QRK_HIP(h, hipStreamSynchronize(h->stream));
         QRK_HIP(h, hipMemcpy(t, p->d_t + p->panels.back().t_off, sizeof(t), hipMemcpyDeviceToHost));
         std::fprintf(stderr, "bb_chain2 ticks: carry-in %.0f  panel QR %.0f  R rows + carry out %.0f  hc %.0f | block->regs %.0f  reflectors %.0f  T recurrences %.0f  "
-                             "update %.0f (V^T W %.0f  partial sums %.0f  T^T w %.0f  W -= V u %.0f) | block store %.0f  unit-lower V %.0f  Gram %.0f | of the reflectors: thread 0 waiting at the barrier as a non-owner %.0f\n",
-                     t[0], t[1], t[2], t[3], t[6], t[7], t[8], t[9], t[10], t[11], t[12], t[13], t[14], t[15], t[16], t[17]);
+                             "update %.0f (V^T W %.0f  partial sums %.0f  T^T w %.0f  W -= V u %.0f) | block store %.0f  unit-lower V %.0f  Gram %.0f | of the reflectors: thread 0 waiting at the barrier as a non-owner %.0f | pipeline: publishing rows-final %.0f  waiting for the panel before %.0f\n",
+                     t[0], t[1], t[2], t[3], t[6], t[7], t[8], t[9], t[10], t[11], t[12], t[13], t[14], t[15], t[16], t[17], t[18], t[19]);
     }
     return QRK_STATUS_OK;
 }
