@@ -238,11 +238,14 @@ __device__ __forceinline__ double bb_recip(double x)
 // for block b + 2 of the one before: two panels are in flight at any time.
 struct BBPipe {
     const double* prev;        // storage of the previous panel (row-major, prev_n columns), or null for the first panel
-    const int* prev_done;      // its rows-final word
+    const int* prev_done;      // its rows-final word: rows below this are final in EVERY column (published after a block's update)
     int* my_done;              // this panel's
+    const int* prev_own;       // its second word: rows below this are final in the columns below it (published after a block's own
+    int* my_own;               //   reflectors, before the block's update of the columns to the right); this panel's
     int* abortw;               // the chain's abort word (done[num_panels]): set by the workgroup whose wait ran out, seen by every waiter
     int prev_n, lo_from, lo_rows, lo_cols, lo_stride;
-    int copied;                // carry rows already taken over
+    int copied;                // carry rows already taken over in full
+    int copied_own;            // carry rows whose entries up to the current block's last column have been taken over
     unsigned spin_limit;       // polls of a rows-final word before the chain is given up
     int aborted;               // this workgroup leaves (its own wait ran out, or a partner's did)
 };
@@ -270,12 +273,13 @@ __device__ __forceinline__ bool bb_pipe_wait(BBPipe* pipe, const int* word, int 
     __syncthreads();
     return pipe->aborted == 0;
 }
-__device__ __forceinline__ void bb_pipe_publish(int* word, int rows_done)
+__device__ __forceinline__ void bb_pipe_publish(int* word, int rows_done, int* word2 = nullptr)
 {
     __syncthreads();           // every thread's stores of the block have been issued and waited for (the barrier's release)
     if (threadIdx.x == 0) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         __hip_atomic_store(word, rows_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (word2) __hip_atomic_store(word2, rows_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -335,26 +339,32 @@ __device__ __attribute__((noinline)) void bb_panel_qr(double* __restrict__ W, co
         int mtop = m;
         if (rlim) { const int lim = rlim[(jb + ob - 1) >> 4]; mtop = lim < m ? lim : m; }
         const int mr = mtop - jb;              // rows jb.. of the panel take part (local row i = panel row jb + i)
-        // 0. (pipelined chain) the carry rows this block reaches, as soon as the previous panel has finalised them
+        // 0. (pipelined chain) the carry rows this block reaches, in TWO steps (round 5): their entries in the columns up to this block's
+        //    last one as soon as the previous panel has run the reflectors of the block that holds them (its "own" word: those entries
+        //    are final then, the previous panel's update of its columns to the right does not touch them) -- enough for this block's
+        //    reflectors --, the entries to the right before this block's own update (step 5), when the previous panel's update is done.
+        //    The block's reflectors so run beside the previous panel's block update instead of behind it.
+        int pipe_need = 0;
         if (pipe && pipe->prev && pipe->copied < pipe->lo_rows) {
             int need = (mtop + pipe->lo_stride - 1) / pipe->lo_stride;
             if (need > pipe->lo_rows) need = pipe->lo_rows;
-            if (need > pipe->copied) {
+            pipe_need = need;
+            if (need > pipe->copied_own) {
 #ifdef QRK_BB_PROF
                 const unsigned long long tq0 = __builtin_amdgcn_s_memtime();
 #endif
-                if (!bb_pipe_wait(pipe, pipe->prev_done, pipe->lo_from + need)) return;       // (uniform: the chain is given up)
+                if (!bb_pipe_wait(pipe, pipe->prev_own, pipe->lo_from + need)) return;       // (uniform: the chain is given up)
 #ifdef QRK_BB_PROF
                 qt[13] += __builtin_amdgcn_s_memtime() - tq0;
 #endif
-                const int c0 = pipe->copied, lc = pipe->lo_cols;
-                for (int e = tid; e < (need - c0) * lc; e += BC_THREADS) {
-                    const int i = c0 + e / lc, j = e % lc;
+                const int c0 = pipe->copied_own, lc = pipe->lo_cols, ce = (jb + ob) < lc ? (jb + ob) : lc;
+                for (int e = tid; e < (need - c0) * ce; e += BC_THREADS) {
+                    const int i = c0 + e / ce, j = e % ce;
                     W[(int64_t)(i * pipe->lo_stride) * n + j] =
                         i <= j ? pipe->prev[(int64_t)(pipe->lo_from + i) * pipe->prev_n + pipe->lo_from + j] : 0.0;
                 }
                 __syncthreads();
-                if (tid == 0) pipe->copied = need;
+                if (tid == 0) pipe->copied_own = need;
                 __syncthreads();
             }
         }
@@ -465,8 +475,9 @@ __device__ __attribute__((noinline)) void bb_panel_qr(double* __restrict__ W, co
             if (i == l) blk[l * ld + i] = 1.0; else if (i < l) blk[l * ld + i] = 0.0;
         }
         const int c_first = jb + OB, nt = n - c_first;     // columns to the right
-        if (nt <= 0) { __syncthreads(); if (pipe) bb_pipe_publish(pipe->my_done, jb + ob); BB_QTICK(8); continue; }
-        __syncthreads();
+        if (nt <= 0) { __syncthreads(); if (pipe) bb_pipe_publish(pipe->my_done, jb + ob, pipe->my_own); BB_QTICK(8); continue; }
+        if (pipe) bb_pipe_publish(pipe->my_own, jb + ob);      // (begins with the barrier this point needs anyway)
+        else __syncthreads();
         BB_QTICK(8);
         // 4. T of the block from V (unit-lower, in LDS since the pass above)
         BB_QTICK(9);
@@ -529,6 +540,28 @@ __device__ __attribute__((noinline)) void bb_panel_qr(double* __restrict__ W, co
         BB_QTICK(2);
         // 5. W(jb:, c_first:) <- (I - V T^T V^T) W(jb:, c_first:): strips of 16 columns, the rows split over the waves
         //    that are left
+        if (pipe && pipe->prev && pipe_need > pipe->copied) {
+            // the rest of the carry rows of step 0: their entries right of this block, final once the previous panel's update is
+#ifdef QRK_BB_PROF
+            const unsigned long long tq0 = __builtin_amdgcn_s_memtime();
+#endif
+            if (!bb_pipe_wait(pipe, pipe->prev_done, pipe->lo_from + pipe_need)) return;
+#ifdef QRK_BB_PROF
+            qt[13] += __builtin_amdgcn_s_memtime() - tq0;
+#endif
+            const int c0 = pipe->copied, lc = pipe->lo_cols, cb = jb + ob;
+            if (cb < lc) {
+                const int wd = lc - cb;
+                for (int e = tid; e < (pipe_need - c0) * wd; e += BC_THREADS) {
+                    const int i = c0 + e / wd, j = cb + e % wd;
+                    W[(int64_t)(i * pipe->lo_stride) * n + j] =
+                        i <= j ? pipe->prev[(int64_t)(pipe->lo_from + i) * pipe->prev_n + pipe->lo_from + j] : 0.0;
+                }
+            }
+            __syncthreads();
+            if (tid == 0) pipe->copied = pipe_need;
+            __syncthreads();
+        }
         const int S_all = (nt + 15) >> 4;
         for (int g0 = 0; g0 < S_all; g0 += 8) {            // (at most 8 strips at a time: LDS for their partial sums)
             const int S = (S_all - g0) < 8 ? (S_all - g0) : 8;
@@ -634,9 +667,9 @@ __device__ __attribute__((noinline)) void bb_panel_qr(double* __restrict__ W, co
             BB_QTICK(3);
         }
 #ifdef QRK_BB_PROF
-        { const unsigned long long tp0 = __builtin_amdgcn_s_memtime(); if (pipe) bb_pipe_publish(pipe->my_done, jb + ob); qt[12] += __builtin_amdgcn_s_memtime() - tp0; q0 = __builtin_amdgcn_s_memtime(); }
+        { const unsigned long long tp0 = __builtin_amdgcn_s_memtime(); if (pipe) bb_pipe_publish(pipe->my_done, jb + ob, pipe->my_own); qt[12] += __builtin_amdgcn_s_memtime() - tp0; q0 = __builtin_amdgcn_s_memtime(); }
 #else
-        if (pipe) bb_pipe_publish(pipe->my_done, jb + ob);
+        if (pipe) bb_pipe_publish(pipe->my_done, jb + ob, pipe->my_own);
 #endif
     }
 #undef BB_QTICK
@@ -699,9 +732,9 @@ bb_chain2_kernel(const BBPanel* __restrict__ panels, int num_panels, const int32
     double* uni = sc + 8;                      // the blocked QR's (bb_panel_qr); a tile of R rows on the way out
     const int tid = threadIdx.x;
     // done != null: the pipelined chain (see BBPipe): this workgroup takes the panels blockIdx.x, blockIdx.x + gridDim.x, ..
-    // (its record lives in the last 64 bytes of the dynamic LDS: the kernel already asks for all 160 KB)
+    // (its record lives in the last 96 bytes of the dynamic LDS: the kernel already asks for all 160 KB)
     BBPipe& s_pipe = *reinterpret_cast<BBPipe*>(uni + uni_doubles);
-    static_assert(sizeof(BBPipe) <= 64, "BBPipe fits its LDS slot");
+    static_assert(sizeof(BBPipe) <= 96, "BBPipe fits its LDS slot (bb_chain2_smem)");
     const bool piped = done != nullptr;
 #ifdef QRK_BB_PROF
     unsigned long long pt[6] = {0, 0, 0, 0, 0, 0}, t0 = 0, qt[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -731,12 +764,14 @@ bb_chain2_kernel(const BBPanel* __restrict__ panels, int num_panels, const int32
             s_pipe.prev = has ? y_vals + panels[pi - 1].y_off : nullptr;
             s_pipe.prev_done = has ? done + pi - 1 : nullptr;
             s_pipe.my_done = done + pi;
+            s_pipe.prev_own = has ? done + num_panels + 1 + pi - 1 : nullptr;
+            s_pipe.my_own = done + num_panels + 1 + pi;
             s_pipe.abortw = done + num_panels;
             s_pipe.spin_limit = spin_limit;
             if (pi == (int)blockIdx.x) s_pipe.aborted = 0;
             s_pipe.prev_n = has ? panels[pi - 1].ncols : 0;
             s_pipe.lo_from = p.lo_from; s_pipe.lo_rows = p.lo_rows; s_pipe.lo_cols = p.lo_cols; s_pipe.lo_stride = p.lo_stride;
-            s_pipe.copied = 0;
+            s_pipe.copied = 0; s_pipe.copied_own = 0;
         }
         __syncthreads();
         const int* rlim = pi == 0 ? rlim_first : rlim_rest;
@@ -1039,7 +1074,7 @@ bb_t_kernel(const BBPanel* __restrict__ panels, int num_panels, const double* __
 size_t bb_chain2_smem(int max_act_rows, int* uni_doubles)
 {
     const size_t all = (size_t)160 * 1024;
-    const size_t fixed = (size_t)(BC_CW + 8 + 8) * sizeof(double);       // hc, sc, and (at the end) the BBPipe record
+    const size_t fixed = (size_t)(BC_CW + 8 + 12) * sizeof(double);      // hc, sc, and (at the end) the BBPipe record (96 bytes)
     const size_t qr = ((size_t)16 * (max_act_rows | 1) + bb_qr_aux_doubles(16)) * sizeof(double);
     *uni_doubles = 0;
     if (fixed + qr > all || max_act_rows > 1024) return 0;      // (bb_panel_qr<16> keeps 16 x 64 rows of a column per wave)
@@ -1411,7 +1446,8 @@ bbs_scatter_kernel(const BBPanel* __restrict__ panels, const double* __restrict_
     }
 }
 
-// done: num_panels + 1 ints (the rows-final words of the pipelined chain and its abort word; zeroed here), or null: one workgroup
+// done: 2 num_panels + 2 ints (the rows-final words of the pipelined chain, its abort word at [num_panels], the second word of every
+// panel from [num_panels + 1] on; zeroed here), or null: one workgroup
 // walks the strips.  single != 0: one workgroup whatever QRK_BBS_PIPE says (the caller's second run after an aborted chain).
 // *piped_out: the chain ran on more than one workgroup -- the caller must read done[num_panels] once the stream has drained.
 hipError_t launch_bbs_chain(const BBPanel* panels, int num_panels, const double* r_packed, int64_t r_stride, int n, int lo,
@@ -1434,7 +1470,7 @@ hipError_t launch_bbs_chain(const BBPanel* panels, int num_panels, const double*
     // QRK_BBS_PIPE_SPINS=0 makes the first unsatisfied wait abort -- the test of the fall-back)
     unsigned spin_limit = 1u << 21;
     if (const char* e3 = std::getenv("QRK_BBS_PIPE_SPINS")) spin_limit = (unsigned)std::strtoul(e3, nullptr, 10);
-    if (G > 1) { e = hipMemsetAsync(done, 0, (size_t)(num_panels + 1) * sizeof(int), stream); if (e != hipSuccess) return e; }
+    if (G > 1) { e = hipMemsetAsync(done, 0, (size_t)(2 * num_panels + 2) * sizeof(int), stream); if (e != hipSuccess) return e; }
     if (piped_out) *piped_out = G > 1;
     hipLaunchKernelGGL(bb_chain2_kernel, dim3((unsigned)G), dim3(BC_THREADS), smem2, stream, panels, num_panels, (const int32_t*)nullptr,
                        (const int32_t*)nullptr, (const int64_t*)nullptr, (const double*)nullptr, lo_buf, y_vals, t_vals, r_stage,

@@ -138,7 +138,7 @@ struct qrk_bbs_plan_s {
     std::vector<qrk::BBPanel> panels;
     qrk::BBPanel* d_panels = nullptr;
     int32_t* d_rlim = nullptr;          // [2][n / 16]: staircase row limits of panel 0 / of the other panels
-    int32_t* d_done = nullptr;          // [N + 1] rows-final words of the pipelined chain and its abort word (banded.hip, BBPipe)
+    int32_t* d_done = nullptr;          // [2 N + 2] rows-final words of the pipelined chain, its abort word at [N], the panels' second words (banded.hip, BBPipe)
     int64_t chain_reruns = 0;           // factorisations whose pipelined chain was given up and run again on one workgroup
     double *d_q = nullptr, *d_ra = nullptr;     // stage A: explicit Q_i (ms x ms each), packed R_i
     int32_t* d_perm = nullptr;
@@ -1846,7 +1846,7 @@ qrk_status qrk_bbs_plan_create(qrk_handle h, int64_t num_strips, int32_t strip_r
         hipMalloc((void**)&p->d_t, (size_t)p->t_len * sizeof(double)) != hipSuccess ||
         hipMalloc((void**)&p->d_stage, (size_t)p->stage_len * sizeof(double)) != hipSuccess ||
         hipMalloc((void**)&p->d_lo, (size_t)(lo > 0 ? lo * lo : 1) * sizeof(double)) != hipSuccess ||
-        hipMalloc((void**)&p->d_done, (size_t)(num_strips + 1) * sizeof(int32_t)) != hipSuccess) {
+        hipMalloc((void**)&p->d_done, (size_t)(2 * num_strips + 2) * sizeof(int32_t)) != hipSuccess) {
         qrk_bbs_plan_destroy(p);
         return fail(h, QRK_STATUS_ALLOC_FAILED, "qrk_bbs_plan_create: cannot allocate the factors (Q of stage A, panels and T of stage B)");
     }
