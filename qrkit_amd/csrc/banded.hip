@@ -200,6 +200,9 @@ typedef double bb_d4 __attribute__((ext_vector_type(4)));
 #ifndef QRK_BB_PIPE_OB16
 #define QRK_BB_PIPE_OB16 1    // blocks of 16 columns in the pipelined strips chain (0: 32 as in round 4, for A/B builds)
 #endif
+#ifndef QRK_BB_P1_ROWS
+#define QRK_BB_P1_ROWS 64    // blocks of at most this many rows: a wave per strip of the block update, all rows (no row parts); 64 / 80 / 96 / 112 / 128 measured
+#endif
 #ifndef QRK_BB_PMAX
 #define QRK_BB_PMAX 8    // most row parts a strip of the block update is split into (each part costs a barrier when the partial sums meet)
 #endif
@@ -563,9 +566,15 @@ __device__ __attribute__((noinline)) void bb_panel_qr(double* __restrict__ W, co
             __syncthreads();
         }
         const int S_all = (nt + 15) >> 4;
-        for (int g0 = 0; g0 < S_all; g0 += 8) {            // (at most 8 strips at a time: LDS for their partial sums)
-            const int S = (S_all - g0) < 8 ? (S_all - g0) : 8;
-            int P = 16 / S; if (P > QRK_BB_PMAX) P = QRK_BB_PMAX;
+        // A SHORT block (the first blocks of a staircase panel: 32 .. 96 rows, the ones the next panel of the pipelined chain waits for)
+        // gives every strip of 16 columns to one wave, all rows: up to 16 strips at once, no partial sums to meet in LDS, no barrier
+        // per row part.  Taller blocks split the rows of a strip over the waves that are left, at most 8 strips at a time (LDS for
+        // their partial sums).
+        const bool whole = mr <= QRK_BB_P1_ROWS;
+        const int GS = whole ? 16 : 8;
+        for (int g0 = 0; g0 < S_all; g0 += GS) {
+            const int S = (S_all - g0) < GS ? (S_all - g0) : GS;
+            int P = whole ? 1 : 16 / S; if (P > QRK_BB_PMAX) P = QRK_BB_PMAX;
             const bool act = wv < S * P;
             const int strip = act ? wv % S : 0, part = act ? wv / S : 0;
             const int colg = c_first + 16 * (g0 + strip) + (ln & 15);
