@@ -247,8 +247,6 @@ struct BBPipe {
     int* my_own;               //   reflectors, before the block's update of the columns to the right); this panel's
     int* abortw;               // the chain's abort word (done[num_panels]): set by the workgroup whose wait ran out, seen by every waiter
     int prev_n, lo_from, lo_rows, lo_cols, lo_stride;
-    int copied;                // carry rows already taken over in full
-    int copied_own;            // carry rows whose entries up to the current block's last column have been taken over
     unsigned spin_limit;       // polls of a rows-final word before the chain is given up
     int aborted;               // this workgroup leaves (its own wait ran out, or a partner's did)
 };
@@ -337,6 +335,7 @@ __device__ __attribute__((noinline)) void bb_panel_qr(double* __restrict__ W, co
 #define BB_QTICK(z) do { } while (0)
 #endif
 
+    int cp_own = 0, cp_full = 0;               // carry rows taken over: up to the current block's last column / in full (the same in every thread)
     for (int jb = 0; jb < n; jb += OB) {
         const int ob = (n - jb) < OB ? (n - jb) : OB;
         int mtop = m;
@@ -348,11 +347,11 @@ __device__ __attribute__((noinline)) void bb_panel_qr(double* __restrict__ W, co
         //    reflectors --, the entries to the right before this block's own update (step 5), when the previous panel's update is done.
         //    The block's reflectors so run beside the previous panel's block update instead of behind it.
         int pipe_need = 0;
-        if (pipe && pipe->prev && pipe->copied < pipe->lo_rows) {
+        if (pipe && pipe->prev && cp_full < pipe->lo_rows) {
             int need = (mtop + pipe->lo_stride - 1) / pipe->lo_stride;
             if (need > pipe->lo_rows) need = pipe->lo_rows;
             pipe_need = need;
-            if (need > pipe->copied_own) {
+            if (need > cp_own) {
 #ifdef QRK_BB_PROF
                 const unsigned long long tq0 = __builtin_amdgcn_s_memtime();
 #endif
@@ -360,15 +359,14 @@ __device__ __attribute__((noinline)) void bb_panel_qr(double* __restrict__ W, co
 #ifdef QRK_BB_PROF
                 qt[13] += __builtin_amdgcn_s_memtime() - tq0;
 #endif
-                const int c0 = pipe->copied_own, lc = pipe->lo_cols, ce = (jb + ob) < lc ? (jb + ob) : lc;
+                const int c0 = cp_own, lc = pipe->lo_cols, ce = (jb + ob) < lc ? (jb + ob) : lc;
                 for (int e = tid; e < (need - c0) * ce; e += BC_THREADS) {
                     const int i = c0 + e / ce, j = e % ce;
                     W[(int64_t)(i * pipe->lo_stride) * n + j] =
                         i <= j ? pipe->prev[(int64_t)(pipe->lo_from + i) * pipe->prev_n + pipe->lo_from + j] : 0.0;
                 }
-                __syncthreads();
-                if (tid == 0) pipe->copied_own = need;
-                __syncthreads();
+                __syncthreads();                 // (the copied entries before the block load reads them)
+                cp_own = need;                   // (every thread keeps the count itself)
             }
         }
         // 1. block to LDS (coalesced rows of W), then to the registers of the owning waves
@@ -543,7 +541,7 @@ __device__ __attribute__((noinline)) void bb_panel_qr(double* __restrict__ W, co
         BB_QTICK(2);
         // 5. W(jb:, c_first:) <- (I - V T^T V^T) W(jb:, c_first:): strips of 16 columns, the rows split over the waves
         //    that are left
-        if (pipe && pipe->prev && pipe_need > pipe->copied) {
+        if (pipe && pipe->prev && pipe_need > cp_full) {
             // the rest of the carry rows of step 0: their entries right of this block, final once the previous panel's update is
 #ifdef QRK_BB_PROF
             const unsigned long long tq0 = __builtin_amdgcn_s_memtime();
@@ -552,7 +550,7 @@ __device__ __attribute__((noinline)) void bb_panel_qr(double* __restrict__ W, co
 #ifdef QRK_BB_PROF
             qt[13] += __builtin_amdgcn_s_memtime() - tq0;
 #endif
-            const int c0 = pipe->copied, lc = pipe->lo_cols, cb = jb + ob;
+            const int c0 = cp_full, lc = pipe->lo_cols, cb = jb + ob;
             if (cb < lc) {
                 const int wd = lc - cb;
                 for (int e = tid; e < (pipe_need - c0) * wd; e += BC_THREADS) {
@@ -561,9 +559,8 @@ __device__ __attribute__((noinline)) void bb_panel_qr(double* __restrict__ W, co
                         i <= j ? pipe->prev[(int64_t)(pipe->lo_from + i) * pipe->prev_n + pipe->lo_from + j] : 0.0;
                 }
             }
-            __syncthreads();
-            if (tid == 0) pipe->copied = pipe_need;
-            __syncthreads();
+            __syncthreads();                     // (the copied entries before the update reads them)
+            cp_full = pipe_need;
         }
         const int S_all = (nt + 15) >> 4;
         // A SHORT block (the first blocks of a staircase panel: 32 .. 96 rows, the ones the next panel of the pipelined chain waits for)
@@ -780,7 +777,6 @@ bb_chain2_kernel(const BBPanel* __restrict__ panels, int num_panels, const int32
             if (pi == (int)blockIdx.x) s_pipe.aborted = 0;
             s_pipe.prev_n = has ? panels[pi - 1].ncols : 0;
             s_pipe.lo_from = p.lo_from; s_pipe.lo_rows = p.lo_rows; s_pipe.lo_cols = p.lo_cols; s_pipe.lo_stride = p.lo_stride;
-            s_pipe.copied = 0; s_pipe.copied_own = 0;
         }
         __syncthreads();
         const int* rlim = pi == 0 ? rlim_first : rlim_rest;
