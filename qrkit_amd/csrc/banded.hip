@@ -237,8 +237,11 @@ __device__ __forceinline__ double bb_recip(double x)
 // works on the carry rows its staircase reaches (stack rows below rlim).  So workgroup g factorises the panels g, g + G, ..; after
 // every block of columns it publishes how many rows of its panel are final (one word per panel, agent-scope release), and before a
 // block it waits until the previous panel has finalised the carry rows that block needs and copies exactly those rows in -- straight
-// from the previous panel's storage, there is no leftover buffer.  For 256 x 192 strips at column step 64 block b of a panel waits
-// for block b + 2 of the one before: two panels are in flight at any time.
+// from the previous panel's storage, there is no leftover buffer.  Round 5: the pipelined chain works in blocks of 16 columns (the grain of
+// the blocks is the grain of the overlap) and a panel publishes TWO words per block -- "own": the rows below are final in the columns
+// below (after the block's reflectors), "done": final everywhere (after its update) -- so that the next panel's block starts its
+// reflectors on the first and only needs the second before its own update.  For 256 x 192 strips at column step 64 the next panel
+// starts when this one has run the reflectors of its first 80 columns; three workgroups, two to three panels in flight.
 struct BBPipe {
     const double* prev;        // storage of the previous panel (row-major, prev_n columns), or null for the first panel
     const int* prev_done;      // its rows-final word: rows below this are final in EVERY column (published after a block's update)
