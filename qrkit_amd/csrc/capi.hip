@@ -250,6 +250,9 @@ struct qrk_dense_plan_s {
     double* d_t = nullptr;
     double* d_r0 = nullptr;    // R0 (n x n), scratch of the second stage
     double* d_q1 = nullptr;    // packed QR of the second stage in Eigen's format (== d_r0 when the row-slab kernels factorise in place)
+    double* d_t1 = nullptr;    // T factors of blocks of 32 reflectors of the second stage (dense_qr.hip: the blocked application of Q1^T)
+    double* d_xw = nullptr;    // two work vectors per right-hand side of that application (allocated on first use)
+    int64_t xw_cap = 0;
     void* d_ws2 = nullptr;
     hipStream_t la_stream = nullptr;               // look-ahead of the first stage: the next panel is factorised beside the trailing update
     hipEvent_t la_urgent = nullptr, la_factored = nullptr;
@@ -1135,6 +1138,7 @@ qrk_status qrk_dense_plan_create(qrk_handle h, int32_t rows, int32_t cols, qrk_b
         else if (p->tall2) bytes2 = qrk::dense_tall_workspace_bytes(cols, cols, h->num_cus, &p->G2, &p->cpad2, &p->rows_per2);
         if (hipMalloc((void**)&p->d_t, qrk::caqr_t_bytes(rows, cols)) != hipSuccess ||
             hipMalloc((void**)&p->d_r0, (size_t)cols * (size_t)cols * sizeof(double)) != hipSuccess ||
+            hipMalloc((void**)&p->d_t1, qrk::dense_q_tfactors_doubles(cols) * sizeof(double)) != hipSuccess ||
             (p->cols2 && hipMalloc((void**)&p->d_q1, (size_t)cols * (size_t)cols * sizeof(double)) != hipSuccess) ||
             (bytes2 && hipMalloc(&p->d_ws2, bytes2) != hipSuccess)) {
             qrk_dense_plan_destroy(p);
@@ -1189,7 +1193,7 @@ qrk_status qrk_dense_plan_destroy(qrk_dense_plan p)
         if (p->la_pipe.ev_n2) (void)hipEventDestroy(p->la_pipe.ev_n2);
         if (p->la_pipe.ev_u) (void)hipEventDestroy(p->la_pipe.ev_u);
         for (int l = 0; l < qrk::CaqrPipe::MAXL; ++l) if (p->la_pipe.ev_lvl[l]) (void)hipEventDestroy(p->la_pipe.ev_lvl[l]);
-        (void)hipFree(p->d_t); if (p->d_q1 != p->d_r0) (void)hipFree(p->d_q1); (void)hipFree(p->d_r0); (void)hipFree(p->d_ws2);
+        (void)hipFree(p->d_t); if (p->d_q1 != p->d_r0) (void)hipFree(p->d_q1); (void)hipFree(p->d_r0); (void)hipFree(p->d_ws2); (void)hipFree(p->d_t1); (void)hipFree(p->d_xw);
     }
     delete p;
     return QRK_STATUS_OK;
@@ -1267,6 +1271,9 @@ qrk_status qrk_dense_factorize(qrk_dense_plan p, double* a, int64_t lda, double*
             }
             // R replaces R0 in the caller's array (consumers read R from its upper triangle, as in Eigen's packed format)
             QRK_HIP(h, qrk::launch_caqr_copy_upper(p->d_q1, n, da, lda, n, 0, h->stream));
+            // the T factors of Q1 by blocks of 32 reflectors: what qrk_dense_apply_q applies it with (three matrix-vector products per
+            // block instead of 32 dependent reflectors)
+            if (p->d_t1) QRK_HIP(h, qrk::launch_dense_q_tfactors(p->d_q1, n, n, n, dhc, p->d_t1, h->stream));
             // a decision of the second stage inside rounding: the exact path redoes the whole matrix in Eigen's operation order
             // and leaves Eigen's packed format; the host has to know which format the factors are in
             QRK_HIP(h, hipMemcpyAsync(p->h_unclear, flag, sizeof(int), hipMemcpyDeviceToHost, h->stream));
@@ -1341,6 +1348,20 @@ qrk_status qrk_dense_apply_q(qrk_dense_plan p, const double* qr, int64_t lda, co
     // Q = Q0 diag(Q1, I) after a two-stage factorisation (the factors of Q1 and the T factors of Q0 live in the plan)
     auto apply = [&](const double* dqr, const double* dhc, double* db) -> hipError_t {
         auto eigen_form = [&](const double* packed, int64_t ld, int rows, int nrefl) -> hipError_t {
+            // Q1^T of a two-stage factorisation: block by block of 32 reflectors with the T factors the factorisation left in the plan, a
+            // launch per block over several workgroups (the reflector-by-reflector kernel pulls all of V through one CU: 1.8 ms of
+            // configs[3]'s solve()); QRK_DENSE_APPLY_BLOCKS=0 keeps that kernel.  (Q1 v, the other direction, stays on it.)
+            const char* sw = std::getenv("QRK_DENSE_APPLY_BLOCKS");
+            if (transpose && packed == p->d_q1 && p->d_t1 && p->ts_active && rows >= 256 && nrhs <= 65535 && !(sw && sw[0] == '0')) {
+                const int64_t need = 2 * (int64_t)rows * nrhs;
+                if (need > p->xw_cap) {
+                    (void)hipStreamSynchronize(h->stream);
+                    (void)hipFree(p->d_xw); p->d_xw = nullptr; p->xw_cap = 0;
+                    if (hipMalloc((void**)&p->d_xw, (size_t)need * sizeof(double)) == hipSuccess) p->xw_cap = need;
+                    else (void)hipGetLastError();
+                }
+                if (p->d_xw) return qrk::launch_dense_apply_qt_blocks(packed, ld, rows, nrefl, p->d_t1, db, ldb, nrhs, p->d_xw, h->stream);
+            }
             if ((size_t)(rows + 4) * sizeof(double) > 150 * 1024)
                 return qrk::launch_dense_apply_q_tall(packed, ld, rows, nrefl, dhc, transpose, db, ldb, nrhs, h->stream);
             return qrk::launch_dense_apply_q(packed, ld, rows, nrefl, dhc, transpose, db, ldb, nrhs, h->stream);

@@ -250,6 +250,167 @@ dense_apply_q_kernel(const double* __restrict__ QR, int64_t lda, int r, int nref
     }
 }
 
+// ---- blocked application of a Householder sequence (round 5) ---------------------------------------------------------------
+// dense_apply_q_kernel applies the reflectors one after the other: ~1 us each (a dot product over a workgroup, three barriers), 2.0 ms
+// for the 2 000 reflectors of the second stage of BASELINE configs[3] per solve().  With the triangular factors T_j of blocks of 32
+// reflectors (Q = prod_j (I - V_j T_j V_j^T), Eigen's make_block_householder_triangular_factor / LAPACK larft, forward columnwise)
+// a block is three matrix-vector products.  T is computed once per factorisation (dense_q_tfactors_kernel, a workgroup per block).
+constexpr int QB = 32;                 // reflectors per block
+
+// T_j of every block: G = V^T V (strict upper part) through LDS tiles of 64 rows, then the column recurrence
+// T(l, l) = tau_l, T(0:l, l) = -tau_l T(0:l, 0:l) G(0:l, l).  V = unit-lower view of QR(:, k0 .. k0 + 31) from row k0.
+__global__ void __launch_bounds__(256)
+dense_q_tfactors_kernel(const double* __restrict__ QR, int64_t lda, int n, int nrefl, const double* __restrict__ tau, double* __restrict__ T)
+{
+    __shared__ double vt[64][QB + 1];
+    __shared__ double G[QB][QB + 1];
+    __shared__ double Ts[QB][QB + 1];
+    const int tid = threadIdx.x, blk = blockIdx.x;
+    const int k0 = blk * QB, kb = (nrefl - k0) < QB ? (nrefl - k0) : QB;
+    // thread -> up to four (a, b) pairs of the 32 x 32 square (a = tid >> 3, b = 4 (tid & 7) .. + 3); only a < b < kb is kept
+    const int a = tid >> 3, b0 = 4 * (tid & 7);
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int r0 = k0; r0 < n; r0 += 64) {
+        __syncthreads();
+        // tile rows r0 .. r0 + 63: lane = row (coalesced along a column), eight columns per pass
+        for (int e = tid; e < 64 * QB; e += 256) {
+            const int l = e >> 6, i = r0 + (e & 63);
+            double v = 0.0;
+            if (l < kb && i < n) v = i > k0 + l ? QR[(int64_t)(k0 + l) * lda + i] : (i == k0 + l ? 1.0 : 0.0);
+            vt[e & 63][l] = v;
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int i = 0; i < 64; ++i) {
+            const double va = vt[i][a];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[q] = fma(va, vt[i][b0 + q], acc[q]);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) G[a][b0 + q] = acc[q];
+    for (int e = tid; e < QB * QB; e += 256) Ts[e >> 5][e & 31] = 0.0;
+    __syncthreads();
+    if (tid < QB) {
+        // row `tid` of T depends on row `tid` only: T(a, l) = -tau_l sum_{b = a .. l-1} T(a, b) G(b, l)
+        const int ar = tid;
+        for (int l = 0; l < kb; ++l) {
+            const double tl = tau[k0 + l];
+            double tv = 0.0;
+            if (ar == l) tv = tl;
+            else if (ar < l) {
+                double sacc = 0.0;
+                for (int bb = ar; bb < l; ++bb) sacc = fma(Ts[ar][bb], G[bb][l], sacc);
+                tv = -tl * sacc;
+            }
+            Ts[ar][l] = tv;
+        }
+    }
+    __syncthreads();
+    for (int e = tid; e < QB * QB; e += 256) T[(int64_t)blk * QB * QB + e] = Ts[e >> 5][e & 31];
+}
+
+// Q^T B with the blocks' T factors on MANY workgroups (round 5): one launch per block of 32 reflectors, blockIdx.x = a slab of the rows
+// below the block's first, blockIdx.y = right-hand side.  The one-workgroup kernels (reflector by reflector, or block by block above)
+// pull the 16 MB of V of a 2 000-reflector sequence through ONE CU -- 13 GB/s, 1.8 ms of configs[3]'s solve().  Here every workgroup of
+// a launch forms the block's w = V^T x itself (the panel of 32 columns is 512 KB at most and sits in L2 after the first reader), applies
+// T^T, and updates ITS slab of x.  x ping-pongs between two work vectors from block to block (a workgroup reads all of x while its
+// neighbours write their slabs); the 32 rows a block finishes go to B as well, the last block writes everything that is left.
+__global__ void __launch_bounds__(256)
+dense_apply_qt_block_kernel(const double* __restrict__ QR, int64_t lda, int n, int k0, int kb, const double* __restrict__ Tb,
+                            const double* __restrict__ xin_all, double* __restrict__ xout_all, int64_t ldw, double* __restrict__ B, int64_t ldb,
+                            int last)
+{
+    __shared__ double part[4 * QB];
+    __shared__ double w[QB];
+    __shared__ double w2[QB];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const double* xin = xin_all + (int64_t)blockIdx.y * ldw;
+    double* xout = xout_all + (int64_t)blockIdx.y * ldw;
+    double* bout = B + (int64_t)blockIdx.y * ldb;
+    const double* V = QR + (int64_t)k0 * lda;
+    // ---- w = V^T x over all the rows below k0
+    double wl[QB];
+#pragma unroll
+    for (int l = 0; l < QB; ++l) wl[l] = 0.0;
+    for (int i = k0 + tid; i < n; i += 256) {
+        const double xi = xin[i];
+        double vv[QB];
+#pragma unroll
+        for (int l = 0; l < QB; ++l) vv[l] = V[(int64_t)(l < kb ? l : 0) * lda + i];      // (all 32 loads of the row in flight)
+        if (i < k0 + QB) {
+#pragma unroll
+            for (int l = 0; l < QB; ++l) vv[l] = i > k0 + l ? vv[l] : (i == k0 + l ? 1.0 : 0.0);
+        }
+#pragma unroll
+        for (int l = 0; l < QB; ++l) wl[l] = fma(l < kb ? vv[l] : 0.0, xi, wl[l]);
+    }
+#pragma unroll
+    for (int l = 0; l < QB; ++l) {
+        const double sgl = dq_wave_sum(wl[l]);
+        if (lane == 0) part[wave * QB + l] = sgl;
+    }
+    __syncthreads();
+    if (tid < QB) w[tid] = (part[tid] + part[QB + tid]) + (part[2 * QB + tid] + part[3 * QB + tid]);
+    __syncthreads();
+    if (tid < QB) {
+        double acc = 0.0;
+        for (int q = 0; q <= tid; ++q) acc = fma(Tb[q * QB + tid], w[q], acc);      // T^T w, T upper triangular, row-major
+        w2[tid] = tid < kb ? acc : 0.0;
+    }
+    __syncthreads();
+    // ---- this workgroup's slab of x - V w'
+    double wr[QB];
+#pragma unroll
+    for (int l = 0; l < QB; ++l) wr[l] = w2[l];
+    const int per = (n - k0 + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int r0 = k0 + (int)blockIdx.x * per, r1 = (r0 + per) < n ? (r0 + per) : n;
+    for (int i = r0 + tid; i < r1; i += 256) {
+        double vv[QB];
+#pragma unroll
+        for (int l = 0; l < QB; ++l) vv[l] = V[(int64_t)(l < kb ? l : 0) * lda + i];
+        if (i < k0 + QB) {
+#pragma unroll
+            for (int l = 0; l < QB; ++l) vv[l] = i > k0 + l ? vv[l] : (i == k0 + l ? 1.0 : 0.0);
+        }
+        double acc = xin[i];
+#pragma unroll
+        for (int l = 0; l < QB; ++l) acc = fma(-(l < kb ? vv[l] : 0.0), wr[l], acc);
+        xout[i] = acc;
+        if (last || i < k0 + QB) bout[i] = acc;
+    }
+}
+
+// B(0:n, :) <- Q^T B for the sequence of nrefl reflectors packed in QR with the T factors of launch_dense_q_tfactors; work: 2 n nrhs doubles
+hipError_t launch_dense_apply_qt_blocks(const double* QR, int64_t lda, int n, int nrefl, const double* T, double* B, int64_t ldb, int64_t nrhs,
+                                        double* work, hipStream_t stream)
+{
+    if (nrhs <= 0 || nrefl <= 0) return hipSuccess;
+    if (nrhs > 65535) return hipErrorInvalidValue;
+    const int nblk = (nrefl + QB - 1) / QB;
+    double* buf[2] = {work, work + (int64_t)n * nrhs};
+    hipError_t e = hipMemcpy2DAsync(buf[0], (size_t)n * sizeof(double), B, (size_t)ldb * sizeof(double), (size_t)n * sizeof(double), (size_t)nrhs,
+                                    hipMemcpyDeviceToDevice, stream);
+    if (e != hipSuccess) return e;
+    for (int g = 0; g < nblk; ++g) {
+        const int k0 = g * QB, kb = (nrefl - k0) < QB ? (nrefl - k0) : QB;
+        // slabs of at least 64 rows, at most 16 workgroups per right-hand side
+        int W = (n - k0 + 63) / 64; if (W > 16) W = 16; if (W < 1) W = 1;      // (1 / 2 / 4 / 8 / 16 / 32 workgroups: 4.49 / 4.35 / 4.29 / 4.26 / 4.22 / 4.23 ms for configs[3]'s solve())
+        hipLaunchKernelGGL(dense_apply_qt_block_kernel, dim3((unsigned)W, (unsigned)nrhs), dim3(256), 0, stream, QR, lda, n, k0, kb,
+                           T + (int64_t)g * QB * QB, buf[g & 1], buf[(g + 1) & 1], (int64_t)n, B, ldb, g == nblk - 1 ? 1 : 0);
+    }
+    return hipGetLastError();
+}
+
+size_t dense_q_tfactors_doubles(int nrefl) { return (size_t)((nrefl + QB - 1) / QB) * QB * QB; }
+
+hipError_t launch_dense_q_tfactors(const double* QR, int64_t lda, int n, int nrefl, const double* tau, double* T, hipStream_t stream)
+{
+    if (nrefl <= 0) return hipSuccess;
+    hipLaunchKernelGGL(dense_q_tfactors_kernel, dim3((unsigned)((nrefl + QB - 1) / QB)), dim3(256), 0, stream, QR, lda, n, nrefl, tau, T);
+    return hipGetLastError();
+}
+
 size_t dense_qr_smem_bytes(int r, int c)
 {
     return (size_t)(r + 2 * c + 2 * DQ_WAVES) * sizeof(double) + (size_t)(c + 2 * DQ_WAVES) * sizeof(int);

@@ -157,6 +157,11 @@ hipError_t launch_bb_chain(const BBPanel* panels, int num_panels, const int32_t*
 hipError_t launch_bb_apply_q(const BBPanel* panels, int num_panels, const double* y_vals, const double* t_vals,
                              int transpose, double* v, int64_t ldv, int64_t nrhs, int max_act_rows, int max_ncols,
                              hipStream_t stream);
+// blocked application of Q1^T of a two-stage factorisation (dense_qr.hip): T factors of blocks of 32 reflectors, then a launch per block over several workgroups
+size_t dense_q_tfactors_doubles(int nrefl);
+hipError_t launch_dense_q_tfactors(const double* QR, int64_t lda, int n, int nrefl, const double* tau, double* T, hipStream_t stream);
+hipError_t launch_dense_apply_qt_blocks(const double* QR, int64_t lda, int n, int nrefl, const double* T, double* B, int64_t ldb, int64_t nrhs,
+                                        double* work, hipStream_t stream);
 hipError_t launch_dense_solve_r(const double* qr, int64_t lda, int n, double* b, int64_t ldb, int64_t nrhs, hipStream_t stream,
                                 int* flags = nullptr, int flags_cap = 0);
 hipError_t launch_bb_solve_r(const BBPanel* panels, int num_panels, const double* r_stage, int cols, double* v, int64_t ldv,
