@@ -251,7 +251,7 @@ struct qrk_dense_plan_s {
     double* d_r0 = nullptr;    // R0 (n x n), scratch of the second stage
     double* d_q1 = nullptr;    // packed QR of the second stage in Eigen's format (== d_r0 when the row-slab kernels factorise in place)
     double* d_t1 = nullptr;    // T factors of blocks of 32 reflectors of the second stage (dense_qr.hip: the blocked application of Q1^T)
-    double* d_xw = nullptr;    // two work vectors per right-hand side of that application (allocated on first use)
+    double* d_xw = nullptr;    // the slabs' partial products of that application, 2 x 16 x 32 per right-hand side (allocated on first use)
     int64_t xw_cap = 0;
     void* d_ws2 = nullptr;
     hipStream_t la_stream = nullptr;               // look-ahead of the first stage: the next panel is factorised beside the trailing update
@@ -1353,7 +1353,7 @@ qrk_status qrk_dense_apply_q(qrk_dense_plan p, const double* qr, int64_t lda, co
             // configs[3]'s solve()); QRK_DENSE_APPLY_BLOCKS=0 keeps that kernel.  (Q1 v, the other direction, stays on it.)
             const char* sw = std::getenv("QRK_DENSE_APPLY_BLOCKS");
             if (transpose && packed == p->d_q1 && p->d_t1 && p->ts_active && rows >= 256 && nrhs <= 65535 && !(sw && sw[0] == '0')) {
-                const int64_t need = 2 * (int64_t)rows * nrhs;
+                const int64_t need = 2 * 16 * 32 * nrhs;  // the slabs' shares of a block's w, two sets
                 if (need > p->xw_cap) {
                     (void)hipStreamSynchronize(h->stream);
                     (void)hipFree(p->d_xw); p->d_xw = nullptr; p->xw_cap = 0;

@@ -310,94 +310,140 @@ dense_q_tfactors_kernel(const double* __restrict__ QR, int64_t lda, int n, int n
     for (int e = tid; e < QB * QB; e += 256) T[(int64_t)blk * QB * QB + e] = Ts[e >> 5][e & 31];
 }
 
-// Q^T B with the blocks' T factors on MANY workgroups (round 5): one launch per block of 32 reflectors, blockIdx.x = a slab of the rows
-// below the block's first, blockIdx.y = right-hand side.  The one-workgroup kernels (reflector by reflector, or block by block above)
-// pull the 16 MB of V of a 2 000-reflector sequence through ONE CU -- 13 GB/s, 1.8 ms of configs[3]'s solve().  Here every workgroup of
-// a launch forms the block's w = V^T x itself (the panel of 32 columns is 512 KB at most and sits in L2 after the first reader), applies
-// T^T, and updates ITS slab of x.  x ping-pongs between two work vectors from block to block (a workgroup reads all of x while its
-// neighbours write their slabs); the 32 rows a block finishes go to B as well, the last block writes everything that is left.
+// Q^T B with the blocks' T factors on MANY workgroups (round 5): ONE launch per block of 32 reflectors (+ one ahead of the first),
+// blockIdx.x = a slab of the rows below the block's first, blockIdx.y = right-hand side.  The one-workgroup kernel (reflector by reflector) pulls the 16 MB of V of a
+// 2 000-reflector sequence through ONE CU -- 13 GB/s, 1.8 ms of configs[3]'s solve().  Here a launch sums the slabs' shares of the block's
+// w = V^T x (32 numbers per slab, left by the launch before), applies T^T, updates its slab in place and, rows in hand, leaves the slab's
+// share of the NEXT block's w: every workgroup reads its slab of two 32-column panels and nothing else.  (A first form with ONE launch per block, every workgroup forming all of w itself and x
+// ping-ponging between two work vectors, pulled the whole panel through every CU: 20 us per block, profiles/r05_solve.txt.)
+__device__ __forceinline__ void dq_panel_row(const double* __restrict__ V, int64_t lda, int i, int k0, int kb, double (&vv)[QB])
+{
+#pragma unroll
+    for (int l = 0; l < QB; ++l) vv[l] = V[(int64_t)(l < kb ? l : 0) * lda + i];      // (all 32 loads of the row in flight)
+    if (i < k0 + QB) {
+#pragma unroll
+        for (int l = 0; l < QB; ++l) vv[l] = i > k0 + l ? vv[l] : (i == k0 + l ? 1.0 : 0.0);
+    }
+#pragma unroll
+    for (int l = 0; l < QB; ++l) vv[l] = l < kb ? vv[l] : 0.0;
+}
+
 __global__ void __launch_bounds__(256)
-dense_apply_qt_block_kernel(const double* __restrict__ QR, int64_t lda, int n, int k0, int kb, const double* __restrict__ Tb,
-                            const double* __restrict__ xin_all, double* __restrict__ xout_all, int64_t ldw, double* __restrict__ B, int64_t ldb,
-                            int last)
+dense_qt_dot_kernel(const double* __restrict__ QR, int64_t lda, int n, int k0, int kb, const double* __restrict__ B, int64_t ldb,
+                    double* __restrict__ partial)
 {
     __shared__ double part[4 * QB];
-    __shared__ double w[QB];
-    __shared__ double w2[QB];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const double* xin = xin_all + (int64_t)blockIdx.y * ldw;
-    double* xout = xout_all + (int64_t)blockIdx.y * ldw;
-    double* bout = B + (int64_t)blockIdx.y * ldb;
+    const double* x = B + (int64_t)blockIdx.y * ldb;
     const double* V = QR + (int64_t)k0 * lda;
-    // ---- w = V^T x over all the rows below k0
+    const int per = (n - k0 + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int r0 = k0 + (int)blockIdx.x * per, r1 = (r0 + per) < n ? (r0 + per) : n;
     double wl[QB];
 #pragma unroll
     for (int l = 0; l < QB; ++l) wl[l] = 0.0;
-    for (int i = k0 + tid; i < n; i += 256) {
-        const double xi = xin[i];
+    for (int i = r0 + tid; i < r1; i += 256) {
+        const double xi = x[i];
         double vv[QB];
+        dq_panel_row(V, lda, i, k0, kb, vv);
 #pragma unroll
-        for (int l = 0; l < QB; ++l) vv[l] = V[(int64_t)(l < kb ? l : 0) * lda + i];      // (all 32 loads of the row in flight)
-        if (i < k0 + QB) {
-#pragma unroll
-            for (int l = 0; l < QB; ++l) vv[l] = i > k0 + l ? vv[l] : (i == k0 + l ? 1.0 : 0.0);
-        }
-#pragma unroll
-        for (int l = 0; l < QB; ++l) wl[l] = fma(l < kb ? vv[l] : 0.0, xi, wl[l]);
+        for (int l = 0; l < QB; ++l) wl[l] = fma(vv[l], xi, wl[l]);
     }
 #pragma unroll
     for (int l = 0; l < QB; ++l) {
-        const double sgl = dq_wave_sum(wl[l]);
+        const double sgl = dq_wave_sum_dpp(wl[l]);      // (DPP, not __shfl_xor: 32 sums of six ds_bpermute pairs each were 6 us of LDS pipe per launch)
         if (lane == 0) part[wave * QB + l] = sgl;
     }
     __syncthreads();
-    if (tid < QB) w[tid] = (part[tid] + part[QB + tid]) + (part[2 * QB + tid] + part[3 * QB + tid]);
+    if (tid < QB)
+        partial[((int64_t)blockIdx.y * 16 + blockIdx.x) * QB + tid] = (part[tid] + part[QB + tid]) + (part[2 * QB + tid] + part[3 * QB + tid]);
+}
+
+// the slabs' shares of block g (nparts of them, left by the launch before) summed, T^T, the slab updated in place -- and, rows in hand, the
+// slab's share of the NEXT block's w = V_next^T x (knext > 0), so that a block costs one launch
+__global__ void __launch_bounds__(256)
+dense_qt_update_kernel(const double* __restrict__ QR, int64_t lda, int n, int k0, int kb, const double* __restrict__ Tb,
+                       const double* __restrict__ partial, int nparts, double* __restrict__ B, int64_t ldb, int knext,
+                       double* __restrict__ partial_next)
+{
+    __shared__ double w[QB];
+    __shared__ double w2[QB];
+    __shared__ double part[4 * QB];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double* x = B + (int64_t)blockIdx.y * ldb;
+    const double* V = QR + (int64_t)k0 * lda;
+    // (every load of these two small sums in flight at once: a loop with a load per trip is a chain of L2 latencies -- 32 of them were
+    //  15 of the 19 us of a launch)
+    double tv[QB];
+    if (tid < QB) {
+#pragma unroll
+        for (int q = 0; q < QB; ++q) tv[q] = Tb[q * QB + tid];          // column tid of T (upper triangular, row-major): zero below the diagonal
+        double pv[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) pv[q] = q < nparts ? partial[((int64_t)blockIdx.y * 16 + q) * QB + tid] : 0.0;
+        double acc = 0.0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc += pv[q];                       // (a fixed order)
+        w[tid] = acc;
+    }
     __syncthreads();
     if (tid < QB) {
         double acc = 0.0;
-        for (int q = 0; q <= tid; ++q) acc = fma(Tb[q * QB + tid], w[q], acc);      // T^T w, T upper triangular, row-major
+#pragma unroll
+        for (int q = 0; q < QB; ++q) acc = fma(q <= tid ? tv[q] : 0.0, w[q], acc);      // T^T w
         w2[tid] = tid < kb ? acc : 0.0;
     }
     __syncthreads();
-    // ---- this workgroup's slab of x - V w'
-    double wr[QB];
+    double wr[QB], wl[QB];
 #pragma unroll
-    for (int l = 0; l < QB; ++l) wr[l] = w2[l];
+    for (int l = 0; l < QB; ++l) { wr[l] = w2[l]; wl[l] = 0.0; }
     const int per = (n - k0 + (int)gridDim.x - 1) / (int)gridDim.x;
     const int r0 = k0 + (int)blockIdx.x * per, r1 = (r0 + per) < n ? (r0 + per) : n;
+    const int kn = k0 + QB;                              // first row / reflector of the next block
+    const double* Vn = QR + (int64_t)kn * lda;
     for (int i = r0 + tid; i < r1; i += 256) {
         double vv[QB];
+        dq_panel_row(V, lda, i, k0, kb, vv);
+        double acc = x[i];
 #pragma unroll
-        for (int l = 0; l < QB; ++l) vv[l] = V[(int64_t)(l < kb ? l : 0) * lda + i];
-        if (i < k0 + QB) {
+        for (int l = 0; l < QB; ++l) acc = fma(-vv[l], wr[l], acc);
+        x[i] = acc;
+        if (knext > 0 && i >= kn) {
+            dq_panel_row(Vn, lda, i, kn, knext, vv);
 #pragma unroll
-            for (int l = 0; l < QB; ++l) vv[l] = i > k0 + l ? vv[l] : (i == k0 + l ? 1.0 : 0.0);
+            for (int l = 0; l < QB; ++l) wl[l] = fma(vv[l], acc, wl[l]);
         }
-        double acc = xin[i];
+    }
+    if (knext > 0) {
 #pragma unroll
-        for (int l = 0; l < QB; ++l) acc = fma(-(l < kb ? vv[l] : 0.0), wr[l], acc);
-        xout[i] = acc;
-        if (last || i < k0 + QB) bout[i] = acc;
+        for (int l = 0; l < QB; ++l) {
+            const double sgl = dq_wave_sum_dpp(wl[l]);      // (DPP, not __shfl_xor: 32 sums of six ds_bpermute pairs each were 6 us of LDS pipe per launch)
+            if (lane == 0) part[wave * QB + l] = sgl;
+        }
+        __syncthreads();
+        if (tid < QB)
+            partial_next[((int64_t)blockIdx.y * 16 + blockIdx.x) * QB + tid] = (part[tid] + part[QB + tid]) + (part[2 * QB + tid] + part[3 * QB + tid]);
     }
 }
 
-// B(0:n, :) <- Q^T B for the sequence of nrefl reflectors packed in QR with the T factors of launch_dense_q_tfactors; work: 2 n nrhs doubles
+// B(0:n, :) <- Q^T B for the sequence of nrefl reflectors packed in QR with the T factors of launch_dense_q_tfactors; work: 2 * 16 * 32 nrhs doubles
 hipError_t launch_dense_apply_qt_blocks(const double* QR, int64_t lda, int n, int nrefl, const double* T, double* B, int64_t ldb, int64_t nrhs,
                                         double* work, hipStream_t stream)
 {
     if (nrhs <= 0 || nrefl <= 0) return hipSuccess;
     if (nrhs > 65535) return hipErrorInvalidValue;
     const int nblk = (nrefl + QB - 1) / QB;
-    double* buf[2] = {work, work + (int64_t)n * nrhs};
-    hipError_t e = hipMemcpy2DAsync(buf[0], (size_t)n * sizeof(double), B, (size_t)ldb * sizeof(double), (size_t)n * sizeof(double), (size_t)nrhs,
-                                    hipMemcpyDeviceToDevice, stream);
-    if (e != hipSuccess) return e;
+    double* pbuf[2] = {work, work + (int64_t)16 * QB * nrhs};
+    auto slabs = [&](int k0) { int W = (n - k0 + 127) / 128; if (W > 16) W = 16; if (W < 1) W = 1; return W; };   // >= 128 rows each, at most 16
+    int Wprev = slabs(0);
+    hipLaunchKernelGGL(dense_qt_dot_kernel, dim3((unsigned)Wprev, (unsigned)nrhs), dim3(256), 0, stream, QR, lda, n, 0, nrefl < QB ? nrefl : QB, B, ldb,
+                       pbuf[0]);
     for (int g = 0; g < nblk; ++g) {
         const int k0 = g * QB, kb = (nrefl - k0) < QB ? (nrefl - k0) : QB;
-        // slabs of at least 64 rows, at most 16 workgroups per right-hand side
-        int W = (n - k0 + 63) / 64; if (W > 16) W = 16; if (W < 1) W = 1;      // (1 / 2 / 4 / 8 / 16 / 32 workgroups: 4.49 / 4.35 / 4.29 / 4.26 / 4.22 / 4.23 ms for configs[3]'s solve())
-        hipLaunchKernelGGL(dense_apply_qt_block_kernel, dim3((unsigned)W, (unsigned)nrhs), dim3(256), 0, stream, QR, lda, n, k0, kb,
-                           T + (int64_t)g * QB * QB, buf[g & 1], buf[(g + 1) & 1], (int64_t)n, B, ldb, g == nblk - 1 ? 1 : 0);
+        const int kn = k0 + QB, knext = g + 1 < nblk ? ((nrefl - kn) < QB ? (nrefl - kn) : QB) : 0;
+        const int W = slabs(k0);
+        hipLaunchKernelGGL(dense_qt_update_kernel, dim3((unsigned)W, (unsigned)nrhs), dim3(256), 0, stream, QR, lda, n, k0, kb,
+                           T + (int64_t)g * QB * QB, pbuf[g & 1], Wprev, B, ldb, knext, pbuf[(g + 1) & 1]);
+        Wprev = W;
     }
     return hipGetLastError();
 }
