@@ -1352,8 +1352,8 @@ qrk_status qrk_dense_apply_q(qrk_dense_plan p, const double* qr, int64_t lda, co
             // launch per block over several workgroups (the reflector-by-reflector kernel pulls all of V through one CU: 1.8 ms of
             // configs[3]'s solve()); QRK_DENSE_APPLY_BLOCKS=0 keeps that kernel.  (Q1 v, the other direction, stays on it.)
             const char* sw = std::getenv("QRK_DENSE_APPLY_BLOCKS");
-            if (transpose && packed == p->d_q1 && p->d_t1 && p->ts_active && rows >= 256 && nrhs <= 65535 && !(sw && sw[0] == '0')) {
-                const int64_t need = 2 * 16 * 32 * nrhs;  // the slabs' shares of a block's w, two sets
+            if (transpose && packed == p->d_q1 && p->d_t1 && p->ts_active && rows >= 256 && rows <= 8192 && nrhs <= 65535 && !(sw && sw[0] == '0')) {      // (at most 32 slabs of 256 rows)
+                const int64_t need = 2 * 32 * 32 * nrhs;  // the slabs' shares of a block's w (at most 32 slabs), two sets
                 if (need > p->xw_cap) {
                     (void)hipStreamSynchronize(h->stream);
                     (void)hipFree(p->d_xw); p->d_xw = nullptr; p->xw_cap = 0;

@@ -328,6 +328,7 @@ __device__ __forceinline__ void dq_panel_row(const double* __restrict__ V, int64
     for (int l = 0; l < QB; ++l) vv[l] = l < kb ? vv[l] : 0.0;
 }
 
+constexpr int QT_MAXW = 32;            // most slabs (workgroups) of a launch of the blocked Q^T
 __global__ void __launch_bounds__(256)
 dense_qt_dot_kernel(const double* __restrict__ QR, int64_t lda, int n, int k0, int kb, const double* __restrict__ B, int64_t ldb,
                     double* __restrict__ partial)
@@ -355,7 +356,7 @@ dense_qt_dot_kernel(const double* __restrict__ QR, int64_t lda, int n, int k0, i
     }
     __syncthreads();
     if (tid < QB)
-        partial[((int64_t)blockIdx.y * 16 + blockIdx.x) * QB + tid] = (part[tid] + part[QB + tid]) + (part[2 * QB + tid] + part[3 * QB + tid]);
+        partial[((int64_t)blockIdx.y * QT_MAXW + blockIdx.x) * QB + tid] = (part[tid] + part[QB + tid]) + (part[2 * QB + tid] + part[3 * QB + tid]);
 }
 
 // the slabs' shares of block g (nparts of them, left by the launch before) summed, T^T, the slab updated in place -- and, rows in hand, the
@@ -371,18 +372,28 @@ dense_qt_update_kernel(const double* __restrict__ QR, int64_t lda, int n, int k0
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     double* x = B + (int64_t)blockIdx.y * ldb;
     const double* V = QR + (int64_t)k0 * lda;
-    // (every load of these two small sums in flight at once: a loop with a load per trip is a chain of L2 latencies -- 32 of them were
-    //  15 of the 19 us of a launch)
+    const int per = (n - k0 + (int)gridDim.x - 1) / (int)gridDim.x;      // (<= 256 by the launcher: a row per thread)
+    const int r0 = k0 + (int)blockIdx.x * per, r1 = (r0 + per) < n ? (r0 + per) : n;
+    const int kn = k0 + QB;                              // first row / reflector of the next block
+    const double* Vn = QR + (int64_t)kn * lda;
+    // every load of the launch is issued before the first barrier: the row of the two panels (64 strided loads), x, T's column and the
+    // slabs' shares -- one trip to memory instead of three in a row
+    const int i = r0 + tid;
+    const bool rowact = i < r1, nextact = knext > 0 && rowact && i >= kn;
+    double vv[QB], vn[QB];
+    dq_panel_row(V, lda, rowact ? i : r0, k0, kb, vv);
+    dq_panel_row(Vn, lda, nextact ? i : (kn < n ? kn : n - 1), kn, knext > 0 ? knext : 0, vn);
+    const double xi = rowact ? x[i] : 0.0;
     double tv[QB];
     if (tid < QB) {
 #pragma unroll
-        for (int q = 0; q < QB; ++q) tv[q] = Tb[q * QB + tid];          // column tid of T (upper triangular, row-major): zero below the diagonal
-        double pv[16];
+        for (int q = 0; q < QB; ++q) tv[q] = Tb[q * QB + tid];          // column tid of T (upper triangular, row-major)
+        double pv[QT_MAXW];
 #pragma unroll
-        for (int q = 0; q < 16; ++q) pv[q] = q < nparts ? partial[((int64_t)blockIdx.y * 16 + q) * QB + tid] : 0.0;
+        for (int q = 0; q < QT_MAXW; ++q) pv[q] = q < nparts ? partial[((int64_t)blockIdx.y * QT_MAXW + q) * QB + tid] : 0.0;
         double acc = 0.0;
 #pragma unroll
-        for (int q = 0; q < 16; ++q) acc += pv[q];                       // (a fixed order)
+        for (int q = 0; q < QT_MAXW; ++q) acc += pv[q];                       // (a fixed order)
         w[tid] = acc;
     }
     __syncthreads();
@@ -393,47 +404,33 @@ dense_qt_update_kernel(const double* __restrict__ QR, int64_t lda, int n, int k0
         w2[tid] = tid < kb ? acc : 0.0;
     }
     __syncthreads();
-    double wr[QB], wl[QB];
+    double acc = xi;
 #pragma unroll
-    for (int l = 0; l < QB; ++l) { wr[l] = w2[l]; wl[l] = 0.0; }
-    const int per = (n - k0 + (int)gridDim.x - 1) / (int)gridDim.x;
-    const int r0 = k0 + (int)blockIdx.x * per, r1 = (r0 + per) < n ? (r0 + per) : n;
-    const int kn = k0 + QB;                              // first row / reflector of the next block
-    const double* Vn = QR + (int64_t)kn * lda;
-    for (int i = r0 + tid; i < r1; i += 256) {
-        double vv[QB];
-        dq_panel_row(V, lda, i, k0, kb, vv);
-        double acc = x[i];
-#pragma unroll
-        for (int l = 0; l < QB; ++l) acc = fma(-vv[l], wr[l], acc);
-        x[i] = acc;
-        if (knext > 0 && i >= kn) {
-            dq_panel_row(Vn, lda, i, kn, knext, vv);
-#pragma unroll
-            for (int l = 0; l < QB; ++l) wl[l] = fma(vv[l], acc, wl[l]);
-        }
-    }
+    for (int l = 0; l < QB; ++l) acc = fma(-vv[l], w2[l], acc);
+    if (rowact) x[i] = acc;
     if (knext > 0) {
+        const double xa = nextact ? acc : 0.0;
 #pragma unroll
         for (int l = 0; l < QB; ++l) {
-            const double sgl = dq_wave_sum_dpp(wl[l]);      // (DPP, not __shfl_xor: 32 sums of six ds_bpermute pairs each were 6 us of LDS pipe per launch)
+            const double sgl = dq_wave_sum_dpp(vn[l] * xa);
             if (lane == 0) part[wave * QB + l] = sgl;
         }
         __syncthreads();
         if (tid < QB)
-            partial_next[((int64_t)blockIdx.y * 16 + blockIdx.x) * QB + tid] = (part[tid] + part[QB + tid]) + (part[2 * QB + tid] + part[3 * QB + tid]);
+            partial_next[((int64_t)blockIdx.y * QT_MAXW + blockIdx.x) * QB + tid] = (part[tid] + part[QB + tid]) + (part[2 * QB + tid] + part[3 * QB + tid]);
     }
 }
 
-// B(0:n, :) <- Q^T B for the sequence of nrefl reflectors packed in QR with the T factors of launch_dense_q_tfactors; work: 2 * 16 * 32 nrhs doubles
+// B(0:n, :) <- Q^T B for the sequence of nrefl reflectors packed in QR with the T factors of launch_dense_q_tfactors; work: 2 * QT_MAXW * 32 nrhs doubles
 hipError_t launch_dense_apply_qt_blocks(const double* QR, int64_t lda, int n, int nrefl, const double* T, double* B, int64_t ldb, int64_t nrhs,
                                         double* work, hipStream_t stream)
 {
     if (nrhs <= 0 || nrefl <= 0) return hipSuccess;
     if (nrhs > 65535) return hipErrorInvalidValue;
     const int nblk = (nrefl + QB - 1) / QB;
-    double* pbuf[2] = {work, work + (int64_t)16 * QB * nrhs};
-    auto slabs = [&](int k0) { int W = (n - k0 + 127) / 128; if (W > 16) W = 16; if (W < 1) W = 1; return W; };   // >= 128 rows each, at most 16
+    double* pbuf[2] = {work, work + (int64_t)QT_MAXW * QB * nrhs};
+    // slabs of 64 .. 256 rows (a row per thread), at most QT_MAXW per right-hand side (n <= 256 QT_MAXW)
+    auto slabs = [&](int k0) { int W = (n - k0 + 63) / 64; if (W > QT_MAXW) W = QT_MAXW; if (W < 1) W = 1; return W; };
     int Wprev = slabs(0);
     hipLaunchKernelGGL(dense_qt_dot_kernel, dim3((unsigned)Wprev, (unsigned)nrhs), dim3(256), 0, stream, QR, lda, n, 0, nrefl < QB ? nrefl : QB, B, ldb,
                        pbuf[0]);
