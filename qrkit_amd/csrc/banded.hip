@@ -403,6 +403,10 @@ __device__ __attribute__((noinline)) void bb_panel_qr(double* __restrict__ W, co
             if (j >= mr) { if (tid == 0) hc[jb + j] = 0.0; continue; }      // (no rows left: identity)
             if (wv == (j & 15)) {
                 auto head = [&](double (&x)[NR]) {
+                    // (the raw tail goes to LDS first: its stores are under way while the norm is reduced and the scalars are computed)
+                    if (ln > j) vj[ln] = x[0];
+#pragma unroll
+                    for (int r = 1; r < NRB; ++r) vj[r * 64 + ln] = x[r];
                     double part = ln > j ? x[0] * x[0] : 0.0;
 #pragma unroll
                     for (int r = 1; r < NRB; ++r) part = fma(x[r], x[r], part);
@@ -419,10 +423,9 @@ __device__ __attribute__((noinline)) void bb_panel_qr(double* __restrict__ W, co
                         tau = -(s2 * s2) * ng;           // (beta - x0) / beta
                     }
                     if (ln == 0) { scj[0] = s2; scj[1] = ng; hc[jb + j] = tau; tb[j * OB + j] = tau; }
-                    if (ln > j) vj[ln] = x[0];
                     x[0] = ln > j ? x[0] * inv_s : (ln == j ? -nb_ : x[0]);      // essential part (:471-475), beta
 #pragma unroll
-                    for (int r = 1; r < NRB; ++r) { vj[r * 64 + ln] = x[r]; x[r] *= inv_s; }
+                    for (int r = 1; r < NRB; ++r) x[r] *= inv_s;
                 };
                 if (CPW == 1 || (j >> 4) == 0) head(col[0]); else head(col[CPW - 1]);
             }
