@@ -100,6 +100,8 @@ struct qrk_bd_plan_s {
     int32_t* d_redo = nullptr;
     double* d_p4_scratch = nullptr;   // bdqr_pair4.hip (uniform 32 x 32): working copies of its exact path
     int p4_wgs = 0;
+    bool k1_quad32 = false;           // bdqr_quad32.hip (four tiles per wavefront) instead of bdqr_pair4.hip; chosen in qrk_bd_plan_create
+    int q32_wgs = 0;
     int redo_parity = 0;
     double* d_exact_ws = nullptr;        // working copies of tiles too large for the exact kernel's LDS
     int64_t exact_ws_stride = 0;
@@ -406,8 +408,12 @@ qrk_status enqueue_factorize(qrk_bd_plan_s* p, const double* tiles, double* q, d
         else if (p->max_dim <= 16 && p->r >= p->c && h->use_small_kernel)   // 64/G tiles per wavefront (bdqr_small.hip)
             qrk::launch_bdqr_small(p->B, p->r, p->c, nb.pivoting, tiles, q, r, perm, hc, h->num_cus * 32, redo_cnt, redo_ids, h->stream);
         else if (p->d_p4_scratch) {
-            // the two-phase 32 x 32 kernel of bdqr_pair4.hip (four waves per SIMD); it redoes its flagged tiles itself
-            QRK_HIP(h, qrk::launch_bdqr_pair4(p->B, nb.pivoting, tiles, q, r, perm, hc, p->d_p4_scratch, p->p4_wgs, h->stream));
+            // the two-phase 32 x 32 kernels: bdqr_quad32.hip (four tiles per wavefront, two waves per SIMD) or bdqr_pair4.hip (two tiles,
+            // four waves per SIMD); both redo their flagged tiles themselves
+            if (p->k1_quad32)
+                QRK_HIP(h, qrk::launch_bdqr_quad32(p->B, nb.pivoting, tiles, q, r, perm, hc, p->d_p4_scratch, p->q32_wgs, -1, h->stream));
+            else
+                QRK_HIP(h, qrk::launch_bdqr_pair4(p->B, nb.pivoting, tiles, q, r, perm, hc, p->d_p4_scratch, p->p4_wgs, h->stream));
             redo_pass = false;
         } else {
             int wgs = h->num_cus * h->pair_wgs_per_cu;
@@ -792,7 +798,14 @@ qrk_status qrk_bd_plan_create(qrk_handle h, const qrk_bd_layout* L, qrk_q_format
         if (const char* e = std::getenv("QRK_PAIR_WGS")) { const int v = std::atoi(e); if (v > 0) p->p4_wgs = v; }
         // (one working copy per workgroup that can exist: the launch has min(pairs, p4_wgs) of them)
         const int64_t p4_live = std::min<int64_t>((B + 1) / 2, p->p4_wgs);
-        if (hipMalloc((void**)&p->d_p4_scratch, (size_t)qrk::bdqr_pair4_scratch_doubles((int)p4_live) * sizeof(double)) != hipSuccess) {
+        // QRK_K1_FORM: quad32 / pair4 force the kernel (diagnostic); otherwise by the launch size
+        p->q32_wgs = h->num_cus * 8;
+        if (const char* e = std::getenv("QRK_Q32_WGS")) { const int v = std::atoi(e); if (v > 0) p->q32_wgs = v; }
+        p->k1_quad32 = qrk::bdqr_quad32_preferred(B, p->q32_wgs);
+        if (const char* e = std::getenv("QRK_K1_FORM")) p->k1_quad32 = std::strcmp(e, "quad32") == 0 ? true : (std::strcmp(e, "pair4") == 0 ? false : p->k1_quad32);
+        const int64_t q32_live = std::min<int64_t>((B + 3) / 4, p->q32_wgs);
+        const int64_t scratch_doubles = std::max(qrk::bdqr_pair4_scratch_doubles((int)p4_live), qrk::bdqr_quad32_scratch_doubles((int)q32_live));
+        if (hipMalloc((void**)&p->d_p4_scratch, (size_t)scratch_doubles * sizeof(double)) != hipSuccess) {
             qrk_bd_plan_destroy(p);
             return fail(h, QRK_STATUS_ALLOC_FAILED, "qrk_bd_plan_create: cannot allocate the scratch of the 32 x 32 kernel");
         }
@@ -2415,6 +2428,7 @@ const char* qrk_bd_kernel_name(qrk_bd_plan p, int which)
     if (p->uniform && p->max_dim <= 16 && p->r >= p->c && h->use_small_kernel)
         return piv ? "qrk::bdqr_small_kernel<G, true>" : "qrk::bdqr_small_kernel<G, false>";
     // (tau is not stored by the measurement entry point and by callers that pass hcoeffs = NULL: the <.., false> instantiation)
+    if (p->d_p4_scratch && p->k1_quad32) return piv ? "qrk::bdqr_quad32_kernel<true, false>" : "qrk::bdqr_quad32_kernel<false, false>";
     if (p->d_p4_scratch) {
         // (third parameter: the own-norm step, which launch_bdqr_pair4 picks for more than one round of the resident waves)
         const bool own = qrk::bdqr_pair4_own_norm(p->B, p->p4_wgs);

@@ -49,6 +49,11 @@ int64_t bdqr_pair4_scratch_doubles(int num_wg);
 bool bdqr_pair4_own_norm(int64_t num_tiles, int num_wg);
 hipError_t launch_bdqr_pair4(int64_t num_tiles, int pivoting, const double* tiles, double* q_vals, double* r_vals, int32_t* perm,
                              double* hcoeffs, double* scratch, int num_wg, hipStream_t stream);
+// bdqr_quad32.hip: uniform 32 x 32 batches, FOUR tiles per wavefront, two wavefronts per SIMD (num_wg: 8 per CU); direct < 0: by launch size
+int64_t bdqr_quad32_scratch_doubles(int num_wg);
+bool bdqr_quad32_preferred(int64_t num_tiles, int num_wg);
+hipError_t launch_bdqr_quad32(int64_t num_tiles, int pivoting, const double* tiles, double* q_vals, double* r_vals, int32_t* perm,
+                              double* hcoeffs, double* scratch, int num_wg, int direct, hipStream_t stream);
 void launch_bdqr_pair(const WaveBatch& nb, bool full32, const double* tiles, double* q_vals,
                       double* r_vals, int32_t* perm, double* hcoeffs, int max_blocks,
                       int32_t* redo_count, int32_t* redo_ids, hipStream_t stream);

@@ -1,8 +1,9 @@
-"""GPU: both generations of the uniform 32 x 32 kernel -- bdqr_pair4.hip (the default: two tiles per wave, four waves per SIMD, pivot
-column published to LDS, Q by backward accumulation) and bdqr_pair.hip (QRK_PAIR_V2=0: LDS image of A, Q^T carried along) -- against
+"""GPU: the three generations of the uniform 32 x 32 kernel -- bdqr_quad32.hip (QRK_K1_FORM=quad32: four tiles per wave, one per DPP row,
+two columns per lane), bdqr_pair4.hip (QRK_K1_FORM=pair4: two tiles per wave, four waves per SIMD, pivot column published to LDS, Q by
+backward accumulation; the plan picks one of these two by launch size) and bdqr_pair.hip (QRK_PAIR_V2=0: LDS image of A, Q^T carried along) -- against
 the oracle on the same inputs: permutation bit-exact, Q / R / tau within 1e-12 per tile; odd tile counts (the last wave has one tile),
 both block solvers, tie families (the flagged tiles are redone inside the kernel by the exact routine), and at BASELINE's size the
-size-independent properties.  QRK_PAIR_V2 is read when the plan is created."""
+size-independent properties.  QRK_PAIR_V2 / QRK_K1_FORM are read when the plan is created."""
 import numpy as np
 import pytest
 
@@ -23,12 +24,18 @@ def ctx(qa):
     return qa.Context(0)
 
 
-@pytest.fixture(params=["gen2", "gen1"])
-def generation(request, monkeypatch):
-    if request.param == "gen1":
+def select_generation(monkeypatch, gen):
+    if gen == "gen1":
         monkeypatch.setenv("QRK_PAIR_V2", "0")
+        monkeypatch.delenv("QRK_K1_FORM", raising=False)
     else:
         monkeypatch.delenv("QRK_PAIR_V2", raising=False)
+        monkeypatch.setenv("QRK_K1_FORM", "quad32" if gen == "gen3" else "pair4")
+
+
+@pytest.fixture(params=["gen3", "gen2", "gen1"])
+def generation(request, monkeypatch):
+    select_generation(monkeypatch, request.param)
     return request.param
 
 
@@ -51,10 +58,11 @@ def kernel_of(qa, ctx, B, solver):
 def test_generation_switch_selects_the_kernel(qa, ctx, generation):
     name = kernel_of(qa, ctx, 10, 0)
     assert ("bdqr_pair4_kernel" in name) == (generation == "gen2"), name
+    assert ("bdqr_quad32_kernel" in name) == (generation == "gen3"), name
 
 
 @pytest.mark.parametrize("solver", [0, 1])
-@pytest.mark.parametrize("B", [1, 2, 3, 7, 129, 1000])
+@pytest.mark.parametrize("B", [1, 2, 3, 4, 5, 7, 129, 1000])
 def test_generic_batches_against_the_oracle(qa, ctx, generation, B, solver):
     tiles = seeded_tiles(100 + B, 0.5, 5.0, B * 1024)
     rows = cols = np.full(B, 32, np.int32)
@@ -98,17 +106,16 @@ def test_degenerate_tiles(qa, ctx, generation):
 
 
 def test_generations_agree_and_are_deterministic(qa, ctx, monkeypatch):
-    """Same permutation from both kernels, values within 1e-12 of each other, and each kernel bitwise reproducible run to run."""
+    """Same permutation from the three kernels, values within 1e-12 of each other, each kernel bitwise reproducible run to run; the two
+    two-phase kernels (gen2 without the own-norm step -- one round here -- and gen3) compute the same products in the same order:
+    bitwise the same Q and R."""
     B = 4097
     tiles = seeded_tiles(5, -1.0, 1.0, B * 1024)
     rows = cols = np.full(B, 32, np.int32)
     mat = qa.SparseBlockDiagonal.fromTiles(rows, cols, tiles)
     out = {}
-    for gen in ("gen2", "gen1"):
-        if gen == "gen1":
-            monkeypatch.setenv("QRK_PAIR_V2", "0")
-        else:
-            monkeypatch.delenv("QRK_PAIR_V2", raising=False)
+    for gen in ("gen3", "gen2", "gen1"):
+        select_generation(monkeypatch, gen)
         runs = []
         for _ in range(2):
             qr = qa.BlockDiagonalSparseQR(context=ctx)
@@ -121,6 +128,8 @@ def test_generations_agree_and_are_deterministic(qa, ctx, monkeypatch):
     np.testing.assert_allclose(out["gen2"][1], out["gen1"][1], rtol=0, atol=1e-12)
     scale = np.abs(out["gen1"][2]).max()
     np.testing.assert_allclose(out["gen2"][2], out["gen1"][2], rtol=0, atol=1e-12 * scale)
+    for x, y in zip(out["gen3"], out["gen2"]):
+        np.testing.assert_array_equal(x, y)
 
 
 def test_baseline_size_properties(qa, ctx, generation):
@@ -150,12 +159,14 @@ def test_baseline_size_properties(qa, ctx, generation):
     assert bool((d[:, :-1] >= d[:, 1:] * (1 - 1e-9)).all())          # pivoted: |R_kk| non-increasing
 
 
+@pytest.mark.parametrize("gen", ["gen3", "gen2"])
 @pytest.mark.parametrize("wgs,B", [(16, 3001), (7, 1200)])
-def test_many_rounds_per_workgroup(qa, ctx, monkeypatch, wgs, B):
-    """Few workgroups (QRK_PAIR_WGS): a workgroup runs more than the 32 rounds whose flags one word remembers -- several chunks of
-    rounds, each followed by the exact redo of its flagged tiles; tie tiles in every chunk."""
-    monkeypatch.delenv("QRK_PAIR_V2", raising=False)
+def test_many_rounds_per_workgroup(qa, ctx, monkeypatch, wgs, B, gen):
+    """Few workgroups (QRK_PAIR_WGS / QRK_Q32_WGS): a workgroup runs more than the 32 rounds whose flags one word remembers -- several
+    chunks of rounds, each followed by the exact redo of its flagged tiles; tie tiles in every chunk."""
+    select_generation(monkeypatch, gen)
     monkeypatch.setenv("QRK_PAIR_WGS", str(wgs))
+    monkeypatch.setenv("QRK_Q32_WGS", str(wgs))
     rng = np.random.default_rng(B)
     a = rng.uniform(-1, 1, size=(B, 32, 32))
     ties = rng.choice(B, size=B // 7, replace=False)
