@@ -233,7 +233,7 @@ __device__ __forceinline__ void step(double (&a)[WR], double* hl /* this half's 
         // ---- 2. publish the column (it is reflector K of phase 2 as well)
         double* vcol = hl + L_V + cb(K) - (K & ~1);
 #pragma unroll
-#ifdef QRK_P4_ABL      // (timing ablation only: results are wrong) 1: publish 16 bytes instead of the column
+#if defined(QRK_P4_ABL) && (QRK_P4_ABL & 1)      // (timing ablation only: results are wrong) 1: publish 16 bytes instead of the column
         for (int i = K & ~1; i < ((QRK_P4_ABL & 1) ? (K & ~1) + 2 : WR); i += 2) *reinterpret_cast<double2*>(&vcol[i]) = make_double2(a[i], a[i + 1]);
 #else
         // (8-byte stores: a single-lane ds_write_b64 takes the LDS pipe less than half of a ds_write_b128, tools/ubench8.hip; volatile
@@ -456,6 +456,7 @@ bdqr_pair4_kernel(int64_t num_tiles, const double* __restrict__ tiles, double* _
             // is starved and their second pairs start late), so the launch decides.  QRK_P4_PRIO 6 / 7: always / the reverse (measured)
             if ((QRK_P4_PRIO == 0 && steady) || QRK_P4_PRIO == 6) __builtin_amdgcn_s_setprio(2);
             if (QRK_P4_PRIO == 7) __builtin_amdgcn_s_setprio(0);
+            if (QRK_P4_PRIO == 8) __builtin_amdgcn_s_setprio(3);      // (experiment: a wave that is still loading / staging goes ahead of the computing ones)
             double a[WR];
             if (direct) {
                 // every lane its own column, straight from the tile: 16 loads of 16 bytes, 256 bytes between lanes (plain loads: the lines
@@ -485,9 +486,14 @@ bdqr_pair4_kernel(int64_t num_tiles, const double* __restrict__ tiles, double* _
                 const double* s0 = tiles + t0 * 1024 + 2 * lane;
                 const double* s1 = tiles + (t1 < num_tiles ? t1 : t0) * 1024 + 2 * lane;
 #pragma unroll
+#if defined(QRK_P4_COPY) && (QRK_P4_COPY & 8)
+                for (int m = 0; m < 8; ++m) { ld0[m] = d2u{(double)(lane + m), 1.0 + (double)pi}; ld1[m] = d2u{(double)(lane - m), 2.0 + (double)pi}; }
+                (void)s0; (void)s1;
+#else
                 for (int m = 0; m < 8; ++m) ld0[m] = QRK_P4_LOAD(reinterpret_cast<const d2u*>(s0 + 128 * m));
 #pragma unroll
                 for (int m = 0; m < 8; ++m) ld1[m] = QRK_P4_LOAD(reinterpret_cast<const d2u*>(s1 + 128 * m));
+#endif
                 if (QRK_P4_PRIO >= 3 && round == 0 && pi0 == blockIdx.x) {
                     // (after the loads are queued in dispatch order: the later a wave's tiles arrive, the higher its priority on the SIMD;
                     //  4, 5: the waves that carry one pair more than the others -- two chains back to back -- are in the top class)
@@ -526,6 +532,7 @@ bdqr_pair4_kernel(int64_t num_tiles, const double* __restrict__ tiles, double* _
                 __builtin_amdgcn_wave_barrier();
             }
             QRK_P4_STAMP_AT(1);
+            if (QRK_P4_PRIO == 8) __builtin_amdgcn_s_setprio(0);
             {
                 double s0 = 0.0, s1 = 0.0;
 #pragma unroll
@@ -533,7 +540,9 @@ bdqr_pair4_kernel(int64_t num_tiles, const double* __restrict__ tiles, double* _
                 st.nu2 = s0 + s1;
                 st.thr = st.nu2 * THR_HI;
             }
-#if defined(QRK_P4_ABL) && (QRK_P4_ABL & 2)     // (timing ablation: every second pair of a wave skips steps 16..31 and back steps 31..16)
+#if defined(QRK_P4_COPY)                        // (diagnostic: the launch's memory traffic without its arithmetic -- tools/p4_stamps.py, profiles/r06_k1_ramp.txt)
+#define QRK_P4_STEP(K) st.kstep = st.j;
+#elif defined(QRK_P4_ABL) && (QRK_P4_ABL & 2)     // (timing ablation: every second pair of a wave skips steps 16..31 and back steps 31..16)
 #define QRK_P4_STEP(K) if ((K) < 16 || !(round & 1)) step<K, PIVOT, HC, OWN>(a, hl, st);
 #else
 #define QRK_P4_STEP(K) step<K, PIVOT, HC, OWN>(a, hl, st);
@@ -545,7 +554,11 @@ bdqr_pair4_kernel(int64_t num_tiles, const double* __restrict__ tiles, double* _
             // the permutation splice (:519-521): the column chosen at step p ends at position p
             int ln = threadIdx.x;
             asm volatile("" : "+v"(ln));
+#if (defined(QRK_P4_COPY) && (QRK_P4_COPY & 2)) || (defined(QRK_P4_ABL) && (QRK_P4_ABL & 4))      // (timing only: without the stores of R)
+            if (valid && st.nu2 == 12345.678) {
+#else
             if (valid) {
+#endif
                 const int p = st.kstep, jj = ln & 31;
                 const int cbase = (int)(t * 32);
                 perm[cbase + p] = cbase + jj;
@@ -585,7 +598,9 @@ bdqr_pair4_kernel(int64_t num_tiles, const double* __restrict__ tiles, double* _
             // (s_K and ng_K of the 32 reflectors: lane l keeps entries l & 15 and 16 + (l & 15); back_step reads them through DPP)
 #pragma unroll
             for (int m = 0; m < 2; ++m) { sv[m] = hl2[L_S + 16 * m + (ln & 15)]; ngv[m] = hl2[L_NG + 16 * m + (ln & 15)]; }
-#if defined(QRK_P4_ABL) && (QRK_P4_ABL & 2)
+#if defined(QRK_P4_COPY)
+#define QRK_P4_BACK(K) q[K] += sv[K >> 4];
+#elif defined(QRK_P4_ABL) && (QRK_P4_ABL & 2)
 #define QRK_P4_BACK(K) if ((K) < 16 || !(round & 1)) back_step<K>(q, hl2, ln, sv, ngv);
 #else
 #define QRK_P4_BACK(K) back_step<K>(q, hl2, ln, sv, ngv);
@@ -594,7 +609,11 @@ bdqr_pair4_kernel(int64_t num_tiles, const double* __restrict__ tiles, double* _
 #undef QRK_P4_BACK
             // row-major rows of Q_i are the CSR value order of m_Q in both FullQ ([U|N] split, :455-471) and BlockDiagonalQ (:480-492)
             // layouts: lane j holds COLUMN j of Q_i, one coalesced store of 256 bytes per row and half
+#if (defined(QRK_P4_COPY) && (QRK_P4_COPY & 4)) || (defined(QRK_P4_ABL) && (QRK_P4_ABL & 8))      // (timing only: without the stores of Q)
+            if (valid && q[5] == 12345.678) {
+#else
             if (valid) {
+#endif
                 double* dst = q_vals + t * 1024 + jj;
 #pragma unroll
                 for (int i = 0; i < WR; ++i) QRK_P4_STOREQ(q[i], dst + 32 * i);

@@ -17,5 +17,8 @@ for grp in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU S
   i=$((i+1))
   rocprofv3 --pmc $grp --output-format csv -d "$ROOT/$OUT/p$i" -- python3 "$ROOT/bench.py" $ARGS > "$ROOT/$OUT/p$i.log" 2>&1 || echo "pass $i failed: $grp"
 done
-python3 "$ROOT/tools/pmc_summary.py" "$ROOT/$OUT" > "$ROOT/$OUT/summary.txt" 2>&1
+# QRK_PMC_KERNEL: substring of the kernel name to summarise (default: every bdqr kernel of the run); the raw pass directories are
+# removed afterwards unless QRK_PMC_KEEP is set (gpurun merges at most 64 MiB back)
+python3 "$ROOT/tools/pmc_summary.py" "$ROOT/$OUT" ${QRK_PMC_KERNEL:-bdqr} > "$ROOT/$OUT/summary.txt" 2>&1
+[ -n "${QRK_PMC_KEEP:-}" ] || rm -rf "$ROOT/$OUT"/p[0-9]*
 cat "$ROOT/$OUT/summary.txt"

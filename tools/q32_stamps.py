@@ -1,23 +1,23 @@
-"""Diagnostic: timeline of one launch of bdqr_pair4 (library built with -DQRK_P4_STAMP: s_memrealtime, 100 MHz, of every pair at the
+"""Diagnostic: timeline of one launch of bdqr_quad32 (library built with -DQRK_Q32_STAMP: s_memrealtime, 100 MHz, of every quad at the
 start of its round, when its tiles are in registers, at the end of phase 1 and at its end).  Never a timed build.
   python tools/p4_stamps.py build      (here)
   python tools/p4_stamps.py [B]        (GPU box)"""
 import os, subprocess, sys, ctypes as C
 ROOT = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
-out = os.path.join(ROOT, "tools", "abl_stamp", "libqrk_p4stamp%s.so" % os.environ.get("QRK_P4_TAG", ""))
+out = os.path.join(ROOT, "tools", "abl_stamp", "libqrk_q32stamp%s.so" % os.environ.get("QRK_Q32_TAG", ""))
 if len(sys.argv) > 1 and sys.argv[1] == "build":
     import glob
     os.makedirs(os.path.dirname(out), exist_ok=True)
-    objs = [o for o in glob.glob(os.path.join(ROOT, "build", "obj", "*.o")) if not o.endswith("bdqr_pair4.o")]
+    objs = [o for o in glob.glob(os.path.join(ROOT, "build", "obj", "*.o")) if not o.endswith("bdqr_quad32.o")]
     o = out[:-3] + ".o"
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-DQRK_P4_STAMP"] + os.environ.get("QRK_P4_FLAGS", "").split() + ["-I" + os.path.join(ROOT, "include"),
-                           "-I" + os.path.join(ROOT, "qrkit_amd", "csrc"), "-c", os.path.join(ROOT, "qrkit_amd", "csrc", "bdqr_pair4.hip"), "-o", o])
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-DQRK_Q32_STAMP"] + os.environ.get("QRK_Q32_FLAGS", "").split() + ["-I" + os.path.join(ROOT, "include"),
+                           "-I" + os.path.join(ROOT, "qrkit_amd", "csrc"), "-c", os.path.join(ROOT, "qrkit_amd", "csrc", "bdqr_quad32.hip"), "-o", o])
     subprocess.check_call(["/opt/rocm/bin/hipcc", "-shared", "-fPIC", "--offload-arch=gfx950", o] + objs + ["-o", out])
     os.remove(o)
     sys.exit(0)
 os.environ["QRKIT_AMD_LIB"] = out
-os.environ["QRK_K1_FORM"] = "pair4"
+os.environ["QRK_K1_FORM"] = "quad32"
 import numpy as np, torch
 import qrkit_amd
 from qrkit_amd import _capi as capi
@@ -29,7 +29,7 @@ S = 8
 tiles = torch.rand(S * B * 1024, device="cuda", dtype=torch.float64) * 4.5 + 0.5
 qv = torch.empty(S * B * 1024, device="cuda", dtype=torch.float64); rv = torch.empty(S * B * 528, device="cuda", dtype=torch.float64)
 pm = torch.empty(B * 32, device="cuda", dtype=torch.int32)
-NP = (B + 1) // 2
+NP = (B + 3) // 4
 stamps = torch.zeros(NP * 4 + 64, device="cuda", dtype=torch.int64)
 def launch(i):
     capi.check(capi.lib().qrk_bd_factorize(plan, tiles.data_ptr() + (i % S) * B * 8192, qv.data_ptr() + (i % S) * B * 8192, rv.data_ptr() + (i % S) * B * 4224,
@@ -46,10 +46,10 @@ print(f"B={B}: {e0.elapsed_time(e1) * 1e3 / 40:.2f} us per launch (stamped build
 s = stamps.cpu().numpy()[:NP * 4].reshape(NP, 4).astype(np.float64) / 100.0       # us
 t0 = s[:, 0].min()
 s -= t0
-G = min(NP, 4096)
+G = min(NP, 2048)
 print(f"span first stamp -> last stamp: {s.max():.2f} us")
 def q(x): return f"min {x.min():6.2f}  p10 {np.percentile(x, 10):6.2f}  median {np.median(x):6.2f}  p90 {np.percentile(x, 90):6.2f}  max {x.max():6.2f}"
-for name, idx in (("first pair of a wave", np.arange(0, min(NP, G))), ("second pair of a wave", np.arange(G, NP))):
+for name, idx in (("first quad of a wave", np.arange(0, min(NP, G))), ("second quad of a wave", np.arange(G, NP))):
     if len(idx) == 0: continue
     x = s[idx]
     print(f"--- {name}: {len(idx)} pairs")
@@ -58,7 +58,7 @@ for name, idx in (("first pair of a wave", np.arange(0, min(NP, G))), ("second p
     print("  load wait        ", q(x[:, 1] - x[:, 0]))
     print("  phase 1 (A -> R) ", q(x[:, 2] - x[:, 1]))
     print("  phase 2 (Q)      ", q(x[:, 3] - x[:, 2]))
-    print("  pair end         ", q(x[:, 3]))
+    print("  quad end           ", q(x[:, 3]))
 # by launch generation (blockIdx / 1024): do the first waves of a SIMD get their data first?
 for g in range((G + 1023) // 1024):
     idx = np.arange(g * 1024, min((g + 1) * 1024, G))
