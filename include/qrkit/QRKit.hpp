@@ -1598,7 +1598,7 @@ class ShardedBlockAngularSparseQR {
         m_info = m_leftSolver.info();
         if (m_info != Success) throw std::runtime_error("qrkit: ShardedBlockAngularSparseQR: the left solver failed (a collective would hang)");
         m_nb = nloc - m_m1;                                           // rows of this rank's bottom block
-        freeBuf(m_dS); freeBuf(m_dBottom);
+        freeBuf(m_dS); freeBuf(m_dBottom); freeBuf(m_dP2);            // (all three are sized by this call's right block)
         // T = Q1^T (rowPerm1 J2.top(n1)) on the device
         Buf dTop(m_handle, m_n1 * m_m2), dT(m_handle, m_n1 * m_m2);
         {

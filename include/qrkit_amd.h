@@ -320,7 +320,11 @@ qrk_status qrk_bbs_plan_create(qrk_handle h, int64_t num_strips, int32_t strip_r
 qrk_status qrk_bbs_plan_destroy(qrk_bbs_plan plan);
 /* rows, cols of the matrix; r_len = doubles of R kept by the plan (col_step x strip_cols per strip, strip_cols^2 for the last) */
 qrk_status qrk_bbs_plan_sizes(qrk_bbs_plan plan, int64_t* rows, int64_t* cols, int64_t* r_len);
-/* strips: strip i column-major (leading dimension strip_rows) at strips + i strip_rows strip_cols.  Enqueue only. */
+/* strips: strip i column-major (leading dimension strip_rows) at strips + i strip_rows strip_cols.
+ * Stage A is enqueued on the handle's stream.  When stage B takes the pipelined chain (three workgroups, more than two strips) the call
+ * then SYNCHRONISES that stream: it reads the chain's abort word on the host and, if a hand-off wait ran out, runs stage B again on one
+ * workgroup before it returns -- so the factors are complete on return in that case (the one-workgroup chain stays enqueue-only).
+ * A caller that overlaps host work or other streams with this call should issue that work first. */
 qrk_status qrk_bbs_factorize(qrk_bbs_plan plan, const double* strips);
 /* the rows of R emitted by strip i: rows [i col_step, ..) x columns [i col_step, i col_step + strip_cols), column-major with
  * leading dimension = the number of rows (col_step; strip_cols for the last strip), upper trapezoidal */

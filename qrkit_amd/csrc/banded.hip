@@ -1537,17 +1537,15 @@ hipError_t launch_bb_solve_r(const BBPanel* panels, int num_panels, const double
 // SMALLER blockIdx.x, which were dispatched before it: no co-residency assumption, no deadlock; the wait is bounded all the same.
 // flags: [nrhs][nblk] ints, zero before the launch.  (The sums run over the column blocks from the bottom up: not the order of the
 // one-workgroup kernel, the same result to rounding.)
-__global__ void __launch_bounds__(BS_THREADS)
-dense_solve_r_coop_kernel(const double* __restrict__ R, int64_t lda, int n, double* __restrict__ b, int64_t ldb, int* __restrict__ flags,
-                          int nblk)
+// Block kb of one right-hand side.  WAIT: the workgroup waits for the flag of every block below (2 = aborted: it stops); else every block
+// below is final.  Returns false when a wait ran out or met an aborted block: nothing of x has been written then.
+template <bool WAIT>
+__device__ __forceinline__ bool dense_solve_r_block(const double* __restrict__ R, int64_t lda, int n, double* __restrict__ x, int* __restrict__ fl,
+                                                    int nblk, int kb, double* blk /* [64 * 65] */, double* part /* [4 * 64] */, int* ok /* LDS word */,
+                                                    int max_spins)
 {
-    __shared__ double blk[64 * 65];          // diagonal block, blk[j * 65 + i] = R(i, j)
-    __shared__ double part[4 * 64];
     const int tid = threadIdx.x, ln = tid & 63, grp = tid >> 6;
-    const int kb = nblk - 1 - (int)blockIdx.x;
     const int c0 = kb * 64, nr = (n - c0) < 64 ? (n - c0) : 64;
-    double* x = b + (int64_t)blockIdx.y * ldb;
-    int* fl = flags + (int64_t)blockIdx.y * nblk;
     for (int e = tid; e < nr * nr; e += BS_THREADS) {
         const int j = e / nr, i = e - j * nr;
         blk[j * 65 + i] = R[(int64_t)(c0 + j) * lda + c0 + i];
@@ -1555,12 +1553,18 @@ dense_solve_r_coop_kernel(const double* __restrict__ R, int64_t lda, int n, doub
     double acc = 0.0;
     const double* rrow = R + c0 + (ln < nr ? ln : 0);
     for (int jb = nblk - 1; jb > kb; --jb) {
-        if (tid == 0) {
-            int spins = 0;
-            while (__hip_atomic_load(&fl[jb], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0 && ++spins < (1 << 22)) __builtin_amdgcn_s_sleep(2);
+        if (WAIT) {
+            if (tid == 0) {
+                int spins = 0, f;
+                while ((f = __hip_atomic_load(&fl[jb], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) == 0 && ++spins < max_spins) __builtin_amdgcn_s_sleep(2);
+                *ok = f == 1;
+            }
+            __syncthreads();
+            const bool go = *ok != 0;
+            __syncthreads();
+            if (!go) return false;                           // (never on with x_jb that is not there: the finishing kernel takes over)
+            __threadfence();                                 // (x of block jb as its owner wrote it, not a stale line of this CU's L1)
         }
-        __syncthreads();
-        __threadfence();                                     // (x of block jb as its owner wrote it, not a stale line of this CU's L1)
         const int j0 = jb * 64, j1 = (n - j0) < 64 ? n : j0 + 64;
         // the 64 columns of the block dealt round-robin to the four waves, eight loads in flight
         constexpr int U = 8;
@@ -1597,6 +1601,44 @@ dense_solve_r_coop_kernel(const double* __restrict__ R, int64_t lda, int n, doub
         __threadfence();
         if (ln == 0) __hip_atomic_store(&fl[kb], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
+    __syncthreads();
+    return true;
+}
+
+__global__ void __launch_bounds__(BS_THREADS)
+dense_solve_r_coop_kernel(const double* __restrict__ R, int64_t lda, int n, double* __restrict__ b, int64_t ldb, int* __restrict__ flags,
+                          int nblk, int* __restrict__ abort_word, int max_spins)
+{
+    __shared__ double blk[64 * 65];          // diagonal block, blk[j * 65 + i] = R(i, j)
+    __shared__ double part[4 * 64];
+    __shared__ int ok;
+    const int kb = nblk - 1 - (int)blockIdx.x;
+    int* fl = flags + (int64_t)blockIdx.y * nblk;
+    if (!dense_solve_r_block<true>(R, lda, n, b + (int64_t)blockIdx.y * ldb, fl, nblk, kb, blk, part, &ok, max_spins) && threadIdx.x == 0) {
+        // a wait ran out (a preempted or contended GPU): this block's rows of b are untouched; its flag says so to the blocks above, the
+        // word to the finishing kernel
+        __hip_atomic_store(&fl[kb], 2, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(abort_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// Queued behind the many-workgroup kernel: nothing to do unless a wait ran out there -- then the blocks that stopped (a prefix from the top:
+// a block stops exactly when one below it did) are solved here, bottom first, on one workgroup per right-hand side, from the rows of b
+// they left untouched.  No wait inside: every workgroup of the first kernel has ended.
+__global__ void __launch_bounds__(BS_THREADS)
+dense_solve_r_finish_kernel(const double* __restrict__ R, int64_t lda, int n, double* __restrict__ b, int64_t ldb, int* __restrict__ flags,
+                            int nblk, const int* __restrict__ abort_word)
+{
+    __shared__ double blk[64 * 65];
+    __shared__ double part[4 * 64];
+    __shared__ int ok;
+    if (__hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) return;
+    int* fl = flags + (int64_t)blockIdx.y * nblk;
+    for (int kb = nblk - 1; kb >= 0; --kb) {
+        if (__hip_atomic_load(&fl[kb], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 1) continue;      // (uniform: every thread reads the same word)
+        __threadfence();
+        (void)dense_solve_r_block<false>(R, lda, n, b + (int64_t)blockIdx.y * ldb, fl, nblk, kb, blk, part, &ok, 0);
+    }
 }
 
 // b(0:n, :) <- R^-1 b(0:n, :) for the upper triangle R (n x n) of a column-major array with leading dimension lda.
@@ -1606,12 +1648,21 @@ hipError_t launch_dense_solve_r(const double* qr, int64_t lda, int n, double* b,
 {
     if (nrhs <= 0 || n <= 0) return hipSuccess;
     if (lda > INT32_MAX) return hipErrorInvalidValue;
-    static const bool coop = !(std::getenv("QRK_SOLVE_R_COOP") && std::getenv("QRK_SOLVE_R_COOP")[0] == '0');
+    // (diagnostic switches, read on every call like QRK_BBS_MAPS: QRK_SOLVE_R_COOP=0 keeps the one-workgroup kernel, QRK_SOLVE_R_SPINS
+    //  bounds the flag waits -- 0 makes every block but the bottom one stop, which is how the tests reach the finishing kernel)
+    const char* csw = std::getenv("QRK_SOLVE_R_COOP");
+    const bool coop = !(csw && csw[0] == '0');
+    int max_spins = 1 << 22;
+    if (const char* e = std::getenv("QRK_SOLVE_R_SPINS")) max_spins = std::atoi(e);
     const int nblk = (n + 63) / 64;
-    if (coop && flags && n >= 512 && nrhs * nblk <= flags_cap) {
-        if (hipError_t e = hipMemsetAsync(flags, 0, (size_t)nrhs * nblk * sizeof(int), stream)) return e;
+    if (coop && flags && n >= 512 && nrhs * nblk + 1 <= flags_cap) {
+        // flags: [nrhs][nblk] (0 = not yet, 1 = x of the block is final, 2 = the block stopped on a wait that ran out) + the abort word
+        int* abort_word = flags + nrhs * nblk;
+        if (hipError_t e = hipMemsetAsync(flags, 0, (size_t)(nrhs * nblk + 1) * sizeof(int), stream)) return e;
         hipLaunchKernelGGL(dense_solve_r_coop_kernel, dim3((unsigned)nblk, (unsigned)nrhs), dim3(BS_THREADS), 0, stream, qr, lda, n, b, ldb,
-                           flags, nblk);
+                           flags, nblk, abort_word, max_spins);
+        hipLaunchKernelGGL(dense_solve_r_finish_kernel, dim3(1, (unsigned)nrhs), dim3(BS_THREADS), 0, stream, qr, lda, n, b, ldb, flags, nblk,
+                           abort_word);
         return hipGetLastError();
     }
     BBPanel one{};

@@ -664,7 +664,7 @@ void bbs_maps_sizes(int num_panels, int lo, int* K, int64_t* cprod_len, int64_t*
     if (gvec_len_per_rhs) *gvec_len_per_rhs = (int64_t)((nga > ngc ? nga : ngc) + 1) * lo;
 }
 
-// the maps of a factorisation: cmap [N][lo][lo] (panels 1 .. N - 2 written), amap [N][lo][lo] or null (s > 64: the triangular solve stays
+// the maps of a factorisation: cmap [N][lo][lo] (panels 1 .. N - 2 written), amap [N][lo][lo] or null (s > 64 or s > lo: the triangular solve stays
 // on bb_solve_r_kernel), and with K > 0 the group products cprod / aprod (bbs_maps_sizes)
 hipError_t launch_bbs_maps(const BBPanel* panels, int num_panels, const double* y_vals, const double* t_vals, const double* r_stage, int n,
                            int lo, double* cmap, double* amap, int K, double* cprod, double* aprod, hipStream_t stream)
@@ -722,7 +722,8 @@ hipError_t launch_bbs_solve_r_maps(const BBPanel* panels, int num_panels, const 
 {
     using namespace bbm;
     if (nrhs <= 0) return hipSuccess;
-    if (nrhs > 65535 || s > 64 || lo <= 0 || lo % 16 || num_panels < 2 || !amap) return hipErrorInvalidValue;
+    // (s > lo: the map of a panel would hold s rows of lo entries in an lo x lo slot, and the scatter would read past a panel's state)
+    if (nrhs > 65535 || s > 64 || lo <= 0 || lo % 16 || s > lo || num_panels < 2 || !amap) return hipErrorInvalidValue;
     hipError_t e = launch_bb_solve_r(panels + (num_panels - 1), 1, r_stage, cols, v, ldv, nrhs, stream);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(bbs_backsub_diag_kernel, dim3((unsigned)num_panels, (unsigned)((nrhs + 3) / 4)), dim3(256), 0, stream, panels, num_panels,

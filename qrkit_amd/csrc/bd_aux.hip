@@ -13,6 +13,15 @@
 
 namespace qrk {
 
+// QRK_SOLVE_GROUPED=0: one wavefront per tile in solve / applyQ / solveR (the kernels of rounds 1-4).  A diagnostic switch, read on every
+// call like the other ones (QRK_BBS_MAPS, QRK_SOLVE_R_COOP): tests toggle it inside one process.
+static bool solve_grouped()
+{
+    const char* e = std::getenv("QRK_SOLVE_GROUPED");
+    return !(e && e[0] == '0');
+}
+
+
 __device__ __forceinline__ void tile_geom(const TileGeom& g, int64_t t, int& r, int& c, int64_t& qoff,
                                           int64_t& roff, int& base_row, int& base_col)
 {
@@ -605,7 +614,7 @@ tail:
 void launch_bd_apply_q(const TileGeom& g, int max_rows, const double* q_vals, const double* b, int64_t nrhs, double* y, hipStream_t stream)
 {
     const int64_t total = g.num_tiles * nrhs;
-    static const bool grouped = !(std::getenv("QRK_SOLVE_GROUPED") && std::getenv("QRK_SOLVE_GROUPED")[0] == '0');
+    const bool grouped = solve_grouped();
     if (total > 0 && grouped && max_rows <= 64) {
         int RP = 2;
         while (RP < max_rows) RP *= 2;
@@ -628,7 +637,7 @@ void launch_bd_solve_r(const TileGeom& g, int max_cols, const double* r_vals, co
 {
     const int64_t total = g.num_tiles * nrhs;
     if (total <= 0) return;
-    static const bool grouped = !(std::getenv("QRK_SOLVE_GROUPED") && std::getenv("QRK_SOLVE_GROUPED")[0] == '0');
+    const bool grouped = solve_grouped();
     if (grouped && max_cols <= 32) {
         int G = 2;
         while (G < max_cols) G *= 2;
@@ -651,7 +660,7 @@ void launch_bd_solve(const TileGeom& g, int max_cols, const double* q_vals, cons
     const int64_t total = g.num_tiles * nrhs;
     if (total <= 0) return;
     const unsigned grid = (unsigned)(total < 262144 ? total : 262144);
-    static const bool grouped = !(std::getenv("QRK_SOLVE_GROUPED") && std::getenv("QRK_SOLVE_GROUPED")[0] == '0');   // (0: one wavefront per tile, rounds 1-4)
+    const bool grouped = solve_grouped();   // (0: one wavefront per tile, rounds 1-4)
     // (up to 32 columns; at 33 .. 64 a group is the whole wavefront and the 64 row registers + 64 unrolled steps were slower than the
     //  loop of bd_solve_kernel: 64 x 64, 20 000 tiles: 393 against 286 us)
     if (max_cols <= 32 && grouped) {

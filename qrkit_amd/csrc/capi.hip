@@ -1986,7 +1986,9 @@ static bool bbs_maps(qrk_bbs_plan p, int64_t nrhs)
         }
         p->maps_K = K;
         if (hipMalloc((void**)&p->d_cmap, (size_t)p->N * l2) != hipSuccess) return give_up();
-        if (p->s <= 64 && hipMalloc((void**)&p->d_amap, (size_t)p->N * l2) != hipSuccess) return give_up();
+        // (the map form of the triangular solve carries lo numbers from panel to panel and takes its s new rows out of them: it needs
+        //  lo >= s -- an overlap shorter than the column step stays with the one-workgroup chain, bb_solve_r_kernel)
+        if (p->s <= 64 && p->lo >= p->s && hipMalloc((void**)&p->d_amap, (size_t)p->N * l2) != hipSuccess) return give_up();
         if (K > 0 && (hipMalloc((void**)&p->d_cprod, (size_t)(cl > 0 ? cl : 1) * sizeof(double)) != hipSuccess ||
                       hipMalloc((void**)&p->d_aprod, (size_t)(al > 0 ? al : 1) * sizeof(double)) != hipSuccess)) return give_up();
     }

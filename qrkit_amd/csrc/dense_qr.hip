@@ -375,14 +375,16 @@ dense_qt_update_kernel(const double* __restrict__ QR, int64_t lda, int n, int k0
     const int per = (n - k0 + (int)gridDim.x - 1) / (int)gridDim.x;      // (<= 256 by the launcher: a row per thread)
     const int r0 = k0 + (int)blockIdx.x * per, r1 = (r0 + per) < n ? (r0 + per) : n;
     const int kn = k0 + QB;                              // first row / reflector of the next block
-    const double* Vn = QR + (int64_t)kn * lda;
+    // (the last block has no next panel: column kn lies past the reflectors -- and, for the square second stage, past the buffer; its
+    //  32 loads then read this block's own panel and are discarded)
+    const double* Vn = knext > 0 ? QR + (int64_t)kn * lda : V;
     // every load of the launch is issued before the first barrier: the row of the two panels (64 strided loads), x, T's column and the
     // slabs' shares -- one trip to memory instead of three in a row
     const int i = r0 + tid;
     const bool rowact = i < r1, nextact = knext > 0 && rowact && i >= kn;
     double vv[QB], vn[QB];
     dq_panel_row(V, lda, rowact ? i : r0, k0, kb, vv);
-    dq_panel_row(Vn, lda, nextact ? i : (kn < n ? kn : n - 1), kn, knext > 0 ? knext : 0, vn);
+    dq_panel_row(Vn, lda, nextact ? i : (knext > 0 ? kn : k0), kn, knext > 0 ? knext : 0, vn);
     const double xi = rowact ? x[i] : 0.0;
     double tv[QB];
     if (tid < QB) {

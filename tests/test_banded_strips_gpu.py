@@ -188,7 +188,10 @@ def test_given_up_pipeline_falls_back_to_one_workgroup(capfd):
 @pytest.mark.gpu
 @pytest.mark.parametrize("N,ms,n,s", [(2, 64, 48, 16), (3, 64, 48, 16), (9, 40, 32, 16), (12, 96, 64, 32), (24, 256, 192, 64), (7, 256, 256, 64),
                                       (6, 256, 192, 96), (5, 256, 240, 16), (40, 128, 128, 64), (70, 64, 48, 16), (131, 96, 64, 32),
-                                      (100, 256, 192, 64), (66, 256, 240, 16)])
+                                      (100, 256, 192, 64), (66, 256, 240, 16),
+                                      # an overlap SHORTER than the column step (0 < lo < s): the carry maps serve Q^T b / Q x, the
+                                      # triangular solve must stay on the one-workgroup chain (its map form needs lo >= s)
+                                      (8, 128, 96, 64), (9, 64, 64, 48), (7, 96, 80, 64), (70, 128, 96, 64)])
 def test_carry_maps_agree_with_the_one_workgroup_chains(N, ms, n, s):
     """banded_maps.hip: Q^T b, Q x and the triangular solve through one small matrix per strip (M_i = the linear map of the carry,
     G_i = D_i^-1 U_i) against the chains that walk the strips on one workgroup (QRK_BBS_MAPS=0): the same operators associated

@@ -98,6 +98,35 @@ def test_dense_solve_r_on_device(rows, cols):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("spins", [None, "0", "3"])
+def test_dense_solve_r_many_workgroups_and_its_finishing_kernel(spins, monkeypatch):
+    """n >= 512: the triangular solve runs a workgroup per block of 64 rows, each waiting on the flags of the blocks below.  A wait that
+    runs out must never let a block go on with x that is not there: the block stops, the blocks above it stop, and the kernel queued
+    behind solves them on one workgroup from the untouched rows of b.  QRK_SOLVE_R_SPINS=0 makes every block but the bottom one stop (the
+    whole solve is then the finishing kernel's), 3 some of them; the answers are those of the one-workgroup kernel and of the host."""
+    import scipy.linalg as sl
+    import torch
+    rows, cols = 900, 840
+    rng = np.random.default_rng(9)
+    A = rng.uniform(-1.0, 1.0, (rows, cols))
+    qr, _ = _factor(A, 0, None)
+    R = qr.matrixR().cpu().numpy()[:cols, :cols]
+    Y = rng.uniform(-1, 1, (cols, 4))
+    want = sl.solve_triangular(R, Y, lower=False)
+    tol = 1e-10 * max(1.0, np.linalg.cond(R) * 1e-6)
+    monkeypatch.setenv("QRK_SOLVE_R_COOP", "0")
+    B0 = torch.from_numpy(Y.T.copy()).cuda().t()
+    qr.solveR(B0); torch.cuda.synchronize()
+    monkeypatch.delenv("QRK_SOLVE_R_COOP")
+    if spins is not None:
+        monkeypatch.setenv("QRK_SOLVE_R_SPINS", spins)
+    B = torch.from_numpy(Y.T.copy()).cuda().t()
+    qr.solveR(B); torch.cuda.synchronize()
+    assert rel_fro(B.cpu().numpy(), want) <= tol
+    assert rel_fro(B.cpu().numpy(), B0.cpu().numpy()) <= 1e-12 * max(1.0, np.linalg.cond(R) * 1e-6)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("rows,cols,sparse_in", [(2000, 96, False), (7168, 384, False), (500, 40, True)])
 def test_blocked_thin_dense_qr_matches_oracle(rows, cols, sparse_in):
     """BlockedThinDenseQR / BlockedThinSparseQR (BlockedThinDenseQR.h:104-176; 7168 x 384 is the right block of the
