@@ -459,18 +459,90 @@ def strong_scaling(args, ctx, dev, dist, backend, rank, world, torch, np):
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             return tt.item() / iters
 
+        # the two consumers that scale (qrkit_amd/sharding.py): x only gathered (block-local solve), and R gathered in PIECES pieces,
+        # a piece on its way while the next one is factorised
+        PIECES = 4
+        bvec = torch.rand(nb * BR, generator=g, device=dev, dtype=torch.float64)
+        xloc = torch.empty(nb * BC, device=dev, dtype=torch.float64)
+        X_all = torch.empty(B * BC, device=xdev, dtype=torch.float64) if rank == 0 else None
+
+        def step_x():
+            capi.check(capi.lib().qrk_bd_factorize(plan, t.data_ptr(), q.data_ptr(), r.data_ptr(), p.data_ptr(), None,
+                                                   capi.MEM_DEVICE), ctx.handle)
+            capi.check(capi.lib().qrk_bd_solve(plan, q.data_ptr(), r.data_ptr(), p.data_ptr(), bvec.data_ptr(), 1, xloc.data_ptr(),
+                                               capi.MEM_DEVICE), ctx.handle)
+            gather_ragged_to_root(xloc.to(xdev), p_sizes, X_all, 0, rank, world)
+
+        cuts = [[a + (b - a) * k // PIECES for k in range(PIECES + 1)] for a, b in ranges]      # every rank's piece boundaries
+        pplans = []
+        for k in range(PIECES):
+            n = cuts[rank][k + 1] - cuts[rank][k]
+            pl = capi.BDLayout()
+            pl.num_blocks, pl.block_rows, pl.block_cols = n, BR, BC
+            pl.rows = pl.cols = None
+            pl.mat_rows, pl.mat_cols = n * BR, n * BC
+            pp_ = C.c_void_p()
+            if n > 0:
+                capi.check(capi.lib().qrk_bd_plan_create(ctx.handle, C.byref(pl), capi.FULL_Q, capi.COLPIV_HOUSEHOLDER, C.byref(pp_)), ctx.handle)
+            pplans.append((pp_, cuts[rank][k] - lo, n))
+
+        def step_ov():
+            reqs = []
+            for k, (pp_, off, n) in enumerate(pplans):
+                if n > 0:
+                    capi.check(capi.lib().qrk_bd_factorize(pp_, t.data_ptr() + off * BR * BC * 8, q.data_ptr() + off * BR * BR * 8,
+                                                           r.data_ptr() + off * 528 * 8, p.data_ptr() + off * BC * 4, None, capi.MEM_DEVICE),
+                               ctx.handle)
+                ops = []
+                if rank == 0:
+                    if n > 0:
+                        R_all[(cuts[0][k]) * 528:(cuts[0][k] + n) * 528].copy_(r[off * 528:(off + n) * 528])
+                    for peer in range(1, world):
+                        a, b = cuts[peer][k], cuts[peer][k + 1]
+                        if b > a:
+                            ops.append(dist.P2POp(dist.irecv, R_all[a * 528:b * 528], peer))
+                elif n > 0:
+                    ops.append(dist.P2POp(dist.isend, r[off * 528:(off + n) * 528].to(xdev), 0))
+                if ops:
+                    reqs.extend(dist.batch_isend_irecv(ops))      # (not waited for: the next piece is factorised meanwhile)
+            for w in reqs:
+                w.wait()
+            gather_ragged_to_root((p + base_col).to(xdev), p_sizes, P_all, 0, rank, world)
+
+        def timed_fn(iters, fn):
+            dist.barrier(); torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(iters):
+                fn()
+            torch.cuda.synchronize(); dist.barrier()
+            dt = time.perf_counter() - t0
+            tt = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            return tt.item() / iters
+
         iters = 50 if B <= 100000 else 10
         timed(3, True)
         with_g = timed(iters, True)
         without = timed(iters, False)
+        timed_fn(3, step_x)
+        with_x = timed_fn(iters, step_x)
+        timed_fn(3, step_ov)
+        with_ov = timed_fn(iters, step_ov)
         res.append({"blocks": B, "blocks_per_rank": [b - a for a, b in ranges], "ms_per_factorization_with_gather": with_g * 1e3,
                     "ms_factorize_only": without * 1e3, "gather_ms": (with_g - without) * 1e3,
                     "factorizations_per_s": 1.0 / with_g, "block_factorizations_per_s": B / with_g,
-                    "gathered_bytes_on_root": B * (528 * 8 + BC * 4)})
+                    "gathered_bytes_on_root": B * (528 * 8 + BC * 4),
+                    "ms_factorize_solve_gather_x_only": with_x * 1e3, "x_bytes_on_root": B * BC * 8,
+                    "ms_factorize_with_gather_overlapped": with_ov * 1e3, "pieces": PIECES})
         capi.lib().qrk_bd_plan_destroy(plan)
-        del t, q, r, p, R_all, P_all
+        for pp_, _, n in pplans:
+            if n > 0:
+                capi.lib().qrk_bd_plan_destroy(pp_)
+        del t, q, r, p, R_all, P_all, X_all
     return {"scaling": "strong", "collective": "grouped send/recv of R (f64) and perm (i32) shards to rank 0, true byte counts, "
-                                               "inside the timed region", "backend": backend, "runs": res}
+                                               "inside the timed region; also timed: the least-squares consumer (block-local solve, x only "
+                                               "gathered) and the gather of R in pieces behind the factorisation of the next piece",
+            "backend": backend, "runs": res}
 
 
 def _timed(dist, torch, dev, backend, fn, iters):
@@ -486,15 +558,36 @@ def _timed(dist, torch, dev, backend, fn, iters):
 
 
 def strong_shard_emulation(ctx, dev, torch, np, make_plan, run):
-    """What ONE GPU would do in the strong-scaling legs (B tiles of 32 x 32 cut into N contiguous shards, R and perm of
-    the remote shards gathered on rank 0), timed on this one GPU: T(B / N) for N in {1, 2, 4, 8} of B = 10 000 and B = 1 000 000, the
-    bytes rank 0 receives, and the speed-up these imply at best (the gather priced at one xGMI link per sender, 153 GB/s nominal).
-    UNMEASURED on more than one GPU: an upper bound from the kernel's own latency law, not a scaling result."""
+    """What ONE GPU would do in the strong-scaling legs (B tiles of 32 x 32 cut into N contiguous shards), timed on this
+    one GPU for N in {1, 2, 4, 8} of B = 10 000 and B = 1 000 000, with the bytes each consumer moves to rank 0 priced at one xGMI
+    link per sender (153 GB/s nominal), and the speed-up these imply at best.  Three consumers:
+      * R gathered (ShardedBlockDiagonalQR.gatherR): T(B / N) + the R / perm bytes of one shard over its link;
+      * R gathered, overlapped (computeGatherR, 4 pieces per rank): the shard factorised as 4 launches of B / (4 N) tiles (timed here),
+        a piece's R on its way during the next piece -- max(factorisation, gather) + the smaller of the two / 4;
+      * x only (ShardedBlockDiagonalQR.solve): factorisation + block-local solve of the shard (both timed here) + 256 B per tile.
+    UNMEASURED on more than one GPU: upper bounds from the kernels' own latency laws, not a scaling result."""
     from qrkit_amd import _capi as capi
     XGMI_LINK_GBS = 153.0
+    PIECES = 4
     out = []
+
+    def solve_us(plan, nb, q, r, p, iters):
+        b = torch.rand(nb * BR, device=dev, dtype=torch.float64)
+        x = torch.empty(nb * BC, device=dev, dtype=torch.float64)
+        go = lambda: capi.check(capi.lib().qrk_bd_solve(plan, q.data_ptr(), r.data_ptr(), p.data_ptr(), b.data_ptr(), 1, x.data_ptr(),
+                                                         capi.MEM_DEVICE), ctx.handle)
+        for _ in range(3):
+            go()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            go()
+        e1.record(); torch.cuda.synchronize()
+        return e0.elapsed_time(e1) * 1e3 / iters
+
     for B, iters in ((10000, 200), (1000000, 6)):
-        per = {}
+        per, per_solve, per_pieces = {}, {}, {}
         for N in (1, 2, 4, 8):
             nb = B // N
             plan = make_plan(nb)
@@ -506,20 +599,38 @@ def strong_shard_emulation(ctx, dev, torch, np, make_plan, run):
             p = torch.empty(S * nb * BC, device=dev, dtype=torch.int32)
             run(plan, max(2, iters // 10), t, q, r, p, S)
             per[N] = min(run(plan, iters, t, q, r, p, S) for _ in range(3)) * 1e3      # us per launch
+            per_solve[N] = solve_us(plan, nb, q, r, p, max(3, iters // 4))
             capi.lib().qrk_bd_plan_destroy(plan)
+            # the shard as PIECES launches of nb / PIECES tiles, one after the other on the stream
+            npc = nb // PIECES
+            pplan = make_plan(npc)
+            run(pplan, PIECES * 2, t, q, r, p, PIECES)
+            per_pieces[N] = min(run(pplan, PIECES * max(2, iters // 4), t, q, r, p, PIECES) for _ in range(3)) * 1e3 * PIECES
+            capi.lib().qrk_bd_plan_destroy(pplan)
             del t, q, r, p
         legs = []
         for N in (2, 4, 8):
-            recv = (B - B // N) * (528 * 8 + BC * 4)                 # bytes rank 0 receives (R f64 + perm i32 of the other shards)
-            gather_us = (B // N) * (528 * 8 + BC * 4) / (XGMI_LINK_GBS * 1e3)        # every sender on its own link to rank 0, concurrently
-            legs.append({"gpus": N, "tiles_per_gpu": B // N, "shard_us": per[N], "gather_bytes_to_rank0": recv,
-                         "gather_us_at_one_link_per_sender": gather_us,
+            nb = B // N
+            r_bytes = nb * (528 * 8 + BC * 4)                        # one sender's R (f64) + perm (i32)
+            x_bytes = nb * BC * 8                                    # one sender's x, one right-hand side
+            gather_us = r_bytes / (XGMI_LINK_GBS * 1e3)             # every sender on its own link to rank 0, concurrently
+            x_us = x_bytes / (XGMI_LINK_GBS * 1e3)
+            t_r = per[N] + gather_us
+            t_ov = max(per_pieces[N], gather_us) + min(per_pieces[N], gather_us) / PIECES
+            t_x = per[N] + per_solve[N] + x_us
+            legs.append({"gpus": N, "tiles_per_gpu": nb, "shard_us": per[N], "shard_in_%d_pieces_us" % PIECES: per_pieces[N],
+                         "shard_solve_us": per_solve[N],
+                         "gather_bytes_to_rank0": (B - nb) * (528 * 8 + BC * 4), "gather_us_at_one_link_per_sender": gather_us,
+                         "x_bytes_to_rank0": (B - nb) * BC * 8, "x_us_at_one_link_per_sender": x_us,
                          "speedup_upper_bound_no_gather": per[1] / per[N],
-                         "speedup_upper_bound_with_gather": per[1] / (per[N] + gather_us)})
-        out.append({"blocks": B, "one_gpu_us": per[1], "legs": legs})
-    return {"what": "one-GPU emulation of the per-GPU shard of the strong-scaling legs (unmeasured on 8 GPUs): the shard's launch time on "
-                    "this GPU, the bytes of the R / perm gather and the speed-up they bound",
-            "xgmi_link_GBs_nominal": XGMI_LINK_GBS, "runs": out}
+                         "speedup_upper_bound_with_gather": per[1] / t_r,
+                         "speedup_upper_bound_with_gather_overlapped": per[1] / t_ov,
+                         "speedup_upper_bound_x_only": (per[1] + per_solve[1]) / t_x})
+        out.append({"blocks": B, "one_gpu_us": per[1], "one_gpu_solve_us": per_solve[1], "legs": legs})
+    return {"what": "one-GPU emulation of the per-GPU shard of the strong-scaling legs (unmeasured on 8 GPUs): the shard's launch and solve "
+                    "times on this GPU, the bytes of the three consumers (R gathered / R gathered overlapped with the factorisation of the "
+                    "next piece / x only) and the speed-ups they bound",
+            "xgmi_link_GBs_nominal": XGMI_LINK_GBS, "pieces": PIECES, "runs": out}
 
 
 def concurrent_streams(dev, torch, tiles, qv, rv, pm, S, steps=300):

@@ -532,6 +532,31 @@ class ShardedBlockDiagonalSparseQR : public BlockDiagonalSparseQR<BlockQRSolver,
         if (dp) qrk_device_free(this->m_handle, dp);
         this->check(st);
     }
+    // The least-squares solve of the whole matrix without the composed R: _solve_impl (BlockDiagonalSparseQR.h:257-280) is block-local,
+    // so every rank solves its own range (bLocal: the rows of b that belong to it) and ONLY x is gathered -- 8 bytes per column against
+    // the 4 224 + 128 bytes per 32 x 32 tile of gatherR.  On the root: x of the whole matrix; elsewhere empty.  Collective.
+    Vector solve(const Vector& bLocal, int root) const {
+        const qrk_shard& end = m_shards[(size_t)m_world];
+        const int64_t nc = m_shards[(size_t)m_rank + 1].base_col - shard().base_col;
+        Vector xl;
+        if (m_local.size() > 0) xl = Base::solve(bLocal);
+        void *dxl = 0, *dx = 0;
+        qrk_status st = qrk_device_alloc(this->m_handle, std::max<int64_t>(nc, 1) * (int64_t)sizeof(double), &dxl);
+        if (st == QRK_STATUS_OK && m_rank == root) st = qrk_device_alloc(this->m_handle, std::max<int64_t>(end.base_col, 1) * (int64_t)sizeof(double), &dx);
+        if (st == QRK_STATUS_OK && nc > 0) st = qrk_memcpy(this->m_handle, dxl, xl.data(), nc * (int64_t)sizeof(double), 0);
+        if (st == QRK_STATUS_OK)
+            st = qrk_gather_x(this->m_handle, m_comm, (int32_t)m_rank, (int32_t)m_world, (int32_t)root, m_shards.data(), (const double*)dxl, 1, (double*)dx);
+        Vector x;
+        if (st == QRK_STATUS_OK && m_rank == root) {
+            x.assign((size_t)end.base_col, 0.0);
+            if (end.base_col > 0) st = qrk_memcpy(this->m_handle, x.data(), dx, end.base_col * (int64_t)sizeof(double), 1);
+        }
+        if (st == QRK_STATUS_OK) st = qrk_synchronize(this->m_handle);
+        if (dxl) qrk_device_free(this->m_handle, dxl);
+        if (dx) qrk_device_free(this->m_handle, dx);
+        this->check(st);
+        return x;
+    }
   protected:
     int m_rank, m_world;
     void* m_comm;

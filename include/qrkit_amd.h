@@ -458,6 +458,15 @@ qrk_status qrk_shard_ranges(int64_t num_blocks, int32_t block_rows, int32_t bloc
 qrk_status qrk_gather_r(qrk_handle h, void* nccl_comm, int32_t rank, int32_t world, int32_t root, const qrk_shard* shards,
                         const double* r_local, const int32_t* perm_local, double* r_all, int32_t* perm_all);
 
+/* The sharded SOLVE: _solve_impl (BlockDiagonalSparseQR.h:257-280) is block-local -- x_g = P_g R_g^-1 (Q_g^T b_g)(0:cols_g) needs
+ * only the rank's own Q, R and permutation (qrk_bd_solve on the rank's plan) -- so a least-squares consumer never needs the composed
+ * R: only x travels, 8 bytes per column and right-hand side (256 B per 32 x 32 tile against 4 352 B of R and permutation).
+ * x_local: this rank's solution as qrk_bd_solve wrote it (device; nrhs vectors of cols_g entries, vector k at k * cols_g).  x_all: device,
+ * root only: nrhs vectors of the whole matrix's columns, vector k at k * total_cols, rank g's piece at base_col of its shard.  One
+ * grouped ncclSend / ncclRecv per peer and right-hand side, true counts, on the handle's stream. */
+qrk_status qrk_gather_x(qrk_handle h, void* nccl_comm, int32_t rank, int32_t world, int32_t root, const qrk_shard* shards,
+                        const double* x_local, int64_t nrhs, double* x_all);
+
 /* The two exchanges of the ANGULAR solver sharded by rows (the TSQR route of qrk_tsqr_* above; BlockAngularSparseQR.h:361-369, 459-514;
  * host side: qrkit::ShardedBlockAngularSparseQR, qrkit_amd/sharding.py): every rank's `count` doubles to `root` (recv: world * count
  * doubles on the root, piece g at g * count; one n x n triangle, or one n-vector, per rank), and `bytes` bytes at `buf` from `root` to

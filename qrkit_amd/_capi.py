@@ -30,7 +30,7 @@ EXPORTS = (
     "qrk_sparse_window_to_dense",
     "qrk_thin_sparse_factorize", "qrk_thin_destroy", "qrk_thin_info", "qrk_thin_matrix_r", "qrk_thin_apply_q", "qrk_thin_solve",
     "qrk_bbs_plan_create", "qrk_bbs_plan_destroy", "qrk_bbs_plan_sizes", "qrk_bbs_factorize", "qrk_bbs_r_rows", "qrk_bbs_apply_q", "qrk_bbs_solve",
-    "qrk_shard_ranges", "qrk_gather_r",
+    "qrk_shard_ranges", "qrk_gather_r", "qrk_gather_x",
 )
 
 

@@ -2413,6 +2413,43 @@ qrk_status qrk_gather_r(qrk_handle h, void* nccl_comm, int32_t rank, int32_t wor
     return QRK_STATUS_OK;
 }
 
+qrk_status qrk_gather_x(qrk_handle h, void* nccl_comm, int32_t rank, int32_t world, int32_t root, const qrk_shard* sh,
+                        const double* x_local, int64_t nrhs, double* x_all)
+{
+    if (!h || !sh || world <= 0 || rank < 0 || rank >= world || root < 0 || root >= world || nrhs < 0 || (world > 1 && !nccl_comm) ||
+        (rank == root && !x_all && nrhs > 0))
+        return fail(h, QRK_STATUS_INVALID_ARGUMENT, "qrk_gather_x: bad argument");
+    QRK_HIP(h, hipSetDevice(h->device));
+    const int64_t total = sh[world].base_col, nc = sh[rank + 1].base_col - sh[rank].base_col;
+    if (nc > 0 && nrhs > 0 && !x_local) return fail(h, QRK_STATUS_INVALID_ARGUMENT, "qrk_gather_x: NULL shard");
+    if (nrhs == 0) return QRK_STATUS_OK;
+    if (rank == root && nc > 0)
+        QRK_HIP(h, hipMemcpy2DAsync(x_all + sh[rank].base_col, (size_t)total * sizeof(double), x_local, (size_t)nc * sizeof(double),
+                                    (size_t)nc * sizeof(double), (size_t)nrhs, hipMemcpyDeviceToDevice, h->stream));
+    if (world > 1) {
+        const RcclApi& api = rccl_api();
+        if (!api.ok) return fail(h, QRK_STATUS_UNSUPPORTED, "qrk_gather_x: no RCCL in this process and librccl.so cannot be loaded");
+        ncclComm_t comm = static_cast<ncclComm_t>(nccl_comm);
+        ncclResult_t e = api.GroupStart();
+        if (e != ncclSuccess) return fail(h, QRK_STATUS_HIP_ERROR, "qrk_gather_x: ncclGroupStart failed");
+        for (int64_t k = 0; k < nrhs && e == ncclSuccess; ++k) {
+            if (rank == root) {
+                for (int32_t peer = 0; peer < world && e == ncclSuccess; ++peer) {
+                    const int64_t pc = sh[peer + 1].base_col - sh[peer].base_col;
+                    if (peer != root && pc > 0) e = api.Recv(x_all + k * total + sh[peer].base_col, (size_t)pc, ncclFloat64, peer, comm, h->stream);
+                }
+            } else if (nc > 0) {
+                e = api.Send(x_local + k * nc, (size_t)nc, ncclFloat64, root, comm, h->stream);
+            }
+        }
+        const ncclResult_t e2 = api.GroupEnd();
+        if (e != ncclSuccess || e2 != ncclSuccess)
+            return fail(h, QRK_STATUS_HIP_ERROR, std::string("qrk_gather_x: ncclSend / ncclRecv: ") +
+                                                     (api.GetErrorString ? api.GetErrorString(e != ncclSuccess ? e : e2) : "RCCL error"));
+    }
+    return QRK_STATUS_OK;
+}
+
 const char* qrk_bd_kernel_name(qrk_bd_plan p, int which)
 {
     (void)which;

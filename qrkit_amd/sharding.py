@@ -107,7 +107,8 @@ def all_gather_ragged(local: torch.Tensor, group=None, sizes: Sequence[int] = No
 
 
 class ShardedBlockDiagonalQR:
-    """Each rank factorises its contiguous block range; gatherR()/gatherPerm() compose the global factor.
+    """Each rank factorises its contiguous block range; gatherR()/gatherPerm() compose the global factor, solve() answers the least-squares
+    problem with x as the only thing that travels, computeGatherR() hides the gather of R behind the factorisation of the next piece.
 
     `solver_factory()` returns an object with the BlockDiagonalSparseQR interface (compute, rValues,
     qValues, colsPermutation); the default is the HIP solver on this rank's GPU.
@@ -165,6 +166,144 @@ class ShardedBlockDiagonalQR:
         out = torch.empty(sum(sizes), dtype=torch.int32, device=p.device) if self.rank_id == root else None
         gather_ragged_to_root(p, sizes, out, root, self.rank_id, self.world, self.group)
         return out
+
+
+    # -- consumers that scale: the gather of R is the bound of the strong-scaling legs (4 352 B per 32 x 32 tile over one xGMI link per
+    #    sender, bench.py strong_shard_emulation), so (1) a least-squares consumer gathers x only and (2) a consumer that does need R
+    #    sends a chunk while the next one is being factorised
+    def solve(self, b_local, root=None) -> torch.Tensor:
+        """x = solve(J, b) without the composed R.  _solve_impl (BlockDiagonalSparseQR.h:257-280) is block-local -- Q, R and the column
+        permutation are block diagonal -- so the rank solves its own range on its own factors (b_local: the rows of b that belong
+        to its blocks; [rows_g] or [rows_g, nrhs]) and ONLY x travels: 8 bytes per column and right-hand side (256 B per 32 x 32 tile
+        against 4 352 B of R and permutation).  Returns x of the whole matrix ([cols] or [cols, nrhs]) on every rank (root=None) or on
+        `root` (None elsewhere)."""
+        x = self.solver.solve(b_local)
+        x = torch.as_tensor(x)
+        vec = x.dim() == 1
+        x2 = x.reshape(x.shape[0], -1).contiguous()                  # [cols_g, nrhs] row-major: shards concatenate along dim 0
+        nrhs = x2.shape[1]
+        sizes = [n * nrhs for n in self._c_sizes()]
+        flat = x2.reshape(-1)
+        if root is None:
+            out = all_gather_ragged(flat, self.group, sizes)
+        else:
+            out = torch.empty(sum(sizes), dtype=flat.dtype, device=flat.device) if self.rank_id == root else None
+            gather_ragged_to_root(flat, sizes, out, root, self.rank_id, self.world, self.group)
+            if out is None:
+                return None
+        out = out.reshape(-1, nrhs)
+        return out[:, 0] if vec else out
+
+    def chunk_ranges(self, chunks: int) -> List[Tuple[int, int]]:
+        """The rank's block range cut into `chunks` contiguous pieces balanced like the shards themselves (global block indices)."""
+        lr, lc = self.local_layout()
+        return [(self.start + a, self.start + b) for a, b in shard_ranges(lr, lc, max(1, int(chunks)))]
+
+    def computeGatherR(self, local_mat, chunks: int = 4, root: int = 0, slice_mat=None, solver_factory=None):
+        """compute() + gatherR(root) with the exchange hidden behind the arithmetic: the rank's range is cut into `chunks` pieces, each
+        with its own plan; piece i is factorised and its R posted (non-blocking grouped send / receive, true byte counts) while piece
+        i + 1 is being factorised -- over RCCL the transfers run on the communicator's stream beside the kernels of the next piece.
+        Every rank uses the same number of pieces (the root posts one receive per peer and piece).  Returns the composed packed R on
+        `root` (None elsewhere); afterwards rValues() / colsPermutation() / solve() of this object answer from the pieces.
+        slice_mat(local_mat, a, b): the blocks [a, b) of the rank's matrix (default: SparseBlockDiagonal tiles, host or device)."""
+        chunks = max(1, int(chunks))
+        if slice_mat is None:
+            slice_mat = _slice_block_diagonal
+        if solver_factory is None:
+            solver_factory = type(self.solver)
+        c = self.block_cols.astype(np.int64)
+        r_len = lambda a, b: int((c[a:b] * (c[a:b] + 1) // 2).sum())
+        pieces = [ShardedBlockDiagonalQR.chunk_ranges(_Range(self.block_rows, self.block_cols, a, b), chunks) for a, b in self.ranges]
+        mine = pieces[self.rank_id]
+        sizes = self._r_sizes()
+        out = None
+        solvers, reqs, keep = [], [], []
+        for i, (a, b) in enumerate(mine):
+            sv = solver_factory()
+            if b > a:
+                sv.compute(slice_mat(local_mat, a - self.start, b - self.start))
+            solvers.append((a, b, sv))
+            if self.rank_id == root:
+                if out is None:
+                    ref = sv.rValues() if b > a else None
+                    dev = ref.device if ref is not None else "cpu"
+                    out = torch.empty(sum(sizes), dtype=torch.float64, device=dev)
+                ops = []
+                for peer in range(self.world):
+                    pa, pb = pieces[peer][i]
+                    off = r_len(0, pa)
+                    n = r_len(pa, pb)
+                    if n == 0:
+                        continue
+                    if peer == root:
+                        out[off:off + n].copy_(sv.rValues())
+                    else:
+                        ops.append(dist.P2POp(dist.irecv, out[off:off + n], peer, self.group))
+            else:
+                ops = []
+                if b > a:
+                    src = sv.rValues().contiguous()
+                    if out is not None and src.device != out.device:
+                        src = src.to(out.device)
+                    keep.append(src)
+                    ops.append(dist.P2POp(dist.isend, src, root, self.group))
+            if ops and self.world > 1:
+                reqs.extend(dist.batch_isend_irecv(ops))          # (not waited for here: the next piece is factorised meanwhile)
+        for q in reqs:
+            q.wait()
+        self.solver = _ChunkedSolver(solvers, self.block_rows, self.block_cols, self.start)
+        return out if self.rank_id == root else None
+
+
+class _Range:
+    """(helper of computeGatherR) the layout fields chunk_ranges reads, for any rank's block range"""
+
+    def __init__(self, block_rows, block_cols, start, end):
+        self.block_rows, self.block_cols, self.start, self.end = block_rows, block_cols, start, end
+
+    def local_layout(self):
+        return self.block_rows[self.start:self.end], self.block_cols[self.start:self.end]
+
+
+def _slice_block_diagonal(mat, a: int, b: int):
+    """Blocks [a, b) of a SparseBlockDiagonal (host or device tiles) as a SparseBlockDiagonal of its own: a view, no copy."""
+    from .solvers import SparseBlockDiagonal
+    sz = mat.block_rows.astype(np.int64) * mat.block_cols.astype(np.int64)
+    t0, t1 = int(sz[:a].sum()), int(sz[:b].sum())
+    tiles = mat.tiles_dev[t0:t1] if mat.tiles_dev is not None else mat.tiles[t0:t1]
+    return SparseBlockDiagonal.fromTiles(mat.block_rows[a:b], mat.block_cols[a:b], tiles)
+
+
+class _ChunkedSolver:
+    """The solvers of the pieces of computeGatherR behind the interface ShardedBlockDiagonalQR uses (rValues, qValues,
+    colsPermutation, solve): concatenations in block order, local column indices re-based to the rank's range."""
+
+    def __init__(self, pieces, block_rows, block_cols, start):
+        self.pieces = [(a, b, sv) for a, b, sv in pieces if b > a]
+        self._rows = np.asarray(block_rows, dtype=np.int64)
+        self._cols = np.asarray(block_cols, dtype=np.int64)
+        self._start = start
+
+    def rValues(self):
+        return torch.cat([sv.rValues().reshape(-1) for _, _, sv in self.pieces])
+
+    def qValues(self):
+        return torch.cat([sv.qValues().reshape(-1) for _, _, sv in self.pieces])
+
+    def colsPermutation(self):
+        out = []
+        for a, _, sv in self.pieces:
+            out.append(np.asarray(sv.colsPermutation()) + int(self._cols[self._start:a].sum()))
+        return np.concatenate(out) if out else np.zeros(0, np.int32)
+
+    def solve(self, b):
+        bt = torch.as_tensor(b)
+        xs, r0 = [], 0
+        for a, e, sv in self.pieces:
+            nr = int(self._rows[a:e].sum())
+            xs.append(torch.as_tensor(sv.solve(bt[r0:r0 + nr])))
+            r0 += nr
+        return torch.cat(xs, dim=0)
 
 
 class ShardedBlockAngularQR:

@@ -80,6 +80,15 @@ int main() {
     for (size_t j = 0; ok && j < perm.size(); ++j) ok = perm[j] == whole.colsPermutation().indices()[j];
     std::printf("ShardedBlockDiagonalSparseQR world 1 over RCCL, %zu R values, %zu columns: %s\n", rv.size(), perm.size(), ok ? "Passed." : "Failed.");
     if (!ok) ++fails;
+    {
+        // the sharded solve: block-local solve + gather of x only (qrk_gather_x); world 1: bit for bit the un-sharded solver's x
+        Vector b((size_t)rows);
+        for (double& v : b) v = u(g);
+        const Vector xs = shard.solve(b, 0), xw = whole.solve(b);
+        const bool oks = xs.size() == xw.size() && xs.size() == (size_t)cols && std::memcmp(xs.data(), xw.data(), xs.size() * sizeof(double)) == 0;
+        std::printf("ShardedBlockDiagonalSparseQR::solve (x only gathered), %zu columns: %s\n", xs.size(), oks ? "Passed." : "Failed.");
+        if (!oks) ++fails;
+    }
 
     // ShardedBlockAngularSparseQR with world = 1 over the same communicator: 400 tiles of 8 x 6 on the left, 96 dense columns on the
     // right, rows below the left block as well; the least-squares solution must be the un-sharded BlockAngularSparseQR's and the

@@ -141,3 +141,4 @@ def test_c_shard_ranges_match_the_python_mirror():
     assert [s.num_blocks for s in sh[:8]] == [1250] * 8 and sh[8].tiles_off == 10000 * 1024
     assert lib.qrk_shard_ranges(10, 0, 0, None, None, 2, sh) == _capi.STATUS_INVALID_ARGUMENT
     assert lib.qrk_gather_r(None, None, 0, 1, 0, sh, None, None, None, None) == _capi.STATUS_INVALID_ARGUMENT
+    assert lib.qrk_gather_x(None, None, 0, 1, 0, sh, None, 1, None) == _capi.STATUS_INVALID_ARGUMENT

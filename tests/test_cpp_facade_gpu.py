@@ -36,7 +36,7 @@ def test_cpp_sharded_world1_over_rccl():
     out = subprocess.run([os.path.join(ROOT, "build", "test_sharded")], capture_output=True, text=True, timeout=600)
     print(out.stdout, out.stderr)
     assert out.returncode == 0, out.stdout + out.stderr
-    assert "Failed." not in out.stdout and out.stdout.count("Passed.") == 3
+    assert "Failed." not in out.stdout and out.stdout.count("Passed.") == 4
 
 
 def test_cpp_facade_compiles():

@@ -1,5 +1,6 @@
 """Multi-process tests of the multi-GPU path (gloo): shard -> per-rank factorisation -> gather of R / perm reproduces the
-unsharded factorisation.
+unsharded factorisation; the sharded solve (block-local, x only gathered) reproduces the un-sharded _solve_impl; the overlapped gather
+(pieces of the range, a piece's R on its way while the next piece is factorised) reproduces the plain one.
 
 * CPU (world 2 and 3): the per-rank worker is an oracle-backed stand-in with the solver interface -- a test of the sharding and
   of the ragged gathers (to every rank, and to the root only with true byte counts), not of the kernels.
@@ -21,7 +22,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 class _OracleSolver:
     def compute(self, mat):
         from oracle import oracle as orc
-        self._res = orc.BDProblem(mat["rows"], mat["cols"], mat["tiles"]).factorize()
+        self._prob = orc.BDProblem(mat["rows"], mat["cols"], mat["tiles"])
+        self._res = self._prob.factorize()
+
+    def solve(self, b):
+        return torch.from_numpy(np.ascontiguousarray(self._prob.solve(self._res, np.asarray(b, dtype=np.float64))))
 
     def rValues(self):
         return torch.from_numpy(self._res.R_vals.copy())
@@ -33,7 +38,7 @@ class _OracleSolver:
         return self._res.perm
 
 
-def _worker(rank, world, port, rows, cols, tiles, out, use_gpu):
+def _worker(rank, world, port, rows, cols, tiles, b, out, use_gpu):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -67,6 +72,42 @@ def _worker(rank, world, port, rows, cols, tiles, out, use_gpu):
     np.save(f"{out}_R{rank}.npy", R); np.save(f"{out}_P{rank}.npy", P)
     if rank == 0:
         np.save(out + "_R0.root.npy", R0.numpy()); np.save(out + "_P0.root.npy", P0.numpy())
+    # the sharded solve: block-local solve, x only gathered (every rank / the root only; one and three right-hand sides)
+    r0, r1 = int(rows[:sh.start].sum()), int(rows[:sh.end].sum())
+    if use_gpu:
+        sh.solver = sh.solver.i
+        class _HostX:
+            def __init__(s, inner): s.i = inner
+            def rValues(s): return s.i.rValues().cpu()
+            def colsPermutation(s): return s.i.colsPermutation()
+            def solve(s, b): return torch.as_tensor(s.i.solve(b)).cpu()
+        sh.solver = _HostX(sh.solver)
+    x_all = sh.solve(torch.from_numpy(b[r0:r1]))
+    x_root = sh.solve(torch.from_numpy(b[r0:r1]), root=0)
+    x3 = sh.solve(torch.from_numpy(np.stack([b[r0:r1], 2.0 * b[r0:r1], -b[r0:r1]], axis=1)))
+    assert (x_root is None) == (rank != 0)
+    np.save(f"{out}_x{rank}.npy", x_all.numpy()); np.save(f"{out}_x3_{rank}.npy", x3.numpy())
+    if rank == 0:
+        np.save(out + "_x.root.npy", x_root.numpy())
+    # the overlapped gather: the range in three pieces, a piece's R on its way while the next one is factorised; then the solve
+    # through the pieces
+    if use_gpu:
+        import qrkit_amd
+        class _HostSolver(qrkit_amd.BlockDiagonalSparseQR):
+            def rValues(s): return super().rValues().cpu()
+            def solve(s, bb): return torch.as_tensor(super().solve(bb)).cpu()
+        local = qrkit_amd.SparseBlockDiagonal.fromTiles(lr, lc, tiles[t0:t1])
+        Rov = sh.computeGatherR(local, chunks=3, root=0, solver_factory=_HostSolver)
+    else:
+        cut = lambda m, a, e: {"rows": m["rows"][a:e], "cols": m["cols"][a:e],
+                               "tiles": m["tiles"][int((m["rows"][:a].astype(np.int64) * m["cols"][:a]).sum()):
+                                                   int((m["rows"][:e].astype(np.int64) * m["cols"][:e]).sum())]}
+        Rov = sh.computeGatherR({"rows": lr, "cols": lc, "tiles": tiles[t0:t1]}, chunks=3, root=0, slice_mat=cut, solver_factory=_OracleSolver)
+    assert (Rov is None) == (rank != 0)
+    if rank == 0:
+        np.save(out + "_Rov.npy", Rov.numpy())
+    np.save(f"{out}_Pov{rank}.npy", sh.gatherPerm().numpy())
+    np.save(f"{out}_xov{rank}.npy", sh.solve(torch.from_numpy(b[r0:r1])).numpy())
     dist.barrier()
     dist.destroy_process_group()
 
@@ -78,10 +119,13 @@ def _run(tmp_path, world, use_gpu, seed=2, B=37):
     cols = rng.integers(1, 20, B).astype(np.int32)
     rows = (cols + rng.integers(0, 5, B)).astype(np.int32)
     tiles = orc.gen_uniform(9, -1.0, 1.0, int((rows.astype(np.int64) * cols).sum()))
-    ref = orc.BDProblem(rows, cols, tiles).factorize()
+    prob = orc.BDProblem(rows, cols, tiles)
+    ref = prob.factorize()
+    b = rng.uniform(-1.0, 1.0, int(rows.sum()))
+    xref = prob.solve(ref, b)
     out = str(tmp_path / "g")
     port = 29500 + (os.getpid() % 2000) + world
-    mp.spawn(_worker, args=(world, port, rows, cols, tiles, out, use_gpu), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, rows, cols, tiles, b, out, use_gpu), nprocs=world, join=True)
     for rank in range(world):
         np.testing.assert_array_equal(np.load(f"{out}_P{rank}.npy"), ref.perm)
         if use_gpu:
@@ -90,6 +134,22 @@ def _run(tmp_path, world, use_gpu, seed=2, B=37):
             np.testing.assert_array_equal(np.load(f"{out}_R{rank}.npy"), ref.R_vals)
     np.testing.assert_array_equal(np.load(out + "_P0.root.npy"), ref.perm)
     np.testing.assert_array_equal(np.load(out + "_R0.root.npy"), np.load(f"{out}_R0.npy"))
+    # the sharded solve (x only gathered) = the un-sharded _solve_impl; the overlapped gather = the plain one
+    tol = 1e-9 if use_gpu else 0.0
+    for rank in range(world):
+        for name, want in (("x", xref), ("xov", xref)):
+            got = np.load(f"{out}_{name}{rank}.npy")
+            assert got.shape == xref.shape and np.linalg.norm(got - want) <= tol * np.linalg.norm(want), (name, rank)
+        x3 = np.load(f"{out}_x3_{rank}.npy")
+        assert x3.shape == (xref.size, 3)
+        for k, f in enumerate((1.0, 2.0, -1.0)):
+            assert np.linalg.norm(x3[:, k] - f * xref) <= max(tol, 1e-13) * np.linalg.norm(xref)
+        np.testing.assert_array_equal(np.load(f"{out}_Pov{rank}.npy"), ref.perm)
+    np.testing.assert_array_equal(np.load(out + "_x.root.npy"), np.load(f"{out}_x0.npy"))
+    if use_gpu:
+        assert np.linalg.norm(np.load(out + "_Rov.npy") - ref.R_vals) <= 1e-12 * np.linalg.norm(ref.R_vals)
+    else:
+        np.testing.assert_array_equal(np.load(out + "_Rov.npy"), ref.R_vals)
 
 
 @pytest.mark.parametrize("world", [2, 3])
