@@ -35,7 +35,7 @@
 // Two kernels share the step: bdqr_pair_kernel (one pair per workgroup, any tile shape <= 32x32,
 // coalesced I/O staged through LDS) and bdqr_pair32_kernel (uniform 32x32 batches: persistent
 // workgroups that prefetch their next tile into dead registers and store Q rows straight from
-// registers).  Measured history and the per-phase cycle counts are in DESIGN.md.
+// registers).  Measured history and the per-phase cycle counts are in HISTORY.md (the current numbers in DESIGN.md).
 #include "qrk_device.h"
 #include "bdqr_exact_tile.h"
 
