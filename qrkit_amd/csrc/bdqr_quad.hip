@@ -18,9 +18,11 @@
 // over a tile stops at the half-row mirror.  See the hazard note at fmac_bcast.
 // Tiles with fewer than 16 (8) rows are zero-padded below (zero rows change neither the reflectors nor any sum); the steps run to the
 // launch's number of columns.  Decisions exactly as bdqr_pair.hip ("Decisions and the exact path"): integer arg-max on the high
-// words with a filter, margins, LAWN-176 band, degenerate reflector, sign of beta, noise-level pivot; a flagged tile goes to the redo
-// list of the exact path (bdqr_exact.hip), like bdqr_small.hip's.
+// words with a filter, margins, LAWN-176 band, degenerate reflector, sign of beta, noise-level pivot; a flagged tile is redone by the
+// wave itself after its rounds, in Eigen's own operation order (bdqr_exact_tile.h, as bdqr_pair4.hip does) -- round 6: no redo list and no
+// second launch behind this one, which at BASELINE configs[3]'s 20 000 tiles of 8 x 6 was a third of the time of factorize().
 #include "qrk_device.h"
+#include "bdqr_exact_tile.h"
 
 #include <float.h>
 
@@ -360,6 +362,40 @@ __device__ __forceinline__ void back_step(double (&q)[WR], const double* tl, con
     }
 }
 
+// A flagged tile again, by the wave that factorised it, in Eigen's own operation order (bitwise what bdqr_exact_kernel computes): the
+// tables, the working copy and Q in the wave's LDS
+template <int WR, bool PIVOT>
+__device__ __noinline__ void redo_exact(int64_t t, int r, int c, double* lds, const double* __restrict__ tiles, double* __restrict__ q_vals,
+                                        double* __restrict__ r_vals, int32_t* __restrict__ perm, double* __restrict__ hcoeffs)
+{
+    static_assert((64 / WR) * Lay<WR>::L_TILE * 8 >= (4 * WR + 64) * 8 + (2 * WR + 64) * 4 + 16 + 2 * WR * WR * 8, "tables + W + Q in the wave's LDS");
+    exact::Shared sh;
+    double* W = exact::carve_shared<64>(reinterpret_cast<unsigned char*>(lds), WR, WR, sh);
+    double* q = W + r * c;
+    const int nr = (c * (c + 1)) >> 1;
+    __syncthreads();
+    exact::tile_qr<PIVOT, 64>(r, c, tiles + t * (int64_t)(r * c), W, q, sh);
+    exact::tile_store<64>(r, c, (int)(t * c), W, q, sh, perm, hcoeffs, r_vals + t * nr, q_vals + t * (int64_t)(r * r));
+    __syncthreads();
+}
+
+// the flagged tiles of a chunk of rounds: bit rnd of flagbits in the lanes of tile slot g2
+template <int WR, bool PIVOT>
+__device__ __noinline__ void redo_flagged(unsigned flagbits, int64_t qi0, int r, int c, double* lds, const double* __restrict__ tiles,
+                                          double* __restrict__ q_vals, double* __restrict__ r_vals, int32_t* __restrict__ perm,
+                                          double* __restrict__ hcoeffs)
+{
+    constexpr int TPW = 64 / WR;
+    for (int g2 = 0; g2 < TPW; ++g2) {
+        unsigned m = (unsigned)__builtin_amdgcn_readlane((int)flagbits, g2 * WR);
+        while (m) {
+            const int rnd = __builtin_ctz(m);
+            m &= m - 1;
+            redo_exact<WR, PIVOT>((int64_t)TPW * (qi0 + (int64_t)rnd * gridDim.x) + g2, r, c, lds, tiles, q_vals, r_vals, perm, hcoeffs);
+        }
+    }
+}
+
 }  // namespace q16
 
 #ifndef QRK_QUAD_WAVES
@@ -385,7 +421,11 @@ bdqr_quad_kernel(int64_t num_tiles, int r, int c, const double* __restrict__ til
     __shared__ __attribute__((aligned(16))) double lds[TPW * L_TILE];
     const int64_t nquads = (num_tiles + TPW - 1) / TPW;
     const int rc = r * c, rr = r * r, nr = (c * (c + 1)) >> 1;
-    for (int64_t qi = blockIdx.x; qi < nquads; qi += gridDim.x) {
+    constexpr int CHUNK = 32;                // rounds per chunk: one 32-bit word per tile remembers the flagged rounds
+    for (int64_t qi0 = blockIdx.x; qi0 < nquads; qi0 += (int64_t)CHUNK * gridDim.x) {
+    unsigned flagbits = 0u;                  // bit r: the tile of this group of lanes in round r of the chunk was flagged
+    int64_t qi = qi0;
+    for (int round = 0; round < CHUNK && qi < nquads; ++round, qi += gridDim.x) {
         // (per-lane values are re-derived from an opaque lane id in every round: hipcc otherwise hoists loop-invariant address
         //  arithmetic out of the loop and keeps it in registers across the factorisation)
         int lane = threadIdx.x;
@@ -474,9 +514,9 @@ bdqr_quad_kernel(int64_t num_tiles, int r, int c, const double* __restrict__ til
                     if (i <= p) dst[i] = a[i];
                 if (HC && hcoeffs) hcoeffs[cbase + jj] = lds[(ln >> LG) * L_TILE + L_TAU + jj];
             }
-            // a decision inside its error margin, anywhere in the tile: the exact path redoes it (bdqr_exact.hip)
+            // a decision inside its error margin, anywhere in the tile: the wave redoes the tile after its rounds
             const bool f = ((st.unclearm >> (WR * (ln >> LG))) & ((1ull << WR) - 1ull)) != 0ull;
-            if (f && valid && jj == 0 && redo_count) redo_ids[atomicAdd(redo_count, 1)] = (int32_t)t;
+            if (f && valid) flagbits |= 1u << round;
         }
         {
             // =============== phase 2: Q = H_0 ... H_{c-1}, backward ===============
@@ -503,6 +543,12 @@ bdqr_quad_kernel(int64_t num_tiles, int r, int c, const double* __restrict__ til
         }
         __builtin_amdgcn_wave_barrier();
     }
+    // ---- the flagged tiles, again, with the reference's own operation order (rare: generic data never gets here; one call, out of
+    // line, so that the loop above keeps its registers)
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(flagbits != 0u) != 0ull, 0))
+        redo_flagged<WR, PIVOT>(flagbits, qi0, r, c, lds, tiles, q_vals, r_vals, perm, HC ? hcoeffs : nullptr);
+    }
+    (void)redo_count; (void)redo_ids;
 }
 
 int bdqr_quad_waves_per_cu(int r) { return 4 * (r > 8 ? QRK_QUAD_WAVES : QRK_QUAD_WAVES8); }

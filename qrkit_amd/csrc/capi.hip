@@ -404,7 +404,11 @@ qrk_status enqueue_factorize(qrk_bd_plan_s* p, const double* tiles, double* q, d
         else if (p->max_dim <= 16 && p->r >= p->c && p->c <= 2 && h->use_small_kernel && h->use_thin_kernel)   // a tile per lane (bdqr_thin.hip)
             qrk::launch_bdqr_thin(p->B, p->r, p->c, nb.pivoting, tiles, q, r, perm, hc, h->num_cus * 32, redo_cnt, redo_ids, h->stream);
         else if (p->max_dim <= 16 && h->use_small_kernel && h->use_quad_kernel && p->r >= h->quad_min_rows && qrk::bdqr_quad_supported(p->r, p->c))   // four or eight tiles per wavefront (bdqr_quad.hip)
+        {
+            // (four or eight tiles per wavefront; it redoes its flagged tiles itself: no launch of the exact kernel behind it)
             qrk::launch_bdqr_quad(p->B, p->r, p->c, nb.pivoting, tiles, q, r, perm, hc, h->num_cus * qrk::bdqr_quad_waves_per_cu(p->r), redo_cnt, redo_ids, h->stream);
+            redo_pass = false;
+        }
         else if (p->max_dim <= 16 && p->r >= p->c && h->use_small_kernel)   // 64/G tiles per wavefront (bdqr_small.hip)
             qrk::launch_bdqr_small(p->B, p->r, p->c, nb.pivoting, tiles, q, r, perm, hc, h->num_cus * 32, redo_cnt, redo_ids, h->stream);
         else if (p->d_p4_scratch) {
