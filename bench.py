@@ -712,35 +712,60 @@ def solve_leg(ctx, dev, torch, np):
 
 def small_tiles(ctx, dev, torch, np):
     """Uniform batches of the small and middle tile classes on the final build (tiles/s and the fraction of the HBM roofline at the
-    algorithmic bytes of SURVEY.md 8(d): 8 r c in, 8 r^2 + 4 c (c + 1) + 4 c out): 8 x 6 is the left stage of BASELINE configs[3], 7 x 2 and
-    9 x 2 the reference's own test blocks, 16 x 16 the top of bdqr_small, 33 x 33 / 64 x 64 the ends of bdqr_w64."""
+    algorithmic bytes of SURVEY.md 8(d): 8 r c in, 8 r^2 + 4 c (c + 1) + 4 c out): 8 x 6 is the left stage of BASELINE configs[3] (20 000 tiles
+    there), 7 x 2 and 9 x 2 the reference's own test blocks, 16 x 16 the top of bdqr_quad, 33 x 33 / 64 x 64 the ends of bdqr_w64.  Timed like the
+    headline: HIP events around back-to-back factorisations on the handle's stream (qrk_bd_time_factorize), rotating over several
+    matrices -- the Python mirror's factorize() allocates three tensors per call and is host-bound below ~ 20 us per launch (it was the
+    clock of this leg in round 5: `ms_python_mirror` keeps that figure for the BASELINE-sized batches)."""
     import qrkit_amd
+    from qrkit_amd import _capi as capi
     out = []
     for r, c, B in ((7, 2, 1000000), (9, 2, 1000000), (8, 6, 20000), (8, 6, 1000000), (16, 16, 400000), (33, 33, 2000), (33, 33, 20000),
                     (64, 64, 2000), (64, 64, 40000)):
+        S = max(1, min(8, 1600000 // (B * r)))
         g = torch.Generator(device=dev); g.manual_seed(7 * r + c)
-        tiles = torch.rand(B * r * c, generator=g, device=dev, dtype=torch.float64) * 2.0 - 1.0
-        rows, cols = np.full(B, r, np.int32), np.full(B, c, np.int32)
-        mat = qrkit_amd.SparseBlockDiagonal.fromTiles(rows, cols, tiles)
-        qr = qrkit_amd.BlockDiagonalSparseQR(context=ctx)
-        qr.analyzePattern(mat)
+        tiles = torch.rand(S * B * r * c, generator=g, device=dev, dtype=torch.float64) * 2.0 - 1.0
+        q = torch.empty(S * B * r * r, device=dev, dtype=torch.float64)
+        rv = torch.empty(S * B * (c * (c + 1) // 2), device=dev, dtype=torch.float64)
+        pm = torch.empty(S * B * c, device=dev, dtype=torch.int32)
+        lay = capi.BDLayout()
+        lay.num_blocks, lay.block_rows, lay.block_cols = B, r, c
+        lay.rows = lay.cols = None
+        lay.mat_rows, lay.mat_cols = B * r, B * c
+        plan = C.c_void_p()
+        capi.check(capi.lib().qrk_bd_plan_create(ctx.handle, C.byref(lay), capi.FULL_Q, capi.COLPIV_HOUSEHOLDER, C.byref(plan)), ctx.handle)
+        ms = C.c_float()
 
-        def once():
-            qr.factorize(mat)
-        for _ in range(3):
-            once()
-        torch.cuda.synchronize()
-        best = 1e30
-        for _ in range(3):
-            t0 = time.perf_counter()
-            for _ in range(10):
-                once()
-            torch.cuda.synchronize()
-            best = min(best, (time.perf_counter() - t0) / 10)
+        def run(it):
+            capi.check(capi.lib().qrk_bd_time_factorize(plan, tiles.data_ptr(), q.data_ptr(), rv.data_ptr(), pm.data_ptr(), S, it, C.byref(ms)),
+                       ctx.handle)
+            return ms.value * 1e-3
+        iters = 50 if B * r * r < 4e7 else 10
+        run(max(3, iters // 5))
+        best = min(run(iters) for _ in range(3))
         by = 8 * r * c + 8 * r * r + 4 * c * (c + 1) + 4 * c
-        out.append({"tile": f"{r}x{c}", "tiles": B, "ms": best * 1e3, "tiles_per_s": B / best, "algorithmic_GBs": B * by / best / 1e9,
-                    "frac_of_hbm": B * by / best / 1e9 / HBM_PEAK_GBS})
-        del qr, mat, tiles
+        e = {"tile": f"{r}x{c}", "tiles": B, "ms": best * 1e3, "tiles_per_s": B / best, "algorithmic_GBs": B * by / best / 1e9,
+             "frac_of_hbm": B * by / best / 1e9 / HBM_PEAK_GBS}
+        capi.lib().qrk_bd_plan_destroy(plan)
+        if B <= 20000:
+            rows, cols = np.full(B, r, np.int32), np.full(B, c, np.int32)
+            mat = qrkit_amd.SparseBlockDiagonal.fromTiles(rows, cols, tiles[:B * r * c])
+            qr = qrkit_amd.BlockDiagonalSparseQR(context=ctx)
+            qr.analyzePattern(mat)
+            for _ in range(3):
+                qr.factorize(mat)
+            torch.cuda.synchronize()
+            bp = 1e30
+            for _ in range(3):
+                t0 = time.perf_counter()
+                for _ in range(10):
+                    qr.factorize(mat)
+                torch.cuda.synchronize()
+                bp = min(bp, (time.perf_counter() - t0) / 10)
+            e["ms_python_mirror"] = bp * 1e3
+            del qr, mat
+        out.append(e)
+        del tiles, q, rv, pm
     return out
 
 
