@@ -1596,6 +1596,9 @@ class BlockAngularSparseQR {
 //   * the permutation P2 of the right block goes back to every rank (qrk_bcast).
 // solve (_solve_impl :202-227) follows the same route with one m2-vector per rank up and z2 down; every rank gets the entries of x
 // of its own tiles and the m2 entries of the right block.
+// Failure contract: compute() / solve() are collectives.  An exception thrown on ONE rank before its qrk_gather_equal / qrk_bcast (a
+// failed left solver, an allocation) leaves the other ranks inside the collective -- as with any RCCL program, the caller must treat an
+// exception on any rank as fatal for the communicator (abort the job or ncclCommAbort); no status word is exchanged ahead of the data.
 template <typename LeftSolver = BlockDiagonalSparseQR<> >
 class ShardedBlockAngularSparseQR {
   public:
