@@ -72,6 +72,15 @@ static_assert(2 * STAGE_TILE <= 4 * L_TILE, "two staged tiles fit the wave's LDS
 #ifndef QRK_Q32_TSQ_EARLY
 #define QRK_Q32_TSQ_EARLY 0
 #endif
+// QRK_Q32_ILV 1 (experiment; implies TSQ_EARLY): the dependent operations of |x_tail|^2 / square root / reciprocal are issued BETWEEN groups of
+// four dot-product FMAs, order pinned -- a wave issues in order, so a stalled dependent operation otherwise holds up the independent FMAs behind it
+#ifndef QRK_Q32_ILV
+#define QRK_Q32_ILV 0
+#endif
+#if QRK_Q32_ILV
+#undef QRK_Q32_TSQ_EARLY
+#define QRK_Q32_TSQ_EARLY 1
+#endif
 // QRK_Q32_PRIO (experiments): 1 = the wave in an odd slot of its SIMD runs at priority 1 for the whole launch (static asymmetry between
 // the two waves of a SIMD); 2 = that wave starts its first phase 1 half a step late
 #ifndef QRK_Q32_PRIO
@@ -292,6 +301,26 @@ __device__ __forceinline__ void step(double (&a0)[WR], double (&a1)[WR], double*
 #pragma unroll
                 for (int i = K; i < WR; ++i) *(QRK_Q32_PUBQ lds_f64*)(&vcol[i]) = a1[i];
             }
+        } else if (QRK_Q32_PUB == 2) {
+            // select first, store afterwards, sixteen elements at a time: a ds_write behind a VALU instruction of the same wave waits for the
+            // vector pipe to drain (tools/ubench_publish.hip: 42 cycles per element when every store follows its two v_cndmask, 12.7 for a
+            // store in a run of stores), so the selects of a batch all come before its stores
+            if (ispiv0 || ispiv1) {
+#pragma unroll
+                for (int i0 = K; i0 < WR; i0 += 16) {
+                    double x[16];
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) {
+                        if (i0 + q < WR) {
+                            x[q] = ispiv1 ? a1[i0 + q < WR ? i0 + q : 0] : a0[i0 + q < WR ? i0 + q : 0];
+                            asm volatile("" : "+v"(x[q]));
+                        }
+                    }
+#pragma unroll
+                    for (int q = 0; q < 16; ++q)
+                        if (i0 + q < WR) *(volatile lds_f64*)(&vcol[i0 + q]) = x[q];
+                }
+            }
         } else if (QRK_Q32_PUB) {
             if (ispiv0 || ispiv1) {
                 // (the selects run QRK_Q32_SKEW elements ahead of the stores: a store that waits for the select just before it holds up
@@ -336,6 +365,98 @@ __device__ __forceinline__ void step(double (&a0)[WR], double (&a1)[WR], double*
     else xk = *(const volatile lds_f64*)(tl + L_V + cb(K));          // (row K is the last one of its chunk: not among the loaded ones)
     asm volatile("" : "+v"(xk));
     Q32_TICK(2);
+#if QRK_Q32_ILV
+    const double ak0 = a0[K], ak1 = a1[K];
+    double d0a = 0.0, d0b = 0.0, d1a = 0.0, d1b = 0.0;
+#pragma unroll
+    for (int m = M0; m < 2; ++m) asm volatile("s_nop 1" : "+v"(xc[m]));
+    // group G: rows K + 1 + 2 G and K + 2 + 2 G of both slots (the same products in the same order per accumulator as the plain form)
+#define QRK_Q32_DOTG(G)                                                                                                  \
+    {                                                                                                                    \
+        constexpr int I0 = K + 1 + 2 * (G), I1 = I0 + 1;                                                                 \
+        if constexpr (I0 < WR) { fmac_bcast<(I0 & 15)>((I0 & 1) ? d0b : d0a, xc[I0 >> 4], a0[I0]); fmac_bcast<(I0 & 15)>((I0 & 1) ? d1b : d1a, xc[I0 >> 4], a1[I0]); } \
+        if constexpr (I1 < WR) { fmac_bcast<(I1 & 15)>((I1 & 1) ? d0b : d0a, xc[I1 >> 4], a0[I1]); fmac_bcast<(I1 & 15)>((I1 & 1) ? d1b : d1a, xc[I1 >> 4], a1[I1]); } \
+        __builtin_amdgcn_sched_barrier(0);                                                                               \
+    }
+    double tsq = 0.0, s = 0.0, ngp = 0.0;
+    unsigned long long degm = ~0ull;
+    {
+        double sq = 0.0;
+        if (K + 1 < WR) {
+            if (M0 == 0) { const double u = st.c > K ? xc[0] : 0.0; sq = u * u; }
+            { const double u = 16 + st.c > K ? xc[1] : 0.0; sq = fma(u, u, sq); }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        QRK_Q32_DOTG(0)
+        sq += dpp_f64<0xB1>(sq);
+        __builtin_amdgcn_sched_barrier(0);
+        QRK_Q32_DOTG(1)
+        sq += dpp_f64<0x4E>(sq);
+        __builtin_amdgcn_sched_barrier(0);
+        QRK_Q32_DOTG(2)
+        sq += dpp_f64<0x141>(sq);
+        __builtin_amdgcn_sched_barrier(0);
+        QRK_Q32_DOTG(3)
+        sq += dpp_f64<0x140>(sq);
+        tsq = K + 1 < WR ? sq : 0.0;
+        const double n2 = fma(xk, xk, tsq);
+        __builtin_amdgcn_sched_barrier(0);
+        QRK_Q32_DOTG(4)
+        if (K == 0 && !PIVOT) st.a2 = n2;
+        {
+            unsigned long long um = 0ull;
+            if (K + 1 < WR) {
+                degm = __builtin_amdgcn_fcmp(tsq, DBL_MIN, 13 /* ULE */);
+                um = degm | __builtin_amdgcn_fcmp(xk * xk, X0_TINY2 * st.a2, 5 /* OLE */);
+            }
+            if (PIVOT) um |= __builtin_amdgcn_fcmp(n2, PIV_TINY2 * st.a2, 5 /* OLE */);
+            st.unclearm |= um;
+        }
+        const double y = __builtin_amdgcn_rsq(n2);
+        __builtin_amdgcn_sched_barrier(0);
+        QRK_Q32_DOTG(5) QRK_Q32_DOTG(6)
+        double g = n2 * y, hh = 0.5 * y;
+        __builtin_amdgcn_sched_barrier(0);
+        QRK_Q32_DOTG(7)
+        const double e = fma(-hh, g, 0.5);
+        __builtin_amdgcn_sched_barrier(0);
+        QRK_Q32_DOTG(8)
+        g = fma(g, e, g); hh = fma(hh, e, hh);
+        __builtin_amdgcn_sched_barrier(0);
+        QRK_Q32_DOTG(9)
+        const double dd = fma(-g, g, n2);
+        __builtin_amdgcn_sched_barrier(0);
+        QRK_Q32_DOTG(10)
+        const double nrm = fma(dd, hh, g);
+        double nbv = __builtin_copysign(nrm, xk);            // beta = -nbv
+        __builtin_amdgcn_sched_barrier(0);
+        QRK_Q32_DOTG(11)
+        s = nbv + xk;
+        const double pr = nbv * s;
+        double y2 = __builtin_amdgcn_rcp(pr);
+        __builtin_amdgcn_sched_barrier(0);
+        QRK_Q32_DOTG(12) QRK_Q32_DOTG(13)
+        double e2 = fma(-pr, y2, 1.0);
+        __builtin_amdgcn_sched_barrier(0);
+        QRK_Q32_DOTG(14)
+        y2 = fma(y2, e2, y2);
+        __builtin_amdgcn_sched_barrier(0);
+        QRK_Q32_DOTG(15)
+        e2 = fma(-pr, y2, 1.0);
+        y2 = fma(y2, e2, y2);
+        ngp = y2;
+        if (__builtin_expect(degm != 0ull, 0)) {
+            asm volatile("");
+            if ((degm >> lane) & 1ull) { nbv = -xk; s = 0.0; ngp = 0.0; }
+        }
+    }
+#undef QRK_Q32_DOTG
+    double ds0 = d0a + d0b, ds1 = d1a + d1b;
+    if (st.c == 0) {
+        tl[L_S + K] = s; tl[L_NG + K] = ngp;
+        if (HC) tl[L_TAU + K] = (s * s) * ngp;
+    }
+#else
 #if QRK_Q32_TSQ_EARLY
     // (experiment) |x_tail|^2 from the chunks, summed over the row: independent of the dot products below, so the reflector's scalars
     // overlap with them; another summation order than the pivot lane's own dot product
@@ -418,6 +539,7 @@ __device__ __forceinline__ void step(double (&a0)[WR], double (&a1)[WR], double*
         tl[L_S + K] = s; tl[L_NG + K] = ngp;
         if (HC) tl[L_TAU + K] = (s * s) * ngp;
     }
+#endif
     double ngam0 = fma(s, ak0, ds0) * -ngp, ngam1 = fma(s, ak1, ds1) * -ngp;      // -gamma of the lane's columns
 #ifdef QRK_Q32_PROF
     asm volatile("s_nop 0" : "+v"(ngam0), "+v"(ngam1));
