@@ -123,8 +123,14 @@ class ShardedBlockDiagonalQR:
         self.base_row, self.base_col, self.q_off, self.r_off = shard_offsets(self.block_rows, self.block_cols,
                                                                             self.start, self.end)
         if solver_factory is None:
-            from .solvers import BlockDiagonalSparseQR
-            solver_factory = BlockDiagonalSparseQR
+            # one process per GPU: the rank's own device (LOCAL_RANK under torch.distributed.run), never "device 0 on every rank"; one C-ABI
+            # handle for the solver and for the pieces of computeGatherR
+            import os
+            from .solvers import BlockDiagonalSparseQR, Context
+            ndev = max(torch.cuda.device_count(), 1)
+            ctx = Context(int(os.environ.get("LOCAL_RANK", rank)) % ndev)
+            solver_factory = lambda: BlockDiagonalSparseQR(context=ctx)
+        self._solver_factory = solver_factory
         self.solver = solver_factory()
 
     def local_layout(self):
@@ -210,7 +216,7 @@ class ShardedBlockDiagonalQR:
         if slice_mat is None:
             slice_mat = _slice_block_diagonal
         if solver_factory is None:
-            solver_factory = type(self.solver)
+            solver_factory = self._solver_factory
         c = self.block_cols.astype(np.int64)
         r_len = lambda a, b: int((c[a:b] * (c[a:b] + 1) // 2).sum())
         pieces = [ShardedBlockDiagonalQR.chunk_ranges(_Range(self.block_rows, self.block_cols, a, b), chunks) for a, b in self.ranges]
