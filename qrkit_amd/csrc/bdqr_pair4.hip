@@ -58,8 +58,10 @@ static_assert(WR * STAGE_LD <= 2 * L_HALF, "the staging buffer fits the wave's L
 // QRK_P4_NT: 1 = the tiles are loaded, 2 = Q and R are stored, 3 = both with the non-temporal hint.  Measured (profiles/r04_p4_nt.txt):
 // loads 78.0 -> 74.3 us per 10 000 tiles (the input does not displace the results being merged in L2); stores 130 us (16-byte pieces of
 // R no longer merge)
+// Round 6: bit 4 = the rows of Q alone with the hint (every store instruction fills whole 128-byte lines, unlike the pieces of R): 1 250 tiles
+// 25.9 -> 25.0 us, 5 000 46.4 -> 45.6, 10 000 72.6 -> 72.2, 160 000 923 -> 920 (two interleaved A/B runs each, profiles/r06_k1_ramp.txt)
 #ifndef QRK_P4_NT
-#define QRK_P4_NT 1
+#define QRK_P4_NT 5
 #endif
 #if QRK_P4_NT & 1
 #define QRK_P4_LOAD(p) __builtin_nontemporal_load(p)
