@@ -436,7 +436,17 @@ bdqr_pair4_kernel(int64_t num_tiles, const double* __restrict__ tiles, double* _
             default: break;
         }
     }
-    for (int64_t pi0 = blockIdx.x; pi0 < npairs; pi0 += (int64_t)CHUNK * gridDim.x) {
+    // QRK_P4_PERM (experiment, verdict r05 item 2b: channel camping by the 16 KB wave stride?): workgroup -> pair map permuted.  > 1: the
+    // pair of workgroup b is (b * QRK_P4_PERM) mod gridDim (odd multiplier, gridDim a power of two); 1: every XCD a contiguous range of pairs
+#if defined(QRK_P4_PERM)
+    const unsigned gd = gridDim.x;
+    const int64_t bid0 = (gd & (gd - 1u)) ? (int64_t)blockIdx.x
+                                          : (QRK_P4_PERM == 1 ? (int64_t)((blockIdx.x & 7u) * (gd >> 3) + (blockIdx.x >> 3))
+                                                              : (int64_t)((blockIdx.x * (unsigned)QRK_P4_PERM) & (gd - 1u)));
+#else
+    const int64_t bid0 = blockIdx.x;
+#endif
+    for (int64_t pi0 = bid0; pi0 < npairs; pi0 += (int64_t)CHUNK * gridDim.x) {
     unsigned flagbits = 0u;                  // bit r: the tile of this half in round r of the chunk was flagged
     int64_t pi = pi0;
     for (int round = 0; round < CHUNK && pi < npairs; ++round, pi += gridDim.x) {
