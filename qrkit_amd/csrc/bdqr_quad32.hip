@@ -879,9 +879,9 @@ hipError_t launch_bdqr_quad32(int64_t num_tiles, int pivoting, const double* til
     const int64_t nquads = (num_tiles + 3) / 4;
     const int64_t nwg = nquads < num_wg ? nquads : num_wg;
     if (direct < 0) {
-        // (as bdqr_pair4.hip found: a launch of one round and a bit starts with every wave loading at once, and there the 64 separate lines
-        //  of a direct load instruction cost more than the staging)
-        direct = (nquads >= 2 * (int64_t)num_wg || 2 * nquads <= (int64_t)num_wg) ? 1 : 0;
+        // (measured, profiles/r06_k1_quad32.txt: every lane loading its two columns directly is slower than the staging through LDS at every
+        //  launch size -- +0.3 / +7 / +64 us at 1 250 / 8 192 / 100 000 tiles; QRK_Q32_DIRECT=1 is the diagnostic switch)
+        direct = 0;
         if (const char* e = std::getenv("QRK_Q32_DIRECT")) direct = std::atoi(e) != 0;
     }
     const dim3 grid((unsigned)nwg), block(64);
