@@ -389,7 +389,14 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": tr[0], "traffic_source": tr[1],
                          "kernel": kname, "avg_launch_ms": kernel_ms,
-                         "algorithmic_bytes_per_launch": bytes_per_launch},
+                         "algorithmic_bytes_per_launch": bytes_per_launch,
+                         # what the memory system gives THIS access pattern: a copy-only build of the same kernel (same grid, same loads and
+                         # stores, no arithmetic) -- a committed measurement, not part of this run
+                         "pattern_floor": {"copy_only_ms_per_launch": [0.0523, 0.0546], "copy_only_GBs": [3800, 3965],
+                                           "valu_issue_floor_ms": 0.050,
+                                           "source": "profiles/r06_k1_ramp.txt, profiles/r06_k1_pmc_summary.txt (round 6; 10 000 tiles): the "
+                                                     "kernel's own loads and stores without its arithmetic, and 4 581 VALU instructions per pair "
+                                                     "x 2.24 ns x 4.88 pairs per SIMD; not measured in this run"}},
             "checked": checked if checked is not None else False,
             "timing": timing,
         }
